@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/fixtures/*.npz from the reference's fixture BAM/SAM files.
+
+Run in the build container, where /root/reference exists:  python tests/golden/make_golden.py
+Each .npz holds the decoded records of one reference fixture (tests/data/<name>) as the SoA
+the C ABI consumes (tid,pos,flag,mapq,l_seq,nm,nm_kind,cigar_off,cigar,mtid,mpos,tlen), the
+header (names, lengths) and the read names, so parity tests run where the reference is absent.
+Decoding uses oracle/bamio.py (pure Python BGZF/BAM/SAM reader).  Also writes the genome
+definition used by the CLI goldens (same content as the reference's tests/data/7seqs.definition:
+genome<TAB>contig, one line per contig, derived here from the 7seqs BAM header names).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle import bamio  # noqa: E402
+from tests.golden import cases  # noqa: E402
+
+REF_DATA = "/root/reference/tests/data"
+
+
+def main():
+    out = os.path.join(HERE, "fixtures")
+    os.makedirs(out, exist_ok=True)
+    for name in cases.FIXTURE_FILES:
+        d = bamio.read_alignment_file(os.path.join(REF_DATA, name))
+        np.savez_compressed(
+            os.path.join(out, name + ".npz"),
+            ref_names=np.frombuffer("\n".join(d.ref_names).encode(), dtype=np.uint8),
+            ref_lens=d.ref_lens, tid=d.tid, pos=d.pos, flag=d.flag, mapq=d.mapq, l_seq=d.l_seq, nm=d.nm,
+            nm_kind=d.nm_kind, cigar_off=d.cigar_off, cigar=d.cigar, mtid=d.mtid, mpos=d.mpos, tlen=d.tlen,
+            qname=np.frombuffer(b"\n".join(d.qname), dtype=np.uint8))
+        print("%-45s %6d records %7d refs" % (name, d.n_records, len(d.ref_names)))
+    d = bamio.read_alignment_file(os.path.join(REF_DATA, "7seqs.reads_for_seq1_and_seq2.bam"))
+    with open(os.path.join(out, "7seqs.definition"), "w") as fh:
+        for n in d.ref_names:
+            fh.write("%s\t%s\n" % (n.split("~")[0], n))
+
+
+if __name__ == "__main__":
+    main()
