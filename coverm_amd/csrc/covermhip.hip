@@ -1,0 +1,537 @@
+// libcovermhip.so — session management and the C ABI declared in include/covermhip.h.
+// Host code here only moves bytes and launches kernels; every statistic is computed on the device
+// (pileup_kernels.hip.h).  There is deliberately no CPU fallback: without a usable HIP device every
+// entry point fails with COV_ERR_HIP.
+#include "pileup_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/covermhip.h"
+
+using namespace covk;
+
+namespace {
+
+#define HIPCHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            char b_[512];                                                                     \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            s->err = b_;                                                                      \
+            return COV_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n, hipStream_t st, size_t keep = 0) {
+        if (n <= cap) return hipSuccess;
+        size_t nc = std::max(n, cap + cap / 2);
+        T *q = nullptr;
+        hipError_t e = hipMalloc(&q, nc * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (keep && p) {
+            e = hipMemcpyAsync(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return e;
+            e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+        }
+        if (p) (void)hipFree(p);
+        p = q; cap = nc;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+std::string g_create_error;
+
+}  // namespace
+
+struct cov_session {
+    cov_config cfg{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    int nt = 512;  // k_pileup workgroup size (COVERM_PILEUP_NT = 256 | 512 | 1024)
+
+    // targets
+    uint32_t n_targets = 0;
+    std::vector<uint32_t> h_tlen;
+    std::vector<uint32_t> h_tile_first;  // first tile of each contig (+ sentinel)
+    uint32_t n_tiles = 0;
+    DevBuf<u32> d_tlen, d_tile_contig, d_tile_start;
+    DevBuf<uint8_t> d_mask;
+    bool have_mask = false;
+    DevBuf<DevContig> d_ctg;
+    DevBuf<DevGlobal> d_glob;
+    DevBuf<uint2> d_cand;
+
+    // record store (owned) or adopted device batch
+    DevBuf<int32_t> s_tid, s_pos;
+    DevBuf<uint16_t> s_flag;
+    DevBuf<uint8_t> s_mapq, s_nmk;
+    DevBuf<u32> s_nm, s_lseq, s_coff, s_cig;
+    uint64_t n_records = 0, n_cigar = 0;
+    bool adopted = false;
+    cov_batch adopted_batch{};
+    uint64_t adopted_ncig = 0;
+
+    DevBuf<uint2> d_runs;
+    DevBuf<double> d_ident;
+    DevBuf<u32> d_arena;
+    DevBuf<u64> d_chist;
+    DevBuf<int32_t> d_depth;
+
+    // results of the last finish
+    bool finished = false;
+    std::vector<DevContig> h_ctg;
+    DevGlobal h_glob{};
+    uint64_t algo_bytes = 0;
+
+    hipEvent_t ev[COV_K_COUNT][2] = {};
+    float k_ms[COV_K_COUNT] = {};
+    uint32_t k_launches[COV_K_COUNT] = {};
+};
+
+namespace {
+
+Records records_of(const cov_session *s) {
+    Records r{};
+    if (s->adopted) {
+        const cov_batch &b = s->adopted_batch;
+        r.tid = b.tid; r.pos = b.pos; r.flag = b.flag; r.mapq = b.mapq; r.nm = b.nm; r.nm_kind = b.nm_kind;
+        r.l_seq = b.l_seq; r.cigar_off = b.cigar_off; r.cigar = b.cigar;
+    } else {
+        r.tid = s->s_tid.p; r.pos = s->s_pos.p; r.flag = s->s_flag.p; r.mapq = s->s_mapq.p; r.nm = s->s_nm.p;
+        r.nm_kind = s->s_nmk.p; r.l_seq = s->s_lseq.p; r.cigar_off = s->s_coff.p; r.cigar = s->s_cig.p;
+    }
+    r.n = (u32)s->n_records;
+    return r;
+}
+
+__global__ void k_rebase_offsets(u32 *off, u32 n, u32 sub, u32 add) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) off[i] = off[i] - sub + add;
+}
+
+cov_status append(cov_session *s, const cov_batch *b, bool from_device) {
+    const uint64_t n = b->n_records;
+    if (n == 0) return COV_OK;
+    if (s->n_records + n >= 0xfffffff0ull) { s->err = "more than 2^32 records in one session"; return COV_ERR_INVALID_ARG; }
+    const hipMemcpyKind kind = from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    u32 off0 = 0, offn = 0;
+    if (from_device) {
+        HIPCHK(hipMemcpyAsync(&off0, b->cigar_off, 4, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(&offn, b->cigar_off + n, 4, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    } else {
+        off0 = b->cigar_off[0]; offn = b->cigar_off[n];
+    }
+    const uint64_t ncig = (uint64_t)offn - off0;
+    if (s->n_cigar + ncig >= 0xfffffff0ull) { s->err = "more than 2^32 CIGAR words in one session"; return COV_ERR_INVALID_ARG; }
+    const uint64_t R = s->n_records, N = R + n;
+    hipStream_t st = s->stream;
+    HIPCHK(s->s_tid.reserve(N, st, R)); HIPCHK(s->s_pos.reserve(N, st, R)); HIPCHK(s->s_flag.reserve(N, st, R));
+    HIPCHK(s->s_mapq.reserve(N, st, R)); HIPCHK(s->s_nmk.reserve(N, st, R)); HIPCHK(s->s_nm.reserve(N, st, R));
+    HIPCHK(s->s_lseq.reserve(N, st, R)); HIPCHK(s->s_coff.reserve(N + 1, st, R + 1));
+    HIPCHK(s->s_cig.reserve(s->n_cigar + ncig + 1, st, s->n_cigar));
+    HIPCHK(hipMemcpyAsync(s->s_tid.p + R, b->tid, n * 4, kind, st));
+    HIPCHK(hipMemcpyAsync(s->s_pos.p + R, b->pos, n * 4, kind, st));
+    HIPCHK(hipMemcpyAsync(s->s_flag.p + R, b->flag, n * 2, kind, st));
+    HIPCHK(hipMemcpyAsync(s->s_mapq.p + R, b->mapq, n, kind, st));
+    HIPCHK(hipMemcpyAsync(s->s_nmk.p + R, b->nm_kind, n, kind, st));
+    HIPCHK(hipMemcpyAsync(s->s_nm.p + R, b->nm, n * 4, kind, st));
+    HIPCHK(hipMemcpyAsync(s->s_lseq.p + R, b->l_seq, n * 4, kind, st));
+    HIPCHK(hipMemcpyAsync(s->s_coff.p + R, b->cigar_off, (n + 1) * 4, kind, st));
+    if (ncig) HIPCHK(hipMemcpyAsync(s->s_cig.p + s->n_cigar, b->cigar + off0, ncig * 4, kind, st));
+    if (off0 != (u32)s->n_cigar) {
+        const u32 cnt = (u32)(n + 1);
+        hipLaunchKernelGGL(k_rebase_offsets, dim3((cnt + 255) / 256), dim3(256), 0, st, s->s_coff.p + R, cnt, off0,
+                           (u32)s->n_cigar);
+        HIPCHK(hipGetLastError());
+    }
+    s->n_records = N; s->n_cigar += ncig;
+    s->finished = false;
+    return COV_OK;
+}
+
+void time_begin(cov_session *s, int k) { (void)hipEventRecord(s->ev[k][0], s->stream); }
+void time_end(cov_session *s, int k) { (void)hipEventRecord(s->ev[k][1], s->stream); s->k_launches[k]++; }
+
+template <int NT, bool H, bool W>
+void launch_pileup_t(cov_session *s, const PileupArgs &a, u32 grid) {
+    const size_t smem = pileup_smem_bytes(NT, H);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup<NT, H, W>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_pileup<NT, H, W>), dim3(grid), dim3(NT), smem, s->stream, a);
+}
+template <bool H, bool W>
+void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
+    if (s->nt == 1024) launch_pileup_t<1024, H, W>(s, a, grid);
+    else if (s->nt == 256) launch_pileup_t<256, H, W>(s, a, grid);
+    else launch_pileup_t<512, H, W>(s, a, grid);
+}
+
+PileupArgs pileup_args(cov_session *s) {
+    PileupArgs a{};
+    a.tile_contig = s->d_tile_contig.p; a.tile_start = s->d_tile_start.p; a.cand = s->d_cand.p;
+    a.runs = s->d_runs.p; a.r = records_of(s); a.tlen = s->d_tlen.p; a.ctg = s->d_ctg.p; a.g = s->d_glob.p;
+    a.hist_arena = s->d_arena.p; a.excl = s->cfg.contig_end_exclusion; a.depth_out = nullptr; a.tile_base = 0;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cov_abi_version(void) { return COVERMHIP_ABI_VERSION; }
+
+const char *cov_last_error(const cov_session *s) { return s ? s->err.c_str() : g_create_error.c_str(); }
+
+cov_status cov_create(const cov_config *cfg, cov_session **out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return COV_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("no usable HIP device: ") + hipGetErrorString(e) +
+                         " (the engine has no CPU fallback)";
+        return COV_ERR_HIP;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return COV_ERR_INVALID_ARG; }
+    e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return COV_ERR_HIP; }
+    cov_session *s = new cov_session();
+    s->cfg = *cfg;
+    if (const char *nt = getenv("COVERM_PILEUP_NT")) {
+        int v = atoi(nt);
+        if (v == 256 || v == 512 || v == 1024) s->nt = v;
+    }
+    e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete s; return COV_ERR_HIP; }
+    for (int k = 0; k < COV_K_COUNT; k++)
+        for (int j = 0; j < 2; j++) (void)hipEventCreate(&s->ev[k][j]);
+    e = s->d_glob.reserve(1, s->stream);
+    if (e != hipSuccess) { g_create_error = std::string("hipMalloc: ") + hipGetErrorString(e); cov_destroy(s); return COV_ERR_HIP; }
+    *out = s;
+    return COV_OK;
+}
+
+void cov_destroy(cov_session *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->cfg.device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    s->d_tlen.release(); s->d_tile_contig.release(); s->d_tile_start.release(); s->d_mask.release();
+    s->d_ctg.release(); s->d_glob.release(); s->d_cand.release();
+    s->s_tid.release(); s->s_pos.release(); s->s_flag.release(); s->s_mapq.release(); s->s_nmk.release();
+    s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
+    s->d_runs.release(); s->d_ident.release(); s->d_arena.release(); s->d_chist.release(); s->d_depth.release();
+    for (int k = 0; k < COV_K_COUNT; k++)
+        for (int j = 0; j < 2; j++) if (s->ev[k][j]) (void)hipEventDestroy(s->ev[k][j]);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+cov_status cov_set_targets(cov_session *s, uint32_t n_targets, const uint64_t *target_len) {
+    if (!s || (!target_len && n_targets)) return COV_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    s->n_targets = n_targets;
+    s->h_tlen.resize(n_targets);
+    s->h_tile_first.assign((size_t)n_targets + 1, 0);
+    uint64_t nt = 0;
+    for (uint32_t c = 0; c < n_targets; c++) {
+        if (target_len[c] > 0x7fffffffull) { s->err = "target length exceeds BAM's i32 range"; return COV_ERR_INVALID_ARG; }
+        s->h_tlen[c] = (uint32_t)target_len[c];
+        s->h_tile_first[c] = (uint32_t)nt;
+        nt += (target_len[c] + TILE - 1) / TILE;
+    }
+    if (nt >= 0x7fffffffull) { s->err = "too many tiles"; return COV_ERR_INVALID_ARG; }
+    s->h_tile_first[n_targets] = (uint32_t)nt;
+    s->n_tiles = (uint32_t)nt;
+    std::vector<u32> tc(nt), ts(nt);
+    for (uint32_t c = 0; c < n_targets; c++) {
+        u32 k = s->h_tile_first[c];
+        for (uint64_t p = 0; p < target_len[c]; p += TILE, k++) { tc[k] = c; ts[k] = (u32)p; }
+    }
+    HIPCHK(s->d_tlen.reserve(std::max<size_t>(1, n_targets), s->stream));
+    HIPCHK(s->d_tile_contig.reserve(std::max<size_t>(1, nt), s->stream));
+    HIPCHK(s->d_tile_start.reserve(std::max<size_t>(1, nt), s->stream));
+    HIPCHK(s->d_cand.reserve(std::max<size_t>(1, nt), s->stream));
+    HIPCHK(s->d_ctg.reserve(std::max<size_t>(1, n_targets), s->stream));
+    if (n_targets) HIPCHK(hipMemcpyAsync(s->d_tlen.p, s->h_tlen.data(), (size_t)n_targets * 4, hipMemcpyHostToDevice, s->stream));
+    if (nt) {
+        HIPCHK(hipMemcpyAsync(s->d_tile_contig.p, tc.data(), nt * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->d_tile_start.p, ts.data(), nt * 4, hipMemcpyHostToDevice, s->stream));
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->have_mask = false;
+    s->finished = false;
+    return COV_OK;
+}
+
+cov_status cov_set_target_mask(cov_session *s, const uint8_t *mask) {
+    if (!s) return COV_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    if (!mask) { s->have_mask = false; return COV_OK; }
+    HIPCHK(s->d_mask.reserve(std::max<size_t>(1, s->n_targets), s->stream));
+    if (s->n_targets) HIPCHK(hipMemcpyAsync(s->d_mask.p, mask, s->n_targets, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->have_mask = true;
+    s->finished = false;
+    return COV_OK;
+}
+
+cov_status cov_push_batch(cov_session *s, const cov_batch *b) {
+    if (!s || !b) return COV_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    if (s->adopted) {  // materialise the adopted device batch into the owned store first
+        cov_batch ab = s->adopted_batch;
+        s->adopted = false; s->n_records = 0; s->n_cigar = 0;
+        cov_status st = append(s, &ab, true);
+        if (st) return st;
+    }
+    return append(s, b, false);
+}
+
+cov_status cov_push_batch_device(cov_session *s, const cov_batch *b) {
+    if (!s || !b) return COV_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    if (s->n_records == 0 && !s->adopted) {
+        if (b->n_records >= 0xfffffff0ull) { s->err = "more than 2^32 records in one session"; return COV_ERR_INVALID_ARG; }
+        u32 o0 = 0, o1 = 0;
+        if (b->n_records) {
+            HIPCHK(hipMemcpy(&o0, b->cigar_off, 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&o1, b->cigar_off + b->n_records, 4, hipMemcpyDeviceToHost));
+        }
+        s->adopted = true; s->adopted_batch = *b; s->n_records = b->n_records;
+        s->adopted_ncig = (uint64_t)o1 - o0;
+        s->finished = false;
+        return COV_OK;
+    }
+    if (s->adopted) {
+        cov_batch ab = s->adopted_batch;
+        s->adopted = false; s->n_records = 0; s->n_cigar = 0;
+        cov_status st = append(s, &ab, true);
+        if (st) return st;
+    }
+    return append(s, b, true);
+}
+
+cov_status cov_reset(cov_session *s) {
+    if (!s) return COV_ERR_INVALID_ARG;
+    s->adopted = false; s->n_records = 0; s->n_cigar = 0; s->finished = false;
+    return COV_OK;
+}
+
+cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summary) {
+    if (!s || (!stats && s->n_targets)) return COV_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    hipStream_t st = s->stream;
+    const u32 nT = s->n_targets;
+    const u32 R = (u32)s->n_records;
+    const bool want_hist = s->cfg.want & COV_WANT_HIST, want_id = s->cfg.want & COV_WANT_IDENTITY;
+    for (int k = 0; k < COV_K_COUNT; k++) { s->k_launches[k] = 0; s->k_ms[k] = 0.f; }
+
+    HIPCHK(s->d_runs.reserve(std::max<size_t>(1, R), st));
+    if (want_id) HIPCHK(s->d_ident.reserve(std::max<size_t>(1, R), st));
+    if (want_hist) HIPCHK(s->d_arena.reserve((size_t)R + nT + 1, st));
+
+    hipLaunchKernelGGL(k_init, dim3((std::max(nT, 1u) + 255) / 256), dim3(256), 0, st, s->d_ctg.p, nT, s->d_glob.p);
+    HIPCHK(hipGetLastError());
+
+    FilterCfg f{};
+    f.include_improper_pairs = s->cfg.include_improper_pairs; f.include_supplementary = s->cfg.include_supplementary;
+    f.include_secondary = s->cfg.include_secondary; f.filter_single = s->cfg.filter_single;
+    f.min_mapq = s->cfg.min_mapq; f.min_aligned_length = s->cfg.min_aligned_length;
+    f.min_percent_identity = s->cfg.min_percent_identity; f.min_aligned_percent = s->cfg.min_aligned_percent;
+    const Records r = records_of(s);
+    const uint8_t *mask = s->have_mask ? s->d_mask.p : nullptr;
+
+    if (R) {
+        time_begin(s, COV_K_PREP);
+        if (want_id)
+            hipLaunchKernelGGL((k_prep<true>), dim3((R + 255) / 256), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
+                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, s->d_ident.p);
+        else
+            hipLaunchKernelGGL((k_prep<false>), dim3((R + 255) / 256), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
+                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, (double *)nullptr);
+        time_end(s, COV_K_PREP);
+        HIPCHK(hipGetLastError());
+    }
+    if (R && s->n_tiles) {
+        time_begin(s, COV_K_RANGES);
+        if (want_hist)
+            hipLaunchKernelGGL((k_ranges<true>), dim3((s->n_tiles + 255) / 256), dim3(256), 0, st, s->d_tile_contig.p,
+                               s->d_tile_start.p, s->n_tiles, r.pos, mask, s->d_ctg.p, s->d_cand.p);
+        else
+            hipLaunchKernelGGL((k_ranges<false>), dim3((s->n_tiles + 255) / 256), dim3(256), 0, st, s->d_tile_contig.p,
+                               s->d_tile_start.p, s->n_tiles, r.pos, mask, s->d_ctg.p, s->d_cand.p);
+        time_end(s, COV_K_RANGES);
+        HIPCHK(hipGetLastError());
+        if (want_hist) {
+            time_begin(s, COV_K_HIST);
+            hipLaunchKernelGGL((k_hist_layout<0>), dim3(1), dim3(1024), 0, st, s->d_ctg.p, nT, s->d_tlen.p, mask,
+                               (u64)s->cfg.contig_end_exclusion, s->d_glob.p);
+            hipLaunchKernelGGL(k_zero_u32, dim3(2048), dim3(256), 0, st, s->d_arena.p, &s->d_glob.p->hist_cap_total);
+            time_end(s, COV_K_HIST);
+            HIPCHK(hipGetLastError());
+        }
+        PileupArgs a = pileup_args(s);
+        time_begin(s, COV_K_PILEUP);
+        if (want_hist) launch_pileup<true, false>(s, a, s->n_tiles);
+        else launch_pileup<false, false>(s, a, s->n_tiles);
+        time_end(s, COV_K_PILEUP);
+        HIPCHK(hipGetLastError());
+        if (want_id) {
+            time_begin(s, COV_K_IDENTITY);
+            hipLaunchKernelGGL(k_identity, dim3(nT), dim3(64), 0, st, s->d_ctg.p, nT, s->d_ident.p, r.flag, r.tid);
+            time_end(s, COV_K_IDENTITY);
+            HIPCHK(hipGetLastError());
+        }
+        if (want_hist) {
+            hipLaunchKernelGGL((k_hist_layout<1>), dim3(1), dim3(1024), 0, st, s->d_ctg.p, nT, s->d_tlen.p, mask,
+                               (u64)s->cfg.contig_end_exclusion, s->d_glob.p);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    s->h_ctg.resize(nT);
+    if (nT) HIPCHK(hipMemcpyAsync(s->h_ctg.data(), s->d_ctg.p, (size_t)nT * sizeof(DevContig), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&s->h_glob, s->d_glob.p, sizeof(DevGlobal), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int k = 0; k < COV_K_COUNT; k++)
+        if (s->k_launches[k]) (void)hipEventElapsedTime(&s->k_ms[k], s->ev[k][0], s->ev[k][1]);
+
+    // algorithmic bytes: each record's SoA fields and CIGAR words are needed once; results written once
+    {
+        const uint64_t ncig = s->adopted ? s->adopted_ncig : s->n_cigar;
+        s->algo_bytes = (uint64_t)R * 24 + ncig * 4 + (uint64_t)nT * sizeof(DevContig);
+    }
+
+    if (s->h_glob.internal_error) { s->err = "internal error: depth exceeded its proven bound"; return COV_ERR_STATE; }
+    // errors in file order (the reference panics at the first offending record)
+    uint64_t err_rec = ~0ull; int err_code = 0;
+    if (s->h_glob.first_error != ~0ull) { err_rec = s->h_glob.first_error >> 8; err_code = (int)(s->h_glob.first_error & 0xff); }
+    // sortedness: the considered records of successive touched contigs must not interleave
+    // (contig.rs:129-132 panics when a considered record has tid < the previous considered tid)
+    {
+        uint64_t prev_last = 0; bool any = false; uint64_t unsorted_at = ~0ull;
+        for (u32 c = 0; c < nT; c++) {
+            const DevContig &C = s->h_ctg[c];
+            if (C.n_pass == 0) continue;
+            if (any && C.first_rec < prev_last) unsorted_at = std::min<uint64_t>(unsorted_at, std::max<uint64_t>(C.first_rec, 0));
+            prev_last = any ? std::max<uint64_t>(prev_last, C.last_rec) : C.last_rec;
+            any = true;
+        }
+        if (unsorted_at != ~0ull && unsorted_at <= err_rec) {
+            s->err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)";
+            return COV_ERR_UNSORTED;
+        }
+    }
+    if (err_code) {
+        char b[256];
+        const char *what = err_code == 2 ? "Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM format"
+                         : err_code == 3 ? "Unexpected data type of NM aux tag"
+                         : err_code == 4 ? "aligned block starts at or beyond the end of its reference sequence"
+                         : err_code == 7 ? "record refers to a reference id outside the header (Corrupt BAM file?)"
+                                         : "invalid CIGAR operation";
+        snprintf(b, sizeof b, "%s (record %llu)", what, (unsigned long long)err_rec);
+        s->err = b;
+        return (cov_status)err_code;
+    }
+
+    const u64 excl = s->cfg.contig_end_exclusion;
+    uint64_t hist_total = 0;
+    for (u32 c = 0; c < nT; c++) {
+        const DevContig &C = s->h_ctg[c];
+        cov_contig_stats &o = stats[c];
+        memset(&o, 0, sizeof o);
+        o.n_primary = C.n_primary; o.n_pass = C.n_pass; o.n_nonsupp = C.n_nonsupp;
+        o.sum_nm = C.sum_nm; o.sum_indel = C.sum_indel;
+        o.sum_identity_primary = C.id_primary; o.sum_identity_nonsupp = C.id_nonsupp;
+        o.win_sum_d = C.sum_d; o.win_sum_d2 = C.sum_d2; o.win_covered = C.cov_win; o.full_covered = C.cov_full;
+        o.first_record = C.first_rec; o.last_record = C.last_rec;
+        const u64 L = s->h_tlen[c];
+        const u64 win_len = 2 * excl < L ? L - 2 * excl : 0;
+        if (C.n_pass && win_len) {
+            o.win_max_d = C.max_d;
+            o.win_min_d = (C.proc_win < win_len || C.min_d == 0xffffffffu) ? 0u : C.min_d;
+        }
+        if (want_hist) { o.hist_len = C.hist_len; o.hist_off = C.chist_off; hist_total += C.hist_len; }
+    }
+    if (summary) {
+        summary->num_detected_primary_alignments = s->h_glob.n_primary_all;
+        summary->n_records = R;
+        summary->n_considered = s->h_glob.n_considered;
+        summary->hist_total = hist_total;
+    }
+    s->finished = true;
+    return COV_OK;
+}
+
+cov_status cov_fetch_hist(cov_session *s, uint64_t *hist) {
+    if (!s || !s->finished || !(s->cfg.want & COV_WANT_HIST)) return COV_ERR_STATE;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    const uint64_t total = s->h_glob.chist_total;
+    if (total == 0) return COV_OK;
+    if (!hist) return COV_ERR_INVALID_ARG;
+    HIPCHK(s->d_chist.reserve(total, s->stream));
+    time_begin(s, COV_K_HIST);
+    hipLaunchKernelGGL(k_hist_compact, dim3(s->n_targets), dim3(256), 0, s->stream, s->d_ctg.p, s->n_targets, s->d_tlen.p,
+                       (u64)s->cfg.contig_end_exclusion, s->d_arena.p, s->d_chist.p);
+    time_end(s, COV_K_HIST);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hist, s->d_chist.p, total * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return COV_OK;
+}
+
+cov_status cov_copy_depth(cov_session *s, uint32_t tid, int32_t *depth_out) {
+    if (!s || !s->finished) return COV_ERR_STATE;
+    if (tid >= s->n_targets || !depth_out) return COV_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    const u32 L = s->h_tlen[tid];
+    if (L == 0) return COV_OK;
+    HIPCHK(s->d_depth.reserve(L, s->stream));
+    HIPCHK(hipMemsetAsync(s->d_depth.p, 0, (size_t)L * 4, s->stream));
+    PileupArgs a = pileup_args(s);
+    // depth materialisation must not disturb the accumulated statistics: run against a scratch copy
+    DevBuf<DevContig> scratch;
+    HIPCHK(scratch.reserve(s->n_targets, s->stream));
+    HIPCHK(hipMemcpyAsync(scratch.p, s->d_ctg.p, (size_t)s->n_targets * sizeof(DevContig), hipMemcpyDeviceToDevice, s->stream));
+    a.ctg = scratch.p;
+    a.depth_out = s->d_depth.p;
+    a.tile_base = s->h_tile_first[tid];
+    const u32 grid = s->h_tile_first[tid + 1] - s->h_tile_first[tid];
+    launch_pileup<false, true>(s, a, grid);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(depth_out, s->d_depth.p, (size_t)L * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    scratch.release();
+    return COV_OK;
+}
+
+cov_status cov_kernel_ms(const cov_session *s, cov_kernel_id k, double *ms_total, uint32_t *launches) {
+    if (!s || k < 0 || k >= COV_K_COUNT) return COV_ERR_INVALID_ARG;
+    if (ms_total) *ms_total = s->k_ms[k];
+    if (launches) *launches = s->k_launches[k];
+    return COV_OK;
+}
+
+cov_status cov_algorithmic_bytes(const cov_session *s, uint64_t *bytes) {
+    if (!s || !bytes) return COV_ERR_INVALID_ARG;
+    *bytes = s->algo_bytes;
+    return COV_OK;
+}
+
+}  // extern "C"

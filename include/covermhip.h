@@ -1,0 +1,191 @@
+/*
+ * covermhip.h — C ABI of the MI355X-native coverage engine (libcovermhip.so).
+ *
+ * This is the drop-in boundary for CoverM's BAM -> pileup -> per-contig hot path.  The reference
+ * (wwood/CoverM v0.8.0) has no FFI of its own; the seam is the body of its three scan loops
+ *   contig_coverage                               src/contig.rs:13-253
+ *   mosdepth_genome_coverage_with_contig_names    src/genome.rs:17-322
+ *   mosdepth_genome_coverage                      src/genome.rs:419-797
+ * and of `CoverageEstimator::add_contig` (src/mosdepth_genome_coverage_estimators.rs:366-528).
+ * A host (Rust via `extern "C"`, C++, Python/ctypes) keeps decoding BAM on the CPU and keeps
+ * `calculate_coverage` / `CoverageTaker` untouched; it streams packed record batches through this
+ * ABI and receives, per contig, the exact integer sufficient statistics from which every
+ * estimator's f32 is finalised (INTEGRATION.md shows the Rust binding).
+ *
+ * Plain C, POD only, caller-owned buffers.  Every function returns a cov_status; on failure
+ * cov_last_error() describes it.  A session is bound to one HIP device and one sample (BAM); it is
+ * not thread-safe (single producer), and owns its own HIP stream.
+ */
+#ifndef COVERMHIP_H
+#define COVERMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COVERMHIP_ABI_VERSION 1
+
+typedef struct cov_session cov_session;
+
+/* Status codes.  The UNSORTED / NM_* / POS_OOB codes map 1:1 onto the reference's panics. */
+typedef enum {
+    COV_OK = 0,
+    COV_ERR_UNSORTED = 1,   /* contig.rs:129-132, genome.rs:133-136, 549-552 */
+    COV_ERR_NM_MISSING = 2, /* lib.rs:149-156 */
+    COV_ERR_NM_BADTYPE = 3, /* lib.rs:144-147 */
+    COV_ERR_POS_OOB = 4,    /* index panic at contig.rs:178 (M/=/X run starting at or past contig end) */
+    COV_ERR_BAD_CIGAR = 6,  /* CIGAR op code > 8 */
+    COV_ERR_BAD_TID = 7,    /* considered record whose tid is outside the header ("Corrupt BAM file?", contig.rs:145) */
+    COV_ERR_INVALID_ARG = 16,
+    COV_ERR_HIP = 17,       /* HIP runtime failure or no usable device: the engine never falls back to the CPU */
+    COV_ERR_STATE = 18
+} cov_status;
+
+/* nm_kind values: how the record's NM aux tag was encoded (lib.rs:138-158). */
+#define COV_NM_ABSENT 0
+#define COV_NM_UNSIGNED 1 /* BAM type C, S or I */
+#define COV_NM_BADTYPE 2  /* any other type: the reference panics */
+
+/* cov_config.want bits */
+#define COV_WANT_HIST 1u     /* per-contig depth histogram (trimmed_mean, coverage_histogram) */
+#define COV_WANT_IDENTITY 2u /* ordered f64 identity sums (anir) */
+
+typedef struct {
+    int32_t device; /* HIP device ordinal */
+    /* FlagFilter, lib.rs:60-79 (CLI defaults: improper in, supplementary in, secondary out; coverm.rs:1661-1665) */
+    uint8_t include_improper_pairs;
+    uint8_t include_supplementary;
+    uint8_t include_secondary;
+    /* Single-read alignment thresholds = the stateless branch of ReferenceSortedBamFilter::read
+     * (filter.rs:88-116, 243-279).  filter_single = 1 iff that branch is the active reader
+     * (filtering_single && !filtering_pairs, filter.rs:48-61). */
+    uint8_t filter_single;
+    uint8_t min_mapq; /* 255 = no MAPQ test (filter.rs:13) */
+    uint8_t reserved0[3];
+    uint32_t min_aligned_length;
+    float min_percent_identity; /* fraction in [0,1] */
+    float min_aligned_percent;  /* fraction in [0,1] */
+    /* --contig-end-exclusion: window [excl, L-excl) for the mean / trimmed_mean / variance /
+     * histogram family (estimators.rs:386-398, 436-449). */
+    uint64_t contig_end_exclusion;
+    uint32_t want; /* COV_WANT_* */
+    uint32_t reserved1;
+} cov_config;
+
+/*
+ * One batch of BAM records in file order, struct-of-arrays.  Field provenance (rust-htslib accessors
+ * used by the reference): tid/pos contig.rs:124,166; flag lib.rs:67-78; mapq filter.rs:251; NM
+ * lib.rs:138-158; l_seq = record.seq().len() filter.rs:277; cigar contig.rs:168.
+ * cigar words are raw BAM: len << 4 | op, op order MIDNSHP=X.  cigar_off has n_records + 1 entries
+ * indexing `cigar` (cigar_off[0] may be non-zero; n_cigar = cigar_off[n] - cigar_off[0]).
+ */
+typedef struct {
+    const int32_t *tid;
+    const int32_t *pos;
+    const uint16_t *flag;
+    const uint8_t *mapq;
+    const uint32_t *nm;
+    const uint8_t *nm_kind;
+    const uint32_t *l_seq;
+    const uint32_t *cigar_off;
+    const uint32_t *cigar;
+    uint64_t n_records;
+} cov_batch;
+
+/*
+ * Per-contig result.  "considered" = record survives the reader stage (filter_single), passes
+ * FlagFilter and is mapped — i.e. reaches the CIGAR walk of the scan loops.  Depth statistics are
+ * over per-base depth d[p] = prefix sum of the +1/-1 events of every M/=/X run (contig.rs:171-186):
+ *   window  = [excl, L-excl) if 2*excl < L, else empty           (estimators.rs:386-398)
+ *   full    = [0, L)                                              (estimators.rs:492-501)
+ */
+typedef struct {
+    uint64_t n_primary;  /* considered && !secondary && !supplementary        contig.rs:157-159 */
+    uint64_t n_pass;     /* considered                                         genome.rs:173-174 */
+    uint64_t n_nonsupp;  /* considered && !supplementary                       genome.rs:677-682 */
+    uint64_t sum_nm;     /* sum of NM over considered records                  contig.rs:207 */
+    uint64_t sum_indel;  /* sum of I and D lengths                             contig.rs:189,197 */
+    double sum_identity_primary; /* in file order; contig.rs:208-211, genome.rs:724-727 (COV_WANT_IDENTITY) */
+    double sum_identity_nonsupp; /* in file order; genome.rs:220-223                      (COV_WANT_IDENTITY) */
+    uint64_t win_sum_d;   /* sum of d over window (wrapping u64) */
+    uint64_t win_sum_d2;  /* sum of d*d over window (wrapping u64) */
+    uint64_t win_covered; /* #{p in window : d > 0} */
+    uint64_t full_covered; /* #{p in [0,L) : d > 0} */
+    uint64_t first_record; /* file-order index of the first / last considered record of this contig */
+    uint64_t last_record;  /*   (sortedness is judged from these, see cov_finish) */
+    uint32_t win_min_d;    /* min / max depth over the window (0 / 0 when the window is empty) */
+    uint32_t win_max_d;
+    uint32_t hist_len;     /* COV_WANT_HIST: win_max_d + 1 bins at hist[hist_off ..], else 0 */
+    uint32_t reserved;
+    uint64_t hist_off;
+} cov_contig_stats;
+
+typedef struct {
+    uint64_t num_detected_primary_alignments; /* every record pushed with !secondary && !supplementary
+                                                 (bam_generator.rs:114-118, filter.rs:94-96) */
+    uint64_t n_records;
+    uint64_t n_considered;
+    uint64_t hist_total; /* number of u64 bins cov_fetch_hist() will write */
+} cov_summary;
+
+/* Named kernels of the device pipeline, for cov_kernel_ms(). */
+typedef enum {
+    COV_K_PREP = 0,     /* filter + CIGAR summary + per-contig record counters */
+    COV_K_RANGES = 1,   /* tile -> candidate record range */
+    COV_K_PILEUP = 2,   /* LDS-tiled events + scan + statistics (the dominant kernel) */
+    COV_K_IDENTITY = 3, /* ordered f64 identity sums */
+    COV_K_HIST = 4,     /* histogram layout / zero / compaction */
+    COV_K_COUNT = 5
+} cov_kernel_id;
+
+/* --- lifecycle ------------------------------------------------------------------------------- */
+int cov_abi_version(void);
+/* Creates a session on cfg->device.  Fails with COV_ERR_HIP (never falls back) if no GPU. */
+cov_status cov_create(const cov_config *cfg, cov_session **out);
+void cov_destroy(cov_session *s);
+const char *cov_last_error(const cov_session *s); /* s may be NULL for cov_create failures */
+
+/* BAM header: n reference sequences and their lengths (HeaderView::target_len, contig.rs:145). */
+cov_status cov_set_targets(cov_session *s, uint32_t n_targets, const uint64_t *target_len);
+
+/* Optional: mask[t] == 0 removes target t from the CIGAR walk, the NM requirement and the depth
+ * statistics while its records still take part in the sortedness check — exactly what
+ * mosdepth_genome_coverage_with_contig_names does for contigs outside every genome
+ * (genome.rs:170-171).  NULL (default) = every target participates. */
+cov_status cov_set_target_mask(cov_session *s, const uint8_t *mask);
+
+/* Appends a batch of records held in HOST memory (copied to the device on the session stream). */
+cov_status cov_push_batch(cov_session *s, const cov_batch *host_batch);
+/* Appends a batch whose arrays already live in DEVICE memory (no copy; the caller keeps them
+ * alive and unmodified until cov_finish returns).  Used when ingest writes straight to HBM. */
+cov_status cov_push_batch_device(cov_session *s, const cov_batch *device_batch);
+
+/*
+ * Runs the device pipeline over everything pushed and writes one cov_contig_stats per target into
+ * `stats` (n_targets entries, caller-owned).  Returns COV_ERR_UNSORTED / COV_ERR_NM_* /
+ * COV_ERR_POS_OOB exactly when the reference's scan would have panicked.  The session keeps its
+ * records, so cov_finish may be called again (e.g. for benchmarking) and cov_copy_depth works
+ * afterwards; cov_reset drops the records.
+ */
+cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summary);
+/* After cov_finish with COV_WANT_HIST: concatenated histograms, hist[stats[t].hist_off + d] =
+ * #{p in window of contig t : depth == d}, summary.hist_total entries. */
+cov_status cov_fetch_hist(cov_session *s, uint64_t *hist);
+/* Bit-exact per-base depth of one contig (target_len[tid] entries), for parity checks. */
+cov_status cov_copy_depth(cov_session *s, uint32_t tid, int32_t *depth_out);
+cov_status cov_reset(cov_session *s);
+
+/* Average duration (ms) of one launch of kernel `k` during the last cov_finish, measured with HIP
+ * events recorded on the session's stream around that kernel; *launches receives the count. */
+cov_status cov_kernel_ms(const cov_session *s, cov_kernel_id k, double *ms_total, uint32_t *launches);
+/* Algorithmic HBM bytes of the last cov_finish (DESIGN.md "Algorithmic bytes"): record SoA + CIGAR
+ * words read once, plus result structs written. */
+cov_status cov_algorithmic_bytes(const cov_session *s, uint64_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COVERMHIP_H */

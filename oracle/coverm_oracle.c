@@ -921,3 +921,99 @@ float orc_estimate_one(const orc_est_param *p, const int32_t *ud, u64 len, u64 n
     est_free(e, 1);
     return c;
 }
+
+/* ------------------------------------------------------------------ integer sufficient statistics
+ * What the device must return per contig (covermhip.h cov_contig_stats), computed the reference's way:
+ * one delta array per contig built by the CIGAR walk (contig.rs:144-202), then a sequential prefix sum
+ * with the window test of estimators.rs:393-404 / 447-465 and the full-length loop of :496-501.
+ * mask[t] == 0 reproduces genome.rs:170-171 (contigs outside every genome: counted as seen, not walked). */
+typedef struct {
+    u64 n_primary, n_pass, n_nonsupp, sum_nm, sum_indel;
+    double id_primary, id_nonsupp;
+    u64 win_sum_d, win_sum_d2, win_covered, full_covered, first_record, last_record;
+    uint32_t win_min_d, win_max_d, hist_len, seen;
+    u64 hist_off;
+} orc_stats;
+
+int orc_integer_stats(const orc_records *r, const i64 *target_len, int32_t n_targets, const uint8_t *mask,
+                      const orc_flag_filter *ff, u64 excl, orc_stats *out, u64 **hist_out, u64 *hist_total) {
+    memset(out, 0, sizeof(orc_stats) * (size_t)(n_targets ? n_targets : 1));
+    u64 *hist = NULL; size_t hn = 0, hcap = 0;
+    int32_t last_tid = -2;
+    int32_t *ud = NULL; size_t L = 0;
+    int rc = ORC_OK;
+    for (u64 oi = 0; oi <= r->n_order; oi++) {
+        int flush = (oi == r->n_order);
+        u64 i = 0; uint16_t flag = 0; int32_t tid = -1;
+        if (!flush) {
+            i = r->order ? r->order[oi] : oi;
+            flag = r->flag[i];
+            if (!flag_passes(ff, flag) || (flag & 0x4)) continue;
+            tid = r->tid[i];
+            if (tid != last_tid) {
+                if (tid < last_tid) { rc = ORC_ERR_UNSORTED; goto done; }
+                flush = 1;
+            }
+        }
+        if (flush && last_tid >= 0 && (!mask || mask[last_tid])) {
+            orc_stats *o = &out[last_tid];
+            int32_t c = 0;
+            for (size_t p = 0; p < L; p++) { c += ud[p]; if (c > 0) o->full_covered++; }
+            if (2 * excl < (u64)L) {
+                size_t s = (size_t)excl, e = L - (size_t)excl - 1;
+                c = 0;
+                uint32_t mn = 0xffffffffu, mx = 0;
+                for (size_t p = 0; p < L; p++) {
+                    c += ud[p];
+                    if (p >= s && p <= e) {
+                        if (c > 0) o->win_covered++;
+                        o->win_sum_d += (u64)(i64)c;
+                        o->win_sum_d2 += (u64)(i64)c * (u64)(i64)c;
+                        if ((uint32_t)c < mn) mn = (uint32_t)c;
+                        if ((uint32_t)c > mx) mx = (uint32_t)c;
+                    }
+                }
+                o->win_min_d = mn; o->win_max_d = mx; o->hist_len = mx + 1;
+                o->hist_off = hn;
+                if (hn + mx + 1 > hcap) { hcap = (hn + mx + 1) * 2; hist = (u64 *)realloc(hist, hcap * sizeof(u64)); }
+                memset(hist + hn, 0, (size_t)(mx + 1) * sizeof(u64));
+                c = 0;
+                for (size_t p = 0; p < L; p++) { c += ud[p]; if (p >= s && p <= e) hist[hn + (size_t)c]++; }
+                hn += mx + 1;
+            }
+        }
+        if (oi == r->n_order) break;
+        if (tid != last_tid) {
+            free(ud);
+            L = (size_t)target_len[tid];
+            ud = (int32_t *)calloc(L ? L : 1, sizeof(int32_t));
+            last_tid = tid;
+            out[tid].first_record = i;
+            out[tid].seen = 1;
+        }
+        orc_stats *o = &out[tid];
+        o->last_record = i;
+        o->n_pass++;
+        int primary = !(flag & 0x800) && !(flag & 0x100);
+        if (primary) o->n_primary++;
+        if (!(flag & 0x800)) o->n_nonsupp++;
+        if (mask && !mask[tid]) continue;
+        u64 indels = 0, aligned = 0;
+        rc = cigar_walk(r, i, ud, L, &indels, &aligned);
+        if (rc) goto done;
+        u64 edit;
+        rc = nm_of(r, i, &edit);
+        if (rc) goto done;
+        o->sum_nm += edit; o->sum_indel += indels;
+        if (aligned > 0) {
+            double idv = ((double)aligned - (double)edit) / (double)aligned;
+            if (primary) o->id_primary += idv;
+            if (!(flag & 0x800)) o->id_nonsupp += idv;
+        }
+    }
+done:
+    free(ud);
+    *hist_out = hist; *hist_total = hn;
+    return rc;
+}
+void orc_free(void *p) { free(p); }

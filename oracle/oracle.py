@@ -90,6 +90,8 @@ def lib():
         _lib = C.CDLL(build())
         _lib.orc_estimate_one.restype = C.c_float
         _lib.orc_count_primary.restype = C.c_uint64
+        _lib.orc_free.argtypes = [C.c_void_p]
+        _lib.orc_free.restype = None
     return _lib
 
 
@@ -727,6 +729,37 @@ def contig_deltas(b: BamData, flag_filters: FlagFilter, tid: int, order=None) ->
     if rc:
         raise OracleError(rc)
     return ud
+
+
+ORC_STATS_DTYPE = np.dtype([
+    ("n_primary", "<u8"), ("n_pass", "<u8"), ("n_nonsupp", "<u8"), ("sum_nm", "<u8"), ("sum_indel", "<u8"),
+    ("id_primary", "<f8"), ("id_nonsupp", "<f8"), ("win_sum_d", "<u8"), ("win_sum_d2", "<u8"),
+    ("win_covered", "<u8"), ("full_covered", "<u8"), ("first_record", "<u8"), ("last_record", "<u8"),
+    ("win_min_d", "<u4"), ("win_max_d", "<u4"), ("hist_len", "<u4"), ("seen", "<u4"), ("hist_off", "<u8")])
+
+
+def integer_stats(b: BamData, flag_filters: FlagFilter, filter_params: Optional[FilterParameters], excl: int,
+                  mask: Optional[np.ndarray] = None):
+    """Per-contig integer sufficient statistics computed the reference's way (orc_integer_stats).
+    Returns (stats[n_targets] as ORC_STATS_DTYPE, hist uint64[], num_detected_primary_alignments)."""
+    order, prim = reader_stage(b, filter_params)
+    r, keep = _records(b, order)
+    tl = np.ascontiguousarray(b.ref_lens, np.int64)
+    out = np.zeros(max(1, len(tl)), dtype=ORC_STATS_DTYPE)
+    hist_p = C.c_void_p()
+    hn = C.c_uint64(0)
+    ff = flag_filters.c()
+    m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+    rc = lib().orc_integer_stats(C.byref(r), tl.ctypes.data_as(C.c_void_p), C.c_int32(len(tl)),
+                                 m.ctypes.data_as(C.c_void_p) if m is not None else None, C.byref(ff),
+                                 C.c_uint64(excl), out.ctypes.data_as(C.c_void_p), C.byref(hist_p), C.byref(hn))
+    hist = np.zeros(hn.value, dtype=np.uint64)
+    if hn.value:
+        C.memmove(hist.ctypes.data, hist_p, hn.value * 8)
+    lib().orc_free(hist_p)
+    if rc:
+        raise OracleError(rc)
+    return out[:len(tl)], hist, prim
 
 
 def estimate_one(p: EstParam, ud: np.ndarray, n_reads=0, mismatches=0, sum_identity=0.0, unobserved=(0,)):

@@ -1,0 +1,203 @@
+"""GPU parity tests through the C ABI (libcovermhip.so) against the CPU oracle.
+
+Bar: every integer (depth arrays, window/full statistics, histograms, read counters) bit-exact;
+identity sums bit-exact as well (the device keeps the reference's file-order f64 summation).
+"""
+import numpy as np
+import pytest
+
+from coverm_amd import synth
+from coverm_amd.engine import FilterConfig, RecordBatch, Session
+from coverm_amd.native import CovError, ERR_NM_MISSING, ERR_POS_OOB, ERR_UNSORTED
+from oracle import oracle as O
+from oracle.bamio import BamData
+from tests.fixtures import load_fixture
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def to_batch(b: BamData) -> RecordBatch:
+    return RecordBatch.from_arrays(b.tid, b.pos, b.flag, b.mapq, b.nm, b.nm_kind, b.l_seq, b.cigar_off, b.cigar)
+
+
+def to_bamdata(batch: RecordBatch, ref_lens, names=None) -> BamData:
+    n = batch.n_records
+    names = names or ["c%d" % i for i in range(len(ref_lens))]
+    z = np.zeros(n, np.int32)
+    return BamData(names, np.asarray(ref_lens, np.int64), batch.tid, batch.pos, batch.flag, batch.mapq,
+                   batch.l_seq.astype(np.int32), batch.nm, batch.nm_kind, batch.cigar_off, batch.cigar, z, z, z,
+                   [b"r%d" % i for i in range(n)] if n < 100000 else [], "")
+
+
+def compare(b: BamData, ff=(True, True, False), fp=None, excl=75, mask=None, check_depth=(), chunks=1):
+    off = O.FlagFilter(*ff)
+    ofp = None
+    filt = FilterConfig(*ff)
+    if fp is not None:
+        ofp = O.FilterParameters(off, **fp)
+        fs, fpair = O.filter_mode(ofp)
+        assert fs and not fpair, "ABI covers the single-read branch"
+        filt = FilterConfig(*ff, filter_single=True, min_mapq=ofp.min_mapq,
+                            min_aligned_length=ofp.min_aligned_length_single,
+                            min_percent_identity=ofp.min_percent_identity_single,
+                            min_aligned_percent=ofp.min_aligned_percent_single)
+    exp, exp_hist, prim = O.integer_stats(b, off, ofp, excl, mask)
+    batch = to_batch(b)
+    with Session(0, filt, excl, want_hist=True, want_identity=True) as s:
+        s.set_targets(b.ref_lens, mask)
+        n = batch.n_records
+        edges = np.linspace(0, n, chunks + 1).astype(int)
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            s.push(batch.slice(lo, hi))
+        st, summ = s.finish()
+        hist = s.hist()
+        assert summ.num_detected_primary_alignments == prim
+        live = exp["seen"] == 1 if mask is None else (exp["seen"] == 1) & (np.asarray(mask) != 0)
+        for f in ("n_primary", "n_pass", "n_nonsupp"):
+            np.testing.assert_array_equal(st[f], exp[f], err_msg=f)
+        for f in ("sum_nm", "sum_indel", "win_sum_d", "win_sum_d2", "win_covered", "full_covered", "win_min_d",
+                  "win_max_d"):
+            np.testing.assert_array_equal(st[f][live], exp[f][live], err_msg=f)
+            assert (st[f][~live] == 0).all(), f
+        seen = exp["seen"] == 1
+        np.testing.assert_array_equal(st["first_record"][seen], exp["first_record"][seen])
+        np.testing.assert_array_equal(st["last_record"][seen], exp["last_record"][seen])
+        # identity sums: bit-exact f64
+        np.testing.assert_array_equal(st["sum_identity_primary"][live].view(np.uint64),
+                                      exp["id_primary"][live].view(np.uint64))
+        np.testing.assert_array_equal(st["sum_identity_nonsupp"][live].view(np.uint64),
+                                      exp["id_nonsupp"][live].view(np.uint64))
+        # histograms
+        np.testing.assert_array_equal(st["hist_len"][live], exp["hist_len"][live])
+        assert (st["hist_len"][~live] == 0).all()
+        for t in np.nonzero(live)[0]:
+            n_b = int(exp["hist_len"][t])
+            np.testing.assert_array_equal(hist[int(st["hist_off"][t]):int(st["hist_off"][t]) + n_b],
+                                          exp_hist[int(exp["hist_off"][t]):int(exp["hist_off"][t]) + n_b],
+                                          err_msg="hist of contig %d" % t)
+        for t in check_depth:
+            order, _ = O.reader_stage(b, ofp)
+            ud = O.contig_deltas(b, off, t, order)
+            np.testing.assert_array_equal(s.depth(t), np.cumsum(ud, dtype=np.int64).astype(np.int32),
+                                          err_msg="depth of contig %d" % t)
+    return st
+
+
+FIXTURES = [f for f in cases.FIXTURE_FILES if "unsorted" not in f]
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("excl", [0, 75])
+def test_fixture_stats_and_depth(name, excl):
+    b = load_fixture(name)
+    touched = sorted(set(int(t) for t in b.tid if t >= 0))[:4]
+    if name.startswith("1read"):   # unmapped mate without NM: default flags include it? it is unmapped -> fine
+        pass
+    compare(b, ff=(True, True, False), excl=excl, check_depth=touched)
+
+
+@pytest.mark.parametrize("ff", [(True, False, False), (False, True, True), (True, True, True)])
+def test_fixture_flag_filters(ff):
+    for name in ["7seqs.reads_for_seq1_and_seq2.bam", "2seqs.bad_read.1.with_supplementary.bam",
+                 "k141_2005182.bam", "eg2.bam"]:
+        compare(load_fixture(name), ff=ff, excl=75)
+
+
+def test_fixture_single_read_filter():
+    for name, fp in [("2seqs.bad_read.1.bam", dict(min_percent_identity_single=0.99)),
+                     ("mapq_test.sam", dict(min_mapq=51)),
+                     ("k141_2005182.head11.bam", dict(min_percent_identity_single=float(np.float32(0.97001)))),
+                     ("eg2.bam", dict(min_aligned_length_single=100, min_aligned_percent_single=0.9,
+                                      min_percent_identity_single=0.95))]:
+        compare(load_fixture(name), ff=(True, True, True), fp=fp, excl=75)
+
+
+def test_unsorted_error():
+    b = load_fixture("2seqs.bad_read.1.unsorted.bam")
+    with Session(0, FilterConfig(), 75) as s:
+        s.set_targets(b.ref_lens)
+        s.push(to_batch(b))
+        with pytest.raises(CovError) as ei:
+            s.finish()
+        assert ei.value.status == ERR_UNSORTED
+        assert "BAM file appears to be unsorted" in ei.value.message
+
+
+def test_nm_missing_and_pos_oob_errors():
+    b = load_fixture("7seqs.reads_for_seq1_and_seq2.bam")
+    bad = to_batch(b)
+    bad.nm_kind = bad.nm_kind.copy(); bad.nm_kind[5] = 0
+    with Session(0, FilterConfig(), 75) as s:
+        s.set_targets(b.ref_lens); s.push(bad)
+        with pytest.raises(CovError) as ei:
+            s.finish()
+        assert ei.value.status == ERR_NM_MISSING and "record 5" in ei.value.message
+    bad = to_batch(b)
+    bad.pos = bad.pos.copy(); bad.pos[3] = int(b.ref_lens[b.tid[3]]) + 7
+    with Session(0, FilterConfig(), 75) as s:
+        s.set_targets(b.ref_lens); s.push(bad)
+        with pytest.raises(CovError) as ei:
+            s.finish()
+        assert ei.value.status == ERR_POS_OOB
+
+
+@pytest.mark.parametrize("n_contigs,total,n_reads,chunks", [(40, 3_000_000, 60_000, 1), (300, 20_000_000, 400_000, 3)])
+def test_synthetic_all_ops(n_contigs, total, n_reads, chunks):
+    ref = synth.make_reference(n_contigs, total, seed=11, min_len=1500, max_len=400_000)
+    batch = synth.make_reads(ref, n_reads, seed=12)
+    b = to_bamdata(batch, ref.lengths, ref.names)
+    ops = np.bincount(batch.cigar & 15, minlength=9)
+    assert ops[7] and ops[8] and ops[3] and ops[2] and ops[1] and ops[4]   # = X N D I S all present
+    compare(b, ff=(True, True, False), excl=75, check_depth=[0, 1, n_contigs // 2, n_contigs - 1], chunks=chunks)
+    compare(b, ff=(False, False, False), excl=0,
+            fp=dict(min_percent_identity_single=0.95, min_aligned_length_single=50), chunks=chunks)
+
+
+def test_mask_matches_contig_names_mode():
+    ref = synth.make_reference(30, 2_000_000, seed=3, min_len=1500, max_len=300_000)
+    batch = synth.make_reads(ref, 30_000, seed=4)
+    b = to_bamdata(batch, ref.lengths, ref.names)
+    mask = (np.arange(30) % 3 != 0).astype(np.uint8)
+    compare(b, ff=(True, False, False), excl=75, mask=mask)
+
+
+def test_edge_cases_empty_and_tiny():
+    ref_lens = np.asarray([100, 5, 149, 150, 151, 16384, 16385, 40000], dtype=np.int64)
+    # no records at all
+    empty = RecordBatch.from_arrays([], [], [], [], [], [], [], [0], [])
+    with Session(0, FilterConfig(), 75, want_hist=True) as s:
+        s.set_targets(ref_lens)
+        st, summ = s.finish()
+        assert summ.n_records == 0 and (st["n_pass"] == 0).all()
+        s.push(empty)
+        st, summ = s.finish()
+        assert (st["win_sum_d"] == 0).all()
+    # reads running off contig ends, contigs shorter than 2*excl, zero-length ops, deep pile at one base
+    tid, pos, cig, coff = [], [], [], [0]
+
+    def add(t, p, ops):
+        tid.append(t); pos.append(p)
+        cig.extend((l << 4) | "MIDNSHP=X".index(o) for l, o in ops)
+        coff.append(len(cig))
+    add(0, 0, [(100, "M")]); add(0, 50, [(80, "M")]); add(0, 99, [(1, "M"), (5, "S")])
+    add(1, 0, [(5, "M")]); add(1, 4, [(3, "M")])
+    add(2, 10, [(5, "S"), (20, "M"), (3, "I"), (0, "M"), (30, "M"), (10, "D"), (40, "=")])
+    add(3, 0, [(150, "X")])
+    for _ in range(3000):
+        add(4, 75, [(1, "M")])
+    add(5, 16383, [(1, "M")]); add(5, 16300, [(84, "M")][:1])
+    add(6, 16380, [(2, "M"), (2, "N"), (1, "M")]); add(6, 16384, [(1, "M")])
+    add(7, 100, [(30000, "M")]); add(7, 16000, [(500, "M"), (8000, "N"), (500, "M")]); add(7, 39999, [(1, "M")])
+    n = len(tid)
+    order = np.lexsort((pos, tid))
+    tid = np.asarray(tid)[order]; posa = np.asarray(pos)[order]
+    coff = np.asarray(coff); cig = np.asarray(cig, dtype=np.uint32)
+    ncig = (coff[1:] - coff[:-1])[order]
+    new_off = np.zeros(n + 1, dtype=np.uint32); np.cumsum(ncig, out=new_off[1:])
+    new_cig = np.concatenate([cig[coff[i]:coff[i + 1]] for i in order])
+    batch = RecordBatch.from_arrays(tid, posa, np.full(n, 99), np.full(n, 30), np.ones(n), np.ones(n),
+                                    np.full(n, 150), new_off, new_cig)
+    b = to_bamdata(batch, ref_lens)
+    for excl in (0, 75, 8000):
+        compare(b, ff=(True, True, False), excl=excl, check_depth=range(8))
