@@ -1,0 +1,338 @@
+"""`coverm contig` / `coverm genome` over --bam-files, on the MI355X engine.
+
+Mirrors the reference orchestrator for this path only (src/bin/coverm.rs): FilterParameters (:1648-1704),
+EstimatorsAndTaker::generate_from_clap (:1315-1504), run_contig (:2088-2131), run_genome (:1539-1628),
+parse_percentage (:1296-1312), parse_separator (:1522-1537).  Read mapping, index building, dereplication
+and the other subcommands are out of scope.
+
+Records reach the GPU through coverm_amd.engine.Session (C ABI); the per-sample statistics come back and
+the C++ host layer (coverm_amd.host) turns them into the reference's exact output text.
+"""
+import argparse
+import os
+import sys
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import host
+from .engine import FilterConfig, RecordBatch, Session
+from .host import CoverageEstimator, CoverageTaker, SampleResult
+
+CONCATENATED_FASTA_FILE_SEPARATOR = "~"  # lib.rs:46
+UNSORTED_MESSAGE = ("BAM file appears to be unsorted. Input BAM files must be sorted by reference "
+                    "(i.e. by samtools sort)")
+
+
+@dataclass
+class AlignmentFile:
+    """A decoded BAM/SAM: header + records in file order (+ mate fields for pair-mode filtering)."""
+    path: str
+    ref_names: List[str]
+    ref_lens: np.ndarray
+    records: RecordBatch
+    qname: Optional[List[bytes]] = None
+    mtid: Optional[np.ndarray] = None
+
+    @property
+    def stoit_name(self):  # bam_generator.rs:358-365: file stem
+        return os.path.splitext(os.path.basename(self.path))[0]
+
+
+@dataclass
+class FlagFilter:  # lib.rs:60-64
+    include_improper_pairs: bool = True
+    include_supplementary: bool = True
+    include_secondary: bool = False
+
+
+@dataclass
+class FilterParameters:  # bin/coverm.rs:1648-1657
+    flag_filters: FlagFilter = field(default_factory=FlagFilter)
+    min_aligned_length_single: int = 0
+    min_percent_identity_single: float = 0.0
+    min_aligned_percent_single: float = 0.0
+    min_mapq: int = 255
+    min_aligned_length_pair: int = 0
+    min_percent_identity_pair: float = 0.0
+    min_aligned_percent_pair: float = 0.0
+
+    def doing_filtering(self):  # :1695-1703
+        return (self.min_percent_identity_single > 0.0 or self.min_percent_identity_pair > 0.0
+                or self.min_aligned_percent_single > 0.0 or self.min_mapq < 255
+                or self.min_aligned_percent_pair > 0.0 or self.min_aligned_length_single > 0
+                or self.min_aligned_length_pair > 0)
+
+    def filter_mode(self):
+        """ReferenceSortedBamFilter::new mode selection, filter.rs:48-61 -> (filtering_single, filtering_pairs)."""
+        fs0 = (self.min_aligned_length_single > 0 or self.min_percent_identity_single > 0.0
+               or self.min_aligned_percent_single > 0.0)
+        fp0 = (self.min_aligned_length_pair > 0 or self.min_percent_identity_pair > 0.0
+               or self.min_aligned_percent_pair > 0.0)
+        fs = fs0 or (not fp0 and self.min_mapq != 255)
+        fp = fp0 or ((not fs or not self.flag_filters.include_improper_pairs) and self.min_mapq != 255)
+        return fs, fp
+
+
+def parse_percentage(v) -> float:
+    """bin/coverm.rs:1296-1312: f32; values in [1,100] are divided by 100."""
+    if v is None:
+        return 0.0
+    p = np.float32(v)
+    if 1.0 <= p <= 100.0:
+        p = np.float32(p / np.float32(100.0))
+    elif not (0.0 <= p <= 100.0):
+        raise SystemExit("Invalid alignment percentage: '%s'" % v)
+    return float(p)
+
+
+@dataclass
+class EstimatorsAndTaker:  # bin/coverm.rs:1315-1504
+    estimators: List[CoverageEstimator]
+    taker: CoverageTaker
+    printer: int
+    columns_to_normalise: List[int]
+    rpkm_column: Optional[int]
+    tpm_column: Optional[int]
+
+    @staticmethod
+    def generate(methods: Sequence[str], min_covered_fraction, contig_end_exclusion: int, trim_min, trim_max,
+                 output_format: str) -> "EstimatorsAndTaker":
+        E = CoverageEstimator
+        mcf = parse_percentage(min_covered_fraction)
+        est, norm, rpkm, tpm = [], [], None, None
+        if "metabat" in methods:
+            if len(methods) > 1:
+                raise SystemExit("Cannot specify the metabat method with any other coverage methods")
+            est = [E.new_estimator_length(), E.new_estimator_mean(mcf, contig_end_exclusion, False),
+                   E.new_estimator_variance(mcf, contig_end_exclusion)]
+            return EstimatorsAndTaker(est, CoverageTaker.new_cached_single_float_coverage_taker(3),
+                                      host.PRINTER_METABAT, [], None, None)
+        for i, m in enumerate(methods):
+            if m == "mean": est.append(E.new_estimator_mean(mcf, contig_end_exclusion, False))
+            elif m == "coverage_histogram": est.append(E.new_estimator_pileup_counts(mcf, contig_end_exclusion))
+            elif m == "trimmed_mean":
+                est.append(E.new_estimator_trimmed_mean(parse_percentage(trim_min), parse_percentage(trim_max), mcf,
+                                                        contig_end_exclusion))
+            elif m == "covered_fraction": est.append(E.new_estimator_covered_fraction(mcf))
+            elif m == "covered_bases": est.append(E.new_estimator_covered_bases(mcf))
+            elif m == "rpkm":
+                if rpkm is not None:
+                    raise SystemExit("The RPKM column cannot be specified more than once")
+                rpkm = i; est.append(E.new_estimator_rpkm(mcf))
+            elif m == "tpm":
+                if tpm is not None:
+                    raise SystemExit("The TPM column cannot be specified more than once")
+                tpm = i; est.append(E.new_estimator_tpm(mcf))
+            elif m == "variance": est.append(E.new_estimator_variance(mcf, contig_end_exclusion))
+            elif m == "length": est.append(E.new_estimator_length())
+            elif m == "relative_abundance":
+                norm.append(i); est.append(E.new_estimator_mean(mcf, contig_end_exclusion, False))
+            elif m == "count": est.append(E.new_estimator_read_count())
+            elif m == "reads_per_base": est.append(E.new_estimator_reads_per_base())
+            elif m == "anir": est.append(E.new_estimator_anir())
+            else: raise SystemExit("unknown method %r" % m)
+        if "coverage_histogram" in methods:
+            if len(methods) > 1:
+                raise SystemExit("Cannot specify the coverage_histogram method with any other coverage methods")
+            taker, printer = CoverageTaker.new_pileup_coverage_coverage_printer(), host.PRINTER_STREAMED
+        elif not norm and rpkm is None and tpm is None and output_format == "sparse":
+            taker, printer = CoverageTaker.new_single_float_coverage_streaming_coverage_printer(), host.PRINTER_STREAMED
+        else:
+            taker = CoverageTaker.new_cached_single_float_coverage_taker(len(est))
+            printer = host.PRINTER_SPARSE if output_format == "sparse" else host.PRINTER_DENSE
+        if mcf != 0.0:  # :1472-1494
+            bad = {host.READ_COUNT: "counts", host.LENGTH: "length", host.READS_PER_BASE: "reads_per_base",
+                   host.ANIR: "anir"}
+            for e in est:
+                if e.kind in bad:
+                    raise SystemExit("The '%s' coverage estimator cannot be used when --min-covered-fraction is > 0"
+                                     % bad[e.kind])
+        return EstimatorsAndTaker(est, taker, printer, norm, rpkm, tpm)
+
+    def headers(self):
+        hs = [h for e in self.estimators for h in e.column_headers()]
+        for i in self.columns_to_normalise:
+            hs[i] = "Relative Abundance (%)"
+        return hs
+
+
+# ---------------------------------------------------------------------------------------------------
+# Reader stage.  Single-read thresholds run on the GPU (k_prep); mate pairing needs read names and is a
+# host-side pre-pass for now (filter.rs:117-228, a "next" row of the scope table).
+def _aligned(c, ops):
+    op = c & 15
+    m = np.zeros(len(c), bool)
+    for o in ops:
+        m |= op == o
+    return int((c >> 4)[m].sum()) & 0xFFFFFFFF
+
+
+def pair_mode_order(af: AlignmentFile, fp: FilterParameters):
+    """Indices of the records ReferenceSortedBamFilter::read returns in pair mode (filter_out = true)."""
+    r = af.records
+    f32 = np.float32
+    fs, _ = fp.filter_mode()
+
+    def nm(i):
+        if r.nm_kind[i] != 1:
+            raise SystemExit("Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM "
+                             "format" if r.nm_kind[i] == 0 else "Unexpected data type of NM aux tag")
+        return int(r.nm[i])
+
+    def cig(i):
+        return r.cigar[r.cigar_off[i]:r.cigar_off[i + 1]]
+
+    def single_ok(i):  # filter.rs:243-279
+        if fp.min_mapq != 255 and (r.mapq[i] < fp.min_mapq or r.mapq[i] == 255):
+            return False
+        e = nm(i)
+        al = _aligned(cig(i), (0, 1, 2, 7, 8))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return bool(al >= fp.min_aligned_length_single
+                        and f32(al) / f32(int(r.l_seq[i])) >= f32(fp.min_aligned_percent_single)
+                        and f32(1.0) - f32(e) / f32(al) >= f32(fp.min_percent_identity_single))
+
+    def pair_ok(i2, i1):  # filter.rs:281-336
+        if fp.min_mapq != 255 and (r.mapq[i1] < fp.min_mapq or r.mapq[i2] < fp.min_mapq
+                                   or r.mapq[i1] == 255 or r.mapq[i2] == 255):
+            return False
+        e = nm(i2) + nm(i1)
+        al = (_aligned(cig(i2), (0, 1, 7, 8)) + _aligned(cig(i1), (0, 1, 7, 8))) & 0xFFFFFFFF
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return bool(al >= fp.min_aligned_length_pair
+                        and f32(al) / f32(int(r.l_seq[i1]) + int(r.l_seq[i2])) >= f32(fp.min_aligned_percent_pair)
+                        and f32(1.0) - f32(e) / f32(al) >= f32(fp.min_percent_identity_pair))
+
+    order, first_set, cur = [], {}, -1
+    for i in range(r.n_records):
+        flag = int(r.flag[i])
+        if flag & 0x900 or not flag & 0x2:
+            continue
+        if r.tid[i] != cur:
+            cur = int(r.tid[i]); first_set = {}
+        q = af.qname[i]
+        if q not in first_set:
+            if af.mtid[i] == cur:
+                first_set[q] = i
+        else:
+            i1 = first_set.pop(q)
+            if ((not fs) or (single_ok(i1) and single_ok(i))) and pair_ok(i, i1):
+                order += [i1, i]
+    return np.asarray(order, dtype=np.int64)
+
+
+def _select(r: RecordBatch, idx) -> RecordBatch:
+    n = (r.cigar_off[1:].astype(np.int64) - r.cigar_off[:-1].astype(np.int64))[idx]
+    off = np.zeros(len(idx) + 1, dtype=np.uint32)
+    np.cumsum(n, out=off[1:])
+    cig = np.concatenate([r.cigar[r.cigar_off[i]:r.cigar_off[i + 1]] for i in idx]) if len(idx) else np.zeros(0, np.uint32)
+    return RecordBatch(r.tid[idx], r.pos[idx], r.flag[idx], r.mapq[idx], r.nm[idx], r.nm_kind[idx], r.l_seq[idx], off,
+                       cig.astype(np.uint32))
+
+
+def device_sample(af: AlignmentFile, fp: FilterParameters, contig_end_exclusion: int, want_hist: bool,
+                  want_identity: bool, mask=None, device: int = 0) -> SampleResult:
+    """One BAM through a covermhip session (the only provider used outside tests)."""
+    ff = fp.flag_filters
+    filt = FilterConfig(ff.include_improper_pairs, ff.include_supplementary, ff.include_secondary)
+    records = af.records
+    prim = None
+    if fp.doing_filtering():
+        fs, fpairs = fp.filter_mode()
+        if fs and not fpairs:
+            filt.filter_single = True
+            filt.min_mapq = fp.min_mapq
+            filt.min_aligned_length = fp.min_aligned_length_single
+            filt.min_percent_identity = fp.min_percent_identity_single
+            filt.min_aligned_percent = fp.min_aligned_percent_single
+        else:
+            prim = int(((records.flag & 0x900) == 0).sum())   # filter.rs:129-131, every record read
+            records = _select(records, pair_mode_order(af, fp))
+    with Session(device, filt, contig_end_exclusion, want_hist, want_identity) as s:
+        s.set_targets(af.ref_lens, mask)
+        s.push(records)
+        stats, summ = s.finish()
+        hist = s.hist() if want_hist else None
+        if prim is None:
+            prim = int(summ.num_detected_primary_alignments)
+    return SampleResult(af.stoit_name, stats, hist, prim)
+
+
+def read_genome_definition(path: str):
+    """genome_parsing.rs:77-141: `genome<TAB>contig` lines -> (genomes, contig -> genome index)."""
+    genomes, idx, c2g = [], {}, {}
+    with open(path) as fh:
+        for line in fh:
+            line = line.rstrip("\n").rstrip("\r")
+            if not line:
+                continue
+            f = line.split("\t")
+            if len(f) != 2:
+                raise SystemExit("Unexpected line in genome definition file: %r" % line)
+            if f[0] not in idx:
+                idx[f[0]] = len(genomes); genomes.append(f[0])
+            c2g[f[1]] = idx[f[0]]
+    return genomes, c2g
+
+
+def run(mode: str, files: Sequence[AlignmentFile], methods: Optional[Sequence[str]] = None,
+        min_covered_fraction=None, contig_end_exclusion: int = 75, trim_min=5, trim_max=95,
+        output_format: str = "dense", no_zeros: bool = False, proper_pairs_only: bool = False,
+        exclude_supplementary: bool = False, include_secondary: bool = False, min_read_aligned_length: int = 0,
+        min_read_percent_identity=None, min_read_aligned_percent=None, min_mapq: int = 255,
+        min_read_aligned_length_pair: int = 0, min_read_percent_identity_pair=None,
+        min_read_aligned_percent_pair=None, separator: Optional[str] = None, single_genome: bool = False,
+        genome_definition: Optional[str] = None, device: int = 0,
+        sample_provider: Callable[..., SampleResult] = device_sample) -> str:
+    """Runs `coverm <mode>` on decoded alignment files and returns what the reference prints to stdout."""
+    if methods is None:
+        methods = ["mean"] if mode == "contig" else ["relative_abundance"]   # cli.rs:2521, 2048
+    if min_covered_fraction is None:
+        min_covered_fraction = 0 if mode == "contig" else 10                  # cli.rs:2528, 2065
+    et = EstimatorsAndTaker.generate(methods, min_covered_fraction, contig_end_exclusion, trim_min, trim_max,
+                                     output_format)
+    fp = FilterParameters(FlagFilter(not proper_pairs_only, not exclude_supplementary, include_secondary),
+                          min_read_aligned_length, parse_percentage(min_read_percent_identity),
+                          parse_percentage(min_read_aligned_percent), min_mapq, min_read_aligned_length_pair,
+                          parse_percentage(min_read_percent_identity_pair),
+                          parse_percentage(min_read_aligned_percent_pair))
+    if list(methods) == ["metabat"]:   # add_metabat_filtering_if_required, :1680-1693
+        fp.min_percent_identity_single = float(np.float32(0.97001))
+        fp.flag_filters = FlagFilter(True, True, True)
+    headers = et.headers()
+    entry_type = "Contig" if mode == "contig" else "Genome"
+    host.print_headers(et.taker, et.printer, entry_type, headers)
+    want_hist, want_identity = host.wants(et.estimators)
+    names, lens = files[0].ref_names, files[0].ref_lens
+
+    genomes = genome_of_tid = None
+    if mode == "genome" and separator is None and not single_genome:
+        if genome_definition is None:
+            raise SystemExit("genome mode over BAM files needs --separator, --single-genome or --genome-definition")
+        genomes, c2g = read_genome_definition(genome_definition)
+
+    samples = []
+    for af in files:
+        mask = None
+        if genomes is not None:
+            g_of = np.asarray([c2g.get(n, -1) for n in af.ref_names], dtype=np.int32)
+            if (g_of >= 0).sum() == 0:
+                raise SystemExit("Error: There are no found reference sequences that are a part of a genome")
+            mask = (g_of >= 0).astype(np.uint8)
+            genome_of_tid = g_of
+        samples.append(sample_provider(af, fp, contig_end_exclusion, want_hist, want_identity, mask=mask,
+                                       device=device))
+    print_zeros = not no_zeros
+    if mode == "contig":
+        rms = host.contig_coverage(names, lens, samples, et.taker, et.estimators, print_zeros)
+    elif separator is not None or single_genome:
+        rms = host.mosdepth_genome_coverage(names, lens, samples, "0" if single_genome else separator, et.taker,
+                                            print_zeros, et.estimators, single_genome)
+    else:
+        rms = host.mosdepth_genome_coverage_with_contig_names(names, lens, samples, genomes, genome_of_tid, et.taker,
+                                                              print_zeros, et.estimators)
+    host.finalise_printing(et.taker, et.printer, entry_type, headers, rms, et.columns_to_normalise, et.rpkm_column,
+                           et.tpm_column)
+    return et.taker.text()

@@ -59,7 +59,9 @@ struct cov_session {
     cov_config cfg{};
     hipStream_t stream = nullptr;
     std::string err;
-    int nt = 512;  // k_pileup workgroup size (COVERM_PILEUP_NT = 256 | 512 | 1024)
+    int tile = 4096;  // bases per k_pileup workgroup (COVERM_TILE = 4096 | 8192 | 16384)
+    int nt = 256;     // k_pileup workgroup size (COVERM_PILEUP_NT)
+    uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
 
     // targets
     uint32_t n_targets = 0;
@@ -71,7 +73,7 @@ struct cov_session {
     bool have_mask = false;
     DevBuf<DevContig> d_ctg;
     DevBuf<DevGlobal> d_glob;
-    DevBuf<uint2> d_cand;
+    DevBuf<uint4> d_desc;
 
     // record store (owned) or adopted device batch
     DevBuf<int32_t> s_tid, s_pos;
@@ -165,29 +167,36 @@ cov_status append(cov_session *s, const cov_batch *b, bool from_device) {
 void time_begin(cov_session *s, int k) { (void)hipEventRecord(s->ev[k][0], s->stream); }
 void time_end(cov_session *s, int k) { (void)hipEventRecord(s->ev[k][1], s->stream); s->k_launches[k]++; }
 
-template <int NT, bool H, bool W>
+template <int TL, int NT, bool H, bool W>
 void launch_pileup_t(cov_session *s, const PileupArgs &a, u32 grid) {
-    const size_t smem = pileup_smem_bytes(NT, H);
+    const size_t smem = pileup_smem_bytes(TL, NT, H);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup<NT, H, W>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup<TL, NT, H, W>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_pileup<NT, H, W>), dim3(grid), dim3(NT), smem, s->stream, a);
+    hipLaunchKernelGGL((k_pileup<TL, NT, H, W>), dim3(grid), dim3(NT), smem, s->stream, a);
 }
+// (tile, workgroup) geometries compiled in; session picks one (default 4096 x 256)
 template <bool H, bool W>
 void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
-    if (s->nt == 1024) launch_pileup_t<1024, H, W>(s, a, grid);
-    else if (s->nt == 256) launch_pileup_t<256, H, W>(s, a, grid);
-    else launch_pileup_t<512, H, W>(s, a, grid);
+    const int key = s->tile * 10000 + s->nt;
+    switch (key) {
+    case 16384 * 10000 + 1024: launch_pileup_t<16384, 1024, H, W>(s, a, grid); break;
+    case 16384 * 10000 + 512: launch_pileup_t<16384, 512, H, W>(s, a, grid); break;
+    case 8192 * 10000 + 512: launch_pileup_t<8192, 512, H, W>(s, a, grid); break;
+    case 8192 * 10000 + 256: launch_pileup_t<8192, 256, H, W>(s, a, grid); break;
+    case 4096 * 10000 + 128: launch_pileup_t<4096, 128, H, W>(s, a, grid); break;
+    default: launch_pileup_t<4096, 256, H, W>(s, a, grid); break;
+    }
 }
 
 PileupArgs pileup_args(cov_session *s) {
     PileupArgs a{};
-    a.tile_contig = s->d_tile_contig.p; a.tile_start = s->d_tile_start.p; a.cand = s->d_cand.p;
-    a.runs = s->d_runs.p; a.r = records_of(s); a.tlen = s->d_tlen.p; a.ctg = s->d_ctg.p; a.g = s->d_glob.p;
-    a.hist_arena = s->d_arena.p; a.excl = s->cfg.contig_end_exclusion; a.depth_out = nullptr; a.tile_base = 0;
+    a.tile_contig = s->d_tile_contig.p; a.tile_start = s->d_tile_start.p; a.desc = s->d_desc.p;
+    a.runs = s->d_runs.p; a.r = records_of(s); a.ctg = s->d_ctg.p; a.g = s->d_glob.p;
+    a.hist_arena = s->d_arena.p; a.excl = s->cfg.contig_end_exclusion; a.depth_out = nullptr; a.tile_base = 0; a.ablate = s->ablate;
     return a;
 }
 
@@ -214,10 +223,16 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return COV_ERR_HIP; }
     cov_session *s = new cov_session();
     s->cfg = *cfg;
-    if (const char *nt = getenv("COVERM_PILEUP_NT")) {
-        int v = atoi(nt);
-        if (v == 256 || v == 512 || v == 1024) s->nt = v;
+    {
+        const char *tl = getenv("COVERM_TILE"), *nt = getenv("COVERM_PILEUP_NT");
+        int t = tl ? atoi(tl) : 4096, n = nt ? atoi(nt) : 0;
+        if (t != 4096 && t != 8192 && t != 16384) t = 4096;
+        if (t == 16384) n = (n == 1024) ? 1024 : 512;
+        else if (t == 8192) n = (n == 256) ? 256 : 512;
+        else n = (n == 128) ? 128 : 256;
+        s->tile = t; s->nt = n;
     }
+    if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
     e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete s; return COV_ERR_HIP; }
     for (int k = 0; k < COV_K_COUNT; k++)
@@ -233,7 +248,7 @@ void cov_destroy(cov_session *s) {
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->d_tlen.release(); s->d_tile_contig.release(); s->d_tile_start.release(); s->d_mask.release();
-    s->d_ctg.release(); s->d_glob.release(); s->d_cand.release();
+    s->d_ctg.release(); s->d_glob.release(); s->d_desc.release();
     s->s_tid.release(); s->s_pos.release(); s->s_flag.release(); s->s_mapq.release(); s->s_nmk.release();
     s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
     s->d_runs.release(); s->d_ident.release(); s->d_arena.release(); s->d_chist.release(); s->d_depth.release();
@@ -254,7 +269,7 @@ cov_status cov_set_targets(cov_session *s, uint32_t n_targets, const uint64_t *t
         if (target_len[c] > 0x7fffffffull) { s->err = "target length exceeds BAM's i32 range"; return COV_ERR_INVALID_ARG; }
         s->h_tlen[c] = (uint32_t)target_len[c];
         s->h_tile_first[c] = (uint32_t)nt;
-        nt += (target_len[c] + TILE - 1) / TILE;
+        nt += (target_len[c] + (uint64_t)s->tile - 1) / (uint64_t)s->tile;
     }
     if (nt >= 0x7fffffffull) { s->err = "too many tiles"; return COV_ERR_INVALID_ARG; }
     s->h_tile_first[n_targets] = (uint32_t)nt;
@@ -262,12 +277,12 @@ cov_status cov_set_targets(cov_session *s, uint32_t n_targets, const uint64_t *t
     std::vector<u32> tc(nt), ts(nt);
     for (uint32_t c = 0; c < n_targets; c++) {
         u32 k = s->h_tile_first[c];
-        for (uint64_t p = 0; p < target_len[c]; p += TILE, k++) { tc[k] = c; ts[k] = (u32)p; }
+        for (uint64_t p = 0; p < target_len[c]; p += (uint64_t)s->tile, k++) { tc[k] = c; ts[k] = (u32)p; }
     }
     HIPCHK(s->d_tlen.reserve(std::max<size_t>(1, n_targets), s->stream));
     HIPCHK(s->d_tile_contig.reserve(std::max<size_t>(1, nt), s->stream));
     HIPCHK(s->d_tile_start.reserve(std::max<size_t>(1, nt), s->stream));
-    HIPCHK(s->d_cand.reserve(std::max<size_t>(1, nt), s->stream));
+    HIPCHK(s->d_desc.reserve(std::max<size_t>(1, nt), s->stream));
     HIPCHK(s->d_ctg.reserve(std::max<size_t>(1, n_targets), s->stream));
     if (n_targets) HIPCHK(hipMemcpyAsync(s->d_tlen.p, s->h_tlen.data(), (size_t)n_targets * 4, hipMemcpyHostToDevice, s->stream));
     if (nt) {
@@ -347,7 +362,7 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
     if (want_id) HIPCHK(s->d_ident.reserve(std::max<size_t>(1, R), st));
     if (want_hist) HIPCHK(s->d_arena.reserve((size_t)R + nT + 1, st));
 
-    hipLaunchKernelGGL(k_init, dim3((std::max(nT, 1u) + 255) / 256), dim3(256), 0, st, s->d_ctg.p, nT, s->d_glob.p);
+    hipLaunchKernelGGL(k_init, dim3((std::max(nT, COUNTER_SLOTS * 8) + 255) / 256), dim3(256), 0, st, s->d_ctg.p, nT, s->d_glob.p);
     HIPCHK(hipGetLastError());
 
     FilterCfg f{};
@@ -361,10 +376,10 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
     if (R) {
         time_begin(s, COV_K_PREP);
         if (want_id)
-            hipLaunchKernelGGL((k_prep<true>), dim3((R + 255) / 256), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
+            hipLaunchKernelGGL((k_prep<true>), dim3((R + PREP_CHUNK - 1) / PREP_CHUNK), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
                                s->d_ctg.p, s->d_glob.p, s->d_runs.p, s->d_ident.p);
         else
-            hipLaunchKernelGGL((k_prep<false>), dim3((R + 255) / 256), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
+            hipLaunchKernelGGL((k_prep<false>), dim3((R + PREP_CHUNK - 1) / PREP_CHUNK), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
                                s->d_ctg.p, s->d_glob.p, s->d_runs.p, (double *)nullptr);
         time_end(s, COV_K_PREP);
         HIPCHK(hipGetLastError());
@@ -373,10 +388,10 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
         time_begin(s, COV_K_RANGES);
         if (want_hist)
             hipLaunchKernelGGL((k_ranges<true>), dim3((s->n_tiles + 255) / 256), dim3(256), 0, st, s->d_tile_contig.p,
-                               s->d_tile_start.p, s->n_tiles, r.pos, mask, s->d_ctg.p, s->d_cand.p);
+                               s->d_tile_start.p, s->n_tiles, (u32)s->tile, r.pos, s->d_tlen.p, mask, s->d_ctg.p, s->d_desc.p);
         else
             hipLaunchKernelGGL((k_ranges<false>), dim3((s->n_tiles + 255) / 256), dim3(256), 0, st, s->d_tile_contig.p,
-                               s->d_tile_start.p, s->n_tiles, r.pos, mask, s->d_ctg.p, s->d_cand.p);
+                               s->d_tile_start.p, s->n_tiles, (u32)s->tile, r.pos, s->d_tlen.p, mask, s->d_ctg.p, s->d_desc.p);
         time_end(s, COV_K_RANGES);
         HIPCHK(hipGetLastError());
         if (want_hist) {
@@ -470,9 +485,11 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
         if (want_hist) { o.hist_len = C.hist_len; o.hist_off = C.chist_off; hist_total += C.hist_len; }
     }
     if (summary) {
-        summary->num_detected_primary_alignments = s->h_glob.n_primary_all;
+        uint64_t prim = 0, cons = 0;
+        for (u32 k = 0; k < COUNTER_SLOTS * 8; k++) { prim += s->h_glob.prim_slots[k]; cons += s->h_glob.cons_slots[k]; }
+        summary->num_detected_primary_alignments = prim;
         summary->n_records = R;
-        summary->n_considered = s->h_glob.n_considered;
+        summary->n_considered = cons;
         summary->hist_total = hist_total;
     }
     s->finished = true;

@@ -1,0 +1,723 @@
+// Host side above the covermhip ABI (include/coverm_host.h): estimator finalisation from integer
+// statistics, the three scan drivers, CoverageTaker implementations and CoveragePrinter.
+// Pure C++17, no HIP: this is where the reference's Rust `calculate_coverage` / takers / printers sit.
+#include "../../include/coverm_host.h"
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <optional>
+#include <string>
+#include <string_view>
+#include <vector>
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+namespace {
+
+thread_local std::string g_err;
+
+// ------------------------------------------------------------------ Rust float Display
+template <typename F>
+size_t fmt_float(F v, char *buf, size_t cap) {
+    std::string s;
+    if (std::isnan(v)) s = "NaN";
+    else if (std::isinf(v)) s = v > 0 ? "inf" : "-inf";
+    else if (v == 0) s = std::signbit(v) ? "-0" : "0";
+    else {
+        char tmp[512];
+        auto r = std::to_chars(tmp, tmp + sizeof tmp, v, std::chars_format::fixed);  // shortest round-trip
+        s.assign(tmp, r.ptr);
+    }
+    if (cap) {
+        size_t n = std::min(cap - 1, s.size());
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size();
+}
+std::string f32s(float v) { char b[512]; fmt_float(v, b, sizeof b); return b; }
+std::string f64s(double v) { char b[512]; fmt_float(v, b, sizeof b); return b; }
+
+// Rust `x as usize` for f32: saturating, NaN -> 0
+u64 f32_to_usize(float x) {
+    if (!(x == x) || x <= 0.0f) return 0;
+    if (x >= 18446744073709551616.0f) return std::numeric_limits<u64>::max();
+    return (u64)x;
+}
+
+// ------------------------------------------------------------------ entry accumulator
+// What the estimators of one entry (contig or genome) would hold after add_contig over its contigs
+// (estimators.rs:366-528), expressed in the integer statistics the device returns.
+struct EntryAcc {
+    u64 win_len = 0, win_sum_d = 0, win_sum_d2 = 0, win_covered = 0;
+    u64 full_len = 0, full_covered = 0, n_reads = 0, mismatches = 0;
+    u32 win_min_d = 0xffffffffu;
+    double sum_identity = 0.0;
+    std::vector<u64> hist;  // merged counts; hist.size() == counts.len()
+    void reset() { *this = EntryAcc(); }
+    void add_contig(const cov_contig_stats &s, u64 L, u64 excl, u64 n, double identity, const u64 *h) {
+        n_reads += n;
+        mismatches += s.sum_nm - s.sum_indel;   // total_edit_distance - total_indels (u64 wrapping, contig.rs:59)
+        sum_identity += identity;
+        full_len += L;
+        full_covered += s.full_covered;
+        if (2 * excl < L) {                      // estimators.rs:386-392, 436-445
+            win_len += L - 2 * excl;
+            win_sum_d += s.win_sum_d; win_sum_d2 += s.win_sum_d2; win_covered += s.win_covered;
+            win_min_d = std::min(win_min_d, s.win_min_d);
+            if (h && s.hist_len) {
+                if (hist.size() < s.hist_len) hist.resize(s.hist_len, 0);
+                for (u32 d = 0; d < s.hist_len; d++) hist[d] += h[s.hist_off + d];
+            } else if (!h) {
+                // no histogram requested: remember only how long counts would be
+                if (hist_len_only < (u64)s.win_max_d + 1) hist_len_only = (u64)s.win_max_d + 1;
+            }
+        }
+    }
+    // same, from an explicit entry (unit tests)
+    u64 hist_len_only = 0;
+};
+
+u64 unobserved_bases(const u64 *u, size_t n, u64 excl) {  // estimators.rs:226-242
+    u64 s = 0, e = 2 * excl;
+    for (size_t i = 0; i < n; i++) s += u[i] < e ? u[i] : u[i] - e;
+    return s;
+}
+u64 sum_u64(const u64 *u, size_t n) { u64 s = 0; for (size_t i = 0; i < n; i++) s += u[i]; return s; }
+
+// estimators.rs:530-839, every branch in the reference's operation order
+float calculate(const covh_estimator &e, const EntryAcc &a, const u64 *unobs, size_t n_unobs) {
+    const float minfrac = e.min_fraction_covered_bases;
+    switch (e.kind) {
+    case COVH_MEAN: {
+        const u64 T = a.win_len + unobserved_bases(unobs, n_unobs, e.contig_end_exclusion);
+        if (T == 0 || ((float)a.win_covered / (float)T) < minfrac) return 0.0f;
+        const float num = e.exclude_mismatches ? (float)(a.win_sum_d - a.mismatches) : (float)a.win_sum_d;
+        return num / (float)T;
+    }
+    case COVH_TRIMMED_MEAN: {
+        const u64 U = unobserved_bases(unobs, n_unobs, e.contig_end_exclusion);
+        const u64 T = a.win_len + U;
+        if (T == 0) return 0.0f;
+        if (((float)a.win_covered / (float)T) < minfrac) return 0.0f;
+        const u64 min_index = f32_to_usize(std::floor(e.trim_min * (float)T));
+        const u64 max_index = f32_to_usize(std::ceil(e.trim_max * (float)T));
+        if (a.win_covered == 0) return 0.0f;
+        u64 acc = 0, total = 0;
+        bool started = false;
+        for (size_t i = 0; i < a.hist.size(); i++) {
+            const u64 n = a.hist[i] + (i == 0 ? U : 0);  // counts[0] += unobserved (:596)
+            acc += n;
+            if (acc >= min_index) {
+                if (started) {
+                    if (acc > max_index) {
+                        const u64 excess = acc - n;
+                        total += (max_index >= excess ? max_index - excess + 1 : 0) * (u64)i;
+                        break;
+                    } else total += n * (u64)i;
+                } else if (acc > max_index) { total = (max_index - min_index + 1) * (u64)i; started = true; }  // no break (:626-629)
+                else if (acc < min_index) {}
+                else { total = (acc - min_index + 1) * (u64)i; started = true; }
+            }
+        }
+        return (float)total / (float)(max_index - min_index);
+    }
+    case COVH_PILEUP_COUNTS: {
+        if (a.win_len == 0) return 0.0f;
+        const u64 T = a.win_len + unobserved_bases(unobs, n_unobs, e.contig_end_exclusion);
+        if (((float)a.win_covered / (float)T) < minfrac) return 0.0f;
+        return (float)(T - a.win_covered + 1);
+    }
+    case COVH_COVERED_FRACTION: {
+        const u64 T = a.full_len + sum_u64(unobs, n_unobs);
+        if (T == 0 || ((float)a.full_covered / (float)T) < minfrac) return 0.0f;
+        return (float)a.full_covered / (float)T;
+    }
+    case COVH_COVERED_BASES: {
+        const u64 T = a.full_len + sum_u64(unobs, n_unobs);
+        if (T == 0 || ((float)a.full_covered / (float)T) < minfrac) return 0.0f;
+        return (float)a.full_covered;
+    }
+    case COVH_RPKM: {
+        const u64 T = a.full_len + sum_u64(unobs, n_unobs);
+        if (T == 0 || ((float)a.full_covered / (float)T) < minfrac) return 0.0f;
+        return (float)(a.n_reads * 1000000000ull) / (float)T;
+    }
+    case COVH_TPM: {
+        const u64 T = a.full_len + sum_u64(unobs, n_unobs);
+        if (T == 0 || ((float)a.full_covered / (float)T) < minfrac) return 0.0f;
+        return (float)std::exp(std::log((double)a.n_reads) - std::log((double)T));
+    }
+    case COVH_VARIANCE: {
+        const u64 U = unobserved_bases(unobs, n_unobs, e.contig_end_exclusion);
+        const u64 T = a.win_len + U;
+        if (T == 0) return 0.0f;
+        // counts.is_empty()  <=>  no contig contributed a window position  <=>  win_len == 0
+        if (((float)a.win_covered / (float)T) < minfrac || T < 3 || a.win_len == 0) return 0.0f;
+        // shifted sums: k = lowest occupied depth (0 as soon as unobserved bases land in counts[0]); the
+        // reference's ex = sum (x-k) n and ex2 = sum (x-k)^2 n over the histogram are these integers
+        const u64 k = U > 0 ? 0 : a.win_min_d;
+        const u64 N = a.win_len + U;
+        const u64 ex = a.win_sum_d - k * N;
+        const u64 ex2 = a.win_sum_d2 - 2 * k * a.win_sum_d + k * k * N;
+        return ((float)ex2 - (float)(ex * ex) / (float)T) / (float)(T - 1);
+    }
+    case COVH_LENGTH: return (float)(a.full_len + sum_u64(unobs, n_unobs));
+    case COVH_READ_COUNT: return (float)a.n_reads;
+    case COVH_READS_PER_BASE: return (float)a.n_reads / (float)(a.full_len + sum_u64(unobs, n_unobs));
+    case COVH_ANIR: return a.n_reads == 0 ? 0.0f : (float)(a.sum_identity / (double)a.n_reads);
+    }
+    return 0.0f;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ takers (coverage_takers.rs)
+struct covh_taker {
+    int kind;
+    size_t num_coverages;
+    std::string text;
+    std::string cur_stoit, cur_entry_name;
+    // cached
+    std::vector<std::string> stoit_names;
+    std::vector<std::optional<std::string>> entry_names;
+    std::vector<std::vector<std::pair<size_t, float>>> coverages;
+    size_t cur_stoit_i = 0, cur_entry_i = 0;
+    bool mismatch = false;
+
+    void start_stoit(const std::string &n) {
+        if (kind == COVH_TAKER_CACHED) { stoit_names.push_back(n); coverages.emplace_back(); cur_stoit_i = stoit_names.size() - 1; }
+        else cur_stoit = n;
+    }
+    void start_entry(size_t id, std::string_view name) {
+        if (kind == COVH_TAKER_STREAM) { text += cur_stoit; text += '\t'; text.append(name); }
+        else if (kind == COVH_TAKER_PILEUP) cur_entry_name.assign(name);
+        else {
+            if (id >= entry_names.size()) entry_names.resize(id + 1);
+            if (!entry_names[id]) entry_names[id] = std::string(name);
+            if (*entry_names[id] != name) mismatch = true;  // coverage_takers.rs:140-148 (process::exit(1))
+            cur_entry_i = id;
+        }
+    }
+    void add_single_coverage(float c) {
+        if (kind == COVH_TAKER_STREAM) { text += '\t'; text += (c == 0.0f) ? std::string("0") : f32s(c); }
+        else if (kind == COVH_TAKER_CACHED) coverages[cur_stoit_i].emplace_back(cur_entry_i, c);
+    }
+    void add_coverage_entry(u64 num_reads, u64 num_bases) {
+        if (kind == COVH_TAKER_PILEUP) {
+            text += cur_stoit; text += '\t'; text += cur_entry_name; text += '\t';
+            text += std::to_string(num_reads); text += '\t'; text += std::to_string(num_bases); text += '\n';
+        }
+    }
+    void finish_entry() { if (kind == COVH_TAKER_STREAM) text += '\n'; }
+};
+
+namespace {
+
+struct EntryAndCoverages { size_t entry_index, stoit_index; std::vector<float> coverages; };
+
+// CoverageTakerTypeIterator, coverage_takers.rs:265-377
+std::vector<EntryAndCoverages> iterate_cached(const covh_taker &t) {
+    std::vector<EntryAndCoverages> out;
+    const size_t ns = t.stoit_names.size(), nc = t.num_coverages;
+    if (ns == 0) return out;
+    std::vector<size_t> nxt(ns, 0);
+    size_t cur = 0;
+    std::optional<size_t> last;
+    while (cur <= ns) {
+        std::optional<size_t> lowest;
+        for (size_t si = 0; si < ns; si++) {
+            if (nxt[si] < t.coverages[si].size()) {
+                const size_t ei = t.coverages[si][nxt[si]].first;
+                if (!last || ei > *last) { if (!lowest || ei < *lowest) lowest = ei; }
+            }
+        }
+        if (lowest) {
+            const size_t chosen = nxt[cur];
+            const auto &lst = t.coverages[cur];
+            EntryAndCoverages e{*lowest, cur, {}};
+            if (chosen >= lst.size() || lst[chosen].first != *lowest) e.coverages.assign(nc, 0.0f);
+            else for (size_t k = 0; k < nc; k++) e.coverages.push_back(lst[chosen + k].second);
+            for (size_t si = 0; si < ns; si++)
+                if (t.coverages[si].size() > nxt[si] && t.coverages[si][nxt[si]].first == *lowest) nxt[si] += nc;
+            last = *lowest;
+            out.push_back(std::move(e));
+        } else {
+            cur++;
+            if (cur >= ns) break;
+            std::fill(nxt.begin(), nxt.end(), 0);
+            last.reset();
+        }
+    }
+    return out;
+}
+
+void print_coverage(const covh_estimator &e, const EntryAcc &a, float coverage, covh_taker &t) {  // estimators.rs:936-969
+    if (e.kind != COVH_PILEUP_COUNTS) { t.add_single_coverage(coverage); return; }
+    for (size_t i = 0; i < a.hist.size(); i++) {
+        u64 cov;
+        if (i == 0) { const u64 c = f32_to_usize(std::floor(coverage)); cov = c == 0 ? 0 : c - 1; }
+        else cov = a.hist[i];
+        t.add_coverage_entry(i, cov);
+    }
+}
+void print_zero_coverage(const covh_estimator &e, covh_taker &t, u64 entry_length) {  // estimators.rs:971-991
+    if (e.kind == COVH_PILEUP_COUNTS) return;
+    t.add_single_coverage(e.kind == COVH_LENGTH ? (float)entry_length : 0.0f);
+}
+
+std::string_view target_name(const covh_header *h, u32 tid) {
+    return std::string_view(h->names + h->name_off[tid], h->name_off[tid + 1] - h->name_off[tid]);
+}
+
+bool check_excl(const covh_estimator *est, size_t n) {
+    bool have = false; u64 x = 0;
+    for (size_t i = 0; i < n; i++) {
+        const int k = est[i].kind;
+        if (k == COVH_MEAN || k == COVH_TRIMMED_MEAN || k == COVH_PILEUP_COUNTS || k == COVH_VARIANCE) {
+            if (have && x != est[i].contig_end_exclusion) return false;
+            have = true; x = est[i].contig_end_exclusion;
+        }
+    }
+    return true;
+}
+u64 session_excl(const covh_estimator *est, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        const int k = est[i].kind;
+        if (k == COVH_MEAN || k == COVH_TRIMMED_MEAN || k == COVH_PILEUP_COUNTS || k == COVH_VARIANCE)
+            return est[i].contig_end_exclusion;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *covh_last_error(void) { return g_err.c_str(); }
+size_t covh_format_f32(float v, char *buf, size_t cap) { return fmt_float(v, buf, cap); }
+size_t covh_format_f64(double v, char *buf, size_t cap) { return fmt_float(v, buf, cap); }
+
+covh_taker *covh_taker_new(int kind, size_t num_coverages) {
+    covh_taker *t = new covh_taker();
+    t->kind = kind; t->num_coverages = num_coverages;
+    return t;
+}
+void covh_taker_free(covh_taker *t) { delete t; }
+const char *covh_taker_text(const covh_taker *t, size_t *len) { if (len) *len = t->text.size(); return t->text.c_str(); }
+void covh_taker_clear_text(covh_taker *t) { t->text.clear(); }
+
+uint32_t covh_wants(const covh_estimator *est, size_t n_est) {
+    uint32_t w = 0;
+    for (size_t i = 0; i < n_est; i++) {
+        if (est[i].kind == COVH_TRIMMED_MEAN || est[i].kind == COVH_PILEUP_COUNTS) w |= COV_WANT_HIST;
+        if (est[i].kind == COVH_ANIR) w |= COV_WANT_IDENTITY;
+    }
+    return w;
+}
+
+float covh_calculate_coverage(const covh_estimator *e, const covh_entry *en, const uint64_t *unobs, size_t n) {
+    EntryAcc a;
+    a.win_len = en->win_len; a.win_sum_d = en->win_sum_d; a.win_sum_d2 = en->win_sum_d2; a.win_covered = en->win_covered;
+    a.full_len = en->full_len; a.full_covered = en->full_covered; a.n_reads = en->n_reads; a.mismatches = en->mismatches;
+    a.win_min_d = en->win_min_d; a.sum_identity = en->sum_identity;
+    if (en->hist) a.hist.assign(en->hist, en->hist + en->hist_len);
+    return calculate(*e, a, unobs, n);
+}
+
+// ------------------------------------------------------------------ contig.rs:13-253
+int covh_contig_coverage(const covh_header *h, const covh_sample *samples, size_t n_samples, covh_taker *taker,
+                         const covh_estimator *est, size_t n_est, int print_zero, covh_reads_mapped *rm_out) {
+    if (!check_excl(est, n_est)) { g_err = "estimators disagree on contig_end_exclusion"; return COV_ERR_INVALID_ARG; }
+    const u64 excl = session_excl(est, n_est);
+    const u64 zero = 0;
+    std::vector<float> cov(n_est);
+    for (size_t si = 0; si < n_samples; si++) {
+        const covh_sample &S = samples[si];
+        taker->start_stoit(S.stoit_name);
+        u64 mapped_total = 0;
+        int64_t prev = -1;
+        auto zero_rows = [&](int64_t from, int64_t to) {   // print_previous_zero_coverage_contigs, :255-277
+            for (int64_t t = from + 1; t < to; t++) {
+                taker->start_entry((size_t)t, target_name(h, (u32)t));
+                for (size_t k = 0; k < n_est; k++) print_zero_coverage(est[k], *taker, h->target_len[t]);
+                taker->finish_entry();
+            }
+        };
+        EntryAcc acc;
+        for (u32 t = 0; t < h->n_targets; t++) {
+            const cov_contig_stats &s = S.stats[t];
+            if (s.n_pass == 0) continue;   // no considered record: the scan never allocated this contig
+            if (print_zero) zero_rows(prev, t);
+            acc.reset();
+            acc.add_contig(s, h->target_len[t], excl, s.n_primary, s.sum_identity_primary, S.hist);
+            bool nonzero = false;
+            for (size_t k = 0; k < n_est; k++) { cov[k] = calculate(est[k], acc, &zero, 1); nonzero |= cov[k] > 0.0f; }
+            if (nonzero) mapped_total += s.n_primary;           // :67-72
+            if (print_zero || nonzero) {
+                taker->start_entry(t, target_name(h, t));
+                for (size_t k = 0; k < n_est; k++) print_coverage(est[k], acc, cov[k], *taker);
+                taker->finish_entry();
+            }
+            prev = t;
+        }
+        if (print_zero) zero_rows(prev, h->n_targets);
+        if (rm_out) { rm_out[si].num_mapped_reads = mapped_total; rm_out[si].num_reads = S.num_detected_primary_alignments; }
+    }
+    return COV_OK;
+}
+
+// ------------------------------------------------------------------ genome.rs:17-322
+int covh_genome_coverage_with_contig_names(const covh_header *h, const covh_sample *samples, size_t n_samples,
+                                           const int32_t *genome_of_tid, const char *const *genome_names,
+                                           size_t n_genomes, covh_taker *taker, int print_zero,
+                                           const covh_estimator *est, size_t n_est, covh_reads_mapped *rm_out) {
+    if (!check_excl(est, n_est)) { g_err = "estimators disagree on contig_end_exclusion"; return COV_ERR_INVALID_ARG; }
+    const u64 excl = session_excl(est, n_est);
+    std::vector<std::vector<u32>> refs(n_genomes);
+    for (u32 t = 0; t < h->n_targets; t++) if (genome_of_tid[t] >= 0) refs[genome_of_tid[t]].push_back(t);
+    std::vector<float> cov(n_est);
+    for (size_t si = 0; si < n_samples; si++) {
+        const covh_sample &S = samples[si];
+        taker->start_stoit(S.stoit_name);
+        std::vector<EntryAcc> acc(n_genomes);
+        std::vector<u64> reads_in_genome(n_genomes, 0);
+        bool any_seen = false;
+        for (u32 t = 0; t < h->n_targets; t++) {
+            const cov_contig_stats &s = S.stats[t];
+            if (s.n_pass == 0) continue;
+            any_seen = true;
+            const int32_t g = genome_of_tid[t];
+            if (g < 0) continue;                               // :170-171
+            reads_in_genome[g] += s.n_pass;                    // :173-174 every record passing the flag filter
+            acc[g].add_contig(s, h->target_len[t], excl, s.n_pass, s.sum_identity_nonsupp, S.hist);
+        }
+        u64 mapped_total = 0;
+        if (!any_seen && S.num_detected_primary_alignments == 0) {
+            // warn only (:230-234)
+        } else {
+            std::vector<u64> unobs;
+            for (size_t gi = 0; gi < n_genomes; gi++) {
+                unobs.clear();
+                u64 genome_len = 0;
+                for (u32 t : refs[gi]) { genome_len += h->target_len[t]; if (S.stats[t].n_pass == 0) unobs.push_back(h->target_len[t]); }
+                bool nonzero = false;
+                for (size_t k = 0; k < n_est; k++) { cov[k] = calculate(est[k], acc[gi], unobs.data(), unobs.size()); nonzero |= cov[k] > 0.0f; }
+                if (nonzero) mapped_total += reads_in_genome[gi];
+                if (print_zero || nonzero) {
+                    taker->start_entry(gi, genome_names[gi]);
+                    for (size_t k = 0; k < n_est; k++) {
+                        if (cov[k] > 0.0f) print_coverage(est[k], acc[gi], cov[k], *taker);
+                        else print_zero_coverage(est[k], *taker, genome_len);
+                    }
+                    taker->finish_entry();
+                }
+            }
+        }
+        if (rm_out) { rm_out[si].num_mapped_reads = mapped_total; rm_out[si].num_reads = S.num_detected_primary_alignments; }
+    }
+    return COV_OK;
+}
+
+// ------------------------------------------------------------------ genome.rs:419-929
+namespace {
+struct SepCtx {
+    const covh_header *h; uint8_t split; bool single; bool err = false;
+    std::string_view genome(u32 tid) {   // extract_genome, :799-805
+        std::string_view n = target_name(h, tid);
+        size_t p = n.find((char)split);
+        if (p == std::string_view::npos) { err = true; return n; }
+        return n.substr(0, p);
+    }
+};
+struct Unobs { std::vector<u64> v; size_t first_tid = 0; };
+
+void fill_backwards(SepCtx &c, u32 current_tid, std::string_view target, Unobs &u) {   // :807-853
+    u.v.clear();
+    if (current_tid == 0) { u.first_tid = 0; return; }
+    u32 my = current_tid - 1;
+    while (c.single || c.genome(my) == target) {
+        u.v.push_back(c.h->target_len[my]);
+        if (my == 0) { u.first_tid = 0; return; }
+        my--;
+    }
+    u.first_tid = (size_t)my + 1;
+}
+void fill_backwards_to_last(SepCtx &c, u32 current_tid, u32 last_tid, std::string_view target, Unobs &u) {  // :477-499
+    if (current_tid == 0) return;
+    for (u32 my = last_tid + 1; my < current_tid; my++) {
+        if (c.single || c.genome(my) == target) u.v.push_back(c.h->target_len[my]); else break;
+    }
+}
+void fill_forwards(SepCtx &c, u32 current_tid, const std::optional<std::string_view> &target, Unobs &u) {   // :448-475
+    if (!target) return;
+    for (u32 my = current_tid + 1; my < c.h->n_targets; my++) {
+        if (c.single || c.genome(my) == *target) u.v.push_back(c.h->target_len[my]); else break;
+    }
+}
+// print_previous_zero_coverage_genomes2, :859-929
+void zero_genomes2(SepCtx &c, const std::optional<std::string_view> &last_genome, std::string_view current_genome,
+                   u32 current_tid, const covh_estimator *est, size_t n_est, covh_taker &t) {
+    std::string_view my_current = current_genome;
+    u32 tid = current_tid;
+    std::vector<std::string_view> names; std::vector<size_t> first_tids; std::vector<u64> lens;
+    u64 unobserved = 0;
+    std::optional<u32> last_first;
+    for (;;) {
+        std::string_view g = c.genome(tid);
+        if (last_genome && g == *last_genome) break;
+        else if (g != my_current) {
+            if (last_first) {
+                if (!last_genome || g != *last_genome) { first_tids.push_back(*last_first); names.push_back(my_current); lens.push_back(unobserved); }
+            }
+            my_current = g; last_first = tid; unobserved = c.h->target_len[tid];
+        } else if (g != current_genome) { last_first = tid; unobserved += c.h->target_len[tid]; }
+        if (tid == 0) break;
+        tid--;
+    }
+    if (last_first) { first_tids.push_back(*last_first); names.push_back(my_current); lens.push_back(unobserved); }
+    for (size_t i = names.size(); i-- > 0;) {
+        t.start_entry(first_tids[i], names[i]);
+        for (size_t k = 0; k < n_est; k++) print_zero_coverage(est[k], t, lens[i]);
+        t.finish_entry();
+    }
+}
+}  // namespace
+
+int covh_genome_coverage_separator(const covh_header *h, const covh_sample *samples, size_t n_samples,
+                                   uint8_t split_char, covh_taker *taker, int print_zero,
+                                   const covh_estimator *est, size_t n_est, int single_genome,
+                                   covh_reads_mapped *rm_out) {
+    if (!check_excl(est, n_est)) { g_err = "estimators disagree on contig_end_exclusion"; return COV_ERR_INVALID_ARG; }
+    const u64 excl = session_excl(est, n_est);
+    std::vector<float> cov(n_est);
+    for (size_t si = 0; si < n_samples; si++) {
+        const covh_sample &S = samples[si];
+        taker->start_stoit(S.stoit_name);
+        SepCtx cx{h, split_char, single_genome != 0};
+        EntryAcc acc;
+        Unobs u;
+        bool doing_first = true;
+        u32 last_tid = 0;
+        std::optional<std::string_view> last_genome;
+        u64 mapped_total = 0, n_in_genome = 0;
+        auto add_last_contig = [&]() {
+            // estimator.add_contig(&ups_and_downs, ...) for the contig the scan was in (last_tid); before the
+            // first mapped record ups_and_downs is an empty Vec, which adds nothing
+            if (doing_first) return;
+            const cov_contig_stats &s = S.stats[last_tid];
+            acc.add_contig(s, h->target_len[last_tid], excl, s.n_nonsupp, s.sum_identity_primary, S.hist);
+        };
+        // print_last_genomes, :331-416
+        auto print_last_genomes = [&](std::string_view current_genome, u32 tid_to_print_zeros_to, bool had_contig) -> bool {
+            if (had_contig) add_last_contig();
+            bool positive = false;
+            for (size_t k = 0; k < n_est; k++) { cov[k] = calculate(est[k], acc, u.v.data(), u.v.size()); positive |= cov[k] > 0.0f; }
+            if ((print_zero || positive) && last_genome) {
+                taker->start_entry(u.first_tid, *last_genome);
+                for (size_t k = 0; k < n_est; k++) {
+                    if (cov[k] > 0.0f) print_coverage(est[k], acc, cov[k], *taker);
+                    else print_zero_coverage(est[k], *taker, 9);
+                }
+                taker->finish_entry();
+            }
+            acc.reset();
+            if (print_zero && !cx.single) zero_genomes2(cx, last_genome, current_genome, tid_to_print_zeros_to, est, n_est, *taker);
+            return positive;
+        };
+        for (u32 tid = 0; tid < h->n_targets; tid++) {
+            const cov_contig_stats &s = S.stats[tid];
+            if (s.n_pass == 0) continue;
+            std::string_view current_genome = cx.single ? std::string_view() : cx.genome(tid);
+            if (cx.err) { g_err = "Contig name does not contain split symbol, so cannot determine which genome it belongs to"; return COV_ERR_INVALID_ARG; }
+            if (doing_first) {
+                acc.reset();
+                fill_backwards(cx, tid, current_genome, u);
+                last_genome = current_genome;
+                if (print_zero && !cx.single) zero_genomes2(cx, std::nullopt, current_genome, tid, est, n_est, *taker);
+                doing_first = false;
+            } else if (current_genome == *last_genome) {
+                add_last_contig();
+                fill_backwards_to_last(cx, tid, last_tid, current_genome, u);
+            } else {
+                fill_backwards_to_last(cx, tid, last_tid, *last_genome, u);
+                if (print_last_genomes(current_genome, tid, true)) mapped_total += n_in_genome;
+                n_in_genome = 0;
+                last_genome = current_genome;
+                fill_backwards(cx, tid, current_genome, u);
+            }
+            if (cx.err) { g_err = "Contig name does not contain split symbol, so cannot determine which genome it belongs to"; return COV_ERR_INVALID_ARG; }
+            last_tid = tid;
+            n_in_genome += s.n_nonsupp;    // :677-682
+        }
+        if (doing_first && S.num_detected_primary_alignments == 0) {
+            // warn only (:731-735)
+        } else {
+            static const char g1[] = "genome1";
+            const bool had_contig = !doing_first;
+            if (cx.single) last_genome = std::string_view(g1, 7);   // :739-741
+            fill_forwards(cx, last_tid, last_genome, u);
+            if (print_last_genomes(std::string_view(), h->n_targets - 1, had_contig)) mapped_total += n_in_genome;
+            if (cx.err) { g_err = "Contig name does not contain split symbol, so cannot determine which genome it belongs to"; return COV_ERR_INVALID_ARG; }
+        }
+        if (rm_out) { rm_out[si].num_mapped_reads = mapped_total; rm_out[si].num_reads = S.num_detected_primary_alignments; }
+    }
+    return COV_OK;
+}
+
+// ------------------------------------------------------------------ coverage_printer.rs
+void covh_print_headers(covh_taker *t, int printer, const char *entry_type, const char *const *headers, size_t n) {
+    if (printer == 0 || printer == 1) {   // :130-137
+        t->text += "Sample\t"; t->text += entry_type;
+        for (size_t i = 0; i < n; i++) { t->text += '\t'; t->text += headers[i]; }
+        t->text += '\n';
+    }
+}
+
+namespace {
+bool contains(const int64_t *v, size_t n, size_t x) { for (size_t i = 0; i < n; i++) if ((size_t)v[i] == x) return true; return false; }
+std::string rstrip_cr(const std::string &s) { size_t n = s.size(); while (n && s[n - 1] == '\r') n--; return s.substr(0, n); }
+double round4(double v) { return std::round(v) / 10000.0; }  // (x * 10000.0).round() / 10000.0 with x*10000 passed in
+
+void print_sparse(covh_taker &t, const covh_reads_mapped *rm, const int64_t *norm, size_t n_norm, int64_t rpkm_col, int64_t tpm_col) {
+    const size_t nc = t.num_coverages;
+    size_t extra_cols = 0;
+    for (auto &n : t.entry_names) if (n) { extra_cols = std::count(n->begin(), n->end(), '\t'); break; }
+    auto all = iterate_cached(t);
+    std::string &o = t.text;
+    auto print_previous = [&](const std::vector<const EntryAndCoverages *> &rows, size_t si) {
+        std::vector<std::optional<float>> mult(nc), totals(nc);
+        for (size_t k = 0; k < n_norm; k++) {
+            const size_t i = (size_t)norm[k];
+            float tot = 0.0f;
+            for (auto r : rows) tot += r->coverages[i];
+            totals[i] = tot;
+            if (rm) mult[i] = (float)rm[si].num_mapped_reads / (float)rm[si].num_reads;
+        }
+        if (tpm_col >= 0) { float tot = 0.0f; for (auto r : rows) tot += r->coverages[tpm_col]; totals[tpm_col] = tot; }
+        const std::string &stoit = t.stoit_names[si];
+        if (n_norm) {
+            o += stoit; o += "\tunmapped"; o.append(extra_cols, '\t');
+            for (size_t k = 0; k < n_norm; k++) {
+                const size_t col = (size_t)norm[k];
+                const size_t lo = k == 0 ? 0 : (size_t)norm[k - 1] + 1;
+                for (size_t j = lo; j < col; j++) o += "\tNA";
+                o += '\t'; o += f32s(100.0f * (1.0f - *mult[col]));
+            }
+            for (size_t j = (size_t)norm[n_norm - 1] + 1; j < nc; j++) o += "\tNA";
+            o += '\n';
+        }
+        for (auto r : rows) {
+            o += stoit; o += '\t'; o += rstrip_cr(*t.entry_names[r->entry_index]);
+            for (size_t i = 0; i < nc; i++) {
+                o += '\t';
+                const float c = r->coverages[i];
+                if (contains(norm, n_norm, i)) o += f32s(c * 100.0f * *mult[i] / *totals[i]);          // :285-286
+                else if (rpkm_col == (int64_t)i) { const u64 n = rm[si].num_mapped_reads; o += f32s(n == 0 ? 0.0f : c / (float)n); }
+                else if (tpm_col == (int64_t)i) {
+                    const u64 n = rm[si].num_mapped_reads;
+                    if (n == 0) o += f64s(0.0);
+                    else o += f64s((double)std::exp(std::log(c) - std::log(*totals[i])) * (double)1000000);   // :320-323
+                } else o += f32s(c);
+            }
+            o += '\n';
+        }
+    };
+    std::vector<const EntryAndCoverages *> rows;
+    size_t cur = 0;
+    for (auto &e : all) {
+        if (cur != e.stoit_index) { print_previous(rows, cur); rows.clear(); cur = e.stoit_index; }
+        rows.push_back(&e);
+    }
+    if (!t.stoit_names.empty()) print_previous(rows, cur);
+}
+
+void print_dense(covh_taker &t, const char *entry_type, const char *const *headers, size_t n_headers, const covh_reads_mapped *rm,
+                 size_t n_samples, const int64_t *norm, size_t n_norm, int64_t rpkm_col, int64_t tpm_col) {
+    const size_t nc = t.num_coverages;
+    std::string &o = t.text;
+    o += entry_type;
+    for (auto &s : t.stoit_names) for (size_t i = 0; i < n_headers; i++) { o += '\t'; o += s; o += ' '; o += headers[i]; }
+    o += '\n';
+    std::vector<float> mult;
+    if (rm) for (size_t i = 0; i < n_samples; i++) mult.push_back((float)rm[i].num_mapped_reads / (float)rm[i].num_reads);
+    if (n_norm) {
+        o += "unmapped";
+        o.append(std::count(entry_type, entry_type + strlen(entry_type), '\t'), '\t');
+        for (size_t si = 0; si < t.stoit_names.size(); si++) {
+            for (size_t k = 0; k < n_norm; k++) {
+                const size_t col = (size_t)norm[k];
+                const size_t lo = k == 0 ? 0 : (size_t)norm[k - 1] + 1;
+                for (size_t j = lo; j < col; j++) o += "\tNA";
+                o += '\t'; o += f32s(100.0f * (1.0f - mult[si]));
+            }
+            for (size_t j = (size_t)norm[n_norm - 1] + 1; j < nc; j++) o += "\tNA";
+        }
+        o += '\n';
+    }
+    auto all = iterate_cached(t);
+    std::vector<std::vector<std::optional<float>>> totals(t.stoit_names.size(), std::vector<std::optional<float>>(nc));
+    std::vector<std::vector<const EntryAndCoverages *>> by_stoit;
+    for (auto &e : all) {
+        auto addt = [&](size_t i) { auto &x = totals[e.stoit_index][i]; x = x ? *x + e.coverages[i] : e.coverages[i]; };
+        for (size_t k = 0; k < n_norm; k++) addt((size_t)norm[k]);
+        if (tpm_col >= 0) addt((size_t)tpm_col);
+        if (by_stoit.size() <= e.stoit_index) by_stoit.emplace_back();
+        by_stoit[e.stoit_index].push_back(&e);
+    }
+    if (by_stoit.empty()) return;
+    for (size_t k = 0; k < by_stoit[0].size(); k++) {
+        o += rstrip_cr(*t.entry_names[by_stoit[0][k]->entry_index]);
+        for (size_t si = 0; si < by_stoit.size(); si++) {
+            const EntryAndCoverages *e = by_stoit[si][k];
+            for (size_t i = 0; i < e->coverages.size(); i++) {
+                o += '\t';
+                const float c = e->coverages[i];
+                if (contains(norm, n_norm, i)) o += f32s(c / *totals[e->stoit_index][i] * 100.0f * mult[si]);   // :496-502
+                else if (rpkm_col == (int64_t)i) { const u64 n = rm[si].num_mapped_reads; o += f32s(n == 0 ? 0.0f : c / (float)n); }
+                else if (tpm_col == (int64_t)i) {
+                    const u64 n = rm[si].num_mapped_reads;
+                    o += f32s(n == 0 ? 0.0f : std::exp(std::log(c) - std::log(*totals[e->stoit_index][i])) * (float)1000000);  // :536-539
+                } else o += f32s(c);
+            }
+        }
+        o += '\n';
+    }
+}
+
+void print_metabat(covh_taker &t) {   // coverage_printer.rs:57-119
+    std::string &o = t.text;
+    o += "contigName\tcontigLen\ttotalAvgDepth";
+    for (auto &s : t.stoit_names) { o += '\t'; o += s; o += ".bam\t"; o += s; o += ".bam-var"; }
+    o += '\n';
+    auto all = iterate_cached(t);
+    std::vector<std::vector<const EntryAndCoverages *>> by_stoit;
+    for (auto &e : all) { if (by_stoit.size() <= e.stoit_index) by_stoit.emplace_back(); by_stoit[e.stoit_index].push_back(&e); }
+    if (by_stoit.empty()) return;
+    for (size_t k = 0; k < by_stoit[0].size(); k++) {
+        float total = 0.0f;
+        for (auto &st : by_stoit) total += st[k]->coverages[1];
+        o += *t.entry_names[k]; o += '\t'; o += f32s(by_stoit[0][k]->coverages[0]); o += '\t';
+        o += f64s(round4((double)total * 10000.0 / (double)t.coverages.size()));
+        for (auto &st : by_stoit) {
+            o += '\t'; o += f64s(round4((double)st[k]->coverages[1] * 10000.0));
+            o += '\t'; o += f64s(round4((double)st[k]->coverages[2] * 10000.0));
+        }
+        o += '\n';
+    }
+}
+}  // namespace
+
+void covh_finalise_printing(covh_taker *t, int printer, const char *entry_type, const char *const *headers,
+                            size_t n_headers, const covh_reads_mapped *rm, size_t n_samples,
+                            const int64_t *norm, size_t n_norm, int64_t rpkm_col, int64_t tpm_col) {
+    if (printer == 1) print_sparse(*t, rm, norm, n_norm, rpkm_col, tpm_col);
+    else if (printer == 2) print_dense(*t, entry_type, headers, n_headers, rm, n_samples, norm, n_norm, rpkm_col, tpm_col);
+    else if (printer == 3) print_metabat(*t);
+}
+
+}  // extern "C"

@@ -25,9 +25,12 @@ namespace covk {
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-constexpr int TILE = 16384;   // bases per tile: 64 KiB of i32 in LDS, two workgroups per CU
-constexpr int HB = 2048;      // LDS histogram bins; deeper positions go straight to the global histogram
+// Tile = bases handled by one workgroup, resident in LDS as i32 (TILE * 4 bytes).  Smaller tiles put more
+// workgroups on a CU (160 KiB LDS), which is what hides the dependent global-load latency of the event phase.
+constexpr int hist_bins(int tile) { return tile >= 16384 ? 2048 : 1024; }  // LDS histogram bins per tile
 constexpr u32 F_POS_UNSORTED = 1u;
+// run-word types (top two bits of .y)
+constexpr u32 RW_SINGLE = 0u, RW_DOUBLE = 1u, RW_COMPLEX = 2u;
 
 // Per-contig device accumulators (128 B).
 struct DevContig {
@@ -48,14 +51,16 @@ struct DevContig {
 };
 static_assert(sizeof(DevContig) == 160, "DevContig layout");
 
+constexpr u32 COUNTER_SLOTS = 64;   // device-wide counters are spread over this many 64-byte lines
 struct DevGlobal {
-    u64 n_primary_all;   // bam_generator.rs:114-118 / filter.rs:94-96
-    u64 n_considered;
     u64 first_error;     // min over erroring records of (record_index << 8 | code); ~0 = none
     u64 hist_cap_total;  // arena bins in use
     u64 chist_total;     // compact histogram bins
     u32 internal_error;  // depth exceeded its proven bound (would indicate a bug), etc.
     u32 pad;
+    u64 pad2[4];
+    u64 prim_slots[COUNTER_SLOTS * 8];  // sum = num_detected_primary_alignments (bam_generator.rs:114-118)
+    u64 cons_slots[COUNTER_SLOTS * 8];  // sum = number of considered records
 };
 
 struct FilterCfg {
@@ -78,12 +83,15 @@ struct Records {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Inclusive wave64 prefix sum with DPP lane moves (VALU latency, no LDS crossbar round trips):
+// row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2-3.
 __device__ __forceinline__ int wave_incl_scan(int v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o);
-        if (lane_id() >= o) v += t;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
 }
 __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
@@ -115,9 +123,9 @@ __device__ __forceinline__ void report_error(DevGlobal *g, u32 rec, u32 code) {
 __global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g) {
     u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0) {
-        g->n_primary_all = 0; g->n_considered = 0; g->first_error = ~0ull; g->hist_cap_total = 0;
-        g->chist_total = 0; g->internal_error = 0;
+        g->first_error = ~0ull; g->hist_cap_total = 0; g->chist_total = 0; g->internal_error = 0;
     }
+    if (c < COUNTER_SLOTS * 8) { g->prim_slots[c] = 0; g->cons_slots[c] = 0; }
     if (c >= n_targets) return;
     DevContig z;
     z.n_primary = z.n_pass = z.n_nonsupp = z.sum_nm = z.sum_indel = 0;
@@ -132,162 +140,214 @@ __global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g) {
 }
 
 // ------------------------------------------------------------------------------------ k_prep
-// Run word: x = start of the first merged M/=/X run (contig coordinate), y = its length with bit 31
-// set when the record has further runs (a D or N gap), in which case k_pileup re-walks the CIGAR.
+// Run word (8 bytes per record, all k_pileup needs for almost every read): x = start of the first merged
+// M/=/X run (contig coordinate); y = 0 for "no events", else top two bits give the type:
+//   RW_SINGLE  y = length of the only run
+//   RW_DOUBLE  two runs split by one short D/N gap: len1 (10 bits) | gap (8 bits) << 10 | len2 (10 bits) << 18
+//   RW_COMPLEX anything else (long reads, several gaps): k_pileup re-walks the CIGAR
 // Adjacent runs separated only by I/S/H/P are merged: their +1/-1 events cancel (contig.rs:178-183).
+//
+// One workgroup walks PREP_CHUNK consecutive records (PREP_ITEMS coalesced passes).  Each wave keeps
+// per-lane running sums for the contig it is currently in and flushes them with one set of atomics
+// only when the contig changes: a single hot address costs ~12 ns per atomic on MI355X, so per-wave
+// (let alone per-record) atomics on the per-contig or global counters would dominate the kernel.
+constexpr int PREP_ITEMS = 16;
+constexpr int PREP_CHUNK = 256 * PREP_ITEMS;
+
+struct PrepAcc {
+    u32 prim, pass, nons, span, first, last;
+    u64 nm, indel;
+    __device__ __forceinline__ void reset() { prim = pass = nons = span = 0; first = 0xffffffffu; last = 0; nm = indel = 0; }
+};
+
+__device__ __forceinline__ void prep_flush(DevContig *ctg, int cur, PrepAcc &a) {
+    if (cur >= 0) {
+        const u32 prim = wave_sum_u32(a.prim), pass = wave_sum_u32(a.pass), nons = wave_sum_u32(a.nons);
+        const u32 span = wave_max_u32(a.span), first = wave_min_u32(a.first), last = wave_max_u32(a.last);
+        const u64 nm = wave_sum_u64(a.nm), indel = wave_sum_u64(a.indel);
+        if (lane_id() == 0 && pass) {
+            DevContig *C = &ctg[cur];
+            if (prim) atomicAdd(&C->n_primary, (u64)prim);
+            atomicAdd(&C->n_pass, (u64)pass);
+            if (nons) atomicAdd(&C->n_nonsupp, (u64)nons);
+            if (nm) atomicAdd(&C->sum_nm, nm);
+            if (indel) atomicAdd(&C->sum_indel, indel);
+            if (span) atomicMax(&C->max_span, span);
+            atomicMin(&C->first_rec, first);
+            atomicMax(&C->last_rec, last);
+        }
+    }
+    a.reset();
+}
+
 template <bool WANT_IDENTITY>
 __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__ tlen, u32 n_targets,
                                               const uint8_t *__restrict__ mask, FilterCfg f, DevContig *ctg,
                                               DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ ident) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i < r.n;
-    const u32 flag = in ? r.flag[i] : 0x904u;
-    const int tid = in ? r.tid[i] : -1;
-    const int pos = in ? r.pos[i] : 0;
-    const int lane = lane_id();
+    __shared__ u32 blk_cnt[2][4];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const u32 chunk = blockIdx.x * (u32)PREP_CHUNK;
+    PrepAcc acc; acc.reset();
+    int cur = -1;            // wave-uniform: contig the running sums belong to
+    u32 g_prim = 0, g_cons = 0;
 
-    // every record read counts towards num_detected_primary_alignments when !secondary && !supplementary
-    {
-        u64 b = __ballot(in && !(flag & 0x900u));
-        if (lane == 0 && b) atomicAdd(&g->n_primary_all, (u64)__popcll(b));
-    }
-    const bool tid_ok = in && tid >= 0 && (u32)tid < n_targets;
-    // span of records carrying this tid + grouping / position-order checks (all records, considered or not)
-    if (tid_ok) {
-        const int ptid = i > 0 ? r.tid[i - 1] : -2;
-        if (ptid != tid) {
-            atomicMin(&ctg[tid].rec_start, i);
-            atomicAdd(&ctg[tid].n_groups, 1u);
-        } else if (r.pos[i - 1] > pos) {
-            atomicOr(&ctg[tid].flags, F_POS_UNSORTED);
+    for (int it = 0; it < PREP_ITEMS; it++) {
+        const u32 i = chunk + (u32)it * 256u + threadIdx.x;
+        const bool in = i < r.n;
+        if (!__any(in)) break;
+        const u32 flag = in ? r.flag[i] : 0x904u;
+        const int tid = in ? r.tid[i] : -1;
+        const int pos = in ? r.pos[i] : 0;
+        // every record read counts towards num_detected_primary_alignments when !secondary && !supplementary
+        g_prim += (in && !(flag & 0x900u)) ? 1u : 0u;
+        const bool tid_ok = in && tid >= 0 && (u32)tid < n_targets;
+        // span of records carrying this tid + grouping / position-order checks (all records, considered or not)
+        if (tid_ok) {
+            const int ptid = i > 0 ? r.tid[i - 1] : -2;
+            if (ptid != tid) {
+                atomicMin(&ctg[tid].rec_start, i);
+                atomicAdd(&ctg[tid].n_groups, 1u);
+            } else if (r.pos[i - 1] > pos) {
+                atomicOr(&ctg[tid].flags, F_POS_UNSORTED);
+            }
+            const int ntid = (i + 1 < r.n) ? r.tid[i + 1] : -2;
+            if (ntid != tid) atomicMax(&ctg[tid].rec_end, i + 1);
         }
-        const int ntid = (i + 1 < r.n) ? r.tid[i + 1] : -2;
-        if (ntid != tid) atomicMax(&ctg[tid].rec_end, i + 1);
-    }
 
-    const bool unmapped = flag & 0x4u;
-    const bool supp = flag & 0x800u, sec = flag & 0x100u;
-    // reader stage: ReferenceSortedBamFilter::read single-read branch, filter_out = true (filter.rs:88-116)
-    bool survives = in;
-    bool need_filter_eval = false;
-    if (f.filter_single) {
-        survives = false;
-        const bool p1 = in && !unmapped && (f.include_supplementary || !supp) && (f.include_secondary || !sec);
-        if (p1) {
-            const u32 mq = r.mapq[i];
-            if (!(f.min_mapq != 255u && (mq < f.min_mapq || mq == 255u))) need_filter_eval = true;  // :250-254
+        const bool unmapped = flag & 0x4u;
+        const bool supp = flag & 0x800u, sec = flag & 0x100u;
+        // reader stage: ReferenceSortedBamFilter::read single-read branch, filter_out = true (filter.rs:88-116)
+        bool survives = in;
+        bool need_filter_eval = false;
+        if (f.filter_single) {
+            survives = false;
+            const bool p1 = in && !unmapped && (f.include_supplementary || !supp) && (f.include_secondary || !sec);
+            if (p1) {
+                const u32 mq = r.mapq[i];
+                if (!(f.min_mapq != 255u && (mq < f.min_mapq || mq == 255u))) need_filter_eval = true;  // :250-254
+            }
         }
-    }
-    // scan stage gate: FlagFilter::passes (lib.rs:67-78) then !unmapped (contig.rs:125)
-    const bool flags_ok = !(!f.include_secondary && sec) && !(!f.include_supplementary && supp) &&
-                          !(!f.include_improper_pairs && !(flag & 0x2u));
-    const bool scan_gate = in && flags_ok && !unmapped;
+        // scan stage gate: FlagFilter::passes (lib.rs:67-78) then !unmapped (contig.rs:125)
+        const bool flags_ok = !(!f.include_secondary && sec) && !(!f.include_supplementary && supp) &&
+                              !(!f.include_improper_pairs && !(flag & 0x2u));
+        const bool scan_gate = in && flags_ok && !unmapped;
 
-    u64 aligned = 0, indel = 0;
-    u32 run_start = 0, run_len = 0, n_runs = 0, span = 0;
-    bool oob = false, badcig = false;
-    // with the reader-stage filter on, only records that reach single_read_passes_filter can survive
-    const bool do_walk = f.filter_single ? need_filter_eval : scan_gate;
-    if (do_walk) {
-        const u32 L = tid_ok ? tlen[tid] : 0u;
-        long long cursor = pos;
-        long long cur_s = 0, cur_e = -1;  // open merged run [cur_s, cur_e)
-        const u32 c0 = r.cigar_off[i], c1 = r.cigar_off[i + 1];
-        for (u32 c = c0; c < c1; c++) {
-            const u32 w = r.cigar[c];
-            const u32 op = w & 15u, len = w >> 4;
-            if (op == 0u || op == 7u || op == 8u) {          // M = X  (contig.rs:171-186)
-                if (cursor < 0 || cursor >= (long long)L) oob = true;
-                if (n_runs > 0 && cursor == cur_e) {
-                    cur_e += len;
-                    if (n_runs == 1) run_len += len;
-                } else {
-                    n_runs++;
-                    cur_s = cursor; cur_e = cursor + len;
-                    if (n_runs == 1) { run_start = (u32)cursor; run_len = len; }
-                }
-                cursor += len; aligned += len;
-            } else if (op == 2u) { cursor += len; indel += len; aligned += len; }  // D  (:187-191)
-            else if (op == 3u) { cursor += len; }                                  // N  (:192-195)
-            else if (op == 1u) { indel += len; aligned += len; }                   // I  (:196-199)
-            else if (op > 8u) badcig = true;                                       // S H P ignored (:200)
+        u64 aligned = 0, indel = 0;
+        u32 run_start = 0, run_len = 0, run2_start = 0, run2_len = 0, n_runs = 0, span = 0;
+        bool oob = false, badcig = false;
+        // with the reader-stage filter on, only records that reach single_read_passes_filter can survive
+        const bool do_walk = f.filter_single ? need_filter_eval : scan_gate;
+        if (do_walk) {
+            const u32 L = tid_ok ? tlen[tid] : 0u;
+            long long cursor = pos;
+            long long cur_e = -1;  // end of the open merged run
+            const u32 c0 = r.cigar_off[i], c1 = r.cigar_off[i + 1];
+            for (u32 c = c0; c < c1; c++) {
+                const u32 wd = r.cigar[c];
+                const u32 op = wd & 15u, len = wd >> 4;
+                if (op == 0u || op == 7u || op == 8u) {          // M = X  (contig.rs:171-186)
+                    if (cursor < 0 || cursor >= (long long)L) oob = true;
+                    if (n_runs > 0 && cursor == cur_e) {
+                        cur_e += len;
+                        if (n_runs == 1) run_len += len; else if (n_runs == 2) run2_len += len;
+                    } else {
+                        n_runs++;
+                        cur_e = cursor + len;
+                        if (n_runs == 1) { run_start = (u32)cursor; run_len = len; }
+                        else if (n_runs == 2) { run2_start = (u32)cursor; run2_len = len; }
+                    }
+                    cursor += len; aligned += len;
+                } else if (op == 2u) { cursor += len; indel += len; aligned += len; }  // D  (:187-191)
+                else if (op == 3u) { cursor += len; }                                  // N  (:192-195)
+                else if (op == 1u) { indel += len; aligned += len; }                   // I  (:196-199)
+                else if (op > 8u) badcig = true;                                       // S H P ignored (:200)
+            }
+            const long long sp = cursor - (long long)pos;
+            span = sp > 0 ? (u32)min(sp, (long long)0xffffffffu) : 0u;
         }
-        (void)cur_s;
-        const long long sp = cursor - (long long)pos;
-        span = sp > 0 ? (u32)min(sp, (long long)0xffffffffu) : 0u;
-    }
-    if (need_filter_eval) {  // single_read_passes_filter, filter.rs:256-278
-        const u32 k = r.nm_kind[i];
-        if (k != 1u) report_error(g, i, k == 0u ? 2u : 3u);
-        else {
-            const u32 al = (u32)aligned;  // u32 accumulation in the reference
-            const float a = (float)al;
-            survives = al >= f.min_aligned_length && a / (float)r.l_seq[i] >= f.min_aligned_percent &&
-                       1.0f - (float)r.nm[i] / a >= f.min_percent_identity;
+        if (need_filter_eval) {  // single_read_passes_filter, filter.rs:256-278
+            const u32 k = r.nm_kind[i];
+            if (k != 1u) report_error(g, i, k == 0u ? 2u : 3u);
+            else {
+                const u32 al = (u32)aligned;  // u32 accumulation in the reference
+                const float a = (float)al;
+                survives = al >= f.min_aligned_length && a / (float)r.l_seq[i] >= f.min_aligned_percent &&
+                           1.0f - (float)r.nm[i] / a >= f.min_percent_identity;
+            }
         }
-    }
-    const bool considered = survives && scan_gate;
-    const bool masked_in = considered && tid_ok && (mask == nullptr || mask[tid]);
-    u64 nmv = 0;
-    double idv = 0.0;
-    if (considered && !tid_ok) report_error(g, i, 7u);  // header.target_len(tid).expect("Corrupt BAM file?")
-    if (masked_in) {
-        if (badcig) report_error(g, i, 6u);
-        else if (oob) report_error(g, i, 4u);
-        const u32 k = r.nm_kind[i];
-        if (k != 1u) report_error(g, i, k == 0u ? 2u : 3u);  // nm(&record), contig.rs:206
-        else nmv = r.nm[i];
-        if (WANT_IDENTITY && aligned > 0) idv = ((double)aligned - (double)nmv) / (double)aligned;
-    }
-    if (in) {
-        uint2 rw;
-        rw.x = masked_in ? run_start : 0u;
-        rw.y = masked_in ? ((run_len & 0x7fffffffu) | (n_runs > 1 ? 0x80000000u : 0u)) : 0u;
-        if (masked_in && n_runs > 1 && run_len == 0) rw.y = 0x80000000u;
-        runs[i] = rw;
-        if (WANT_IDENTITY) ident[i] = (masked_in && !supp) ? idv : 0.0;
-    }
-
-    // per-contig counters, one atomic per wave when every considered lane shares a tid (the common case)
-    const bool cnt = considered && tid_ok;
-    const u64 m = __ballot(cnt);
-    if (m == 0) return;
-    const int first = __ffsll((long long)m) - 1;
-    const int ftid = __shfl(tid, first);
-    const bool uni = __all(!cnt || tid == ftid);
-    const u32 base = i - lane;
-    if (uni) {
-        const u32 c_prim = __popcll(__ballot(cnt && !supp && !sec));
-        const u32 c_nons = __popcll(__ballot(cnt && !supp));
-        const u32 c_pass = __popcll(m);
-        const u64 s_nm = wave_sum_u64(masked_in ? nmv : 0ull);
-        const u64 s_in = wave_sum_u64(masked_in ? indel : 0ull);
-        const u32 mx = wave_max_u32(masked_in ? span : 0u);
-        if (lane == first) {
-            DevContig *C = &ctg[ftid];
-            atomicAdd(&C->n_primary, (u64)c_prim);
-            atomicAdd(&C->n_pass, (u64)c_pass);
-            atomicAdd(&C->n_nonsupp, (u64)c_nons);
-            if (s_nm) atomicAdd(&C->sum_nm, s_nm);
-            if (s_in) atomicAdd(&C->sum_indel, s_in);
-            atomicMax(&C->max_span, mx);
-            atomicMin(&C->first_rec, base + (u32)first);
-            atomicMax(&C->last_rec, base + (u32)(63 - __clzll((long long)m)));
-            atomicAdd(&g->n_considered, (u64)c_pass);
-        }
-    } else if (cnt) {
-        DevContig *C = &ctg[tid];
-        if (!supp && !sec) atomicAdd(&C->n_primary, 1ull);
-        atomicAdd(&C->n_pass, 1ull);
-        if (!supp) atomicAdd(&C->n_nonsupp, 1ull);
+        const bool considered = survives && scan_gate;
+        const bool masked_in = considered && tid_ok && (mask == nullptr || mask[tid]);
+        u64 nmv = 0;
+        double idv = 0.0;
+        if (considered && !tid_ok) report_error(g, i, 7u);  // header.target_len(tid).expect("Corrupt BAM file?")
         if (masked_in) {
-            if (nmv) atomicAdd(&C->sum_nm, nmv);
-            if (indel) atomicAdd(&C->sum_indel, indel);
-            atomicMax(&C->max_span, span);
+            if (badcig) report_error(g, i, 6u);
+            else if (oob) report_error(g, i, 4u);
+            const u32 k = r.nm_kind[i];
+            if (k != 1u) report_error(g, i, k == 0u ? 2u : 3u);  // nm(&record), contig.rs:206
+            else nmv = r.nm[i];
+            if (WANT_IDENTITY && aligned > 0) idv = ((double)aligned - (double)nmv) / (double)aligned;
         }
-        atomicMin(&C->first_rec, i);
-        atomicMax(&C->last_rec, i);
-        atomicAdd(&g->n_considered, 1ull);
+        if (in) {
+            uint2 rw;
+            rw.x = 0u; rw.y = 0u;
+            if (masked_in && n_runs > 0) {
+                rw.x = run_start;
+                const u32 gap = run2_start - (run_start + run_len);
+                if (n_runs == 1 && run_len < (1u << 30)) rw.y = run_len;   // RW_SINGLE; 0 = nothing to add
+                else if (n_runs == 2 && run_len - 1u < 1023u && run2_len - 1u < 1023u && gap - 1u < 255u)
+                    rw.y = (RW_DOUBLE << 30) | run_len | (gap << 10) | (run2_len << 18);
+                else rw.y = RW_COMPLEX << 30;
+            }
+            runs[i] = rw;
+            if (WANT_IDENTITY) ident[i] = (masked_in && !supp) ? idv : 0.0;
+        }
+
+        // per-contig counters: accumulate per lane while the wave stays inside one contig
+        const bool cnt = considered && tid_ok;
+        g_cons += cnt ? 1u : 0u;
+        const u64 m = __ballot(cnt);
+        if (m != 0) {
+            const int ftid = __shfl(tid, __ffsll((long long)m) - 1);
+            const bool uni = __all(!cnt || tid == ftid);
+            if (uni) {
+                if (ftid != cur) { prep_flush(ctg, cur, acc); cur = ftid; }
+                if (cnt) {
+                    acc.prim += (!supp && !sec) ? 1u : 0u;
+                    acc.pass += 1u;
+                    acc.nons += supp ? 0u : 1u;
+                    acc.first = min(acc.first, i); acc.last = max(acc.last, i);
+                    if (masked_in) { acc.nm += nmv; acc.indel += indel; acc.span = max(acc.span, span); }
+                }
+            } else {  // contig boundary inside this wave pass: rare, resolve with per-lane atomics
+                prep_flush(ctg, cur, acc); cur = -1;
+                if (cnt) {
+                    DevContig *C = &ctg[tid];
+                    if (!supp && !sec) atomicAdd(&C->n_primary, 1ull);
+                    atomicAdd(&C->n_pass, 1ull);
+                    if (!supp) atomicAdd(&C->n_nonsupp, 1ull);
+                    if (masked_in) {
+                        if (nmv) atomicAdd(&C->sum_nm, nmv);
+                        if (indel) atomicAdd(&C->sum_indel, indel);
+                        atomicMax(&C->max_span, span);
+                    }
+                    atomicMin(&C->first_rec, i);
+                    atomicMax(&C->last_rec, i);
+                }
+            }
+        }
+    }
+    prep_flush(ctg, cur, acc);
+    // device-wide counters: one pair of atomics per workgroup, spread over COUNTER_SLOTS cache lines
+    g_prim = wave_sum_u32(g_prim); g_cons = wave_sum_u32(g_cons);
+    if (lane == 0) { blk_cnt[0][w] = g_prim; blk_cnt[1][w] = g_cons; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 p = blk_cnt[0][0] + blk_cnt[0][1] + blk_cnt[0][2] + blk_cnt[0][3];
+        const u32 c = blk_cnt[1][0] + blk_cnt[1][1] + blk_cnt[1][2] + blk_cnt[1][3];
+        const u32 slot = (blockIdx.x % COUNTER_SLOTS) * 8u;
+        if (p) atomicAdd(&g->prim_slots[slot], (u64)p);
+        if (c) atomicAdd(&g->cons_slots[slot], (u64)c);
     }
 }
 
@@ -300,30 +360,33 @@ __device__ __forceinline__ u32 lower_bound_pos(const int32_t *__restrict__ pos, 
     return lo;
 }
 
+// Tile descriptor: x,y = candidate record range, z = contig length, w = flags (bit 0: records of other
+// contigs may be interleaved in the range, check tid).  One 16-byte load gives k_pileup all it needs.
 template <bool WANT_HIST>
 __global__ __launch_bounds__(256) void k_ranges(const u32 *__restrict__ tile_contig, const u32 *__restrict__ tile_start,
-                                                u32 n_tiles, const int32_t *__restrict__ pos,
-                                                const uint8_t *__restrict__ mask, DevContig *ctg,
-                                                uint2 *__restrict__ cand) {
+                                                u32 n_tiles, u32 tile, const int32_t *__restrict__ pos,
+                                                const u32 *__restrict__ tlen, const uint8_t *__restrict__ mask,
+                                                DevContig *ctg, uint4 *__restrict__ desc) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     const u32 c = tile_contig[t];
     DevContig *C = &ctg[c];
-    uint2 out = make_uint2(0u, 0u);
+    uint4 out = make_uint4(0u, 0u, tlen[c], 0u);
     if (C->n_pass != 0 && (mask == nullptr || mask[c])) {
         const u32 rs = C->rec_start, re = C->rec_end;
+        if (C->n_groups != 1u) out.w = 1u;
         if (C->n_groups != 1u || (C->flags & F_POS_UNSORTED)) {
-            out = make_uint2(rs, re);  // generic path: every tile of this contig scans the whole span
+            out.x = rs; out.y = re;  // generic path: every tile of this contig scans the whole span
         } else {
             const long long lo = tile_start[t];
-            // a run [s,e) of a record at `pos` (pos <= s, e <= pos + max_span) overlaps [lo, lo+TILE) only if
-            // pos > lo - max_span and pos < lo + TILE
+            // a run [s,e) of a record at `pos` (pos <= s, e <= pos + max_span) overlaps [lo, lo+tile) only if
+            // pos > lo - max_span and pos < lo + tile
             out.x = lower_bound_pos(pos, rs, re, lo - (long long)C->max_span + 1);
-            out.y = lower_bound_pos(pos, out.x, re, lo + TILE);
+            out.y = lower_bound_pos(pos, out.x, re, lo + (long long)tile);
         }
         if (WANT_HIST && out.y > out.x) atomicMax(&C->hist_cap, out.y - out.x);
     }
-    cand[t] = out;
+    desc[t] = out;
 }
 
 // ------------------------------------------------------------------------------------ histogram layout
@@ -427,38 +490,43 @@ __global__ __launch_bounds__(64) void k_identity(DevContig *ctg, u32 n_targets, 
 // ------------------------------------------------------------------------------------ k_pileup
 struct PileupArgs {
     const u32 *tile_contig, *tile_start;
-    const uint2 *cand;
+    const uint4 *desc;
     const uint2 *runs;
     Records r;
-    const u32 *tlen;
     DevContig *ctg;
     DevGlobal *g;
     u32 *hist_arena;
     u64 excl;
     int32_t *depth_out;   // WRITE_DEPTH: depth of one contig
     u32 tile_base;        // first tile index handled by blockIdx 0
+    u32 ablate;           // experiment knob (COVERM_ABLATE): 1 no events, 2 no stats loop, 4 no hist, 8 no result atomics
 };
 
-template <int NT, bool WANT_HIST, bool WRITE_DEPTH>
+constexpr size_t pileup_smem_bytes(int tile, int nt, bool hist) {
+    return (size_t)tile * 4 + 256 + (size_t)(nt / 64) * 32 + 16 + (hist ? (size_t)hist_bins(tile) * 4 : 0);
+}
+
+template <int TILE, int NT, bool WANT_HIST, bool WRITE_DEPTH>
 __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
     constexpr int NW = NT / 64;
     constexpr int ROWS = TILE / (4 * NT);   // quads per thread
-    static_assert(NW * ROWS == 64, "cross-wave prefix is resolved by one 64-lane scan");
+    constexpr int HB = hist_bins(TILE);
+    static_assert(ROWS >= 1 && NW * ROWS <= 64, "cross-wave prefix is resolved by one 64-lane scan");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *tile = reinterpret_cast<int *>(smem);                       // TILE i32
-    int *wtot = reinterpret_cast<int *>(smem + TILE * 4);            // 64 wave totals
+    int *wtot = reinterpret_cast<int *>(smem + TILE * 4);            // <= 64 (row, wave) totals
     u64 *red64 = reinterpret_cast<u64 *>(smem + TILE * 4 + 256);     // NW * 2
     u32 *red32 = reinterpret_cast<u32 *>(smem + TILE * 4 + 256 + NW * 16);  // NW * 4 (+2 broadcast)
     u32 *lhist = reinterpret_cast<u32 *>(smem + TILE * 4 + 256 + NW * 16 + NW * 16 + 16);
 
     const u32 t = a.tile_base + blockIdx.x;
-    const uint2 cr = a.cand[t];
-    if (cr.x >= cr.y) return;  // no record can touch this tile: depth 0 everywhere, accounted on the host side
-    const u32 c = a.tile_contig[t];
+    const uint4 ds = a.desc[t];
+    if (ds.x >= ds.y) return;  // no record can touch this tile: depth 0 everywhere, accounted on the host side
     const u32 lo = a.tile_start[t];
-    const u32 L = a.tlen[c];
+    const u32 c = a.tile_contig[t];
+    const u32 L = ds.z;
+    const bool generic = ds.w & 1u;
     const u32 tlen_t = min((u32)TILE, L - lo);
-    const bool generic = (a.ctg[c].n_groups != 1u);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int rows_used = (int)((tlen_t + 4 * NT - 1) / (4 * NT));
 
@@ -466,7 +534,9 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
     {
         int4 z = make_int4(0, 0, 0, 0);
         int4 *t4 = reinterpret_cast<int4 *>(tile);
-        for (int rr = 0; rr < rows_used; rr++) t4[rr * NT + tid] = z;
+#pragma unroll
+        for (int rr = 0; rr < ROWS; rr++)
+            if (rr < rows_used) t4[rr * NT + tid] = z;
         if (WANT_HIST)
             for (int b = tid; b < HB; b += NT) lhist[b] = 0u;
     }
@@ -481,13 +551,19 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
             if (e < hi) atomicAdd(&tile[e - lo], -1);
         }
     };
-    for (u32 i = cr.x + tid; i < cr.y; i += NT) {
+    if (!(a.ablate & 1u))
+    for (u32 i = ds.x + tid; i < ds.y; i += NT) {
         const uint2 rw = a.runs[i];
         if (rw.y == 0u) continue;
         if (generic && a.r.tid[i] != (int)c) continue;
-        if (!(rw.y & 0x80000000u)) {
+        const u32 type = rw.y >> 30;
+        if (type == RW_SINGLE) {
             add_run(rw.x, rw.x + rw.y);
-        } else {  // D / N gaps: re-walk the CIGAR (contig.rs:166-202)
+        } else if (type == RW_DOUBLE) {
+            const u32 l1 = rw.y & 1023u, gap = (rw.y >> 10) & 255u, l2 = (rw.y >> 18) & 1023u;
+            add_run(rw.x, rw.x + l1);
+            add_run(rw.x + l1 + gap, rw.x + l1 + gap + l2);
+        } else {  // re-walk the CIGAR (contig.rs:166-202)
             u32 cursor = (u32)a.r.pos[i];
             const u32 c0 = a.r.cigar_off[i], c1 = a.r.cigar_off[i + 1];
             for (u32 k = c0; k < c1; k++) {
@@ -518,7 +594,7 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
     __syncthreads();
     int pre;  // exclusive prefix of (row, wave) totals in row-major order, one entry per lane
     {
-        const int tot = wtot[lane];
+        const int tot = lane < NW * ROWS ? wtot[lane] : 0;
         pre = wave_incl_scan(tot) - tot;
     }
 
@@ -535,13 +611,14 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
     const u64 hoff = WANT_HIST ? C->hist_off : 0;
     const u32 hcap = WANT_HIST ? C->hist_cap : 0;
     auto hist_add = [&](u32 d, u32 x) {
+        if (a.ablate & 4u) return;
         if (d < (u32)HB) atomicAdd(&lhist[d], x);
         else if (d <= hcap) atomicAdd(&a.hist_arena[hoff + d], x);
         else atomicOr(&a.g->internal_error, 1u);
     };
 #pragma unroll
     for (int rr = 0; rr < ROWS; rr++) {
-        if (rr >= rows_used) break;
+        if (rr >= rows_used || (a.ablate & 2u)) break;
         const int base = __shfl(pre, rr * NW + w) + ex[rr];
         const u32 p0 = lo + 4u * (u32)(rr * NT + tid);
         const int dl[4] = {v[rr].x, v[rr].y, v[rr].z, v[rr].w};
@@ -616,7 +693,7 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
         a0 = wave_sum_u64(a0); a1 = wave_sum_u64(a1);
         b0 = wave_sum_u32(b0); b1 = wave_sum_u32(b1);
         b2 = wave_min_u32(b2); b3 = wave_max_u32(b3);
-        if (lane == 0) {
+        if (lane == 0 && !(a.ablate & 8u)) {
             if (a0) atomicAdd(&C->sum_d, a0);
             if (a1) atomicAdd(&C->sum_d2, a1);
             if (b0) atomicAdd(&C->cov_win, (u64)b0);
@@ -626,8 +703,8 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
                 atomicMin(&C->min_d, b2);
                 atomicMax(&C->max_d, b3);
             }
-            red32[NW * 4 + 0] = b2; red32[NW * 4 + 1] = b3;
         }
+        if (lane == 0) { red32[NW * 4 + 0] = b2; red32[NW * 4 + 1] = b3; }
     }
     if (WANT_HIST) {
         __syncthreads();
@@ -639,10 +716,6 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
             }
         }
     }
-}
-
-constexpr size_t pileup_smem_bytes(int nt, bool hist) {
-    return (size_t)TILE * 4 + 256 + (size_t)(nt / 64) * 32 + 16 + (hist ? (size_t)HB * 4 : 0);
 }
 
 }  // namespace covk

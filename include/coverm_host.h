@@ -1,0 +1,135 @@
+/*
+ * coverm_host.h — host side ABOVE the covermhip C ABI, in C++ with a C surface.
+ *
+ * The reference keeps these layers in Rust; no Rust toolchain exists in this build environment, so
+ * they are written in C++ with the same names, argument meaning and error behaviour:
+ *
+ *   CoverageEstimator::{new_estimator_*, calculate_coverage, print_coverage, print_zero_coverage}
+ *                                   src/mosdepth_genome_coverage_estimators.rs:107-224, 530-839, 936-991
+ *   contig_coverage                 src/contig.rs:13-253           (flush + zero-row logic :40-104, 255-277)
+ *   mosdepth_genome_coverage_with_contig_names   src/genome.rs:17-322
+ *   mosdepth_genome_coverage        src/genome.rs:419-929
+ *   CoverageTaker implementations   src/coverage_takers.rs:74-219, 265-377
+ *   CoveragePrinter                 src/coverage_printer.rs:20-553
+ *   EstimatorsAndTaker / FilterParameters  src/bin/coverm.rs:1315-1504, 1648-1704
+ *   BAM/SAM reading (rust-htslib in the reference)  src/bam_generator.rs:103-144, 356-371
+ *
+ * The scan loops here do not touch reads: they consume the per-contig integer statistics a
+ * covermhip session produced (cov_contig_stats + histograms) where the reference would have called
+ * add_contig(ups_and_downs, ...).  Every f32 is formed from those integers with the reference's
+ * operation order, so results are bit-identical, not merely within tolerance.
+ */
+#ifndef COVERM_HOST_H
+#define COVERM_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "covermhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum CoverageEstimator variant order, estimators.rs:4-81 */
+typedef enum {
+    COVH_MEAN = 0,
+    COVH_TRIMMED_MEAN = 1,
+    COVH_PILEUP_COUNTS = 2,
+    COVH_COVERED_FRACTION = 3,
+    COVH_COVERED_BASES = 4,
+    COVH_RPKM = 5,
+    COVH_TPM = 6,
+    COVH_VARIANCE = 7,
+    COVH_LENGTH = 8,
+    COVH_READ_COUNT = 9,
+    COVH_READS_PER_BASE = 10,
+    COVH_ANIR = 11
+} covh_kind;
+
+/* Constructor parameters (estimators.rs:107-224). */
+typedef struct {
+    int32_t kind;
+    float min_fraction_covered_bases;
+    uint64_t contig_end_exclusion; /* must equal the session's cov_config.contig_end_exclusion */
+    int32_t exclude_mismatches;
+    float trim_min, trim_max;
+} covh_estimator;
+
+typedef struct {
+    uint64_t num_mapped_reads, num_reads; /* ReadsMapped, lib.rs:54-57 */
+} covh_reads_mapped;
+
+/* One sample's device results, as returned by cov_finish / cov_fetch_hist. */
+typedef struct {
+    const char *stoit_name;
+    const cov_contig_stats *stats; /* n_targets entries */
+    const uint64_t *hist;          /* may be NULL when no estimator needs histograms */
+    uint64_t num_detected_primary_alignments;
+} covh_sample;
+
+/* BAM header as the scan loops use it (names + lengths). */
+typedef struct {
+    uint32_t n_targets;
+    const char *names;        /* concatenated, not NUL separated */
+    const uint32_t *name_off; /* n_targets + 1 */
+    const uint64_t *target_len;
+} covh_header;
+
+typedef enum {
+    COVH_TAKER_STREAM = 0, /* SingleFloatCoverageStreamingCoveragePrinter */
+    COVH_TAKER_PILEUP = 1, /* PileupCoverageCoveragePrinter */
+    COVH_TAKER_CACHED = 2  /* CachedSingleFloatCoverageTaker */
+} covh_taker_kind;
+
+typedef struct covh_taker covh_taker;     /* owns an output text buffer */
+covh_taker *covh_taker_new(int kind, size_t num_coverages);
+void covh_taker_free(covh_taker *t);
+const char *covh_taker_text(const covh_taker *t, size_t *len); /* streamed output so far */
+void covh_taker_clear_text(covh_taker *t);
+
+/* Which need a histogram / identity sums from the device (COV_WANT_* for the session). */
+uint32_t covh_wants(const covh_estimator *est, size_t n_est);
+
+/* The three scan entry points.  Return COV_OK or a cov_status; *err (optional) receives a static message. */
+int covh_contig_coverage(const covh_header *h, const covh_sample *samples, size_t n_samples, covh_taker *taker,
+                         const covh_estimator *est, size_t n_est, int print_zero_coverage_contigs,
+                         covh_reads_mapped *reads_mapped_out);
+int covh_genome_coverage_with_contig_names(const covh_header *h, const covh_sample *samples, size_t n_samples,
+                                           const int32_t *genome_of_tid, const char *const *genome_names,
+                                           size_t n_genomes, covh_taker *taker, int print_zero_coverage_genomes,
+                                           const covh_estimator *est, size_t n_est,
+                                           covh_reads_mapped *reads_mapped_out);
+int covh_genome_coverage_separator(const covh_header *h, const covh_sample *samples, size_t n_samples,
+                                   uint8_t split_char, covh_taker *taker, int print_zero_coverage_genomes,
+                                   const covh_estimator *est, size_t n_est, int single_genome,
+                                   covh_reads_mapped *reads_mapped_out);
+const char *covh_last_error(void);
+
+/* CoveragePrinter (coverage_printer.rs).  printer: 0 streamed, 1 sparse cached, 2 dense cached, 3 MetaBAT.
+ * Appends to the taker's text buffer. */
+void covh_print_headers(covh_taker *t, int printer, const char *entry_type, const char *const *headers, size_t n);
+void covh_finalise_printing(covh_taker *t, int printer, const char *entry_type, const char *const *headers,
+                            size_t n_headers, const covh_reads_mapped *reads_mapped, size_t n_samples,
+                            const int64_t *columns_to_normalise, size_t n_norm, int64_t rpkm_column,
+                            int64_t tpm_column);
+
+/* Rust `Display` for f32 / f64 (shortest round-trip, positional notation).  Returns bytes written. */
+size_t covh_format_f32(float v, char *buf, size_t cap);
+size_t covh_format_f64(double v, char *buf, size_t cap);
+
+/* calculate_coverage for one entry built from explicit sums (used by unit tests). */
+typedef struct {
+    uint64_t win_len, win_sum_d, win_sum_d2, win_covered, full_len, full_covered, n_reads, mismatches;
+    uint32_t win_min_d;
+    uint32_t hist_len;
+    const uint64_t *hist;
+    double sum_identity;
+} covh_entry;
+float covh_calculate_coverage(const covh_estimator *e, const covh_entry *entry, const uint64_t *unobserved,
+                              size_t n_unobserved);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
