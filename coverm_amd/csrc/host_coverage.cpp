@@ -310,6 +310,12 @@ covh_taker *covh_taker_new(int kind, size_t num_coverages) {
 void covh_taker_free(covh_taker *t) { delete t; }
 const char *covh_taker_text(const covh_taker *t, size_t *len) { if (len) *len = t->text.size(); return t->text.c_str(); }
 void covh_taker_clear_text(covh_taker *t) { t->text.clear(); }
+size_t covh_taker_cached_coverages(const covh_taker *t, size_t stoit, float *out, size_t cap) {
+    if (t->kind != COVH_TAKER_CACHED || stoit >= t->coverages.size()) return 0;
+    const auto &v = t->coverages[stoit];
+    for (size_t i = 0; i < v.size() && i < cap; i++) out[i] = v[i].second;
+    return v.size();
+}
 
 uint32_t covh_wants(const covh_estimator *est, size_t n_est) {
     uint32_t w = 0;
@@ -580,7 +586,7 @@ void covh_print_headers(covh_taker *t, int printer, const char *entry_type, cons
 
 namespace {
 bool contains(const int64_t *v, size_t n, size_t x) { for (size_t i = 0; i < n; i++) if ((size_t)v[i] == x) return true; return false; }
-std::string rstrip_cr(const std::string &s) { size_t n = s.size(); while (n && s[n - 1] == '\r') n--; return s.substr(0, n); }
+static std::string rstrip_cr(const std::string &s) { size_t n = s.size(); while (n && s[n - 1] == '\r') n--; return s.substr(0, n); }
 double round4(double v) { return std::round(v) / 10000.0; }  // (x * 10000.0).round() / 10000.0 with x*10000 passed in
 
 void print_sparse(covh_taker &t, const covh_reads_mapped *rm, const int64_t *norm, size_t n_norm, int64_t rpkm_col, int64_t tpm_col) {

@@ -132,6 +132,8 @@ def _lib():
         L.covh_taker_text.restype = C.c_void_p
         L.covh_taker_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
         L.covh_taker_clear_text.argtypes = [C.c_void_p]
+        L.covh_taker_cached_coverages.restype = C.c_size_t
+        L.covh_taker_cached_coverages.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.covh_last_error.restype = C.c_char_p
         L.covh_wants.restype = C.c_uint32
         L.covh_wants.argtypes = [C.c_void_p, C.c_size_t]
@@ -210,6 +212,14 @@ class CoverageTaker:
         n = C.c_size_t(0)
         p = self._L.covh_taker_text(self._h, C.byref(n))
         return C.string_at(p, n.value).decode()
+
+    def cached_coverages(self, stoit: int = 0) -> np.ndarray:
+        """f32 coverages recorded for one sample by the cached taker (entries x estimators, recording order)."""
+        n = self._L.covh_taker_cached_coverages(self._h, C.c_size_t(stoit), None, C.c_size_t(0))
+        out = np.zeros(n, dtype=np.float32)
+        if n:
+            self._L.covh_taker_cached_coverages(self._h, C.c_size_t(stoit), out.ctypes.data_as(C.c_void_p), C.c_size_t(n))
+        return out
 
     def __del__(self):
         try:

@@ -87,6 +87,9 @@ covh_taker *covh_taker_new(int kind, size_t num_coverages);
 void covh_taker_free(covh_taker *t);
 const char *covh_taker_text(const covh_taker *t, size_t *len); /* streamed output so far */
 void covh_taker_clear_text(covh_taker *t);
+/* Cached taker: the f32 coverages recorded for sample `stoit`, in recording order (entries x estimators);
+ * returns the number available (copies at most cap). */
+size_t covh_taker_cached_coverages(const covh_taker *t, size_t stoit, float *out, size_t cap);
 
 /* Which need a histogram / identity sums from the device (COV_WANT_* for the session). */
 uint32_t covh_wants(const covh_estimator *est, size_t n_est);
