@@ -35,6 +35,8 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     hip, cpp, hdr = sources()
+    if not os.path.exists(CLI) or os.path.getmtime(os.path.join(CSRC, "cli_main.cc")) > os.path.getmtime(CLI):
+        return True
     return any(os.path.getmtime(p) > t for p in hip + cpp + hdr)
 
 
@@ -53,7 +55,22 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    build_cli(verbose)
     return LIB
+
+
+CLI = os.path.join(HERE, "coverm-amd")
+
+
+def build_cli(verbose=False):
+    """The standalone C++ CLI (csrc/cli_main.cc) linked against the in-tree libcovermhip.so."""
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-x", "c++", os.path.join(CSRC, "cli_main.cc"), "-I" + os.path.join(HERE, "..", "include"),
+           "-L" + HERE, "-lcovermhip", "-Wl,-rpath,$ORIGIN", "-o", CLI + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(CLI + ".tmp", CLI)
+    return CLI
 
 
 if __name__ == "__main__":

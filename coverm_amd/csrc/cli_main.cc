@@ -1,0 +1,362 @@
+// coverm-amd — `coverm contig` / `coverm genome` over --bam-files on the MI355X engine.
+//
+// Mirrors the reference orchestrator for this path (src/bin/coverm.rs): FilterParameters::generate_from_clap
+// :1659-1678 + doing_filtering :1695-1703, EstimatorsAndTaker::generate_from_clap :1315-1504, print_headers
+// :1506-1519, run_contig :2088-2131, run_genome :1539-1628, parse_percentage :1296-1312, parse_separator
+// :1522-1537; flag names and defaults from src/cli.rs (contig :2264-2582, genome :1669-2263).
+// Everything else the reference binary does (mapping, indexing, filter/make/cluster subcommands) is out of scope.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/coverm_host.h"
+
+namespace {
+
+[[noreturn]] void die(const std::string &m) { fprintf(stderr, "[coverm-amd] ERROR: %s\n", m.c_str()); exit(1); }
+
+float parse_percentage(const char *v) {   // coverm.rs:1296-1312
+    if (!v) return 0.0f;
+    float p = strtof(v, nullptr);
+    if (p >= 1.0f && p <= 100.0f) p /= 100.0f;
+    else if (!(p >= 0.0f && p <= 100.0f)) die(std::string("Invalid alignment percentage: '") + v + "'");
+    return p;
+}
+
+struct Args {
+    std::string mode;
+    std::vector<std::string> bams, methods;
+    const char *min_covered_fraction = nullptr, *trim_min = "5", *trim_max = "95";
+    uint64_t contig_end_exclusion = 75;
+    std::string output_format = "dense", output_file, genome_definition;
+    bool no_zeros = false, proper_pairs_only = false, exclude_supplementary = false, include_secondary = false;
+    bool single_genome = false, have_separator = false;
+    char separator = '~';
+    uint32_t min_aligned_length = 0, min_aligned_length_pair = 0;
+    const char *min_pid = nullptr, *min_aligned_pct = nullptr, *min_pid_pair = nullptr, *min_aligned_pct_pair = nullptr;
+    int min_mapq = 255, threads = 1, device = 0;
+};
+
+struct Filter {   // FilterParameters, coverm.rs:1648-1657
+    bool improper = true, supp = true, sec = false;
+    uint32_t len_single = 0, len_pair = 0;
+    float pid_single = 0, pct_single = 0, pid_pair = 0, pct_pair = 0;
+    int mapq = 255;
+    bool doing_filtering() const {
+        return pid_single > 0 || pid_pair > 0 || pct_single > 0 || mapq < 255 || pct_pair > 0 || len_single > 0 || len_pair > 0;
+    }
+    void mode(bool &fs, bool &fp) const {   // filter.rs:48-61
+        const bool fs0 = len_single > 0 || pid_single > 0 || pct_single > 0;
+        const bool fp0 = len_pair > 0 || pid_pair > 0 || pct_pair > 0;
+        fs = fs0 || (!fp0 && mapq != 255);
+        fp = fp0 || ((!fs || !improper) && mapq != 255);
+    }
+};
+
+struct Sample {
+    std::string stoit;
+    std::vector<cov_contig_stats> stats;
+    std::vector<uint64_t> hist;
+    uint64_t prim = 0;
+};
+
+// ---- pair-mode reader stage on the host (filter.rs:117-228, filter_out = true): indices in emission order
+uint32_t aligned_of(const cov_batch &b, uint64_t i, bool with_del) {
+    uint32_t a = 0;
+    for (uint32_t c = b.cigar_off[i]; c < b.cigar_off[i + 1]; c++) {
+        const uint32_t op = b.cigar[c] & 15u, len = b.cigar[c] >> 4;
+        if (op == 0 || op == 1 || op == 7 || op == 8 || (with_del && op == 2)) a += len;
+    }
+    return a;
+}
+uint64_t nm_or_die(const cov_batch &b, uint64_t i) {
+    if (b.nm_kind[i] == COV_NM_UNSIGNED) return b.nm[i];
+    die(b.nm_kind[i] == COV_NM_ABSENT ? "Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM format"
+                                      : "Unexpected data type of NM aux tag");
+}
+bool single_ok(const cov_batch &b, uint64_t i, const Filter &f) {   // filter.rs:243-279
+    if (f.mapq != 255 && (b.mapq[i] < f.mapq || b.mapq[i] == 255)) return false;
+    const uint64_t e = nm_or_die(b, i);
+    const uint32_t al = aligned_of(b, i, true);
+    return al >= f.len_single && (float)al / (float)b.l_seq[i] >= f.pct_single && 1.0f - (float)e / (float)al >= f.pid_single;
+}
+bool pair_ok(const cov_batch &b, uint64_t i2, uint64_t i1, const Filter &f) {   // filter.rs:281-336
+    if (f.mapq != 255 && (b.mapq[i1] < f.mapq || b.mapq[i2] < f.mapq || b.mapq[i1] == 255 || b.mapq[i2] == 255)) return false;
+    const uint64_t e = nm_or_die(b, i2) + nm_or_die(b, i1);
+    const uint32_t al = aligned_of(b, i2, false) + aligned_of(b, i1, false);
+    return al >= f.len_pair && (float)al / (float)((uint64_t)b.l_seq[i1] + b.l_seq[i2]) >= f.pct_pair &&
+           1.0f - (float)e / (float)al >= f.pid_pair;
+}
+std::vector<uint64_t> pair_mode_order(const covh_bam *h, const cov_batch &b, const Filter &f) {
+    bool fs, fp;
+    f.mode(fs, fp);
+    const int32_t *mtid = covh_bam_mtid(h);
+    const uint32_t *qo = covh_bam_qname_off(h);
+    const char *qn = covh_bam_qnames(h);
+    std::vector<uint64_t> order;
+    std::unordered_map<std::string, uint64_t> first_set;
+    int32_t cur = -1;
+    for (uint64_t i = 0; i < b.n_records; i++) {
+        const uint16_t flag = b.flag[i];
+        if ((flag & 0x900) || !(flag & 0x2)) continue;
+        if (b.tid[i] != cur) { cur = b.tid[i]; first_set.clear(); }
+        std::string q(qn + qo[i], qo[i + 1] - qo[i]);
+        auto it = first_set.find(q);
+        if (it == first_set.end()) { if (mtid[i] == cur) first_set.emplace(std::move(q), i); }
+        else {
+            const uint64_t i1 = it->second;
+            first_set.erase(it);
+            if ((!fs || (single_ok(b, i1, f) && single_ok(b, i, f))) && pair_ok(b, i, i1, f)) { order.push_back(i1); order.push_back(i); }
+        }
+    }
+    return order;
+}
+
+void check(cov_session *s, cov_status st) { if (st != COV_OK) die(cov_last_error(s)); }
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    Args a;
+    if (argc < 2 || (strcmp(argv[1], "contig") && strcmp(argv[1], "genome"))) {
+        fprintf(stderr, "usage: coverm-amd contig|genome -b <bam>... [-m <methods>...] [options]   (see src/cli.rs of CoverM for the flags)\n");
+        return 2;
+    }
+    a.mode = argv[1];
+    auto collect = [&](int &i, std::vector<std::string> &dst) { while (i + 1 < argc && argv[i + 1][0] != '-') dst.push_back(argv[++i]); };
+    for (int i = 2; i < argc; i++) {
+        const std::string k = argv[i];
+        auto val = [&]() -> const char * { if (i + 1 >= argc) die("missing value for " + k); return argv[++i]; };
+        if (k == "-b" || k == "--bam-files") collect(i, a.bams);
+        else if (k == "-m" || k == "--methods") collect(i, a.methods);
+        else if (k == "--min-covered-fraction") a.min_covered_fraction = val();
+        else if (k == "--contig-end-exclusion") a.contig_end_exclusion = strtoull(val(), nullptr, 10);
+        else if (k == "--trim-min") a.trim_min = val();
+        else if (k == "--trim-max") a.trim_max = val();
+        else if (k == "--output-format") a.output_format = val();
+        else if (k == "-o" || k == "--output-file") a.output_file = val();
+        else if (k == "--no-zeros") a.no_zeros = true;
+        else if (k == "--proper-pairs-only") a.proper_pairs_only = true;
+        else if (k == "--exclude-supplementary") a.exclude_supplementary = true;
+        else if (k == "--include-secondary") a.include_secondary = true;
+        else if (k == "--min-read-aligned-length") a.min_aligned_length = (uint32_t)strtoul(val(), nullptr, 10);
+        else if (k == "--min-read-percent-identity") a.min_pid = val();
+        else if (k == "--min-read-aligned-percent") a.min_aligned_pct = val();
+        else if (k == "--min-read-aligned-length-pair") a.min_aligned_length_pair = (uint32_t)strtoul(val(), nullptr, 10);
+        else if (k == "--min-read-percent-identity-pair") a.min_pid_pair = val();
+        else if (k == "--min-read-aligned-percent-pair") a.min_aligned_pct_pair = val();
+        else if (k == "--min-mapq") a.min_mapq = atoi(val());
+        else if (k == "-s" || k == "--separator") { a.separator = val()[0]; a.have_separator = true; }
+        else if (k == "--single-genome") a.single_genome = true;
+        else if (k == "--genome-definition") a.genome_definition = val();
+        else if (k == "-t" || k == "--threads") a.threads = atoi(val());
+        else if (k == "--device") a.device = atoi(val());
+        else die("unknown argument " + k);
+    }
+    if (a.bams.empty()) die("--bam-files is required (read mapping is out of scope for this engine)");
+    const bool contig = a.mode == "contig";
+    if (a.methods.empty()) a.methods.push_back(contig ? "mean" : "relative_abundance");   // cli.rs:2521, 2048
+    if (!a.min_covered_fraction) a.min_covered_fraction = contig ? "0" : "10";            // cli.rs:2528, 2065
+
+    // ---- EstimatorsAndTaker::generate_from_clap
+    const float mcf = parse_percentage(a.min_covered_fraction);
+    const uint64_t excl = a.contig_end_exclusion;
+    std::vector<covh_estimator> est;
+    std::vector<int64_t> norm;
+    int64_t rpkm = -1, tpm = -1;
+    int printer = 0, taker_kind = COVH_TAKER_STREAM;
+    auto E = [&](int kind, float mf, uint64_t ex, float t0 = 0, float t1 = 0) {
+        covh_estimator e; e.kind = kind; e.min_fraction_covered_bases = mf; e.contig_end_exclusion = ex;
+        e.exclude_mismatches = 0; e.trim_min = t0; e.trim_max = t1; est.push_back(e);
+    };
+    Filter f;
+    f.improper = !a.proper_pairs_only; f.supp = !a.exclude_supplementary; f.sec = a.include_secondary;
+    f.len_single = a.min_aligned_length; f.pid_single = parse_percentage(a.min_pid); f.pct_single = parse_percentage(a.min_aligned_pct);
+    f.mapq = a.min_mapq; f.len_pair = a.min_aligned_length_pair; f.pid_pair = parse_percentage(a.min_pid_pair);
+    f.pct_pair = parse_percentage(a.min_aligned_pct_pair);
+    const bool metabat = a.methods.size() == 1 && a.methods[0] == "metabat";
+    for (auto &m : a.methods) if (m == "metabat" && a.methods.size() > 1) die("Cannot specify the metabat method with any other coverage methods");
+    if (metabat) {
+        E(COVH_LENGTH, 0, 0); E(COVH_MEAN, mcf, excl); E(COVH_VARIANCE, mcf, excl);
+        taker_kind = COVH_TAKER_CACHED; printer = 3;
+        f.pid_single = 0.97001f; f.improper = f.supp = f.sec = true;   // coverm.rs:1680-1693
+    } else {
+        for (size_t i = 0; i < a.methods.size(); i++) {
+            const std::string &m = a.methods[i];
+            if (m == "mean") E(COVH_MEAN, mcf, excl);
+            else if (m == "coverage_histogram") E(COVH_PILEUP_COUNTS, mcf, excl);
+            else if (m == "trimmed_mean") E(COVH_TRIMMED_MEAN, mcf, excl, parse_percentage(a.trim_min), parse_percentage(a.trim_max));
+            else if (m == "covered_fraction") E(COVH_COVERED_FRACTION, mcf, 0);
+            else if (m == "covered_bases") E(COVH_COVERED_BASES, mcf, 0);
+            else if (m == "rpkm") { if (rpkm >= 0) die("The RPKM column cannot be specified more than once"); rpkm = (int64_t)i; E(COVH_RPKM, mcf, 0); }
+            else if (m == "tpm") { if (tpm >= 0) die("The TPM column cannot be specified more than once"); tpm = (int64_t)i; E(COVH_TPM, mcf, 0); }
+            else if (m == "variance") E(COVH_VARIANCE, mcf, excl);
+            else if (m == "length") E(COVH_LENGTH, 0, 0);
+            else if (m == "relative_abundance") { norm.push_back((int64_t)i); E(COVH_MEAN, mcf, excl); }
+            else if (m == "count") E(COVH_READ_COUNT, 0, 0);
+            else if (m == "reads_per_base") E(COVH_READS_PER_BASE, 0, 0);
+            else if (m == "anir") E(COVH_ANIR, 0, 0);
+            else die("unknown method " + m);
+        }
+        bool hist_method = false;
+        for (auto &m : a.methods) hist_method |= m == "coverage_histogram";
+        if (hist_method) {
+            if (a.methods.size() > 1) die("Cannot specify the coverage_histogram method with any other coverage methods");
+            taker_kind = COVH_TAKER_PILEUP; printer = 0;
+        } else if (norm.empty() && rpkm < 0 && tpm < 0 && a.output_format == "sparse") { taker_kind = COVH_TAKER_STREAM; printer = 0; }
+        else { taker_kind = COVH_TAKER_CACHED; printer = a.output_format == "sparse" ? 1 : 2; }
+        if (mcf != 0.0f)
+            for (auto &e : est)
+                if (e.kind == COVH_READ_COUNT || e.kind == COVH_LENGTH || e.kind == COVH_READS_PER_BASE || e.kind == COVH_ANIR)
+                    die("this coverage estimator cannot be used when --min-covered-fraction is > 0");
+    }
+    static const char *HDR[] = {"Mean", "Trimmed Mean", "Coverage\tBases", "Covered Fraction", "Covered Bases", "RPKM", "TPM",
+                                "Variance", "Length", "Read Count", "Reads per base", "ANIr"};
+    std::vector<std::string> headers;
+    for (auto &e : est) {
+        if (e.kind == COVH_PILEUP_COUNTS) { headers.push_back("Coverage"); headers.push_back("Bases"); }
+        else headers.push_back(HDR[e.kind]);
+    }
+    for (int64_t i : norm) headers[(size_t)i] = "Relative Abundance (%)";
+    std::vector<const char *> hptr;
+    for (auto &h : headers) hptr.push_back(h.c_str());
+    const char *entry_type = contig ? "Contig" : "Genome";
+    covh_taker *taker = covh_taker_new(taker_kind, est.size());
+    covh_print_headers(taker, printer, entry_type, hptr.data(), hptr.size());
+
+    // ---- genome definition
+    std::vector<std::string> genomes;
+    std::unordered_map<std::string, int32_t> c2g;
+    const bool by_names = !contig && !a.have_separator && !a.single_genome;
+    if (by_names) {
+        if (a.genome_definition.empty()) die("genome mode over BAM files needs --separator, --single-genome or --genome-definition");
+        FILE *fh = fopen(a.genome_definition.c_str(), "r");
+        if (!fh) die("cannot open " + a.genome_definition);
+        char line[1 << 16];
+        std::unordered_map<std::string, int32_t> gi;
+        while (fgets(line, sizeof line, fh)) {   // genome_parsing.rs:77-141
+            std::string l(line);
+            while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+            if (l.empty()) continue;
+            const size_t t = l.find('\t');
+            if (t == std::string::npos || l.find('\t', t + 1) != std::string::npos) die("Unexpected line in genome definition file");
+            const std::string g = l.substr(0, t), c = l.substr(t + 1);
+            auto it = gi.find(g);
+            if (it == gi.end()) { it = gi.emplace(g, (int32_t)genomes.size()).first; genomes.push_back(g); }
+            c2g[c] = it->second;
+        }
+        fclose(fh);
+    }
+
+    // ---- per BAM: decode (host threads), push, finish
+    const uint32_t want = covh_wants(est.data(), est.size());
+    std::vector<Sample> samples(a.bams.size());
+    std::string names_blob; std::vector<uint32_t> name_off; std::vector<uint64_t> tlen;
+    std::vector<int32_t> genome_of_tid;
+    for (size_t bi = 0; bi < a.bams.size(); bi++) {
+        char err[512] = {0};
+        bool fs = false, fp = false;
+        if (f.doing_filtering()) f.mode(fs, fp);
+        covh_bam *bam = covh_bam_open(a.bams[bi].c_str(), a.threads, fp ? 1 : 0, err, sizeof err);
+        if (!bam) die(err);
+        const uint32_t nt = covh_bam_n_targets(bam);
+        if (bi == 0) {
+            name_off.push_back(0);
+            for (uint32_t t = 0; t < nt; t++) { names_blob += covh_bam_target_name(bam, t); name_off.push_back((uint32_t)names_blob.size()); tlen.push_back(covh_bam_target_len(bam, t)); }
+        } else if (nt != tlen.size()) die("all BAM files must have the same set of reference sequences");
+        std::vector<uint8_t> mask;
+        if (by_names) {
+            genome_of_tid.assign(nt, -1); mask.assign(nt, 0);
+            uint32_t in = 0;
+            for (uint32_t t = 0; t < nt; t++) {
+                auto it = c2g.find(covh_bam_target_name(bam, t));
+                if (it != c2g.end()) { genome_of_tid[t] = it->second; mask[t] = 1; in++; }
+            }
+            if (!in) die("Error: There are no found reference sequences that are a part of a genome");
+        }
+        cov_config cfg; memset(&cfg, 0, sizeof cfg);
+        cfg.device = a.device; cfg.include_improper_pairs = f.improper; cfg.include_supplementary = f.supp;
+        cfg.include_secondary = f.sec; cfg.min_mapq = 255; cfg.contig_end_exclusion = excl; cfg.want = want;
+        cov_batch batch; covh_bam_batch(bam, &batch);
+        Sample &S = samples[bi];
+        // stoit name = file stem (bam_generator.rs:358-365)
+        { std::string p = a.bams[bi]; size_t sl = p.find_last_of('/'); if (sl != std::string::npos) p = p.substr(sl + 1);
+          size_t dot = p.find_last_of('.'); S.stoit = dot == std::string::npos ? p : p.substr(0, dot); }
+        std::vector<int32_t> stid, spos; std::vector<uint16_t> sflag; std::vector<uint8_t> smapq, snmk;
+        std::vector<uint32_t> snm, slseq, scoff, scig;
+        bool prim_from_host = false;
+        if (f.doing_filtering()) {
+            if (fs && !fp) {
+                cfg.filter_single = 1; cfg.min_mapq = (uint8_t)f.mapq; cfg.min_aligned_length = f.len_single;
+                cfg.min_percent_identity = f.pid_single; cfg.min_aligned_percent = f.pct_single;
+            } else {
+                for (uint64_t i = 0; i < batch.n_records; i++) if (!(batch.flag[i] & 0x900)) S.prim++;   // filter.rs:129-131
+                prim_from_host = true;
+                const std::vector<uint64_t> order = pair_mode_order(bam, batch, f);
+                scoff.push_back(0);
+                for (uint64_t i : order) {
+                    stid.push_back(batch.tid[i]); spos.push_back(batch.pos[i]); sflag.push_back(batch.flag[i]);
+                    smapq.push_back(batch.mapq[i]); snmk.push_back(batch.nm_kind[i]); snm.push_back(batch.nm[i]);
+                    slseq.push_back(batch.l_seq[i]);
+                    for (uint32_t c = batch.cigar_off[i]; c < batch.cigar_off[i + 1]; c++) scig.push_back(batch.cigar[c]);
+                    scoff.push_back((uint32_t)scig.size());
+                }
+                if (scig.empty()) scig.push_back(0);
+                batch.tid = stid.data(); batch.pos = spos.data(); batch.flag = sflag.data(); batch.mapq = smapq.data();
+                batch.nm_kind = snmk.data(); batch.nm = snm.data(); batch.l_seq = slseq.data();
+                batch.cigar_off = scoff.data(); batch.cigar = scig.data(); batch.n_records = order.size();
+            }
+        }
+        cov_session *s = nullptr;
+        if (cov_create(&cfg, &s) != COV_OK) die(cov_last_error(nullptr));
+        check(s, cov_set_targets(s, nt, tlen.data()));
+        if (by_names) check(s, cov_set_target_mask(s, mask.data()));
+        check(s, cov_push_batch(s, &batch));
+        S.stats.resize(nt);
+        cov_summary summ;
+        check(s, cov_finish(s, S.stats.data(), &summ));
+        if (want & COV_WANT_HIST) { S.hist.resize(summ.hist_total); check(s, cov_fetch_hist(s, S.hist.data())); }
+        if (!prim_from_host) S.prim = summ.num_detected_primary_alignments;
+        cov_destroy(s);
+        covh_bam_close(bam);
+    }
+
+    covh_header hdr; hdr.n_targets = (uint32_t)tlen.size(); hdr.names = names_blob.c_str(); hdr.name_off = name_off.data(); hdr.target_len = tlen.data();
+    std::vector<covh_sample> hs(samples.size());
+    for (size_t i = 0; i < samples.size(); i++) {
+        hs[i].stoit_name = samples[i].stoit.c_str(); hs[i].stats = samples[i].stats.data();
+        hs[i].hist = samples[i].hist.empty() ? nullptr : samples[i].hist.data();
+        hs[i].num_detected_primary_alignments = samples[i].prim;
+    }
+    std::vector<covh_reads_mapped> rm(samples.size());
+    int rc;
+    if (contig) rc = covh_contig_coverage(&hdr, hs.data(), hs.size(), taker, est.data(), est.size(), !a.no_zeros, rm.data());
+    else if (a.have_separator || a.single_genome)
+        rc = covh_genome_coverage_separator(&hdr, hs.data(), hs.size(), (uint8_t)(a.single_genome ? '0' : a.separator), taker,
+                                            !a.no_zeros, est.data(), est.size(), a.single_genome, rm.data());
+    else {
+        std::vector<const char *> gn;
+        for (auto &g : genomes) gn.push_back(g.c_str());
+        rc = covh_genome_coverage_with_contig_names(&hdr, hs.data(), hs.size(), genome_of_tid.data(), gn.data(), gn.size(), taker,
+                                                    !a.no_zeros, est.data(), est.size(), rm.data());
+    }
+    if (rc != COV_OK) die(covh_last_error());
+    for (size_t i = 0; i < samples.size(); i++)   // contig.rs:233-240
+        fprintf(stderr, "[coverm-amd] In sample '%s', found %llu reads mapped out of %llu total (%.2f%%)\n", samples[i].stoit.c_str(),
+                (unsigned long long)rm[i].num_mapped_reads, (unsigned long long)rm[i].num_reads,
+                (double)(rm[i].num_mapped_reads * 100) / (double)rm[i].num_reads);
+    covh_finalise_printing(taker, printer, entry_type, hptr.data(), hptr.size(), rm.data(), rm.size(), norm.data(), norm.size(), rpkm, tpm);
+    size_t len = 0;
+    const char *txt = covh_taker_text(taker, &len);
+    FILE *out = a.output_file.empty() || a.output_file == "-" ? stdout : fopen(a.output_file.c_str(), "w");
+    if (!out) die("Failed to create output file: " + a.output_file);
+    fwrite(txt, 1, len, out);
+    if (out != stdout) fclose(out);
+    covh_taker_free(taker);
+    return 0;
+}

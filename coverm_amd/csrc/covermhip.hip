@@ -61,6 +61,9 @@ struct cov_session {
     std::string err;
     int tile = 4096;  // bases per k_pileup workgroup (COVERM_TILE = 4096 | 8192 | 16384)
     int nt = 256;     // k_pileup workgroup size (COVERM_PILEUP_NT)
+    int stream_rows = 4;   // > 0: k_pileup_stream with tiles of rows*256 bases per wave (COVERM_PILEUP=stream|tile, COVERM_ROWS)
+    int chunk_tiles = 8;   // consecutive tiles walked by one wave (COVERM_CHUNK)
+    int n_cus = 256;
     uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
 
     // targets
@@ -84,6 +87,7 @@ struct cov_session {
     bool adopted = false;
     cov_batch adopted_batch{};
     uint64_t adopted_ncig = 0;
+    uint32_t adopted_cig_end = 0;
 
     DevBuf<uint2> d_runs;
     DevBuf<double> d_ident;
@@ -115,6 +119,7 @@ Records records_of(const cov_session *s) {
         r.nm_kind = s->s_nmk.p; r.l_seq = s->s_lseq.p; r.cigar_off = s->s_coff.p; r.cigar = s->s_cig.p;
     }
     r.n = (u32)s->n_records;
+    r.cigar_end = s->adopted ? s->adopted_cig_end : (u32)s->n_cigar;
     return r;
 }
 
@@ -192,6 +197,29 @@ void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
     }
 }
 
+template <int ROWS, bool H, bool W>
+void launch_stream_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
+    const size_t smem = pileup_stream_smem_bytes(ROWS);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_stream<ROWS, H, W>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    const u32 chunk = (u32)s->chunk_tiles;
+    const u32 n_chunks = (n_tiles + chunk - 1) / chunk;
+    const u32 wg_per_cu = (u32)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
+    const u32 grid = std::max(1u, std::min((n_chunks + 3) / 4, (u32)s->n_cus * wg_per_cu));
+    hipLaunchKernelGGL((k_pileup_stream<ROWS, H, W>), dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
+}
+// dispatches to the configured pileup kernel
+template <bool H, bool W>
+void launch_any_pileup(cov_session *s, const PileupArgs &a, u32 n_tiles) {
+    if (s->stream_rows == 8) launch_stream_t<8, H, W>(s, a, n_tiles);
+    else if (s->stream_rows == 4) launch_stream_t<4, H, W>(s, a, n_tiles);
+    else launch_pileup<H, W>(s, a, n_tiles);
+}
+
 PileupArgs pileup_args(cov_session *s) {
     PileupArgs a{};
     a.tile_contig = s->d_tile_contig.p; a.tile_start = s->d_tile_start.p; a.desc = s->d_desc.p;
@@ -231,6 +259,15 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
         else if (t == 8192) n = (n == 256) ? 256 : 512;
         else n = (n == 128) ? 128 : 256;
         s->tile = t; s->nt = n;
+        const char *mode = getenv("COVERM_PILEUP"), *rows = getenv("COVERM_ROWS"), *chk = getenv("COVERM_CHUNK");
+        if (mode && !strcmp(mode, "tile")) s->stream_rows = 0;
+        else {
+            s->stream_rows = (rows && atoi(rows) == 8) ? 8 : 4;
+            s->tile = s->stream_rows * 256;
+        }
+        if (chk && atoi(chk) > 0) s->chunk_tiles = atoi(chk);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
     e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
@@ -331,6 +368,7 @@ cov_status cov_push_batch_device(cov_session *s, const cov_batch *b) {
         }
         s->adopted = true; s->adopted_batch = *b; s->n_records = b->n_records;
         s->adopted_ncig = (uint64_t)o1 - o0;
+        s->adopted_cig_end = o1;
         s->finished = false;
         return COV_OK;
     }
@@ -404,8 +442,8 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
         }
         PileupArgs a = pileup_args(s);
         time_begin(s, COV_K_PILEUP);
-        if (want_hist) launch_pileup<true, false>(s, a, s->n_tiles);
-        else launch_pileup<false, false>(s, a, s->n_tiles);
+        if (want_hist) launch_any_pileup<true, false>(s, a, s->n_tiles);
+        else launch_any_pileup<false, false>(s, a, s->n_tiles);
         time_end(s, COV_K_PILEUP);
         HIPCHK(hipGetLastError());
         if (want_id) {
@@ -530,7 +568,7 @@ cov_status cov_copy_depth(cov_session *s, uint32_t tid, int32_t *depth_out) {
     a.depth_out = s->d_depth.p;
     a.tile_base = s->h_tile_first[tid];
     const u32 grid = s->h_tile_first[tid + 1] - s->h_tile_first[tid];
-    launch_pileup<false, true>(s, a, grid);
+    launch_any_pileup<false, true>(s, a, grid);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(depth_out, s->d_depth.p, (size_t)L * 4, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));

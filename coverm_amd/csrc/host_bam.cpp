@@ -1,0 +1,345 @@
+// BGZF / BAM / SAM reader of the host layer (include/coverm_host.h, covh_bam_*).
+//
+// The reference reads alignments through rust-htslib -> htslib (not vendored): bam::Reader::from_path
+// bam_generator.rs:366, Reader::read :114, set_threads(n-1) = BGZF inflate pool :125-129.  This file
+// restates the published container formats (SAM spec section 4: BGZF blocks, BAM header, alignment record
+// layout, aux encoding) and yields exactly the fields the scan consumes, as the SoA batch of covermhip.h:
+// tid, pos, flag, mapq, l_seq, NM (+ how it was typed, lib.rs:138-158), raw CIGAR; plus read names and mate
+// tid for pair-mode filtering (filter.rs:164-176).
+//
+// Decode strategy: BGZF blocks are independent gzip members, so the file is split at block boundaries and
+// inflated by a pool of threads straight into one contiguous buffer (offsets from each block's ISIZE);
+// record boundaries are then found in one cheap serial hop over block_size fields and the per-record field
+// extraction (including the linear aux scan for NM) runs in parallel again.
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/coverm_host.h"
+
+namespace {
+
+struct Bam {
+    std::string path, err;
+    std::vector<std::string> names;
+    std::vector<uint64_t> lens;
+    std::string header_text;
+    // SoA
+    std::vector<int32_t> tid, pos, mtid;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq, nm_kind;
+    std::vector<uint32_t> nm, l_seq, cigar_off, cigar, qname_off;
+    std::string qnames;
+    int threads = 1;
+    bool want_names = false;
+};
+
+inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+
+bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &err) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { err = "Unable to find BAM file " + path; return false; }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    size_t got = n > 0 ? fread(out.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    if (got != out.size()) { err = "short read on " + path; return false; }
+    return true;
+}
+
+template <typename F>
+void parallel_for(size_t n, int threads, F fn) {
+    threads = std::max(1, std::min<int>(threads, (int)std::max<size_t>(1, n)));
+    if (threads == 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    std::atomic<size_t> next{0};
+    const size_t grain = std::max<size_t>(1, n / (threads * 16));
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back([&]() {
+            for (;;) {
+                size_t b = next.fetch_add(grain);
+                if (b >= n) break;
+                size_t e = std::min(n, b + grain);
+                for (size_t i = b; i < e; i++) fn(i);
+            }
+        });
+    for (auto &th : pool) th.join();
+}
+
+// ---- BGZF: block table, parallel inflate
+bool bgzf_inflate_all(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out, int threads, std::string &err) {
+    struct Blk { size_t in_off, in_len; size_t out_off; uint32_t isize, crc; };
+    std::vector<Blk> blocks;
+    size_t p = 0, total = 0;
+    while (p < raw.size()) {
+        if (p + 18 > raw.size() || raw[p] != 0x1f || raw[p + 1] != 0x8b || raw[p + 2] != 8 || !(raw[p + 3] & 4)) {
+            err = "not a BGZF block"; return false;
+        }
+        const uint16_t xlen = rd16(&raw[p + 10]);
+        size_t q = p + 12, bsize = 0;
+        while (q + 4 <= p + 12 + xlen) {
+            const uint16_t slen = rd16(&raw[q + 2]);
+            if (raw[q] == 66 && raw[q + 1] == 67 && slen == 2) bsize = (size_t)rd16(&raw[q + 4]) + 1;
+            q += 4 + slen;
+        }
+        if (bsize == 0 || p + bsize > raw.size()) { err = "truncated BGZF block"; return false; }
+        Blk b;
+        b.in_off = p + 12 + xlen; b.in_len = bsize - 12 - xlen - 8;
+        b.crc = rd32(&raw[p + bsize - 8]); b.isize = rd32(&raw[p + bsize - 4]);
+        b.out_off = total;
+        total += b.isize;
+        blocks.push_back(b);
+        p += bsize;
+    }
+    out.resize(total);
+    std::atomic<bool> ok{true};
+    parallel_for(blocks.size(), threads, [&](size_t i) {
+        const Blk &b = blocks[i];
+        if (b.isize == 0) return;
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) { ok = false; return; }
+        zs.next_in = const_cast<Bytef *>(&raw[b.in_off]); zs.avail_in = (uInt)b.in_len;
+        zs.next_out = &out[b.out_off]; zs.avail_out = b.isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END || zs.total_out != b.isize) { ok = false; return; }
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), &out[b.out_off], b.isize) != b.crc) ok = false;
+    });
+    if (!ok) { err = "BGZF inflate / CRC failure"; return false; }
+    return true;
+}
+
+// linear aux scan for NM (what htslib's bam_aux_get does); returns nm_kind
+uint8_t scan_nm(const uint8_t *p, const uint8_t *end, uint32_t &nm) {
+    while (p + 3 <= end) {
+        const bool is_nm = p[0] == 'N' && p[1] == 'M';
+        const uint8_t t = p[2];
+        p += 3;
+        size_t sz = 0;
+        switch (t) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'Z': case 'H': {
+            const uint8_t *z = (const uint8_t *)memchr(p, 0, (size_t)(end - p));
+            if (is_nm) return COV_NM_BADTYPE;
+            if (!z) return COV_NM_ABSENT;
+            p = z + 1;
+            continue;
+        }
+        case 'B': {
+            if (p + 5 > end) return COV_NM_ABSENT;
+            const uint8_t st = p[0];
+            const uint32_t cnt = rd32(p + 1);
+            const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+            if (is_nm) return COV_NM_BADTYPE;
+            p += 5 + (size_t)cnt * es;
+            continue;
+        }
+        default: return COV_NM_ABSENT;  // malformed aux area
+        }
+        if (is_nm) {
+            if (p + sz > end) return COV_NM_ABSENT;
+            if (t == 'C') { nm = p[0]; return COV_NM_UNSIGNED; }
+            if (t == 'S') { nm = rd16(p); return COV_NM_UNSIGNED; }
+            if (t == 'I') { nm = rd32(p); return COV_NM_UNSIGNED; }
+            return COV_NM_BADTYPE;   // c / s / i / A / f : the reference panics (lib.rs:144-147)
+        }
+        p += sz;
+    }
+    return COV_NM_ABSENT;
+}
+
+bool parse_bam(Bam &b, const std::vector<uint8_t> &u) {
+    if (u.size() < 12 || memcmp(u.data(), "BAM\1", 4) != 0) { b.err = "bad BAM magic"; return false; }
+    size_t p = 4;
+    const uint32_t l_text = rd32(&u[p]); p += 4;
+    if (p + l_text + 4 > u.size()) { b.err = "truncated BAM header"; return false; }
+    b.header_text.assign((const char *)&u[p], l_text); p += l_text;
+    const uint32_t n_ref = rd32(&u[p]); p += 4;
+    b.names.reserve(n_ref); b.lens.reserve(n_ref);
+    for (uint32_t i = 0; i < n_ref; i++) {
+        if (p + 4 > u.size()) { b.err = "truncated BAM header"; return false; }
+        const uint32_t l_name = rd32(&u[p]); p += 4;
+        if (p + l_name + 4 > u.size()) { b.err = "truncated BAM header"; return false; }
+        b.names.emplace_back((const char *)&u[p], l_name ? l_name - 1 : 0); p += l_name;
+        b.lens.push_back(rd32(&u[p])); p += 4;
+    }
+    // record boundaries: one serial hop over block_size
+    std::vector<size_t> rec;
+    while (p + 4 <= u.size()) {
+        const uint32_t bs = rd32(&u[p]);
+        if (bs < 32 || p + 4 + bs > u.size()) { b.err = "truncated BAM record"; return false; }
+        rec.push_back(p);
+        p += 4 + (size_t)bs;
+    }
+    const size_t R = rec.size();
+    b.tid.resize(R); b.pos.resize(R); b.mtid.resize(R); b.flag.resize(R); b.mapq.resize(R); b.nm_kind.resize(R);
+    b.nm.resize(R); b.l_seq.resize(R); b.cigar_off.assign(R + 1, 0);
+    if (b.want_names) b.qname_off.assign(R + 1, 0);
+    // offsets (serial, trivial) then parallel field extraction
+    for (size_t i = 0; i < R; i++) {
+        const uint8_t *r = &u[rec[i]];
+        b.cigar_off[i + 1] = b.cigar_off[i] + rd16(r + 16);
+        if (b.want_names) b.qname_off[i + 1] = b.qname_off[i] + (r[12] ? r[12] - 1u : 0u);
+    }
+    b.cigar.resize(b.cigar_off[R]);
+    if (b.want_names) b.qnames.resize(b.qname_off[R]);
+    std::atomic<bool> ok{true};
+    parallel_for(R, b.threads, [&](size_t i) {
+        const uint8_t *r = &u[rec[i]];
+        const uint32_t bs = rd32(r);
+        const uint8_t *end = r + 4 + bs;
+        b.tid[i] = (int32_t)rd32(r + 4); b.pos[i] = (int32_t)rd32(r + 8);
+        const uint32_t l_read_name = r[12];
+        b.mapq[i] = r[13];
+        const uint32_t n_cig = rd16(r + 16);
+        b.flag[i] = rd16(r + 18);
+        const uint32_t l_seq = rd32(r + 20);
+        b.l_seq[i] = l_seq;
+        b.mtid[i] = (int32_t)rd32(r + 24);
+        const uint8_t *q = r + 36;
+        if (q + l_read_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq > end) { ok = false; return; }
+        if (b.want_names && l_read_name) memcpy(&b.qnames[b.qname_off[i]], q, l_read_name - 1);
+        q += l_read_name;
+        if (n_cig) memcpy(&b.cigar[b.cigar_off[i]], q, 4ull * n_cig);
+        q += 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
+        uint32_t nm = 0;
+        b.nm_kind[i] = scan_nm(q, end, nm);
+        b.nm[i] = nm;
+    });
+    if (!ok) { b.err = "corrupt BAM record"; return false; }
+    return true;
+}
+
+// ---- SAM text (htslib auto-detects the format; needed for e.g. tests/data/mapq_test.sam, filter.rs:758)
+bool parse_sam(Bam &b, const std::vector<uint8_t> &raw) {
+    const char *s = (const char *)raw.data(), *e = s + raw.size();
+    std::vector<std::pair<std::string, size_t>> dummy;
+    auto find_ref = [&](const std::string &n) -> int32_t {
+        for (size_t i = 0; i < b.names.size(); i++) if (b.names[i] == n) return (int32_t)i;
+        return -1;
+    };
+    b.cigar_off.assign(1, 0);
+    if (b.want_names) b.qname_off.assign(1, 0);
+    while (s < e) {
+        const char *nl = (const char *)memchr(s, '\n', (size_t)(e - s));
+        const char *le = nl ? nl : e;
+        std::string line(s, le);
+        s = nl ? nl + 1 : e;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '@') {
+            b.header_text += line; b.header_text += '\n';
+            if (line.compare(0, 3, "@SQ") == 0) {
+                std::string sn; uint64_t ln = 0;
+                size_t p = 3;
+                while (p < line.size()) {
+                    size_t t = line.find('\t', p + 1);
+                    std::string f = line.substr(p + 1, t == std::string::npos ? std::string::npos : t - p - 1);
+                    if (f.compare(0, 3, "SN:") == 0) sn = f.substr(3);
+                    else if (f.compare(0, 3, "LN:") == 0) ln = strtoull(f.c_str() + 3, nullptr, 10);
+                    if (t == std::string::npos) break;
+                    p = t;
+                }
+                b.names.push_back(sn); b.lens.push_back(ln);
+            }
+            continue;
+        }
+        std::vector<std::string> f;
+        size_t p = 0;
+        for (;;) {
+            size_t t = line.find('\t', p);
+            f.push_back(line.substr(p, t == std::string::npos ? std::string::npos : t - p));
+            if (t == std::string::npos) break;
+            p = t + 1;
+        }
+        if (f.size() < 11) { b.err = "malformed SAM line"; return false; }
+        const int32_t t = f[2] == "*" ? -1 : find_ref(f[2]);
+        b.tid.push_back(t);
+        b.flag.push_back((uint16_t)strtoul(f[1].c_str(), nullptr, 10));
+        b.pos.push_back((int32_t)strtol(f[3].c_str(), nullptr, 10) - 1);
+        b.mapq.push_back((uint8_t)strtoul(f[4].c_str(), nullptr, 10));
+        if (f[5] != "*") {
+            uint32_t num = 0;
+            for (char ch : f[5]) {
+                if (ch >= '0' && ch <= '9') num = num * 10 + (uint32_t)(ch - '0');
+                else {
+                    const char *ops = "MIDNSHP=X";
+                    const char *o = strchr(ops, ch);
+                    b.cigar.push_back((num << 4) | (uint32_t)(o ? o - ops : 15));
+                    num = 0;
+                }
+            }
+        }
+        b.cigar_off.push_back((uint32_t)b.cigar.size());
+        b.mtid.push_back(f[6] == "=" ? t : (f[6] == "*" ? -1 : find_ref(f[6])));
+        b.l_seq.push_back(f[9] == "*" ? 0u : (uint32_t)f[9].size());
+        uint32_t nm = 0; uint8_t k = COV_NM_ABSENT;
+        for (size_t a = 11; a < f.size(); a++) {
+            if (f[a].compare(0, 3, "NM:") == 0 && f[a].size() > 5) {
+                // htslib stores a SAM `i` value in the smallest fitting type; non-negative => unsigned
+                if (f[a][3] == 'i' && f[a][5] != '-') { nm = (uint32_t)strtoul(f[a].c_str() + 5, nullptr, 10); k = COV_NM_UNSIGNED; }
+                else k = COV_NM_BADTYPE;
+            }
+        }
+        b.nm.push_back(nm); b.nm_kind.push_back(k);
+        if (b.want_names) { b.qnames += f[0]; b.qname_off.push_back((uint32_t)b.qnames.size()); }
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+struct covh_bam { Bam b; };
+
+covh_bam *covh_bam_open(const char *path, int threads, int want_names, char *err, size_t errcap) {
+    covh_bam *h = new covh_bam();
+    h->b.path = path; h->b.threads = std::max(1, threads); h->b.want_names = want_names != 0;
+    std::vector<uint8_t> raw;
+    bool ok = read_file(path, raw, h->b.err);
+    if (ok) {
+        if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
+            std::vector<uint8_t> u;
+            ok = bgzf_inflate_all(raw, u, h->b.threads, h->b.err);
+            std::vector<uint8_t>().swap(raw);
+            if (ok) ok = parse_bam(h->b, u);
+        } else ok = parse_sam(h->b, raw);
+    }
+    if (!ok) {
+        if (err && errcap) { strncpy(err, h->b.err.c_str(), errcap - 1); err[errcap - 1] = 0; }
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+void covh_bam_close(covh_bam *h) { delete h; }
+uint32_t covh_bam_n_targets(const covh_bam *h) { return (uint32_t)h->b.names.size(); }
+const char *covh_bam_target_name(const covh_bam *h, uint32_t i) { return h->b.names[i].c_str(); }
+uint64_t covh_bam_target_len(const covh_bam *h, uint32_t i) { return h->b.lens[i]; }
+uint64_t covh_bam_n_records(const covh_bam *h) { return h->b.tid.size(); }
+void covh_bam_batch(const covh_bam *h, cov_batch *out) {
+    const Bam &b = h->b;
+    out->tid = b.tid.data(); out->pos = b.pos.data(); out->flag = b.flag.data(); out->mapq = b.mapq.data();
+    out->nm = b.nm.data(); out->nm_kind = b.nm_kind.data(); out->l_seq = b.l_seq.data();
+    out->cigar_off = b.cigar_off.data(); out->cigar = b.cigar.data(); out->n_records = b.tid.size();
+}
+const int32_t *covh_bam_mtid(const covh_bam *h) { return h->b.mtid.data(); }
+const uint32_t *covh_bam_qname_off(const covh_bam *h) { return h->b.qname_off.empty() ? nullptr : h->b.qname_off.data(); }
+const char *covh_bam_qnames(const covh_bam *h) { return h->b.qnames.data(); }
+uint64_t covh_bam_n_cigar(const covh_bam *h) { return h->b.cigar.size(); }
+
+}  // extern "C"

@@ -58,7 +58,10 @@ struct EntryAcc {
     u32 win_min_d = 0xffffffffu;
     double sum_identity = 0.0;
     std::vector<u64> hist;  // merged counts; hist.size() == counts.len()
-    void reset() { *this = EntryAcc(); }
+    void reset() {   // keeps hist's capacity: one reset per contig
+        win_len = win_sum_d = win_sum_d2 = win_covered = full_len = full_covered = n_reads = mismatches = 0;
+        win_min_d = 0xffffffffu; sum_identity = 0.0; hist.clear(); hist_len_only = 0;
+    }
     void add_contig(const cov_contig_stats &s, u64 L, u64 excl, u64 n, double identity, const u64 *h) {
         n_reads += n;
         mismatches += s.sum_nm - s.sum_indel;   // total_edit_distance - total_indels (u64 wrapping, contig.rs:59)

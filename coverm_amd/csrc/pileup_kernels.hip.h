@@ -79,6 +79,7 @@ struct Records {
     const u32 *cigar_off;
     const u32 *cigar;
     u32 n;
+    u32 cigar_end;   // one past the largest index cigar_off can address (for clamped speculative loads)
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -151,8 +152,9 @@ __global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g) {
 // per-lane running sums for the contig it is currently in and flushes them with one set of atomics
 // only when the contig changes: a single hot address costs ~12 ns per atomic on MI355X, so per-wave
 // (let alone per-record) atomics on the per-contig or global counters would dominate the kernel.
-constexpr int PREP_ITEMS = 16;
-constexpr int PREP_CHUNK = 256 * PREP_ITEMS;
+constexpr int PREP_B = 4;        // records per thread per pass: their loads are issued together
+constexpr int PREP_PASSES = 4;
+constexpr int PREP_CHUNK = 256 * PREP_B * PREP_PASSES;
 
 struct PrepAcc {
     u32 prim, pass, nons, span, first, last;
@@ -190,149 +192,172 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
     PrepAcc acc; acc.reset();
     int cur = -1;            // wave-uniform: contig the running sums belong to
     u32 g_prim = 0, g_cons = 0;
+    const u32 nlast = r.n - 1u;                                  // r.n > 0 (host never launches on an empty store)
+    const u32 cig_last = r.cigar_end ? r.cigar_end - 1u : 0u;
 
-    for (int it = 0; it < PREP_ITEMS; it++) {
-        const u32 i = chunk + (u32)it * 256u + threadIdx.x;
-        const bool in = i < r.n;
-        if (!__any(in)) break;
-        const u32 flag = in ? r.flag[i] : 0x904u;
-        const int tid = in ? r.tid[i] : -1;
-        const int pos = in ? r.pos[i] : 0;
-        // every record read counts towards num_detected_primary_alignments when !secondary && !supplementary
-        g_prim += (in && !(flag & 0x900u)) ? 1u : 0u;
-        const bool tid_ok = in && tid >= 0 && (u32)tid < n_targets;
-        // span of records carrying this tid + grouping / position-order checks (all records, considered or not)
-        if (tid_ok) {
-            const int ptid = i > 0 ? r.tid[i - 1] : -2;
-            if (ptid != tid) {
-                atomicMin(&ctg[tid].rec_start, i);
-                atomicAdd(&ctg[tid].n_groups, 1u);
-            } else if (r.pos[i - 1] > pos) {
-                atomicOr(&ctg[tid].flags, F_POS_UNSORTED);
-            }
-            const int ntid = (i + 1 < r.n) ? r.tid[i + 1] : -2;
-            if (ntid != tid) atomicMax(&ctg[tid].rec_end, i + 1);
+    for (int ps = 0; ps < PREP_PASSES; ps++) {
+        const u32 i0 = chunk + (u32)(ps * PREP_B) * 256u + threadIdx.x;
+        if (!__any(i0 < r.n)) break;
+        // ---- phase A: every independent field of PREP_B records, issued back to back (clamped, branch-free)
+        u32 fl[PREP_B], mq[PREP_B], nmk[PREP_B], nmv32[PREP_B], lsq[PREP_B], co0[PREP_B], co1[PREP_B];
+        int td[PREP_B], ps_[PREP_B], ptid[PREP_B], ppos[PREP_B], ntid[PREP_B];
+#pragma unroll
+        for (int k = 0; k < PREP_B; k++) {
+            const u32 i = i0 + (u32)k * 256u;
+            const u32 ic = min(i, nlast);
+            fl[k] = r.flag[ic]; td[k] = r.tid[ic]; ps_[k] = r.pos[ic]; mq[k] = r.mapq[ic]; nmk[k] = r.nm_kind[ic];
+            nmv32[k] = r.nm[ic]; lsq[k] = r.l_seq[ic]; co0[k] = r.cigar_off[ic]; co1[k] = r.cigar_off[ic + 1];
+            const u32 ip = ic > 0 ? ic - 1 : 0, in_ = min(ic + 1, nlast);
+            ptid[k] = r.tid[ip]; ppos[k] = r.pos[ip]; ntid[k] = r.tid[in_];
         }
-
-        const bool unmapped = flag & 0x4u;
-        const bool supp = flag & 0x800u, sec = flag & 0x100u;
-        // reader stage: ReferenceSortedBamFilter::read single-read branch, filter_out = true (filter.rs:88-116)
-        bool survives = in;
-        bool need_filter_eval = false;
-        if (f.filter_single) {
-            survives = false;
-            const bool p1 = in && !unmapped && (f.include_supplementary || !supp) && (f.include_secondary || !sec);
-            if (p1) {
-                const u32 mq = r.mapq[i];
-                if (!(f.min_mapq != 255u && (mq < f.min_mapq || mq == 255u))) need_filter_eval = true;  // :250-254
-            }
+        // ---- phase B: loads that depend on phase A (first three CIGAR words, contig length, mask)
+        u32 cw[PREP_B][3], Lc[PREP_B], mk[PREP_B];
+#pragma unroll
+        for (int k = 0; k < PREP_B; k++) {
+            const bool tok = td[k] >= 0 && (u32)td[k] < n_targets;
+            Lc[k] = tok ? tlen[td[k]] : 0u;
+            mk[k] = (tok && mask != nullptr) ? mask[td[k]] : 1u;
+#pragma unroll
+            for (int c = 0; c < 3; c++) cw[k][c] = r.cigar_end ? r.cigar[min(co0[k] + (u32)c, cig_last)] : 0u;
         }
-        // scan stage gate: FlagFilter::passes (lib.rs:67-78) then !unmapped (contig.rs:125)
-        const bool flags_ok = !(!f.include_secondary && sec) && !(!f.include_supplementary && supp) &&
-                              !(!f.include_improper_pairs && !(flag & 0x2u));
-        const bool scan_gate = in && flags_ok && !unmapped;
-
-        u64 aligned = 0, indel = 0;
-        u32 run_start = 0, run_len = 0, run2_start = 0, run2_len = 0, n_runs = 0, span = 0;
-        bool oob = false, badcig = false;
-        // with the reader-stage filter on, only records that reach single_read_passes_filter can survive
-        const bool do_walk = f.filter_single ? need_filter_eval : scan_gate;
-        if (do_walk) {
-            const u32 L = tid_ok ? tlen[tid] : 0u;
-            long long cursor = pos;
-            long long cur_e = -1;  // end of the open merged run
-            const u32 c0 = r.cigar_off[i], c1 = r.cigar_off[i + 1];
-            for (u32 c = c0; c < c1; c++) {
-                const u32 wd = r.cigar[c];
-                const u32 op = wd & 15u, len = wd >> 4;
-                if (op == 0u || op == 7u || op == 8u) {          // M = X  (contig.rs:171-186)
-                    if (cursor < 0 || cursor >= (long long)L) oob = true;
-                    if (n_runs > 0 && cursor == cur_e) {
-                        cur_e += len;
-                        if (n_runs == 1) run_len += len; else if (n_runs == 2) run2_len += len;
-                    } else {
-                        n_runs++;
-                        cur_e = cursor + len;
-                        if (n_runs == 1) { run_start = (u32)cursor; run_len = len; }
-                        else if (n_runs == 2) { run2_start = (u32)cursor; run2_len = len; }
-                    }
-                    cursor += len; aligned += len;
-                } else if (op == 2u) { cursor += len; indel += len; aligned += len; }  // D  (:187-191)
-                else if (op == 3u) { cursor += len; }                                  // N  (:192-195)
-                else if (op == 1u) { indel += len; aligned += len; }                   // I  (:196-199)
-                else if (op > 8u) badcig = true;                                       // S H P ignored (:200)
-            }
-            const long long sp = cursor - (long long)pos;
-            span = sp > 0 ? (u32)min(sp, (long long)0xffffffffu) : 0u;
-        }
-        if (need_filter_eval) {  // single_read_passes_filter, filter.rs:256-278
-            const u32 k = r.nm_kind[i];
-            if (k != 1u) report_error(g, i, k == 0u ? 2u : 3u);
-            else {
-                const u32 al = (u32)aligned;  // u32 accumulation in the reference
-                const float a = (float)al;
-                survives = al >= f.min_aligned_length && a / (float)r.l_seq[i] >= f.min_aligned_percent &&
-                           1.0f - (float)r.nm[i] / a >= f.min_percent_identity;
-            }
-        }
-        const bool considered = survives && scan_gate;
-        const bool masked_in = considered && tid_ok && (mask == nullptr || mask[tid]);
-        u64 nmv = 0;
-        double idv = 0.0;
-        if (considered && !tid_ok) report_error(g, i, 7u);  // header.target_len(tid).expect("Corrupt BAM file?")
-        if (masked_in) {
-            if (badcig) report_error(g, i, 6u);
-            else if (oob) report_error(g, i, 4u);
-            const u32 k = r.nm_kind[i];
-            if (k != 1u) report_error(g, i, k == 0u ? 2u : 3u);  // nm(&record), contig.rs:206
-            else nmv = r.nm[i];
-            if (WANT_IDENTITY && aligned > 0) idv = ((double)aligned - (double)nmv) / (double)aligned;
-        }
-        if (in) {
-            uint2 rw;
-            rw.x = 0u; rw.y = 0u;
-            if (masked_in && n_runs > 0) {
-                rw.x = run_start;
-                const u32 gap = run2_start - (run_start + run_len);
-                if (n_runs == 1 && run_len < (1u << 30)) rw.y = run_len;   // RW_SINGLE; 0 = nothing to add
-                else if (n_runs == 2 && run_len - 1u < 1023u && run2_len - 1u < 1023u && gap - 1u < 255u)
-                    rw.y = (RW_DOUBLE << 30) | run_len | (gap << 10) | (run2_len << 18);
-                else rw.y = RW_COMPLEX << 30;
-            }
-            runs[i] = rw;
-            if (WANT_IDENTITY) ident[i] = (masked_in && !supp) ? idv : 0.0;
-        }
-
-        // per-contig counters: accumulate per lane while the wave stays inside one contig
-        const bool cnt = considered && tid_ok;
-        g_cons += cnt ? 1u : 0u;
-        const u64 m = __ballot(cnt);
-        if (m != 0) {
-            const int ftid = __shfl(tid, __ffsll((long long)m) - 1);
-            const bool uni = __all(!cnt || tid == ftid);
-            if (uni) {
-                if (ftid != cur) { prep_flush(ctg, cur, acc); cur = ftid; }
-                if (cnt) {
-                    acc.prim += (!supp && !sec) ? 1u : 0u;
-                    acc.pass += 1u;
-                    acc.nons += supp ? 0u : 1u;
-                    acc.first = min(acc.first, i); acc.last = max(acc.last, i);
-                    if (masked_in) { acc.nm += nmv; acc.indel += indel; acc.span = max(acc.span, span); }
+        // ---- phase C: per-record logic
+#pragma unroll
+        for (int k = 0; k < PREP_B; k++) {
+            const u32 i = i0 + (u32)k * 256u;
+            const bool in = i < r.n;
+            const u32 flag = in ? fl[k] : 0x904u;
+            const int tid = in ? td[k] : -1;
+            const int pos = ps_[k];
+            // every record read counts towards num_detected_primary_alignments when !secondary && !supplementary
+            g_prim += (in && !(flag & 0x900u)) ? 1u : 0u;
+            const bool tid_ok = in && tid >= 0 && (u32)tid < n_targets;
+            // span of records carrying this tid + grouping / position-order checks (all records, considered or not)
+            if (tid_ok) {
+                const int pt = i > 0 ? ptid[k] : -2;
+                if (pt != tid) {
+                    atomicMin(&ctg[tid].rec_start, i);
+                    atomicAdd(&ctg[tid].n_groups, 1u);
+                } else if (ppos[k] > pos) {
+                    atomicOr(&ctg[tid].flags, F_POS_UNSORTED);
                 }
-            } else {  // contig boundary inside this wave pass: rare, resolve with per-lane atomics
-                prep_flush(ctg, cur, acc); cur = -1;
-                if (cnt) {
-                    DevContig *C = &ctg[tid];
-                    if (!supp && !sec) atomicAdd(&C->n_primary, 1ull);
-                    atomicAdd(&C->n_pass, 1ull);
-                    if (!supp) atomicAdd(&C->n_nonsupp, 1ull);
-                    if (masked_in) {
-                        if (nmv) atomicAdd(&C->sum_nm, nmv);
-                        if (indel) atomicAdd(&C->sum_indel, indel);
-                        atomicMax(&C->max_span, span);
+                const int nt = (i + 1 < r.n) ? ntid[k] : -2;
+                if (nt != tid) atomicMax(&ctg[tid].rec_end, i + 1);
+            }
+            const bool unmapped = flag & 0x4u;
+            const bool supp = flag & 0x800u, sec = flag & 0x100u;
+            // reader stage: ReferenceSortedBamFilter::read single-read branch, filter_out = true (filter.rs:88-116)
+            bool survives = in;
+            bool need_filter_eval = false;
+            if (f.filter_single) {
+                survives = false;
+                const bool p1 = in && !unmapped && (f.include_supplementary || !supp) && (f.include_secondary || !sec);
+                if (p1 && !(f.min_mapq != 255u && (mq[k] < f.min_mapq || mq[k] == 255u))) need_filter_eval = true;  // :250-254
+            }
+            // scan stage gate: FlagFilter::passes (lib.rs:67-78) then !unmapped (contig.rs:125)
+            const bool flags_ok = !(!f.include_secondary && sec) && !(!f.include_supplementary && supp) &&
+                                  !(!f.include_improper_pairs && !(flag & 0x2u));
+            const bool scan_gate = in && flags_ok && !unmapped;
+
+            u64 aligned = 0, indel = 0;
+            u32 run_start = 0, run_len = 0, run2_start = 0, run2_len = 0, n_runs = 0, span = 0;
+            bool oob = false, badcig = false;
+            // with the reader-stage filter on, only records that reach single_read_passes_filter can survive
+            const bool do_walk = f.filter_single ? need_filter_eval : scan_gate;
+            if (do_walk) {
+                const u32 L = Lc[k];
+                long long cursor = pos;
+                long long cur_e = -1;  // end of the open merged run
+                const u32 nops = co1[k] - co0[k];
+                for (u32 c = 0; c < nops; c++) {
+                    const u32 wd = c == 0 ? cw[k][0] : c == 1 ? cw[k][1] : c == 2 ? cw[k][2] : r.cigar[co0[k] + c];
+                    const u32 op = wd & 15u, len = wd >> 4;
+                    if (op == 0u || op == 7u || op == 8u) {          // M = X  (contig.rs:171-186)
+                        if (cursor < 0 || cursor >= (long long)L) oob = true;
+                        if (n_runs > 0 && cursor == cur_e) {
+                            cur_e += len;
+                            if (n_runs == 1) run_len += len; else if (n_runs == 2) run2_len += len;
+                        } else {
+                            n_runs++;
+                            cur_e = cursor + len;
+                            if (n_runs == 1) { run_start = (u32)cursor; run_len = len; }
+                            else if (n_runs == 2) { run2_start = (u32)cursor; run2_len = len; }
+                        }
+                        cursor += len; aligned += len;
+                    } else if (op == 2u) { cursor += len; indel += len; aligned += len; }  // D  (:187-191)
+                    else if (op == 3u) { cursor += len; }                                  // N  (:192-195)
+                    else if (op == 1u) { indel += len; aligned += len; }                   // I  (:196-199)
+                    else if (op > 8u) badcig = true;                                       // S H P ignored (:200)
+                }
+                const long long sp = cursor - (long long)pos;
+                span = sp > 0 ? (u32)min(sp, (long long)0xffffffffu) : 0u;
+            }
+            if (need_filter_eval) {  // single_read_passes_filter, filter.rs:256-278
+                if (nmk[k] != 1u) report_error(g, i, nmk[k] == 0u ? 2u : 3u);
+                else {
+                    const u32 al = (u32)aligned;  // u32 accumulation in the reference
+                    const float a = (float)al;
+                    survives = al >= f.min_aligned_length && a / (float)lsq[k] >= f.min_aligned_percent &&
+                               1.0f - (float)nmv32[k] / a >= f.min_percent_identity;
+                }
+            }
+            const bool considered = survives && scan_gate;
+            const bool masked_in = considered && tid_ok && mk[k];
+            u64 nmv = 0;
+            double idv = 0.0;
+            if (considered && !tid_ok) report_error(g, i, 7u);  // header.target_len(tid).expect("Corrupt BAM file?")
+            if (masked_in) {
+                if (badcig) report_error(g, i, 6u);
+                else if (oob) report_error(g, i, 4u);
+                if (nmk[k] != 1u) report_error(g, i, nmk[k] == 0u ? 2u : 3u);  // nm(&record), contig.rs:206
+                else nmv = nmv32[k];
+                if (WANT_IDENTITY && aligned > 0) idv = ((double)aligned - (double)nmv) / (double)aligned;
+            }
+            if (in) {
+                uint2 rw;
+                rw.x = 0u; rw.y = 0u;
+                if (masked_in && n_runs > 0) {
+                    rw.x = run_start;
+                    const u32 gap = run2_start - (run_start + run_len);
+                    if (n_runs == 1 && run_len < (1u << 30)) rw.y = run_len;   // RW_SINGLE; 0 = nothing to add
+                    else if (n_runs == 2 && run_len - 1u < 1023u && run2_len - 1u < 1023u && gap - 1u < 255u)
+                        rw.y = (RW_DOUBLE << 30) | run_len | (gap << 10) | (run2_len << 18);
+                    else rw.y = RW_COMPLEX << 30;
+                }
+                runs[i] = rw;
+                if (WANT_IDENTITY) ident[i] = (masked_in && !supp) ? idv : 0.0;
+            }
+
+            // per-contig counters: accumulate per lane while the wave stays inside one contig
+            const bool cnt = considered && tid_ok;
+            g_cons += cnt ? 1u : 0u;
+            const u64 m = __ballot(cnt);
+            if (m != 0) {
+                const int ftid = __shfl(tid, __ffsll((long long)m) - 1);
+                const bool uni = __all(!cnt || tid == ftid);
+                if (uni) {
+                    if (ftid != cur) { prep_flush(ctg, cur, acc); cur = ftid; }
+                    if (cnt) {
+                        acc.prim += (!supp && !sec) ? 1u : 0u;
+                        acc.pass += 1u;
+                        acc.nons += supp ? 0u : 1u;
+                        acc.first = min(acc.first, i); acc.last = max(acc.last, i);
+                        if (masked_in) { acc.nm += nmv; acc.indel += indel; acc.span = max(acc.span, span); }
                     }
-                    atomicMin(&C->first_rec, i);
-                    atomicMax(&C->last_rec, i);
+                } else {  // contig boundary inside this wave pass: rare, resolve with per-lane atomics
+                    prep_flush(ctg, cur, acc); cur = -1;
+                    if (cnt) {
+                        DevContig *C = &ctg[tid];
+                        if (!supp && !sec) atomicAdd(&C->n_primary, 1ull);
+                        atomicAdd(&C->n_pass, 1ull);
+                        if (!supp) atomicAdd(&C->n_nonsupp, 1ull);
+                        if (masked_in) {
+                            if (nmv) atomicAdd(&C->sum_nm, nmv);
+                            if (indel) atomicAdd(&C->sum_indel, indel);
+                            atomicMax(&C->max_span, span);
+                        }
+                        atomicMin(&C->first_rec, i);
+                        atomicMax(&C->last_rec, i);
+                    }
                 }
             }
         }
@@ -717,5 +742,222 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------ k_pileup_stream
+// Barrier-free variant: every WAVE owns a private LDS tile of TW = ROWS*256 bases (+ a private histogram) and
+// walks a chunk of consecutive tiles, keeping its running sums in registers across tiles of one contig and
+// flushing them (one set of global atomics + histogram sweep) only when the contig changes or the chunk ends.
+// No __syncthreads anywhere: 24 independent waves per CU interleave their load latencies.
+//
+// Statistics take one of two exact paths per tile:
+//   sparse  (#changed positions <= TW/4): the non-zero deltas are compacted in place into (position, depth)
+//           pairs and the sums are formed per constant-depth SEGMENT (d*len, d^2*len, one histogram add per
+//           segment) — work proportional to the number of alignment ends, not to the number of bases;
+//   dense   otherwise (deep piles), or when depth is being written out: per-base accumulation as in k_pileup.
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int ROWS, bool WANT_HIST, bool WRITE_DEPTH>
+__global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
+    constexpr int TW = ROWS * 256;
+    constexpr int HBW = 512;
+    constexpr int CAP = TW / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int *tile = reinterpret_cast<int *>(smem + (size_t)w * (TW * 4 + HBW * 4));
+    u32 *lhist = reinterpret_cast<u32 *>(tile + TW);
+    int4 *t4 = reinterpret_cast<int4 *>(tile);
+    const u32 wave_id = blockIdx.x * 4u + (u32)w, n_waves = gridDim.x * 4u;
+    if (WANT_HIST) {
+#pragma unroll
+        for (int b = lane; b < HBW; b += 64) lhist[b] = 0u;
+    }
+    u64 sum_d = 0, sum_d2 = 0, proc_win = 0;
+    u32 cov_w = 0, cov_f = 0, mn = 0xffffffffu, mx = 0;
+    int cur_c = -1;
+    u64 hoff = 0; u32 hcap = 0;
+    const u64 excl = a.excl;
+
+    auto hist_add = [&](u32 d, u32 x) {
+        if (d < (u32)HBW) atomicAdd(&lhist[d], x);
+        else if (d <= hcap) atomicAdd(&a.hist_arena[hoff + d], x);
+        else atomicOr(&a.g->internal_error, 1u);
+    };
+    auto flush = [&]() {
+        if (cur_c >= 0) {
+            const u64 s1 = wave_sum_u64(sum_d), s2 = wave_sum_u64(sum_d2);
+            const u32 c1 = wave_sum_u32(cov_w), c2 = wave_sum_u32(cov_f);
+            const u32 m1 = wave_min_u32(mn), m2 = wave_max_u32(mx);
+            DevContig *C = &a.ctg[cur_c];
+            if (lane == 0) {
+                if (s1) atomicAdd(&C->sum_d, s1);
+                if (s2) atomicAdd(&C->sum_d2, s2);
+                if (c1) atomicAdd(&C->cov_win, (u64)c1);
+                if (c2) atomicAdd(&C->cov_full, (u64)c2);
+                if (proc_win) {
+                    atomicAdd(&C->proc_win, proc_win);
+                    atomicMin(&C->min_d, m1);
+                    atomicMax(&C->max_d, m2);
+                }
+            }
+            if (WANT_HIST && proc_win) {
+                lds_fence();
+                const u32 hi_b = min(m2, (u32)HBW - 1u);
+                for (u32 b = m1 + (u32)lane; b <= hi_b; b += 64) {
+                    const u32 x = lhist[b];
+                    if (x) { atomicAdd(&a.hist_arena[hoff + b], x); lhist[b] = 0u; }
+                }
+                lds_fence();
+            }
+        }
+        sum_d = sum_d2 = 0; proc_win = 0; cov_w = cov_f = 0; mn = 0xffffffffu; mx = 0;
+    };
+
+    const u32 n_chunks = (n_tiles + chunk_tiles - 1) / chunk_tiles;
+    for (u32 ch = wave_id; ch < n_chunks; ch += n_waves) {
+        const u32 t0 = a.tile_base + ch * chunk_tiles, t1 = a.tile_base + min((ch + 1) * chunk_tiles, n_tiles);
+        for (u32 t = t0; t < t1; t++) {
+            const uint4 ds = a.desc[t];
+            if (ds.x >= ds.y) continue;   // depth 0 everywhere: accounted on the host side
+            const u32 c = a.tile_contig[t], lo = a.tile_start[t], L = ds.z;
+            const bool generic = ds.w & 1u;
+            if ((int)c != cur_c) {
+                flush();
+                cur_c = (int)c;
+                if (WANT_HIST) { hoff = a.ctg[c].hist_off; hcap = a.ctg[c].hist_cap; }
+            }
+            const u32 tlen_t = min((u32)TW, L - lo);
+            // ---- zero, scatter events
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) t4[r * 64 + lane] = make_int4(0, 0, 0, 0);
+            lds_fence();
+            const u32 hi = lo + TW;
+            auto add_run = [&](u32 s, u32 e) {
+                if (s < hi && e > lo) {
+                    const u32 s0 = s > lo ? s - lo : 0u;
+                    atomicAdd(&tile[s0], 1);
+                    if (e < hi) atomicAdd(&tile[e - lo], -1);
+                }
+            };
+            for (u32 i = ds.x + (u32)lane; i < ds.y; i += 64) {
+                const uint2 rw = a.runs[i];
+                if (rw.y == 0u) continue;
+                if (generic && a.r.tid[i] != (int)c) continue;
+                const u32 type = rw.y >> 30;
+                if (type == RW_SINGLE) add_run(rw.x, rw.x + rw.y);
+                else if (type == RW_DOUBLE) {
+                    const u32 l1 = rw.y & 1023u, gap = (rw.y >> 10) & 255u, l2 = (rw.y >> 18) & 1023u;
+                    add_run(rw.x, rw.x + l1);
+                    add_run(rw.x + l1 + gap, rw.x + l1 + gap + l2);
+                } else {
+                    u32 cursor = (u32)a.r.pos[i];
+                    const u32 c0 = a.r.cigar_off[i], c1 = a.r.cigar_off[i + 1];
+                    for (u32 k = c0; k < c1; k++) {
+                        const u32 wd = a.r.cigar[k];
+                        const u32 op = wd & 15u, len = wd >> 4;
+                        if (op == 0u || op == 7u || op == 8u) { add_run(cursor, cursor + len); cursor += len; }
+                        else if (op == 2u || op == 3u) cursor += len;
+                    }
+                }
+            }
+            lds_fence();
+            // ---- read back, prefix sums of deltas and of the non-zero count (row-major = position order)
+            int4 v[ROWS];
+            int exd[ROWS], exn[ROWS];
+            int carry_d = 0, carry_n = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                v[r] = t4[r * 64 + lane];
+                const int s3 = v[r].x + v[r].y + v[r].z + v[r].w;
+                const int nz = (v[r].x != 0) + (v[r].y != 0) + (v[r].z != 0) + (v[r].w != 0);
+                const int inc = wave_incl_scan(s3), incn = wave_incl_scan(nz);
+                exd[r] = carry_d + inc - s3;
+                exn[r] = carry_n + incn - nz;
+                carry_d += __builtin_amdgcn_readlane(inc, 63);
+                carry_n += __builtin_amdgcn_readlane(incn, 63);
+            }
+            const u32 E = (u32)carry_n;
+            const bool has_win = 2 * excl < (u64)L;
+            const u32 ws = has_win ? (u32)excl : 0u, we = has_win ? (u32)(L - excl) : 0u;
+            const u32 wst = max(ws, lo), wet = min(we, lo + tlen_t);
+            const bool win_any = has_win && wst < wet;
+            if (win_any) proc_win += (u64)(wet - wst);
+
+            if (!WRITE_DEPTH && E <= (u32)CAP) {
+                // ---- sparse path: compact (local position, depth after) in place, then one pass over segments
+                lds_fence();
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    const int dl[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+                    int d = exd[r], k = exn[r];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        d += dl[j];
+                        if (dl[j] != 0) { tile[k] = 4 * (r * 64 + lane) + j; tile[CAP + k] = d; k++; }
+                    }
+                }
+                lds_fence();
+                const u32 wl0 = win_any ? wst - lo : 0u, wl1 = win_any ? wet - lo : 0u;
+                for (u32 e = (u32)lane; e <= E; e += 64) {
+                    u32 s = e == 0 ? 0u : (u32)tile[e - 1];
+                    const int d = e == 0 ? 0 : tile[CAP + e - 1];
+                    u32 en = e < E ? (u32)tile[e] : tlen_t;
+                    s = min(s, tlen_t); en = min(en, tlen_t);
+                    const u32 du = (u32)d;
+                    if (d > 0) cov_f += en - s;
+                    const u32 a0 = max(s, wl0), a1 = min(en, wl1);
+                    if (a1 > a0) {
+                        const u32 len = a1 - a0;
+                        sum_d += (u64)du * len;
+                        sum_d2 += (u64)du * du * len;
+                        if (d > 0) cov_w += len;
+                        mn = min(mn, du); mx = max(mx, du);
+                        if (WANT_HIST) hist_add(du, len);
+                    }
+                }
+            } else {
+                // ---- dense path: per-base accumulation (change-point histogram as in k_pileup)
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    const u32 p0 = lo + 4u * (u32)(r * 64 + lane);
+                    const int dl[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+                    int d = exd[r];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int prev = d;
+                        d += dl[j];
+                        const u32 p = p0 + j;
+                        const u32 du = (u32)d;
+                        if (p < L) {
+                            cov_f += d > 0;
+                            if (WRITE_DEPTH) a.depth_out[p] = d;
+                            if (win_any && p >= wst && p < wet) {
+                                sum_d += du;
+                                sum_d2 += (u64)du * du;
+                                cov_w += d > 0;
+                                mn = min(mn, du); mx = max(mx, du);
+                                if (WANT_HIST && dl[j] != 0) {
+                                    const u32 rel = p - wst;
+                                    if (rel) { hist_add((u32)prev, rel); hist_add(du, 0u - rel); }
+                                }
+                            }
+                        }
+                    }
+                    if (WANT_HIST && win_any) {
+                        const u32 last = wet - 1;
+                        if (last >= p0 && last < p0 + 4) {
+                            int dd = exd[r];
+                            for (u32 j = 0; j <= last - p0; j++) dd += dl[j];
+                            hist_add((u32)dd, wet - wst);
+                        }
+                    }
+                }
+            }
+        }
+        flush();
+        cur_c = -1;
+    }
+}
+
+constexpr size_t pileup_stream_smem_bytes(int rows) { return (size_t)4 * ((size_t)rows * 256 * 4 + 512 * 4); }
 
 }  // namespace covk

@@ -230,7 +230,15 @@ class CoverageTaker:
             pass
 
 
+_header_cache = {}
+
+
 def _header(names: List[str], target_len):
+    """covh_header for (names, lengths); marshalled once per distinct header object (5000 names cost ~0.5 ms)."""
+    key = (id(names), len(names), id(target_len))
+    hit = _header_cache.get(key)
+    if hit is not None and hit[2] is names and hit[3] is target_len:
+        return hit[0], hit[1]
     enc = [n.encode() for n in names]
     off = np.zeros(len(enc) + 1, dtype=np.uint32)
     if enc:
@@ -238,6 +246,9 @@ def _header(names: List[str], target_len):
     tl = np.ascontiguousarray(target_len, dtype=np.uint64)
     blob = b"".join(enc)
     h = _Header(len(enc), blob, off.ctypes.data, tl.ctypes.data)
+    if len(_header_cache) > 8:
+        _header_cache.clear()
+    _header_cache[key] = (h, (blob, off, tl), names, target_len)
     return h, (blob, off, tl)
 
 

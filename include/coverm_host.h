@@ -121,6 +121,22 @@ void covh_finalise_printing(covh_taker *t, int printer, const char *entry_type, 
 size_t covh_format_f32(float v, char *buf, size_t cap);
 size_t covh_format_f64(double v, char *buf, size_t cap);
 
+/* ---- BGZF / BAM / SAM reader (rust-htslib's role: bam_generator.rs:113-119, 125-129, 356-371).
+ * Decodes the whole file with `threads` inflate/parse threads and exposes the records as a cov_batch whose
+ * arrays stay owned by the handle.  want_names also keeps read names (pair-mode filtering, filter.rs:164). */
+typedef struct covh_bam covh_bam;
+covh_bam *covh_bam_open(const char *path, int threads, int want_names, char *err, size_t errcap);
+void covh_bam_close(covh_bam *h);
+uint32_t covh_bam_n_targets(const covh_bam *h);
+const char *covh_bam_target_name(const covh_bam *h, uint32_t i);
+uint64_t covh_bam_target_len(const covh_bam *h, uint32_t i);
+uint64_t covh_bam_n_records(const covh_bam *h);
+uint64_t covh_bam_n_cigar(const covh_bam *h);
+void covh_bam_batch(const covh_bam *h, cov_batch *out);
+const int32_t *covh_bam_mtid(const covh_bam *h);
+const uint32_t *covh_bam_qname_off(const covh_bam *h); /* n_records + 1, NULL without want_names */
+const char *covh_bam_qnames(const covh_bam *h);
+
 /* calculate_coverage for one entry built from explicit sums (used by unit tests). */
 typedef struct {
     uint64_t win_len, win_sum_d, win_sum_d2, win_covered, full_len, full_covered, n_reads, mismatches;

@@ -1,0 +1,62 @@
+"""The standalone C++ CLI (coverm_amd/coverm-amd): BAM file on disk -> C++ reader -> C ABI -> kernels ->
+C++ host layer -> stdout, compared with the reference's own CLI expectations (tests/test_cmdline.rs)."""
+import os
+import subprocess
+
+import pytest
+
+from oracle import bamio
+from tests.fixtures import FIXDIR, load_fixture
+from tests.golden import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "coverm_amd", "coverm-amd")
+
+
+def argv_of(case, paths):
+    a = case["args"]
+    v = [BIN, case["mode"], "-b"] + paths
+    if "methods" in a: v += ["-m"] + list(a["methods"])
+    if "output_format" in a: v += ["--output-format", a["output_format"]]
+    if "separator" in a: v += ["-s", a["separator"]]
+    if a.get("single_genome"): v += ["--single-genome"]
+    if "min_covered_fraction" in a: v += ["--min-covered-fraction", str(a["min_covered_fraction"])]
+    if "min_mapq" in a: v += ["--min-mapq", str(a["min_mapq"])]
+    if a.get("proper_pairs_only"): v += ["--proper-pairs-only"]
+    if "genome_definition" in a: v += ["--genome-definition", os.path.join(FIXDIR, a["genome_definition"])]
+    return v
+
+
+def test_binary_exists_and_prints_usage():
+    assert os.path.exists(BIN), "build with python -m coverm_amd.build"
+    p = subprocess.run([BIN], capture_output=True, text=True)
+    assert p.returncode == 2 and "usage" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", cases.CLI_CASES, ids=[c["id"] for c in cases.CLI_CASES])
+def test_cli_binary_golden(case, tmp_path):
+    paths = []
+    for b in case["bams"]:
+        stem = os.path.splitext(b)[0]
+        p = str(tmp_path / (stem + ".bam"))     # the stoit name is the file stem
+        bamio.write_bam(p, load_fixture(b), block=3000)
+        paths.append(p)
+    r = subprocess.run(argv_of(case, paths), capture_output=True, text=True, timeout=300)
+    if case["match"] == "error":
+        assert r.returncode != 0 and case["expected"] in r.stderr
+        return
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    if case["match"] == "is":
+        assert out == case["expected"]
+    elif case["match"] == "contains":
+        assert case["expected"] in out
+    elif case["match"] == "contains_all":
+        for e in case["expected"]:
+            assert e in out
+    else:
+        so = out.split("\n"); se = case["expected"].split("\n")
+        assert [so[0]] + sorted(so[1:]) == [se[0]] + sorted(se[1:])
+    if case["mode"] == "contig":
+        assert "reads mapped out of" in r.stderr
