@@ -197,12 +197,12 @@ void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
     }
 }
 
-template <int ROWS, bool H, bool W>
+template <bool H, bool W>
 void launch_stream_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    const size_t smem = pileup_stream_smem_bytes(ROWS);
+    const size_t smem = pileup_stream_smem_bytes();
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_stream<ROWS, H, W>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_stream<H, W>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
@@ -210,13 +210,12 @@ void launch_stream_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
     const u32 n_chunks = (n_tiles + chunk - 1) / chunk;
     const u32 wg_per_cu = (u32)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
     const u32 grid = std::max(1u, std::min((n_chunks + 3) / 4, (u32)s->n_cus * wg_per_cu));
-    hipLaunchKernelGGL((k_pileup_stream<ROWS, H, W>), dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
+    hipLaunchKernelGGL((k_pileup_stream<H, W>), dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
 }
 // dispatches to the configured pileup kernel
 template <bool H, bool W>
 void launch_any_pileup(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    if (s->stream_rows == 8) launch_stream_t<8, H, W>(s, a, n_tiles);
-    else if (s->stream_rows == 4) launch_stream_t<4, H, W>(s, a, n_tiles);
+    if (s->stream_rows) launch_stream_t<H, W>(s, a, n_tiles);
     else launch_pileup<H, W>(s, a, n_tiles);
 }
 
@@ -262,8 +261,9 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
         const char *mode = getenv("COVERM_PILEUP"), *rows = getenv("COVERM_ROWS"), *chk = getenv("COVERM_CHUNK");
         if (mode && !strcmp(mode, "tile")) s->stream_rows = 0;
         else {
-            s->stream_rows = (rows && atoi(rows) == 8) ? 8 : 4;
-            s->tile = s->stream_rows * 256;
+            (void)rows;
+            s->stream_rows = 4;
+            s->tile = STREAM_TW;
         }
         if (chk && atoi(chk) > 0) s->chunk_tiles = atoi(chk);
         hipDeviceProp_t prop;
@@ -319,7 +319,7 @@ cov_status cov_set_targets(cov_session *s, uint32_t n_targets, const uint64_t *t
     HIPCHK(s->d_tlen.reserve(std::max<size_t>(1, n_targets), s->stream));
     HIPCHK(s->d_tile_contig.reserve(std::max<size_t>(1, nt), s->stream));
     HIPCHK(s->d_tile_start.reserve(std::max<size_t>(1, nt), s->stream));
-    HIPCHK(s->d_desc.reserve(std::max<size_t>(1, nt), s->stream));
+    HIPCHK(s->d_desc.reserve(std::max<size_t>(2, 2 * nt), s->stream));
     HIPCHK(s->d_ctg.reserve(std::max<size_t>(1, n_targets), s->stream));
     if (n_targets) HIPCHK(hipMemcpyAsync(s->d_tlen.p, s->h_tlen.data(), (size_t)n_targets * 4, hipMemcpyHostToDevice, s->stream));
     if (nt) {
@@ -568,6 +568,7 @@ cov_status cov_copy_depth(cov_session *s, uint32_t tid, int32_t *depth_out) {
     a.depth_out = s->d_depth.p;
     a.tile_base = s->h_tile_first[tid];
     const u32 grid = s->h_tile_first[tid + 1] - s->h_tile_first[tid];
+    HIPCHK(hipMemsetAsync(&s->d_glob.p->chunk_ctr[0], 0, sizeof(u32) * 8 * 16, s->stream));
     launch_any_pileup<false, true>(s, a, grid);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(depth_out, s->d_depth.p, (size_t)L * 4, hipMemcpyDeviceToHost, s->stream));

@@ -61,6 +61,7 @@ struct DevGlobal {
     u64 pad2[4];
     u64 prim_slots[COUNTER_SLOTS * 8];  // sum = num_detected_primary_alignments (bam_generator.rs:114-118)
     u64 cons_slots[COUNTER_SLOTS * 8];  // sum = number of considered records
+    u32 chunk_ctr[8 * 16];              // k_pileup_stream work queues: one dequeue counter per shard, 64 B apart
 };
 
 struct FilterCfg {
@@ -127,6 +128,7 @@ __global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g) {
         g->first_error = ~0ull; g->hist_cap_total = 0; g->chist_total = 0; g->internal_error = 0;
     }
     if (c < COUNTER_SLOTS * 8) { g->prim_slots[c] = 0; g->cons_slots[c] = 0; }
+    if (c < 8 * 16) g->chunk_ctr[c] = 0;
     if (c >= n_targets) return;
     DevContig z;
     z.n_primary = z.n_pass = z.n_nonsupp = z.sum_nm = z.sum_indel = 0;
@@ -385,8 +387,8 @@ __device__ __forceinline__ u32 lower_bound_pos(const int32_t *__restrict__ pos, 
     return lo;
 }
 
-// Tile descriptor: x,y = candidate record range, z = contig length, w = flags (bit 0: records of other
-// contigs may be interleaved in the range, check tid).  One 16-byte load gives k_pileup all it needs.
+// Tile descriptor, two uint4 per tile: [2t] = (first candidate record, last, contig length, flags — bit 0: records
+// of other contigs may be interleaved in the range, check tid); [2t+1] = (contig, tile start, 0, 0).
 template <bool WANT_HIST>
 __global__ __launch_bounds__(256) void k_ranges(const u32 *__restrict__ tile_contig, const u32 *__restrict__ tile_start,
                                                 u32 n_tiles, u32 tile, const int32_t *__restrict__ pos,
@@ -406,12 +408,21 @@ __global__ __launch_bounds__(256) void k_ranges(const u32 *__restrict__ tile_con
             const long long lo = tile_start[t];
             // a run [s,e) of a record at `pos` (pos <= s, e <= pos + max_span) overlaps [lo, lo+tile) only if
             // pos > lo - max_span and pos < lo + tile
-            out.x = lower_bound_pos(pos, rs, re, lo - (long long)C->max_span + 1);
-            out.y = lower_bound_pos(pos, out.x, re, lo + (long long)tile);
+            // both searches advance together: their loads are independent, which halves the dependent-load chain
+            const long long k0 = lo - (long long)C->max_span + 1, k1 = lo + (long long)tile;
+            u32 l0 = rs, h0 = re, l1 = rs, h1 = re;
+            while (l0 < h0 || l1 < h1) {
+                const u32 m0 = l0 + ((h0 - l0) >> 1), m1 = l1 + ((h1 - l1) >> 1);
+                const long long p0 = l0 < h0 ? (long long)pos[m0] : 0, p1 = l1 < h1 ? (long long)pos[m1] : 0;
+                if (l0 < h0) { if (p0 < k0) l0 = m0 + 1; else h0 = m0; }
+                if (l1 < h1) { if (p1 < k1) l1 = m1 + 1; else h1 = m1; }
+            }
+            out.x = l0; out.y = max(l1, l0);
         }
         if (WANT_HIST && out.y > out.x) atomicMax(&C->hist_cap, out.y - out.x);
     }
-    desc[t] = out;
+    desc[2 * t] = out;
+    desc[2 * t + 1] = make_uint4(c, tile_start[t], 0u, 0u);
 }
 
 // ------------------------------------------------------------------------------------ histogram layout
@@ -513,6 +524,13 @@ __global__ __launch_bounds__(64) void k_identity(DevContig *ctg, u32 n_targets, 
 }
 
 // ------------------------------------------------------------------------------------ k_pileup
+// Histogram bins beyond the LDS window go straight to the contig's slice of the global arena.  Rare (depth
+// >= 512/1024/2048), so it is kept out of line: inlined at every call site it costs dozens of branches.
+__device__ __attribute__((noinline)) void hist_add_overflow(u32 *arena, u64 hoff, u32 hcap, DevGlobal *g, u32 d, u32 x) {
+    if (d <= hcap) atomicAdd(&arena[hoff + d], x);
+    else atomicOr(&g->internal_error, 1u);
+}
+
 struct PileupArgs {
     const u32 *tile_contig, *tile_start;
     const uint4 *desc;
@@ -545,7 +563,7 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
     u32 *lhist = reinterpret_cast<u32 *>(smem + TILE * 4 + 256 + NW * 16 + NW * 16 + 16);
 
     const u32 t = a.tile_base + blockIdx.x;
-    const uint4 ds = a.desc[t];
+    const uint4 ds = a.desc[2 * t];
     if (ds.x >= ds.y) return;  // no record can touch this tile: depth 0 everywhere, accounted on the host side
     const u32 lo = a.tile_start[t];
     const u32 c = a.tile_contig[t];
@@ -636,10 +654,8 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
     const u64 hoff = WANT_HIST ? C->hist_off : 0;
     const u32 hcap = WANT_HIST ? C->hist_cap : 0;
     auto hist_add = [&](u32 d, u32 x) {
-        if (a.ablate & 4u) return;
-        if (d < (u32)HB) atomicAdd(&lhist[d], x);
-        else if (d <= hcap) atomicAdd(&a.hist_arena[hoff + d], x);
-        else atomicOr(&a.g->internal_error, 1u);
+        if (__builtin_expect(d < (u32)HB, 1)) atomicAdd(&lhist[d], x);
+        else hist_add_overflow(a.hist_arena, hoff, hcap, a.g, d, x);
     };
 #pragma unroll
     for (int rr = 0; rr < ROWS; rr++) {
@@ -744,28 +760,32 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ k_pileup_stream
-// Barrier-free variant: every WAVE owns a private LDS tile of TW = ROWS*256 bases (+ a private histogram) and
-// walks a chunk of consecutive tiles, keeping its running sums in registers across tiles of one contig and
+// Barrier-free variant: every WAVE owns a private LDS tile of TW = 1024 bases (+ a private 512-bin histogram)
+// and walks a chunk of consecutive tiles, keeping its running sums in registers across tiles of one contig and
 // flushing them (one set of global atomics + histogram sweep) only when the contig changes or the chunk ends.
-// No __syncthreads anywhere: 24 independent waves per CU interleave their load latencies.
+// No __syncthreads anywhere: the resident waves of a CU interleave their load latencies independently.
 //
-// Statistics take one of two exact paths per tile:
-//   sparse  (#changed positions <= TW/4): the non-zero deltas are compacted in place into (position, depth)
-//           pairs and the sums are formed per constant-depth SEGMENT (d*len, d^2*len, one histogram add per
-//           segment) — work proportional to the number of alignment ends, not to the number of bases;
-//   dense   otherwise (deep piles), or when depth is being written out: per-base accumulation as in k_pileup.
+// Layout inside a tile is TRANSPOSED: base p lives in LDS dword p and is owned by lane p & 63 in row p >> 6.
+// That makes every per-base step a whole-wave instruction over 64 consecutive bases, and turns stream compaction
+// into ballot + popcount (scalar unit) + mbcnt.  Statistics take one of two exact paths per tile:
+//   sparse  (#changed positions <= 256): the non-zero deltas are compacted in position order into (pos, delta)
+//           entries, depth comes from one wave scan per 64 ENTRIES, and the sums are formed per constant-depth
+//           segment (d*len, d^2*len, one histogram add per segment) — work ~ alignment ends, not bases;
+//   dense   otherwise (deep piles), or when depth is written out: one wave scan per 64 bases, per-base sums,
+//           change-point histogram.
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int ROWS, bool WANT_HIST, bool WRITE_DEPTH>
+constexpr int STREAM_TW = 1024, STREAM_HB = 512, STREAM_CAP = 256;
+
+template <bool WANT_HIST, bool WRITE_DEPTH>
 __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
-    constexpr int TW = ROWS * 256;
-    constexpr int HBW = 512;
-    constexpr int CAP = TW / 4;
+    constexpr int TW = STREAM_TW, HBW = STREAM_HB, CAP = STREAM_CAP, ROWS = TW / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int *tile = reinterpret_cast<int *>(smem + (size_t)w * (TW * 4 + HBW * 4));
     u32 *lhist = reinterpret_cast<u32 *>(tile + TW);
     int4 *t4 = reinterpret_cast<int4 *>(tile);
+    int2 *ent = reinterpret_cast<int2 *>(tile);   // sparse path: CAP entries reuse dwords [0, 2*CAP)
     const u32 wave_id = blockIdx.x * 4u + (u32)w, n_waves = gridDim.x * 4u;
     if (WANT_HIST) {
 #pragma unroll
@@ -778,9 +798,8 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
     const u64 excl = a.excl;
 
     auto hist_add = [&](u32 d, u32 x) {
-        if (d < (u32)HBW) atomicAdd(&lhist[d], x);
-        else if (d <= hcap) atomicAdd(&a.hist_arena[hoff + d], x);
-        else atomicOr(&a.g->internal_error, 1u);
+        if (__builtin_expect(d < (u32)HBW, 1)) atomicAdd(&lhist[d], x);
+        else hist_add_overflow(a.hist_arena, hoff, hcap, a.g, d, x);
     };
     auto flush = [&]() {
         if (cur_c >= 0) {
@@ -812,13 +831,71 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
         sum_d = sum_d2 = 0; proc_win = 0; cov_w = cov_f = 0; mn = 0xffffffffu; mx = 0;
     };
 
+    // Software pipeline over the tiles of a chunk: descriptors are fetched two tiles ahead and the first 128
+    // candidate run words one tile ahead, through the VECTOR memory path (vmcnt) so that the LDS fences
+    // (lgkmcnt) of the current tile never wait for them.
+    u32 vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));   // opaque zero: keeps descriptor loads off the scalar path
+    auto load_desc = [&](u32 t, uint4 &d0, uint4 &d1) {
+        const uint4 *p = a.desc + 2 * (size_t)t + vzero;
+        d0 = p[0]; d1 = p[1];
+    };
+    auto uni = [&](uint4 &d) {
+        d.x = __builtin_amdgcn_readfirstlane(d.x); d.y = __builtin_amdgcn_readfirstlane(d.y);
+        d.z = __builtin_amdgcn_readfirstlane(d.z); d.w = __builtin_amdgcn_readfirstlane(d.w);
+    };
+    auto load_runs = [&](const uint4 &d, uint2 &r0, uint2 &r1) {
+        const u32 i0 = d.x + (u32)lane, i1 = i0 + 64u;
+        r0 = i0 < d.y ? a.runs[i0] : make_uint2(0u, 0u);
+        r1 = i1 < d.y ? a.runs[i1] : make_uint2(0u, 0u);
+    };
+    const uint4 EMPTY = make_uint4(0u, 0u, 0u, 0u);
+
+    // Dynamic scheduling: depth is heavy-tailed across contigs, so chunks differ in cost by >10x and any static
+    // assignment leaves the launch waiting for its unluckiest wave.  Chunks are handed out from 8 sharded
+    // counters (one per XCD-sized slice of the chunk range, 64 B apart); a wave drains its home shard, then
+    // steals from the others.  The NEXT chunk id is requested before the current chunk is processed, so the
+    // ~1 us dequeue latency is hidden.
     const u32 n_chunks = (n_tiles + chunk_tiles - 1) / chunk_tiles;
-    for (u32 ch = wave_id; ch < n_chunks; ch += n_waves) {
+    const u32 shard_sz = (n_chunks + 7u) / 8u;
+    u32 shard = blockIdx.x & 7u, tried = 0;
+    auto dequeue = [&]() -> u32 {   // returns a chunk id, or 0xffffffff when every shard is empty
+        for (;;) {
+            u32 c = 0;
+            if (lane == 0) c = atomicAdd(&a.g->chunk_ctr[shard * 16u], 1u);
+            c = __builtin_amdgcn_readfirstlane(c);
+            const u32 base = shard * shard_sz;
+            if (c < shard_sz && base + c < n_chunks) return base + c;
+            if (++tried >= 8u) return 0xffffffffu;
+            shard = (shard + 1u) & 7u;
+        }
+    };
+    // a.ablate bit 5 (COVERM_ABLATE=32) selects the dynamic queue; the default is static round-robin over
+    // chunks, which measured ~10 % faster on the benchmark workload (no dequeue latency, no hot counters).
+    const bool dynamic = a.ablate & 32u;
+    u32 ch = dynamic ? dequeue() : (wave_id < n_chunks ? wave_id : 0xffffffffu);
+    while (ch != 0xffffffffu) {
+        const u32 ch_next = dynamic ? dequeue() : (ch + n_waves < n_chunks ? ch + n_waves : 0xffffffffu);
         const u32 t0 = a.tile_base + ch * chunk_tiles, t1 = a.tile_base + min((ch + 1) * chunk_tiles, n_tiles);
+        uint4 dC0, dC1, dN0 = EMPTY, dN1 = EMPTY;
+        uint2 rC0, rC1;
+        load_desc(t0, dC0, dC1); uni(dC0); uni(dC1);
+        load_runs(dC0, rC0, rC1);
+        if (t0 + 1 < t1) load_desc(t0 + 1, dN0, dN1);
         for (u32 t = t0; t < t1; t++) {
-            const uint4 ds = a.desc[t];
-            if (ds.x >= ds.y) continue;   // depth 0 everywhere: accounted on the host side
-            const u32 c = a.tile_contig[t], lo = a.tile_start[t], L = ds.z;
+            const uint4 ds = dC0;
+            const u32 c = dC1.x, lo = dC1.y, L = ds.z;
+            const uint2 rw0 = rC0, rw1 = rC1;
+            // Issue point for the next tile's loads.  It is placed AFTER this tile's run words have been
+            // consumed: the compiler waits with vmcnt(0), which would otherwise also wait for the young prefetches.
+            auto stage_next = [&]() {
+                uint4 dNN0 = EMPTY, dNN1 = EMPTY;
+                uint2 rN0 = make_uint2(0u, 0u), rN1 = make_uint2(0u, 0u);
+                if (t + 1 < t1) { uni(dN0); uni(dN1); load_runs(dN0, rN0, rN1); }
+                if (t + 2 < t1) load_desc(t + 2, dNN0, dNN1);
+                dC0 = dN0; dC1 = dN1; dN0 = dNN0; dN1 = dNN1; rC0 = rN0; rC1 = rN1;
+            };
+            if (ds.x >= ds.y) { stage_next(); continue; }   // depth 0 everywhere: accounted on the host side
             const bool generic = ds.w & 1u;
             if ((int)c != cur_c) {
                 flush();
@@ -828,7 +905,7 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
             const u32 tlen_t = min((u32)TW, L - lo);
             // ---- zero, scatter events
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) t4[r * 64 + lane] = make_int4(0, 0, 0, 0);
+            for (int k = 0; k < TW / 256; k++) t4[k * 64 + lane] = make_int4(0, 0, 0, 0);
             lds_fence();
             const u32 hi = lo + TW;
             auto add_run = [&](u32 s, u32 e) {
@@ -838,10 +915,9 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
                     if (e < hi) atomicAdd(&tile[e - lo], -1);
                 }
             };
-            for (u32 i = ds.x + (u32)lane; i < ds.y; i += 64) {
-                const uint2 rw = a.runs[i];
-                if (rw.y == 0u) continue;
-                if (generic && a.r.tid[i] != (int)c) continue;
+            auto apply = [&](const uint2 rw, u32 i) {
+                if (rw.y == 0u) return;
+                if (generic && a.r.tid[i] != (int)c) return;
                 const u32 type = rw.y >> 30;
                 if (type == RW_SINGLE) add_run(rw.x, rw.x + rw.y);
                 else if (type == RW_DOUBLE) {
@@ -858,24 +934,19 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
                         else if (op == 2u || op == 3u) cursor += len;
                     }
                 }
-            }
+            };
+            apply(rw0, ds.x + (u32)lane);
+            apply(rw1, ds.x + 64u + (u32)lane);
+            for (u32 i = ds.x + 128u + (u32)lane; i < ds.y; i += 64) apply(a.runs[i], i);   // deep tiles only
+            stage_next();
             lds_fence();
-            // ---- read back, prefix sums of deltas and of the non-zero count (row-major = position order)
-            int4 v[ROWS];
-            int exd[ROWS], exn[ROWS];
-            int carry_d = 0, carry_n = 0;
+            // ---- read the rows back (lane = base mod 64) and count changed positions on the scalar unit
+            int x[ROWS];
+            u32 E = 0;
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                v[r] = t4[r * 64 + lane];
-                const int s3 = v[r].x + v[r].y + v[r].z + v[r].w;
-                const int nz = (v[r].x != 0) + (v[r].y != 0) + (v[r].z != 0) + (v[r].w != 0);
-                const int inc = wave_incl_scan(s3), incn = wave_incl_scan(nz);
-                exd[r] = carry_d + inc - s3;
-                exn[r] = carry_n + incn - nz;
-                carry_d += __builtin_amdgcn_readlane(inc, 63);
-                carry_n += __builtin_amdgcn_readlane(incn, 63);
-            }
-            const u32 E = (u32)carry_n;
+            for (int j = 0; j < ROWS; j++) x[j] = tile[j * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < ROWS; j++) E += (u32)__popcll(__ballot(x[j] != 0));
             const bool has_win = 2 * excl < (u64)L;
             const u32 ws = has_win ? (u32)excl : 0u, we = has_win ? (u32)(L - excl) : 0u;
             const u32 wst = max(ws, lo), wet = min(we, lo + tlen_t);
@@ -883,71 +954,73 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
             if (win_any) proc_win += (u64)(wet - wst);
 
             if (!WRITE_DEPTH && E <= (u32)CAP) {
-                // ---- sparse path: compact (local position, depth after) in place, then one pass over segments
-                lds_fence();
+                // ---- sparse path.  LDS requests of one wave are served in order, so the entry writes below cannot
+                // overtake the row reads above.
+                u32 base = 0;
 #pragma unroll
-                for (int r = 0; r < ROWS; r++) {
-                    const int dl[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
-                    int d = exd[r], k = exn[r];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        d += dl[j];
-                        if (dl[j] != 0) { tile[k] = 4 * (r * 64 + lane) + j; tile[CAP + k] = d; k++; }
+                for (int j = 0; j < ROWS; j++) {
+                    const u64 m = __ballot(x[j] != 0);
+                    if (x[j] != 0) {
+                        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                        ent[base + rank] = make_int2(j * 64 + lane, x[j]);
                     }
+                    base += (u32)__popcll(m);
                 }
                 lds_fence();
                 const u32 wl0 = win_any ? wst - lo : 0u, wl1 = win_any ? wet - lo : 0u;
-                for (u32 e = (u32)lane; e <= E; e += 64) {
-                    u32 s = e == 0 ? 0u : (u32)tile[e - 1];
-                    const int d = e == 0 ? 0 : tile[CAP + e - 1];
-                    u32 en = e < E ? (u32)tile[e] : tlen_t;
-                    s = min(s, tlen_t); en = min(en, tlen_t);
-                    const u32 du = (u32)d;
-                    if (d > 0) cov_f += en - s;
-                    const u32 a0 = max(s, wl0), a1 = min(en, wl1);
-                    if (a1 > a0) {
-                        const u32 len = a1 - a0;
-                        sum_d += (u64)du * len;
-                        sum_d2 += (u64)du * du * len;
-                        if (d > 0) cov_w += len;
-                        mn = min(mn, du); mx = max(mx, du);
-                        if (WANT_HIST) hist_add(du, len);
+                // leading zero-depth segment [0, first entry)
+                if (lane == 0) {
+                    const u32 en = min(E ? (u32)ent[0].x : tlen_t, tlen_t);
+                    const u32 a1 = min(en, wl1);
+                    if (a1 > wl0) { mn = 0u; if (WANT_HIST) hist_add(0u, a1 - wl0); }
+                }
+                int carry = 0;
+                for (u32 e0 = 0; e0 < E; e0 += 64) {
+                    const u32 e = e0 + (u32)lane;
+                    const bool live = e < E;
+                    const int2 en = live ? ent[e] : make_int2(0, 0);
+                    const u32 nxt = (e + 1 < E) ? (u32)ent[e + 1].x : tlen_t;
+                    const int inc = wave_incl_scan(en.y);
+                    const int d = carry + inc;
+                    carry += __builtin_amdgcn_readlane(inc, 63);
+                    if (live) {
+                        const u32 s = min((u32)en.x, tlen_t), t_ = min(nxt, tlen_t);
+                        const u32 du = (u32)d;
+                        if (d > 0) cov_f += t_ - s;
+                        const u32 a0 = max(s, wl0), a1 = min(t_, wl1);
+                        if (a1 > a0) {
+                            const u32 len = a1 - a0;
+                            sum_d += (u64)du * len;
+                            sum_d2 += (u64)du * du * len;
+                            if (d > 0) cov_w += len;
+                            mn = min(mn, du); mx = max(mx, du);
+                            if (WANT_HIST) hist_add(du, len);
+                        }
                     }
                 }
             } else {
-                // ---- dense path: per-base accumulation (change-point histogram as in k_pileup)
+                // ---- dense path: one wave scan per row of 64 bases
+                int carry = 0;
 #pragma unroll
-                for (int r = 0; r < ROWS; r++) {
-                    const u32 p0 = lo + 4u * (u32)(r * 64 + lane);
-                    const int dl[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
-                    int d = exd[r];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int prev = d;
-                        d += dl[j];
-                        const u32 p = p0 + j;
-                        const u32 du = (u32)d;
-                        if (p < L) {
-                            cov_f += d > 0;
-                            if (WRITE_DEPTH) a.depth_out[p] = d;
-                            if (win_any && p >= wst && p < wet) {
-                                sum_d += du;
-                                sum_d2 += (u64)du * du;
-                                cov_w += d > 0;
-                                mn = min(mn, du); mx = max(mx, du);
-                                if (WANT_HIST && dl[j] != 0) {
-                                    const u32 rel = p - wst;
-                                    if (rel) { hist_add((u32)prev, rel); hist_add(du, 0u - rel); }
-                                }
+                for (int j = 0; j < ROWS; j++) {
+                    const int inc = wave_incl_scan(x[j]);
+                    const int d = carry + inc;
+                    carry += __builtin_amdgcn_readlane(inc, 63);
+                    const u32 p = lo + (u32)(j * 64 + lane);
+                    const u32 du = (u32)d;
+                    if (p < L) {
+                        cov_f += d > 0;
+                        if (WRITE_DEPTH) a.depth_out[p] = d;
+                        if (win_any && p >= wst && p < wet) {
+                            sum_d += du;
+                            sum_d2 += (u64)du * du;
+                            cov_w += d > 0;
+                            mn = min(mn, du); mx = max(mx, du);
+                            if (WANT_HIST) {
+                                const u32 rel = p - wst;
+                                if (x[j] != 0 && rel) { hist_add((u32)(d - x[j]), rel); hist_add(du, 0u - rel); }
+                                if (p == wet - 1) hist_add(du, wet - wst);
                             }
-                        }
-                    }
-                    if (WANT_HIST && win_any) {
-                        const u32 last = wet - 1;
-                        if (last >= p0 && last < p0 + 4) {
-                            int dd = exd[r];
-                            for (u32 j = 0; j <= last - p0; j++) dd += dl[j];
-                            hist_add((u32)dd, wet - wst);
                         }
                     }
                 }
@@ -955,9 +1028,10 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
         }
         flush();
         cur_c = -1;
+        ch = ch_next;
     }
 }
 
-constexpr size_t pileup_stream_smem_bytes(int rows) { return (size_t)4 * ((size_t)rows * 256 * 4 + 512 * 4); }
+constexpr size_t pileup_stream_smem_bytes() { return (size_t)4 * ((size_t)STREAM_TW * 4 + STREAM_HB * 4); }
 
 }  // namespace covk
