@@ -81,3 +81,21 @@ def read_alignment_file(path: str, threads: int = None, want_names: bool = True)
         return AlignmentFile(path, names, lens, rec, qn, mtid)
     finally:
         L.covh_bam_close(h)
+
+
+def write_bam(path: str, names, lens, batch: RecordBatch, with_seq: bool = True, level: int = 1, threads: int = None):
+    """Threaded BGZF/BAM writer (covh_bam_write) for synthetic inputs."""
+    L = _lib()
+    if threads is None:
+        threads = min(32, os.cpu_count() or 1)
+    cb = CovBatch()
+    for k in ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar"):
+        a = getattr(batch, k)
+        setattr(cb, k, a.ctypes.data if a.size else None)
+    cb.n_records = batch.n_records
+    nm = (C.c_char_p * max(1, len(names)))(*[n.encode() for n in names])
+    ln = np.ascontiguousarray(lens, dtype=np.uint64)
+    L.covh_bam_write.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(CovBatch), C.c_int, C.c_int, C.c_int]
+    rc = L.covh_bam_write(path.encode(), len(names), nm, ln.ctypes.data, C.byref(cb), int(with_seq), level, threads)
+    if rc:
+        raise IOError("covh_bam_write failed (%d)" % rc)

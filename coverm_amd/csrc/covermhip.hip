@@ -90,7 +90,9 @@ struct cov_session {
     uint32_t adopted_cig_end = 0;
 
     DevBuf<uint2> d_runs;
-    DevBuf<double> d_ident;
+    DevBuf<double> d_ident, d_identp;
+    hipStream_t side = nullptr;     // k_identity overlaps k_ranges / k_pileup
+    hipEvent_t ev_prep_done = nullptr, ev_side_done = nullptr;
     DevBuf<u32> d_arena;
     DevBuf<u64> d_chist;
     DevBuf<int32_t> d_depth;
@@ -270,7 +272,10 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
-    e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    e = hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_prep_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_side_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete s; return COV_ERR_HIP; }
     for (int k = 0; k < COV_K_COUNT; k++)
         for (int j = 0; j < 2; j++) (void)hipEventCreate(&s->ev[k][j]);
@@ -288,7 +293,10 @@ void cov_destroy(cov_session *s) {
     s->d_ctg.release(); s->d_glob.release(); s->d_desc.release();
     s->s_tid.release(); s->s_pos.release(); s->s_flag.release(); s->s_mapq.release(); s->s_nmk.release();
     s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
-    s->d_runs.release(); s->d_ident.release(); s->d_arena.release(); s->d_chist.release(); s->d_depth.release();
+    s->d_runs.release(); s->d_ident.release(); s->d_identp.release();
+    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
+    if (s->ev_prep_done) (void)hipEventDestroy(s->ev_prep_done);
+    if (s->ev_side_done) (void)hipEventDestroy(s->ev_side_done); s->d_arena.release(); s->d_chist.release(); s->d_depth.release();
     for (int k = 0; k < COV_K_COUNT; k++)
         for (int j = 0; j < 2; j++) if (s->ev[k][j]) (void)hipEventDestroy(s->ev[k][j]);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -397,7 +405,7 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
     for (int k = 0; k < COV_K_COUNT; k++) { s->k_launches[k] = 0; s->k_ms[k] = 0.f; }
 
     HIPCHK(s->d_runs.reserve(std::max<size_t>(1, R), st));
-    if (want_id) HIPCHK(s->d_ident.reserve(std::max<size_t>(1, R), st));
+    if (want_id) { HIPCHK(s->d_ident.reserve(std::max<size_t>(1, R), st)); HIPCHK(s->d_identp.reserve(std::max<size_t>(1, R), st)); }
     if (want_hist) HIPCHK(s->d_arena.reserve((size_t)R + nT + 1, st));
 
     hipLaunchKernelGGL(k_init, dim3((std::max(nT, COUNTER_SLOTS * 8) + 255) / 256), dim3(256), 0, st, s->d_ctg.p, nT, s->d_glob.p);
@@ -415,12 +423,22 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
         time_begin(s, COV_K_PREP);
         if (want_id)
             hipLaunchKernelGGL((k_prep<true>), dim3((R + PREP_CHUNK - 1) / PREP_CHUNK), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
-                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, s->d_ident.p);
+                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, s->d_identp.p, s->d_ident.p);
         else
             hipLaunchKernelGGL((k_prep<false>), dim3((R + PREP_CHUNK - 1) / PREP_CHUNK), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
-                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, (double *)nullptr);
+                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, (double *)nullptr, (double *)nullptr);
         time_end(s, COV_K_PREP);
         HIPCHK(hipGetLastError());
+        if (want_id && nT) {   // depends only on k_prep: run beside k_ranges / k_pileup
+            HIPCHK(hipEventRecord(s->ev_prep_done, st));
+            HIPCHK(hipStreamWaitEvent(s->side, s->ev_prep_done, 0));
+            (void)hipEventRecord(s->ev[COV_K_IDENTITY][0], s->side);
+            hipLaunchKernelGGL(k_identity, dim3(nT), dim3(64), 0, s->side, s->d_ctg.p, nT, s->d_identp.p, s->d_ident.p, r.tid);
+            (void)hipEventRecord(s->ev[COV_K_IDENTITY][1], s->side);
+            s->k_launches[COV_K_IDENTITY]++;
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(s->ev_side_done, s->side));   // joined just before the results are copied back
+        }
     }
     if (R && s->n_tiles) {
         time_begin(s, COV_K_RANGES);
@@ -446,12 +464,6 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
         else launch_any_pileup<false, false>(s, a, s->n_tiles);
         time_end(s, COV_K_PILEUP);
         HIPCHK(hipGetLastError());
-        if (want_id) {
-            time_begin(s, COV_K_IDENTITY);
-            hipLaunchKernelGGL(k_identity, dim3(nT), dim3(64), 0, st, s->d_ctg.p, nT, s->d_ident.p, r.flag, r.tid);
-            time_end(s, COV_K_IDENTITY);
-            HIPCHK(hipGetLastError());
-        }
         if (want_hist) {
             hipLaunchKernelGGL((k_hist_layout<1>), dim3(1), dim3(1024), 0, st, s->d_ctg.p, nT, s->d_tlen.p, mask,
                                (u64)s->cfg.contig_end_exclusion, s->d_glob.p);
@@ -459,6 +471,7 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
         }
     }
     s->h_ctg.resize(nT);
+    if (want_id && R && nT) HIPCHK(hipStreamWaitEvent(st, s->ev_side_done, 0));
     if (nT) HIPCHK(hipMemcpyAsync(s->h_ctg.data(), s->d_ctg.p, (size_t)nT * sizeof(DevContig), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&s->h_glob, s->d_glob.p, sizeof(DevGlobal), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

@@ -342,4 +342,87 @@ const uint32_t *covh_bam_qname_off(const covh_bam *h) { return h->b.qname_off.em
 const char *covh_bam_qnames(const covh_bam *h) { return h->b.qnames.data(); }
 uint64_t covh_bam_n_cigar(const covh_bam *h) { return h->b.cigar.size(); }
 
+// ---- writer: SoA batch -> BGZF BAM (synthetic benchmark inputs; SEQ is all 'A', QUAL 0xff, or '*' when !with_seq).
+// Records are serialised in parallel slices, cut into <= 0xff00-byte blocks and deflated by the thread pool.
+int covh_bam_write(const char *path, uint32_t n_targets, const char *const *names, const uint64_t *lens,
+                   const cov_batch *b, int with_seq, int level, int threads) {
+    std::vector<uint8_t> head;
+    auto put32 = [](std::vector<uint8_t> &v, uint32_t x) { uint8_t t[4]; memcpy(t, &x, 4); v.insert(v.end(), t, t + 4); };
+    head.insert(head.end(), {'B', 'A', 'M', 1});
+    std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+    for (uint32_t i = 0; i < n_targets; i++) text += std::string("@SQ\tSN:") + names[i] + "\tLN:" + std::to_string(lens[i]) + "\n";
+    put32(head, (uint32_t)text.size()); head.insert(head.end(), text.begin(), text.end());
+    put32(head, n_targets);
+    for (uint32_t i = 0; i < n_targets; i++) {
+        const size_t l = strlen(names[i]) + 1;
+        put32(head, (uint32_t)l); head.insert(head.end(), names[i], names[i] + l); put32(head, (uint32_t)lens[i]);
+    }
+    const uint64_t R = b->n_records;
+    // per-record sizes -> offsets
+    std::vector<uint64_t> off(R + 1, 0);
+    for (uint64_t i = 0; i < R; i++) {
+        const uint32_t nc = b->cigar_off[i + 1] - b->cigar_off[i];
+        const uint32_t ls = with_seq ? b->l_seq[i] : 0;
+        char qn[32]; const int lq = snprintf(qn, sizeof qn, "r%llu", (unsigned long long)i) + 1;
+        const uint32_t aux = b->nm_kind[i] == COV_NM_UNSIGNED ? (b->nm[i] < 256 ? 4 : b->nm[i] < 65536 ? 5 : 7) : b->nm_kind[i] == COV_NM_BADTYPE ? 4 : 0;
+        off[i + 1] = off[i] + 36 + lq + 4ull * nc + (ls + 1) / 2 + ls + aux;
+    }
+    std::vector<uint8_t> raw(head.size() + off[R]);
+    memcpy(raw.data(), head.data(), head.size());
+    uint8_t *base = raw.data() + head.size();
+    parallel_for(R, threads, [&](size_t i) {
+        uint8_t *p = base + off[i];
+        const uint32_t nc = b->cigar_off[i + 1] - b->cigar_off[i];
+        const uint32_t ls = with_seq ? b->l_seq[i] : 0;
+        char qn[32]; const int lq = snprintf(qn, sizeof qn, "r%llu", (unsigned long long)i) + 1;
+        const uint32_t bs = (uint32_t)(off[i + 1] - off[i] - 4);
+        auto w32 = [&](uint32_t x) { memcpy(p, &x, 4); p += 4; };
+        w32(bs); w32((uint32_t)b->tid[i]); w32((uint32_t)b->pos[i]);
+        *p++ = (uint8_t)lq; *p++ = b->mapq[i];
+        const uint16_t bin = 4680, ncg = (uint16_t)nc, fl = b->flag[i];
+        memcpy(p, &bin, 2); p += 2; memcpy(p, &ncg, 2); p += 2; memcpy(p, &fl, 2); p += 2;
+        w32(ls); w32((uint32_t)-1); w32((uint32_t)-1); w32(0);
+        memcpy(p, qn, lq); p += lq;
+        if (nc) { memcpy(p, b->cigar + b->cigar_off[i], 4ull * nc); p += 4ull * nc; }
+        memset(p, 0x11, (ls + 1) / 2); p += (ls + 1) / 2;
+        memset(p, 0xff, ls); p += ls;
+        if (b->nm_kind[i] == COV_NM_UNSIGNED) {
+            *p++ = 'N'; *p++ = 'M';
+            if (b->nm[i] < 256) { *p++ = 'C'; *p++ = (uint8_t)b->nm[i]; }
+            else if (b->nm[i] < 65536) { *p++ = 'S'; const uint16_t v = (uint16_t)b->nm[i]; memcpy(p, &v, 2); p += 2; }
+            else { *p++ = 'I'; memcpy(p, &b->nm[i], 4); p += 4; }
+        } else if (b->nm_kind[i] == COV_NM_BADTYPE) { *p++ = 'N'; *p++ = 'M'; *p++ = 'c'; *p++ = 1; }
+    });
+    const size_t BLK = 0xff00;
+    const size_t nblk = (raw.size() + BLK - 1) / BLK;
+    std::vector<std::vector<uint8_t>> comp(nblk);
+    std::atomic<bool> ok{true};
+    parallel_for(nblk, threads, [&](size_t k) {
+        const size_t s0 = k * BLK, n = std::min(BLK, raw.size() - s0);
+        std::vector<uint8_t> &o = comp[k];
+        o.resize(n + n / 8 + 128);
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok = false; return; }
+        zs.next_in = &raw[s0]; zs.avail_in = (uInt)n; zs.next_out = o.data() + 18; zs.avail_out = (uInt)(o.size() - 26);
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { ok = false; deflateEnd(&zs); return; }
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        memcpy(o.data(), hdr, 16);
+        const uint16_t bsz = (uint16_t)(clen + 25);
+        memcpy(o.data() + 16, &bsz, 2);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), &raw[s0], (uInt)n), isz = (uint32_t)n;
+        memcpy(o.data() + 18 + clen, &crc, 4); memcpy(o.data() + 22 + clen, &isz, 4);
+        o.resize(clen + 26);
+    });
+    if (!ok) return 1;
+    FILE *f = fopen(path, "wb");
+    if (!f) return 2;
+    for (auto &o : comp) fwrite(o.data(), 1, o.size(), f);
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    fwrite(eof, 1, 28, f);
+    fclose(f);
+    return 0;
+}
+
 }  // extern "C"

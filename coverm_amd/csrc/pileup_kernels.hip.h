@@ -187,7 +187,8 @@ __device__ __forceinline__ void prep_flush(DevContig *ctg, int cur, PrepAcc &a) 
 template <bool WANT_IDENTITY>
 __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__ tlen, u32 n_targets,
                                               const uint8_t *__restrict__ mask, FilterCfg f, DevContig *ctg,
-                                              DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ ident) {
+                                              DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ identp,
+                                              double *__restrict__ identn) {
     __shared__ u32 blk_cnt[2][4];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     const u32 chunk = blockIdx.x * (u32)PREP_CHUNK;
@@ -326,7 +327,10 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                     else rw.y = RW_COMPLEX << 30;
                 }
                 runs[i] = rw;
-                if (WANT_IDENTITY) ident[i] = (masked_in && !supp) ? idv : 0.0;
+                if (WANT_IDENTITY) {
+                    identn[i] = (masked_in && !supp) ? idv : 0.0;
+                    identp[i] = (masked_in && !supp && !sec) ? idv : 0.0;
+                }
             }
 
             // per-contig counters: accumulate per lane while the wave stays inside one contig
@@ -496,10 +500,14 @@ __global__ __launch_bounds__(256) void k_hist_compact(const DevContig *__restric
 }
 
 // ------------------------------------------------------------------------------------ k_identity
-// File-order f64 sums, bit-identical to the reference's sequential `+=` (contig.rs:208-211): every lane
-// of the wave walks the same serial chain, 64 records per coalesced load.
-__global__ __launch_bounds__(64) void k_identity(DevContig *ctg, u32 n_targets, const double *__restrict__ ident,
-                                                 const uint16_t *__restrict__ flag, const int32_t *__restrict__ tidv) {
+// File-order f64 sums, bit-identical to the reference's sequential `+=` (contig.rs:208-211).  The additions of
+// one contig form a strict dependency chain (f64 addition is not associative), so one wave walks each contig:
+// 64 values per coalesced load, then every lane replays the same 64 dependent adds from lane broadcasts.
+// k_prep wrote two value streams: identn (not supplementary) and identp (primary).  Runs on the session's side
+// stream, beside k_ranges / k_pileup.  Cost ~10 cycles per record of the LONGEST contig; an exact parallel
+// formulation (integer summation per binade of the running sum) is planned — see DESIGN.md.
+__global__ __launch_bounds__(64) void k_identity(DevContig *ctg, u32 n_targets, const double *__restrict__ identp,
+                                                 const double *__restrict__ identn, const int32_t *__restrict__ tidv) {
     const u32 c = blockIdx.x;
     if (c >= n_targets) return;
     DevContig *C = &ctg[c];
@@ -508,16 +516,18 @@ __global__ __launch_bounds__(64) void k_identity(DevContig *ctg, u32 n_targets, 
     const bool generic = C->n_groups != 1u;
     double accp = 0.0, accn = 0.0;
     const int lane = lane_id();
+    u32 i = rs + (u32)lane;
+    double xp = 0.0, xn = 0.0;
+    if (i < re && (!generic || tidv[i] == (int)c)) { xp = identp[i]; xn = identn[i]; }
     for (u32 b = rs; b < re; b += 64) {
-        const u32 i = b + lane;
-        double x = 0.0;
-        u32 fl = 0x100u;
-        if (i < re && (!generic || tidv[i] == (int)c)) { x = ident[i]; fl = flag[i]; }
-        const double xp = (fl & 0x100u) ? 0.0 : x;  // primary variant additionally excludes secondary
-#pragma unroll 8
+        const double cp = xp, cn = xn;
+        i += 64;   // prefetch the next 64 while the dependent adds of this batch run
+        xp = 0.0; xn = 0.0;
+        if (i < re && (!generic || tidv[i] == (int)c)) { xp = identp[i]; xn = identn[i]; }
+#pragma unroll 16
         for (int k = 0; k < 64; k++) {
-            accn += __shfl(x, k);
-            accp += __shfl(xp, k);
+            accn += __shfl(cn, k);
+            accp += __shfl(cp, k);
         }
     }
     if (lane == 0) { C->id_primary = accp; C->id_nonsupp = accn; }

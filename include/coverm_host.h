@@ -136,6 +136,10 @@ void covh_bam_batch(const covh_bam *h, cov_batch *out);
 const int32_t *covh_bam_mtid(const covh_bam *h);
 const uint32_t *covh_bam_qname_off(const covh_bam *h); /* n_records + 1, NULL without want_names */
 const char *covh_bam_qnames(const covh_bam *h);
+/* Writes a batch as a coordinate-sorted BGZF BAM (benchmark/test inputs): read names r<i>, SEQ all 'A' (or '*' when
+ * !with_seq), NM typed C/S/I by magnitude.  Returns 0 on success. */
+int covh_bam_write(const char *path, uint32_t n_targets, const char *const *names, const uint64_t *lens,
+                   const cov_batch *batch, int with_seq, int level, int threads);
 
 /* calculate_coverage for one entry built from explicit sums (used by unit tests). */
 typedef struct {

@@ -86,3 +86,18 @@ def test_empty_and_errors(tmp_path):
         fh.write(raw)
     with pytest.raises(IOError):
         cbam.read_alignment_file(bad)
+
+
+def test_cpp_writer_roundtrip(tmp_path):
+    ref = synth.make_reference(9, 300_000, seed=2, min_len=1500, max_len=80_000)
+    b = synth.make_reads(ref, 20_000, seed=3)
+    b.nm = b.nm.copy(); b.nm[5] = 300; b.nm[6] = 70000    # exercise NM types S and I
+    for with_seq in (True, False):
+        p = str(tmp_path / ("w%d.bam" % with_seq))
+        cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=with_seq, threads=4)
+        d = bamio.read_bam(p)                      # oracle reader
+        af = cbam.read_alignment_file(p, threads=4)  # product reader
+        same(af, d)
+        for f in ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "cigar_off", "cigar"):
+            np.testing.assert_array_equal(getattr(af.records, f), getattr(b, f), err_msg=f)
+        np.testing.assert_array_equal(af.records.l_seq, b.l_seq if with_seq else np.zeros_like(b.l_seq))

@@ -1,0 +1,71 @@
+"""End-to-end timing: synthetic BAM on disk -> `coverm-amd contig` (C++ reader + GPU engine) vs CPU oracle.
+
+Reports (i) BAM decode time (C++ reader, t threads), (ii) H2D + device pipeline, (iii) whole binary wall time,
+(iv) the CPU oracle scan on the already-decoded records.  Used for DESIGN.md's end-to-end table; not the bench.
+"""
+import argparse
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from coverm_amd import bam as cbam  # noqa: E402
+from coverm_amd import synth  # noqa: E402
+from coverm_amd.engine import FilterConfig, Session  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reads", type=int, default=10_000_000)
+ap.add_argument("--contigs", type=int, default=1000)
+ap.add_argument("--bp", type=int, default=200_000_000)
+ap.add_argument("--threads", type=int, default=32)
+ap.add_argument("--cpu", type=int, default=1)
+a = ap.parse_args()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "coverm_amd", "coverm-amd")
+
+ref = synth.make_reference(a.contigs, a.bp, seed=1)
+batch = synth.make_reads(ref, a.reads, seed=2)
+tmp = tempfile.mkdtemp(prefix="covbam")
+for with_seq in (True, False):
+    path = os.path.join(tmp, "synth_%s.bam" % ("seq" if with_seq else "lean"))
+    t = time.time()
+    cbam.write_bam(path, ref.names, ref.lengths, batch, with_seq=with_seq, threads=a.threads)
+    tw = time.time() - t
+    size = os.path.getsize(path)
+    t = time.time()
+    af = cbam.read_alignment_file(path, threads=a.threads, want_names=False)
+    td = time.time() - t
+    t = time.time()
+    with Session(0, FilterConfig(), 75, want_hist=True) as s:
+        s.set_targets(af.ref_lens)
+        s.push(af.records)
+        st, summ = s.finish()
+        h = s.hist()
+    tg = time.time() - t
+    t = time.time()
+    r = subprocess.run([BIN, "contig", "-b", path, "-m", "mean", "trimmed_mean", "covered_fraction", "variance", "-t",
+                        str(a.threads), "-o", os.path.join(tmp, "out.tsv")], capture_output=True, text=True)
+    tb = time.time() - t
+    assert r.returncode == 0, r.stderr
+    print("%s BAM: %.2f GB written in %.1fs | decode(%d thr) %.2fs = %.1f M rec/s | session create+push+finish %.3fs | "
+          "coverm-amd binary wall %.2fs = %.2f M reads/s end-to-end" % (
+              "full-SEQ" if with_seq else "lean", size / 1e9, tw, a.threads, td, a.reads / td / 1e6, tg, tb,
+              int(summ.n_considered) / tb / 1e6), flush=True)
+if a.cpu:
+    from oracle import oracle as O
+    from oracle.bamio import BamData
+    import ctypes as C
+    z = np.zeros(batch.n_records, np.int32)
+    b = BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq, batch.l_seq.astype(np.int32),
+                batch.nm, batch.nm_kind, batch.cigar_off, batch.cigar, z, z, z, [], "")
+    est = [O.est_mean(0.0, 75, False), O.est_trimmed_mean(0.05, 0.95, 0.0, 75), O.est_covered_fraction(0.0),
+           O.est_variance(0.0, 75)]
+    import io
+    t = time.time()
+    O.contig_coverage([b], ["s"], O.StreamingTaker(io.StringIO()), est, True, O.FlagFilter(True, True, False))
+    print("CPU oracle scan+estimators on decoded records: %.2fs = %.1f M reads/s (1 thread)" % (
+        time.time() - t, a.reads / (time.time() - t) / 1e6))
