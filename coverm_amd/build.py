@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
         cmd += ["-x", "c++", f]
     for f in hip:
         cmd += ["-x", "hip", f]
-    cmd += ["-o", LIB + ".tmp", "-lz", "-lpthread"]
+    cmd += ["-o", LIB + ".tmp", "-lz", "-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -91,6 +91,8 @@ struct cov_session {
 
     DevBuf<uint2> d_runs;
     DevBuf<double> d_ident, d_identp;
+    DevBuf<IdChunk> d_idch;
+    int id_mode = 1;   // 1 = exact parallel identity sums, 0 = serial chain only (COVERM_IDENTITY=serial)
     hipStream_t side = nullptr;     // k_identity overlaps k_ranges / k_pileup
     hipEvent_t ev_prep_done = nullptr, ev_side_done = nullptr;
     DevBuf<u32> d_arena;
@@ -272,6 +274,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
+    if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
     e = hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_prep_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_side_done, hipEventDisableTiming);
@@ -293,7 +296,7 @@ void cov_destroy(cov_session *s) {
     s->d_ctg.release(); s->d_glob.release(); s->d_desc.release();
     s->s_tid.release(); s->s_pos.release(); s->s_flag.release(); s->s_mapq.release(); s->s_nmk.release();
     s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
-    s->d_runs.release(); s->d_ident.release(); s->d_identp.release();
+    s->d_runs.release(); s->d_ident.release(); s->d_identp.release(); s->d_idch.release();
     if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
     if (s->ev_prep_done) (void)hipEventDestroy(s->ev_prep_done);
     if (s->ev_side_done) (void)hipEventDestroy(s->ev_side_done); s->d_arena.release(); s->d_chist.release(); s->d_depth.release();
@@ -405,7 +408,10 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
     for (int k = 0; k < COV_K_COUNT; k++) { s->k_launches[k] = 0; s->k_ms[k] = 0.f; }
 
     HIPCHK(s->d_runs.reserve(std::max<size_t>(1, R), st));
-    if (want_id) { HIPCHK(s->d_ident.reserve(std::max<size_t>(1, R), st)); HIPCHK(s->d_identp.reserve(std::max<size_t>(1, R), st)); }
+    if (want_id) {
+        HIPCHK(s->d_ident.reserve(std::max<size_t>(1, R), st)); HIPCHK(s->d_identp.reserve(std::max<size_t>(1, R), st));
+        HIPCHK(s->d_idch.reserve((size_t)R / ID_CH + 2, st));
+    }
     if (want_hist) HIPCHK(s->d_arena.reserve((size_t)R + nT + 1, st));
 
     hipLaunchKernelGGL(k_init, dim3((std::max(nT, COUNTER_SLOTS * 8) + 255) / 256), dim3(256), 0, st, s->d_ctg.p, nT, s->d_glob.p);
@@ -433,7 +439,14 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
             HIPCHK(hipEventRecord(s->ev_prep_done, st));
             HIPCHK(hipStreamWaitEvent(s->side, s->ev_prep_done, 0));
             (void)hipEventRecord(s->ev[COV_K_IDENTITY][0], s->side);
-            hipLaunchKernelGGL(k_identity, dim3(nT), dim3(64), 0, s->side, s->d_ctg.p, nT, s->d_identp.p, s->d_ident.p, r.tid);
+            if (s->id_mode) {
+                const u32 nch = (R + ID_CH - 1) / ID_CH;
+                hipLaunchKernelGGL(k_id_approx, dim3(nch), dim3(256), 0, s->side, s->d_identp.p, s->d_ident.p, R, s->d_idch.p);
+                hipLaunchKernelGGL(k_id_predict, dim3(nT), dim3(64), 0, s->side, s->d_ctg.p, nT, s->d_identp.p, s->d_ident.p, s->d_idch.p);
+                hipLaunchKernelGGL(k_id_exact, dim3(nch), dim3(256), 0, s->side, s->d_identp.p, s->d_ident.p, R, s->d_idch.p);
+                hipLaunchKernelGGL(k_id_combine, dim3(nT), dim3(64), 0, s->side, s->d_ctg.p, nT, s->d_identp.p, s->d_ident.p, r.tid, s->d_idch.p);
+            } else
+                hipLaunchKernelGGL(k_identity, dim3(nT), dim3(64), 0, s->side, s->d_ctg.p, nT, s->d_identp.p, s->d_ident.p, r.tid);
             (void)hipEventRecord(s->ev[COV_K_IDENTITY][1], s->side);
             s->k_launches[COV_K_IDENTITY]++;
             HIPCHK(hipGetLastError());

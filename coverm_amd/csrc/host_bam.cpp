@@ -11,6 +11,7 @@
 // inflated by a pool of threads straight into one contiguous buffer (offsets from each block's ISIZE);
 // record boundaries are then found in one cheap serial hop over block_size fields and the per-record field
 // extraction (including the linear aux scan for NM) runs in parallel again.
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -44,19 +45,6 @@ struct Bam {
 inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 inline uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
 
-bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &err) {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) { err = "Unable to find BAM file " + path; return false; }
-    fseek(f, 0, SEEK_END);
-    long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    out.resize(n > 0 ? (size_t)n : 0);
-    size_t got = n > 0 ? fread(out.data(), 1, (size_t)n, f) : 0;
-    fclose(f);
-    if (got != out.size()) { err = "short read on " + path; return false; }
-    return true;
-}
-
 template <typename F>
 void parallel_for(size_t n, int threads, F fn) {
     threads = std::max(1, std::min<int>(threads, (int)std::max<size_t>(1, n)));
@@ -76,8 +64,44 @@ void parallel_for(size_t n, int threads, F fn) {
     for (auto &th : pool) th.join();
 }
 
+// ---- uninitialised byte buffer (a std::vector would memset gigabytes before inflate overwrites them)
+struct Buf {
+    uint8_t *p = nullptr; size_t n = 0;
+    Buf() = default;
+    Buf(const Buf &) = delete;
+    ~Buf() { free(p); }
+    bool alloc(size_t k) { free(p); p = (uint8_t *)malloc(k ? k : 1); n = k; return p != nullptr; }
+    const uint8_t &operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+    const uint8_t *data() const { return p; }
+};
+
+// ---- libdeflate, if the runtime has it (no header in this image: prototypes declared by hand); else zlib
+struct LibDeflate {
+    void *(*alloc)() = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    uint32_t (*crc32)(uint32_t, const void *, size_t) = nullptr;
+    bool ok = false;
+    LibDeflate() {
+        if (getenv("COVERM_NO_LIBDEFLATE")) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        crc32 = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        ok = alloc && decompress && release && crc32;
+    }
+};
+const LibDeflate &libdeflate() { static LibDeflate L; return L; }
+struct TlsDecompressor {
+    void *d = nullptr;
+    ~TlsDecompressor() { if (d) libdeflate().release(d); }
+};
+
 // ---- BGZF: block table, parallel inflate
-bool bgzf_inflate_all(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out, int threads, std::string &err) {
+bool bgzf_inflate_all(const Buf &raw, Buf &out, int threads, std::string &err) {
     struct Blk { size_t in_off, in_len; size_t out_off; uint32_t isize, crc; };
     std::vector<Blk> blocks;
     size_t p = 0, total = 0;
@@ -101,22 +125,45 @@ bool bgzf_inflate_all(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out
         blocks.push_back(b);
         p += bsize;
     }
-    out.resize(total);
+    if (!out.alloc(total)) { err = "out of memory"; return false; }
     std::atomic<bool> ok{true};
+    const LibDeflate &L = libdeflate();
     parallel_for(blocks.size(), threads, [&](size_t i) {
         const Blk &b = blocks[i];
         if (b.isize == 0) return;
+        uint8_t *dst = out.p + b.out_off;
+        if (L.ok) {
+            thread_local TlsDecompressor tls;
+            if (!tls.d) tls.d = L.alloc();
+            size_t got = 0;
+            if (!tls.d || L.decompress(tls.d, raw.p + b.in_off, b.in_len, dst, b.isize, &got) != 0 || got != b.isize) { ok = false; return; }
+            if (L.crc32(0, dst, b.isize) != b.crc) ok = false;
+            return;
+        }
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit2(&zs, -15) != Z_OK) { ok = false; return; }
-        zs.next_in = const_cast<Bytef *>(&raw[b.in_off]); zs.avail_in = (uInt)b.in_len;
-        zs.next_out = &out[b.out_off]; zs.avail_out = b.isize;
+        zs.next_in = const_cast<Bytef *>(raw.p + b.in_off); zs.avail_in = (uInt)b.in_len;
+        zs.next_out = dst; zs.avail_out = b.isize;
         const int rc = inflate(&zs, Z_FINISH);
         inflateEnd(&zs);
         if (rc != Z_STREAM_END || zs.total_out != b.isize) { ok = false; return; }
-        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), &out[b.out_off], b.isize) != b.crc) ok = false;
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.isize) != b.crc) ok = false;
     });
     if (!ok) { err = "BGZF inflate / CRC failure"; return false; }
+    return true;
+}
+
+bool read_file(const std::string &path, Buf &out, std::string &err) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { err = "Unable to find BAM file " + path; return false; }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (!out.alloc(n > 0 ? (size_t)n : 0)) { fclose(f); err = "out of memory"; return false; }
+    size_t got = n > 0 ? fread(out.p, 1, (size_t)n, f) : 0;
+    fclose(f);
+    if (got != out.size()) { err = "short read on " + path; return false; }
     return true;
 }
 
@@ -161,7 +208,7 @@ uint8_t scan_nm(const uint8_t *p, const uint8_t *end, uint32_t &nm) {
     return COV_NM_ABSENT;
 }
 
-bool parse_bam(Bam &b, const std::vector<uint8_t> &u) {
+bool parse_bam(Bam &b, const Buf &u) {
     if (u.size() < 12 || memcmp(u.data(), "BAM\1", 4) != 0) { b.err = "bad BAM magic"; return false; }
     size_t p = 4;
     const uint32_t l_text = rd32(&u[p]); p += 4;
@@ -176,24 +223,24 @@ bool parse_bam(Bam &b, const std::vector<uint8_t> &u) {
         b.names.emplace_back((const char *)&u[p], l_name ? l_name - 1 : 0); p += l_name;
         b.lens.push_back(rd32(&u[p])); p += 4;
     }
-    // record boundaries: one serial hop over block_size
+    // record boundaries, CIGAR and name offsets: one serial hop over the block_size fields
     std::vector<size_t> rec;
+    rec.reserve(u.size() / 200 + 16);
+    b.cigar_off.assign(1, 0);
+    if (b.want_names) b.qname_off.assign(1, 0);
+    uint32_t co = 0, qo = 0;
     while (p + 4 <= u.size()) {
         const uint32_t bs = rd32(&u[p]);
         if (bs < 32 || p + 4 + bs > u.size()) { b.err = "truncated BAM record"; return false; }
         rec.push_back(p);
+        co += rd16(&u[p + 16]);
+        b.cigar_off.push_back(co);
+        if (b.want_names) { qo += u[p + 12] ? u[p + 12] - 1u : 0u; b.qname_off.push_back(qo); }
         p += 4 + (size_t)bs;
     }
     const size_t R = rec.size();
     b.tid.resize(R); b.pos.resize(R); b.mtid.resize(R); b.flag.resize(R); b.mapq.resize(R); b.nm_kind.resize(R);
-    b.nm.resize(R); b.l_seq.resize(R); b.cigar_off.assign(R + 1, 0);
-    if (b.want_names) b.qname_off.assign(R + 1, 0);
-    // offsets (serial, trivial) then parallel field extraction
-    for (size_t i = 0; i < R; i++) {
-        const uint8_t *r = &u[rec[i]];
-        b.cigar_off[i + 1] = b.cigar_off[i] + rd16(r + 16);
-        if (b.want_names) b.qname_off[i + 1] = b.qname_off[i] + (r[12] ? r[12] - 1u : 0u);
-    }
+    b.nm.resize(R); b.l_seq.resize(R);
     b.cigar.resize(b.cigar_off[R]);
     if (b.want_names) b.qnames.resize(b.qname_off[R]);
     std::atomic<bool> ok{true};
@@ -224,7 +271,7 @@ bool parse_bam(Bam &b, const std::vector<uint8_t> &u) {
 }
 
 // ---- SAM text (htslib auto-detects the format; needed for e.g. tests/data/mapq_test.sam, filter.rs:758)
-bool parse_sam(Bam &b, const std::vector<uint8_t> &raw) {
+bool parse_sam(Bam &b, const Buf &raw) {
     const char *s = (const char *)raw.data(), *e = s + raw.size();
     std::vector<std::pair<std::string, size_t>> dummy;
     auto find_ref = [&](const std::string &n) -> int32_t {
@@ -309,13 +356,13 @@ struct covh_bam { Bam b; };
 covh_bam *covh_bam_open(const char *path, int threads, int want_names, char *err, size_t errcap) {
     covh_bam *h = new covh_bam();
     h->b.path = path; h->b.threads = std::max(1, threads); h->b.want_names = want_names != 0;
-    std::vector<uint8_t> raw;
+    Buf raw;
     bool ok = read_file(path, raw, h->b.err);
     if (ok) {
         if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
-            std::vector<uint8_t> u;
+            Buf u;
             ok = bgzf_inflate_all(raw, u, h->b.threads, h->b.err);
-            std::vector<uint8_t>().swap(raw);
+            raw.alloc(0);
             if (ok) ok = parse_bam(h->b, u);
         } else ok = parse_sam(h->b, raw);
     }

@@ -117,6 +117,17 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
     return v;
 }
 
+// broadcast of lane q's value through the scalar unit (v_readlane), far cheaper than a ds_bpermute shuffle
+__device__ __forceinline__ double bcast_f64(double v, int q) {
+    const long long b = __double_as_longlong(v);
+    const u32 lo = __builtin_amdgcn_readlane((u32)b, q), hi = __builtin_amdgcn_readlane((u32)(b >> 32), q);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+__device__ __forceinline__ u64 bcast_u64(u64 v, int q) {
+    const u32 lo = __builtin_amdgcn_readlane((u32)v, q), hi = __builtin_amdgcn_readlane((u32)(v >> 32), q);
+    return ((u64)hi << 32) | lo;
+}
+
 __device__ __forceinline__ void report_error(DevGlobal *g, u32 rec, u32 code) {
     atomicMin(&g->first_error, ((u64)rec << 8) | code);
 }
@@ -531,6 +542,205 @@ __global__ __launch_bounds__(64) void k_identity(DevContig *ctg, u32 n_targets, 
         }
     }
     if (lane == 0) { C->id_primary = accp; C->id_nonsupp = accn; }
+}
+
+// ------------------------------------------------------------------------------------ exact parallel identity sums
+// The reference adds one f64 per read to a running sum (contig.rs:208-211); that is a serial chain of rounded
+// additions.  It is nevertheless parallelisable EXACTLY: while the running sum S stays inside one binade
+// [2^e, 2^(e+1)) its ulp u = 2^(e-52) is constant, S = m*u with m an integer, and for 0 <= x <= 1 <= S
+//     fl(S + x) = (m + q + r) * u,   q = floor(x/u),  r = 1 if frac(x/u) > 1/2, 0 if < 1/2
+// (x/u is an exact shift of x's mantissa).  Only an exact tie frac == 1/2 depends on m (round-half-even) and only a
+// binade crossing changes u.  So a chunk of reads contributes the INTEGER sum of (q + r), computable in any order,
+// provided it has no tie and S does not leave the binade — which the combine step verifies against the exact S,
+// falling back to the serial chain for the few chunks that cross a binade, contain a tie or a value outside
+// [0, 1], or straddle two contigs.  Four small kernels:
+//   k_id_approx   per 1024-record chunk: approximate f64 sums (tree order) + "values outside [0,1]" flag
+//   k_id_predict  per contig: approximate prefix -> predicted binade of S at every interior chunk
+//   k_id_exact    per chunk : exact integer sum at the predicted binade + tie flag
+//   k_id_combine  per contig: exact running sum, verified fast path or serial chain per chunk
+constexpr u32 ID_CH = 1024;
+struct IdChunk {
+    double ap, an;      // approximate sums (primary / not-supplementary stream)
+    u64 tp, tn;         // exact integer sums in units of 2^(e-52)
+    int ep, en;         // predicted binade, or INT_MIN = do this chunk serially
+    u32 flags;          // bit0 irregular value in p stream, bit1 in n stream, bit2 tie p, bit3 tie n
+    u32 pad;
+};
+constexpr int ID_SERIAL = -2147483647 - 1;
+
+__device__ __forceinline__ int f64_exp(double v) { return (int)((__double_as_longlong(v) >> 52) & 0x7ff) - 1023; }
+
+__global__ __launch_bounds__(256) void k_id_approx(const double *__restrict__ identp, const double *__restrict__ identn,
+                                                   u32 n, IdChunk *__restrict__ ch) {
+    __shared__ double sp[4], sn[4];
+    __shared__ u32 sf[4];
+    const u32 k = blockIdx.x, base = k * ID_CH;
+    double ap = 0.0, an = 0.0;
+    u32 fl = 0;
+#pragma unroll
+    for (int j = 0; j < (int)(ID_CH / 256); j++) {
+        const u32 i = base + (u32)j * 256u + threadIdx.x;
+        if (i < n) {
+            const double xp = identp[i], xn = identn[i];
+            if (!(xp >= 0.0 && xp <= 1.0)) fl |= 1u;
+            if (!(xn >= 0.0 && xn <= 1.0)) fl |= 2u;
+            ap += xp; an += xn;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ap += __shfl_xor(ap, o); an += __shfl_xor(an, o); fl |= __shfl_xor(fl, o); }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sp[w] = ap; sn[w] = an; sf[w] = fl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        IdChunk c;
+        c.ap = sp[0] + sp[1] + sp[2] + sp[3]; c.an = sn[0] + sn[1] + sn[2] + sn[3];
+        c.tp = c.tn = 0; c.ep = c.en = ID_SERIAL; c.flags = sf[0] | sf[1] | sf[2] | sf[3]; c.pad = 0;
+        ch[k] = c;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_id_predict(const DevContig *__restrict__ ctg, u32 n_targets,
+                                                   const double *__restrict__ identp, const double *__restrict__ identn,
+                                                   IdChunk *__restrict__ ch) {
+    const u32 c = blockIdx.x;
+    if (c >= n_targets) return;
+    const DevContig *C = &ctg[c];
+    if (C->n_pass == 0 || C->n_groups != 1u) return;
+    const u32 rs = C->rec_start, re = C->rec_end;
+    const u32 k0 = (rs + ID_CH - 1) / ID_CH, k1 = re / ID_CH;   // interior chunks [k0, k1)
+    if (k0 >= k1) return;
+    // approximate sum of the head partial segment [rs, k0*ID_CH)
+    double pp = 0.0, pn = 0.0;
+    for (u32 i = rs + (threadIdx.x & 63); i < k0 * ID_CH; i += 64) { pp += identp[i]; pn += identn[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { pp += __shfl_xor(pp, o); pn += __shfl_xor(pn, o); }
+    const int lane = threadIdx.x & 63;
+    const double lo_f = 1.0 - 1.0 / 1048576.0, hi_f = 1.0 + 1.0 / 1048576.0;
+    // the prefix is only a prediction, so any summation order will do: 64 chunks per step, wave prefix scan
+    for (u32 kb = k0; kb < k1; kb += 64) {
+        const u32 k = kb + (u32)lane;
+        const bool live = k < k1;
+        const double ap = live ? ch[k].ap : 0.0, an = live ? ch[k].an : 0.0;
+        const u32 fl = live ? ch[k].flags : 3u;
+        double ip = ap, in_ = an;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double tp = __shfl_up(ip, o), tn = __shfl_up(in_, o);
+            if (lane >= o) { ip += tp; in_ += tn; }
+        }
+        const double sp = pp + (ip - ap), sn = pn + (in_ - an);   // prefix before this chunk
+        if (live) {
+            int e = ID_SERIAL;
+            if (!(fl & 1u) && sp >= 2.0 && f64_exp(sp * lo_f) == f64_exp((sp + ap) * hi_f)) e = f64_exp(sp);
+            ch[k].ep = e;
+            e = ID_SERIAL;
+            if (!(fl & 2u) && sn >= 2.0 && f64_exp(sn * lo_f) == f64_exp((sn + an) * hi_f)) e = f64_exp(sn);
+            ch[k].en = e;
+        }
+        pp += __shfl(ip, 63); pn += __shfl(in_, 63);
+    }
+}
+
+// (q + r) of one value at binade e; sets tie when frac(x/u) == 1/2 exactly
+__device__ __forceinline__ u64 id_units(double x, int e, bool &tie) {
+    const u64 b = (u64)__double_as_longlong(x);
+    if ((b << 1) == 0) return 0;                      // +-0
+    const int ex = (int)((b >> 52) & 0x7ff);
+    if (ex == 0) { tie = true; return 0; }            // subnormal: let the serial path handle it
+    const u64 mant = (b & 0xfffffffffffffull) | (1ull << 52);
+    const int sh = e - (ex - 1023);                   // x/u = mant >> sh
+    if (sh <= 0) { if (sh < 0) tie = true; return sh == 0 ? mant : 0; }
+    if (sh >= 54) return 0;
+    const u64 q = mant >> sh, rem = mant & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+    if (rem == half) tie = true;
+    return q + (rem > half ? 1ull : 0ull);
+}
+
+__global__ __launch_bounds__(256) void k_id_exact(const double *__restrict__ identp, const double *__restrict__ identn,
+                                                  u32 n, IdChunk *__restrict__ ch) {
+    __shared__ u64 sp[4], sn[4];
+    __shared__ u32 sf[4];
+    const u32 k = blockIdx.x, base = k * ID_CH;
+    const int ep = ch[k].ep, en = ch[k].en;
+    if (ep == ID_SERIAL && en == ID_SERIAL) return;
+    u64 tp = 0, tn = 0;
+    bool tiep = false, tien = false;
+#pragma unroll
+    for (int j = 0; j < (int)(ID_CH / 256); j++) {
+        const u32 i = base + (u32)j * 256u + threadIdx.x;
+        if (i < n) {
+            if (ep != ID_SERIAL) tp += id_units(identp[i], ep, tiep);
+            if (en != ID_SERIAL) tn += id_units(identn[i], en, tien);
+        }
+    }
+    u32 fl = (tiep ? 4u : 0u) | (tien ? 8u : 0u);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { tp += __shfl_xor(tp, o); tn += __shfl_xor(tn, o); fl |= __shfl_xor(fl, o); }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sp[w] = tp; sn[w] = tn; sf[w] = fl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ch[k].tp = sp[0] + sp[1] + sp[2] + sp[3]; ch[k].tn = sn[0] + sn[1] + sn[2] + sn[3];
+        ch[k].flags |= sf[0] | sf[1] | sf[2] | sf[3];
+    }
+}
+
+// adds T units of 2^(e-52) to S if S is in binade e and stays inside it; returns false if not applicable
+__device__ __forceinline__ bool id_fast_add(double &S, int e, u64 T) {
+    const u64 b = (u64)__double_as_longlong(S);
+    if (e == ID_SERIAL || (int)((b >> 52) & 0x7ff) - 1023 != e) return false;
+    const u64 m = (b & 0xfffffffffffffull) | (1ull << 52);
+    if (T >= (1ull << 53) || m + T >= (1ull << 53)) return false;
+    S = __longlong_as_double((long long)((b & 0xfff0000000000000ull) | ((m + T) & 0xfffffffffffffull)));
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_id_combine(DevContig *ctg, u32 n_targets, const double *__restrict__ identp,
+                                                   const double *__restrict__ identn, const int32_t *__restrict__ tidv,
+                                                   const IdChunk *__restrict__ ch) {
+    const u32 c = blockIdx.x;
+    if (c >= n_targets) return;
+    DevContig *C = &ctg[c];
+    if (C->n_pass == 0) return;
+    const u32 rs = C->rec_start, re = C->rec_end;
+    const bool generic = C->n_groups != 1u;
+    const int lane = lane_id();
+    double Sp = 0.0, Sn = 0.0;
+    auto serial = [&](u32 from, u32 to, bool need_p, bool need_n) {   // the reference's serial chain over [from, to)
+        for (u32 b = from; b < to; b += 64) {
+            const u32 i = b + (u32)lane;
+            double xp = 0.0, xn = 0.0;
+            if (i < to && (!generic || tidv[i] == (int)c)) {
+                if (need_p) xp = identp[i];
+                if (need_n) xn = identn[i];
+            }
+#pragma unroll 16
+            for (int q = 0; q < 64; q++) { Sn += __shfl(xn, q); Sp += __shfl(xp, q); }   // bpermutes pipeline; v_readlane does not
+        }
+    };
+    const u32 k0 = generic ? 0u : (rs + ID_CH - 1) / ID_CH, k1 = generic ? 0u : re / ID_CH;   // interior chunks
+    if (k0 >= k1) { serial(rs, re, true, true); }
+    else {
+        serial(rs, k0 * ID_CH, true, true);
+        for (u32 kb = k0; kb < k1; kb += 64) {      // 64 chunk records per load, then walk them in order
+            const u32 kk = kb + (u32)lane;
+            IdChunk x;
+            if (kk < k1) x = ch[kk]; else { x.tp = x.tn = 0; x.ep = x.en = ID_SERIAL; x.flags = 15u; }
+            const u32 nb = min(64u, k1 - kb);
+            for (u32 q = 0; q < nb; q++) {
+                const u32 fl = __builtin_amdgcn_readlane(x.flags, (int)q);
+                const int ep = (int)__builtin_amdgcn_readlane((u32)x.ep, (int)q), en = (int)__builtin_amdgcn_readlane((u32)x.en, (int)q);
+                const u64 tp = bcast_u64(x.tp, (int)q), tn = bcast_u64(x.tn, (int)q);
+                bool need_p = true, need_n = true;
+                if (!(fl & (1u | 4u)) && id_fast_add(Sp, ep, tp)) need_p = false;
+                if (!(fl & (2u | 8u)) && id_fast_add(Sn, en, tn)) need_n = false;
+                if (need_p || need_n) serial((kb + q) * ID_CH, (kb + q + 1) * ID_CH, need_p, need_n);
+            }
+        }
+        serial(k1 * ID_CH, re, true, true);
+    }
+    if (lane == 0) { C->id_primary = Sp; C->id_nonsupp = Sn; }
 }
 
 // ------------------------------------------------------------------------------------ k_pileup

@@ -201,3 +201,20 @@ def test_edge_cases_empty_and_tiny():
     b = to_bamdata(batch, ref_lens)
     for excl in (0, 75, 8000):
         compare(b, ff=(True, True, False), excl=excl, check_depth=range(8))
+
+
+@pytest.mark.parametrize("mode", ["parallel", "serial"])
+def test_identity_sums_hot_contig_bit_exact(mode, monkeypatch):
+    """ANIr sums over contigs with hundreds of thousands of reads: the exact-parallel path (integer sums per binade
+    of the running total, verified against the exact sum) must reproduce the reference's serial f64 chain bit for bit."""
+    monkeypatch.setenv("COVERM_IDENTITY", mode)
+    ref = synth.make_reference(4, 3_000_000, seed=31, min_len=200_000, max_len=1_500_000)
+    batch = synth.make_reads(ref, 900_000, seed=32)
+    rng = np.random.default_rng(5)
+    # make rounding ties and awkward values likely: NM = aligned/2, /4, 0, aligned (identity 0.5, 0.75, 1, 0)
+    batch.nm = batch.nm.copy()
+    sel = rng.random(batch.n_records) < 0.3
+    batch.nm[sel] = rng.choice([0, 75, 150, 37, 1, 2, 3], size=int(sel.sum())).astype(np.uint32)
+    b = to_bamdata(batch, ref.lengths, ref.names)
+    st = compare(b, ff=(True, True, True), excl=75)
+    assert st["n_pass"].max() > 150_000
