@@ -177,8 +177,8 @@ def main():
         ncig = int(batch.cigar_off[-1]) - int(batch.cigar_off[0])
         # algorithmic HBM bytes per launch (DESIGN.md "Algorithmic bytes")
         kbytes = {"k_prep": R * 24 + ncig * 4 + R * 8,                    # SoA + CIGAR read once, run words written
-                  "k_pileup": R * 8 + sess_tiles(sess, ref) * 24 + len(ref.lengths) * 160,  # run words + tile descriptors + results
-                  "k_ranges": sess_tiles(sess, ref) * 24, "k_identity": R * 10, "k_hist": 0}
+                  "k_pileup": R * 8 + sess_tiles(sess, ref) * 32 + len(ref.lengths) * 160,  # run words + tile descriptors + results
+                  "k_ranges": sess_tiles(sess, ref) * 40, "k_identity": R * 32, "k_hist": 0}
         achieved = kbytes[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
         pipe_bytes = sess.algorithmic_bytes()
         pipe_ms = sum(kms.values())
@@ -218,7 +218,8 @@ def main():
 
 
 def sess_tiles(sess, ref):
-    tile = int(os.environ.get("COVERM_TILE", 4096))
+    """Tiles of the configured pileup kernel: 1024 bases per wave (streaming kernel) unless COVERM_PILEUP=tile."""
+    tile = int(os.environ.get("COVERM_TILE", 4096)) if os.environ.get("COVERM_PILEUP") == "tile" else 1024
     return int(((ref.lengths + tile - 1) // tile).sum())
 
 
