@@ -90,6 +90,7 @@ struct cov_session {
     uint32_t adopted_cig_end = 0;
 
     DevBuf<uint2> d_runs;
+    DevBuf<PrepPartial> d_part;
     DevBuf<double> d_ident, d_identp;
     DevBuf<IdChunk> d_idch;
     int id_mode = 1;   // 1 = exact parallel identity sums, 0 = serial chain only (COVERM_IDENTITY=serial)
@@ -296,7 +297,7 @@ void cov_destroy(cov_session *s) {
     s->d_ctg.release(); s->d_glob.release(); s->d_desc.release();
     s->s_tid.release(); s->s_pos.release(); s->s_flag.release(); s->s_mapq.release(); s->s_nmk.release();
     s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
-    s->d_runs.release(); s->d_ident.release(); s->d_identp.release(); s->d_idch.release();
+    s->d_runs.release(); s->d_part.release(); s->d_ident.release(); s->d_identp.release(); s->d_idch.release();
     if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
     if (s->ev_prep_done) (void)hipEventDestroy(s->ev_prep_done);
     if (s->ev_side_done) (void)hipEventDestroy(s->ev_side_done); s->d_arena.release(); s->d_chist.release(); s->d_depth.release();
@@ -408,6 +409,7 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
     for (int k = 0; k < COV_K_COUNT; k++) { s->k_launches[k] = 0; s->k_ms[k] = 0.f; }
 
     HIPCHK(s->d_runs.reserve(std::max<size_t>(1, R), st));
+    HIPCHK(s->d_part.reserve((size_t)R / PREP_CHUNK + 2, st));
     if (want_id) {
         HIPCHK(s->d_ident.reserve(std::max<size_t>(1, R), st)); HIPCHK(s->d_identp.reserve(std::max<size_t>(1, R), st));
         HIPCHK(s->d_idch.reserve((size_t)R / ID_CH + 2, st));
@@ -429,10 +431,11 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
         time_begin(s, COV_K_PREP);
         if (want_id)
             hipLaunchKernelGGL((k_prep<true>), dim3((R + PREP_CHUNK - 1) / PREP_CHUNK), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
-                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, s->d_identp.p, s->d_ident.p);
+                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, s->d_identp.p, s->d_ident.p, s->d_part.p);
         else
             hipLaunchKernelGGL((k_prep<false>), dim3((R + PREP_CHUNK - 1) / PREP_CHUNK), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
-                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, (double *)nullptr, (double *)nullptr);
+                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, (double *)nullptr, (double *)nullptr, s->d_part.p);
+        if (nT) hipLaunchKernelGGL(k_prep_reduce, dim3(nT), dim3(64), 0, st, s->d_ctg.p, nT, s->d_part.p, (R + PREP_CHUNK - 1) / PREP_CHUNK);
         time_end(s, COV_K_PREP);
         HIPCHK(hipGetLastError());
         if (want_id && nT) {   // depends only on k_prep: run beside k_ranges / k_pileup

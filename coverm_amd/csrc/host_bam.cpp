@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -223,20 +224,100 @@ bool parse_bam(Bam &b, const Buf &u) {
         b.names.emplace_back((const char *)&u[p], l_name ? l_name - 1 : 0); p += l_name;
         b.lens.push_back(rd32(&u[p])); p += 4;
     }
-    // record boundaries, CIGAR and name offsets: one serial hop over the block_size fields
+    // ---- record boundaries.  Each record only says how long it is, so finding them is a pointer chase; done
+    // serially it is a chain of cache misses (~60 ns per record) and bounds the whole decode.  Parallel scheme:
+    // cut the buffer into segments, let every thread FIND a record start inside its segment (an offset from which
+    // a chain of 8 records is plausible), hop its own segment, and accept the result only if each segment's
+    // chain lands exactly on the start the next segment found — then it equals the serial hop by induction.
+    // Any mismatch falls back to the plain serial hop, so the outcome never depends on the heuristic.
+    const size_t N = u.size();
+    const int32_t n_ref_i = (int32_t)n_ref;
+    auto plausible = [&](size_t o) -> size_t {   // returns record end, or 0 if `o` cannot start a record
+        if (o + 36 > N) return 0;
+        const uint32_t bs = rd32(&u[o]);
+        if (bs < 32 || o + 4 + (size_t)bs > N) return 0;
+        const int32_t rid = (int32_t)rd32(&u[o + 4]), pos = (int32_t)rd32(&u[o + 8]), nrid = (int32_t)rd32(&u[o + 24]);
+        const uint32_t lname = u[o + 12], ncig = rd16(&u[o + 16]), lseq = rd32(&u[o + 20]);
+        if (rid < -1 || rid >= n_ref_i || nrid < -1 || nrid >= n_ref_i || pos < -1 || lname == 0) return 0;
+        if (rid >= 0 && (uint64_t)pos > b.lens[rid]) return 0;
+        const uint64_t fixed = 32ull + lname + 4ull * ncig + (lseq + 1ull) / 2 + lseq;
+        if (fixed > bs) return 0;
+        if (u[o + 36 + lname - 1] != 0) return 0;
+        return o + 4 + bs;
+    };
+    struct Seg { size_t start = 0, stop = 0; bool found = false; std::vector<size_t> rec; size_t landed = 0; };
     std::vector<size_t> rec;
-    rec.reserve(u.size() / 200 + 16);
-    b.cigar_off.assign(1, 0);
-    if (b.want_names) b.qname_off.assign(1, 0);
-    uint32_t co = 0, qo = 0;
-    while (p + 4 <= u.size()) {
-        const uint32_t bs = rd32(&u[p]);
-        if (bs < 32 || p + 4 + bs > u.size()) { b.err = "truncated BAM record"; return false; }
-        rec.push_back(p);
-        co += rd16(&u[p + 16]);
-        b.cigar_off.push_back(co);
-        if (b.want_names) { qo += u[p + 12] ? u[p + 12] - 1u : 0u; b.qname_off.push_back(qo); }
-        p += 4 + (size_t)bs;
+    bool parallel_ok = false;
+    const size_t body = N - p;
+    int nseg = b.threads > 1 ? std::min<int>(b.threads * 4, (int)(body / (1 << 20))) : 0;
+    if (nseg >= 2) {
+        std::vector<Seg> seg(nseg);
+        for (int k = 0; k < nseg; k++) seg[k].stop = p + body * (size_t)(k + 1) / nseg;
+        seg[0].start = p; seg[0].found = true;
+        parallel_for((size_t)nseg, b.threads, [&](size_t k) {
+            Seg &S = seg[k];
+            if (k > 0) {
+                const size_t from = seg[k - 1].stop;
+                for (size_t o = from; o < S.stop && !S.found; o++) {
+                    size_t q = o; int chain = 0;
+                    while (chain < 8) { const size_t e = plausible(q); if (!e) break; q = e; chain++; if (q == N) break; }
+                    if (chain == 8 || (chain > 0 && q == N)) { S.start = o; S.found = true; }
+                }
+            }
+        });
+        // a segment without a start (one huge record spans it) is absorbed by its predecessor
+        std::vector<int> live;
+        for (int k = 0; k < nseg; k++) if (seg[k].found) live.push_back(k);
+        parallel_for(live.size(), b.threads, [&](size_t j) {
+            Seg &S = seg[live[j]];
+            const size_t limit = j + 1 < live.size() ? seg[live[j + 1]].start : N;
+            size_t q = S.start;
+            S.rec.reserve((limit - q) / 200 + 16);
+            while (q < limit && q + 4 <= N) {
+                const uint32_t bs = rd32(&u[q]);
+                if (bs < 32 || q + 4 + (size_t)bs > N) break;
+                S.rec.push_back(q);
+                q += 4 + (size_t)bs;
+            }
+            S.landed = q;
+        });
+        parallel_ok = true;
+        for (size_t j = 0; j < live.size() && parallel_ok; j++) {
+            const size_t want = j + 1 < live.size() ? seg[live[j + 1]].start : N;
+            if (seg[live[j]].landed != want) parallel_ok = false;
+        }
+        if (parallel_ok) {
+            size_t tot = 0;
+            for (int k : live) tot += seg[k].rec.size();
+            rec.reserve(tot);
+            for (int k : live) rec.insert(rec.end(), seg[k].rec.begin(), seg[k].rec.end());
+        }
+    }
+    if (!parallel_ok) {   // serial hop (small inputs, one thread, or a failed speculation)
+        rec.clear();
+        rec.reserve(body / 200 + 16);
+        size_t q = p;
+        while (q + 4 <= N) {
+            const uint32_t bs = rd32(&u[q]);
+            if (bs < 32 || q + 4 + (size_t)bs > N) { b.err = "truncated BAM record"; return false; }
+            rec.push_back(q);
+            q += 4 + (size_t)bs;
+        }
+        if (q != N) { b.err = "truncated BAM record"; return false; }
+    }
+    // CIGAR / name offsets: per-record counts in parallel, then a prefix sum
+    {
+        const size_t Rn = rec.size();
+        b.cigar_off.assign(Rn + 1, 0);
+        if (b.want_names) b.qname_off.assign(Rn + 1, 0);
+        parallel_for(Rn, b.threads, [&](size_t i) {
+            b.cigar_off[i + 1] = rd16(&u[rec[i] + 16]);
+            if (b.want_names) b.qname_off[i + 1] = u[rec[i] + 12] ? u[rec[i] + 12] - 1u : 0u;
+        });
+        for (size_t i = 0; i < Rn; i++) {
+            b.cigar_off[i + 1] += b.cigar_off[i];
+            if (b.want_names) b.qname_off[i + 1] += b.qname_off[i];
+        }
     }
     const size_t R = rec.size();
     b.tid.resize(R); b.pos.resize(R); b.mtid.resize(R); b.flag.resize(R); b.mapq.resize(R); b.nm_kind.resize(R);
@@ -354,16 +435,23 @@ extern "C" {
 struct covh_bam { Bam b; };
 
 covh_bam *covh_bam_open(const char *path, int threads, int want_names, char *err, size_t errcap) {
+    const bool timing = getenv("COVERM_BAM_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now(), t1 = t0, t2 = t0, t3 = t0;
     covh_bam *h = new covh_bam();
     h->b.path = path; h->b.threads = std::max(1, threads); h->b.want_names = want_names != 0;
     Buf raw;
     bool ok = read_file(path, raw, h->b.err);
+    t1 = now();
     if (ok) {
         if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
             Buf u;
             ok = bgzf_inflate_all(raw, u, h->b.threads, h->b.err);
             raw.alloc(0);
+            t2 = now();
             if (ok) ok = parse_bam(h->b, u);
+            t3 = now();
+            if (timing) fprintf(stderr, "[covh_bam] read %.3fs inflate %.3fs (%zu MB) parse %.3fs\n", t1 - t0, t2 - t1, u.size() >> 20, t3 - t2);
         } else ok = parse_sam(h->b, raw);
     }
     if (!ok) {

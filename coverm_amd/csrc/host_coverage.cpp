@@ -187,7 +187,25 @@ struct covh_taker {
     std::string cur_stoit, cur_entry_name;
     // cached
     std::vector<std::string> stoit_names;
-    std::vector<std::optional<std::string>> entry_names;
+    // entry names live in one arena (a std::string per entry costs an allocation per contig per sample)
+    struct NameRef { int64_t off = -1; uint32_t len = 0; explicit operator bool() const { return off >= 0; } };
+    struct NameTable {
+        std::string arena;
+        std::vector<NameRef> refs;
+        size_t size() const { return refs.size(); }
+        void resize(size_t n) { refs.resize(n); }
+        struct Entry {
+            const NameTable *t; size_t i;
+            explicit operator bool() const { return (bool)t->refs[i]; }
+            std::string operator*() const { return std::string(t->arena.data() + t->refs[i].off, t->refs[i].len); }
+            std::string_view view() const { return std::string_view(t->arena.data() + t->refs[i].off, t->refs[i].len); }
+        };
+        Entry operator[](size_t i) const { return Entry{this, i}; }
+        void set(size_t i, std::string_view n) { refs[i].off = (int64_t)arena.size(); refs[i].len = (uint32_t)n.size(); arena.append(n); }
+        struct Iter { const NameTable *t; size_t i; Entry operator*() const { return Entry{t, i}; } Iter &operator++() { ++i; return *this; } bool operator!=(const Iter &o) const { return i != o.i; } };
+        Iter begin() const { return Iter{this, 0}; }
+        Iter end() const { return Iter{this, refs.size()}; }
+    } entry_names;
     std::vector<std::vector<std::pair<size_t, float>>> coverages;
     size_t cur_stoit_i = 0, cur_entry_i = 0;
     bool mismatch = false;
@@ -201,8 +219,8 @@ struct covh_taker {
         else if (kind == COVH_TAKER_PILEUP) cur_entry_name.assign(name);
         else {
             if (id >= entry_names.size()) entry_names.resize(id + 1);
-            if (!entry_names[id]) entry_names[id] = std::string(name);
-            if (*entry_names[id] != name) mismatch = true;  // coverage_takers.rs:140-148 (process::exit(1))
+            if (!entry_names[id]) entry_names.set(id, name);
+            else if (entry_names[id].view() != name) mismatch = true;  // coverage_takers.rs:140-148 (process::exit(1))
             cur_entry_i = id;
         }
     }
@@ -595,7 +613,7 @@ double round4(double v) { return std::round(v) / 10000.0; }  // (x * 10000.0).ro
 void print_sparse(covh_taker &t, const covh_reads_mapped *rm, const int64_t *norm, size_t n_norm, int64_t rpkm_col, int64_t tpm_col) {
     const size_t nc = t.num_coverages;
     size_t extra_cols = 0;
-    for (auto &n : t.entry_names) if (n) { extra_cols = std::count(n->begin(), n->end(), '\t'); break; }
+    for (auto n : t.entry_names) if (n) { const std::string_view v = n.view(); extra_cols = std::count(v.begin(), v.end(), '\t'); break; }
     auto all = iterate_cached(t);
     std::string &o = t.text;
     auto print_previous = [&](const std::vector<const EntryAndCoverages *> &rows, size_t si) {

@@ -165,9 +165,16 @@ __global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g) {
 // per-lane running sums for the contig it is currently in and flushes them with one set of atomics
 // only when the contig changes: a single hot address costs ~12 ns per atomic on MI355X, so per-wave
 // (let alone per-record) atomics on the per-contig or global counters would dominate the kernel.
-constexpr int PREP_B = 4;        // records per thread per pass: their loads are issued together
-constexpr int PREP_PASSES = 4;
+constexpr int PREP_B = 2;        // records per thread per pass: their loads are issued together
+constexpr int PREP_PASSES = 8;
 constexpr int PREP_CHUNK = 256 * PREP_B * PREP_PASSES;
+
+// Counters of one workgroup that lies entirely inside one contig (tid >= 0), reduced later by k_prep_reduce:
+// per-wave atomics on a hot contig's accumulator line serialise at ~12 ns each and dominated k_prep.
+struct PrepPartial {
+    int tid; u32 prim, pass, nons, span, first, last, pad;
+    u64 nm, indel;
+};
 
 struct PrepAcc {
     u32 prim, pass, nons, span, first, last;
@@ -199,8 +206,10 @@ template <bool WANT_IDENTITY>
 __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__ tlen, u32 n_targets,
                                               const uint8_t *__restrict__ mask, FilterCfg f, DevContig *ctg,
                                               DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ identp,
-                                              double *__restrict__ identn) {
+                                              double *__restrict__ identn, PrepPartial *__restrict__ part) {
     __shared__ u32 blk_cnt[2][4];
+    __shared__ PrepPartial wpart[4];
+    bool flushed_early = false;   // this wave already sent sums for an earlier contig through atomics
     const int lane = lane_id(), w = threadIdx.x >> 6;
     const u32 chunk = blockIdx.x * (u32)PREP_CHUNK;
     PrepAcc acc; acc.reset();
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                 const int ftid = __shfl(tid, __ffsll((long long)m) - 1);
                 const bool uni = __all(!cnt || tid == ftid);
                 if (uni) {
-                    if (ftid != cur) { prep_flush(ctg, cur, acc); cur = ftid; }
+                    if (ftid != cur) { if (cur >= 0) flushed_early = true; prep_flush(ctg, cur, acc); cur = ftid; }
                     if (cnt) {
                         acc.prim += (!supp && !sec) ? 1u : 0u;
                         acc.pass += 1u;
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                         if (masked_in) { acc.nm += nmv; acc.indel += indel; acc.span = max(acc.span, span); }
                     }
                 } else {  // contig boundary inside this wave pass: rare, resolve with per-lane atomics
-                    prep_flush(ctg, cur, acc); cur = -1;
+                    prep_flush(ctg, cur, acc); cur = -1; flushed_early = true;
                     if (cnt) {
                         DevContig *C = &ctg[tid];
                         if (!supp && !sec) atomicAdd(&C->n_primary, 1ull);
@@ -379,17 +388,74 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
             }
         }
     }
-    prep_flush(ctg, cur, acc);
-    // device-wide counters: one pair of atomics per workgroup, spread over COUNTER_SLOTS cache lines
+    // End of chunk: if all four waves stayed inside the same single contig, publish ONE partial record for the
+    // workgroup (reduced by k_prep_reduce); otherwise fall back to atomics.
+    {
+        PrepPartial pw;
+        pw.tid = flushed_early ? -2 : cur;
+        pw.prim = wave_sum_u32(acc.prim); pw.pass = wave_sum_u32(acc.pass); pw.nons = wave_sum_u32(acc.nons);
+        pw.span = wave_max_u32(acc.span); pw.first = wave_min_u32(acc.first); pw.last = wave_max_u32(acc.last);
+        pw.nm = wave_sum_u64(acc.nm); pw.indel = wave_sum_u64(acc.indel); pw.pad = 0;
+        if (lane == 0) wpart[w] = pw;
+    }
     g_prim = wave_sum_u32(g_prim); g_cons = wave_sum_u32(g_cons);
     if (lane == 0) { blk_cnt[0][w] = g_prim; blk_cnt[1][w] = g_cons; }
     __syncthreads();
+    bool uniform_wg = true;
+    {
+        int t0 = -1;
+        for (int k = 0; k < 4; k++) {
+            const int t = wpart[k].tid;
+            if (t == -2) uniform_wg = false;
+            else if (t >= 0) { if (t0 < 0) t0 = t; else if (t != t0) uniform_wg = false; }
+        }
+        if (threadIdx.x == 0) {
+            PrepPartial o; o.tid = -1; o.prim = o.pass = o.nons = o.span = 0; o.first = 0xffffffffu; o.last = 0; o.pad = 0; o.nm = o.indel = 0;
+            if (uniform_wg && t0 >= 0) {
+                o.tid = t0;
+                for (int k = 0; k < 4; k++) {
+                    const PrepPartial &q = wpart[k];
+                    if (q.tid < 0) continue;
+                    o.prim += q.prim; o.pass += q.pass; o.nons += q.nons; o.span = max(o.span, q.span);
+                    o.first = min(o.first, q.first); o.last = max(o.last, q.last); o.nm += q.nm; o.indel += q.indel;
+                }
+            }
+            part[blockIdx.x] = o;
+        }
+    }
+    if (!uniform_wg) prep_flush(ctg, cur, acc);
+    // device-wide counters: one pair of atomics per workgroup, spread over COUNTER_SLOTS cache lines
     if (threadIdx.x == 0) {
         const u32 p = blk_cnt[0][0] + blk_cnt[0][1] + blk_cnt[0][2] + blk_cnt[0][3];
         const u32 c = blk_cnt[1][0] + blk_cnt[1][1] + blk_cnt[1][2] + blk_cnt[1][3];
         const u32 slot = (blockIdx.x % COUNTER_SLOTS) * 8u;
         if (p) atomicAdd(&g->prim_slots[slot], (u64)p);
         if (c) atomicAdd(&g->cons_slots[slot], (u64)c);
+    }
+}
+
+// One wave per contig: adds the partial records of the workgroups that lay entirely inside it.
+__global__ __launch_bounds__(64) void k_prep_reduce(DevContig *ctg, u32 n_targets, const PrepPartial *__restrict__ part,
+                                                    u32 n_parts) {
+    const u32 c = blockIdx.x;
+    if (c >= n_targets) return;
+    DevContig *C = &ctg[c];
+    const u32 rs = C->rec_start, re = C->rec_end;
+    if (rs >= re) return;
+    const u32 b0 = rs / (u32)PREP_CHUNK, b1 = min((re - 1) / (u32)PREP_CHUNK, n_parts - 1);
+    u32 prim = 0, pass = 0, nons = 0, span = 0, first = 0xffffffffu, last = 0;
+    u64 nm = 0, indel = 0;
+    for (u32 b = b0 + (threadIdx.x & 63); b <= b1; b += 64) {
+        const PrepPartial q = part[b];
+        if (q.tid != (int)c) continue;
+        prim += q.prim; pass += q.pass; nons += q.nons; span = max(span, q.span);
+        first = min(first, q.first); last = max(last, q.last); nm += q.nm; indel += q.indel;
+    }
+    prim = wave_sum_u32(prim); pass = wave_sum_u32(pass); nons = wave_sum_u32(nons); span = wave_max_u32(span);
+    first = wave_min_u32(first); last = wave_max_u32(last); nm = wave_sum_u64(nm); indel = wave_sum_u64(indel);
+    if ((threadIdx.x & 63) == 0 && pass) {
+        C->n_primary += prim; C->n_pass += pass; C->n_nonsupp += nons; C->sum_nm += nm; C->sum_indel += indel;
+        C->max_span = max(C->max_span, span); C->first_rec = min(C->first_rec, first); C->last_rec = max(C->last_rec, last);
     }
 }
 

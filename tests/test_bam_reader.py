@@ -101,3 +101,20 @@ def test_cpp_writer_roundtrip(tmp_path):
         for f in ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "cigar_off", "cigar"):
             np.testing.assert_array_equal(getattr(af.records, f), getattr(b, f), err_msg=f)
         np.testing.assert_array_equal(af.records.l_seq, b.l_seq if with_seq else np.zeros_like(b.l_seq))
+
+
+def test_parallel_boundary_detection_matches_serial(tmp_path):
+    """Bodies above 2 MiB take the speculative multi-segment record-boundary path; it must equal the serial hop."""
+    ref = synth.make_reference(30, 5_000_000, seed=8, min_len=5000, max_len=800_000)
+    b = synth.make_reads(ref, 120_000, seed=9)
+    p = str(tmp_path / "big.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=True, threads=4)
+    assert os.path.getsize(p) > 1 << 20
+    one = cbam.read_alignment_file(p, threads=1)
+    for thr in (2, 8, 16):
+        many = cbam.read_alignment_file(p, threads=thr)
+        for f in FIELDS + ("l_seq",):
+            np.testing.assert_array_equal(getattr(many.records, f), getattr(one.records, f), err_msg=f)
+        assert many.qname == one.qname
+    np.testing.assert_array_equal(one.records.pos, b.pos)
+    np.testing.assert_array_equal(one.records.cigar, b.cigar)
