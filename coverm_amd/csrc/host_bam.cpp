@@ -12,6 +12,7 @@
 // record boundaries are then found in one cheap serial hop over block_size fields and the per-record field
 // extraction (including the linear aux scan for NM) runs in parallel again.
 #include <dlfcn.h>
+#include <sys/mman.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -67,11 +68,27 @@ void parallel_for(size_t n, int threads, F fn) {
 
 // ---- uninitialised byte buffer (a std::vector would memset gigabytes before inflate overwrites them)
 struct Buf {
-    uint8_t *p = nullptr; size_t n = 0;
+    uint8_t *p = nullptr; size_t n = 0; size_t mapped = 0;
     Buf() = default;
     Buf(const Buf &) = delete;
-    ~Buf() { free(p); }
-    bool alloc(size_t k) { free(p); p = (uint8_t *)malloc(k ? k : 1); n = k; return p != nullptr; }
+    ~Buf() { release(); }
+    void release() { if (mapped) munmap(p, mapped); else free(p); p = nullptr; n = 0; mapped = 0; }
+    // Large buffers come from an anonymous mapping advised to use transparent huge pages: dozens of inflate
+    // threads first-touching gigabytes of 4 KiB pages otherwise spend most of their time in page faults.
+    bool alloc(size_t k) {
+        release();
+        if (k >= (64u << 20)) {
+            const size_t len = (k + (2u << 20) - 1) & ~((size_t)(2u << 20) - 1);
+            void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, len, MADV_HUGEPAGE);
+                p = (uint8_t *)m; n = k; mapped = len;
+                return true;
+            }
+        }
+        p = (uint8_t *)malloc(k ? k : 1); n = k;
+        return p != nullptr;
+    }
     const uint8_t &operator[](size_t i) const { return p[i]; }
     size_t size() const { return n; }
     const uint8_t *data() const { return p; }

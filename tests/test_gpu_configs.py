@@ -1,0 +1,117 @@
+"""BASELINE.json configs as parity cases (product CLI text == oracle CLI text on seeded synthetic data), and
+size-independent properties at a large size where the oracle would be too slow to be the checker."""
+import numpy as np
+import pytest
+
+from coverm_amd import cli, synth
+from coverm_amd.cli import AlignmentFile
+from coverm_amd.engine import FilterConfig, Session
+from oracle import oracle as O
+from oracle.bamio import BamData
+
+pytestmark = pytest.mark.gpu
+
+ALL_CONTIG_METHODS = ["mean", "trimmed_mean", "covered_fraction", "covered_bases", "variance", "length", "count",
+                      "reads_per_base", "anir", "rpkm", "tpm"]
+
+
+def make(n_contigs, total, n_reads, seed, name="synth"):
+    ref = synth.make_reference(n_contigs, total, seed=seed, min_len=1500, max_len=400_000)
+    batch = synth.make_reads(ref, n_reads, seed=seed + 1)
+    z = np.zeros(batch.n_records, np.int32)
+    b = BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq, batch.l_seq.astype(np.int32),
+                batch.nm, batch.nm_kind, batch.cigar_off, batch.cigar, z, z, z, [], "")
+    return ref, batch, b, AlignmentFile("data/%s.bam" % name, ref.names, ref.lengths, batch)
+
+
+@pytest.mark.parametrize("fmt", ["dense", "sparse"])
+def test_config2_contig_four_methods(fmt):
+    ref, batch, b, af = make(120, 8_000_000, 150_000, seed=41)
+    args = dict(methods=["mean", "trimmed_mean", "covered_fraction", "variance"], output_format=fmt)
+    assert cli.run("contig", [af], **args) == O.run_cli("contig", ["data/synth.bam"], bams=[b], **args)
+
+
+def test_config3_genome_definition_relative_abundance_rpkm_tpm(tmp_path):
+    ref, batch, b, af = make(200, 10_000_000, 200_000, seed=43)
+    gd = tmp_path / "genomes.tsv"
+    gd.write_text("".join("%s\t%s\n" % (n.split("~")[0], n) for n in ref.names[:170]))   # 30 contigs in no genome
+    for fmt in ("dense", "sparse"):
+        args = dict(methods=["relative_abundance", "rpkm", "tpm"], genome_definition=str(gd), output_format=fmt)
+        assert cli.run("genome", [af], **args) == O.run_cli("genome", ["data/synth.bam"], bams=[b], **args)
+    args = dict(methods=["relative_abundance", "mean", "covered_bases"], separator="~", output_format="sparse")
+    assert cli.run("genome", [af], **args) == O.run_cli("genome", ["data/synth.bam"], bams=[b], **args)
+
+
+def test_config4_multi_sample_dense_table():
+    ref = synth.make_reference(60, 4_000_000, seed=45, min_len=1500, max_len=300_000)
+    afs, bs = [], []
+    for k in range(3):
+        batch = synth.make_reads(ref, 60_000, seed=50 + k)
+        z = np.zeros(batch.n_records, np.int32)
+        bs.append(BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq,
+                          batch.l_seq.astype(np.int32), batch.nm, batch.nm_kind, batch.cigar_off, batch.cigar, z, z,
+                          z, [], ""))
+        afs.append(AlignmentFile("data/s%d.bam" % k, ref.names, ref.lengths, batch))
+    args = dict(methods=["mean", "variance", "rpkm"])
+    assert cli.run("contig", afs, **args) == O.run_cli("contig", ["data/s%d.bam" % k for k in range(3)], bams=bs, **args)
+
+
+def test_config5_full_filter_path_all_methods():
+    ref, batch, b, af = make(150, 9_000_000, 250_000, seed=47)
+    args = dict(methods=ALL_CONTIG_METHODS, min_read_percent_identity=95, min_read_aligned_length=50,
+                proper_pairs_only=True, output_format="sparse")
+    got = cli.run("contig", [af], **args)
+    assert got == O.run_cli("contig", ["data/synth.bam"], bams=[b], **args)
+    assert got.count("\n") == 151
+    # coverage_histogram has its own printer and cannot be combined (coverm.rs:1438-1446)
+    args = dict(methods=["coverage_histogram"], min_read_percent_identity=95, min_read_aligned_length=50,
+                proper_pairs_only=True)
+    assert cli.run("contig", [af], **args) == O.run_cli("contig", ["data/synth.bam"], bams=[b], **args)
+
+
+def test_large_size_properties():
+    """20 M reads (~0.4x of config 2): laws that must hold whatever the size."""
+    ref = synth.make_reference(2000, 400_000_000, seed=1)
+    batch = synth.make_reads(ref, 20_000_000, seed=2)
+    flag = batch.flag
+    considered = ((flag & 0x4) == 0) & ((flag & 0x100) == 0)          # default FlagFilter + mapped
+    op = batch.cigar & 15
+    ln = (batch.cigar >> 4).astype(np.int64)
+    m_len = np.where((op == 0) | (op == 7) | (op == 8), ln, 0)
+    per_rec = np.add.reduceat(np.concatenate([m_len, [0]]), batch.cigar_off[:-1].astype(np.int64))
+    per_rec[batch.cigar_off[1:] == batch.cigar_off[:-1]] = 0
+    aligned_per_contig = np.bincount(batch.tid[considered], weights=per_rec[considered].astype(np.float64),
+                                     minlength=len(ref.lengths)).astype(np.int64)
+    reads_per_contig = np.bincount(batch.tid[considered], minlength=len(ref.lengths))
+    with Session(0, FilterConfig(), 0, want_hist=True, want_identity=True) as s:
+        s.set_targets(ref.lengths)
+        s.push(batch)
+        st, summ = s.finish()
+        hist = s.hist()
+        st2, _ = s.finish()
+        assert st.tobytes() == st2.tobytes()                                  # deterministic / idempotent
+        assert (hist == s.hist()).all()
+    assert int(summ.n_considered) == int(considered.sum())
+    np.testing.assert_array_equal(st["n_pass"], reads_per_contig)
+    # conservation: with no end exclusion the summed depth equals the aligned M/=/X bases (reads never leave contigs)
+    np.testing.assert_array_equal(st["win_sum_d"].astype(np.int64), aligned_per_contig)
+    for t in range(0, len(ref.lengths), 37):
+        h = hist[int(st["hist_off"][t]):int(st["hist_off"][t]) + int(st["hist_len"][t])].astype(np.int64)
+        if st["n_pass"][t] == 0:
+            continue
+        d = np.arange(len(h))
+        assert h.sum() == ref.lengths[t]
+        assert (h * d).sum() == st["win_sum_d"][t] and (h * d * d).sum() == st["win_sum_d2"][t]
+        assert h[1:].sum() == st["win_covered"][t] == st["full_covered"][t]
+        assert st["win_max_d"][t] == len(h) - 1 and h[-1] > 0
+    # additivity under tid-range sharding (what the multi-GPU path relies on)
+    cut_tid = len(ref.lengths) // 2
+    cut = int(np.searchsorted(batch.tid, cut_tid, side="left"))
+    parts = []
+    for lo, hi in ((0, cut), (cut, batch.n_records)):
+        with Session(0, FilterConfig(), 0, want_hist=False) as s:
+            s.set_targets(ref.lengths)
+            s.push(batch.slice(lo, hi))
+            parts.append(s.finish()[0])
+    for f in ("n_pass", "win_sum_d", "win_sum_d2", "win_covered", "full_covered", "sum_nm"):
+        np.testing.assert_array_equal(parts[0][f] + parts[1][f], st[f], err_msg=f)
