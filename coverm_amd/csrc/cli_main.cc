@@ -5,6 +5,7 @@
 // :1506-1519, run_contig :2088-2131, run_genome :1539-1628, parse_percentage :1296-1312, parse_separator
 // :1522-1537; flag names and defaults from src/cli.rs (contig :2264-2582, genome :1669-2263).
 // Everything else the reference binary does (mapping, indexing, filter/make/cluster subcommands) is out of scope.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,9 @@
 #include <map>
 #include <string>
 #include <unordered_map>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/coverm_host.h"
@@ -258,12 +262,46 @@ int main(int argc, char **argv) {
     std::vector<Sample> samples(a.bams.size());
     std::string names_blob; std::vector<uint32_t> name_off; std::vector<uint64_t> tlen;
     std::vector<int32_t> genome_of_tid;
+    bool fs = false, fp = false;
+    if (f.doing_filtering()) f.mode(fs, fp);
+    cov_config cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.device = a.device; cfg.include_improper_pairs = f.improper; cfg.include_supplementary = f.supp;
+    cfg.include_secondary = f.sec; cfg.min_mapq = 255; cfg.contig_end_exclusion = excl; cfg.want = want;
+    if (f.doing_filtering() && fs && !fp) {
+        cfg.filter_single = 1; cfg.min_mapq = (uint8_t)f.mapq; cfg.min_aligned_length = f.len_single;
+        cfg.min_percent_identity = f.pid_single; cfg.min_aligned_percent = f.pct_single;
+    }
+    // The HIP runtime and the session come up on their own thread while the first file is being decoded, and a
+    // decoder thread stays one file ahead of the GPU (the reference reads its BAMs strictly one after another,
+    // contig.rs:29).
+    cov_session *s = nullptr;
+    cov_status create_rc = COV_OK;
+    std::thread warm([&] { create_rc = cov_create(&cfg, &s); });
+    struct Decoded { covh_bam *bam = nullptr; std::string err; };
+    std::vector<Decoded> decoded(a.bams.size());
+    std::mutex qm; std::condition_variable qcv;
+    size_t produced = 0, consumed = 0;
+    if (a.bams.size() > 1) covh_bam_set_buffer_cache(1);
+    covh_bam_set_pinned(1);
+    std::thread decoder([&] {
+        for (size_t bi = 0; bi < a.bams.size(); bi++) {
+            { std::unique_lock<std::mutex> lk(qm); qcv.wait(lk, [&] { return produced < consumed + 2; }); }
+            char err[512] = {0};
+            covh_bam *b = covh_bam_open(a.bams[bi].c_str(), a.threads, fp ? 1 : 0, err, sizeof err);
+            { std::lock_guard<std::mutex> lk(qm); decoded[bi].bam = b; decoded[bi].err = err; produced = bi + 1; }
+            qcv.notify_all();
+            if (!b) return;
+        }
+    });
+    decoder.detach();   // die() may exit while it is mid-file
+    const bool timing = getenv("COVERM_CLI_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t bi = 0; bi < a.bams.size(); bi++) {
-        char err[512] = {0};
-        bool fs = false, fp = false;
-        if (f.doing_filtering()) f.mode(fs, fp);
-        covh_bam *bam = covh_bam_open(a.bams[bi].c_str(), a.threads, fp ? 1 : 0, err, sizeof err);
-        if (!bam) die(err);
+        const double tw0 = now();
+        { std::unique_lock<std::mutex> lk(qm); qcv.wait(lk, [&] { return produced > bi; }); }
+        const double tw1 = now();
+        covh_bam *bam = decoded[bi].bam;
+        if (!bam) die(decoded[bi].err);
         const uint32_t nt = covh_bam_n_targets(bam);
         if (bi == 0) {
             name_off.push_back(0);
@@ -279,9 +317,6 @@ int main(int argc, char **argv) {
             }
             if (!in) die("Error: There are no found reference sequences that are a part of a genome");
         }
-        cov_config cfg; memset(&cfg, 0, sizeof cfg);
-        cfg.device = a.device; cfg.include_improper_pairs = f.improper; cfg.include_supplementary = f.supp;
-        cfg.include_secondary = f.sec; cfg.min_mapq = 255; cfg.contig_end_exclusion = excl; cfg.want = want;
         cov_batch batch; covh_bam_batch(bam, &batch);
         Sample &S = samples[bi];
         // stoit name = file stem (bam_generator.rs:358-365)
@@ -291,10 +326,7 @@ int main(int argc, char **argv) {
         std::vector<uint32_t> snm, slseq, scoff, scig;
         bool prim_from_host = false;
         if (f.doing_filtering()) {
-            if (fs && !fp) {
-                cfg.filter_single = 1; cfg.min_mapq = (uint8_t)f.mapq; cfg.min_aligned_length = f.len_single;
-                cfg.min_percent_identity = f.pid_single; cfg.min_aligned_percent = f.pct_single;
-            } else {
+            if (!(fs && !fp)) {
                 for (uint64_t i = 0; i < batch.n_records; i++) if (!(batch.flag[i] & 0x900)) S.prim++;   // filter.rs:129-131
                 prim_from_host = true;
                 const std::vector<uint64_t> order = pair_mode_order(bam, batch, f);
@@ -312,19 +344,29 @@ int main(int argc, char **argv) {
                 batch.cigar_off = scoff.data(); batch.cigar = scig.data(); batch.n_records = order.size();
             }
         }
-        cov_session *s = nullptr;
-        if (cov_create(&cfg, &s) != COV_OK) die(cov_last_error(nullptr));
+        if (bi == 0) {
+            warm.join();
+            if (create_rc != COV_OK) die(cov_last_error(nullptr));
+        } else check(s, cov_reset(s));
+        const double tw2 = now();
         check(s, cov_set_targets(s, nt, tlen.data()));
         if (by_names) check(s, cov_set_target_mask(s, mask.data()));
         check(s, cov_push_batch(s, &batch));
+        const double tw3 = now();
         S.stats.resize(nt);
         cov_summary summ;
         check(s, cov_finish(s, S.stats.data(), &summ));
         if (want & COV_WANT_HIST) { S.hist.resize(summ.hist_total); check(s, cov_fetch_hist(s, S.hist.data())); }
         if (!prim_from_host) S.prim = summ.num_detected_primary_alignments;
-        cov_destroy(s);
+        const double tw4 = now();
         covh_bam_close(bam);
+        if (timing) fprintf(stderr, "[coverm-amd] sample %zu: waited for decoder %.3fs, session ready %.3fs, push %.3fs, finish+fetch %.3fs, close %.3fs\n",
+                            bi, tw1 - tw0, tw2 - tw1, tw3 - tw2, tw4 - tw3, now() - tw4);
+        { std::lock_guard<std::mutex> lk(qm); consumed = bi + 1; }
+        qcv.notify_all();
     }
+    if (a.bams.empty()) warm.join();
+    cov_destroy(s);
 
     covh_header hdr; hdr.n_targets = (uint32_t)tlen.size(); hdr.names = names_blob.c_str(); hdr.name_off = name_off.data(); hdr.target_len = tlen.data();
     std::vector<covh_sample> hs(samples.size());

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -171,6 +173,7 @@ cov_status append(cov_session *s, const cov_batch *b, bool from_device) {
     }
     s->n_records = N; s->n_cigar += ncig;
     s->finished = false;
+    if (!from_device) HIPCHK(hipStreamSynchronize(st));   // contract: host arrays are free to change on return
     return COV_OK;
 }
 
@@ -617,6 +620,52 @@ cov_status cov_algorithmic_bytes(const cov_session *s, uint64_t *bytes) {
     if (!s || !bytes) return COV_ERR_INVALID_ARG;
     *bytes = s->algo_bytes;
     return COV_OK;
+}
+
+// ---- pooled page-locked host memory (covermhip.h: cov_host_alloc / cov_host_free / cov_host_trim)
+namespace {
+struct HostPool {
+    std::mutex m;
+    std::map<void *, size_t> live;          // handed out: ptr -> block size
+    std::multimap<size_t, void *> parked;   // free blocks by size
+    static size_t round_up(size_t b) { const size_t g = (size_t)16 << 20; return b < g ? g : (b + g - 1) / g * g; }
+};
+HostPool g_host_pool;
+}  // namespace
+
+void *cov_host_alloc(size_t bytes) {
+    const size_t want = HostPool::round_up(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_host_pool.m);
+        auto it = g_host_pool.parked.lower_bound(want);
+        if (it != g_host_pool.parked.end() && it->first <= 2 * want) {
+            void *p = it->second; const size_t sz = it->first;
+            g_host_pool.parked.erase(it);
+            g_host_pool.live[p] = sz;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lk(g_host_pool.m);
+    g_host_pool.live[p] = want;
+    return p;
+}
+
+int cov_host_free(void *p) {
+    if (!p) return 0;
+    std::lock_guard<std::mutex> lk(g_host_pool.m);
+    auto it = g_host_pool.live.find(p);
+    if (it == g_host_pool.live.end()) return 0;
+    g_host_pool.parked.emplace(it->second, p);
+    g_host_pool.live.erase(it);
+    return 1;
+}
+
+void cov_host_trim(void) {
+    std::multimap<size_t, void *> drop;
+    { std::lock_guard<std::mutex> lk(g_host_pool.m); drop.swap(g_host_pool.parked); }
+    for (auto &kv : drop) (void)hipHostFree(kv.second);
 }
 
 }  // extern "C"

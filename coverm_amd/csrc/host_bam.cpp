@@ -21,6 +21,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -29,16 +31,53 @@
 
 namespace {
 
+// Allocator for the record arrays: resize() leaves elements uninitialised (the parallel extraction loop is the
+// first touch, so page faults are spread over the threads instead of a serial zero-fill), and large arrays come
+// from anonymous mappings advised to use transparent huge pages.
+std::atomic<bool> g_pinned_records{false};   // covh_bam_set_pinned
+
+template <class T>
+struct RecAlloc {
+    using value_type = T;
+    RecAlloc() = default;
+    template <class U> RecAlloc(const RecAlloc<U> &) {}
+    static size_t mapped_len(size_t bytes) { return (bytes + (2u << 20) - 1) & ~((size_t)(2u << 20) - 1); }
+    T *allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= (1u << 20) && g_pinned_records.load(std::memory_order_relaxed))
+            if (void *h = cov_host_alloc(bytes)) return (T *)h;
+        if (bytes >= (8u << 20)) {
+            void *m = mmap(nullptr, mapped_len(bytes), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (m == MAP_FAILED) throw std::bad_alloc();
+            (void)madvise(m, mapped_len(bytes), MADV_HUGEPAGE);
+            return (T *)m;
+        }
+        void *q = malloc(bytes ? bytes : 1);
+        if (!q) throw std::bad_alloc();
+        return (T *)q;
+    }
+    void deallocate(T *q, size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= (1u << 20) && cov_host_free(q)) return;
+        if (bytes >= (8u << 20)) munmap(q, mapped_len(bytes)); else free(q);
+    }
+    template <class U> void construct(U *q) { ::new ((void *)q) U; }   // default-init: no zeroing
+    template <class U, class... A> void construct(U *q, A &&...a) { ::new ((void *)q) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const RecAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const RecAlloc<U> &) const { return false; }
+};
+template <class T> using RecVec = std::vector<T, RecAlloc<T>>;
+
 struct Bam {
     std::string path, err;
     std::vector<std::string> names;
     std::vector<uint64_t> lens;
     std::string header_text;
     // SoA
-    std::vector<int32_t> tid, pos, mtid;
-    std::vector<uint16_t> flag;
-    std::vector<uint8_t> mapq, nm_kind;
-    std::vector<uint32_t> nm, l_seq, cigar_off, cigar, qname_off;
+    RecVec<int32_t> tid, pos, mtid;
+    RecVec<uint16_t> flag;
+    RecVec<uint8_t> mapq, nm_kind;
+    RecVec<uint32_t> nm, l_seq, cigar_off, cigar, qname_off;
     std::string qnames;
     int threads = 1;
     bool want_names = false;
@@ -67,18 +106,67 @@ void parallel_for(size_t n, int threads, F fn) {
 }
 
 // ---- uninitialised byte buffer (a std::vector would memset gigabytes before inflate overwrites them)
+// Large buffers come from anonymous mappings advised to use transparent huge pages: dozens of inflate threads
+// first-touching gigabytes of 4 KiB pages otherwise spend most of their time in page faults.  Unmapping gigabytes
+// is itself ~0.15 s, so released mappings are either parked in a one-slot cache for the next file (opt-in,
+// covh_bam_set_buffer_cache) or unmapped on a detached thread.
+struct MapCache {
+    static constexpr int SLOTS = 4;
+    std::mutex m;
+    bool enabled = false;
+    void *p[SLOTS] = {nullptr, nullptr, nullptr, nullptr}; size_t len[SLOTS] = {0, 0, 0, 0};
+    static void unmap_async(void *q, size_t l) {
+        if (!q) return;
+        try { std::thread([q, l] { munmap(q, l); }).detach(); } catch (...) { munmap(q, l); }
+    }
+    // best fit, but never hand a block more than 4x the request (the compressed-file buffer must not take the
+    // slot sized for the inflated stream)
+    void *take(size_t need, size_t &got) {
+        std::lock_guard<std::mutex> lk(m);
+        int best = -1;
+        for (int i = 0; i < SLOTS; i++)
+            if (p[i] && len[i] >= need && len[i] <= 4 * need && (best < 0 || len[i] < len[best])) best = i;
+        if (best < 0) return nullptr;
+        void *q = p[best]; got = len[best]; p[best] = nullptr; len[best] = 0;
+        return q;
+    }
+    void give(void *q, size_t l) {
+        void *old = q; size_t oldl = l;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (enabled) {
+                int slot = -1;
+                for (int i = 0; i < SLOTS && slot < 0; i++) if (!p[i]) slot = i;
+                if (slot < 0) { slot = 0; for (int i = 1; i < SLOTS; i++) if (len[i] < len[slot]) slot = i; }
+                if (!p[slot] || len[slot] < l) { old = p[slot]; oldl = len[slot]; p[slot] = q; len[slot] = l; }
+            }
+        }
+        unmap_async(old, oldl);
+    }
+    void set(bool on) {
+        void *old[SLOTS]; size_t oldl[SLOTS];
+        {
+            std::lock_guard<std::mutex> lk(m);
+            enabled = on;
+            for (int i = 0; i < SLOTS; i++) { old[i] = nullptr; oldl[i] = 0; if (!on) { old[i] = p[i]; oldl[i] = len[i]; p[i] = nullptr; len[i] = 0; } }
+        }
+        for (int i = 0; i < SLOTS; i++) if (old[i]) munmap(old[i], oldl[i]);
+    }
+};
+MapCache g_map_cache;
+
 struct Buf {
     uint8_t *p = nullptr; size_t n = 0; size_t mapped = 0;
     Buf() = default;
     Buf(const Buf &) = delete;
     ~Buf() { release(); }
-    void release() { if (mapped) munmap(p, mapped); else free(p); p = nullptr; n = 0; mapped = 0; }
-    // Large buffers come from an anonymous mapping advised to use transparent huge pages: dozens of inflate
-    // threads first-touching gigabytes of 4 KiB pages otherwise spend most of their time in page faults.
+    void release() { if (mapped) g_map_cache.give(p, mapped); else free(p); p = nullptr; n = 0; mapped = 0; }
     bool alloc(size_t k) {
         release();
         if (k >= (64u << 20)) {
             const size_t len = (k + (2u << 20) - 1) & ~((size_t)(2u << 20) - 1);
+            size_t got = 0;
+            if (void *c = g_map_cache.take(len, got)) { p = (uint8_t *)c; n = k; mapped = got; return true; }
             void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
             if (m != MAP_FAILED) {
                 (void)madvise(m, len, MADV_HUGEPAGE);
@@ -263,7 +351,7 @@ bool parse_bam(Bam &b, const Buf &u) {
         return o + 4 + bs;
     };
     struct Seg { size_t start = 0, stop = 0; bool found = false; std::vector<size_t> rec; size_t landed = 0; };
-    std::vector<size_t> rec;
+    RecVec<size_t> rec;
     bool parallel_ok = false;
     const size_t body = N - p;
     int nseg = b.threads > 1 ? std::min<int>(b.threads * 4, (int)(body / (1 << 20))) : 0;
@@ -304,10 +392,13 @@ bool parse_bam(Bam &b, const Buf &u) {
             if (seg[live[j]].landed != want) parallel_ok = false;
         }
         if (parallel_ok) {
-            size_t tot = 0;
-            for (int k : live) tot += seg[k].rec.size();
-            rec.reserve(tot);
-            for (int k : live) rec.insert(rec.end(), seg[k].rec.begin(), seg[k].rec.end());
+            std::vector<size_t> base(live.size() + 1, 0);
+            for (size_t j = 0; j < live.size(); j++) base[j + 1] = base[j] + seg[live[j]].rec.size();
+            rec.resize(base.back());
+            parallel_for(live.size(), b.threads, [&](size_t j) {
+                const auto &v = seg[live[j]].rec;
+                if (!v.empty()) memcpy(&rec[base[j]], v.data(), v.size() * sizeof(size_t));
+            });
         }
     }
     if (!parallel_ok) {   // serial hop (small inputs, one thread, or a failed speculation)
@@ -325,16 +416,28 @@ bool parse_bam(Bam &b, const Buf &u) {
     // CIGAR / name offsets: per-record counts in parallel, then a prefix sum
     {
         const size_t Rn = rec.size();
-        b.cigar_off.assign(Rn + 1, 0);
-        if (b.want_names) b.qname_off.assign(Rn + 1, 0);
-        parallel_for(Rn, b.threads, [&](size_t i) {
-            b.cigar_off[i + 1] = rd16(&u[rec[i] + 16]);
-            if (b.want_names) b.qname_off[i + 1] = u[rec[i] + 12] ? u[rec[i] + 12] - 1u : 0u;
+        b.cigar_off.resize(Rn + 1); b.cigar_off[0] = 0;
+        if (b.want_names) { b.qname_off.resize(Rn + 1); b.qname_off[0] = 0; }
+        // blocked inclusive scan: per-block counts, serial scan of the block totals, per-block fix-up
+        const size_t nblk = std::max<size_t>(1, std::min<size_t>((size_t)b.threads * 4, Rn / 65536 + 1));
+        std::vector<uint64_t> cs(nblk + 1, 0), qs(nblk + 1, 0);
+        parallel_for(nblk, b.threads, [&](size_t k) {
+            const size_t lo = Rn * k / nblk, hi = Rn * (k + 1) / nblk;
+            uint64_t c = 0, q = 0;
+            for (size_t i = lo; i < hi; i++) {
+                c += rd16(&u[rec[i] + 16]); b.cigar_off[i + 1] = (uint32_t)c;
+                if (b.want_names) { q += u[rec[i] + 12] ? u[rec[i] + 12] - 1u : 0u; b.qname_off[i + 1] = (uint32_t)q; }
+            }
+            cs[k + 1] = c; qs[k + 1] = q;
         });
-        for (size_t i = 0; i < Rn; i++) {
-            b.cigar_off[i + 1] += b.cigar_off[i];
-            if (b.want_names) b.qname_off[i + 1] += b.qname_off[i];
-        }
+        for (size_t k = 0; k < nblk; k++) { cs[k + 1] += cs[k]; qs[k + 1] += qs[k]; }
+        if (cs[nblk] > 0xffffffffull || qs[nblk] > 0xffffffffull) { b.err = "BAM too large for 32-bit CIGAR/name offsets"; return false; }
+        parallel_for(nblk, b.threads, [&](size_t k) {
+            if (!k) return;
+            const size_t lo = Rn * k / nblk, hi = Rn * (k + 1) / nblk;
+            const uint32_t c = (uint32_t)cs[k], q = (uint32_t)qs[k];
+            for (size_t i = lo; i < hi; i++) { b.cigar_off[i + 1] += c; if (b.want_names) b.qname_off[i + 1] += q; }
+        });
     }
     const size_t R = rec.size();
     b.tid.resize(R); b.pos.resize(R); b.mtid.resize(R); b.flag.resize(R); b.mapq.resize(R); b.nm_kind.resize(R);
@@ -376,8 +479,8 @@ bool parse_sam(Bam &b, const Buf &raw) {
         for (size_t i = 0; i < b.names.size(); i++) if (b.names[i] == n) return (int32_t)i;
         return -1;
     };
-    b.cigar_off.assign(1, 0);
-    if (b.want_names) b.qname_off.assign(1, 0);
+    b.cigar_off.assign(1, 0u);
+    if (b.want_names) b.qname_off.assign(1, 0u);
     while (s < e) {
         const char *nl = (const char *)memchr(s, '\n', (size_t)(e - s));
         const char *le = nl ? nl : e;
@@ -468,7 +571,9 @@ covh_bam *covh_bam_open(const char *path, int threads, int want_names, char *err
             t2 = now();
             if (ok) ok = parse_bam(h->b, u);
             t3 = now();
-            if (timing) fprintf(stderr, "[covh_bam] read %.3fs inflate %.3fs (%zu MB) parse %.3fs\n", t1 - t0, t2 - t1, u.size() >> 20, t3 - t2);
+            const size_t umb = u.size() >> 20;
+            u.alloc(0);
+            if (timing) fprintf(stderr, "[covh_bam] read %.3fs inflate %.3fs (%zu MB) parse %.3fs release %.3fs\n", t1 - t0, t2 - t1, umb, t3 - t2, now() - t3);
         } else ok = parse_sam(h->b, raw);
     }
     if (!ok) {
@@ -479,6 +584,8 @@ covh_bam *covh_bam_open(const char *path, int threads, int want_names, char *err
     return h;
 }
 void covh_bam_close(covh_bam *h) { delete h; }
+void covh_bam_set_buffer_cache(int on) { g_map_cache.set(on != 0); }
+void covh_bam_set_pinned(int on) { g_pinned_records.store(on != 0); }
 uint32_t covh_bam_n_targets(const covh_bam *h) { return (uint32_t)h->b.names.size(); }
 const char *covh_bam_target_name(const covh_bam *h, uint32_t i) { return h->b.names[i].c_str(); }
 uint64_t covh_bam_target_len(const covh_bam *h, uint32_t i) { return h->b.lens[i]; }

@@ -127,6 +127,12 @@ size_t covh_format_f64(double v, char *buf, size_t cap);
 typedef struct covh_bam covh_bam;
 covh_bam *covh_bam_open(const char *path, int threads, int want_names, char *err, size_t errcap);
 void covh_bam_close(covh_bam *h);
+/* Keep the largest inflate buffer mapped between files (off by default; turning it off frees it).  A tool that
+ * reads many BAMs in a row saves the unmap + first-touch of gigabytes per file. */
+void covh_bam_set_buffer_cache(int on);
+/* Decode record arrays into page-locked memory from cov_host_alloc (off by default; falls back to ordinary memory
+ * when no device is usable), so that cov_push_batch is a plain DMA. */
+void covh_bam_set_pinned(int on);
 uint32_t covh_bam_n_targets(const covh_bam *h);
 const char *covh_bam_target_name(const covh_bam *h, uint32_t i);
 uint64_t covh_bam_target_len(const covh_bam *h, uint32_t i);

@@ -157,7 +157,9 @@ cov_status cov_set_targets(cov_session *s, uint32_t n_targets, const uint64_t *t
  * (genome.rs:170-171).  NULL (default) = every target participates. */
 cov_status cov_set_target_mask(cov_session *s, const uint8_t *mask);
 
-/* Appends a batch of records held in HOST memory (copied to the device on the session stream). */
+/* Appends a batch of records held in HOST memory (copied to the device on the session stream).  The arrays may
+ * be changed or freed as soon as the call returns.  Arrays in page-locked memory (cov_host_alloc, hipHostMalloc)
+ * move by DMA at link rate without the runtime's per-call pinning of pageable pages. */
 cov_status cov_push_batch(cov_session *s, const cov_batch *host_batch);
 /* Appends a batch whose arrays already live in DEVICE memory (no copy; the caller keeps them
  * alive and unmodified until cov_finish returns).  Used when ingest writes straight to HBM. */
@@ -184,6 +186,15 @@ cov_status cov_kernel_ms(const cov_session *s, cov_kernel_id k, double *ms_total
 /* Algorithmic HBM bytes of the last cov_finish (DESIGN.md "Algorithmic bytes"): record SoA + CIGAR
  * words read once, plus result structs written. */
 cov_status cov_algorithmic_bytes(const cov_session *s, uint64_t *bytes);
+
+
+/* Page-locked host memory for record batches, pooled: a freed block is kept for the next request of similar size
+ * (a decoder filling one batch per BAM file gets its arrays back without re-pinning).  cov_host_alloc returns NULL
+ * when no HIP device is usable; cov_host_free returns 0 if `p` did not come from cov_host_alloc; cov_host_trim
+ * gives the parked blocks back to the system. */
+void *cov_host_alloc(size_t bytes);
+int cov_host_free(void *p);
+void cov_host_trim(void);
 
 #ifdef __cplusplus
 }

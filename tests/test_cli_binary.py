@@ -60,3 +60,40 @@ def test_cli_binary_golden(case, tmp_path):
         assert [so[0]] + sorted(so[1:]) == [se[0]] + sorted(se[1:])
     if case["mode"] == "contig":
         assert "reads mapped out of" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_binary_multi_sample_pipeline(tmp_path):
+    """Config 4 shape (several BAMs -> one dense table) through the decoder-ahead pipeline and the reused session,
+    including a filtered (single-read mode) pass; checked against the oracle's CLI text."""
+    import numpy as np
+
+    from coverm_amd import bam as cbam, synth
+    from oracle import oracle as O
+    from oracle.bamio import BamData
+    ref = synth.make_reference(80, 5_000_000, seed=61, min_len=1500, max_len=300_000)
+    paths, bs = [], []
+    for k in range(4):
+        batch = synth.make_reads(ref, 40_000 + 15_000 * k, seed=70 + k)
+        p = str(tmp_path / ("sample%d.bam" % k))
+        cbam.write_bam(p, ref.names, ref.lengths, batch, with_seq=(k % 2 == 0))
+        paths.append(p)
+        z = np.zeros(batch.n_records, np.int32)
+        bs.append(BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq,
+                          batch.l_seq.astype(np.int32), batch.nm, batch.nm_kind, batch.cigar_off, batch.cigar, z, z, z,
+                          [], ""))
+    r = subprocess.run([BIN, "contig", "-b"] + paths + ["-m", "mean", "variance", "rpkm", "-t", "8"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == O.run_cli("contig", paths, bams=bs, methods=["mean", "variance", "rpkm"])
+    assert r.stderr.count("reads mapped out of") == 4
+    r = subprocess.run([BIN, "contig", "-b"] + paths + ["-m", "trimmed_mean", "anir", "--min-read-percent-identity",
+                                                         "97", "--min-read-aligned-length", "60", "-t", "8"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == O.run_cli("contig", paths, bams=bs, methods=["trimmed_mean", "anir"],
+                                 min_read_percent_identity=97, min_read_aligned_length=60)
+    # a missing file in the middle of the list is reported, not hung on
+    r = subprocess.run([BIN, "contig", "-b", paths[0], str(tmp_path / "absent.bam"), paths[1], "-m", "mean"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "absent.bam" in r.stderr

@@ -23,6 +23,7 @@ ap.add_argument("--contigs", type=int, default=1000)
 ap.add_argument("--bp", type=int, default=200_000_000)
 ap.add_argument("--threads", type=int, default=32)
 ap.add_argument("--cpu", type=int, default=1)
+ap.add_argument("--samples", type=int, default=0, help="also time N lean BAMs -> one dense table (config 4 shape)")
 a = ap.parse_args()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "coverm_amd", "coverm-amd")
@@ -55,6 +56,21 @@ for with_seq in (True, False):
           "coverm-amd binary wall %.2fs = %.2f M reads/s end-to-end" % (
               "full-SEQ" if with_seq else "lean", size / 1e9, tw, a.threads, td, a.reads / td / 1e6, tg, tb,
               int(summ.n_considered) / tb / 1e6), flush=True)
+if a.samples:
+    paths = []
+    for k in range(a.samples):
+        bk = synth.make_reads(ref, a.reads, seed=10 + k)
+        pk = os.path.join(tmp, "s%d.bam" % k)
+        cbam.write_bam(pk, ref.names, ref.lengths, bk, with_seq=True, threads=a.threads)
+        paths.append(pk)
+    t = time.time()
+    r = subprocess.run([BIN, "contig", "-b"] + paths + ["-m", "mean", "variance", "rpkm", "-t", str(a.threads), "-o",
+                        os.path.join(tmp, "out.tsv")], capture_output=True, text=True)
+    tb = time.time() - t
+    assert r.returncode == 0, r.stderr
+    sys.stderr.write(r.stderr)
+    print("%d full-SEQ BAMs x %d reads -> dense table: coverm-amd wall %.2fs = %.2f M reads/s end-to-end" % (
+        a.samples, a.reads, tb, a.samples * a.reads / tb / 1e6), flush=True)
 if a.cpu:
     from oracle import oracle as O
     from oracle.bamio import BamData
