@@ -169,6 +169,39 @@ constexpr int PREP_B = 2;        // records per thread per pass: their loads are
 constexpr int PREP_PASSES = 8;
 constexpr int PREP_CHUNK = 256 * PREP_B * PREP_PASSES;
 
+// Literal 64-bit CIGAR walk (the path every record took before the branch-free fast walk existed); k_prep keeps it
+// for records the fast walk cannot take: more than CIG_FAST_OPS operations or an operation of >= 2^24 bases.
+constexpr u32 CIG_FAST_OPS = 128;
+__device__ __forceinline__ void cigar_walk_slow(const u32 *__restrict__ cigar, u32 co0, u32 nops, int pos, u32 L, u64 &aligned,
+                                             u64 &indel, u32 &run_start, u32 &run_len, u32 &run2_start, u32 &run2_len,
+                                             u32 &n_runs, u32 &span, bool &oob, bool &badcig) {
+    aligned = 0; indel = 0; run_start = run_len = run2_start = run2_len = n_runs = span = 0; oob = false; badcig = false;
+    long long cursor = pos;
+    long long cur_e = -1;  // end of the open merged run
+    for (u32 c = 0; c < nops; c++) {
+        const u32 wd = cigar[co0 + c];
+        const u32 op = wd & 15u, len = wd >> 4;
+        if (op == 0u || op == 7u || op == 8u) {          // M = X  (contig.rs:171-186)
+            if (cursor < 0 || cursor >= (long long)L) oob = true;
+            if (n_runs > 0 && cursor == cur_e) {
+                cur_e += len;
+                if (n_runs == 1) run_len += len; else if (n_runs == 2) run2_len += len;
+            } else {
+                n_runs++;
+                cur_e = cursor + len;
+                if (n_runs == 1) { run_start = (u32)cursor; run_len = len; }
+                else if (n_runs == 2) { run2_start = (u32)cursor; run2_len = len; }
+            }
+            cursor += len; aligned += len;
+        } else if (op == 2u) { cursor += len; indel += len; aligned += len; }  // D  (:187-191)
+        else if (op == 3u) { cursor += len; }                                  // N  (:192-195)
+        else if (op == 1u) { indel += len; aligned += len; }                   // I  (:196-199)
+        else if (op > 8u) badcig = true;                                       // S H P ignored (:200)
+    }
+    const long long sp = cursor - (long long)pos;
+    span = sp > 0 ? (u32)min(sp, (long long)0xffffffffu) : 0u;
+}
+
 // Counters of one workgroup that lies entirely inside one contig (tid >= 0), reduced later by k_prep_reduce:
 // per-wave atomics on a hot contig's accumulator line serialise at ~12 ns each and dominated k_prep.
 struct PrepPartial {
@@ -218,20 +251,30 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
     const u32 nlast = r.n - 1u;                                  // r.n > 0 (host never launches on an empty store)
     const u32 cig_last = r.cigar_end ? r.cigar_end - 1u : 0u;
 
+    // Chunk-relative addressing: uniform (SGPR) bases + a small per-thread offset, so every load is
+    // `global_load v, voff, s[base]` instead of a 64-bit per-lane address computation.
+    const u32 lmax = min(r.n - chunk, (u32)PREP_CHUNK) - 1u;     // last valid chunk-relative index (r.n > chunk)
+    const uint16_t *flag_c = r.flag + chunk; const int *tid_c = r.tid + chunk; const int *pos_c = r.pos + chunk;
+    const uint8_t *mapq_c = r.mapq + chunk; const uint8_t *nmk_c = r.nm_kind + chunk; const u32 *nm_c = r.nm + chunk;
+    const u32 *lseq_c = r.l_seq + chunk; const u32 *coff_c = r.cigar_off + chunk;
+    const int *tid_m = r.tid + chunk - 1; const int *pos_m = r.pos + chunk - 1;   // [x + 1] = record x (never read below 0)
+    uint2 *runs_c = runs + chunk;
+
     for (int ps = 0; ps < PREP_PASSES; ps++) {
-        const u32 i0 = chunk + (u32)(ps * PREP_B) * 256u + threadIdx.x;
+        const u32 l0 = (u32)(ps * PREP_B) * 256u + threadIdx.x;
+        const u32 i0 = chunk + l0;
         if (!__any(i0 < r.n)) break;
         // ---- phase A: every independent field of PREP_B records, issued back to back (clamped, branch-free)
         u32 fl[PREP_B], mq[PREP_B], nmk[PREP_B], nmv32[PREP_B], lsq[PREP_B], co0[PREP_B], co1[PREP_B];
         int td[PREP_B], ps_[PREP_B], ptid[PREP_B], ppos[PREP_B], ntid[PREP_B];
 #pragma unroll
         for (int k = 0; k < PREP_B; k++) {
-            const u32 i = i0 + (u32)k * 256u;
-            const u32 ic = min(i, nlast);
-            fl[k] = r.flag[ic]; td[k] = r.tid[ic]; ps_[k] = r.pos[ic]; mq[k] = r.mapq[ic]; nmk[k] = r.nm_kind[ic];
-            nmv32[k] = r.nm[ic]; lsq[k] = r.l_seq[ic]; co0[k] = r.cigar_off[ic]; co1[k] = r.cigar_off[ic + 1];
-            const u32 ip = ic > 0 ? ic - 1 : 0, in_ = min(ic + 1, nlast);
-            ptid[k] = r.tid[ip]; ppos[k] = r.pos[ip]; ntid[k] = r.tid[in_];
+            const u32 lc = min(l0 + (u32)k * 256u, lmax) & (u32)(PREP_CHUNK - 1);   // the mask is a no-op that bounds lc for the compiler
+            const u32 ic = chunk + lc;
+            fl[k] = flag_c[lc]; td[k] = tid_c[lc]; ps_[k] = pos_c[lc]; mq[k] = mapq_c[lc]; nmk[k] = nmk_c[lc];
+            nmv32[k] = nm_c[lc]; lsq[k] = lseq_c[lc]; co0[k] = coff_c[lc]; co1[k] = coff_c[lc + 1u];
+            const u32 lp = (lc + (ic > 0u ? 0u : 1u)) & (u32)(2 * PREP_CHUNK - 1), ln = (lc + (ic < nlast ? 1u : 0u)) & (u32)(2 * PREP_CHUNK - 1);
+            ptid[k] = tid_m[lp]; ppos[k] = pos_m[lp]; ntid[k] = tid_c[ln];
         }
         // ---- phase B: loads that depend on phase A (first three CIGAR words, contig length, mask)
         u32 cw[PREP_B][3], Lc[PREP_B], mk[PREP_B];
@@ -286,33 +329,46 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
             bool oob = false, badcig = false;
             // with the reader-stage filter on, only records that reach single_read_passes_filter can survive
             const bool do_walk = f.filter_single ? need_filter_eval : scan_gate;
-            if (do_walk) {
+            const u32 nops_all = do_walk ? co1[k] - co0[k] : 0u;
+            // Fast walk: branch-free, 32-bit, trip count uniform over the wave.  Valid while nothing can overflow
+            // 32 bits: at most CIG_FAST_OPS ops of < 2^24 each (sum < 2^31); anything else (long reads, absurd
+            // lengths) is redone by the literal 64-bit walk below.
+            bool hard = nops_all > CIG_FAST_OPS;
+            {
+                const u32 nops = hard ? 0u : nops_all;
                 const u32 L = Lc[k];
-                long long cursor = pos;
-                long long cur_e = -1;  // end of the open merged run
-                const u32 nops = co1[k] - co0[k];
-                for (u32 c = 0; c < nops; c++) {
-                    const u32 wd = c == 0 ? cw[k][0] : c == 1 ? cw[k][1] : c == 2 ? cw[k][2] : r.cigar[co0[k] + c];
-                    const u32 op = wd & 15u, len = wd >> 4;
-                    if (op == 0u || op == 7u || op == 8u) {          // M = X  (contig.rs:171-186)
-                        if (cursor < 0 || cursor >= (long long)L) oob = true;
-                        if (n_runs > 0 && cursor == cur_e) {
-                            cur_e += len;
-                            if (n_runs == 1) run_len += len; else if (n_runs == 2) run2_len += len;
-                        } else {
-                            n_runs++;
-                            cur_e = cursor + len;
-                            if (n_runs == 1) { run_start = (u32)cursor; run_len = len; }
-                            else if (n_runs == 2) { run2_start = (u32)cursor; run2_len = len; }
-                        }
-                        cursor += len; aligned += len;
-                    } else if (op == 2u) { cursor += len; indel += len; aligned += len; }  // D  (:187-191)
-                    else if (op == 3u) { cursor += len; }                                  // N  (:192-195)
-                    else if (op == 1u) { indel += len; aligned += len; }                   // I  (:196-199)
-                    else if (op > 8u) badcig = true;                                       // S H P ignored (:200)
+                u32 cursor = (u32)pos, cur_e = 0, al32 = 0, in32 = 0;
+                auto step = [&](u32 wd, bool act) {
+                    const u32 len = wd >> 4, bit = 1u << (wd & 15u);
+                    hard |= act && len >= (1u << 24);
+                    const bool m = act && (bit & 0x181u);                      // M = X   (contig.rs:171-186)
+                    badcig |= act && (bit & 0xfe00u);
+                    oob |= m && cursor >= L;                                   // negative cursors wrap to >= 2^31 > L
+                    const bool ext = m && n_runs > 0u && cursor == cur_e;      // continues the open merged run
+                    n_runs += (m && !ext) ? 1u : 0u;
+                    const bool r1 = m && n_runs == 1u, r2 = m && n_runs == 2u;
+                    run_start = (r1 && !ext) ? cursor : run_start;
+                    run2_start = (r2 && !ext) ? cursor : run2_start;
+                    run_len = r1 ? (ext ? run_len : 0u) + len : run_len;
+                    run2_len = r2 ? (ext ? run2_len : 0u) + len : run2_len;
+                    cur_e = m ? cursor + len : cur_e;
+                    cursor += (act && (bit & 0x18du)) ? len : 0u;              // M D N = X consume the reference
+                    al32 += (act && (bit & 0x187u)) ? len : 0u;                // M I D = X   (:187-199)
+                    in32 += (act && (bit & 0x006u)) ? len : 0u;                // I D
+                };
+                step(cw[k][0], 0u < nops);
+                step(cw[k][1], 1u < nops);
+                step(cw[k][2], 2u < nops);
+                for (u32 c = 3; __any(c < nops); c++) {
+                    const bool act = c < nops;
+                    step(act ? r.cigar[co0[k] + c] : 0u, act);
                 }
-                const long long sp = cursor - (long long)pos;
-                span = sp > 0 ? (u32)min(sp, (long long)0xffffffffu) : 0u;
+                aligned = al32; indel = in32;
+                span = cursor - (u32)pos;
+            }
+            if (__any(hard)) {
+                if (hard) cigar_walk_slow(r.cigar, co0[k], nops_all, pos, Lc[k], aligned, indel, run_start, run_len, run2_start,
+                                          run2_len, n_runs, span, oob, badcig);
             }
             if (need_filter_eval) {  // single_read_passes_filter, filter.rs:256-278
                 if (nmk[k] != 1u) report_error(g, i, nmk[k] == 0u ? 2u : 3u);
@@ -346,7 +402,7 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                         rw.y = (RW_DOUBLE << 30) | run_len | (gap << 10) | (run2_len << 18);
                     else rw.y = RW_COMPLEX << 30;
                 }
-                runs[i] = rw;
+                runs_c[i - chunk] = rw;
                 if (WANT_IDENTITY) {
                     identn[i] = (masked_in && !supp) ? idv : 0.0;
                     identp[i] = (masked_in && !supp && !sec) ? idv : 0.0;
