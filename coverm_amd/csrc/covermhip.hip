@@ -74,6 +74,8 @@ struct cov_session {
     std::vector<uint32_t> h_tile_first;  // first tile of each contig (+ sentinel)
     uint32_t n_tiles = 0;
     DevBuf<u32> d_tlen, d_tile_contig, d_tile_start;
+    DevBuf<u32> d_tile_first, d_tcnt, d_fov, d_tscan, d_ttop;   // TileIdx (pileup_kernels.hip.h)
+    uint32_t tile_shift = 10;
     DevBuf<uint8_t> d_mask;
     bool have_mask = false;
     DevBuf<DevContig> d_ctg;
@@ -104,7 +106,9 @@ struct cov_session {
 
     // results of the last finish
     bool finished = false;
-    std::vector<DevContig> h_ctg;
+    // result staging in page-locked memory: [DevGlobal][DevContig x n_targets], one DMA pair per finish
+    uint8_t *h_res = nullptr; size_t h_res_cap = 0;
+    DevContig *h_ctg = nullptr;
     DevGlobal h_glob{};
     uint64_t algo_bytes = 0;
 
@@ -297,7 +301,10 @@ void cov_destroy(cov_session *s) {
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->d_tlen.release(); s->d_tile_contig.release(); s->d_tile_start.release(); s->d_mask.release();
+    s->d_tile_first.release(); s->d_tcnt.release(); s->d_fov.release(); s->d_tscan.release(); s->d_ttop.release();
     s->d_ctg.release(); s->d_glob.release(); s->d_desc.release();
+    if (s->h_res) (void)hipHostFree(s->h_res);
+    s->h_res = nullptr; s->h_res_cap = 0; s->h_ctg = nullptr;
     s->s_tid.release(); s->s_pos.release(); s->s_flag.release(); s->s_mapq.release(); s->s_nmk.release();
     s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
     s->d_runs.release(); s->d_part.release(); s->d_ident.release(); s->d_identp.release(); s->d_idch.release();
@@ -335,6 +342,12 @@ cov_status cov_set_targets(cov_session *s, uint32_t n_targets, const uint64_t *t
     HIPCHK(s->d_tile_contig.reserve(std::max<size_t>(1, nt), s->stream));
     HIPCHK(s->d_tile_start.reserve(std::max<size_t>(1, nt), s->stream));
     HIPCHK(s->d_desc.reserve(std::max<size_t>(2, 2 * nt), s->stream));
+    HIPCHK(s->d_tile_first.reserve((size_t)n_targets + 1, s->stream));
+    HIPCHK(s->d_tcnt.reserve(std::max<size_t>(1, nt), s->stream)); HIPCHK(s->d_fov.reserve(std::max<size_t>(1, nt), s->stream));
+    HIPCHK(s->d_tscan.reserve(std::max<size_t>(1, nt), s->stream)); HIPCHK(s->d_ttop.reserve(nt / 1024 + 2, s->stream));
+    HIPCHK(hipMemcpyAsync(s->d_tile_first.p, s->h_tile_first.data(), ((size_t)n_targets + 1) * 4, hipMemcpyHostToDevice, s->stream));
+    s->tile_shift = 0;
+    while ((1u << s->tile_shift) < (uint32_t)s->tile) s->tile_shift++;
     HIPCHK(s->d_ctg.reserve(std::max<size_t>(1, n_targets), s->stream));
     if (n_targets) HIPCHK(hipMemcpyAsync(s->d_tlen.p, s->h_tlen.data(), (size_t)n_targets * 4, hipMemcpyHostToDevice, s->stream));
     if (nt) {
@@ -419,7 +432,10 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
     }
     if (want_hist) HIPCHK(s->d_arena.reserve((size_t)R + nT + 1, st));
 
-    hipLaunchKernelGGL(k_init, dim3((std::max(nT, COUNTER_SLOTS * 8) + 255) / 256), dim3(256), 0, st, s->d_ctg.p, nT, s->d_glob.p);
+    TileIdx ti{};
+    ti.tile_first = s->d_tile_first.p; ti.tcnt = s->d_tcnt.p; ti.fov = s->d_fov.p; ti.shift = s->tile_shift; ti.n_tiles = s->n_tiles; ti.ablate = s->ablate >> 8;
+    hipLaunchKernelGGL(k_init, dim3((std::max(std::max(nT, COUNTER_SLOTS * 8), s->n_tiles) + 255) / 256), dim3(256), 0, st, s->d_ctg.p,
+                       nT, s->d_glob.p, ti);
     HIPCHK(hipGetLastError());
 
     FilterCfg f{};
@@ -434,10 +450,10 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
         time_begin(s, COV_K_PREP);
         if (want_id)
             hipLaunchKernelGGL((k_prep<true>), dim3((R + PREP_CHUNK - 1) / PREP_CHUNK), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
-                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, s->d_identp.p, s->d_ident.p, s->d_part.p);
+                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, s->d_identp.p, s->d_ident.p, s->d_part.p, ti);
         else
             hipLaunchKernelGGL((k_prep<false>), dim3((R + PREP_CHUNK - 1) / PREP_CHUNK), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
-                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, (double *)nullptr, (double *)nullptr, s->d_part.p);
+                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, (double *)nullptr, (double *)nullptr, s->d_part.p, ti);
         if (nT) hipLaunchKernelGGL(k_prep_reduce, dim3(nT), dim3(64), 0, st, s->d_ctg.p, nT, s->d_part.p, (R + PREP_CHUNK - 1) / PREP_CHUNK);
         time_end(s, COV_K_PREP);
         HIPCHK(hipGetLastError());
@@ -461,12 +477,17 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
     }
     if (R && s->n_tiles) {
         time_begin(s, COV_K_RANGES);
+        const u32 n_blocks = (s->n_tiles + 1023u) / 1024u;
+        hipLaunchKernelGGL(k_tile_scan1, dim3(n_blocks), dim3(1024), 0, st, s->d_tcnt.p, s->n_tiles, s->d_tscan.p, s->d_ttop.p);
+        hipLaunchKernelGGL(k_tile_scan2, dim3(1), dim3(1024), 0, st, s->d_ttop.p, n_blocks);
         if (want_hist)
             hipLaunchKernelGGL((k_ranges<true>), dim3((s->n_tiles + 255) / 256), dim3(256), 0, st, s->d_tile_contig.p,
-                               s->d_tile_start.p, s->n_tiles, (u32)s->tile, r.pos, s->d_tlen.p, mask, s->d_ctg.p, s->d_desc.p);
+                               s->d_tile_start.p, s->n_tiles, s->d_tlen.p, mask, s->d_ctg.p, s->d_desc.p, ti, s->d_tscan.p,
+                               s->d_ttop.p);
         else
             hipLaunchKernelGGL((k_ranges<false>), dim3((s->n_tiles + 255) / 256), dim3(256), 0, st, s->d_tile_contig.p,
-                               s->d_tile_start.p, s->n_tiles, (u32)s->tile, r.pos, s->d_tlen.p, mask, s->d_ctg.p, s->d_desc.p);
+                               s->d_tile_start.p, s->n_tiles, s->d_tlen.p, mask, s->d_ctg.p, s->d_desc.p, ti, s->d_tscan.p,
+                               s->d_ttop.p);
         time_end(s, COV_K_RANGES);
         HIPCHK(hipGetLastError());
         if (want_hist) {
@@ -489,11 +510,21 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
             HIPCHK(hipGetLastError());
         }
     }
-    s->h_ctg.resize(nT);
+    {
+        const size_t need = sizeof(DevGlobal) + (size_t)std::max<u32>(nT, 1) * sizeof(DevContig);
+        if (need > s->h_res_cap) {
+            if (s->h_res) (void)hipHostFree(s->h_res);
+            s->h_res = nullptr; s->h_res_cap = 0;
+            HIPCHK(hipHostMalloc((void **)&s->h_res, need + need / 2, hipHostMallocDefault));
+            s->h_res_cap = need + need / 2;
+        }
+        s->h_ctg = (DevContig *)(s->h_res + sizeof(DevGlobal));
+    }
     if (want_id && R && nT) HIPCHK(hipStreamWaitEvent(st, s->ev_side_done, 0));
-    if (nT) HIPCHK(hipMemcpyAsync(s->h_ctg.data(), s->d_ctg.p, (size_t)nT * sizeof(DevContig), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&s->h_glob, s->d_glob.p, sizeof(DevGlobal), hipMemcpyDeviceToHost, st));
+    if (nT) HIPCHK(hipMemcpyAsync(s->h_ctg, s->d_ctg.p, (size_t)nT * sizeof(DevContig), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s->h_res, s->d_glob.p, sizeof(DevGlobal), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    memcpy(&s->h_glob, s->h_res, sizeof(DevGlobal));
     for (int k = 0; k < COV_K_COUNT; k++)
         if (s->k_launches[k]) (void)hipEventElapsedTime(&s->k_ms[k], s->ev[k][0], s->ev[k][1]);
 

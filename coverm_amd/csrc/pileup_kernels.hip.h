@@ -133,8 +133,23 @@ __device__ __forceinline__ void report_error(DevGlobal *g, u32 rec, u32 code) {
 }
 
 // ------------------------------------------------------------------------------------ k_init
-__global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g) {
+// Per-tile record bookkeeping filled by k_prep and turned into candidate ranges by k_tile_scan* + k_ranges:
+//   tcnt[t]  records of the tile's contig whose (clamped) start position lies in tile t
+//   fov[t]   smallest index of a record that starts LEFT of tile t and reaches into it (0xffffffff = none)
+// For a position-sorted contig, F(X) = first record with pos >= X is rec_start + (prefix sum of tcnt), so the
+// records that can touch tile t are [min(F(lo_t), fov[t]), F(lo_t) + tcnt[t]) -- no binary search, and one long
+// read widens only the tiles it really spans.
+struct TileIdx {
+    const u32 *tile_first;   // n_targets + 1: first tile of each contig
+    u32 *tcnt, *fov;
+    u32 shift;               // log2(tile width)
+    u32 n_tiles;
+    u32 ablate;              // experiment switches (COVERM_ABLATE >> 8); 0 in production
+};
+
+__global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g, TileIdx ti) {
     u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ti.n_tiles) { ti.tcnt[c] = 0u; ti.fov[c] = 0xffffffffu; }
     if (c == 0) {
         g->first_error = ~0ull; g->hist_cap_total = 0; g->chist_total = 0; g->internal_error = 0;
     }
@@ -239,7 +254,7 @@ template <bool WANT_IDENTITY>
 __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__ tlen, u32 n_targets,
                                               const uint8_t *__restrict__ mask, FilterCfg f, DevContig *ctg,
                                               DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ identp,
-                                              double *__restrict__ identn, PrepPartial *__restrict__ part) {
+                                              double *__restrict__ identn, PrepPartial *__restrict__ part, TileIdx ti) {
     __shared__ u32 blk_cnt[2][4];
     __shared__ PrepPartial wpart[4];
     bool flushed_early = false;   // this wave already sent sums for an earlier contig through atomics
@@ -277,11 +292,12 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
             ptid[k] = tid_m[lp]; ppos[k] = pos_m[lp]; ntid[k] = tid_c[ln];
         }
         // ---- phase B: loads that depend on phase A (first three CIGAR words, contig length, mask)
-        u32 cw[PREP_B][3], Lc[PREP_B], mk[PREP_B];
+        u32 cw[PREP_B][3], Lc[PREP_B], mk[PREP_B], t0[PREP_B];
 #pragma unroll
         for (int k = 0; k < PREP_B; k++) {
             const bool tok = td[k] >= 0 && (u32)td[k] < n_targets;
             Lc[k] = tok ? tlen[td[k]] : 0u;
+            t0[k] = tok ? ti.tile_first[td[k]] : 0u;
             mk[k] = (tok && mask != nullptr) ? mask[td[k]] : 1u;
 #pragma unroll
             for (int c = 0; c < 3; c++) cw[k][c] = r.cigar_end ? r.cigar[min(co0[k] + (u32)c, cig_last)] : 0u;
@@ -409,6 +425,35 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                 }
             }
 
+            // ---- tile bookkeeping for k_ranges (every record of a real contig counts towards F, considered or not)
+            {
+                const u32 L = Lc[k];
+                const bool tv = tid_ok && L > 0u;
+                const u32 pc = pos < 0 ? 0u : min((u32)pos, L - 1u);
+                const u32 tl = pc >> ti.shift;
+                const u32 key = tv ? t0[k] + tl : 0xffffffffu;
+                const u32 pk = (u32)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)key, 0x138, 0xf, 0xf, false);   // wave_shr:1
+                const bool lead = tv && (lane == 0 || key != pk);
+                const u64 bm = __ballot(lead) | ~__ballot(tv);              // lanes where a run of equal keys ends
+                if (lead && !(ti.ablate & 1u)) {
+                    const u64 rest = (bm >> lane) >> 1;
+                    const u32 follow = rest ? (u32)__builtin_ctzll(rest) : (u32)(63 - lane);
+                    atomicAdd(&ti.tcnt[key], 1u + follow);
+                }
+                // records that reach beyond their own tile announce themselves to the tiles they enter
+                const u32 e = span > L - pc ? L : pc + span;                 // end of the record's reference extent, clipped
+                const u32 te = (tv && span > 0u) ? (e - 1u) >> ti.shift : 0u;
+                const bool cross = tv && masked_in && n_runs > 0u && span > 0u && te > tl;
+                const u64 cm = __ballot(cross);
+                if (cm != 0 && !(ti.ablate & 2u)) {
+                    const int fl0 = __ffsll((long long)cm) - 1;
+                    const u32 tgt = key + 1u, tgt0 = __builtin_amdgcn_readlane(tgt, fl0);
+                    // usual case: all of them enter the same single tile, and the lowest lane has the smallest index
+                    if (__all(!cross || (te == tl + 1u && tgt == tgt0))) { if (lane == fl0) atomicMin(&ti.fov[tgt0], i); }
+                    else if (cross) for (u32 t2 = tl + 1u; t2 <= te; t2++) atomicMin(&ti.fov[t0[k] + t2], i);
+                }
+            }
+
             // per-contig counters: accumulate per lane while the wave stays inside one contig
             const bool cnt = considered && tid_ok;
             g_cons += cnt ? 1u : 0u;
@@ -526,11 +571,50 @@ __device__ __forceinline__ u32 lower_bound_pos(const int32_t *__restrict__ pos, 
 
 // Tile descriptor, two uint4 per tile: [2t] = (first candidate record, last, contig length, flags — bit 0: records
 // of other contigs may be interleaved in the range, check tid); [2t+1] = (contig, tile start, 0, 0).
+// Exclusive prefix sums of tcnt over all tiles: per 1024-tile block (k_tile_scan1) + over the block totals (k_tile_scan2).
+__global__ __launch_bounds__(1024) void k_tile_scan1(const u32 *__restrict__ tcnt, u32 n_tiles, u32 *__restrict__ tscan,
+                                                     u32 *__restrict__ ttop) {
+    __shared__ u32 wtot[16];
+    const u32 t = blockIdx.x * 1024u + threadIdx.x;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const u32 v = t < n_tiles ? tcnt[t] : 0u;
+    const u32 inc = (u32)wave_incl_scan((int)v);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    u32 wbase = 0, tot = 0;
+    for (int k = 0; k < 16; k++) { const u32 x = wtot[k]; if (k < w) wbase += x; tot += x; }
+    if (t < n_tiles) tscan[t] = wbase + inc - v;
+    if (threadIdx.x == 0) ttop[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void k_tile_scan2(u32 *ttop, u32 n_blocks) {
+    __shared__ u32 wtot[16];
+    __shared__ u32 carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    for (u32 base = 0; base < n_blocks; base += 1024u) {
+        const u32 b = base + threadIdx.x;
+        const u32 v = b < n_blocks ? ttop[b] : 0u;
+        const u32 inc = (u32)wave_incl_scan((int)v);
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        u32 wbase = 0, tot = 0;
+        for (int k = 0; k < 16; k++) { const u32 x = wtot[k]; if (k < w) wbase += x; tot += x; }
+        const u32 carry = carry_s;
+        if (b < n_blocks) ttop[b] = carry + wbase + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+}
+
+// One thread per tile: candidate record range [x, y) from the tile counts (see TileIdx), contig length, generic flag.
 template <bool WANT_HIST>
 __global__ __launch_bounds__(256) void k_ranges(const u32 *__restrict__ tile_contig, const u32 *__restrict__ tile_start,
-                                                u32 n_tiles, u32 tile, const int32_t *__restrict__ pos,
-                                                const u32 *__restrict__ tlen, const uint8_t *__restrict__ mask,
-                                                DevContig *ctg, uint4 *__restrict__ desc) {
+                                                u32 n_tiles, const u32 *__restrict__ tlen, const uint8_t *__restrict__ mask,
+                                                DevContig *ctg, uint4 *__restrict__ desc, TileIdx ti,
+                                                const u32 *__restrict__ tscan, const u32 *__restrict__ ttop) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     const u32 c = tile_contig[t];
@@ -542,21 +626,20 @@ __global__ __launch_bounds__(256) void k_ranges(const u32 *__restrict__ tile_con
         if (C->n_groups != 1u || (C->flags & F_POS_UNSORTED)) {
             out.x = rs; out.y = re;  // generic path: every tile of this contig scans the whole span
         } else {
-            const long long lo = tile_start[t];
-            // a run [s,e) of a record at `pos` (pos <= s, e <= pos + max_span) overlaps [lo, lo+tile) only if
-            // pos > lo - max_span and pos < lo + tile
-            // both searches advance together: their loads are independent, which halves the dependent-load chain
-            const long long k0 = lo - (long long)C->max_span + 1, k1 = lo + (long long)tile;
-            u32 l0 = rs, h0 = re, l1 = rs, h1 = re;
-            while (l0 < h0 || l1 < h1) {
-                const u32 m0 = l0 + ((h0 - l0) >> 1), m1 = l1 + ((h1 - l1) >> 1);
-                const long long p0 = l0 < h0 ? (long long)pos[m0] : 0, p1 = l1 < h1 ? (long long)pos[m1] : 0;
-                if (l0 < h0) { if (p0 < k0) l0 = m0 + 1; else h0 = m0; }
-                if (l1 < h1) { if (p1 < k1) l1 = m1 + 1; else h1 = m1; }
-            }
-            out.x = l0; out.y = max(l1, l0);
+            const u32 tf = ti.tile_first[c];
+            const u32 before = (tscan[t] + ttop[t >> 10]) - (tscan[tf] + ttop[tf >> 10]);   // records starting left of the tile
+            const u32 f = rs + before;                    // F(lo_t)
+            out.y = min(f + ti.tcnt[t], re);              // F(lo_t + tile)
+            out.x = max(min(f, ti.fov[t]), rs);
+            out.x = min(out.x, out.y);
         }
-        if (WANT_HIST && out.y > out.x) atomicMax(&C->hist_cap, out.y - out.x);
+    }
+    if (WANT_HIST) {   // one atomic per wave when all its tiles belong to one contig (the usual case)
+        const u32 cap = out.y - out.x;
+        if (__all(c == (u32)__builtin_amdgcn_readfirstlane((int)c))) {
+            const u32 m = wave_max_u32(cap);
+            if (lane_id() == 0 && m) atomicMax(&C->hist_cap, m);
+        } else if (cap) atomicMax(&C->hist_cap, cap);
     }
     desc[2 * t] = out;
     desc[2 * t + 1] = make_uint4(c, tile_start[t], 0u, 0u);
