@@ -1400,6 +1400,10 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
                     if (a1 > wl0) { mn = 0u; if (WANT_HIST) hist_add(0u, a1 - wl0); }
                 }
                 int carry = 0;
+                // Per-tile 32-bit partial sums: while depth < 1024 the products fit 24-bit multiplies (full rate; a
+                // 64-bit multiply is several quarter-rate instructions) and, the segments of a tile being disjoint,
+                // sum(d*len) <= 2^20 and sum(d^2*len) <= 2^30 per lane.
+                u32 s1t = 0, s2t = 0;
                 for (u32 e0 = 0; e0 < E; e0 += 64) {
                     const u32 e = e0 + (u32)lane;
                     const bool live = e < E;
@@ -1408,21 +1412,23 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
                     const int inc = wave_incl_scan(en.y);
                     const int d = carry + inc;
                     carry += __builtin_amdgcn_readlane(inc, 63);
+                    const u32 du = (u32)d;
+                    const bool small = !__any(live && du >= 1024u);
                     if (live) {
                         const u32 s = min((u32)en.x, tlen_t), t_ = min(nxt, tlen_t);
-                        const u32 du = (u32)d;
                         if (d > 0) cov_f += t_ - s;
                         const u32 a0 = max(s, wl0), a1 = min(t_, wl1);
                         if (a1 > a0) {
                             const u32 len = a1 - a0;
-                            sum_d += (u64)du * len;
-                            sum_d2 += (u64)du * du * len;
+                            if (small) { s1t += __umul24(du, len); s2t += __umul24(__umul24(du, du), len); }
+                            else { sum_d += (u64)du * len; sum_d2 += (u64)du * du * len; }
                             if (d > 0) cov_w += len;
                             mn = min(mn, du); mx = max(mx, du);
                             if (WANT_HIST) hist_add(du, len);
                         }
                     }
                 }
+                sum_d += s1t; sum_d2 += s2t;
             } else {
                 // ---- dense path: one wave scan per row of 64 bases
                 int carry = 0;
