@@ -218,3 +218,68 @@ def test_identity_sums_hot_contig_bit_exact(mode, monkeypatch):
     b = to_bamdata(batch, ref.lengths, ref.names)
     st = compare(b, ff=(True, True, True), excl=75)
     assert st["n_pass"].max() > 150_000
+
+
+def _long_read_batch(ref_lens, n_long, n_short, seed, huge_skip=False):
+    """Long reads with hundreds of CIGAR operations (every op type), mixed with short reads; optional 2^24+ N skip."""
+    rng = np.random.default_rng(seed)
+    recs = []   # (tid, pos, [(len, op)])
+    ops_mid = "MIDN=X"
+    for _ in range(n_long):
+        t = int(rng.integers(0, len(ref_lens)))
+        L = int(ref_lens[t])
+        n_ops = int(rng.choice([5, 40, 130, 400]))
+        ops = [(int(rng.integers(1, 30)), "S")] if rng.random() < 0.3 else []
+        ref_used = 0
+        for k in range(n_ops):
+            o = "M" if k % 2 == 0 else ops_mid[int(rng.integers(1, 6))]
+            ln = int(rng.integers(1, 120)) if o in "M=X" else int(rng.integers(1, 12)) if o in "ID" else int(rng.integers(1, 3000))
+            ops.append((ln, o))
+            if o in "MDN=X": ref_used += ln
+        if ref_used >= L - 1:
+            continue
+        recs.append((t, int(rng.integers(0, L - ref_used)), ops))
+    for _ in range(n_short):
+        t = int(rng.integers(0, len(ref_lens)))
+        L = int(ref_lens[t])
+        recs.append((t, int(rng.integers(0, L - 150)), [(150, "M")]))
+    if huge_skip:   # a spliced-style record whose N operation alone exceeds 2^24 bases
+        t = int(np.argmax(ref_lens))
+        recs.append((t, 1000, [(100, "M"), ((1 << 24) + 12345, "N"), (80, "M"), (5, "D"), (20, "=")]))
+    recs.sort(key=lambda r: (r[0], r[1]))
+    tid = np.asarray([r[0] for r in recs]); pos = np.asarray([r[1] for r in recs])
+    coff = np.zeros(len(recs) + 1, dtype=np.uint32)
+    np.cumsum([len(r[2]) for r in recs], out=coff[1:])
+    cig = np.asarray([(l << 4) | "MIDNSHP=X".index(o) for r in recs for l, o in r[2]], dtype=np.uint32)
+    n = len(recs)
+    flag = np.where(rng.random(n) < 0.05, 0x800 | 99, 99)
+    return RecordBatch.from_arrays(tid, pos, flag, np.full(n, 40), rng.integers(0, 50, n), np.ones(n),
+                                   np.full(n, 5000), coff, cig)
+
+
+def test_long_reads_many_ops():
+    """CIGARs beyond the fast walk's 128 operations, reads spanning tens of tiles, mixed with short reads."""
+    ref_lens = np.asarray([300_000, 1_200_000, 80_000, 2_000_000], dtype=np.int64)
+    batch = _long_read_batch(ref_lens, 1500, 20_000, seed=5)
+    nops = np.diff(batch.cigar_off.astype(np.int64))
+    assert (nops > 128).sum() > 100 and (nops > 3).sum() > 1000
+    b = to_bamdata(batch, ref_lens)
+    compare(b, ff=(True, True, False), excl=75, check_depth=range(4))
+    compare(b, ff=(False, False, False), excl=0, fp=dict(min_percent_identity_single=0.5, min_aligned_length_single=1000))
+
+
+def test_huge_skip_operation():
+    """One operation of >= 2^24 bases forces the literal 64-bit walk for that record only."""
+    ref_lens = np.asarray([50_000, 40_000_000, 70_000], dtype=np.int64)
+    batch = _long_read_batch(ref_lens, 200, 5_000, seed=6, huge_skip=True)
+    assert ((batch.cigar >> 4) >= (1 << 24)).sum() == 1
+    b = to_bamdata(batch, ref_lens)
+    compare(b, ff=(True, True, False), excl=75, check_depth=[0, 2])
+    with Session(0, FilterConfig(), 0, want_hist=False) as s:   # depth of the large contig around the two blocks
+        s.set_targets(ref_lens)
+        s.push(batch)
+        s.finish()
+        d = s.depth(1)
+    order, _ = O.reader_stage(b, None)
+    ud = O.contig_deltas(b, O.FlagFilter(True, True, False), 1, order)
+    np.testing.assert_array_equal(d, np.cumsum(ud, dtype=np.int64).astype(np.int32))
