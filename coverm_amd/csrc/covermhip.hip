@@ -76,6 +76,8 @@ struct cov_session {
     DevBuf<u32> d_tlen, d_tile_contig, d_tile_start;
     DevBuf<u32> d_tile_first, d_tcnt, d_fov, d_tscan, d_ttop;   // TileIdx (pileup_kernels.hip.h)
     uint32_t tile_shift = 10;
+    DevBuf<u32> d_cx_list, d_cx_cnt, d_cx_cur, d_cx_scan, d_cx_top;   // CxIdx: long-CIGAR buckets
+    DevBuf<uint2> d_cx_runs;
     DevBuf<uint8_t> d_mask;
     bool have_mask = false;
     DevBuf<DevContig> d_ctg;
@@ -248,7 +250,7 @@ void launch_any_pileup(cov_session *s, const PileupArgs &a, u32 n_tiles) {
 PileupArgs pileup_args(cov_session *s) {
     PileupArgs a{};
     a.tile_contig = s->d_tile_contig.p; a.tile_start = s->d_tile_start.p; a.desc = s->d_desc.p;
-    a.runs = s->d_runs.p; a.r = records_of(s); a.ctg = s->d_ctg.p; a.g = s->d_glob.p;
+    a.runs = s->d_runs.p; a.cx_runs = s->d_cx_runs.p; a.r = records_of(s); a.ctg = s->d_ctg.p; a.g = s->d_glob.p;
     a.hist_arena = s->d_arena.p; a.excl = s->cfg.contig_end_exclusion; a.depth_out = nullptr; a.tile_base = 0; a.ablate = s->ablate;
     return a;
 }
@@ -316,6 +318,7 @@ void cov_destroy(cov_session *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->d_tlen.release(); s->d_tile_contig.release(); s->d_tile_start.release(); s->d_mask.release();
     s->d_tile_first.release(); s->d_tcnt.release(); s->d_fov.release(); s->d_tscan.release(); s->d_ttop.release();
+    s->d_cx_list.release(); s->d_cx_cnt.release(); s->d_cx_cur.release(); s->d_cx_scan.release(); s->d_cx_top.release(); s->d_cx_runs.release();
     s->d_ctg.release(); s->d_glob.release(); s->d_desc.release();
     if (s->h_res) (void)hipHostFree(s->h_res);
     s->h_res = nullptr; s->h_res_cap = 0; s->h_ctg = nullptr;
@@ -359,6 +362,8 @@ cov_status cov_set_targets(cov_session *s, uint32_t n_targets, const uint64_t *t
     HIPCHK(s->d_tile_first.reserve((size_t)n_targets + 1, s->stream));
     HIPCHK(s->d_tcnt.reserve(std::max<size_t>(1, nt), s->stream)); HIPCHK(s->d_fov.reserve(std::max<size_t>(1, nt), s->stream));
     HIPCHK(s->d_tscan.reserve(std::max<size_t>(1, nt), s->stream)); HIPCHK(s->d_ttop.reserve(nt / 1024 + 2, s->stream));
+    HIPCHK(s->d_cx_cnt.reserve(std::max<size_t>(1, nt), s->stream)); HIPCHK(s->d_cx_cur.reserve(std::max<size_t>(1, nt), s->stream));
+    HIPCHK(s->d_cx_scan.reserve(std::max<size_t>(1, nt), s->stream)); HIPCHK(s->d_cx_top.reserve(nt / 1024 + 2, s->stream));
     HIPCHK(hipMemcpyAsync(s->d_tile_first.p, s->h_tile_first.data(), ((size_t)n_targets + 1) * 4, hipMemcpyHostToDevice, s->stream));
     s->tile_shift = 0;
     while ((1u << s->tile_shift) < (uint32_t)s->tile) s->tile_shift++;
@@ -429,7 +434,20 @@ cov_status cov_reset(cov_session *s) {
     return COV_OK;
 }
 
+static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summary *summary, bool &again);
+
 cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summary) {
+    // The buckets of long-CIGAR records are sized optimistically: a pass that finds them too small has already
+    // computed the exact need, grows the buffer and runs once more (at most once per growth of the workload).
+    bool again = false;
+    cov_status st = finish_once(s, stats, summary, again);
+    if (st == COV_OK && again) st = finish_once(s, stats, summary, again);
+    if (st == COV_OK && again) { s->err = "internal error: bucket sizing did not converge"; return COV_ERR_STATE; }
+    return st;
+}
+
+static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summary *summary, bool &again) {
+    again = false;
     if (!s || (!stats && s->n_targets)) return COV_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(s->cfg.device));
     hipStream_t st = s->stream;
@@ -439,7 +457,14 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
     for (int k = 0; k < COV_K_COUNT; k++) { s->k_launches[k] = 0; s->k_ms[k] = 0.f; }
 
     HIPCHK(s->d_runs.reserve(std::max<size_t>(1, R), st));
-    HIPCHK(s->d_part.reserve((size_t)R / PREP_CHUNK + 2, st));
+    // k_prep geometry: 8 passes of 512 records per workgroup for short reads; one pass when CIGARs are long, where the
+    // work per record is large and records are few (long-read mappings), so that every CU gets workgroups
+    const uint64_t ncig_all = s->adopted ? s->adopted_ncig : s->n_cigar;
+    const bool long_cigars = R && ncig_all / R >= 16;
+    const int prep_passes = long_cigars ? 1 : PREP_PASSES, prep_b = long_cigars ? 1 : PREP_B;
+    const u32 prep_chunk = (u32)(256 * prep_b * prep_passes);
+    const u32 prep_grid = (R + prep_chunk - 1) / prep_chunk;
+    HIPCHK(s->d_part.reserve((size_t)prep_grid + 2, st));
     if (want_id) {
         HIPCHK(s->d_ident.reserve(std::max<size_t>(1, R), st)); HIPCHK(s->d_identp.reserve(std::max<size_t>(1, R), st));
         HIPCHK(s->d_idch.reserve((size_t)R / ID_CH + 2, st));
@@ -448,8 +473,16 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
 
     TileIdx ti{};
     ti.tile_first = s->d_tile_first.p; ti.tcnt = s->d_tcnt.p; ti.fov = s->d_fov.p; ti.shift = s->tile_shift; ti.n_tiles = s->n_tiles; ti.ablate = s->ablate >> 8;
+    CxIdx cx{};
+    {
+        const uint64_t ncig_now = s->adopted ? s->adopted_ncig : s->n_cigar;
+        HIPCHK(s->d_cx_list.reserve((size_t)(ncig_now / CX_MIN_OPS) + 64, st));
+        cx.list = s->d_cx_list.p; cx.list_cap = (u32)std::min<uint64_t>(ncig_now / CX_MIN_OPS + 64, 0xffffffffull);
+        cx.cnt = s->d_cx_cnt.p; cx.cur = s->d_cx_cur.p; cx.cscan = s->d_cx_scan.p; cx.ctop = s->d_cx_top.p;
+        cx.runs = s->d_cx_runs.p; cx.runs_cap = s->d_cx_runs.cap;
+    }
     hipLaunchKernelGGL(k_init, dim3((std::max(std::max(nT, COUNTER_SLOTS * 8), s->n_tiles) + 255) / 256), dim3(256), 0, st, s->d_ctg.p,
-                       nT, s->d_glob.p, ti);
+                       nT, s->d_glob.p, ti, cx);
     HIPCHK(hipGetLastError());
 
     FilterCfg f{};
@@ -463,12 +496,12 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
     if (R) {
         time_begin(s, COV_K_PREP);
         if (want_id)
-            hipLaunchKernelGGL((k_prep<true>), dim3((R + PREP_CHUNK - 1) / PREP_CHUNK), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
-                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, s->d_identp.p, s->d_ident.p, s->d_part.p, ti);
+            hipLaunchKernelGGL((k_prep<true>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
+                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, s->d_identp.p, s->d_ident.p, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap);
         else
-            hipLaunchKernelGGL((k_prep<false>), dim3((R + PREP_CHUNK - 1) / PREP_CHUNK), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
-                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, (double *)nullptr, (double *)nullptr, s->d_part.p, ti);
-        if (nT) hipLaunchKernelGGL(k_prep_reduce, dim3(nT), dim3(64), 0, st, s->d_ctg.p, nT, s->d_part.p, (R + PREP_CHUNK - 1) / PREP_CHUNK);
+            hipLaunchKernelGGL((k_prep<false>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
+                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, (double *)nullptr, (double *)nullptr, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap);
+        if (nT) hipLaunchKernelGGL(k_prep_reduce, dim3(nT), dim3(64), 0, st, s->d_ctg.p, nT, s->d_part.p, prep_grid, prep_chunk);
         time_end(s, COV_K_PREP);
         HIPCHK(hipGetLastError());
         if (want_id && nT) {   // depends only on k_prep: run beside k_ranges / k_pileup
@@ -492,16 +525,21 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
     if (R && s->n_tiles) {
         time_begin(s, COV_K_RANGES);
         const u32 n_blocks = (s->n_tiles + 1023u) / 1024u;
+        const u32 cx_grid = (u32)s->n_cus * 8u;     // waves stride over the RW_BUCKET list; nothing to do for short reads
+        hipLaunchKernelGGL((k_cx_expand<false>), dim3(cx_grid), dim3(256), 0, st, r, s->d_tlen.p, s->d_glob.p, cx, ti);
         hipLaunchKernelGGL(k_tile_scan1, dim3(n_blocks), dim3(1024), 0, st, s->d_tcnt.p, s->n_tiles, s->d_tscan.p, s->d_ttop.p);
-        hipLaunchKernelGGL(k_tile_scan2, dim3(1), dim3(1024), 0, st, s->d_ttop.p, n_blocks);
+        hipLaunchKernelGGL(k_tile_scan2, dim3(1), dim3(1024), 0, st, s->d_ttop.p, n_blocks, (u64 *)nullptr);
+        hipLaunchKernelGGL(k_tile_scan1, dim3(n_blocks), dim3(1024), 0, st, s->d_cx_cnt.p, s->n_tiles, s->d_cx_scan.p, s->d_cx_top.p);
+        hipLaunchKernelGGL(k_tile_scan2, dim3(1), dim3(1024), 0, st, s->d_cx_top.p, n_blocks, &s->d_glob.p->cx_total);
+        hipLaunchKernelGGL((k_cx_expand<true>), dim3(cx_grid), dim3(256), 0, st, r, s->d_tlen.p, s->d_glob.p, cx, ti);
         if (want_hist)
             hipLaunchKernelGGL((k_ranges<true>), dim3((s->n_tiles + 255) / 256), dim3(256), 0, st, s->d_tile_contig.p,
                                s->d_tile_start.p, s->n_tiles, s->d_tlen.p, mask, s->d_ctg.p, s->d_desc.p, ti, s->d_tscan.p,
-                               s->d_ttop.p);
+                               s->d_ttop.p, cx, s->d_glob.p);
         else
             hipLaunchKernelGGL((k_ranges<false>), dim3((s->n_tiles + 255) / 256), dim3(256), 0, st, s->d_tile_contig.p,
                                s->d_tile_start.p, s->n_tiles, s->d_tlen.p, mask, s->d_ctg.p, s->d_desc.p, ti, s->d_tscan.p,
-                               s->d_ttop.p);
+                               s->d_ttop.p, cx, s->d_glob.p);
         time_end(s, COV_K_RANGES);
         HIPCHK(hipGetLastError());
         if (want_hist) {
@@ -539,6 +577,13 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
     HIPCHK(hipMemcpyAsync(s->h_res, s->d_glob.p, sizeof(DevGlobal), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     memcpy(&s->h_glob, s->h_res, sizeof(DevGlobal));
+    if (s->h_glob.cx_total > s->d_cx_runs.cap) {
+        const uint64_t need = s->h_glob.cx_total + s->h_glob.cx_total / 8 + 1024;
+        s->d_cx_runs.release();
+        HIPCHK(s->d_cx_runs.reserve((size_t)need, st));
+        again = true;
+        return COV_OK;
+    }
     for (int k = 0; k < COV_K_COUNT; k++)
         if (s->k_launches[k]) (void)hipEventElapsedTime(&s->k_ms[k], s->ev[k][0], s->ev[k][1]);
 

@@ -30,7 +30,8 @@ typedef unsigned int u32;
 constexpr int hist_bins(int tile) { return tile >= 16384 ? 2048 : 1024; }  // LDS histogram bins per tile
 constexpr u32 F_POS_UNSORTED = 1u;
 // run-word types (top two bits of .y)
-constexpr u32 RW_SINGLE = 0u, RW_DOUBLE = 1u, RW_COMPLEX = 2u;
+constexpr u32 RW_SINGLE = 0u, RW_DOUBLE = 1u, RW_COMPLEX = 2u, RW_BUCKET = 3u;
+constexpr u32 CX_MIN_OPS = 16;   // RW_COMPLEX records with more CIGAR operations than this go through the per-tile buckets
 
 // Per-contig device accumulators (128 B).
 struct DevContig {
@@ -57,8 +58,9 @@ struct DevGlobal {
     u64 hist_cap_total;  // arena bins in use
     u64 chist_total;     // compact histogram bins
     u32 internal_error;  // depth exceeded its proven bound (would indicate a bug), etc.
-    u32 pad;
-    u64 pad2[4];
+    u32 n_cx;            // RW_BUCKET records appended to CxIdx::list
+    u64 cx_total;        // (operation, tile) pairs they expand to = entries needed in CxIdx::runs
+    u64 pad2[3];
     u64 prim_slots[COUNTER_SLOTS * 8];  // sum = num_detected_primary_alignments (bam_generator.rs:114-118)
     u64 cons_slots[COUNTER_SLOTS * 8];  // sum = number of considered records
     u32 chunk_ctr[8 * 16];              // k_pileup_stream work queues: one dequeue counter per shard, 64 B apart
@@ -94,6 +96,17 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+// Inclusive wave64 running maximum (same DPP schedule as wave_incl_scan; lanes without a source keep INT_MIN).
+__device__ __forceinline__ int wave_incl_max(int v) {
+    const int NEG = (int)0x80000000;
+    v = max(v, __builtin_amdgcn_update_dpp(NEG, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(NEG, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(NEG, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(NEG, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(NEG, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(NEG, v, 0x143, 0xc, 0xf, false));
     return v;
 }
 __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
@@ -147,11 +160,21 @@ struct TileIdx {
     u32 ablate;              // experiment switches (COVERM_ABLATE >> 8); 0 in production
 };
 
-__global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g, TileIdx ti) {
+// Per-tile buckets of expanded M/=/X operations of RW_BUCKET records (k_cx_expand): cnt[t] entries at
+// runs[off(t) ..), off = exclusive prefix sum of cnt (cscan + ctop, two-level like tcnt).
+struct CxIdx {
+    u32 *list; u32 list_cap;     // record indices of RW_BUCKET records, any order
+    u32 *cnt, *cur;              // per tile: entries, fill cursor
+    const u32 *cscan, *ctop;     // exclusive prefix sums of cnt (valid after k_tile_scan1/2)
+    uint2 *runs; u64 runs_cap;   // (start, end) in contig coordinates
+};
+
+__global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g, TileIdx ti, CxIdx cx) {
     u32 c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < ti.n_tiles) { ti.tcnt[c] = 0u; ti.fov[c] = 0xffffffffu; }
+    if (c < ti.n_tiles) { ti.tcnt[c] = 0u; ti.fov[c] = 0xffffffffu; cx.cnt[c] = 0u; cx.cur[c] = 0u; }
     if (c == 0) {
         g->first_error = ~0ull; g->hist_cap_total = 0; g->chist_total = 0; g->internal_error = 0;
+        g->n_cx = 0; g->cx_total = 0;
     }
     if (c < COUNTER_SLOTS * 8) { g->prim_slots[c] = 0; g->cons_slots[c] = 0; }
     if (c < 8 * 16) g->chunk_ctr[c] = 0;
@@ -173,7 +196,9 @@ __global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g, TileIdx ti) 
 // M/=/X run (contig coordinate); y = 0 for "no events", else top two bits give the type:
 //   RW_SINGLE  y = length of the only run
 //   RW_DOUBLE  two runs split by one short D/N gap: len1 (10 bits) | gap (8 bits) << 10 | len2 (10 bits) << 18
-//   RW_COMPLEX anything else (long reads, several gaps): k_pileup re-walks the CIGAR
+//   RW_COMPLEX anything else with a short CIGAR (several gaps): k_pileup re-walks the CIGAR
+//   RW_BUCKET  long CIGARs (long-read mappings): k_cx_expand writes every M/=/X operation into the buckets of the tiles
+//              it overlaps; k_pileup reads its tile's bucket (coalesced) and ignores the record itself
 // Adjacent runs separated only by I/S/H/P are merged: their +1/-1 events cancel (contig.rs:178-183).
 //
 // One workgroup walks PREP_CHUNK consecutive records (PREP_ITEMS coalesced passes).  Each wave keeps
@@ -217,6 +242,73 @@ __device__ __forceinline__ void cigar_walk_slow(const u32 *__restrict__ cigar, u
     span = sp > 0 ? (u32)min(sp, (long long)0xffffffffu) : 0u;
 }
 
+// Whole-wave walk of ONE long CIGAR (all arguments wave-uniform; every lane returns the same result): 64 operations
+// per step, loaded coalesced; reference positions come from a wave prefix sum of the reference-consuming lengths and
+// run boundaries from a running maximum of the M/=/X ends (an M op continues the open run iff it starts where the
+// previous M op ended, contig.rs:178-183).  A long-read record costs nops/64 steps instead of nops serial iterations
+// of one lane.  `absurd` (an operation of >= 2^24 bases) sends the record to the literal serial walk.
+struct WalkOut {
+    u64 aligned, indel;
+    u32 run_start, run_len, run2_start, run2_len, n_runs, span;
+    bool oob, badcig, absurd;
+};
+__device__ __forceinline__ void cigar_walk_wave(const u32 *__restrict__ cigar, u32 co0, u32 nops, int pos, u32 L, WalkOut &o) {
+    const int lane = lane_id();
+    const int NEG = (int)0x80000000;
+    long long cur0 = pos, last_e = 0, rs1 = 0, rs2 = 0, r1end = 0;
+    bool have_prev = false, oobl = false, badl = false;
+    u64 al = 0, in_ = 0;
+    u32 n_runs = 0;
+    o.absurd = false;
+    u32 wd_next = (u32)lane < nops ? cigar[co0 + (u32)lane] : 4u;  // padding = 0S: no flag set
+    for (u32 base = 0; base < nops; base += 64) {
+        const u32 wd = wd_next;
+        const u32 idn = base + 64u + (u32)lane;                    // next step's words are in flight during this one
+        wd_next = idn < nops ? cigar[co0 + idn] : 4u;
+        const u32 len = wd >> 4, bit = 1u << (wd & 15u);
+        if (__any(len >= (1u << 24))) { o.absurd = true; return; }
+        const u32 fr = (bit & 0x18du) ? len : 0u;
+        const u32 incl = (u32)wave_incl_scan((int)fr), excl = incl - fr;
+        const bool m = (bit & 0x181u) != 0u;
+        badl |= (bit & 0xfe00u) != 0u;
+        al += (bit & 0x187u) ? len : 0u;
+        in_ += (bit & 0x006u) ? len : 0u;
+        const long long sj = cur0 + (long long)excl;
+        oobl |= m && (sj < 0 || sj >= (long long)L);
+        const int erel = m ? (int)(excl + len) : NEG;
+        int pm = wave_incl_max(erel);
+        pm = __builtin_amdgcn_update_dpp(NEG, pm, 0x138, 0xf, 0xf, false);      // exclusive: wave_shr:1
+        const int carry_rel = have_prev ? (int)(last_e - cur0) : NEG;            // <= 0
+        pm = max(pm, carry_rel);
+        const bool nr = m && (pm == NEG || (int)excl != pm);
+        u64 mm = __ballot(nr);
+        while (mm != 0 && n_runs < 2u) {
+            const int l = __ffsll((long long)mm) - 1;
+            const long long sl = cur0 + (long long)__builtin_amdgcn_readlane(excl, l);
+            if (n_runs == 0u) rs1 = sl;
+            else { rs2 = sl; r1end = cur0 + (long long)(int)__builtin_amdgcn_readlane((u32)pm, l); }
+            n_runs++;
+            mm &= mm - 1;
+        }
+        n_runs += (u32)__popcll(mm);
+        const u64 mb = __ballot(m);
+        if (mb != 0) {
+            const int lm = 63 - __builtin_clzll(mb);
+            last_e = cur0 + (long long)__builtin_amdgcn_readlane(excl + len, lm);
+            have_prev = true;
+        }
+        cur0 += (long long)__builtin_amdgcn_readlane(incl, 63);
+    }
+    o.aligned = wave_sum_u64(al); o.indel = wave_sum_u64(in_);
+    o.oob = __any(oobl); o.badcig = __any(badl);
+    const long long sp = cur0 - (long long)pos;
+    o.span = sp > 0 ? (u32)min(sp, (long long)0xffffffffu) : 0u;
+    o.n_runs = n_runs;
+    o.run_start = (u32)rs1; o.run2_start = (u32)rs2;
+    o.run_len = n_runs == 1u ? (u32)(last_e - rs1) : (u32)(r1end - rs1);
+    o.run2_len = n_runs >= 2u ? (u32)(last_e - rs2) : 0u;      // only meaningful when n_runs == 2
+}
+
 // Counters of one workgroup that lies entirely inside one contig (tid >= 0), reduced later by k_prep_reduce:
 // per-wave atomics on a hot contig's accumulator line serialise at ~12 ns each and dominated k_prep.
 struct PrepPartial {
@@ -254,12 +346,16 @@ template <bool WANT_IDENTITY>
 __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__ tlen, u32 n_targets,
                                               const uint8_t *__restrict__ mask, FilterCfg f, DevContig *ctg,
                                               DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ identp,
-                                              double *__restrict__ identn, PrepPartial *__restrict__ part, TileIdx ti) {
+                                              double *__restrict__ identn, PrepPartial *__restrict__ part, TileIdx ti,
+                                              int passes, int b_active, u32 *__restrict__ cx_list, u32 cx_list_cap) {
     __shared__ u32 blk_cnt[2][4];
     __shared__ PrepPartial wpart[4];
     bool flushed_early = false;   // this wave already sent sums for an earlier contig through atomics
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    const u32 chunk = blockIdx.x * (u32)PREP_CHUNK;
+    // records per workgroup: the host picks one pass of one record per thread for long CIGARs (few records, each a lot
+    // of work: more, smaller workgroups), 8 passes of PREP_B records for short reads
+    const u32 chunk_recs = 256u * (u32)b_active * (u32)passes;
+    const u32 chunk = blockIdx.x * chunk_recs;
     PrepAcc acc; acc.reset();
     int cur = -1;            // wave-uniform: contig the running sums belong to
     u32 g_prim = 0, g_cons = 0;
@@ -268,15 +364,15 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
 
     // Chunk-relative addressing: uniform (SGPR) bases + a small per-thread offset, so every load is
     // `global_load v, voff, s[base]` instead of a 64-bit per-lane address computation.
-    const u32 lmax = min(r.n - chunk, (u32)PREP_CHUNK) - 1u;     // last valid chunk-relative index (r.n > chunk)
+    const u32 lmax = min(r.n - chunk, chunk_recs) - 1u;     // last valid chunk-relative index (r.n > chunk)
     const uint16_t *flag_c = r.flag + chunk; const int *tid_c = r.tid + chunk; const int *pos_c = r.pos + chunk;
     const uint8_t *mapq_c = r.mapq + chunk; const uint8_t *nmk_c = r.nm_kind + chunk; const u32 *nm_c = r.nm + chunk;
     const u32 *lseq_c = r.l_seq + chunk; const u32 *coff_c = r.cigar_off + chunk;
     const int *tid_m = r.tid + chunk - 1; const int *pos_m = r.pos + chunk - 1;   // [x + 1] = record x (never read below 0)
     uint2 *runs_c = runs + chunk;
 
-    for (int ps = 0; ps < PREP_PASSES; ps++) {
-        const u32 l0 = (u32)(ps * PREP_B) * 256u + threadIdx.x;
+    for (int ps = 0; ps < passes; ps++) {
+        const u32 l0 = (u32)(ps * b_active) * 256u + threadIdx.x;
         const u32 i0 = chunk + l0;
         if (!__any(i0 < r.n)) break;
         // ---- phase A: every independent field of PREP_B records, issued back to back (clamped, branch-free)
@@ -306,7 +402,7 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
 #pragma unroll
         for (int k = 0; k < PREP_B; k++) {
             const u32 i = i0 + (u32)k * 256u;
-            const bool in = i < r.n;
+            const bool in = i < r.n && k < b_active;
             const u32 flag = in ? fl[k] : 0x904u;
             const int tid = in ? td[k] : -1;
             const int pos = ps_[k];
@@ -350,13 +446,14 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
             // 32 bits: at most CIG_FAST_OPS ops of < 2^24 each (sum < 2^31); anything else (long reads, absurd
             // lengths) is redone by the literal 64-bit walk below.
             bool hard = nops_all > CIG_FAST_OPS;
+            bool big = false;   // an operation of >= 2^24 bases: such a record never takes the bucket path
             {
                 const u32 nops = hard ? 0u : nops_all;
                 const u32 L = Lc[k];
                 u32 cursor = (u32)pos, cur_e = 0, al32 = 0, in32 = 0;
                 auto step = [&](u32 wd, bool act) {
                     const u32 len = wd >> 4, bit = 1u << (wd & 15u);
-                    hard |= act && len >= (1u << 24);
+                    big |= act && len >= (1u << 24);
                     const bool m = act && (bit & 0x181u);                      // M = X   (contig.rs:171-186)
                     badcig |= act && (bit & 0xfe00u);
                     oob |= m && cursor >= L;                                   // negative cursors wrap to >= 2^31 > L
@@ -381,10 +478,23 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                 }
                 aligned = al32; indel = in32;
                 span = cursor - (u32)pos;
+                hard |= big;
             }
-            if (__any(hard)) {
-                if (hard) cigar_walk_slow(r.cigar, co0[k], nops_all, pos, Lc[k], aligned, indel, run_start, run_len, run2_start,
-                                          run2_len, n_runs, span, oob, badcig);
+            for (u64 hm = __ballot(hard); hm != 0; hm &= hm - 1) {      // long CIGARs: one at a time, whole wave on each
+                const int l = __ffsll((long long)hm) - 1;
+                WalkOut o;
+                cigar_walk_wave(r.cigar, __builtin_amdgcn_readlane(co0[k], l), __builtin_amdgcn_readlane(nops_all, l),
+                                (int)__builtin_amdgcn_readlane((u32)pos, l), __builtin_amdgcn_readlane(Lc[k], l), o);
+                if (lane == l) {
+                    big |= o.absurd;
+                    if (o.absurd) cigar_walk_slow(r.cigar, co0[k], nops_all, pos, Lc[k], aligned, indel, run_start, run_len,
+                                                  run2_start, run2_len, n_runs, span, oob, badcig);
+                    else {
+                        aligned = o.aligned; indel = o.indel; run_start = o.run_start; run_len = o.run_len;
+                        run2_start = o.run2_start; run2_len = o.run2_len; n_runs = o.n_runs; span = o.span;
+                        oob = o.oob; badcig = o.badcig;
+                    }
+                }
             }
             if (need_filter_eval) {  // single_read_passes_filter, filter.rs:256-278
                 if (nmk[k] != 1u) report_error(g, i, nmk[k] == 0u ? 2u : 3u);
@@ -407,6 +517,7 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                 else nmv = nmv32[k];
                 if (WANT_IDENTITY && aligned > 0) idv = ((double)aligned - (double)nmv) / (double)aligned;
             }
+            bool is_bucket = false;
             if (in) {
                 uint2 rw;
                 rw.x = 0u; rw.y = 0u;
@@ -416,7 +527,10 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                     if (n_runs == 1 && run_len < (1u << 30)) rw.y = run_len;   // RW_SINGLE; 0 = nothing to add
                     else if (n_runs == 2 && run_len - 1u < 1023u && run2_len - 1u < 1023u && gap - 1u < 255u)
                         rw.y = (RW_DOUBLE << 30) | run_len | (gap << 10) | (run2_len << 18);
-                    else rw.y = RW_COMPLEX << 30;
+                    else {
+                        is_bucket = nops_all > CX_MIN_OPS && !big;
+                        rw.y = (is_bucket ? RW_BUCKET : RW_COMPLEX) << 30;
+                    }
                 }
                 runs_c[i - chunk] = rw;
                 if (WANT_IDENTITY) {
@@ -425,6 +539,17 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                 }
             }
 
+            {   // RW_BUCKET records: one aggregated append per wave
+                const u64 qm = __ballot(is_bucket);
+                if (qm != 0) {
+                    const int l = __ffsll((long long)qm) - 1;
+                    u32 b = 0;
+                    if (lane == l) b = atomicAdd(&g->n_cx, (u32)__popcll(qm));
+                    b = __builtin_amdgcn_readlane(b, l);
+                    const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(qm >> 32), __builtin_amdgcn_mbcnt_lo((u32)qm, 0u));
+                    if (is_bucket && b + rank < cx_list_cap) cx_list[b + rank] = i;
+                }
+            }
             // ---- tile bookkeeping for k_ranges (every record of a real contig counts towards F, considered or not)
             {
                 const u32 L = Lc[k];
@@ -443,7 +568,7 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                 // records that reach beyond their own tile announce themselves to the tiles they enter
                 const u32 e = span > L - pc ? L : pc + span;                 // end of the record's reference extent, clipped
                 const u32 te = (tv && span > 0u) ? (e - 1u) >> ti.shift : 0u;
-                const bool cross = tv && masked_in && n_runs > 0u && span > 0u && te > tl;
+                const bool cross = tv && masked_in && n_runs > 0u && span > 0u && te > tl && !is_bucket;   // buckets deliver those
                 const u64 cm = __ballot(cross);
                 if (cm != 0 && !(ti.ablate & 2u)) {
                     const int fl0 = __ffsll((long long)cm) - 1;
@@ -537,13 +662,13 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
 
 // One wave per contig: adds the partial records of the workgroups that lay entirely inside it.
 __global__ __launch_bounds__(64) void k_prep_reduce(DevContig *ctg, u32 n_targets, const PrepPartial *__restrict__ part,
-                                                    u32 n_parts) {
+                                                    u32 n_parts, u32 chunk_recs) {
     const u32 c = blockIdx.x;
     if (c >= n_targets) return;
     DevContig *C = &ctg[c];
     const u32 rs = C->rec_start, re = C->rec_end;
     if (rs >= re) return;
-    const u32 b0 = rs / (u32)PREP_CHUNK, b1 = min((re - 1) / (u32)PREP_CHUNK, n_parts - 1);
+    const u32 b0 = rs / chunk_recs, b1 = min((re - 1) / chunk_recs, n_parts - 1);
     u32 prim = 0, pass = 0, nons = 0, span = 0, first = 0xffffffffu, last = 0;
     u64 nm = 0, indel = 0;
     for (u32 b = b0 + (threadIdx.x & 63); b <= b1; b += 64) {
@@ -587,7 +712,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan1(const u32 *__restrict__ tcn
     if (threadIdx.x == 0) ttop[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(1024) void k_tile_scan2(u32 *ttop, u32 n_blocks) {
+__global__ __launch_bounds__(1024) void k_tile_scan2(u32 *ttop, u32 n_blocks, u64 *total) {
     __shared__ u32 wtot[16];
     __shared__ u32 carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -607,6 +732,58 @@ __global__ __launch_bounds__(1024) void k_tile_scan2(u32 *ttop, u32 n_blocks) {
         if (threadIdx.x == 0) carry_s = carry + tot;
         __syncthreads();
     }
+    if (total != nullptr && threadIdx.x == 0) *total = carry_s;
+}
+
+// Expansion of RW_BUCKET records (long CIGARs): one wave per record walks the CIGAR 64 operations per step (as
+// cigar_walk_wave does) and, for every M/=/X operation, visits the tiles it overlaps: FILL = false counts entries per
+// tile, FILL = true writes (start, end) at the tile's cursor.  Lanes that hit the same tile share one atomic.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_cx_expand(Records r, const u32 *__restrict__ tlen, DevGlobal *g, CxIdx cx, TileIdx ti) {
+    const int lane = lane_id();
+    const u32 n = min(g->n_cx, cx.list_cap);
+    if (FILL && g->cx_total > cx.runs_cap) return;     // the host grows the buffer and runs the pipeline again
+    const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (u32 j = wave; j < n; j += n_waves) {
+        const u32 i = cx.list[j];
+        const int tid = r.tid[i];
+        const u32 co0 = r.cigar_off[i], nops = r.cigar_off[i + 1] - co0;
+        const u32 L = tlen[tid], t0 = ti.tile_first[tid];
+        long long cur0 = r.pos[i];
+        u32 wd_next = (u32)lane < nops ? r.cigar[co0 + (u32)lane] : 4u;
+        for (u32 base = 0; base < nops; base += 64) {
+            const u32 wd = wd_next;
+            const u32 idn = base + 64u + (u32)lane;
+            wd_next = idn < nops ? r.cigar[co0 + idn] : 4u;
+            const u32 len = wd >> 4, bit = 1u << (wd & 15u);             // every len < 2^24 (k_prep's `big` test)
+            const u32 fr = (bit & 0x18du) ? len : 0u;
+            const u32 incl = (u32)wave_incl_scan((int)fr), excl = incl - fr;
+            const long long sj = cur0 + (long long)excl;
+            const bool m = (bit & 0x181u) != 0u && len > 0u && sj >= 0 && sj < (long long)L;
+            const u32 sv = (u32)sj, ev = sv + len;
+            const u32 ts = sv >> ti.shift, te = m ? (min(ev, L) - 1u) >> ti.shift : 0u;
+            for (u32 k = 0; __any(m && ts + k <= te); k++) {              // k-th tile of every operation
+                const bool v = m && ts + k <= te;
+                const u32 key = t0 + ts + k;
+                u32 slot = 0;
+                for (u64 todo = __ballot(v); todo != 0;) {
+                    const int l = __ffsll((long long)todo) - 1;
+                    const u32 k0 = __builtin_amdgcn_readlane(key, l);
+                    const u64 grp = __ballot(v && key == k0);
+                    u32 b = 0;
+                    if (lane == l) b = atomicAdd(FILL ? &cx.cur[k0] : &cx.cnt[k0], (u32)__popcll(grp));
+                    if (FILL) {
+                        b = __builtin_amdgcn_readlane(b, l);
+                        if (v && key == k0) slot = b + (u32)__popcll(grp & lt);
+                    }
+                    todo &= ~grp;
+                }
+                if (FILL && v) cx.runs[(u64)cx.cscan[key] + cx.ctop[key >> 10] + slot] = make_uint2(sv, ev);
+            }
+            cur0 += (long long)__builtin_amdgcn_readlane(incl, 63);
+        }
+    }
 }
 
 // One thread per tile: candidate record range [x, y) from the tile counts (see TileIdx), contig length, generic flag.
@@ -614,14 +791,19 @@ template <bool WANT_HIST>
 __global__ __launch_bounds__(256) void k_ranges(const u32 *__restrict__ tile_contig, const u32 *__restrict__ tile_start,
                                                 u32 n_tiles, const u32 *__restrict__ tlen, const uint8_t *__restrict__ mask,
                                                 DevContig *ctg, uint4 *__restrict__ desc, TileIdx ti,
-                                                const u32 *__restrict__ tscan, const u32 *__restrict__ ttop) {
+                                                const u32 *__restrict__ tscan, const u32 *__restrict__ ttop, CxIdx cx,
+                                                const DevGlobal *__restrict__ g) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     const u32 c = tile_contig[t];
     DevContig *C = &ctg[c];
     uint4 out = make_uint4(0u, 0u, tlen[c], 0u);
+    u32 cxn = 0, cxo = 0, nrec = 0;
     if (C->n_pass != 0 && (mask == nullptr || mask[c])) {
         const u32 rs = C->rec_start, re = C->rec_end;
+        // buckets that did not fit were not filled: this pass is discarded and repeated by the host (cov_finish)
+        cxn = g->cx_total <= cx.runs_cap ? cx.cnt[t] : 0u;
+        cxo = cx.cscan[t] + cx.ctop[t >> 10]; nrec = re - rs;
         if (C->n_groups != 1u) out.w = 1u;
         if (C->n_groups != 1u || (C->flags & F_POS_UNSORTED)) {
             out.x = rs; out.y = re;  // generic path: every tile of this contig scans the whole span
@@ -635,14 +817,14 @@ __global__ __launch_bounds__(256) void k_ranges(const u32 *__restrict__ tile_con
         }
     }
     if (WANT_HIST) {   // one atomic per wave when all its tiles belong to one contig (the usual case)
-        const u32 cap = out.y - out.x;
+        const u32 cap = min(out.y - out.x + cxn, nrec);   // depth <= candidates + bucket entries, and <= records of the contig
         if (__all(c == (u32)__builtin_amdgcn_readfirstlane((int)c))) {
             const u32 m = wave_max_u32(cap);
             if (lane_id() == 0 && m) atomicMax(&C->hist_cap, m);
         } else if (cap) atomicMax(&C->hist_cap, cap);
     }
     desc[2 * t] = out;
-    desc[2 * t + 1] = make_uint4(c, tile_start[t], 0u, 0u);
+    desc[2 * t + 1] = make_uint4(c, tile_start[t], cxo, cxn);
 }
 
 // ------------------------------------------------------------------------------------ histogram layout
@@ -960,6 +1142,7 @@ struct PileupArgs {
     const u32 *tile_contig, *tile_start;
     const uint4 *desc;
     const uint2 *runs;
+    const uint2 *cx_runs;   // per-tile buckets of RW_BUCKET records (desc[2t+1].z = offset, .w = count)
     Records r;
     DevContig *ctg;
     DevGlobal *g;
@@ -989,7 +1172,8 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
 
     const u32 t = a.tile_base + blockIdx.x;
     const uint4 ds = a.desc[2 * t];
-    if (ds.x >= ds.y) return;  // no record can touch this tile: depth 0 everywhere, accounted on the host side
+    const uint4 ds1 = a.desc[2 * t + 1];
+    if (ds.x >= ds.y && ds1.w == 0u) return;  // no record can touch this tile: depth 0 everywhere, accounted on the host side
     const u32 lo = a.tile_start[t];
     const u32 c = a.tile_contig[t];
     const u32 L = ds.z;
@@ -1031,7 +1215,7 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
             const u32 l1 = rw.y & 1023u, gap = (rw.y >> 10) & 255u, l2 = (rw.y >> 18) & 1023u;
             add_run(rw.x, rw.x + l1);
             add_run(rw.x + l1 + gap, rw.x + l1 + gap + l2);
-        } else {  // re-walk the CIGAR (contig.rs:166-202)
+        } else if (type == RW_COMPLEX) {  // re-walk the CIGAR (contig.rs:166-202)
             u32 cursor = (u32)a.r.pos[i];
             const u32 c0 = a.r.cigar_off[i], c1 = a.r.cigar_off[i + 1];
             for (u32 k = c0; k < c1; k++) {
@@ -1040,8 +1224,10 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
                 if (op == 0u || op == 7u || op == 8u) { add_run(cursor, cursor + len); cursor += len; }
                 else if (op == 2u || op == 3u) cursor += len;
             }
-        }
+        }   // RW_BUCKET: delivered through the tile's bucket below
     }
+    if (!(a.ablate & 1u))
+    for (u32 j = tid; j < ds1.w; j += NT) { const uint2 q = a.cx_runs[(u64)ds1.z + j]; add_run(q.x, q.y); }
     __syncthreads();
 
     // ---- block-wide prefix sum.  Thread `tid` owns quad q = row * NT + tid of every row (striped, so the
@@ -1320,7 +1506,8 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
                 if (t + 2 < t1) load_desc(t + 2, dNN0, dNN1);
                 dC0 = dN0; dC1 = dN1; dN0 = dNN0; dN1 = dNN1; rC0 = rN0; rC1 = rN1;
             };
-            if (ds.x >= ds.y) { stage_next(); continue; }   // depth 0 everywhere: accounted on the host side
+            const u32 cxo = dC1.z, cxn = dC1.w;
+            if (ds.x >= ds.y && cxn == 0u) { stage_next(); continue; }   // depth 0 everywhere: accounted on the host side
             const bool generic = ds.w & 1u;
             if ((int)c != cur_c) {
                 flush();
@@ -1349,7 +1536,7 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
                     const u32 l1 = rw.y & 1023u, gap = (rw.y >> 10) & 255u, l2 = (rw.y >> 18) & 1023u;
                     add_run(rw.x, rw.x + l1);
                     add_run(rw.x + l1 + gap, rw.x + l1 + gap + l2);
-                } else {
+                } else if (type == RW_COMPLEX) {
                     u32 cursor = (u32)a.r.pos[i];
                     const u32 c0 = a.r.cigar_off[i], c1 = a.r.cigar_off[i + 1];
                     for (u32 k = c0; k < c1; k++) {
@@ -1358,11 +1545,12 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
                         if (op == 0u || op == 7u || op == 8u) { add_run(cursor, cursor + len); cursor += len; }
                         else if (op == 2u || op == 3u) cursor += len;
                     }
-                }
+                }   // RW_BUCKET: delivered through the tile's bucket
             };
             apply(rw0, ds.x + (u32)lane);
             apply(rw1, ds.x + 64u + (u32)lane);
             for (u32 i = ds.x + 128u + (u32)lane; i < ds.y; i += 64) apply(a.runs[i], i);   // deep tiles only
+            for (u32 j = (u32)lane; j < cxn; j += 64) { const uint2 q = a.cx_runs[(u64)cxo + j]; add_run(q.x, q.y); }   // long reads
             stage_next();
             lds_fence();
             // ---- read the rows back (lane = base mod 64) and count changed positions on the scalar unit

@@ -117,3 +117,49 @@ def aligned_bases(batch: RecordBatch) -> int:
     op = batch.cigar & 15
     ln = (batch.cigar >> 4).astype(np.int64)
     return int(ln[(op == 0) | (op == 7) | (op == 8)].sum())
+
+
+def make_long_reads(ref: SynthReference, n_reads: int, seed=2, mean_len=10_000, indel_rate=0.08) -> RecordBatch:
+    """Long-read profile (ONT/PacBio-like mappings): read lengths ~ lognormal around `mean_len`, one 1-3 base I or D
+    every ~1/indel_rate aligned bases (so thousands of CIGAR operations per read), leading/trailing soft clips on a
+    fifth of the reads.  Coordinate sorted; vectorised so tens of millions of CIGAR words take seconds."""
+    rng = np.random.default_rng(seed)
+    L = ref.lengths
+    n = int(n_reads)
+    rl = np.clip(rng.lognormal(np.log(mean_len) - 0.125, 0.5, n), 500, 60_000)
+    j = rng.poisson(rl * indel_rate).astype(np.int64)              # indel events per read
+    seg_read = np.repeat(np.arange(n), j + 1)                       # read of every M segment
+    n_seg = len(seg_read)
+    mlen = 1 + rng.geometric(indel_rate, n_seg).astype(np.int64)
+    np.minimum(mlen, 400, out=mlen)
+    seg_start = np.zeros(n + 1, dtype=np.int64); np.cumsum(j + 1, out=seg_start[1:])
+    k_in = np.arange(n_seg) - seg_start[seg_read]                   # index of the segment within its read
+    has_x = k_in < j[seg_read]                                      # every segment but the last is followed by I/D
+    xop = np.where(rng.random(n_seg) < 0.5, 1, 2).astype(np.uint32)  # I / D
+    xlen = rng.integers(1, 4, n_seg).astype(np.int64)
+    clip5 = rng.random(n) < 0.2
+    clip3 = rng.random(n) < 0.2
+    nops = 2 * j + 1 + clip5 + clip3
+    coff = np.zeros(n + 1, dtype=np.int64); np.cumsum(nops, out=coff[1:])
+    ref_span = np.bincount(seg_read, weights=mlen + np.where(has_x & (xop == 2), xlen, 0), minlength=n).astype(np.int64)
+    w = np.maximum(L - ref_span.max() - 1, 0) * rng.lognormal(0.0, 1.0, len(L))
+    assert w.sum() > 0, "reference contigs are shorter than the longest read"
+    cdf = np.cumsum(w) / w.sum()
+    tid = np.minimum(np.searchsorted(cdf, rng.random(n), side="right"), len(L) - 1).astype(np.int32)
+    pos = (rng.random(n) * (L[tid] - ref_span - 1)).astype(np.int32)
+    cig = np.zeros(int(coff[-1]), dtype=np.uint32)
+    base = coff[:-1] + clip5
+    cig[coff[:-1][clip5]] = (rng.integers(5, 200, int(clip5.sum())).astype(np.uint32) << 4) | 4
+    cig[(coff[1:] - 1)[clip3]] = (rng.integers(5, 200, int(clip3.sum())).astype(np.uint32) << 4) | 4
+    mi = base[seg_read] + 2 * k_in
+    cig[mi] = (mlen.astype(np.uint32) << 4)
+    cig[mi[has_x] + 1] = (xlen[has_x].astype(np.uint32) << 4) | xop[has_x]
+    aligned = np.bincount(seg_read, weights=mlen + np.where(has_x, xlen, 0), minlength=n)
+    nm = rng.poisson(aligned * 0.03).astype(np.uint32)
+    order = np.lexsort((pos, tid))
+    new_off = np.zeros(n + 1, dtype=np.int64); np.cumsum(nops[order], out=new_off[1:])
+    src = np.repeat(coff[:-1][order] - new_off[:-1], nops[order]) + np.arange(int(new_off[-1]))
+    flag = np.where(rng.random(n) < 0.03, 0x800, 0).astype(np.uint16) | np.where(rng.random(n) < 0.5, 16, 0).astype(np.uint16) | 2
+    lseq = (aligned + 0).astype(np.uint32)
+    return RecordBatch.from_arrays(tid[order], pos[order], flag[order], np.full(n, 60), nm[order], np.ones(n), lseq[order],
+                                   new_off.astype(np.uint32), cig[src])
