@@ -283,3 +283,33 @@ def test_huge_skip_operation():
     order, _ = O.reader_stage(b, None)
     ud = O.contig_deltas(b, O.FlagFilter(True, True, False), 1, order)
     np.testing.assert_array_equal(d, np.cumsum(ud, dtype=np.int64).astype(np.int32))
+
+
+def test_bucket_regrowth_and_session_reuse():
+    """One session, several samples: long reads (bucket buffer sized on a first pass and the pipeline repeated), then
+    short reads, then a larger long-read sample (second growth); every result equals the oracle's, and the depth
+    read-out after a repeated pass is exact."""
+    ref_lens = np.asarray([400_000, 900_000, 150_000], dtype=np.int64)
+    ref = synth.SynthReference(["c0", "c1", "c2"], ref_lens, np.zeros(3, np.int32), ["g"])
+    samples = [_long_read_batch(ref_lens, 300, 2_000, seed=21), synth.make_reads(ref, 30_000, seed=22),
+               _long_read_batch(ref_lens, 2_500, 10_000, seed=23)]
+    off = O.FlagFilter(True, True, False)
+    with Session(0, FilterConfig(), 75, want_hist=True, want_identity=True) as s:
+        s.set_targets(ref_lens)
+        for k, batch in enumerate(samples):
+            b = to_bamdata(batch, ref_lens)
+            exp, exp_hist, prim = O.integer_stats(b, off, None, 75, None)
+            s.reset()
+            s.push(batch)
+            st, summ = s.finish()
+            hist = s.hist()
+            live = exp["seen"] == 1
+            for f in ("n_pass", "sum_nm", "sum_indel", "win_sum_d", "win_sum_d2", "win_covered", "full_covered",
+                      "win_min_d", "win_max_d", "hist_len"):
+                np.testing.assert_array_equal(st[f][live], exp[f][live], err_msg="sample %d %s" % (k, f))
+            for t in np.nonzero(live)[0]:
+                n_b = int(exp["hist_len"][t])
+                np.testing.assert_array_equal(hist[int(st["hist_off"][t]):int(st["hist_off"][t]) + n_b],
+                                              exp_hist[int(exp["hist_off"][t]):int(exp["hist_off"][t]) + n_b])
+            order, _ = O.reader_stage(b, None)
+            np.testing.assert_array_equal(s.depth(1), np.cumsum(O.contig_deltas(b, off, 1, order), dtype=np.int64).astype(np.int32))
