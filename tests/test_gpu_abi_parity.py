@@ -313,3 +313,93 @@ def test_bucket_regrowth_and_session_reuse():
                                               exp_hist[int(exp["hist_off"][t]):int(exp["hist_off"][t]) + n_b])
             order, _ = O.reader_stage(b, None)
             np.testing.assert_array_equal(s.depth(1), np.cumsum(O.contig_deltas(b, off, 1, order), dtype=np.int64).astype(np.int32))
+
+
+def _fuzz_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n_ctg = int(rng.integers(1, 12))
+    pool = [1, 5, 149, 150, 151, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 4096, 4097, 9000, 33000, 70000]
+    ref_lens = np.asarray([pool[int(rng.integers(0, len(pool)))] for _ in range(n_ctg)], dtype=np.int64)
+    n_rec = int(rng.integers(1, 3000))
+    ops_all = "MIDNSHP=X"
+    recs = []
+    for _ in range(n_rec):
+        t = int(rng.integers(0, n_ctg))
+        L = int(ref_lens[t])
+        style = rng.random()
+        n_ops = 1 if style < 0.5 else int(rng.integers(2, 8)) if style < 0.9 else int(rng.integers(8, 40)) if style < 0.985 \
+            else int(rng.integers(129, 200))
+        ops, ref_used = [], 0
+        budget = L - 1
+        for k in range(n_ops):
+            o = ops_all[int(rng.integers(0, 9))] if n_ops > 1 else "M"
+            mx = 160 if n_ops < 8 else 12
+            ln = int(rng.integers(0, mx)) if rng.random() < 0.97 else int(rng.integers(0, 3000))
+            if o in "MDN=X":
+                ln = min(ln, max(0, budget - ref_used))
+                ref_used += ln
+            ops.append((ln, o))
+        pos = int(rng.integers(0, max(1, L - ref_used)))
+        if rng.random() < 0.05 and ops[-1][1] in "M=X":          # run off the end of the contig: clipped, not an error
+            ops[-1] = (ops[-1][0] + int(rng.integers(1, 400)), ops[-1][1])
+            if pos + ref_used - 0 >= L: pos = max(0, L - ref_used - 1)
+        recs.append([t, pos, ops])
+    recs.sort(key=lambda r: (r[0], r[1]))
+    if rng.random() < 0.3:                                          # positions out of order inside one contig: accepted
+        t = recs[int(rng.integers(0, len(recs)))][0]
+        idx = [i for i, r in enumerate(recs) if r[0] == t]
+        perm = rng.permutation(len(idx))
+        sub = [recs[idx[j]] for j in perm]
+        for i, r in zip(idx, sub): recs[i] = r
+    n = len(recs)
+    tid = np.asarray([r[0] for r in recs]); pos = np.asarray([r[1] for r in recs])
+    coff = np.zeros(n + 1, dtype=np.uint32)
+    np.cumsum([len(r[2]) for r in recs], out=coff[1:])
+    cig = np.asarray([(l << 4) | ops_all.index(o) for r in recs for l, o in r[2]], dtype=np.uint32)
+    base = rng.choice([99, 147, 83, 163, 97, 145, 0, 16], n)
+    flag = base | np.where(rng.random(n) < 0.05, 0x100, 0) | np.where(rng.random(n) < 0.05, 0x800, 0) \
+        | np.where(rng.random(n) < 0.04, 0x4, 0)
+    nm = rng.integers(0, 30, n)
+    batch = RecordBatch.from_arrays(tid, pos, flag, rng.integers(0, 61, n), nm, np.ones(n), rng.integers(1, 300, n), coff, cig)
+    return ref_lens, batch, rng
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_small_cases(seed):
+    """Random small inputs aimed at the index/bucket/walk machinery: contig lengths around tile boundaries, zero-length
+    operations, every CIGAR op, CIGARs above the 16- and 128-operation thresholds, reads clipped by the contig end,
+    position-unsorted contigs, all flag combinations, random filters, end exclusions and masks."""
+    ref_lens, batch, rng = _fuzz_case(seed)
+    b = to_bamdata(batch, ref_lens)
+    ff = tuple(bool(x) for x in rng.integers(0, 2, 3))
+    excl = int(rng.choice([0, 10, 75, 500]))
+    mask = (rng.random(len(ref_lens)) < 0.8).astype(np.uint8) if rng.random() < 0.3 else None
+    fp = None
+    if rng.random() < 0.35 and mask is None:
+        fp = dict(min_percent_identity_single=float(np.float32(rng.choice([0.0, 0.5, 0.9]))),
+                  min_aligned_length_single=int(rng.choice([0, 20, 100])),
+                  min_aligned_percent_single=float(np.float32(rng.choice([0.0, 0.3]))))
+        if fp["min_percent_identity_single"] == 0.0 and fp["min_aligned_length_single"] == 0 and fp["min_aligned_percent_single"] == 0.0:
+            fp = None
+    depth_of = [t for t in range(min(3, len(ref_lens))) if mask is None or mask[t]]    # a masked contig has no depth here
+    compare(b, ff=ff, fp=fp, excl=excl, mask=mask, check_depth=depth_of, chunks=int(rng.integers(1, 4)))
+
+
+@pytest.mark.parametrize("tile", ["4096", "16384"])
+def test_workgroup_per_tile_kernel(tile, monkeypatch):
+    """The simpler cross-check implementation (COVERM_PILEUP=tile: one workgroup per 4096/16384-base tile) must agree
+    with the oracle on the same inputs as the default wave-per-tile streaming kernel."""
+    monkeypatch.setenv("COVERM_PILEUP", "tile")
+    monkeypatch.setenv("COVERM_TILE", tile)
+    for name in ["7seqs.reads_for_seq1_and_seq2.bam", "k141_2005182.bam", "eg2.bam"]:
+        compare(load_fixture(name), ff=(True, True, False), excl=75)
+    ref = synth.make_reference(40, 3_000_000, seed=11, min_len=1500, max_len=400_000)
+    b = to_bamdata(synth.make_reads(ref, 60_000, seed=12), ref.lengths, ref.names)
+    compare(b, ff=(True, True, False), excl=75, check_depth=[0, 1, 39], chunks=2)
+    ref_lens = np.asarray([300_000, 1_200_000, 80_000], dtype=np.int64)
+    compare(to_bamdata(_long_read_batch(ref_lens, 400, 5_000, seed=5), ref_lens), ff=(True, True, False), excl=75,
+            check_depth=range(3))
+    for seed in range(0, 48, 5):
+        ref_lens, batch, rng = _fuzz_case(seed)
+        compare(to_bamdata(batch, ref_lens), ff=(True, True, False), excl=int(rng.choice([0, 75])),
+                check_depth=range(min(3, len(ref_lens))))
