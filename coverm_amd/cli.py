@@ -14,6 +14,8 @@ import sys
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
 
+import ctypes as C
+
 import numpy as np
 
 from . import host
@@ -159,68 +161,49 @@ class EstimatorsAndTaker:  # bin/coverm.rs:1315-1504
 
 
 # ---------------------------------------------------------------------------------------------------
-# Reader stage.  Single-read thresholds run on the GPU (k_prep); mate pairing needs read names and is a
-# host-side pre-pass for now (filter.rs:117-228, a "next" row of the scope table).
-def _aligned(c, ops):
-    op = c & 15
-    m = np.zeros(len(c), bool)
-    for o in ops:
-        m |= op == o
-    return int((c >> 4)[m].sum()) & 0xFFFFFFFF
+# Reader stage.  Single-read thresholds run on the GPU (k_prep); mate pairing needs read names, which do not cross
+# the C ABI, so it is the host layer's threaded C++ pre-pass (csrc/host_filter.cpp, filter.rs:117-228).
+class _PairFilter(C.Structure):   # covh_pair_filter
+    _fields_ = [("filter_single", C.c_int32), ("min_mapq", C.c_uint8), ("min_aligned_length_single", C.c_uint32),
+                ("min_percent_identity_single", C.c_float), ("min_aligned_percent_single", C.c_float),
+                ("min_aligned_length_pair", C.c_uint32), ("min_percent_identity_pair", C.c_float),
+                ("min_aligned_percent_pair", C.c_float)]
 
 
-def pair_mode_order(af: AlignmentFile, fp: FilterParameters):
+def pair_mode_order(af: AlignmentFile, fp: FilterParameters, threads: int = 8):
     """Indices of the records ReferenceSortedBamFilter::read returns in pair mode (filter_out = true)."""
+    from . import native
+    from .native import CovBatch
+    L = native.lib()
     r = af.records
-    f32 = np.float32
+    n = r.n_records
     fs, _ = fp.filter_mode()
-
-    def nm(i):
-        if r.nm_kind[i] != 1:
-            raise SystemExit("Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM "
-                             "format" if r.nm_kind[i] == 0 else "Unexpected data type of NM aux tag")
-        return int(r.nm[i])
-
-    def cig(i):
-        return r.cigar[r.cigar_off[i]:r.cigar_off[i + 1]]
-
-    def single_ok(i):  # filter.rs:243-279
-        if fp.min_mapq != 255 and (r.mapq[i] < fp.min_mapq or r.mapq[i] == 255):
-            return False
-        e = nm(i)
-        al = _aligned(cig(i), (0, 1, 2, 7, 8))
-        with np.errstate(divide="ignore", invalid="ignore"):
-            return bool(al >= fp.min_aligned_length_single
-                        and f32(al) / f32(int(r.l_seq[i])) >= f32(fp.min_aligned_percent_single)
-                        and f32(1.0) - f32(e) / f32(al) >= f32(fp.min_percent_identity_single))
-
-    def pair_ok(i2, i1):  # filter.rs:281-336
-        if fp.min_mapq != 255 and (r.mapq[i1] < fp.min_mapq or r.mapq[i2] < fp.min_mapq
-                                   or r.mapq[i1] == 255 or r.mapq[i2] == 255):
-            return False
-        e = nm(i2) + nm(i1)
-        al = (_aligned(cig(i2), (0, 1, 7, 8)) + _aligned(cig(i1), (0, 1, 7, 8))) & 0xFFFFFFFF
-        with np.errstate(divide="ignore", invalid="ignore"):
-            return bool(al >= fp.min_aligned_length_pair
-                        and f32(al) / f32(int(r.l_seq[i1]) + int(r.l_seq[i2])) >= f32(fp.min_aligned_percent_pair)
-                        and f32(1.0) - f32(e) / f32(al) >= f32(fp.min_percent_identity_pair))
-
-    order, first_set, cur = [], {}, -1
-    for i in range(r.n_records):
-        flag = int(r.flag[i])
-        if flag & 0x900 or not flag & 0x2:
-            continue
-        if r.tid[i] != cur:
-            cur = int(r.tid[i]); first_set = {}
-        q = af.qname[i]
-        if q not in first_set:
-            if af.mtid[i] == cur:
-                first_set[q] = i
-        else:
-            i1 = first_set.pop(q)
-            if ((not fs) or (single_ok(i1) and single_ok(i))) and pair_ok(i, i1):
-                order += [i1, i]
-    return np.asarray(order, dtype=np.int64)
+    pf = _PairFilter(int(fs), fp.min_mapq, fp.min_aligned_length_single, fp.min_percent_identity_single,
+                     fp.min_aligned_percent_single, fp.min_aligned_length_pair, fp.min_percent_identity_pair,
+                     fp.min_aligned_percent_pair)
+    cb = CovBatch()
+    for k in ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar"):
+        a = getattr(r, k)
+        setattr(cb, k, a.ctypes.data if a.size else None)
+    cb.n_records = n
+    qoff = np.zeros(n + 1, dtype=np.uint32)
+    np.cumsum([len(q) for q in af.qname], out=qoff[1:])
+    blob = b"".join(af.qname) or b"\0"
+    mtid = np.ascontiguousarray(af.mtid, dtype=np.int32)
+    out = C.c_void_p()
+    n_out = C.c_uint64(0)
+    L.covh_pair_mode_order.argtypes = [C.POINTER(CovBatch), C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(_PairFilter),
+                                       C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.covh_free.argtypes = [C.c_void_p]
+    rc = L.covh_pair_mode_order(C.byref(cb), mtid.ctypes.data if n else None, qoff.ctypes.data, blob, C.byref(pf), threads,
+                                C.byref(out), C.byref(n_out))
+    if rc == native.ERR_NM_MISSING:
+        raise SystemExit("Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM format")
+    if rc:
+        raise SystemExit("Unexpected data type of NM aux tag" if rc == native.ERR_NM_BADTYPE else "pair filter failed (%d)" % rc)
+    order = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(max(1, n_out.value),))[:n_out.value].astype(np.int64)
+    L.covh_free(out)
+    return order
 
 
 def _select(r: RecordBatch, idx) -> RecordBatch:

@@ -69,58 +69,6 @@ struct Sample {
     uint64_t prim = 0;
 };
 
-// ---- pair-mode reader stage on the host (filter.rs:117-228, filter_out = true): indices in emission order
-uint32_t aligned_of(const cov_batch &b, uint64_t i, bool with_del) {
-    uint32_t a = 0;
-    for (uint32_t c = b.cigar_off[i]; c < b.cigar_off[i + 1]; c++) {
-        const uint32_t op = b.cigar[c] & 15u, len = b.cigar[c] >> 4;
-        if (op == 0 || op == 1 || op == 7 || op == 8 || (with_del && op == 2)) a += len;
-    }
-    return a;
-}
-uint64_t nm_or_die(const cov_batch &b, uint64_t i) {
-    if (b.nm_kind[i] == COV_NM_UNSIGNED) return b.nm[i];
-    die(b.nm_kind[i] == COV_NM_ABSENT ? "Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM format"
-                                      : "Unexpected data type of NM aux tag");
-}
-bool single_ok(const cov_batch &b, uint64_t i, const Filter &f) {   // filter.rs:243-279
-    if (f.mapq != 255 && (b.mapq[i] < f.mapq || b.mapq[i] == 255)) return false;
-    const uint64_t e = nm_or_die(b, i);
-    const uint32_t al = aligned_of(b, i, true);
-    return al >= f.len_single && (float)al / (float)b.l_seq[i] >= f.pct_single && 1.0f - (float)e / (float)al >= f.pid_single;
-}
-bool pair_ok(const cov_batch &b, uint64_t i2, uint64_t i1, const Filter &f) {   // filter.rs:281-336
-    if (f.mapq != 255 && (b.mapq[i1] < f.mapq || b.mapq[i2] < f.mapq || b.mapq[i1] == 255 || b.mapq[i2] == 255)) return false;
-    const uint64_t e = nm_or_die(b, i2) + nm_or_die(b, i1);
-    const uint32_t al = aligned_of(b, i2, false) + aligned_of(b, i1, false);
-    return al >= f.len_pair && (float)al / (float)((uint64_t)b.l_seq[i1] + b.l_seq[i2]) >= f.pct_pair &&
-           1.0f - (float)e / (float)al >= f.pid_pair;
-}
-std::vector<uint64_t> pair_mode_order(const covh_bam *h, const cov_batch &b, const Filter &f) {
-    bool fs, fp;
-    f.mode(fs, fp);
-    const int32_t *mtid = covh_bam_mtid(h);
-    const uint32_t *qo = covh_bam_qname_off(h);
-    const char *qn = covh_bam_qnames(h);
-    std::vector<uint64_t> order;
-    std::unordered_map<std::string, uint64_t> first_set;
-    int32_t cur = -1;
-    for (uint64_t i = 0; i < b.n_records; i++) {
-        const uint16_t flag = b.flag[i];
-        if ((flag & 0x900) || !(flag & 0x2)) continue;
-        if (b.tid[i] != cur) { cur = b.tid[i]; first_set.clear(); }
-        std::string q(qn + qo[i], qo[i + 1] - qo[i]);
-        auto it = first_set.find(q);
-        if (it == first_set.end()) { if (mtid[i] == cur) first_set.emplace(std::move(q), i); }
-        else {
-            const uint64_t i1 = it->second;
-            first_set.erase(it);
-            if ((!fs || (single_ok(b, i1, f) && single_ok(b, i, f))) && pair_ok(b, i, i1, f)) { order.push_back(i1); order.push_back(i); }
-        }
-    }
-    return order;
-}
-
 void check(cov_session *s, cov_status st) { if (st != COV_OK) die(cov_last_error(s)); }
 
 }  // namespace
@@ -322,26 +270,25 @@ int main(int argc, char **argv) {
         // stoit name = file stem (bam_generator.rs:358-365)
         { std::string p = a.bams[bi]; size_t sl = p.find_last_of('/'); if (sl != std::string::npos) p = p.substr(sl + 1);
           size_t dot = p.find_last_of('.'); S.stoit = dot == std::string::npos ? p : p.substr(0, dot); }
-        std::vector<int32_t> stid, spos; std::vector<uint16_t> sflag; std::vector<uint8_t> smapq, snmk;
-        std::vector<uint32_t> snm, slseq, scoff, scig;
+        cov_batch selected; memset(&selected, 0, sizeof selected);
+        bool have_selected = false;
         bool prim_from_host = false;
         if (f.doing_filtering()) {
             if (!(fs && !fp)) {
                 for (uint64_t i = 0; i < batch.n_records; i++) if (!(batch.flag[i] & 0x900)) S.prim++;   // filter.rs:129-131
                 prim_from_host = true;
-                const std::vector<uint64_t> order = pair_mode_order(bam, batch, f);
-                scoff.push_back(0);
-                for (uint64_t i : order) {
-                    stid.push_back(batch.tid[i]); spos.push_back(batch.pos[i]); sflag.push_back(batch.flag[i]);
-                    smapq.push_back(batch.mapq[i]); snmk.push_back(batch.nm_kind[i]); snm.push_back(batch.nm[i]);
-                    slseq.push_back(batch.l_seq[i]);
-                    for (uint32_t c = batch.cigar_off[i]; c < batch.cigar_off[i + 1]; c++) scig.push_back(batch.cigar[c]);
-                    scoff.push_back((uint32_t)scig.size());
-                }
-                if (scig.empty()) scig.push_back(0);
-                batch.tid = stid.data(); batch.pos = spos.data(); batch.flag = sflag.data(); batch.mapq = smapq.data();
-                batch.nm_kind = snmk.data(); batch.nm = snm.data(); batch.l_seq = slseq.data();
-                batch.cigar_off = scoff.data(); batch.cigar = scig.data(); batch.n_records = order.size();
+                covh_pair_filter pf; memset(&pf, 0, sizeof pf);
+                pf.filter_single = fs; pf.min_mapq = (uint8_t)f.mapq; pf.min_aligned_length_single = f.len_single;
+                pf.min_percent_identity_single = f.pid_single; pf.min_aligned_percent_single = f.pct_single;
+                pf.min_aligned_length_pair = f.len_pair; pf.min_percent_identity_pair = f.pid_pair; pf.min_aligned_percent_pair = f.pct_pair;
+                uint64_t *order = nullptr, n_order = 0;
+                const int prc = covh_pair_mode_order(&batch, covh_bam_mtid(bam), covh_bam_qname_off(bam), covh_bam_qnames(bam), &pf,
+                                                     a.threads, &order, &n_order);
+                if (prc == COV_ERR_NM_MISSING) die("Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM format");
+                if (prc != COV_OK) die(prc == COV_ERR_NM_BADTYPE ? "Unexpected data type of NM aux tag" : "pair filter failed");
+                if (covh_batch_select(&batch, order, n_order, a.threads, &selected) != COV_OK) die("pair filter: selection failed");
+                covh_free(order);
+                batch = selected; have_selected = true;
             }
         }
         if (bi == 0) {
@@ -359,6 +306,7 @@ int main(int argc, char **argv) {
         if (want & COV_WANT_HIST) { S.hist.resize(summ.hist_total); check(s, cov_fetch_hist(s, S.hist.data())); }
         if (!prim_from_host) S.prim = summ.num_detected_primary_alignments;
         const double tw4 = now();
+        if (have_selected) covh_batch_free(&selected);
         covh_bam_close(bam);
         if (timing) fprintf(stderr, "[coverm-amd] sample %zu: waited for decoder %.3fs, session ready %.3fs, push %.3fs, finish+fetch %.3fs, close %.3fs\n",
                             bi, tw1 - tw0, tw2 - tw1, tw3 - tw2, tw4 - tw3, now() - tw4);

@@ -147,6 +147,28 @@ const char *covh_bam_qnames(const covh_bam *h);
 int covh_bam_write(const char *path, uint32_t n_targets, const char *const *names, const uint64_t *lens,
                    const cov_batch *batch, int with_seq, int level, int threads);
 
+/* ---- reader-stage PAIR filter (ReferenceSortedBamFilter::read pair branch, filter.rs:117-228, filter_out = true).
+ * The single-read branch runs on the device (cov_config.filter_single); the pair branch needs read names, which never
+ * cross the covermhip ABI, so it runs here, threaded over references.  Thresholds as FilterParameters holds them
+ * (coverm.rs:1648-1704); filter_single = ReferenceSortedBamFilter::filter_single (filter.rs:48-55). */
+typedef struct {
+    int32_t filter_single;
+    uint8_t min_mapq; /* 255 = off */
+    uint32_t min_aligned_length_single;
+    float min_percent_identity_single, min_aligned_percent_single;
+    uint32_t min_aligned_length_pair;
+    float min_percent_identity_pair, min_aligned_percent_pair;
+} covh_pair_filter;
+/* Indices of the records the reference's filter would return, in its order (first mate then second mate, pairs
+ * ordered by where the second mate sits in the file).  *order_out is released with covh_free.  Returns COV_OK, or
+ * COV_ERR_NM_MISSING / COV_ERR_NM_BADTYPE where the reference's nm() would have panicked. */
+int covh_pair_mode_order(const cov_batch *b, const int32_t *mtid, const uint32_t *qname_off, const char *qnames,
+                         const covh_pair_filter *f, int threads, uint64_t **order_out, uint64_t *n_out);
+void covh_free(void *p);
+/* Gathers records order[0..n) of src into a new batch (page-locked memory when a device is usable). */
+int covh_batch_select(const cov_batch *src, const uint64_t *order, uint64_t n, int threads, cov_batch *out);
+void covh_batch_free(cov_batch *b);
+
 /* calculate_coverage for one entry built from explicit sums (used by unit tests). */
 typedef struct {
     uint64_t win_len, win_sum_d, win_sum_d2, win_covered, full_len, full_covered, n_reads, mismatches;

@@ -185,3 +185,61 @@ def test_exports_and_no_gpu_failure_is_loud():
     for name in native.EXPORTS:
         assert hasattr(L, name)
     assert L.cov_abi_version() == 1
+
+
+def _paired_sample(n_pairs, seed):
+    """Coordinate-sorted synthetic proper pairs with names: 85 % both mates on one contig, the rest split over two
+    contigs (never paired), a few names used by two pairs (the parked-set state machine), a few with missing mates."""
+    import numpy as np
+    from oracle.bamio import BamData
+    rng = np.random.default_rng(seed)
+    ref_lens = np.asarray([50_000, 120_000, 8_000, 300_000, 20_000], dtype=np.int64)
+    rows = []   # tid, pos, flag, mapq, nm, lseq, cig, mtid, name
+    for p in range(n_pairs):
+        name = b"p%d" % (p if rng.random() > 0.02 else int(rng.integers(0, max(1, p))))
+        t1 = int(rng.integers(0, 5))
+        t2 = t1 if rng.random() < 0.85 else int(rng.integers(0, 5))
+        for k, (t, mt) in enumerate(((t1, t2), (t2, t1))):
+            if k == 1 and rng.random() < 0.03:
+                continue                                    # mate absent from the file
+            L = int(ref_lens[t])
+            ln = int(rng.integers(60, 151))
+            cig = [(ln << 4)] if rng.random() < 0.8 else [((ln // 2) << 4), (int(rng.integers(1, 4)) << 4) | int(rng.integers(1, 3)), ((ln - ln // 2) << 4)]
+            flag = (99 if k == 0 else 147) if rng.random() < 0.9 else (97 if k == 0 else 145)   # 10 % not proper pairs
+            if rng.random() < 0.02: flag |= 0x100
+            rows.append((t, int(rng.integers(0, L - 200)), flag, int(rng.integers(0, 61)), int(rng.integers(0, 12)), ln + int(rng.integers(0, 20)), cig, mt, name))
+    rows.sort(key=lambda r: (r[0], r[1]))
+    n = len(rows)
+    coff = np.zeros(n + 1, dtype=np.uint32)
+    np.cumsum([len(r[6]) for r in rows], out=coff[1:])
+    z = np.zeros(n, np.int32)
+    return BamData(["c%d" % i for i in range(5)], ref_lens, np.asarray([r[0] for r in rows], np.int32),
+                   np.asarray([r[1] for r in rows], np.int32), np.asarray([r[2] for r in rows], np.uint16),
+                   np.asarray([r[3] for r in rows], np.uint8), np.asarray([r[5] for r in rows], np.int32),
+                   np.asarray([r[4] for r in rows], np.uint32), np.ones(n, np.uint8), coff,
+                   np.asarray([w for r in rows for w in r[6]], np.uint32), np.asarray([r[7] for r in rows], np.int32), z, z,
+                   [r[8] for r in rows], "")
+
+
+@pytest.mark.parametrize("threads", [1, 7])
+@pytest.mark.parametrize("params", [dict(min_percent_identity_pair=0.95), dict(min_aligned_length_pair=200, min_mapq=20),
+                                    dict(min_percent_identity_single=0.9, min_aligned_percent_pair=0.8),
+                                    dict(min_mapq=30, proper=True)])
+def test_pair_stage_cpp_matches_oracle_at_scale(params, threads):
+    """The threaded C++ pair stage (csrc/host_filter.cpp) returns exactly the oracle's order on 40 k synthetic pairs."""
+    import numpy as np
+    from coverm_amd.engine import RecordBatch
+    from oracle import oracle as O
+    params = dict(params)
+    proper = params.pop("proper", False)
+    b = _paired_sample(40_000, seed=3)
+    ofp = O.FilterParameters(O.FlagFilter(not proper, True, False), **params)
+    fs, fpairs = O.filter_mode(ofp)
+    assert fpairs
+    want, _ = O.reader_stage(b, ofp)
+    rec = RecordBatch.from_arrays(b.tid, b.pos, b.flag, b.mapq, b.nm, b.nm_kind, b.l_seq, b.cigar_off, b.cigar)
+    af = cli.AlignmentFile("x.bam", b.ref_names, b.ref_lens, rec, b.qname, b.mtid)
+    fp = cli.FilterParameters(cli.FlagFilter(not proper, True, False), **params)
+    got = cli.pair_mode_order(af, fp, threads=threads)
+    assert len(got) > 1000
+    np.testing.assert_array_equal(got, np.asarray(want, dtype=np.int64))
