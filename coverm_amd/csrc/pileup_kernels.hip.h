@@ -1094,16 +1094,51 @@ __global__ __launch_bounds__(64) void k_id_combine(DevContig *ctg, u32 n_targets
     const bool generic = C->n_groups != 1u;
     const int lane = lane_id();
     double Sp = 0.0, Sn = 0.0;
+    // Exact in-order addition of 64 values (lane order) to S.  While S stays in one binade every addition is an
+    // integer addition of round(x/ulp) to the mantissa, so a wave prefix sum applies all values up to the first one
+    // that leaves the binade, is an exact rounding tie, or is not in [0, 1]; that one value takes a true f64 add (the
+    // reference's own operation) and the rest continue in the new binade.  Replaces a 64-step dependent add chain.
+    auto block_add = [&](double &S, const double xv) {
+        const bool irregular = !(xv >= 0.0 && xv <= 1.0);
+        u32 q = 0;
+        while (q < 64u) {
+            const u64 bits = (u64)__double_as_longlong(S);
+            const int e_cur = (int)((bits >> 52) & 0x7ff) - 1023;
+            if (e_cur < 1 || (bits >> 63)) { S += bcast_f64(xv, (int)q); q++; continue; }   // |S| < 2 or S < 0 (negative identities: NM > aligned): plain adds
+            const u64 m = (bits & 0xfffffffffffffull) | (1ull << 52);
+            bool tie = false;
+            const u64 t = irregular ? 0ull : id_units(xv, e_cur, tie);        // <= 2^52 for x <= 1, e >= 1
+            const bool in_range = (u32)lane >= q;
+            u64 P = in_range ? t : 0ull;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const u64 u = __shfl_up(P, o); if (lane >= o) P += u; }
+            const bool fits = in_range && !tie && !irregular && m + P < (1ull << 53);
+            const u64 failm = __ballot(in_range && !fits);
+            const u32 jstar = failm ? (u32)(__ffsll((long long)failm) - 1) : 64u;
+            if (jstar > q) {
+                const u64 T = bcast_u64(P, (int)(jstar - 1));
+                S = __longlong_as_double((long long)((bits & 0xfff0000000000000ull) | ((m + T) & 0xfffffffffffffull)));
+            }
+            if (jstar < 64u) S += bcast_f64(xv, (int)jstar);
+            q = jstar + 1;
+        }
+    };
     auto serial = [&](u32 from, u32 to, bool need_p, bool need_n) {   // the reference's serial chain over [from, to)
-        for (u32 b = from; b < to; b += 64) {
+        auto fetch = [&](u32 b, double &xp, double &xn) {
             const u32 i = b + (u32)lane;
-            double xp = 0.0, xn = 0.0;
+            xp = 0.0; xn = 0.0;
             if (i < to && (!generic || tidv[i] == (int)c)) {
                 if (need_p) xp = identp[i];
                 if (need_n) xn = identn[i];
             }
-#pragma unroll 16
-            for (int q = 0; q < 64; q++) { Sn += __shfl(xn, q); Sp += __shfl(xp, q); }   // bpermutes pipeline; v_readlane does not
+        };
+        double xp, xn;
+        if (from < to) fetch(from, xp, xn);
+        for (u32 b = from; b < to; b += 64) {
+            const double cp = xp, cn = xn;
+            if (b + 64 < to) fetch(b + 64, xp, xn);      // next block's values are in flight during this one
+            if (need_n) block_add(Sn, cn);
+            if (need_p) block_add(Sp, cp);
         }
     };
     const u32 k0 = generic ? 0u : (rs + ID_CH - 1) / ID_CH, k1 = generic ? 0u : re / ID_CH;   // interior chunks
@@ -1115,15 +1150,35 @@ __global__ __launch_bounds__(64) void k_id_combine(DevContig *ctg, u32 n_targets
             IdChunk x;
             if (kk < k1) x = ch[kk]; else { x.tp = x.tn = 0; x.ep = x.en = ID_SERIAL; x.flags = 15u; }
             const u32 nb = min(64u, k1 - kb);
-            for (u32 q = 0; q < nb; q++) {
-                const u32 fl = __builtin_amdgcn_readlane(x.flags, (int)q);
-                const int ep = (int)__builtin_amdgcn_readlane((u32)x.ep, (int)q), en = (int)__builtin_amdgcn_readlane((u32)x.en, (int)q);
-                const u64 tp = bcast_u64(x.tp, (int)q), tn = bcast_u64(x.tn, (int)q);
-                bool need_p = true, need_n = true;
-                if (!(fl & (1u | 4u)) && id_fast_add(Sp, ep, tp)) need_p = false;
-                if (!(fl & (2u | 8u)) && id_fast_add(Sn, en, tn)) need_n = false;
-                if (need_p || need_n) serial((kb + q) * ID_CH, (kb + q + 1) * ID_CH, need_p, need_n);
-            }
+            // All chunks of the batch whose predicted binade is the binade S is in, and that keep S inside it, are
+            // verified together: S only grows, so "the running mantissa after chunk j is still < 2^53" for the last
+            // chunk implies it for every earlier one.  One wave prefix sum finds the first chunk that does not fit
+            // (binade crossing, tie, irregular value, unpredicted); that one is replayed serially and the rest of the
+            // batch continues from there.  A contig of 1.5 M reads costs ~25 steps + ~20 replays instead of 1500 steps.
+            auto run_stream = [&](double &S, const int e_l, const u64 t_l, const bool bad_l, const bool is_p) {
+                u32 q = 0;
+                while (q < nb) {
+                    const u64 bits = (u64)__double_as_longlong(S);
+                    const int e_cur = (int)((bits >> 52) & 0x7ff) - 1023;
+                    const u64 m = (bits & 0xfffffffffffffull) | (1ull << 52);
+                    const bool in_range = (u32)lane >= q && (u32)lane < nb;
+                    u64 P = in_range ? t_l : 0ull;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const u64 t = __shfl_up(P, o); if (lane >= o) P += t; }
+                    const bool fits = in_range && !bad_l && !(bits >> 63) && e_l == e_cur && t_l < (1ull << 53) &&
+                                      P < (1ull << 53) && m + P < (1ull << 53);
+                    const u64 failm = __ballot(in_range && !fits);
+                    const u32 jstar = failm ? (u32)(__ffsll((long long)failm) - 1) : nb;
+                    if (jstar > q) {
+                        const u64 T = bcast_u64(P, (int)(jstar - 1));
+                        S = __longlong_as_double((long long)((bits & 0xfff0000000000000ull) | ((m + T) & 0xfffffffffffffull)));
+                    }
+                    if (jstar < nb) serial((kb + jstar) * ID_CH, (kb + jstar + 1) * ID_CH, is_p, !is_p);
+                    q = jstar + 1;
+                }
+            };
+            run_stream(Sp, x.ep, x.tp, (x.flags & (1u | 4u)) != 0u, true);
+            run_stream(Sn, x.en, x.tn, (x.flags & (2u | 8u)) != 0u, false);
         }
         serial(k1 * ID_CH, re, true, true);
     }

@@ -403,3 +403,19 @@ def test_workgroup_per_tile_kernel(tile, monkeypatch):
         ref_lens, batch, rng = _fuzz_case(seed)
         compare(to_bamdata(batch, ref_lens), ff=(True, True, False), excl=int(rng.choice([0, 75])),
                 check_depth=range(min(3, len(ref_lens))))
+
+
+@pytest.mark.parametrize("neg_frac", [0.02, 0.6])
+def test_identity_sums_with_negative_identities(neg_frac):
+    """NM > aligned length gives a negative per-read identity (the reference adds it all the same, contig.rs:208-211).
+    With a few of them the running sum dips and re-crosses binades; with most of them it goes negative, where the
+    integer fast path must stand aside."""
+    ref = synth.make_reference(3, 2_000_000, seed=41, min_len=300_000, max_len=1_000_000)
+    batch = synth.make_reads(ref, 500_000, seed=42)
+    rng = np.random.default_rng(6)
+    batch.nm = batch.nm.copy()
+    sel = (rng.random(batch.n_records) < neg_frac) & (batch.nm_kind == 1)
+    batch.nm[sel] = rng.integers(151, 4000, int(sel.sum())).astype(np.uint32)
+    b = to_bamdata(batch, ref.lengths, ref.names)
+    st = compare(b, ff=(True, True, True), excl=0)
+    assert (st["sum_identity_primary"] < 0).any() == (neg_frac > 0.5)
