@@ -295,6 +295,8 @@ def run(mode: str, files: Sequence[AlignmentFile], methods: Optional[Sequence[st
         if genome_definition is None:
             raise SystemExit("genome mode over BAM files needs --separator, --single-genome or --genome-definition")
         genomes, c2g = read_genome_definition(genome_definition)
+    if want_identity:   # contig.rs:208 and genome.rs:724 sum over primary reads, genome.rs:220 over not-supplementary ones
+        want_identity = "nonsupp" if genomes is not None else "primary"
 
     samples = []
     for af in files:

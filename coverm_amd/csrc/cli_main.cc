@@ -206,7 +206,9 @@ int main(int argc, char **argv) {
     }
 
     // ---- per BAM: decode (host threads), push, finish
-    const uint32_t want = covh_wants(est.data(), est.size());
+    uint32_t want = covh_wants(est.data(), est.size());
+    if (want & COV_WANT_IDENTITY)   // contig.rs:208 / genome.rs:724 use the primary-read sum, genome.rs:220 the not-supplementary one
+        want |= by_names ? COV_WANT_IDENTITY_NONSUPP_ONLY : COV_WANT_IDENTITY_PRIMARY_ONLY;
     std::vector<Sample> samples(a.bams.size());
     std::string names_blob; std::vector<uint32_t> name_off; std::vector<uint64_t> tlen;
     std::vector<int32_t> genome_of_tid;

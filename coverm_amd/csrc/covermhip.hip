@@ -466,7 +466,8 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     const u32 prep_grid = (R + prep_chunk - 1) / prep_chunk;
     HIPCHK(s->d_part.reserve((size_t)prep_grid + 2, st));
     if (want_id) {
-        HIPCHK(s->d_ident.reserve(std::max<size_t>(1, R), st)); HIPCHK(s->d_identp.reserve(std::max<size_t>(1, R), st));
+        if (!(s->cfg.want & COV_WANT_IDENTITY_PRIMARY_ONLY)) HIPCHK(s->d_ident.reserve(std::max<size_t>(1, R), st));
+        if (!(s->cfg.want & COV_WANT_IDENTITY_NONSUPP_ONLY)) HIPCHK(s->d_identp.reserve(std::max<size_t>(1, R), st));
         HIPCHK(s->d_idch.reserve((size_t)R / ID_CH + 2, st));
     }
     if (want_hist) HIPCHK(s->d_arena.reserve((size_t)R + nT + 1, st));
@@ -492,12 +493,15 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     f.min_percent_identity = s->cfg.min_percent_identity; f.min_aligned_percent = s->cfg.min_aligned_percent;
     const Records r = records_of(s);
     const uint8_t *mask = s->have_mask ? s->d_mask.p : nullptr;
+    // identity streams actually needed (NULL = skipped by k_prep and the k_id_* kernels)
+    double *idp = (want_id && !(s->cfg.want & COV_WANT_IDENTITY_NONSUPP_ONLY)) ? s->d_identp.p : nullptr;
+    double *idn = (want_id && !(s->cfg.want & COV_WANT_IDENTITY_PRIMARY_ONLY)) ? s->d_ident.p : nullptr;
 
     if (R) {
         time_begin(s, COV_K_PREP);
         if (want_id)
             hipLaunchKernelGGL((k_prep<true>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
-                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, s->d_identp.p, s->d_ident.p, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap);
+                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, idp, idn, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap);
         else
             hipLaunchKernelGGL((k_prep<false>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
                                s->d_ctg.p, s->d_glob.p, s->d_runs.p, (double *)nullptr, (double *)nullptr, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap);
@@ -510,12 +514,12 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
             (void)hipEventRecord(s->ev[COV_K_IDENTITY][0], s->side);
             if (s->id_mode) {
                 const u32 nch = (R + ID_CH - 1) / ID_CH;
-                hipLaunchKernelGGL(k_id_approx, dim3(nch), dim3(256), 0, s->side, s->d_identp.p, s->d_ident.p, R, s->d_idch.p);
-                hipLaunchKernelGGL(k_id_predict, dim3(nT), dim3(64), 0, s->side, s->d_ctg.p, nT, s->d_identp.p, s->d_ident.p, s->d_idch.p);
-                hipLaunchKernelGGL(k_id_exact, dim3(nch), dim3(256), 0, s->side, s->d_identp.p, s->d_ident.p, R, s->d_idch.p);
-                hipLaunchKernelGGL(k_id_combine, dim3(nT), dim3(64), 0, s->side, s->d_ctg.p, nT, s->d_identp.p, s->d_ident.p, r.tid, s->d_idch.p);
+                hipLaunchKernelGGL(k_id_approx, dim3(nch), dim3(256), 0, s->side, idp, idn, R, s->d_idch.p);
+                hipLaunchKernelGGL(k_id_predict, dim3(nT), dim3(64), 0, s->side, s->d_ctg.p, nT, idp, idn, s->d_idch.p);
+                hipLaunchKernelGGL(k_id_exact, dim3(nch), dim3(256), 0, s->side, idp, idn, R, s->d_idch.p);
+                hipLaunchKernelGGL(k_id_combine, dim3(nT), dim3(64), 0, s->side, s->d_ctg.p, nT, idp, idn, r.tid, s->d_idch.p);
             } else
-                hipLaunchKernelGGL(k_identity, dim3(nT), dim3(64), 0, s->side, s->d_ctg.p, nT, s->d_identp.p, s->d_ident.p, r.tid);
+                hipLaunchKernelGGL(k_identity, dim3(nT), dim3(64), 0, s->side, s->d_ctg.p, nT, idp, idn, r.tid);
             (void)hipEventRecord(s->ev[COV_K_IDENTITY][1], s->side);
             s->k_launches[COV_K_IDENTITY]++;
             HIPCHK(hipGetLastError());

@@ -533,9 +533,9 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                     }
                 }
                 runs_c[i - chunk] = rw;
-                if (WANT_IDENTITY) {
-                    identn[i] = (masked_in && !supp) ? idv : 0.0;
-                    identp[i] = (masked_in && !supp && !sec) ? idv : 0.0;
+                if (WANT_IDENTITY) {   // a NULL stream is one the caller does not need (COV_WANT_IDENTITY_*_ONLY)
+                    if (identn != nullptr) identn[i] = (masked_in && !supp) ? idv : 0.0;
+                    if (identp != nullptr) identp[i] = (masked_in && !supp && !sec) ? idv : 0.0;
                 }
             }
 
@@ -916,12 +916,12 @@ __global__ __launch_bounds__(64) void k_identity(DevContig *ctg, u32 n_targets, 
     const int lane = lane_id();
     u32 i = rs + (u32)lane;
     double xp = 0.0, xn = 0.0;
-    if (i < re && (!generic || tidv[i] == (int)c)) { xp = identp[i]; xn = identn[i]; }
+    if (i < re && (!generic || tidv[i] == (int)c)) { if (identp) xp = identp[i]; if (identn) xn = identn[i]; }
     for (u32 b = rs; b < re; b += 64) {
         const double cp = xp, cn = xn;
         i += 64;   // prefetch the next 64 while the dependent adds of this batch run
         xp = 0.0; xn = 0.0;
-        if (i < re && (!generic || tidv[i] == (int)c)) { xp = identp[i]; xn = identn[i]; }
+        if (i < re && (!generic || tidv[i] == (int)c)) { if (identp) xp = identp[i]; if (identn) xn = identn[i]; }
 #pragma unroll 16
         for (int k = 0; k < 64; k++) {
             accn += __shfl(cn, k);
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(256) void k_id_approx(const double *__restrict__ id
     for (int j = 0; j < (int)(ID_CH / 256); j++) {
         const u32 i = base + (u32)j * 256u + threadIdx.x;
         if (i < n) {
-            const double xp = identp[i], xn = identn[i];
+            const double xp = identp ? identp[i] : 0.0, xn = identn ? identn[i] : 0.0;
             if (!(xp >= 0.0 && xp <= 1.0)) fl |= 1u;
             if (!(xn >= 0.0 && xn <= 1.0)) fl |= 2u;
             ap += xp; an += xn;
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(64) void k_id_predict(const DevContig *__restrict__
     if (k0 >= k1) return;
     // approximate sum of the head partial segment [rs, k0*ID_CH)
     double pp = 0.0, pn = 0.0;
-    for (u32 i = rs + (threadIdx.x & 63); i < k0 * ID_CH; i += 64) { pp += identp[i]; pn += identn[i]; }
+    for (u32 i = rs + (threadIdx.x & 63); i < k0 * ID_CH; i += 64) { if (identp) pp += identp[i]; if (identn) pn += identn[i]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { pp += __shfl_xor(pp, o); pn += __shfl_xor(pn, o); }
     const int lane = threadIdx.x & 63;
@@ -1019,10 +1019,10 @@ __global__ __launch_bounds__(64) void k_id_predict(const DevContig *__restrict__
         const double sp = pp + (ip - ap), sn = pn + (in_ - an);   // prefix before this chunk
         if (live) {
             int e = ID_SERIAL;
-            if (!(fl & 1u) && sp >= 2.0 && f64_exp(sp * lo_f) == f64_exp((sp + ap) * hi_f)) e = f64_exp(sp);
+            if (identp && !(fl & 1u) && sp >= 2.0 && f64_exp(sp * lo_f) == f64_exp((sp + ap) * hi_f)) e = f64_exp(sp);
             ch[k].ep = e;
             e = ID_SERIAL;
-            if (!(fl & 2u) && sn >= 2.0 && f64_exp(sn * lo_f) == f64_exp((sn + an) * hi_f)) e = f64_exp(sn);
+            if (identn && !(fl & 2u) && sn >= 2.0 && f64_exp(sn * lo_f) == f64_exp((sn + an) * hi_f)) e = f64_exp(sn);
             ch[k].en = e;
         }
         pp += __shfl(ip, 63); pn += __shfl(in_, 63);
@@ -1132,6 +1132,7 @@ __global__ __launch_bounds__(64) void k_id_combine(DevContig *ctg, u32 n_targets
                 if (need_n) xn = identn[i];
             }
         };
+        need_p = need_p && identp != nullptr; need_n = need_n && identn != nullptr;
         double xp, xn;
         if (from < to) fetch(from, xp, xn);
         for (u32 b = from; b < to; b += 64) {
@@ -1177,8 +1178,8 @@ __global__ __launch_bounds__(64) void k_id_combine(DevContig *ctg, u32 n_targets
                     q = jstar + 1;
                 }
             };
-            run_stream(Sp, x.ep, x.tp, (x.flags & (1u | 4u)) != 0u, true);
-            run_stream(Sn, x.en, x.tn, (x.flags & (2u | 8u)) != 0u, false);
+            if (identp != nullptr) run_stream(Sp, x.ep, x.tp, (x.flags & (1u | 4u)) != 0u, true);
+            if (identn != nullptr) run_stream(Sn, x.en, x.tn, (x.flags & (2u | 8u)) != 0u, false);
         }
         serial(k1 * ID_CH, re, true, true);
     }

@@ -80,7 +80,12 @@ class Session:
         cfg.min_percent_identity = filt.min_percent_identity
         cfg.min_aligned_percent = filt.min_aligned_percent
         cfg.contig_end_exclusion = contig_end_exclusion
+        # want_identity: False, True (both sums) or "primary" / "nonsupp" (only the one a given scan loop uses)
         cfg.want = (native.WANT_HIST if want_hist else 0) | (native.WANT_IDENTITY if want_identity else 0)
+        if want_identity == "primary":
+            cfg.want |= native.WANT_IDENTITY_PRIMARY_ONLY
+        elif want_identity == "nonsupp":
+            cfg.want |= native.WANT_IDENTITY_NONSUPP_ONLY
         self.cfg = cfg
         self._h = C.c_void_p()
         st = self._lib.cov_create(C.byref(cfg), C.byref(self._h))

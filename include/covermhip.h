@@ -52,6 +52,11 @@ typedef enum {
 /* cov_config.want bits */
 #define COV_WANT_HIST 1u     /* per-contig depth histogram (trimmed_mean, coverage_histogram) */
 #define COV_WANT_IDENTITY 2u /* ordered f64 identity sums (anir) */
+/* with COV_WANT_IDENTITY: compute only one of the two sums (the other comes back 0).  contig_coverage and the
+ * separator / single-genome scan use the primary-read sum (contig.rs:208, genome.rs:724), the contig-names genome scan
+ * the not-supplementary one (genome.rs:220). */
+#define COV_WANT_IDENTITY_PRIMARY_ONLY 4u
+#define COV_WANT_IDENTITY_NONSUPP_ONLY 8u
 
 typedef struct {
     int32_t device; /* HIP device ordinal */

@@ -419,3 +419,23 @@ def test_identity_sums_with_negative_identities(neg_frac):
     b = to_bamdata(batch, ref.lengths, ref.names)
     st = compare(b, ff=(True, True, True), excl=0)
     assert (st["sum_identity_primary"] < 0).any() == (neg_frac > 0.5)
+
+
+def test_single_identity_stream_flags():
+    """COV_WANT_IDENTITY_PRIMARY_ONLY / _NONSUPP_ONLY: the requested sum is bit-identical to the two-stream run, the
+    other one comes back 0."""
+    ref = synth.make_reference(6, 2_000_000, seed=51, min_len=100_000, max_len=900_000)
+    batch = synth.make_reads(ref, 300_000, seed=52)
+    res = {}
+    for mode in (True, "primary", "nonsupp"):
+        with Session(0, FilterConfig(True, True, True), 75, want_hist=False, want_identity=mode) as s:
+            s.set_targets(ref.lengths)
+            s.push(batch)
+            res[mode] = s.finish()[0]
+    both = res[True]
+    assert (both["sum_identity_primary"] != both["sum_identity_nonsupp"]).any()
+    np.testing.assert_array_equal(res["primary"]["sum_identity_primary"].view(np.uint64), both["sum_identity_primary"].view(np.uint64))
+    np.testing.assert_array_equal(res["nonsupp"]["sum_identity_nonsupp"].view(np.uint64), both["sum_identity_nonsupp"].view(np.uint64))
+    assert (res["primary"]["sum_identity_nonsupp"] == 0).all() and (res["nonsupp"]["sum_identity_primary"] == 0).all()
+    for f in ("n_pass", "win_sum_d", "win_sum_d2", "sum_nm"):
+        np.testing.assert_array_equal(res["primary"][f], both[f])

@@ -16,7 +16,7 @@ ap.add_argument("--contigs", type=int, default=1000)
 ap.add_argument("--bp", type=int, default=200_000_000)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--hist", type=int, default=1)
-ap.add_argument("--identity", type=int, default=0)
+ap.add_argument("--identity", type=int, default=0, help="1 both identity sums, 2 primary-read sum only")
 ap.add_argument("--filter", type=int, default=0)
 ap.add_argument("--long", type=int, default=0, help="mean read length of a long-read profile (0 = short reads)")
 ap.add_argument("--excl", type=int, default=75)
@@ -29,7 +29,7 @@ print("generated %d reads over %d contigs (%.0f Mbp) in %.1fs" % (a.reads, a.con
                                                                    time.time() - t), flush=True)
 filt = FilterConfig(include_improper_pairs=not a.filter, filter_single=bool(a.filter), min_aligned_length=50 if a.filter else 0,
                     min_percent_identity=0.95 if a.filter else 0.0)
-with Session(0, filt, a.excl, want_hist=bool(a.hist), want_identity=bool(a.identity)) as s:
+with Session(0, filt, a.excl, want_hist=bool(a.hist), want_identity=("primary" if a.identity == 2 else bool(a.identity))) as s:
     s.set_targets(ref.lengths)
     t = time.time()
     s.push(batch)
