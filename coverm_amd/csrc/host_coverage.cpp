@@ -214,6 +214,13 @@ struct covh_taker {
         if (kind == COVH_TAKER_CACHED) { stoit_names.push_back(n); coverages.emplace_back(); cur_stoit_i = stoit_names.size() - 1; }
         else cur_stoit = n;
     }
+    // capacity hint from the scan drivers: entries per sample, coverages per entry, bytes of all entry names
+    void reserve(size_t entries, size_t per_entry, size_t name_bytes) {
+        if (kind != COVH_TAKER_CACHED) { text.reserve(text.size() + entries * (per_entry * 12 + 24) + name_bytes); return; }
+        if (!coverages.empty()) coverages.back().reserve(entries * per_entry);
+        if (entry_names.refs.capacity() < entries) entry_names.refs.reserve(entries);
+        if (entry_names.arena.capacity() < name_bytes) entry_names.arena.reserve(name_bytes);
+    }
     void start_entry(size_t id, std::string_view name) {
         if (kind == COVH_TAKER_STREAM) { text += cur_stoit; text += '\t'; text.append(name); }
         else if (kind == COVH_TAKER_PILEUP) cur_entry_name.assign(name);
@@ -366,6 +373,7 @@ int covh_contig_coverage(const covh_header *h, const covh_sample *samples, size_
     for (size_t si = 0; si < n_samples; si++) {
         const covh_sample &S = samples[si];
         taker->start_stoit(S.stoit_name);
+        taker->reserve(h->n_targets, n_est, h->name_off[h->n_targets]);
         u64 mapped_total = 0;
         int64_t prev = -1;
         auto zero_rows = [&](int64_t from, int64_t to) {   // print_previous_zero_coverage_contigs, :255-277
