@@ -59,6 +59,21 @@ class NativeLibraryMissing(RuntimeError):
     pass
 
 
+def _torch_hip_first():
+    """PyTorch-ROCm ships its own copy of the HIP runtime.  If torch is already imported in this process its runtime
+    must come up BEFORE libcovermhip.so is loaded: the loader then binds our NEEDED libamdhip64 to the copy torch
+    loaded (same SONAME) and both share one runtime; in the other order torch later reports "No HIP GPUs are available"."""
+    import sys
+    t = sys.modules.get("torch")
+    if t is None:
+        return
+    try:
+        if t.cuda.is_available():
+            t.cuda.init()
+    except Exception:
+        pass
+
+
 def lib():
     """Loads libcovermhip.so.  Raises if it has not been built: the HIP path is the only path."""
     global _lib
@@ -68,6 +83,7 @@ def lib():
         raise NativeLibraryMissing(
             "%s not found — build it with `python -m coverm_amd.build` (hipcc, gfx950). "
             "coverm_amd has no CPU fallback for the coverage hot path." % LIB_PATH)
+    _torch_hip_first()
     L = C.CDLL(LIB_PATH)
     L.cov_abi_version.restype = C.c_int
     L.cov_last_error.restype = C.c_char_p

@@ -439,3 +439,72 @@ def test_single_identity_stream_flags():
     assert (res["primary"]["sum_identity_nonsupp"] == 0).all() and (res["nonsupp"]["sum_identity_primary"] == 0).all()
     for f in ("n_pass", "win_sum_d", "win_sum_d2", "sum_nm"):
         np.testing.assert_array_equal(res["primary"][f], both[f])
+
+
+def _device_tensors(batch, lo=0, hi=None):
+    """cov_batch fields as torch device tensors; [lo, hi) is a VIEW into the full arrays, so cigar_off[0] != 0."""
+    import torch
+    hi = batch.n_records if hi is None else hi
+    dev = torch.device("cuda", 0)
+    full = {k: torch.from_numpy(np.ascontiguousarray(getattr(batch, k))).to(dev) for k in
+            ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar")}
+    view = {k: (v[lo:hi] if k not in ("cigar_off", "cigar") else v) for k, v in full.items()}
+    view["cigar_off"] = full["cigar_off"][lo:hi + 1]
+    torch.cuda.synchronize()
+    return view, hi - lo
+
+
+def _finish_all(s):
+    st, summ = s.finish()
+    return st, s.hist(), int(summ.num_detected_primary_alignments)
+
+
+def test_push_batch_device_matches_host_push():
+    """cov_push_batch_device: adopted in place (zero copy, cigar offsets not starting at 0), then materialised when a
+    second batch follows; short and long-read (bucket + repeated pass) inputs; all equal to pushing from the host."""
+    ref = synth.make_reference(20, 4_000_000, seed=61, min_len=20_000, max_len=900_000)
+    short = synth.make_reads(ref, 120_000, seed=62)
+    ref_lens = np.asarray([300_000, 1_200_000, 80_000], dtype=np.int64)
+    longb = _long_read_batch(ref_lens, 600, 4_000, seed=63)
+    for batch, lens in ((short, ref.lengths), (longb, ref_lens)):
+        n = batch.n_records
+        cut = n // 3
+        with Session(0, FilterConfig(), 75, want_hist=True, want_identity=True) as s:
+            s.set_targets(lens)
+            s.push(batch)
+            want = _finish_all(s)
+            want_depth = s.depth(1)
+        # whole batch adopted
+        t_all, n_all = _device_tensors(batch)
+        with Session(0, FilterConfig(), 75, want_hist=True, want_identity=True) as s:
+            s.set_targets(lens)
+            s.push_device(t_all, n_all)
+            got = _finish_all(s)
+            assert got[0].tobytes() == want[0].tobytes() and (got[1] == want[1]).all() and got[2] == want[2]
+            np.testing.assert_array_equal(s.depth(1), want_depth)
+        # a view that starts in the middle of the CIGAR array, followed by a host batch -> materialised, offsets rebased
+        t_tail, n_tail = _device_tensors(batch, cut, n)
+        with Session(0, FilterConfig(), 75, want_hist=True, want_identity=True) as s:
+            s.set_targets(lens)
+            s.push(batch.slice(0, cut))
+            s.push_device(t_tail, n_tail)
+            got = _finish_all(s)
+            assert got[0].tobytes() == want[0].tobytes() and (got[1] == want[1]).all() and got[2] == want[2]
+        t_head, n_head = _device_tensors(batch, 0, cut)
+        with Session(0, FilterConfig(), 75, want_hist=True, want_identity=True) as s:
+            s.set_targets(lens)
+            s.push_device(t_head, n_head)          # adopted ...
+            s.push(batch.slice(cut, n))            # ... then copied into the owned store in front of this one
+            got = _finish_all(s)
+            assert got[0].tobytes() == want[0].tobytes() and (got[1] == want[1]).all() and got[2] == want[2]
+        # adopted view alone: equals the host push of the same slice
+        with Session(0, FilterConfig(), 75, want_hist=True, want_identity=True) as s:
+            s.set_targets(lens)
+            s.push(batch.slice(cut, n))
+            w2 = _finish_all(s)
+        with Session(0, FilterConfig(), 75, want_hist=True, want_identity=True) as s:
+            s.set_targets(lens)
+            s.push_device(t_tail, n_tail)
+            g2 = _finish_all(s)
+            # record indices (first/last_record) are relative to the pushed batch in both cases
+            assert g2[0].tobytes() == w2[0].tobytes() and (g2[1] == w2[1]).all()
