@@ -202,6 +202,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": profile_traffic(dom),
                          "kernel_ms": kms[dom], "algorithmic_bytes": kbytes[dom],
                          "all_kernels_ms": kms,
+                         "note": "per-base depth lives only in LDS, so the dominant kernel's compulsory HBM bytes are ~0.4 GB "
+                                 "per launch and its HBM fraction is small by construction; it is bound by VALU issue (~55-60 % busy, "
+                                 "4 waves/SIMD) and dependent LDS round trips (DESIGN.md sections 4-5, profiles/r01g_*); "
+                                 "SURVEY 8d's arena-in-HBM byte count for the same job is reported as arena_design_equivalent",
                          "pipeline": {"algorithmic_bytes": pipe_bytes, "kernels_ms": pipe_ms,
                                       "achieved_GBps": pipe_bytes / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0},
                          "arena_design_equivalent": {"bytes": arena_bytes,
