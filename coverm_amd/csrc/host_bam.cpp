@@ -562,6 +562,7 @@ covh_bam *covh_bam_open(const char *path, int threads, int want_names, char *err
     h->b.path = path; h->b.threads = std::max(1, threads); h->b.want_names = want_names != 0;
     Buf raw;
     bool ok = read_file(path, raw, h->b.err);
+    if (ok && raw.size() == 0) { ok = false; h->b.err = std::string(path) + ": empty file (no BAM/SAM header)"; }   // htslib: sam_hdr_read fails
     t1 = now();
     if (ok) {
         if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {

@@ -118,3 +118,28 @@ def test_parallel_boundary_detection_matches_serial(tmp_path):
         assert many.qname == one.qname
     np.testing.assert_array_equal(one.records.pos, b.pos)
     np.testing.assert_array_equal(one.records.cigar, b.cigar)
+
+
+def test_malformed_inputs_are_errors_not_crashes(tmp_path):
+    """Truncated BGZF stream, truncated record, wrong magic, empty and missing files: an IOError with a message."""
+    from coverm_amd import bam as cbam
+    b = load_fixture("7seqs.reads_for_seq1_and_seq2.bam")
+    good = str(tmp_path / "good.bam")
+    bamio.write_bam(good, b, block=700)
+    raw = open(good, "rb").read()
+    cases = {
+        "missing": None,
+        "empty": b"",
+        "garbage": bytes(range(256)) * 8,
+        "cut_block": raw[:len(raw) // 2],                  # ends inside a BGZF block
+        "bad_crc": raw[:200] + bytes([raw[200] ^ 0xff]) + raw[201:],
+    }
+    for name, data in cases.items():
+        p = str(tmp_path / (name + ".bam"))
+        if data is not None:
+            open(p, "wb").write(data)
+        with pytest.raises(IOError) as ei:
+            cbam.read_alignment_file(p, threads=3)
+        assert str(ei.value), name
+    af = cbam.read_alignment_file(good, threads=2)
+    assert af.records.n_records == b.n_records
