@@ -770,6 +770,182 @@ def estimate_one(p: EstParam, ud: np.ndarray, n_reads=0, mismatches=0, sum_ident
                                         un.ctypes.data_as(C.c_void_p), C.c_uint64(len(un))))
 
 
+# ------------------------------------------------------------------ per-gene coverage (src/genes.rs)
+import re as _re
+
+_GFF_KEYS = ("ID", "locus_tag", "gene_id", "Name", "gene", "Parent")
+
+
+def _gff_attribute(attributes: str, key: str):  # genes.rs:144-161
+    for entry in attributes.split(";"):
+        entry = entry.strip()
+        if not entry:
+            continue
+        if entry.startswith(key + "="):
+            return entry[len(key) + 1:].strip()
+        if entry.startswith(key + " "):
+            return entry[len(key) + 1:].strip().strip('"')
+    return None
+
+
+def read_gff(path: str, feature_type: Optional[str] = None):
+    """GeneDefinitions::read_gff, genes.rs:42-126 -> list of (id, contig, start0, end0_exclusive)."""
+    genes, auto_id = [], 0
+    with open(path) as fh:
+        for line in fh.read().split("\n"):
+            trimmed = line.rstrip()
+            if not trimmed or trimmed.startswith("#"):
+                continue
+            f = trimmed.split("\t")
+            if len(f) < 8:
+                continue
+            if feature_type is not None and f[2] != feature_type:
+                continue
+            if not _re.fullmatch(r"\+?[0-9]+", f[3]) or not _re.fullmatch(r"\+?[0-9]+", f[4]):
+                continue
+            s1, e1 = int(f[3]), int(f[4])
+            if s1 >= 1 << 64 or e1 >= 1 << 64 or s1 == 0 or e1 < s1:
+                continue
+            attrs = f[8] if len(f) > 8 else ""
+            gid = None
+            for k in _GFF_KEYS:
+                v = _gff_attribute(attrs, k)
+                if v:
+                    gid = v
+                    break
+            if gid is None:
+                auto_id += 1
+                gid = "%s_gene_%d" % (f[0], auto_id)
+            genes.append((gid, f[0], s1 - 1, e1))
+    return genes
+
+
+def resolve_genes(genes, ref_names, ref_lens, genome_namer=None):
+    """resolve_genes_against_header, genes.rs:346-419 -> per-tid lists of [entry_id, display name, start, end]."""
+    name_to_tid = {}
+    for tid, n in enumerate(ref_names):
+        name_to_tid[n] = tid                      # HashMap::insert: a repeated name keeps the last tid
+    by_tid = [[] for _ in ref_names]
+    for gid, contig, start, end in genes:
+        tid = name_to_tid.get(contig)
+        if tid is None:
+            continue
+        L = int(ref_lens[tid])
+        s, e = min(start, L), min(end, L)
+        if s >= e:
+            continue
+        if genome_namer is not None:
+            g = genome_namer(contig)
+            if g is None:
+                continue
+            name = "%s\t%s\t%s" % (gid, contig, g)
+        else:
+            name = "%s\t%s" % (gid, contig)
+        by_tid[tid].append([0, name, s, e])
+    nxt = 0
+    for lst in by_tid:
+        lst.sort(key=lambda g: g[2])               # stable, like sort_by_key
+        for g in lst:
+            g[0] = nxt
+            nxt += 1
+    return by_tid
+
+
+def gene_coverage(bams: Sequence[BamData], stoit_names: Sequence[str], taker, estimators: Sequence[EstParam], genes,
+                  genome_namer, print_zero_coverage_genes: bool, flag_filters: FlagFilter,
+                  filter_params: Optional[FilterParameters] = None) -> List[ReadsMapped]:
+    """gene_coverage, genes.rs:182-344 (+ emit_genes_for_contig :462-552).  Depth deltas of a contig come from the C
+    restatement of the contig scan (same CIGAR walk, :258-290); per-gene estimator values from orc_estimate_one fed with
+    the gene's delta array exactly as :508-535 builds it."""
+    for e in estimators:
+        if e.kind == 2:
+            raise NotImplementedError("coverage_histogram with --gff is not restated")
+    out_rm = []
+    for b, name in zip(bams, stoit_names):
+        order, prim = reader_stage(b, filter_params)
+        taker.start_stoit(name)
+        by_tid = resolve_genes(genes, b.ref_names, b.ref_lens, genome_namer)
+        idx = np.arange(b.n_records) if order is None else np.asarray(order, dtype=np.int64)
+
+        def zero_genes(tid):
+            for eid, gname, s, e in by_tid[tid]:
+                taker.start_entry(eid, gname)
+                for p in estimators:
+                    taker.add_single_coverage(float(e - s) if p.kind == 8 else 0.0)   # print_zero_coverage, estimators.rs:971-991
+                taker.finish_entry()
+
+        def emit(tid, starts, is_prim, mism, ident):
+            glist = by_tid[tid]
+            if not glist:
+                return
+            ud = contig_deltas(b, flag_filters, tid, order)
+            L = len(ud)
+            cov = np.cumsum(ud, dtype=np.int32)
+            st = np.asarray(starts, dtype=np.uint64)
+            pp = np.concatenate([[0], np.cumsum(np.asarray(is_prim, dtype=np.uint64), dtype=np.uint64)])
+            pm = np.concatenate([[0], np.cumsum(np.asarray(mism, dtype=np.uint64), dtype=np.uint64)])
+            pi = np.concatenate([[0.0], np.add.accumulate(np.asarray(ident, dtype=np.float64))]) if len(ident) else np.zeros(1)
+            for eid, gname, s, e in glist:
+                e = min(e, L)
+                if s >= e:
+                    continue
+                gud = np.empty(e - s, dtype=np.int32)
+                gud[0] = cov[s]
+                gud[1:] = ud[s + 1:e]
+                lo = int(np.searchsorted(st, s, side="left")); hi = int(np.searchsorted(st, e, side="left"))
+                n_reads = int(pp[hi] - pp[lo]); mm = int(pm[hi] - pm[lo]); sid = float(pi[hi] - pi[lo])
+                covs = [estimate_one(p, gud, n_reads, mm, sid) for p in estimators]
+                if print_zero_coverage_genes or any(c > 0.0 for c in covs):
+                    taker.start_entry(eid, gname)
+                    for c in covs:
+                        taker.add_single_coverage(c)
+                    taker.finish_entry()
+
+        last_tid = -2
+        starts, is_prim, mism, ident = [], [], [], []
+        mapped_total = 0
+        ff = flag_filters
+
+        def previous(last, cur):
+            if last != -2:
+                emit(last, starts, is_prim, mism, ident)
+            if print_zero_coverage_genes:
+                t = 0 if last == -2 else last + 1
+                while t < cur:
+                    zero_genes(t)
+                    t += 1
+
+        for i in idx:
+            flag = int(b.flag[i])
+            if (not ff.include_secondary and flag & 0x100) or (not ff.include_supplementary and flag & 0x800) \
+                    or (not ff.include_improper_pairs and not flag & 0x2):
+                continue
+            if flag & 0x4:
+                continue
+            tid = int(b.tid[i])
+            if tid != last_tid:
+                if tid < last_tid:
+                    raise OracleError(1)
+                previous(last_tid, tid)
+                last_tid = tid
+                starts, is_prim, mism, ident = [], [], [], []
+            primary = not (flag & 0x900)
+            mapped_total += primary
+            c = b.cigar[b.cigar_off[i]:b.cigar_off[i + 1]]
+            op, ln = c & 15, (c >> 4).astype(np.int64)
+            aligned = int(ln[(op == 0) | (op == 7) | (op == 8) | (op == 2) | (op == 1)].sum())
+            indels = int(ln[(op == 2) | (op == 1)].sum())
+            if b.nm_kind[i] != 1:
+                raise OracleError(2 if b.nm_kind[i] == 0 else 3)
+            edit = int(b.nm[i])
+            starts.append(int(b.pos[i])); is_prim.append(1 if primary else 0)
+            mism.append(max(0, edit - indels))                                    # saturating_sub, :296
+            ident.append((float(aligned) - float(edit)) / float(aligned) if primary and aligned > 0 else 0.0)
+        previous(last_tid, len(b.ref_names))
+        out_rm.append(ReadsMapped(int(mapped_total), int(prim)))
+    return out_rm
+
+
 # ------------------------------------------------------------------ CLI-level driver (bin/coverm.rs)
 def read_genome_definition(path: str):
     """genome_parsing.rs:77-141: TSV genome<TAB>contig; returns (genomes, contig->genome index)."""
@@ -832,7 +1008,7 @@ def run_cli(mode: str, bam_paths: Sequence[str], methods: Sequence[str] = None, 
             min_read_aligned_percent=None, min_mapq=255, min_read_aligned_length_pair=0,
             min_read_percent_identity_pair=None, min_read_aligned_percent_pair=None,
             separator: Optional[str] = None, single_genome=False, genome_definition: Optional[str] = None,
-            bams: Optional[Sequence[BamData]] = None) -> str:
+            bams: Optional[Sequence[BamData]] = None, gff: Optional[str] = None, gff_feature_type: Optional[str] = None) -> str:
     """`coverm contig|genome --bam-files ...` restated end to end (bin/coverm.rs:56-407, 473-663)."""
     if methods is None:
         methods = ["mean"] if mode == "contig" else ["relative_abundance"]
@@ -855,11 +1031,25 @@ def run_cli(mode: str, bam_paths: Sequence[str], methods: Sequence[str] = None, 
     for i in et["columns_to_normalise"]:
         headers[i] = "Relative Abundance (%)"
     entry_type = "Contig" if mode == "contig" else "Genome"
+    if gff is not None:   # coverm.rs:511-518, 1557-1590
+        entry_type = "Gene\tContig" if mode == "contig" else "Gene\tContig\tGenome"
     print_headers(et["printer"], entry_type, headers, stream)
     if bams is None:
         bams = [bamio.read_alignment_file(p) for p in bam_paths]
     stoits = [os.path.splitext(os.path.basename(p))[0] for p in bam_paths]  # bam_generator.rs:358-365
-    if mode == "contig":
+    if gff is not None:
+        genes = read_gff(gff, gff_feature_type)
+        namer = None
+        if mode == "genome":
+            if single_genome:
+                namer = lambda c: "genome1"
+            elif separator is not None:
+                namer = lambda c: c.split(separator, 1)[0] if separator in c else None
+            else:
+                _g, c2g = read_genome_definition(genome_definition)
+                namer = lambda c: _g[c2g[c]] if c in c2g else None
+        rms = gene_coverage(bams, stoits, et["taker"], et["estimators"], genes, namer, not no_zeros, fp.flag_filters, fp)
+    elif mode == "contig":
         rms = contig_coverage(bams, stoits, et["taker"], et["estimators"], not no_zeros, fp.flag_filters, fp)
     elif separator is not None or single_genome:
         rms = genome_coverage_separator(bams, stoits, "0" if single_genome else separator, et["taker"],

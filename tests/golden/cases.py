@@ -392,5 +392,35 @@ CLI_CASES = [
          expected="Genome\t2seqs.bad_read.1.with_supplementary ANIr\ngenome1\t0.999\n"),
 ]
 
+# ---- per-gene coverage (--gff): genes.rs unit tests :621-766 and tests/test_cmdline.rs:134-206
+_G2 = [("gene_seq1", "seq1", 0, 1000), ("gene_seq2", "seq2", 0, 1000)]
+_B1 = "2seqs.reads_for_seq1"
+GENE_API_CASES = [
+    dict(id="genes_whole_contig_matches_contig_coverage", cite="genes.rs:649-684", bam=_B1 + ".bam", genes=_G2,
+         est=("mean", 0.0, 0, False), namer=None, print_zeros=True,
+         expected=_B1 + "\tgene_seq1\tseq1\t1.2\n" + _B1 + "\tgene_seq2\tseq2\t0\n"),
+    dict(id="genes_genome_namer_column", cite="genes.rs:686-723", bam=_B1 + ".bam", genes=_G2,
+         est=("mean", 0.0, 0, False), namer={"seq1": "genomeA"}, print_zeros=True,
+         expected=_B1 + "\tgene_seq1\tseq1\tgenomeA\t1.2\n"),
+    dict(id="genes_no_zeros", cite="genes.rs:725-749", bam=_B1 + ".bam", genes=_G2,
+         est=("mean", 0.0, 0, False), namer=None, print_zeros=False, expected=_B1 + "\tgene_seq1\tseq1\t1.2\n"),
+    dict(id="genes_count_method", cite="genes.rs:751-765", bam=_B1 + ".bam", genes=_G2[:1],
+         est=("count",), namer=None, print_zeros=False, expected=_B1 + "\tgene_seq1\tseq1\t12\n"),
+]
+GFF_PARSE_EXPECTED = [("gene1", "seq1", 0, 1000), ("gene2", "seq1", 99, 200), ("gene3", "seq2", 0, 1000)]   # genes.rs:621-647
+GENE_CLI_CASES = [
+    dict(id="cli_contig_per_gene_mean", cite="tests/test_cmdline.rs:134-158", mode="contig", bams=[_B1 + ".bam"],
+         args=dict(gff="2seqs.gff", methods=["mean"], contig_end_exclusion=0, output_format="sparse"), match="contains_all",
+         expected=["Sample\tGene\tContig\tMean", _B1 + "\tgene1\tseq1\t1.2", _B1 + "\tgene3\tseq2\t0"]),
+    dict(id="cli_contig_per_gene_count", cite="tests/test_cmdline.rs:160-179", mode="contig", bams=[_B1 + ".bam"],
+         args=dict(gff="2seqs.gff", methods=["count"], output_format="sparse", no_zeros=True), match="contains_all",
+         expected=[_B1 + "\tgene1\tseq1\t12"]),
+    dict(id="cli_genome_per_gene_mean", cite="tests/test_cmdline.rs:181-206", mode="genome", bams=[_B1 + ".bam"],
+         args=dict(gff="2seqs.gff", genome_definition="2seqs.genome-definition", methods=["mean"], contig_end_exclusion=0,
+                   min_covered_fraction=0, output_format="sparse"), match="contains_all",
+         expected=["Sample\tGene\tContig\tGenome\tMean", _B1 + "\tgene1\tseq1\tgenomeA\t1.2",
+                   _B1 + "\tgene3\tseq2\tgenomeB\t0"]),
+]
+
 FIXTURE_FILES = sorted({b for c in API_CASES for b in c["bams"]} | {c["bam"] for c in FILTER_CASES}
                        | {b for c in CLI_CASES for b in c["bams"]})

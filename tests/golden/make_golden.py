@@ -38,6 +38,17 @@ def main():
     with open(os.path.join(out, "7seqs.definition"), "w") as fh:
         for n in d.ref_names:
             fh.write("%s\t%s\n" % (n.split("~")[0], n))
+    # per-gene goldens (genes.rs:621-766, tests/test_cmdline.rs:134-206): three gene lines as the reference's
+    # tests/data/2seqs.gff describes them (gene1 = seq1:1-1000, gene2 = seq1:100-200, gene3 = seq2:1-1000, with a
+    # directive, a second attribute and a comment line, which the parser must skip) and the two-line genome definition
+    with open(os.path.join(out, "2seqs.gff"), "w") as fh:
+        fh.write("##gff-version 3\n"
+                 "seq1\ttest\tgene\t1\t1000\t.\t+\t.\tID=gene1;Name=first_gene\n"
+                 "seq1\ttest\tgene\t100\t200\t.\t-\t.\tID=gene2\n"
+                 "# a comment line that should be ignored\n"
+                 "seq2\ttest\tgene\t1\t1000\t.\t+\t.\tID=gene3\n")
+    with open(os.path.join(out, "2seqs.genome-definition"), "w") as fh:
+        fh.write("genomeA\tseq1\ngenomeB\tseq2\n")
 
 
 if __name__ == "__main__":

@@ -103,3 +103,36 @@ def test_rust_float_display():
     assert O.fmt_f32(0.0) == "0"
     assert O.fmt_f64(900000.0357627869) == "900000.0357627869"
     assert O.fmt_f32(np.float32(1e-7)) == "0.0000001"
+
+
+# ---- per-gene coverage (--gff)
+def test_oracle_gff_parsing():
+    assert O.read_gff(os.path.join(FIXDIR, "2seqs.gff")) == cases.GFF_PARSE_EXPECTED
+    assert O.read_gff(os.path.join(FIXDIR, "2seqs.gff"), "CDS") == []
+
+
+def _gene_est(spec):
+    return {"mean": lambda: O.est_mean(*spec[1:]), "count": lambda: O.est_read_count()}[spec[0]]()
+
+
+@pytest.mark.parametrize("case", cases.GENE_API_CASES, ids=[c["id"] for c in cases.GENE_API_CASES])
+def test_oracle_gene_api_golden(case):
+    import io
+    b = load_fixture(case["bam"])
+    out = io.StringIO()
+    namer = (lambda c: case["namer"].get(c)) if case["namer"] is not None else None
+    O.gene_coverage([b], [os.path.splitext(case["bam"])[0]], O.StreamingTaker(out), [_gene_est(case["est"])], case["genes"],
+                    namer, case["print_zeros"], O.FlagFilter(True, False, False))
+    assert out.getvalue() == case["expected"]
+
+
+@pytest.mark.parametrize("case", cases.GENE_CLI_CASES, ids=[c["id"] for c in cases.GENE_CLI_CASES])
+def test_oracle_gene_cli_golden(case):
+    bams = [load_fixture(b) for b in case["bams"]]
+    args = dict(case["args"])
+    for k in ("gff", "genome_definition"):
+        if k in args:
+            args[k] = os.path.join(FIXDIR, args[k])
+    out = O.run_cli(case["mode"], case["bams"], bams=bams, **args)
+    for e in case["expected"]:
+        assert e in out, out
