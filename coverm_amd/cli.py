@@ -215,6 +215,67 @@ def _select(r: RecordBatch, idx) -> RecordBatch:
                        cig.astype(np.uint32))
 
 
+def reader_stage(af: AlignmentFile, fp: FilterParameters):
+    """(records the scan sees, device FilterConfig, primary-alignment count if the host had to count it)."""
+    ff = fp.flag_filters
+    filt = FilterConfig(ff.include_improper_pairs, ff.include_supplementary, ff.include_secondary)
+    records, prim = af.records, None
+    if fp.doing_filtering():
+        fs, fpairs = fp.filter_mode()
+        if fs and not fpairs:
+            filt.filter_single = True
+            filt.min_mapq = fp.min_mapq
+            filt.min_aligned_length = fp.min_aligned_length_single
+            filt.min_percent_identity = fp.min_percent_identity_single
+            filt.min_aligned_percent = fp.min_aligned_percent_single
+        else:
+            prim = int(((records.flag & 0x900) == 0).sum())   # filter.rs:129-131, every record read
+            records = _select(records, pair_mode_order(af, fp))
+    return records, filt, prim
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def device_depth(af: AlignmentFile, records, filt, device: int = 0):
+    """Per-gene coverage: one finished session per BAM; yields (depth_of(tid), primary-alignment count, session cfg)."""
+    with Session(device, filt, 0, want_hist=False, want_identity=False) as s:
+        s.set_targets(af.ref_lens)
+        s.push(records)
+        stats, summ = s.finish()
+        yield s.depth, int(summ.num_detected_primary_alignments), s.cfg
+
+
+def _run_genes(mode, files, et, fp, contig_end_exclusion, gff, feature_type, separator, single_genome, genome_definition,
+               print_zeros, device, depth_provider):
+    """run_contig / run_genome with --gff (coverm.rs:1557-1590, 2099-2109)."""
+    for e in et.estimators:
+        if e.kind == 2:
+            raise SystemExit("coverage_histogram is not available per gene in this build")
+    genes = host.Genes.read_gff(gff, feature_type)
+    namer_mode, genomes, c2g = 0, None, None
+    if mode == "genome":
+        if single_genome:
+            namer_mode = 1
+        elif separator is not None:
+            namer_mode = 2
+        else:
+            if genome_definition is None:
+                raise SystemExit("A genome definition is required when using --gff in genome mode")
+            genomes, c2g = read_genome_definition(genome_definition)
+            namer_mode = 3
+    rms = []
+    for af in files:
+        records, filt, prim = reader_stage(af, fp)
+        g_of = np.asarray([c2g.get(n, -1) for n in af.ref_names], dtype=np.int32) if namer_mode == 3 else None
+        with depth_provider(af, records, filt, device) as (depth_of, prim_dev, cfg):
+            rms.append(host.gene_coverage(af.ref_names, af.ref_lens, genes, af.stoit_name, records, cfg, depth_of,
+                                          prim if prim is not None else prim_dev, et.taker, et.estimators, print_zeros,
+                                          namer_mode, separator or "~", g_of, genomes))
+    return rms
+
+
 def device_sample(af: AlignmentFile, fp: FilterParameters, contig_end_exclusion: int, want_hist: bool,
                   want_identity: bool, mask=None, device: int = 0) -> SampleResult:
     """One BAM through a covermhip session (the only provider used outside tests)."""
@@ -268,7 +329,8 @@ def run(mode: str, files: Sequence[AlignmentFile], methods: Optional[Sequence[st
         min_read_aligned_length_pair: int = 0, min_read_percent_identity_pair=None,
         min_read_aligned_percent_pair=None, separator: Optional[str] = None, single_genome: bool = False,
         genome_definition: Optional[str] = None, device: int = 0,
-        sample_provider: Callable[..., SampleResult] = device_sample) -> str:
+        sample_provider: Callable[..., SampleResult] = device_sample, gff: Optional[str] = None,
+        gff_feature_type: Optional[str] = None, depth_provider=None) -> str:
     """Runs `coverm <mode>` on decoded alignment files and returns what the reference prints to stdout."""
     if methods is None:
         methods = ["mean"] if mode == "contig" else ["relative_abundance"]   # cli.rs:2521, 2048
@@ -286,7 +348,15 @@ def run(mode: str, files: Sequence[AlignmentFile], methods: Optional[Sequence[st
         fp.flag_filters = FlagFilter(True, True, True)
     headers = et.headers()
     entry_type = "Contig" if mode == "contig" else "Genome"
+    if gff is not None:   # coverm.rs:511-518, 1557-1590
+        entry_type = "Gene\tContig" if mode == "contig" else "Gene\tContig\tGenome"
     host.print_headers(et.taker, et.printer, entry_type, headers)
+    if gff is not None:
+        rms = _run_genes(mode, files, et, fp, contig_end_exclusion, gff, gff_feature_type, separator, single_genome,
+                         genome_definition, not no_zeros, device, depth_provider or device_depth)
+        host.finalise_printing(et.taker, et.printer, entry_type, headers, rms, et.columns_to_normalise, et.rpkm_column,
+                               et.tpm_column)
+        return et.taker.text()
     want_hist, want_identity = host.wants(et.estimators)
     names, lens = files[0].ref_names, files[0].ref_lens
 

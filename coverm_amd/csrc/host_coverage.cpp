@@ -756,3 +756,291 @@ void covh_finalise_printing(covh_taker *t, int printer, const char *entry_type, 
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Per-gene coverage (--gff): src/genes.rs.  The pileup stays on the device (the depth of a contig comes through a
+// callback: cov_copy_depth in the product, the oracle's depth in CPU tests); what genes.rs adds on top of the contig
+// scan — GFF parsing (:42-161), gene resolution against the header (:346-419), per-gene window statistics over the
+// contig's depth (:508-535) and per-gene read aggregates by leftmost position (:521-526) — is this host code, feeding the
+// same calculate() / print_coverage() as the contig scan.
+namespace {
+
+struct GeneDef { std::string id, contig; u64 start, end; };
+
+bool parse_u64(const std::string &s, u64 &v) {   // Rust u64::from_str: optional '+', decimal digits, no overflow
+    size_t i = 0;
+    if (i < s.size() && s[i] == '+') i++;
+    if (i >= s.size()) return false;
+    u64 x = 0;
+    for (; i < s.size(); i++) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        const u64 d = (u64)(s[i] - '0');
+        if (x > (0xffffffffffffffffull - d) / 10) return false;
+        x = x * 10 + d;
+    }
+    v = x;
+    return true;
+}
+std::string trim(const std::string &s) {
+    size_t a = 0, b = s.size();
+    auto ws = [](unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); };
+    while (a < b && ws((unsigned char)s[a])) a++;
+    while (b > a && ws((unsigned char)s[b - 1])) b--;
+    return s.substr(a, b - a);
+}
+bool gff_attribute(const std::string &attrs, const std::string &key, std::string &out) {   // genes.rs:144-161
+    size_t p = 0;
+    while (p <= attrs.size()) {
+        size_t q = attrs.find(';', p);
+        if (q == std::string::npos) q = attrs.size();
+        const std::string entry = trim(attrs.substr(p, q - p));
+        if (!entry.empty()) {
+            if (entry.compare(0, key.size() + 1, key + "=") == 0) { out = trim(entry.substr(key.size() + 1)); return true; }
+            if (entry.compare(0, key.size() + 1, key + " ") == 0) {
+                std::string v = trim(entry.substr(key.size() + 1));
+                size_t a = 0, b = v.size();
+                while (a < b && v[a] == '"') a++;
+                while (b > a && v[b - 1] == '"') b--;
+                out = v.substr(a, b - a);
+                return true;
+            }
+        }
+        p = q + 1;
+    }
+    return false;
+}
+
+struct ResolvedGene { size_t entry_id; std::string name; u64 start, end; };
+
+}  // namespace
+
+struct covh_genes { std::vector<GeneDef> genes; };
+
+extern "C" {
+
+covh_genes *covh_genes_read_gff(const char *path, const char *feature_type, char *err, size_t errcap) {
+    FILE *fh = fopen(path, "rb");
+    if (!fh) {
+        if (err && errcap) snprintf(err, errcap, "Failed to open GFF file %s", path);
+        return nullptr;
+    }
+    std::string all;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, fh)) > 0) all.append(buf, n);
+    fclose(fh);
+    covh_genes *g = new covh_genes();
+    u64 auto_id = 0;
+    size_t p = 0;
+    while (p < all.size()) {
+        size_t q = all.find('\n', p);
+        if (q == std::string::npos) q = all.size();
+        std::string line = all.substr(p, q - p);
+        p = q + 1;
+        {   // trim_end
+            size_t b = line.size();
+            while (b > 0 && (line[b - 1] == ' ' || ((unsigned char)line[b - 1] >= 9 && (unsigned char)line[b - 1] <= 13))) b--;
+            line.resize(b);
+        }
+        if (line.empty() || line[0] == '#') continue;
+        std::vector<std::string> f;
+        for (size_t a = 0;;) {
+            const size_t t = line.find('\t', a);
+            if (t == std::string::npos) { f.push_back(line.substr(a)); break; }
+            f.push_back(line.substr(a, t - a));
+            a = t + 1;
+        }
+        if (f.size() < 8) continue;
+        if (feature_type && f[2] != feature_type) continue;
+        u64 s1, e1;
+        if (!parse_u64(f[3], s1) || !parse_u64(f[4], e1)) continue;
+        if (s1 == 0 || e1 < s1) continue;
+        const std::string attrs = f.size() > 8 ? f[8] : std::string();
+        std::string id;
+        bool have = false;
+        for (const char *k : {"ID", "locus_tag", "gene_id", "Name", "gene", "Parent"}) {
+            std::string v;
+            if (gff_attribute(attrs, k, v) && !v.empty()) { id = v; have = true; break; }
+        }
+        if (!have) { auto_id++; id = f[0] + "_gene_" + std::to_string(auto_id); }
+        g->genes.push_back(GeneDef{id, f[0], s1 - 1, e1});
+    }
+    return g;
+}
+
+covh_genes *covh_genes_from_arrays(const char *const *ids, const char *const *contigs, const uint64_t *start,
+                                   const uint64_t *end, size_t n) {
+    covh_genes *g = new covh_genes();
+    for (size_t i = 0; i < n; i++) g->genes.push_back(GeneDef{ids[i], contigs[i], start[i], end[i]});
+    return g;
+}
+size_t covh_genes_count(const covh_genes *g) { return g ? g->genes.size() : 0; }
+void covh_genes_get(const covh_genes *g, size_t i, const char **id, const char **contig, uint64_t *start, uint64_t *end) {
+    const GeneDef &d = g->genes[i];
+    if (id) *id = d.id.c_str();
+    if (contig) *contig = d.contig.c_str();
+    if (start) *start = d.start;
+    if (end) *end = d.end;
+}
+void covh_genes_free(covh_genes *g) { delete g; }
+
+int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh_genome_namer *namer, const char *stoit_name,
+                       const cov_batch *rec, const cov_config *cfg, covh_depth_fn depth_fn, void *depth_ctx,
+                       uint64_t num_detected_primary_alignments, covh_taker *taker, const covh_estimator *est, size_t n_est,
+                       int print_zero, covh_reads_mapped *rm_out) {
+    if (!h || !genes || !rec || !cfg || !depth_fn || !taker || (!est && n_est)) return COV_ERR_INVALID_ARG;
+    if (!check_excl(est, n_est)) { g_err = "estimators disagree on contig_end_exclusion"; return COV_ERR_INVALID_ARG; }
+    for (size_t k = 0; k < n_est; k++)
+        if (est[k].kind == COVH_PILEUP_COUNTS) { g_err = "coverage_histogram is not available per gene in this build"; return COV_ERR_INVALID_ARG; }
+    const u64 excl = session_excl(est, n_est);
+    const u64 zero = 0;
+    const u32 nT = h->n_targets;
+
+    // ---- resolve_genes_against_header, genes.rs:346-419
+    std::vector<std::vector<ResolvedGene>> by_tid(nT);
+    {
+        std::unordered_map<std::string_view, u32> name_to_tid;
+        name_to_tid.reserve(nT * 2);
+        for (u32 t = 0; t < nT; t++) name_to_tid[target_name(h, t)] = t;      // a repeated name keeps the last tid
+        for (const GeneDef &g : genes->genes) {
+            auto it = name_to_tid.find(std::string_view(g.contig));
+            if (it == name_to_tid.end()) continue;
+            const u32 tid = it->second;
+            const u64 L = h->target_len[tid];
+            const u64 s = std::min(g.start, L), e = std::min(g.end, L);
+            if (s >= e) continue;
+            std::string name = g.id + "\t" + g.contig;
+            if (namer && namer->mode != 0) {
+                if (namer->mode == 1) name += "\tgenome1";
+                else if (namer->mode == 2) {
+                    const size_t sp = g.contig.find((char)namer->separator);
+                    if (sp == std::string::npos) continue;
+                    name += "\t" + g.contig.substr(0, sp);
+                } else {
+                    const int32_t gi = namer->genome_of_tid ? namer->genome_of_tid[tid] : -1;
+                    if (gi < 0) continue;
+                    name += std::string("\t") + namer->genome_names[gi];
+                }
+            }
+            by_tid[tid].push_back(ResolvedGene{0, std::move(name), s, e});
+        }
+        size_t next_id = 0;
+        for (auto &v : by_tid) {
+            std::stable_sort(v.begin(), v.end(), [](const ResolvedGene &a, const ResolvedGene &b) { return a.start < b.start; });
+            for (auto &g : v) g.entry_id = next_id++;
+        }
+    }
+
+    taker->start_stoit(stoit_name);
+    auto zero_genes = [&](u32 tid) {   // emit_zero_coverage_genes, :554-567
+        for (const ResolvedGene &g : by_tid[tid]) {
+            taker->start_entry(g.entry_id, g.name);
+            for (size_t k = 0; k < n_est; k++) print_zero_coverage(est[k], *taker, g.end - g.start);
+            taker->finish_entry();
+        }
+    };
+
+    std::vector<u64> starts, pprim, pmism;
+    std::vector<double> pident;
+    std::vector<int32_t> depth;
+    std::vector<float> cov(n_est);
+    EntryAcc acc;
+    int rc_err = COV_OK;
+    auto emit = [&](u32 tid) {   // emit_genes_for_contig, :462-552
+        const auto &gl = by_tid[tid];
+        if (gl.empty()) return;
+        const u64 L = h->target_len[tid];
+        depth.resize((size_t)L);
+        const int rc = depth_fn(depth_ctx, tid, depth.data());
+        if (rc != COV_OK) { if (!rc_err) rc_err = rc; return; }
+        for (const ResolvedGene &g : gl) {
+            const u64 s = g.start, e = std::min(g.end, L);
+            if (s >= e) continue;
+            const u64 len = e - s;
+            acc.reset();
+            acc.full_len = len;
+            for (u64 p = s; p < e; p++) acc.full_covered += depth[p] > 0;
+            if (2 * excl < len) {                              // add_contig's window on the GENE's own array (:394-404)
+                acc.win_len = len - 2 * excl;
+                u32 mx = 0;
+                for (u64 p = s + excl; p < e - excl; p++) {
+                    const u32 d = (u32)depth[p];
+                    acc.win_sum_d += d; acc.win_sum_d2 += (u64)d * d; acc.win_covered += d > 0;
+                    acc.win_min_d = std::min(acc.win_min_d, d); mx = std::max(mx, d);
+                }
+                acc.hist.assign((size_t)mx + 1, 0);
+                for (u64 p = s + excl; p < e - excl; p++) acc.hist[(u32)depth[p]]++;
+            }
+            const size_t lo = std::lower_bound(starts.begin(), starts.end(), s) - starts.begin();
+            const size_t hi = std::lower_bound(starts.begin(), starts.end(), e) - starts.begin();
+            acc.n_reads = pprim[hi] - pprim[lo];
+            acc.mismatches = pmism[hi] - pmism[lo];
+            acc.sum_identity = pident[hi] - pident[lo];       // difference of the running f64 prefix sums, as :526 does
+            bool nonzero = false;
+            for (size_t k = 0; k < n_est; k++) { cov[k] = calculate(est[k], acc, &zero, 1); nonzero |= cov[k] > 0.0f; }
+            if (print_zero || nonzero) {
+                taker->start_entry(g.entry_id, g.name);
+                for (size_t k = 0; k < n_est; k++) print_coverage(est[k], acc, cov[k], *taker);
+                taker->finish_entry();
+            }
+        }
+    };
+    auto previous = [&](int64_t last, int64_t cur) {   // process_previous_genes, :421-460
+        if (last != -2) emit((u32)last);
+        if (print_zero) for (int64_t t = last == -2 ? 0 : last + 1; t < cur; t++) zero_genes((u32)t);
+    };
+
+    int64_t last_tid = -2;
+    u64 mapped_total = 0;
+    auto reset_contig = [&]() { starts.clear(); pprim.assign(1, 0); pmism.assign(1, 0); pident.assign(1, 0.0); };
+    reset_contig();
+    for (u64 i = 0; i < rec->n_records; i++) {
+        const u32 flag = rec->flag[i];
+        const bool supp = flag & 0x800u, sec = flag & 0x100u, unmapped = flag & 0x4u;
+        u64 aligned = 0, indels = 0;
+        auto walk = [&]() {
+            for (u32 c = rec->cigar_off[i]; c < rec->cigar_off[i + 1]; c++) {
+                const u32 op = rec->cigar[c] & 15u, len = rec->cigar[c] >> 4;
+                if (op == 0 || op == 7 || op == 8) aligned += len;
+                else if (op == 2 || op == 1) { aligned += len; indels += len; }
+            }
+        };
+        bool walked = false;
+        if (cfg->filter_single) {   // reader stage, single-read branch (filter.rs:88-116, 243-279), as k_prep applies it
+            if (unmapped || (!cfg->include_supplementary && supp) || (!cfg->include_secondary && sec)) continue;
+            if (cfg->min_mapq != 255 && (rec->mapq[i] < cfg->min_mapq || rec->mapq[i] == 255)) continue;
+            if (rec->nm_kind[i] != COV_NM_UNSIGNED) return rec->nm_kind[i] == COV_NM_ABSENT ? COV_ERR_NM_MISSING : COV_ERR_NM_BADTYPE;
+            walk(); walked = true;
+            const u32 al = (u32)aligned;
+            const float a = (float)al;
+            if (!(al >= cfg->min_aligned_length && a / (float)rec->l_seq[i] >= cfg->min_aligned_percent &&
+                  1.0f - (float)rec->nm[i] / a >= cfg->min_percent_identity)) continue;
+        }
+        if ((!cfg->include_secondary && sec) || (!cfg->include_supplementary && supp) || (!cfg->include_improper_pairs && !(flag & 0x2u))) continue;
+        if (unmapped) continue;
+        const int64_t tid = rec->tid[i];
+        if (tid != last_tid) {
+            if (tid < last_tid) { g_err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)"; return COV_ERR_UNSORTED; }
+            if (tid < 0 || (u64)tid >= nT) { g_err = "record refers to a reference id outside the header (Corrupt BAM file?)"; return COV_ERR_BAD_TID; }
+            previous(last_tid, tid);
+            if (rc_err) return rc_err;
+            last_tid = tid;
+            reset_contig();
+        }
+        const bool primary = !supp && !sec;
+        mapped_total += primary;
+        if (!walked) walk();
+        if (rec->nm_kind[i] != COV_NM_UNSIGNED) return rec->nm_kind[i] == COV_NM_ABSENT ? COV_ERR_NM_MISSING : COV_ERR_NM_BADTYPE;
+        const u64 edit = rec->nm[i];
+        starts.push_back((u64)(int64_t)rec->pos[i]);
+        pprim.push_back(pprim.back() + (primary ? 1 : 0));
+        pmism.push_back(pmism.back() + (edit > indels ? edit - indels : 0));      // saturating_sub, :296
+        pident.push_back(pident.back() + ((primary && aligned > 0) ? ((double)aligned - (double)edit) / (double)aligned : 0.0));
+    }
+    previous(last_tid, nT);
+    if (rc_err) return rc_err;
+    if (rm_out) { rm_out->num_mapped_reads = mapped_total; rm_out->num_reads = num_detected_primary_alignments; }
+    return COV_OK;
+}
+
+}  // extern "C"

@@ -64,28 +64,34 @@ class FilterConfig:
     min_aligned_percent: float = 0.0
 
 
+def make_config(device: int = 0, filt: Optional[FilterConfig] = None, contig_end_exclusion: int = 75,
+                want_hist: bool = False, want_identity=False) -> CovConfig:
+    """cov_config from a FilterConfig.  want_identity: False, True (both sums) or "primary" / "nonsupp"."""
+    filt = filt or FilterConfig()
+    cfg = CovConfig()
+    cfg.device = device
+    cfg.include_improper_pairs = int(filt.include_improper_pairs)
+    cfg.include_supplementary = int(filt.include_supplementary)
+    cfg.include_secondary = int(filt.include_secondary)
+    cfg.filter_single = int(filt.filter_single)
+    cfg.min_mapq = filt.min_mapq
+    cfg.min_aligned_length = filt.min_aligned_length
+    cfg.min_percent_identity = filt.min_percent_identity
+    cfg.min_aligned_percent = filt.min_aligned_percent
+    cfg.contig_end_exclusion = contig_end_exclusion
+    cfg.want = (native.WANT_HIST if want_hist else 0) | (native.WANT_IDENTITY if want_identity else 0)
+    if want_identity == "primary":
+        cfg.want |= native.WANT_IDENTITY_PRIMARY_ONLY
+    elif want_identity == "nonsupp":
+        cfg.want |= native.WANT_IDENTITY_NONSUPP_ONLY
+    return cfg
+
+
 class Session:
     def __init__(self, device: int = 0, filt: Optional[FilterConfig] = None, contig_end_exclusion: int = 75,
                  want_hist: bool = False, want_identity: bool = False):
         self._lib = native.lib()
-        filt = filt or FilterConfig()
-        cfg = CovConfig()
-        cfg.device = device
-        cfg.include_improper_pairs = int(filt.include_improper_pairs)
-        cfg.include_supplementary = int(filt.include_supplementary)
-        cfg.include_secondary = int(filt.include_secondary)
-        cfg.filter_single = int(filt.filter_single)
-        cfg.min_mapq = filt.min_mapq
-        cfg.min_aligned_length = filt.min_aligned_length
-        cfg.min_percent_identity = filt.min_percent_identity
-        cfg.min_aligned_percent = filt.min_aligned_percent
-        cfg.contig_end_exclusion = contig_end_exclusion
-        # want_identity: False, True (both sums) or "primary" / "nonsupp" (only the one a given scan loop uses)
-        cfg.want = (native.WANT_HIST if want_hist else 0) | (native.WANT_IDENTITY if want_identity else 0)
-        if want_identity == "primary":
-            cfg.want |= native.WANT_IDENTITY_PRIMARY_ONLY
-        elif want_identity == "nonsupp":
-            cfg.want |= native.WANT_IDENTITY_NONSUPP_ONLY
+        cfg = make_config(device, filt, contig_end_exclusion, want_hist, want_identity)
         self.cfg = cfg
         self._h = C.c_void_p()
         st = self._lib.cov_create(C.byref(cfg), C.byref(self._h))

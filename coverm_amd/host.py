@@ -333,3 +333,114 @@ def finalise_printing(taker: CoverageTaker, printer: int, entry_type: str, heade
                                   C.c_size_t(len(columns_to_normalise)),
                                   C.c_int64(-1 if rpkm_column is None else rpkm_column),
                                   C.c_int64(-1 if tpm_column is None else tpm_column))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Per-gene coverage (--gff; src/genes.rs) through covh_gene_coverage.
+_DEPTH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32))
+
+
+class _GenomeNamer(C.Structure):   # covh_genome_namer
+    _fields_ = [("mode", C.c_int32), ("separator", C.c_uint8), ("genome_of_tid", C.c_void_p),
+                ("genome_names", C.POINTER(C.c_char_p))]
+
+
+class Genes:
+    """GeneDefinitions (genes.rs:28-32): parsed from a GFF/GTF file or given explicitly (0-based half-open)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def read_gff(path: str, feature_type: Optional[str] = None) -> "Genes":
+        L = _lib()
+        L.covh_genes_read_gff.restype = C.c_void_p
+        L.covh_genes_read_gff.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        err = C.create_string_buffer(512)
+        h = L.covh_genes_read_gff(path.encode(), feature_type.encode() if feature_type is not None else None, err, 512)
+        if not h:
+            raise IOError(err.value.decode())
+        return Genes(h)
+
+    @staticmethod
+    def from_list(genes) -> "Genes":
+        L = _lib()
+        L.covh_genes_from_arrays.restype = C.c_void_p
+        n = len(genes)
+        ids = (C.c_char_p * max(1, n))(*[g[0].encode() for g in genes])
+        ctg = (C.c_char_p * max(1, n))(*[g[1].encode() for g in genes])
+        st = np.asarray([g[2] for g in genes], dtype=np.uint64)
+        en = np.asarray([g[3] for g in genes], dtype=np.uint64)
+        L.covh_genes_from_arrays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        return Genes(L.covh_genes_from_arrays(ids, ctg, st.ctypes.data, en.ctypes.data, n))
+
+    def as_list(self):
+        L = _lib()
+        L.covh_genes_count.restype = C.c_size_t
+        L.covh_genes_count.argtypes = [C.c_void_p]
+        L.covh_genes_get.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        out = []
+        for i in range(L.covh_genes_count(self._h)):
+            a, b, s, e = C.c_char_p(), C.c_char_p(), C.c_uint64(), C.c_uint64()
+            L.covh_genes_get(self._h, i, C.byref(a), C.byref(b), C.byref(s), C.byref(e))
+            out.append((a.value.decode(), b.value.decode(), int(s.value), int(e.value)))
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                L = _lib()
+                L.covh_genes_free.argtypes = [C.c_void_p]
+                L.covh_genes_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def gene_coverage(names, target_len, genes: Genes, stoit_name: str, records, cfg, depth_of, num_detected_primary: int,
+                  coverage_taker: CoverageTaker, coverage_estimators, print_zero_coverage_genes: bool,
+                  namer_mode: int = 0, separator: str = "~", genome_of_tid=None, genome_names=None) -> ReadsMapped:
+    """genes.rs:182-344 for one BAM.  `records`: engine.RecordBatch the scan sees; `cfg`: native.CovConfig (flag filter,
+    single-read thresholds); `depth_of(tid)` returns the contig's int32 depth (Session.depth in the product)."""
+    from .native import CovBatch
+    L = _lib()
+    h, k1 = _header(names, target_len)
+    cb = CovBatch()
+    for k in ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar"):
+        a = getattr(records, k)
+        setattr(cb, k, a.ctypes.data if a.size else None)
+    cb.n_records = records.n_records
+    errs = []
+
+    def _depth(ctx, tid, out):
+        try:
+            d = np.ascontiguousarray(depth_of(int(tid)), dtype=np.int32)
+            C.memmove(out, d.ctypes.data, d.nbytes)
+            return 0
+        except Exception as e:   # reported by the caller
+            errs.append(e)
+            return 18
+    cbk = _DEPTH_FN(_depth)
+    nm = _GenomeNamer()
+    nm.mode = namer_mode
+    nm.separator = ord(separator) if separator else 0
+    keep = None
+    if namer_mode == 3:
+        g = np.ascontiguousarray(genome_of_tid, dtype=np.int32)
+        gn = (C.c_char_p * max(1, len(genome_names)))(*[x.encode() for x in genome_names])
+        nm.genome_of_tid = g.ctypes.data
+        nm.genome_names = gn
+        keep = (g, gn)
+    rm = _ReadsMapped()
+    L.covh_gene_coverage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, _DEPTH_FN,
+                                     C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    rc = L.covh_gene_coverage(C.byref(h), genes._h, C.byref(nm), stoit_name.encode(), C.byref(cb), C.byref(cfg), cbk, None,
+                              int(num_detected_primary), coverage_taker._h, _est_array(coverage_estimators),
+                              len(coverage_estimators), int(print_zero_coverage_genes), C.byref(rm))
+    del keep
+    if errs:
+        raise errs[0]
+    if rc:
+        raise HostError(rc, _lib().covh_last_error().decode())
+    return ReadsMapped(int(rm.num_mapped_reads), int(rm.num_reads))

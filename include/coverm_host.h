@@ -169,6 +169,30 @@ void covh_free(void *p);
 int covh_batch_select(const cov_batch *src, const uint64_t *order, uint64_t n, int threads, cov_batch *out);
 void covh_batch_free(cov_batch *b);
 
+/* ---- per-gene coverage (--gff; src/genes.rs:182-567).  The contig's depth comes through a callback (cov_copy_depth of a
+ * finished session in the product); GFF parsing, gene resolution, per-gene window statistics and per-gene read aggregates
+ * (reads are assigned to the gene their leftmost position falls in) are this host code.  One call per BAM. */
+typedef struct covh_genes covh_genes;
+covh_genes *covh_genes_read_gff(const char *path, const char *feature_type /* NULL = every feature */, char *err, size_t errcap);
+covh_genes *covh_genes_from_arrays(const char *const *ids, const char *const *contigs, const uint64_t *start,
+                                   const uint64_t *end, size_t n); /* 0-based half-open */
+size_t covh_genes_count(const covh_genes *g);
+void covh_genes_get(const covh_genes *g, size_t i, const char **id, const char **contig, uint64_t *start, uint64_t *end);
+void covh_genes_free(covh_genes *g);
+typedef int (*covh_depth_fn)(void *ctx, uint32_t tid, int32_t *depth_out); /* target_len[tid] entries; COV_OK or a status */
+typedef struct {
+    int32_t mode; /* 0 no genome column (contig mode), 1 single genome "genome1", 2 prefix before `separator`, 3 table */
+    uint8_t separator;
+    const int32_t *genome_of_tid;    /* mode 3: -1 = contig in no genome (its genes are not reported) */
+    const char *const *genome_names; /* mode 3 */
+} covh_genome_namer;
+/* records = what the scan sees (after a pair-mode reader stage, if any); cfg carries the flag filter, the single-read
+ * thresholds (filter_single) and nothing else that matters here; num_detected_primary_alignments as the reader counted it. */
+int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh_genome_namer *namer, const char *stoit_name,
+                       const cov_batch *records, const cov_config *cfg, covh_depth_fn depth, void *depth_ctx,
+                       uint64_t num_detected_primary_alignments, covh_taker *taker, const covh_estimator *est, size_t n_est,
+                       int print_zero_coverage_genes, covh_reads_mapped *reads_mapped_out);
+
 /* calculate_coverage for one entry built from explicit sums (used by unit tests). */
 typedef struct {
     uint64_t win_len, win_sum_d, win_sum_d2, win_covered, full_len, full_covered, n_reads, mismatches;
