@@ -37,7 +37,8 @@ struct Args {
     std::vector<std::string> bams, methods;
     const char *min_covered_fraction = nullptr, *trim_min = "5", *trim_max = "95";
     uint64_t contig_end_exclusion = 75;
-    std::string output_format = "dense", output_file, genome_definition;
+    std::string output_format = "dense", output_file, genome_definition, gff, gff_feature_type;
+    bool have_gff_feature_type = false;
     bool no_zeros = false, proper_pairs_only = false, exclude_supplementary = false, include_secondary = false;
     bool single_genome = false, have_separator = false;
     char separator = '~';
@@ -106,6 +107,8 @@ int main(int argc, char **argv) {
         else if (k == "-s" || k == "--separator") { a.separator = val()[0]; a.have_separator = true; }
         else if (k == "--single-genome") a.single_genome = true;
         else if (k == "--genome-definition") a.genome_definition = val();
+        else if (k == "--gff") a.gff = val();
+        else if (k == "--gff-feature-type") { a.gff_feature_type = val(); a.have_gff_feature_type = true; }
         else if (k == "-t" || k == "--threads") a.threads = atoi(val());
         else if (k == "--device") a.device = atoi(val());
         else die("unknown argument " + k);
@@ -178,9 +181,18 @@ int main(int argc, char **argv) {
     std::vector<const char *> hptr;
     for (auto &h : headers) hptr.push_back(h.c_str());
     const char *entry_type = contig ? "Contig" : "Genome";
+    const bool per_gene = !a.gff.empty();                           // coverm.rs:488-518, 1557-1590
+    if (per_gene) entry_type = contig ? "Gene\tContig" : "Gene\tContig\tGenome";
     covh_taker *taker = covh_taker_new(taker_kind, est.size());
     covh_print_headers(taker, printer, entry_type, hptr.data(), hptr.size());
 
+    covh_genes *genes = nullptr;
+    if (per_gene) {
+        if (a.methods.size() == 1 && a.methods[0] == "metabat") die("The metabat method cannot be used with --gff");
+        char gerr[512] = {0};
+        genes = covh_genes_read_gff(a.gff.c_str(), a.have_gff_feature_type ? a.gff_feature_type.c_str() : nullptr, gerr, sizeof gerr);
+        if (!genes) die(gerr);
+    }
     // ---- genome definition
     std::vector<std::string> genomes;
     std::unordered_map<std::string, int32_t> c2g;
@@ -210,6 +222,7 @@ int main(int argc, char **argv) {
     if (want & COV_WANT_IDENTITY)   // contig.rs:208 / genome.rs:724 use the primary-read sum, genome.rs:220 the not-supplementary one
         want |= by_names ? COV_WANT_IDENTITY_NONSUPP_ONLY : COV_WANT_IDENTITY_PRIMARY_ONLY;
     std::vector<Sample> samples(a.bams.size());
+    std::vector<covh_reads_mapped> gene_rm;
     std::string names_blob; std::vector<uint32_t> name_off; std::vector<uint64_t> tlen;
     std::vector<int32_t> genome_of_tid;
     bool fs = false, fp = false;
@@ -307,6 +320,23 @@ int main(int argc, char **argv) {
         check(s, cov_finish(s, S.stats.data(), &summ));
         if (want & COV_WANT_HIST) { S.hist.resize(summ.hist_total); check(s, cov_fetch_hist(s, S.hist.data())); }
         if (!prim_from_host) S.prim = summ.num_detected_primary_alignments;
+        if (per_gene) {   // genes.rs:182-344: per-gene reductions over this sample's depth, while the session holds it
+            covh_header gh; gh.n_targets = nt; gh.names = names_blob.c_str(); gh.name_off = name_off.data(); gh.target_len = tlen.data();
+            covh_genome_namer nm; memset(&nm, 0, sizeof nm);
+            std::vector<const char *> gn;
+            for (auto &g : genomes) gn.push_back(g.c_str());
+            if (!contig) {
+                nm.mode = a.single_genome ? 1 : a.have_separator ? 2 : 3;
+                nm.separator = (uint8_t)a.separator;
+                nm.genome_of_tid = genome_of_tid.data(); nm.genome_names = gn.data();
+            }
+            gene_rm.resize(a.bams.size());
+            auto depth_cb = [](void *ctx, uint32_t tid, int32_t *out) -> int { return (int)cov_copy_depth((cov_session *)ctx, tid, out); };
+            const int grc = covh_gene_coverage(&gh, genes, &nm, S.stoit.c_str(), &batch, &cfg, depth_cb, s, S.prim, taker, est.data(),
+                                               est.size(), !a.no_zeros, &gene_rm[bi]);
+            if (grc == COV_ERR_HIP || grc == COV_ERR_STATE) die(cov_last_error(s));
+            if (grc != COV_OK) die(covh_last_error());
+        }
         const double tw4 = now();
         if (have_selected) covh_batch_free(&selected);
         covh_bam_close(bam);
@@ -327,7 +357,8 @@ int main(int argc, char **argv) {
     }
     std::vector<covh_reads_mapped> rm(samples.size());
     int rc;
-    if (contig) rc = covh_contig_coverage(&hdr, hs.data(), hs.size(), taker, est.data(), est.size(), !a.no_zeros, rm.data());
+    if (per_gene) { rm = gene_rm; rc = COV_OK; }
+    else if (contig) rc = covh_contig_coverage(&hdr, hs.data(), hs.size(), taker, est.data(), est.size(), !a.no_zeros, rm.data());
     else if (a.have_separator || a.single_genome)
         rc = covh_genome_coverage_separator(&hdr, hs.data(), hs.size(), (uint8_t)(a.single_genome ? '0' : a.separator), taker,
                                             !a.no_zeros, est.data(), est.size(), a.single_genome, rm.data());

@@ -97,3 +97,30 @@ def test_cli_binary_multi_sample_pipeline(tmp_path):
     r = subprocess.run([BIN, "contig", "-b", paths[0], str(tmp_path / "absent.bam"), paths[1], "-m", "mean"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "absent.bam" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", cases.GENE_CLI_CASES, ids=[c["id"] for c in cases.GENE_CLI_CASES])
+def test_cli_binary_per_gene_golden(case, tmp_path):
+    """--gff through the standalone binary (C++ GFF parser + gene driver over cov_copy_depth); text == the oracle's."""
+    from oracle import oracle as O
+    paths = []
+    for b in case["bams"]:
+        p = str(tmp_path / (os.path.splitext(b)[0] + ".bam"))
+        bamio.write_bam(p, load_fixture(b), block=3000)
+        paths.append(p)
+    a = dict(case["args"])
+    v = [BIN, case["mode"], "-b"] + paths + ["--gff", os.path.join(FIXDIR, a["gff"]), "-m"] + list(a["methods"])
+    if "output_format" in a: v += ["--output-format", a["output_format"]]
+    if "contig_end_exclusion" in a: v += ["--contig-end-exclusion", str(a["contig_end_exclusion"])]
+    if "min_covered_fraction" in a: v += ["--min-covered-fraction", str(a["min_covered_fraction"])]
+    if a.get("no_zeros"): v += ["--no-zeros"]
+    if "genome_definition" in a: v += ["--genome-definition", os.path.join(FIXDIR, a["genome_definition"])]
+    r = subprocess.run(v, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for e in case["expected"]:
+        assert e in r.stdout, r.stdout
+    oa = dict(a)
+    for k in ("gff", "genome_definition"):
+        if k in oa: oa[k] = os.path.join(FIXDIR, oa[k])
+    assert r.stdout == O.run_cli(case["mode"], case["bams"], bams=[load_fixture(b) for b in case["bams"]], **oa)
