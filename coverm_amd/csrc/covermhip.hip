@@ -78,6 +78,7 @@ struct cov_session {
     uint32_t tile_shift = 10;
     DevBuf<u32> d_cx_list, d_cx_cnt, d_cx_cur, d_cx_scan, d_cx_top;   // CxIdx: long-CIGAR buckets
     DevBuf<uint2> d_cx_runs;
+    DevBuf<DevContig> d_ctg_scratch;   // cov_copy_depth works on a copy of the accumulators
     DevBuf<uint8_t> d_mask;
     bool have_mask = false;
     DevBuf<DevContig> d_ctg;
@@ -318,6 +319,7 @@ void cov_destroy(cov_session *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->d_tlen.release(); s->d_tile_contig.release(); s->d_tile_start.release(); s->d_mask.release();
     s->d_tile_first.release(); s->d_tcnt.release(); s->d_fov.release(); s->d_tscan.release(); s->d_ttop.release();
+    s->d_ctg_scratch.release();
     s->d_cx_list.release(); s->d_cx_cnt.release(); s->d_cx_cur.release(); s->d_cx_scan.release(); s->d_cx_top.release(); s->d_cx_runs.release();
     s->d_ctg.release(); s->d_glob.release(); s->d_desc.release();
     if (s->h_res) (void)hipHostFree(s->h_res);
@@ -687,7 +689,7 @@ cov_status cov_copy_depth(cov_session *s, uint32_t tid, int32_t *depth_out) {
     HIPCHK(hipMemsetAsync(s->d_depth.p, 0, (size_t)L * 4, s->stream));
     PileupArgs a = pileup_args(s);
     // depth materialisation must not disturb the accumulated statistics: run against a scratch copy
-    DevBuf<DevContig> scratch;
+    DevBuf<DevContig> &scratch = s->d_ctg_scratch;   // kept for the next call: per-gene coverage asks for every contig
     HIPCHK(scratch.reserve(s->n_targets, s->stream));
     HIPCHK(hipMemcpyAsync(scratch.p, s->d_ctg.p, (size_t)s->n_targets * sizeof(DevContig), hipMemcpyDeviceToDevice, s->stream));
     a.ctg = scratch.p;
@@ -699,7 +701,6 @@ cov_status cov_copy_depth(cov_session *s, uint32_t tid, int32_t *depth_out) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(depth_out, s->d_depth.p, (size_t)L * 4, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    scratch.release();
     return COV_OK;
 }
 

@@ -23,6 +23,7 @@ ap.add_argument("--contigs", type=int, default=1000)
 ap.add_argument("--bp", type=int, default=200_000_000)
 ap.add_argument("--threads", type=int, default=32)
 ap.add_argument("--cpu", type=int, default=1)
+ap.add_argument("--genes", type=int, default=0, help="also time --gff with one gene per this many bases")
 ap.add_argument("--samples", type=int, default=0, help="also time N lean BAMs -> one dense table (config 4 shape)")
 a = ap.parse_args()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,6 +57,26 @@ for with_seq in (True, False):
           "coverm-amd binary wall %.2fs = %.2f M reads/s end-to-end" % (
               "full-SEQ" if with_seq else "lean", size / 1e9, tw, a.threads, td, a.reads / td / 1e6, tg, tb,
               int(summ.n_considered) / tb / 1e6), flush=True)
+if a.genes:
+    gff = os.path.join(tmp, "genes.gff")
+    rng = np.random.default_rng(7)
+    with open(gff, "w") as fh:
+        ng = 0
+        for name, L in zip(ref.names, ref.lengths):
+            p0 = 1
+            while p0 + 300 < L:
+                ln = int(rng.integers(300, 2 * a.genes - 300))
+                e0 = min(int(L), p0 + ln)
+                fh.write("%s\tsyn\tCDS\t%d\t%d\t.\t+\t0\tID=g%d\n" % (name, p0, e0, ng))
+                ng += 1
+                p0 = e0 + int(rng.integers(1, 200))
+    path = os.path.join(tmp, "synth_lean.bam")
+    t = time.time()
+    r = subprocess.run([BIN, "contig", "-b", path, "--gff", gff, "-m", "mean", "covered_fraction", "count", "-t", str(a.threads),
+                        "-o", os.path.join(tmp, "genes.tsv")], capture_output=True, text=True)
+    tb = time.time() - t
+    assert r.returncode == 0, r.stderr
+    print("per-gene: %d genes over %d contigs, lean BAM: coverm-amd --gff wall %.2fs" % (ng, len(ref.names), tb), flush=True)
 if a.samples:
     paths = []
     for k in range(a.samples):
