@@ -111,6 +111,7 @@ int main(int argc, char **argv) {
         else if (k == "--gff-feature-type") { a.gff_feature_type = val(); a.have_gff_feature_type = true; }
         else if (k == "-t" || k == "--threads") a.threads = atoi(val());
         else if (k == "--device") a.device = atoi(val());
+        else if (k == "-v" || k == "--verbose" || k == "-q" || k == "--quiet") {}   // logging verbosity: nothing to tune here
         else die("unknown argument " + k);
     }
     if (a.bams.empty()) die("--bam-files is required (read mapping is out of scope for this engine)");
