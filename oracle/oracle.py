@@ -10,6 +10,7 @@ loops and estimators) and restates the small CPU-only layers around it in Python
   * method-name -> estimator construction  bin/coverm.rs:1315-1504
   * FilterParameters / parse_percentage    bin/coverm.rs:1296-1312, 1648-1704
   * genome definition TSV                  genome_parsing.rs:77-141
+  * per-gene coverage (--gff)              genes.rs:42-567
 
 Floats are formatted like Rust's `Display` for f32/f64 (shortest round-trip, positional).
 """

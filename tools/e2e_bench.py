@@ -1,7 +1,8 @@
 """End-to-end timing: synthetic BAM on disk -> `coverm-amd contig` (C++ reader + GPU engine) vs CPU oracle.
 
 Reports (i) BAM decode time (C++ reader, t threads), (ii) H2D + device pipeline, (iii) whole binary wall time,
-(iv) the CPU oracle scan on the already-decoded records.  Used for DESIGN.md's end-to-end table; not the bench.
+
+Used for DESIGN.md's end-to-end table; not the bench.  (The CPU port is timed only by bench.py's cpu_baseline leg.)
 """
 import argparse
 import os
@@ -22,7 +23,7 @@ ap.add_argument("--reads", type=int, default=10_000_000)
 ap.add_argument("--contigs", type=int, default=1000)
 ap.add_argument("--bp", type=int, default=200_000_000)
 ap.add_argument("--threads", type=int, default=32)
-ap.add_argument("--cpu", type=int, default=1)
+ap.add_argument("--cpu", type=int, default=0, help="unused (the CPU port is timed by bench.py's cpu_baseline leg only)")
 ap.add_argument("--genes", type=int, default=0, help="also time --gff with one gene per this many bases")
 ap.add_argument("--samples", type=int, default=0, help="also time N lean BAMs -> one dense table (config 4 shape)")
 a = ap.parse_args()
@@ -92,17 +93,3 @@ if a.samples:
     sys.stderr.write(r.stderr)
     print("%d full-SEQ BAMs x %d reads -> dense table: coverm-amd wall %.2fs = %.2f M reads/s end-to-end" % (
         a.samples, a.reads, tb, a.samples * a.reads / tb / 1e6), flush=True)
-if a.cpu:
-    from oracle import oracle as O
-    from oracle.bamio import BamData
-    import ctypes as C
-    z = np.zeros(batch.n_records, np.int32)
-    b = BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq, batch.l_seq.astype(np.int32),
-                batch.nm, batch.nm_kind, batch.cigar_off, batch.cigar, z, z, z, [], "")
-    est = [O.est_mean(0.0, 75, False), O.est_trimmed_mean(0.05, 0.95, 0.0, 75), O.est_covered_fraction(0.0),
-           O.est_variance(0.0, 75)]
-    import io
-    t = time.time()
-    O.contig_coverage([b], ["s"], O.StreamingTaker(io.StringIO()), est, True, O.FlagFilter(True, True, False))
-    print("CPU oracle scan+estimators on decoded records: %.2fs = %.1f M reads/s (1 thread)" % (
-        time.time() - t, a.reads / (time.time() - t) / 1e6))
