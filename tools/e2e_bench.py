@@ -1,4 +1,4 @@
-"""End-to-end timing: synthetic BAM on disk -> `coverm-amd contig` (C++ reader + GPU engine) vs CPU oracle.
+"""End-to-end timing: synthetic BAM on disk -> `coverm-amd contig` (C++ reader + GPU engine).
 
 Reports (i) BAM decode time (C++ reader, t threads), (ii) H2D + device pipeline, (iii) whole binary wall time,
 
