@@ -244,7 +244,7 @@ def device_depth(af: AlignmentFile, records, filt, device: int = 0):
         s.set_targets(af.ref_lens)
         s.push(records)
         stats, summ = s.finish()
-        yield s.depth, int(summ.num_detected_primary_alignments), s.cfg
+        yield s.depth, int(summ.num_detected_primary_alignments), s.cfg, (None if os.environ.get("COVERM_GENES_ON_HOST") else s)
 
 
 def _run_genes(mode, files, et, fp, contig_end_exclusion, gff, feature_type, separator, single_genome, genome_definition,
@@ -269,10 +269,11 @@ def _run_genes(mode, files, et, fp, contig_end_exclusion, gff, feature_type, sep
     for af in files:
         records, filt, prim = reader_stage(af, fp)
         g_of = np.asarray([c2g.get(n, -1) for n in af.ref_names], dtype=np.int32) if namer_mode == 3 else None
-        with depth_provider(af, records, filt, device) as (depth_of, prim_dev, cfg):
+        with depth_provider(af, records, filt, device) as prov:
+            depth_of, prim_dev, cfg = prov[:3]
             rms.append(host.gene_coverage(af.ref_names, af.ref_lens, genes, af.stoit_name, records, cfg, depth_of,
                                           prim if prim is not None else prim_dev, et.taker, et.estimators, print_zeros,
-                                          namer_mode, separator or "~", g_of, genomes))
+                                          namer_mode, separator or "~", g_of, genomes, prov[3] if len(prov) > 3 else None))
     return rms
 
 

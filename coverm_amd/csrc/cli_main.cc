@@ -333,7 +333,7 @@ int main(int argc, char **argv) {
             }
             gene_rm.resize(a.bams.size());
             auto depth_cb = [](void *ctx, uint32_t tid, int32_t *out) -> int { return (int)cov_copy_depth((cov_session *)ctx, tid, out); };
-            const int grc = covh_gene_coverage(&gh, genes, &nm, S.stoit.c_str(), &batch, &cfg, depth_cb, s, S.prim, taker, est.data(),
+            const int grc = covh_gene_coverage(&gh, genes, &nm, S.stoit.c_str(), &batch, &cfg, getenv("COVERM_GENES_ON_HOST") ? nullptr : s, depth_cb, s, S.prim, taker, est.data(),
                                                est.size(), !a.no_zeros, &gene_rm[bi]);
             if (grc == COV_ERR_HIP || grc == COV_ERR_STATE) die(cov_last_error(s));
             if (grc != COV_OK) die(covh_last_error());

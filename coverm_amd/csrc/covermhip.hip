@@ -79,6 +79,9 @@ struct cov_session {
     DevBuf<u32> d_cx_list, d_cx_cnt, d_cx_cur, d_cx_scan, d_cx_top;   // CxIdx: long-CIGAR buckets
     DevBuf<uint2> d_cx_runs;
     DevBuf<DevContig> d_ctg_scratch;   // cov_copy_depth works on a copy of the accumulators
+    // per-interval statistics (cov_interval_stats_compute): depth of every target, materialised on demand
+    DevBuf<int32_t> d_depth_all; DevBuf<u64> d_depth_off; bool depth_all_valid = false;
+    DevBuf<DevInterval> d_iv; DevBuf<DevIntervalStats> d_ivst; DevBuf<unsigned long long> d_ivhist; uint64_t ivhist_total = 0;
     DevBuf<uint8_t> d_mask;
     bool have_mask = false;
     DevBuf<DevContig> d_ctg;
@@ -319,7 +322,7 @@ void cov_destroy(cov_session *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->d_tlen.release(); s->d_tile_contig.release(); s->d_tile_start.release(); s->d_mask.release();
     s->d_tile_first.release(); s->d_tcnt.release(); s->d_fov.release(); s->d_tscan.release(); s->d_ttop.release();
-    s->d_ctg_scratch.release();
+    s->d_ctg_scratch.release(); s->d_depth_all.release(); s->d_depth_off.release(); s->d_iv.release(); s->d_ivst.release(); s->d_ivhist.release();
     s->d_cx_list.release(); s->d_cx_cnt.release(); s->d_cx_cur.release(); s->d_cx_scan.release(); s->d_cx_top.release(); s->d_cx_runs.release();
     s->d_ctg.release(); s->d_glob.release(); s->d_desc.release();
     if (s->h_res) (void)hipHostFree(s->h_res);
@@ -432,7 +435,7 @@ cov_status cov_push_batch_device(cov_session *s, const cov_batch *b) {
 
 cov_status cov_reset(cov_session *s) {
     if (!s) return COV_ERR_INVALID_ARG;
-    s->adopted = false; s->n_records = 0; s->n_cigar = 0; s->finished = false;
+    s->adopted = false; s->n_records = 0; s->n_cigar = 0; s->finished = false; s->depth_all_valid = false;
     return COV_OK;
 }
 
@@ -451,6 +454,7 @@ cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summ
 static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summary *summary, bool &again) {
     again = false;
     if (!s || (!stats && s->n_targets)) return COV_ERR_INVALID_ARG;
+    s->depth_all_valid = false;
     HIPCHK(hipSetDevice(s->cfg.device));
     hipStream_t st = s->stream;
     const u32 nT = s->n_targets;
@@ -700,6 +704,76 @@ cov_status cov_copy_depth(cov_session *s, uint32_t tid, int32_t *depth_out) {
     launch_any_pileup<false, true>(s, a, grid);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(depth_out, s->d_depth.p, (size_t)L * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return COV_OK;
+}
+
+cov_status cov_interval_stats_compute(cov_session *s, const cov_interval *iv, uint64_t n, uint64_t excl, int want_hist,
+                                      cov_interval_stats *out, uint64_t *hist_total) {
+    if (!s || !s->finished) return COV_ERR_STATE;
+    if ((n && (!iv || !out))) return COV_ERR_INVALID_ARG;
+    if (hist_total) *hist_total = 0;
+    s->ivhist_total = 0;
+    if (n == 0) return COV_OK;
+    for (uint64_t i = 0; i < n; i++)
+        if (iv[i].tid >= s->n_targets || iv[i].start >= iv[i].end || iv[i].end > s->h_tlen[iv[i].tid]) {
+            s->err = "interval outside its target"; return COV_ERR_INVALID_ARG;
+        }
+    HIPCHK(hipSetDevice(s->cfg.device));
+    hipStream_t st = s->stream;
+    if (!s->depth_all_valid) {   // depth of every target, once per finish
+        std::vector<u64> off((size_t)s->n_targets + 1, 0);
+        for (u32 c = 0; c < s->n_targets; c++) off[c + 1] = off[c] + s->h_tlen[c];
+        HIPCHK(s->d_depth_off.reserve(off.size(), st));
+        HIPCHK(hipMemcpyAsync(s->d_depth_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(s->d_depth_all.reserve(std::max<size_t>(1, off.back()), st));
+        HIPCHK(hipMemsetAsync(s->d_depth_all.p, 0, (size_t)off.back() * 4, st));
+        if (s->n_records && s->n_tiles) {
+            PileupArgs a = pileup_args(s);
+            HIPCHK(s->d_ctg_scratch.reserve(s->n_targets, st));   // the accumulated statistics must stay as they are
+            HIPCHK(hipMemcpyAsync(s->d_ctg_scratch.p, s->d_ctg.p, (size_t)s->n_targets * sizeof(DevContig), hipMemcpyDeviceToDevice, st));
+            a.ctg = s->d_ctg_scratch.p;
+            a.depth_out = s->d_depth_all.p; a.depth_off = s->d_depth_off.p; a.tile_base = 0;
+            HIPCHK(hipMemsetAsync(&s->d_glob.p->chunk_ctr[0], 0, sizeof(u32) * 8 * 16, st));
+            launch_any_pileup<false, true>(s, a, s->n_tiles);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(st));   // `off` is read by the copy above
+        s->depth_all_valid = true;
+    }
+    static_assert(sizeof(DevInterval) == sizeof(cov_interval) && sizeof(DevIntervalStats) == sizeof(cov_interval_stats), "ABI structs mirror the device ones");
+    HIPCHK(s->d_iv.reserve(n, st)); HIPCHK(s->d_ivst.reserve(n, st));
+    HIPCHK(hipMemcpyAsync(s->d_iv.p, iv, n * sizeof(cov_interval), hipMemcpyHostToDevice, st));
+    const u32 grid = (u32)std::max<uint64_t>(1, std::min<uint64_t>((n + 3) / 4, (uint64_t)s->n_cus * 16));
+    hipLaunchKernelGGL(k_interval_stats, dim3(grid), dim3(256), 0, st, s->d_depth_all.p, s->d_depth_off.p, s->d_iv.p, n, excl, s->d_ivst.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, s->d_ivst.p, n * sizeof(cov_interval_stats), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    uint64_t tot = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (want_hist) { out[i].hist_off = tot; tot += out[i].hist_len; }
+        else out[i].hist_len = 0;
+    }
+    if (want_hist && tot) {
+        HIPCHK(s->d_ivhist.reserve(tot, st));
+        HIPCHK(hipMemsetAsync(s->d_ivhist.p, 0, tot * 8, st));
+        HIPCHK(hipMemcpyAsync(s->d_ivst.p, out, n * sizeof(cov_interval_stats), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_interval_hist, dim3(grid), dim3(256), 0, st, s->d_depth_all.p, s->d_depth_off.p, s->d_iv.p, n, excl, s->d_ivst.p,
+                           s->d_ivhist.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    s->ivhist_total = want_hist ? tot : 0;
+    if (hist_total) *hist_total = s->ivhist_total;
+    return COV_OK;
+}
+
+cov_status cov_fetch_interval_hist(cov_session *s, uint64_t *hist) {
+    if (!s || !s->finished) return COV_ERR_STATE;
+    if (s->ivhist_total == 0) return COV_OK;
+    if (!hist) return COV_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    HIPCHK(hipMemcpyAsync(hist, s->d_ivhist.p, s->ivhist_total * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return COV_OK;
 }

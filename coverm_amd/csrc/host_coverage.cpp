@@ -885,10 +885,10 @@ void covh_genes_get(const covh_genes *g, size_t i, const char **id, const char *
 void covh_genes_free(covh_genes *g) { delete g; }
 
 int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh_genome_namer *namer, const char *stoit_name,
-                       const cov_batch *rec, const cov_config *cfg, covh_depth_fn depth_fn, void *depth_ctx,
-                       uint64_t num_detected_primary_alignments, covh_taker *taker, const covh_estimator *est, size_t n_est,
-                       int print_zero, covh_reads_mapped *rm_out) {
-    if (!h || !genes || !rec || !cfg || !depth_fn || !taker || (!est && n_est)) return COV_ERR_INVALID_ARG;
+                       const cov_batch *rec, const cov_config *cfg, cov_session *device_session, covh_depth_fn depth_fn,
+                       void *depth_ctx, uint64_t num_detected_primary_alignments, covh_taker *taker, const covh_estimator *est,
+                       size_t n_est, int print_zero, covh_reads_mapped *rm_out) {
+    if (!h || !genes || !rec || !cfg || (!depth_fn && !device_session) || !taker || (!est && n_est)) return COV_ERR_INVALID_ARG;
     if (!check_excl(est, n_est)) { g_err = "estimators disagree on contig_end_exclusion"; return COV_ERR_INVALID_ARG; }
     for (size_t k = 0; k < n_est; k++)
         if (est[k].kind == COVH_PILEUP_COUNTS) { g_err = "coverage_histogram is not available per gene in this build"; return COV_ERR_INVALID_ARG; }
@@ -931,6 +931,22 @@ int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh
         }
     }
 
+    // ---- device path: every resolved gene is one interval, reduced on the GPU over the materialised depth
+    std::vector<cov_interval_stats> dstats;
+    std::vector<uint64_t> dhist;
+    if (device_session) {
+        std::vector<cov_interval> ivs;
+        for (u32 t = 0; t < nT; t++)
+            for (const ResolvedGene &g : by_tid[t]) { cov_interval iv; iv.tid = t; iv.pad = 0; iv.start = g.start; iv.end = g.end; ivs.push_back(iv); }
+        bool want_hist = false;
+        for (size_t k = 0; k < n_est; k++) want_hist |= est[k].kind == COVH_TRIMMED_MEAN;
+        dstats.resize(ivs.size());
+        uint64_t htot = 0;
+        int rc = (int)cov_interval_stats_compute(device_session, ivs.data(), ivs.size(), excl, want_hist, dstats.data(), &htot);
+        if (rc == COV_OK && htot) { dhist.resize(htot); rc = (int)cov_fetch_interval_hist(device_session, dhist.data()); }
+        if (rc != COV_OK) { g_err = cov_last_error(device_session); return rc; }
+    }
+
     taker->start_stoit(stoit_name);
     auto zero_genes = [&](u32 tid) {   // emit_zero_coverage_genes, :554-567
         for (const ResolvedGene &g : by_tid[tid]) {
@@ -950,15 +966,27 @@ int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh
         const auto &gl = by_tid[tid];
         if (gl.empty()) return;
         const u64 L = h->target_len[tid];
-        depth.resize((size_t)L);
-        const int rc = depth_fn(depth_ctx, tid, depth.data());
-        if (rc != COV_OK) { if (!rc_err) rc_err = rc; return; }
+        if (!device_session) {
+            depth.resize((size_t)L);
+            const int rc = depth_fn(depth_ctx, tid, depth.data());
+            if (rc != COV_OK) { if (!rc_err) rc_err = rc; return; }
+        }
         for (const ResolvedGene &g : gl) {
             const u64 s = g.start, e = std::min(g.end, L);
             if (s >= e) continue;
             const u64 len = e - s;
             acc.reset();
             acc.full_len = len;
+            if (device_session) {
+                const cov_interval_stats &D = dstats[g.entry_id];
+                acc.full_covered = D.full_covered;
+                if (2 * excl < len) {
+                    acc.win_len = len - 2 * excl;
+                    acc.win_sum_d = D.win_sum_d; acc.win_sum_d2 = D.win_sum_d2; acc.win_covered = D.win_covered; acc.win_min_d = D.win_min_d;
+                    if (D.hist_len && !dhist.empty()) acc.hist.assign(dhist.begin() + (ptrdiff_t)D.hist_off, dhist.begin() + (ptrdiff_t)(D.hist_off + D.hist_len));
+                    else acc.hist_len_only = (u64)D.win_max_d + 1;
+                }
+            } else {
             for (u64 p = s; p < e; p++) acc.full_covered += depth[p] > 0;
             if (2 * excl < len) {                              // add_contig's window on the GENE's own array (:394-404)
                 acc.win_len = len - 2 * excl;
@@ -970,6 +998,7 @@ int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh
                 }
                 acc.hist.assign((size_t)mx + 1, 0);
                 for (u64 p = s + excl; p < e - excl; p++) acc.hist[(u32)depth[p]]++;
+            }
             }
             const size_t lo = std::lower_bound(starts.begin(), starts.end(), s) - starts.begin();
             const size_t hi = std::lower_bound(starts.begin(), starts.end(), e) - starts.begin();

@@ -1204,7 +1204,8 @@ struct PileupArgs {
     DevGlobal *g;
     u32 *hist_arena;
     u64 excl;
-    int32_t *depth_out;   // WRITE_DEPTH: depth of one contig
+    int32_t *depth_out;   // WRITE_DEPTH: depth of one contig, or of every contig when depth_off is set
+    const u64 *depth_off; // WRITE_DEPTH over all tiles: offset of each contig in depth_out (NULL = depth_out is one contig)
     u32 tile_base;        // first tile index handled by blockIdx 0
     u32 ablate;           // experiment knob (COVERM_ABLATE): 1 no events, 2 no stats loop, 4 no hist, 8 no result atomics
 };
@@ -1235,6 +1236,7 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
     const u32 L = ds.z;
     const bool generic = ds.w & 1u;
     const u32 tlen_t = min((u32)TILE, L - lo);
+    const u64 dbase = (WRITE_DEPTH && a.depth_off != nullptr) ? a.depth_off[c] : 0ull;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int rows_used = (int)((tlen_t + 4 * NT - 1) / (4 * NT));
 
@@ -1345,7 +1347,7 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
                     const u32 rel = p0 + j - wst;
                     if (rel) { hist_add((u32)prev, rel); hist_add(du, 0u - rel); }
                 }
-                if (WRITE_DEPTH) a.depth_out[p0 + j] = d;
+                if (WRITE_DEPTH) a.depth_out[dbase + p0 + j] = d;
             }
             cov_f = cov_w;
         } else {
@@ -1357,7 +1359,7 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
                 const u32 du = (u32)d;
                 if (p < L) {
                     cov_f += d > 0;
-                    if (WRITE_DEPTH) a.depth_out[p] = d;
+                    if (WRITE_DEPTH) a.depth_out[dbase + p] = d;
                     if (win_any && p >= wst && p < wet) {
                         sum_d += du;
                         sum_d2 += (u64)du * du;
@@ -1537,6 +1539,7 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
             uint2 rw0, rw1;
             load_runs(ds, rw0, rw1);
             const u32 c = dC1.x, lo = dC1.y, L = ds.z;
+            const u64 dbase = (WRITE_DEPTH && a.depth_off != nullptr) ? a.depth_off[c] : 0ull;
             const u32 cxo = dC1.z, cxn = dC1.w;
             if (ds.x >= ds.y && cxn == 0u) continue;   // depth 0 everywhere: accounted on the host side
             const bool generic = ds.w & 1u;
@@ -1659,7 +1662,7 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
                     const u32 du = (u32)d;
                     if (p < L) {
                         cov_f += d > 0;
-                        if (WRITE_DEPTH) a.depth_out[p] = d;
+                        if (WRITE_DEPTH) a.depth_out[dbase + p] = d;
                         if (win_any && p >= wst && p < wet) {
                             sum_d += du;
                             sum_d2 += (u64)du * du;
@@ -1682,5 +1685,66 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
 }
 
 constexpr size_t pileup_stream_smem_bytes() { return (size_t)4 * ((size_t)STREAM_TW * 4 + STREAM_HB * 4); }
+
+// ------------------------------------------------------------------------------------ interval statistics
+// Per-interval (per-gene, genes.rs:508-535) statistics over a materialised depth arena: one wave per interval.
+// The window is the interval shrunk by `excl` at both of ITS ends (the reference hands the gene's own delta array to
+// add_contig); covered bases without exclusion.  k_interval_hist fills each interval's histogram slice afterwards.
+struct DevInterval { u32 tid, pad; u64 start, end; };
+struct DevIntervalStats { u64 win_sum_d, win_sum_d2, win_covered, full_covered; u32 win_min_d, win_max_d, hist_len, pad; u64 hist_off; };
+
+__global__ __launch_bounds__(256) void k_interval_stats(const int32_t *__restrict__ depth, const u64 *__restrict__ depth_off,
+                                                        const DevInterval *__restrict__ iv, u64 n, u64 excl,
+                                                        DevIntervalStats *__restrict__ out) {
+    const int lane = lane_id();
+    const u64 wave = (u64)blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = (u64)gridDim.x * 4u;
+    for (u64 g = wave; g < n; g += n_waves) {
+        const DevInterval I = iv[g];
+        const int32_t *d = depth + depth_off[I.tid];
+        const u64 len = I.end - I.start;
+        const bool has_win = 2 * excl < len;
+        const u64 ws = I.start + excl, we = has_win ? I.end - excl : ws;
+        u64 s1 = 0, s2 = 0;
+        u32 cw = 0, cf = 0, mn = 0xffffffffu, mx = 0;
+        for (u64 p = I.start + (u64)lane; p < I.end; p += 64) {
+            const u32 v = (u32)d[p];
+            cf += v > 0u;
+            if (has_win && p >= ws && p < we) { s1 += v; s2 += (u64)v * v; cw += v > 0u; mn = min(mn, v); mx = max(mx, v); }
+        }
+        s1 = wave_sum_u64(s1); s2 = wave_sum_u64(s2);
+        cw = wave_sum_u32(cw); cf = wave_sum_u32(cf); mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+        if (lane == 0) {
+            DevIntervalStats o;
+            o.win_sum_d = s1; o.win_sum_d2 = s2; o.win_covered = cw; o.full_covered = cf;
+            o.win_min_d = has_win ? mn : 0u; o.win_max_d = mx; o.hist_len = has_win ? mx + 1u : 0u; o.pad = 0; o.hist_off = 0;
+            out[g] = o;
+        }
+    }
+}
+
+constexpr int IV_HB = 512;
+__global__ __launch_bounds__(256) void k_interval_hist(const int32_t *__restrict__ depth, const u64 *__restrict__ depth_off,
+                                                       const DevInterval *__restrict__ iv, u64 n, u64 excl,
+                                                       const DevIntervalStats *__restrict__ st, unsigned long long *__restrict__ hist) {
+    __shared__ u32 lh[4][IV_HB];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const u64 wave = (u64)blockIdx.x * 4u + (u64)w, n_waves = (u64)gridDim.x * 4u;
+    for (int b = lane; b < IV_HB; b += 64) lh[w][b] = 0u;
+    for (u64 g = wave; g < n; g += n_waves) {
+        const DevInterval I = iv[g];
+        const DevIntervalStats S = st[g];
+        if (S.hist_len == 0u) continue;
+        const int32_t *d = depth + depth_off[I.tid];
+        unsigned long long *h = hist + S.hist_off;
+        for (u64 p = I.start + excl + (u64)lane; p < I.end - excl; p += 64) {
+            const u32 v = (u32)d[p];
+            if (v < (u32)IV_HB) atomicAdd(&lh[w][v], 1u); else atomicAdd(&h[v], 1ull);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const u32 hb = min(S.hist_len, (u32)IV_HB);
+        for (u32 b = (u32)lane; b < hb; b += 64) { const u32 x = lh[w][b]; if (x) { atomicAdd(&h[b], (unsigned long long)x); lh[w][b] = 0u; } }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
 
 }  // namespace covk

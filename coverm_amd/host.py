@@ -400,9 +400,10 @@ class Genes:
 
 def gene_coverage(names, target_len, genes: Genes, stoit_name: str, records, cfg, depth_of, num_detected_primary: int,
                   coverage_taker: CoverageTaker, coverage_estimators, print_zero_coverage_genes: bool,
-                  namer_mode: int = 0, separator: str = "~", genome_of_tid=None, genome_names=None) -> ReadsMapped:
+                  namer_mode: int = 0, separator: str = "~", genome_of_tid=None, genome_names=None, session=None) -> ReadsMapped:
     """genes.rs:182-344 for one BAM.  `records`: engine.RecordBatch the scan sees; `cfg`: native.CovConfig (flag filter,
-    single-read thresholds); `depth_of(tid)` returns the contig's int32 depth (Session.depth in the product)."""
+    single-read thresholds); `session` (a finished engine.Session holding `records`) selects the device reductions; without
+    it `depth_of(tid)` supplies the contig's int32 depth and the reductions run on the host."""
     from .native import CovBatch
     L = _lib()
     h, k1 = _header(names, target_len)
@@ -433,9 +434,10 @@ def gene_coverage(names, target_len, genes: Genes, stoit_name: str, records, cfg
         nm.genome_names = gn
         keep = (g, gn)
     rm = _ReadsMapped()
-    L.covh_gene_coverage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, _DEPTH_FN,
+    L.covh_gene_coverage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, _DEPTH_FN,
                                      C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-    rc = L.covh_gene_coverage(C.byref(h), genes._h, C.byref(nm), stoit_name.encode(), C.byref(cb), C.byref(cfg), cbk, None,
+    rc = L.covh_gene_coverage(C.byref(h), genes._h, C.byref(nm), stoit_name.encode(), C.byref(cb), C.byref(cfg),
+                              session._h if session is not None else None, cbk, None,
                               int(num_detected_primary), coverage_taker._h, _est_array(coverage_estimators),
                               len(coverage_estimators), int(print_zero_coverage_genes), C.byref(rm))
     del keep

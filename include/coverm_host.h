@@ -187,11 +187,13 @@ typedef struct {
     const char *const *genome_names; /* mode 3 */
 } covh_genome_namer;
 /* records = what the scan sees (after a pair-mode reader stage, if any); cfg carries the flag filter, the single-read
- * thresholds (filter_single) and nothing else that matters here; num_detected_primary_alignments as the reader counted it. */
+ * thresholds (filter_single) and nothing else that matters here; num_detected_primary_alignments as the reader counted it.
+ * device_session (a finished session holding these records) selects the device reductions (cov_interval_stats_compute: one
+ * wave per gene over the depth kept in HBM); with NULL the depth callback is used and the reductions run on the host. */
 int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh_genome_namer *namer, const char *stoit_name,
-                       const cov_batch *records, const cov_config *cfg, covh_depth_fn depth, void *depth_ctx,
-                       uint64_t num_detected_primary_alignments, covh_taker *taker, const covh_estimator *est, size_t n_est,
-                       int print_zero_coverage_genes, covh_reads_mapped *reads_mapped_out);
+                       const cov_batch *records, const cov_config *cfg, cov_session *device_session, covh_depth_fn depth,
+                       void *depth_ctx, uint64_t num_detected_primary_alignments, covh_taker *taker, const covh_estimator *est,
+                       size_t n_est, int print_zero_coverage_genes, covh_reads_mapped *reads_mapped_out);
 
 /* calculate_coverage for one entry built from explicit sums (used by unit tests). */
 typedef struct {

@@ -193,6 +193,21 @@ cov_status cov_kernel_ms(const cov_session *s, cov_kernel_id k, double *ms_total
 cov_status cov_algorithmic_bytes(const cov_session *s, uint64_t *bytes);
 
 
+/* ---- per-interval statistics (per-gene coverage, the reference's src/genes.rs:508-535).  After cov_finish: the depth of
+ * every target is materialised once in HBM (4 B per base, kept until the next push / reset / finish) and each interval
+ * [start, end) of target `tid` is reduced by one wave.  contig_end_exclusion applies to the INTERVAL's own ends: the
+ * window is [start+excl, end-excl) when 2*excl < end-start, else empty; full_covered has no exclusion. */
+typedef struct { uint32_t tid, pad; uint64_t start, end; } cov_interval;
+typedef struct {
+    uint64_t win_sum_d, win_sum_d2, win_covered, full_covered;
+    uint32_t win_min_d, win_max_d; /* over the window; 0 when it is empty */
+    uint32_t hist_len, pad;        /* window non-empty: win_max_d + 1 bins at hist[hist_off ..] (when want_hist), else 0 */
+    uint64_t hist_off;
+} cov_interval_stats;
+cov_status cov_interval_stats_compute(cov_session *s, const cov_interval *intervals, uint64_t n, uint64_t contig_end_exclusion,
+                                      int want_hist, cov_interval_stats *out, uint64_t *hist_total);
+cov_status cov_fetch_interval_hist(cov_session *s, uint64_t *hist);
+
 /* Page-locked host memory for record batches, pooled: a freed block is kept for the next request of similar size
  * (a decoder filling one batch per BAM file gets its arrays back without re-pinning).  cov_host_alloc returns NULL
  * when no HIP device is usable; cov_host_free returns 0 if `p` did not come from cov_host_alloc; cov_host_trim

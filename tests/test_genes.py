@@ -62,9 +62,11 @@ def _run_api_case(case, provider):
         names = sorted(set(case["namer"].values()))
         g_of = np.asarray([names.index(case["namer"][n]) if n in case["namer"] else -1 for n in af.ref_names], np.int32)
         mode = 3
-    with provider(af, records, filt, 0) as (depth_of, prim_dev, cfg):
+    with provider(af, records, filt, 0) as prov:
+        depth_of, prim_dev, cfg = prov[:3]
         rm = host.gene_coverage(af.ref_names, af.ref_lens, genes, af.stoit_name, records, cfg, depth_of, prim_dev, taker,
-                                [_est(case["est"])], case["print_zeros"], mode, "~", g_of, names)
+                                [_est(case["est"])], case["print_zeros"], mode, "~", g_of, names,
+                                prov[3] if len(prov) > 3 else None)
     assert taker.text() == case["expected"]
     return rm
 
@@ -182,5 +184,68 @@ def test_gene_synthetic_matches_oracle_cpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_gene_synthetic_matches_oracle_gpu(tmp_path):
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_gene_synthetic_matches_oracle_gpu(tmp_path, where, monkeypatch):
+    """device: per-gene reductions by cov_interval_stats_compute over the depth kept in HBM; host: over cov_copy_depth."""
+    if where == "host":
+        monkeypatch.setenv("COVERM_GENES_ON_HOST", "1")
     _synthetic_cases(tmp_path, lambda b: cli.device_depth)
+
+
+@pytest.mark.gpu
+def test_interval_stats_abi(tmp_path):
+    """cov_interval_stats_compute against numpy on the depth read back by cov_copy_depth: windows, empty windows,
+    histograms (incl. bins beyond the LDS window), intervals touching contig ends; then a second finish + recompute."""
+    import ctypes as C
+    from coverm_amd import native
+    from coverm_amd.engine import FilterConfig, Session
+    ref = synth.make_reference(6, 600_000, seed=81, min_len=20_000, max_len=300_000)
+    batch = synth.make_reads(ref, 60_000, seed=82)
+    # a deep pile so that some depths exceed the 512 bins kept in LDS: the first 3000 records of contig 0 start together
+    batch.pos = batch.pos.copy()
+    batch.pos[:3000] = batch.pos[0]
+    assert (batch.tid[:3000] == 0).all()
+    rng = np.random.default_rng(9)
+
+    class IV(C.Structure):
+        _fields_ = [("tid", C.c_uint32), ("pad", C.c_uint32), ("start", C.c_uint64), ("end", C.c_uint64)]
+
+    class ST(C.Structure):
+        _fields_ = [("win_sum_d", C.c_uint64), ("win_sum_d2", C.c_uint64), ("win_covered", C.c_uint64), ("full_covered", C.c_uint64),
+                    ("win_min_d", C.c_uint32), ("win_max_d", C.c_uint32), ("hist_len", C.c_uint32), ("pad", C.c_uint32),
+                    ("hist_off", C.c_uint64)]
+    L = native.lib()
+    L.cov_interval_stats_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.cov_fetch_interval_hist.argtypes = [C.c_void_p, C.c_void_p]
+    with Session(0, FilterConfig(), 0, want_hist=False) as s:
+        s.set_targets(ref.lengths)
+        s.push(batch)
+        for rnd in range(2):
+            s.finish()
+            depth = [s.depth(t) for t in range(len(ref.lengths))]
+            ivs = []
+            for t, Lc in enumerate(ref.lengths):
+                ivs += [(t, 0, int(Lc)), (t, int(Lc) - 10, int(Lc)), (t, 0, 1), (t, max(0, int(batch.pos[0]) - 50), min(int(Lc), int(batch.pos[0]) + 400))]
+                for _ in range(40):
+                    a = int(rng.integers(0, Lc - 1)); b = min(int(Lc), a + int(rng.integers(1, 5000)))
+                    ivs.append((t, a, b))
+            arr = (IV * len(ivs))(*[IV(t, 0, a, b) for t, a, b in ivs])
+            for excl in (0, 75, 3000):
+                out = (ST * len(ivs))()
+                tot = C.c_uint64(0)
+                assert L.cov_interval_stats_compute(s._h, arr, len(ivs), excl, 1, out, C.byref(tot)) == 0
+                hist = np.zeros(max(1, tot.value), np.uint64)
+                assert L.cov_fetch_interval_hist(s._h, hist.ctypes.data) == 0
+                for (t, a, b), o in zip(ivs, out):
+                    d = depth[t][a:b].astype(np.int64)
+                    assert o.full_covered == int((d > 0).sum())
+                    if 2 * excl < b - a:
+                        w = d[excl:len(d) - excl]
+                        assert (o.win_sum_d, o.win_sum_d2, o.win_covered) == (int(w.sum()), int((w * w).sum()), int((w > 0).sum()))
+                        assert (o.win_min_d, o.win_max_d, o.hist_len) == (int(w.min()), int(w.max()), int(w.max()) + 1)
+                        np.testing.assert_array_equal(hist[o.hist_off:o.hist_off + o.hist_len], np.bincount(w, minlength=int(w.max()) + 1).astype(np.uint64))
+                    else:
+                        assert (o.win_sum_d, o.win_covered, o.hist_len) == (0, 0, 0)
+            s.reset()
+            s.push(batch)
+    assert max(int(x.max()) for x in depth) > 1000
