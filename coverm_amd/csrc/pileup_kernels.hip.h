@@ -833,45 +833,57 @@ __global__ __launch_bounds__(256) void k_ranges(const u32 *__restrict__ tile_con
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_hist_layout(DevContig *ctg, u32 n_targets, const u32 *__restrict__ tlen,
                                                       const uint8_t *__restrict__ mask, u64 excl, DevGlobal *g) {
+    // Each thread owns a run of consecutive contigs (its loads are independent and issued together), then one block scan
+    // of the per-thread totals: a single latency round instead of one per 1024 contigs.
+    constexpr u32 HL_MAX = 16;                       // contigs per thread in the register-resident fast case
     __shared__ u64 wtot[16];
-    __shared__ u64 carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    for (u32 base = 0; base < n_targets; base += 1024) {
-        const u32 c = base + threadIdx.x;
-        u64 v = 0;
-        if (c < n_targets) {
-            DevContig *C = &ctg[c];
-            const bool live = C->n_pass != 0 && (mask == nullptr || mask[c]);
-            if (MODE == 0) v = live ? (u64)C->hist_cap + 1 : 0;
-            else {
-                const bool has_win = 2 * excl < (u64)tlen[c];
-                v = (live && has_win) ? (u64)C->max_d + 1 : 0;
-                C->hist_len = (u32)v;
-            }
-        }
-        u64 inc = v;
+    const u32 per = (n_targets + 1023u) / 1024u;
+    const u32 c0 = threadIdx.x * per, c1 = min(n_targets, c0 + per);
+    auto value = [&](u32 c) -> u64 {
+        DevContig *C = &ctg[c];
+        const bool live = C->n_pass != 0 && (mask == nullptr || mask[c]);
+        if (MODE == 0) return live ? (u64)C->hist_cap + 1 : 0;
+        const bool has_win = 2 * excl < (u64)tlen[c];
+        const u64 v = (live && has_win) ? (u64)C->max_d + 1 : 0;
+        C->hist_len = (u32)v;
+        return v;
+    };
+    u64 vals[HL_MAX];
+    u64 mine = 0;
+    if (per <= HL_MAX) {
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            u64 t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
+        for (u32 k = 0; k < HL_MAX; k++) { vals[k] = (k < per && c0 + k < c1) ? value(c0 + k) : 0; mine += vals[k]; }
+    } else {
+        for (u32 c = c0; c < c1; c++) mine += value(c);
+    }
+    u64 inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    u64 wbase = 0, total = 0;
+    for (int k = 0; k < 16; k++) { const u64 x = wtot[k]; if (k < w) wbase += x; total += x; }
+    u64 run = wbase + inc - mine;                     // exclusive prefix of this thread's first contig
+    if (per <= HL_MAX) {
+#pragma unroll
+        for (u32 k = 0; k < HL_MAX; k++)
+            if (k < per && c0 + k < c1) {
+                if (MODE == 0) ctg[c0 + k].hist_off = run; else ctg[c0 + k].chist_off = run;
+                run += vals[k];
+            }
+    } else {
+        for (u32 c = c0; c < c1; c++) {
+            const u64 v = MODE == 0 ? ((ctg[c].n_pass != 0 && (mask == nullptr || mask[c])) ? (u64)ctg[c].hist_cap + 1 : 0) : (u64)ctg[c].hist_len;
+            if (MODE == 0) ctg[c].hist_off = run; else ctg[c].chist_off = run;
+            run += v;
         }
-        if (lane == 63) wtot[w] = inc;
-        __syncthreads();
-        u64 wbase = 0;
-        for (int k = 0; k < w; k++) wbase += wtot[k];
-        const u64 carry = carry_s;
-        if (c < n_targets) {
-            if (MODE == 0) ctg[c].hist_off = carry + wbase + inc - v;
-            else ctg[c].chist_off = carry + wbase + inc - v;
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + wbase + inc;
-        __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if (MODE == 0) g->hist_cap_total = carry_s; else g->chist_total = carry_s;
+        if (MODE == 0) g->hist_cap_total = total; else g->chist_total = total;
     }
 }
 
