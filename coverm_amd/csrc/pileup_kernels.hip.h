@@ -1577,11 +1577,16 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
                 if (rw.y == 0u) return;
                 if (generic && a.r.tid[i] != (int)c) return;
                 const u32 type = rw.y >> 30;
-                if (type == RW_SINGLE) add_run(rw.x, rw.x + rw.y);
-                else if (type == RW_DOUBLE) {
-                    const u32 l1 = rw.y & 1023u, gap = (rw.y >> 10) & 255u, l2 = (rw.y >> 18) & 1023u;
+                if (type <= RW_DOUBLE) {
+                    // one shared first run for both encodings (a wave almost always holds both kinds, so separate
+                    // branches would issue the run's two LDS atomics twice), second run only for RW_DOUBLE lanes
+                    const bool dbl = type == RW_DOUBLE;
+                    const u32 l1 = dbl ? (rw.y & 1023u) : rw.y;
                     add_run(rw.x, rw.x + l1);
-                    add_run(rw.x + l1 + gap, rw.x + l1 + gap + l2);
+                    if (dbl) {
+                        const u32 s2 = rw.x + l1 + ((rw.y >> 10) & 255u);
+                        add_run(s2, s2 + ((rw.y >> 18) & 1023u));
+                    }
                 } else if (type == RW_COMPLEX) {
                     u32 cursor = (u32)a.r.pos[i];
                     const u32 c0 = a.r.cigar_off[i], c1 = a.r.cigar_off[i + 1];
