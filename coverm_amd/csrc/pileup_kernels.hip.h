@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
 //           change-point histogram.
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-constexpr int STREAM_TW = 1024, STREAM_HB = 512, STREAM_CAP = 256;
+constexpr int STREAM_TW = 1024, STREAM_HB = 512, STREAM_CAP = 512;
 
 template <bool WANT_HIST, bool WRITE_DEPTH>
 __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
