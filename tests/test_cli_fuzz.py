@@ -1,0 +1,65 @@
+"""Randomised end-to-end check: product CLI text (Python face -> C ABI -> kernels -> C++ host layer) == oracle CLI text for
+random combinations of mode, methods, read filters (single-read and pair branches), output format, end exclusion and
+zero-row settings on a small paired synthetic sample."""
+import numpy as np
+import pytest
+
+from coverm_amd import cli
+from coverm_amd.cli import AlignmentFile
+from coverm_amd.engine import RecordBatch
+from oracle import oracle as O
+from tests.test_host_golden import _paired_sample
+
+pytestmark = pytest.mark.gpu
+
+CONTIG_METHODS = ["mean", "trimmed_mean", "covered_fraction", "covered_bases", "variance", "length", "count", "reads_per_base",
+                  "anir", "rpkm", "tpm"]
+GENOME_METHODS = CONTIG_METHODS + ["relative_abundance"]
+
+
+@pytest.fixture(scope="module")
+def sample():
+    b = _paired_sample(6_000, seed=11)
+    # genome-style names so that separator mode works: two genomes over five contigs
+    b.ref_names = ["gA~c0", "gA~c1", "gB~c2", "gB~c3", "gB~c4"]
+    rec = RecordBatch.from_arrays(b.tid, b.pos, b.flag, b.mapq, b.nm, b.nm_kind, b.l_seq, b.cigar_off, b.cigar)
+    return b, AlignmentFile("data/fz.bam", b.ref_names, b.ref_lens, rec, b.qname, b.mtid)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_cli_text_equals_oracle(sample, seed, tmp_path):
+    b, af = sample
+    rng = np.random.default_rng(500 + seed)
+    mode = "contig" if rng.random() < 0.5 else "genome"
+    pool = CONTIG_METHODS if mode == "contig" else GENOME_METHODS
+    methods = list(rng.choice(pool, size=int(rng.integers(1, 5)), replace=False))
+    kw = dict(methods=methods, output_format=str(rng.choice(["dense", "sparse"])), no_zeros=bool(rng.random() < 0.3),
+              contig_end_exclusion=int(rng.choice([0, 75, 2000])), min_covered_fraction=int(rng.choice([0, 10, 50])),
+              trim_min=int(rng.choice([5, 20])), trim_max=int(rng.choice([95, 80])))
+    if mode == "genome":
+        r = rng.random()
+        if r < 0.4:
+            kw["separator"] = "~"
+        elif r < 0.6:
+            kw["single_genome"] = True
+        else:
+            gd = tmp_path / "gd.tsv"
+            gd.write_text("gA\tgA~c0\ngA\tgA~c1\ngB\tgB~c3\n")          # c2 and c4 in no genome
+            kw["genome_definition"] = str(gd)
+    f = rng.random()
+    if f < 0.25:
+        kw.update(min_read_percent_identity=int(rng.choice([90, 97])), min_read_aligned_length=int(rng.choice([0, 80])))
+    elif f < 0.45:
+        kw.update(min_read_percent_identity_pair=95)
+    elif f < 0.6:
+        kw.update(min_mapq=int(rng.choice([10, 30])), proper_pairs_only=bool(rng.random() < 0.5))
+    elif f < 0.7:
+        kw.update(min_read_aligned_percent_pair=80, min_read_aligned_length=60)
+    if rng.random() < 0.2:
+        kw["exclude_supplementary"] = True
+    if rng.random() < 0.2:
+        kw["include_secondary"] = True
+    if (kw["min_covered_fraction"] > 0) and any(m in ("length", "count", "reads_per_base", "rpkm", "tpm", "anir") for m in methods):
+        kw["min_covered_fraction"] = 0        # those estimators refuse a covered-fraction threshold (coverm.rs:1480-1503)
+    got = cli.run(mode, [af], **kw)
+    assert got == O.run_cli(mode, ["data/fz.bam"], bams=[b], **kw), (mode, kw)
