@@ -10,6 +10,7 @@
 #include <limits>
 #include <optional>
 #include <string>
+#include <thread>
 #include <string_view>
 #include <vector>
 
@@ -1023,9 +1024,17 @@ int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh
     u64 mapped_total = 0;
     auto reset_contig = [&]() { starts.clear(); pprim.assign(1, 0); pmism.assign(1, 0); pident.assign(1, 0.0); };
     reset_contig();
-    for (u64 i = 0; i < rec->n_records; i++) {
+    // Per-record work (filters, CIGAR walk, identity) is independent: blocks of records are classified by a few threads,
+    // then consumed in file order (contig changes, prefix sums and emission are sequential, as in the reference).
+    enum : uint8_t { SKIP = 0, TAKE = 1, NM_MISSING = 2, NM_BADTYPE = 3 };
+    const u64 BLOCK = 1u << 20;
+    std::vector<uint8_t> state(std::min<u64>(BLOCK, rec->n_records));
+    std::vector<u64> mism(state.size());
+    std::vector<double> ident(state.size());
+    auto classify = [&](u64 i, u64 k) {
         const u32 flag = rec->flag[i];
         const bool supp = flag & 0x800u, sec = flag & 0x100u, unmapped = flag & 0x4u;
+        state[k] = SKIP;
         u64 aligned = 0, indels = 0;
         auto walk = [&]() {
             for (u32 c = rec->cigar_off[i]; c < rec->cigar_off[i + 1]; c++) {
@@ -1036,35 +1045,61 @@ int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh
         };
         bool walked = false;
         if (cfg->filter_single) {   // reader stage, single-read branch (filter.rs:88-116, 243-279), as k_prep applies it
-            if (unmapped || (!cfg->include_supplementary && supp) || (!cfg->include_secondary && sec)) continue;
-            if (cfg->min_mapq != 255 && (rec->mapq[i] < cfg->min_mapq || rec->mapq[i] == 255)) continue;
-            if (rec->nm_kind[i] != COV_NM_UNSIGNED) return rec->nm_kind[i] == COV_NM_ABSENT ? COV_ERR_NM_MISSING : COV_ERR_NM_BADTYPE;
+            if (unmapped || (!cfg->include_supplementary && supp) || (!cfg->include_secondary && sec)) return;
+            if (cfg->min_mapq != 255 && (rec->mapq[i] < cfg->min_mapq || rec->mapq[i] == 255)) return;
+            if (rec->nm_kind[i] != COV_NM_UNSIGNED) { state[k] = rec->nm_kind[i] == COV_NM_ABSENT ? NM_MISSING : NM_BADTYPE; return; }
             walk(); walked = true;
             const u32 al = (u32)aligned;
             const float a = (float)al;
             if (!(al >= cfg->min_aligned_length && a / (float)rec->l_seq[i] >= cfg->min_aligned_percent &&
-                  1.0f - (float)rec->nm[i] / a >= cfg->min_percent_identity)) continue;
+                  1.0f - (float)rec->nm[i] / a >= cfg->min_percent_identity)) return;
         }
-        if ((!cfg->include_secondary && sec) || (!cfg->include_supplementary && supp) || (!cfg->include_improper_pairs && !(flag & 0x2u))) continue;
-        if (unmapped) continue;
-        const int64_t tid = rec->tid[i];
-        if (tid != last_tid) {
-            if (tid < last_tid) { g_err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)"; return COV_ERR_UNSORTED; }
-            if (tid < 0 || (u64)tid >= nT) { g_err = "record refers to a reference id outside the header (Corrupt BAM file?)"; return COV_ERR_BAD_TID; }
-            previous(last_tid, tid);
-            if (rc_err) return rc_err;
-            last_tid = tid;
-            reset_contig();
-        }
-        const bool primary = !supp && !sec;
-        mapped_total += primary;
+        if ((!cfg->include_secondary && sec) || (!cfg->include_supplementary && supp) || (!cfg->include_improper_pairs && !(flag & 0x2u))) return;
+        if (unmapped) return;
         if (!walked) walk();
-        if (rec->nm_kind[i] != COV_NM_UNSIGNED) return rec->nm_kind[i] == COV_NM_ABSENT ? COV_ERR_NM_MISSING : COV_ERR_NM_BADTYPE;
+        if (rec->nm_kind[i] != COV_NM_UNSIGNED) { state[k] = rec->nm_kind[i] == COV_NM_ABSENT ? NM_MISSING : NM_BADTYPE; return; }
         const u64 edit = rec->nm[i];
-        starts.push_back((u64)(int64_t)rec->pos[i]);
-        pprim.push_back(pprim.back() + (primary ? 1 : 0));
-        pmism.push_back(pmism.back() + (edit > indels ? edit - indels : 0));      // saturating_sub, :296
-        pident.push_back(pident.back() + ((primary && aligned > 0) ? ((double)aligned - (double)edit) / (double)aligned : 0.0));
+        const bool primary = !supp && !sec;
+        state[k] = TAKE;
+        mism[k] = edit > indels ? edit - indels : 0;                                   // saturating_sub, :296
+        ident[k] = (primary && aligned > 0) ? ((double)aligned - (double)edit) / (double)aligned : 0.0;
+    };
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    for (u64 b0 = 0; b0 < rec->n_records; b0 += BLOCK) {
+        const u64 nb = std::min<u64>(BLOCK, rec->n_records - b0);
+        if (nb >= (1u << 16) && hw > 1) {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < hw; t++)
+                pool.emplace_back([&, t]() { for (u64 k = nb * t / hw, e = nb * (t + 1) / hw; k < e; k++) classify(b0 + k, k); });
+            for (auto &th : pool) th.join();
+        } else {
+            for (u64 k = 0; k < nb; k++) classify(b0 + k, k);
+        }
+        for (u64 k = 0; k < nb; k++) {
+            const u64 i = b0 + k;
+            // a record that fails the NM requirement before its contig is reached still ends the scan there, like the panic
+            if (state[k] == SKIP) continue;
+            if (state[k] != TAKE) {
+                // single-read mode meets nm() inside the filter, before the flag filter; otherwise after it: classify()
+                // already ordered those tests, so any error state is the reference's panic at this record
+                return state[k] == NM_MISSING ? COV_ERR_NM_MISSING : COV_ERR_NM_BADTYPE;
+            }
+            const int64_t tid = rec->tid[i];
+            if (tid != last_tid) {
+                if (tid < last_tid) { g_err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)"; return COV_ERR_UNSORTED; }
+                if (tid < 0 || (u64)tid >= nT) { g_err = "record refers to a reference id outside the header (Corrupt BAM file?)"; return COV_ERR_BAD_TID; }
+                previous(last_tid, tid);
+                if (rc_err) return rc_err;
+                last_tid = tid;
+                reset_contig();
+            }
+            const bool primary = !(rec->flag[i] & 0x900u);
+            mapped_total += primary;
+            starts.push_back((u64)(int64_t)rec->pos[i]);
+            pprim.push_back(pprim.back() + (primary ? 1 : 0));
+            pmism.push_back(pmism.back() + mism[k]);
+            pident.push_back(pident.back() + ident[k]);
+        }
     }
     previous(last_tid, nT);
     if (rc_err) return rc_err;
