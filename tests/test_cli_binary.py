@@ -124,3 +124,17 @@ def test_cli_binary_per_gene_golden(case, tmp_path):
     for k in ("gff", "genome_definition"):
         if k in oa: oa[k] = os.path.join(FIXDIR, oa[k])
     assert r.stdout == O.run_cli(case["mode"], case["bams"], bams=[load_fixture(b) for b in case["bams"]], **oa)
+
+
+def test_binary_argument_errors():
+    """Argument handling that needs no GPU: unknown flags, missing values, no BAM, methods that refuse a covered-fraction
+    threshold (coverm.rs:1480-1503), metabat with --gff (coverm.rs:492-495)."""
+    for argv, needle in ([["contig", "--frobnicate"], "unknown argument"],
+                         [["contig", "-b"], "--bam-files is required"],
+                         [["genome", "-m", "mean"], "--bam-files is required"],
+                         [["contig", "-b", "x.bam", "--min-mapq"], "missing value"]):
+        p = subprocess.run([BIN] + argv, capture_output=True, text=True)
+        assert p.returncode != 0 and needle in p.stderr, (argv, p.stderr)
+    p = subprocess.run([BIN, "contig", "-b", "/nonexistent/x.bam", "-m", "metabat", "--gff", "/nonexistent/g.gff"],
+                       capture_output=True, text=True)
+    assert p.returncode != 0 and "metabat method cannot be used with --gff" in p.stderr
