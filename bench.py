@@ -104,13 +104,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the coverage engine has no CPU fallback")
+    # Functional check of the N > 1 path on a single-GPU box: COVERM_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    # exchanges over gloo (RCCL refuses two ranks on one device).  Never set by the driver; such a line is not a measurement.
+    share = os.environ.get("COVERM_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = torch.device("cpu") if share else dev          # where the exchanged tensors live
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- synthetic sample of this rank (one BAM per GPU; seed 2 at N=1, 10+rank otherwise)
     t0 = time.time()
@@ -127,7 +136,7 @@ def main():
     sess.set_targets(ref.lengths)
     sess.push_device(dt, batch.n_records)
     n_cov = len(ref.lengths) * len(est)
-    gather_buf = [torch.empty(n_cov, dtype=torch.float32, device=dev) for _ in range(world)] if (dist and rank == 0) else None
+    gather_buf = [torch.empty(n_cov, dtype=torch.float32, device=xdev) for _ in range(world)] if (dist and rank == 0) else None
 
     def step():
         stats, summ = sess.finish()
@@ -138,7 +147,7 @@ def main():
         if dist:
             # per-contig coverages of this sample -> rank 0 (one gather over RCCL/xGMI)
             cov = taker.cached_coverages(0)   # n_contigs x n_estimators f32, contig order (zeros printed)
-            t = torch.from_numpy(cov).to(dev)
+            t = torch.from_numpy(cov).to(xdev)
             dist.gather(t, gather_buf, dst=0)
         return summ, rm, taker
 
@@ -159,7 +168,7 @@ def main():
     elapsed = time.perf_counter() - t0
     considered = int(summ.n_considered)
     if dist:
-        tt = torch.tensor([elapsed, float(considered)], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, float(considered)], dtype=torch.float64, device=xdev)
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
@@ -196,7 +205,8 @@ def main():
                                    "--methods %s, records resident in HBM" % (a.reads, a.contigs,
                                                                              ref.lengths.sum() / 1e9, " ".join(METHODS)),
                        "reads_per_gpu": a.reads, "contigs": a.contigs, "reference_bp": int(ref.lengths.sum()),
-                       "samples": world, "sharding": "one sample per GPU, RCCL gather of per-contig coverages" if world > 1 else "single GPU"},
+                       "samples": world, "sharding": ("FUNCTIONAL CHECK ONLY: ranks share one GPU, gloo exchange" if share else
+                                                       "one sample per GPU, RCCL gather of per-contig coverages") if world > 1 else "single GPU"},
             "gbp_per_s": aligned_bp * world * a.steps / elapsed / 1e9,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": profile_traffic(dom),
