@@ -180,8 +180,22 @@ def test_format_matches_rust_display():
         assert host.format_f32(v) == O.fmt_f32(v)
 
 
-def test_exports_and_no_gpu_failure_is_loud():
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/*.h is exported by libcovermhip.so (parsed from the headers, so a declaration
+    without a definition cannot slip through)."""
+    import re
     L = native.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    declared = set()
+    for h in ("covermhip.h", "coverm_host.h"):
+        text = open(os.path.join(root, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)                       # comments mention function names too
+        text = re.sub(r"typedef[^;{]*\([^;]*;", " ", text)                         # function-pointer typedefs
+        declared |= set(re.findall(r"\b(covh?_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) > 45 and {"cov_finish", "cov_interval_stats_compute", "covh_gene_coverage", "covh_pair_mode_order",
+                                   "cov_host_alloc", "covh_bam_open"} <= declared
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, missing
     for name in native.EXPORTS:
         assert hasattr(L, name)
     assert L.cov_abi_version() == 1
