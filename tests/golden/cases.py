@@ -345,6 +345,9 @@ CLI_CASES = [
     dict(id="cli_genome_sep_unsorted", cite="tests/test_cmdline.rs:3083-3096", mode="genome",
          bams=["2seqs.bad_read.1.unsorted.bam"], args=dict(separator="e"), match="error",
          expected="BAM file appears to be unsorted"),
+    dict(id="cli_genome_names_unsorted", cite="tests/test_cmdline.rs:3098-3114 (genomes_dir given as the equivalent definition)",
+         mode="genome", bams=["2seqs.bad_read.1.unsorted.bam"], args=dict(genome_definition="2seqs.by-file.definition"),
+         match="error", expected="BAM file appears to be unsorted"),
     dict(id="cli_tpm_contig_sparse", cite="tests/test_cmdline.rs:3457-3480", mode="contig", bams=["tpm_test.bam"],
          args=dict(output_format="sparse", methods=["mean", "tpm"]), match="is",
          expected="Sample\tContig\tMean\tTPM\n" + _rows("tpm_test\t", G7, [

@@ -49,6 +49,9 @@ def main():
                  "seq2\ttest\tgene\t1\t1000\t.\t+\t.\tID=gene3\n")
     with open(os.path.join(out, "2seqs.genome-definition"), "w") as fh:
         fh.write("genomeA\tseq1\ngenomeB\tseq2\n")
+    # tests/data/genomes_dir holds seq1.fna (>seq1) and seq2.fna (>seq2): the same genome <-> contig table as a definition
+    with open(os.path.join(out, "2seqs.by-file.definition"), "w") as fh:
+        fh.write("seq1\tseq1\nseq2\tseq2\n")
 
 
 if __name__ == "__main__":
