@@ -306,19 +306,28 @@ def device_sample(af: AlignmentFile, fp: FilterParameters, contig_end_exclusion:
 
 
 def read_genome_definition(path: str):
-    """genome_parsing.rs:77-141: `genome<TAB>contig` lines -> (genomes, contig -> genome index)."""
+    """read_genome_definition_file, genome_parsing.rs:71-141: `genome<TAB>contig [comment]` lines -> (genomes in file
+    order, contig -> genome index).  The contig is the first whitespace-separated token of the second column."""
     genomes, idx, c2g = [], {}, {}
-    with open(path) as fh:
-        for line in fh:
-            line = line.rstrip("\n").rstrip("\r")
-            if not line:
-                continue
-            f = line.split("\t")
-            if len(f) != 2:
-                raise SystemExit("Unexpected line in genome definition file: %r" % line)
-            if f[0] not in idx:
-                idx[f[0]] = len(genomes); genomes.append(f[0])
-            c2g[f[1]] = idx[f[0]]
+    with open(path, newline="") as fh:
+        lines = fh.read().split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    for line in lines:
+        if line.endswith("\r"):
+            line = line[:-1]
+        f = line.split("\t")
+        if len(f) != 2:
+            raise SystemExit('The line "%s" in the genome definition file is not a genome name and contig name separated by a tab' % line)
+        g, toks = f[0].strip(), f[1].split()
+        if not toks:
+            raise SystemExit("Failed to split contig name by whitespace in genome definition file")
+        c = toks[0]
+        if c in c2g and genomes[c2g[c]] != g:
+            raise SystemExit("The contig name '%s' was assigned to multiple genomes" % c)
+        if g not in idx:
+            idx[g] = len(genomes); genomes.append(g)
+        c2g.setdefault(c, idx[g])
     return genomes, c2g
 
 

@@ -204,16 +204,27 @@ int main(int argc, char **argv) {
         if (!fh) die("cannot open " + a.genome_definition);
         char line[1 << 16];
         std::unordered_map<std::string, int32_t> gi;
-        while (fgets(line, sizeof line, fh)) {   // genome_parsing.rs:77-141
+        auto is_ws = [](unsigned char ch) { return ch == ' ' || (ch >= 9 && ch <= 13); };
+        while (fgets(line, sizeof line, fh)) {   // read_genome_definition_file, genome_parsing.rs:71-141
             std::string l(line);
-            while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
-            if (l.empty()) continue;
+            if (!l.empty() && l.back() == '\n') l.pop_back();
+            if (!l.empty() && l.back() == '\r') l.pop_back();
             const size_t t = l.find('\t');
-            if (t == std::string::npos || l.find('\t', t + 1) != std::string::npos) die("Unexpected line in genome definition file");
-            const std::string g = l.substr(0, t), c = l.substr(t + 1);
+            if (t == std::string::npos || l.find('\t', t + 1) != std::string::npos)   // blank lines included (:116-124)
+                die("The line \"" + l + "\" in the genome definition file is not a genome name and contig name separated by a tab");
+            std::string g = l.substr(0, t);
+            { size_t a = 0, b = g.size(); while (a < b && is_ws((unsigned char)g[a])) a++; while (b > a && is_ws((unsigned char)g[b - 1])) b--; g = g.substr(a, b - a); }
+            size_t a = t + 1;
+            while (a < l.size() && is_ws((unsigned char)l[a])) a++;
+            size_t b = a;
+            while (b < l.size() && !is_ws((unsigned char)l[b])) b++;
+            if (a == b) die("Failed to split contig name by whitespace in genome definition file");
+            const std::string c = l.substr(a, b - a);                                  // first token: comments after it are dropped
             auto it = gi.find(g);
             if (it == gi.end()) { it = gi.emplace(g, (int32_t)genomes.size()).first; genomes.push_back(g); }
-            c2g[c] = it->second;
+            auto cit = c2g.find(c);
+            if (cit != c2g.end() && cit->second != it->second) die("The contig name '" + c + "' was assigned to multiple genomes");
+            if (cit == c2g.end()) c2g[c] = it->second;
         }
         fclose(fh);
     }

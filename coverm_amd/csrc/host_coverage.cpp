@@ -748,6 +748,25 @@ void print_metabat(covh_taker &t) {   // coverage_printer.rs:57-119
 }
 }  // namespace
 
+// ---- trait CoverageTaker (coverage_takers.rs:29-38) as plain calls, for hosts that drive a taker themselves
+void covh_taker_start_stoit(covh_taker *t, const char *stoit_name) { t->start_stoit(stoit_name); }
+void covh_taker_start_entry(covh_taker *t, size_t entry_order_id, const char *entry_name) { t->start_entry(entry_order_id, entry_name); }
+void covh_taker_add_single_coverage(covh_taker *t, float coverage) { t->add_single_coverage(coverage); }
+void covh_taker_add_coverage_entry(covh_taker *t, uint64_t num_reads, uint64_t num_bases) { t->add_coverage_entry(num_reads, num_bases); }
+void covh_taker_finish_entry(covh_taker *t) { t->finish_entry(); }
+int covh_taker_names_mismatch(const covh_taker *t) { return t->mismatch ? 1 : 0; }
+// CoverageTakerTypeIterator (coverage_takers.rs:265-377) flattened: returns the number of (entry, stoit) items and fills up to
+// `cap` of them; coverages holds num_coverages floats per item.
+size_t covh_taker_iterate(const covh_taker *t, uint64_t *entry_index, uint64_t *stoit_index, float *coverages, size_t cap) {
+    const auto all = iterate_cached(*t);
+    for (size_t i = 0; i < all.size() && i < cap; i++) {
+        if (entry_index) entry_index[i] = all[i].entry_index;
+        if (stoit_index) stoit_index[i] = all[i].stoit_index;
+        if (coverages) for (size_t k = 0; k < all[i].coverages.size(); k++) coverages[i * t->num_coverages + k] = all[i].coverages[k];
+    }
+    return all.size();
+}
+
 void covh_finalise_printing(covh_taker *t, int printer, const char *entry_type, const char *const *headers,
                             size_t n_headers, const covh_reads_mapped *rm, size_t n_samples,
                             const int64_t *norm, size_t n_norm, int64_t rpkm_col, int64_t tpm_col) {

@@ -128,6 +128,11 @@ def _lib():
         L.covh_taker_new.restype = C.c_void_p
         L.covh_taker_new.argtypes = [C.c_int, C.c_size_t]
         L.covh_taker_free.argtypes = [C.c_void_p]
+        L.covh_taker_start_stoit.argtypes = [C.c_void_p, C.c_char_p]
+        L.covh_taker_start_entry.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p]
+        L.covh_taker_add_single_coverage.argtypes = [C.c_void_p, C.c_float]
+        L.covh_taker_finish_entry.argtypes = [C.c_void_p]
+        L.covh_taker_iterate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.covh_taker_free.restype = None
         L.covh_taker_text.restype = C.c_void_p
         L.covh_taker_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
@@ -212,6 +217,30 @@ class CoverageTaker:
         n = C.c_size_t(0)
         p = self._L.covh_taker_text(self._h, C.byref(n))
         return C.string_at(p, n.value).decode()
+
+    # trait CoverageTaker (coverage_takers.rs:29-38)
+    def start_stoit(self, name: str):
+        _lib().covh_taker_start_stoit(self._h, name.encode())
+
+    def start_entry(self, entry_order_id: int, entry_name: str):
+        _lib().covh_taker_start_entry(self._h, C.c_size_t(entry_order_id), entry_name.encode())
+
+    def add_single_coverage(self, cov: float):
+        _lib().covh_taker_add_single_coverage(self._h, C.c_float(cov))
+
+    def finish_entry(self):
+        _lib().covh_taker_finish_entry(self._h)
+
+    def iterate(self, num_coverages: int):
+        """CoverageTakerTypeIterator: list of (entry_index, stoit_index, [coverages])."""
+        L = _lib()
+        L.covh_taker_iterate.restype = C.c_size_t
+        n = L.covh_taker_iterate(self._h, None, None, None, C.c_size_t(0))
+        ei = np.zeros(max(1, n), np.uint64); si = np.zeros(max(1, n), np.uint64)
+        cv = np.zeros(max(1, n * num_coverages), np.float32)
+        L.covh_taker_iterate(self._h, ei.ctypes.data_as(C.c_void_p), si.ctypes.data_as(C.c_void_p), cv.ctypes.data_as(C.c_void_p),
+                             C.c_size_t(n))
+        return [(int(ei[i]), int(si[i]), [float(x) for x in cv[i * num_coverages:(i + 1) * num_coverages]]) for i in range(n)]
 
     def cached_coverages(self, stoit: int = 0) -> np.ndarray:
         """f32 coverages recorded for one sample by the cached taker (entries x estimators, recording order)."""

@@ -91,6 +91,17 @@ void covh_taker_clear_text(covh_taker *t);
  * returns the number available (copies at most cap). */
 size_t covh_taker_cached_coverages(const covh_taker *t, size_t stoit, float *out, size_t cap);
 
+/* trait CoverageTaker (coverage_takers.rs:29-38): start_stoit once per BAM; per entry start_entry -> add_* (one per
+ * estimator, in estimator order) -> finish_entry.  The scan drivers below make these calls themselves. */
+void covh_taker_start_stoit(covh_taker *t, const char *stoit_name);
+void covh_taker_start_entry(covh_taker *t, size_t entry_order_id, const char *entry_name);
+void covh_taker_add_single_coverage(covh_taker *t, float coverage);
+void covh_taker_add_coverage_entry(covh_taker *t, uint64_t num_reads, uint64_t num_bases);
+void covh_taker_finish_entry(covh_taker *t);
+int covh_taker_names_mismatch(const covh_taker *t); /* an entry id arrived with two different names (:140-148) */
+/* Cached taker: CoverageTakerTypeIterator (coverage_takers.rs:265-377), flattened; returns the item count. */
+size_t covh_taker_iterate(const covh_taker *t, uint64_t *entry_index, uint64_t *stoit_index, float *coverages, size_t cap);
+
 /* Which need a histogram / identity sums from the device (COV_WANT_* for the session). */
 uint32_t covh_wants(const covh_estimator *est, size_t n_est);
 

@@ -949,21 +949,32 @@ def gene_coverage(bams: Sequence[BamData], stoit_names: Sequence[str], taker, es
 
 # ------------------------------------------------------------------ CLI-level driver (bin/coverm.rs)
 def read_genome_definition(path: str):
-    """genome_parsing.rs:77-141: TSV genome<TAB>contig; returns (genomes, contig->genome index)."""
+    """read_genome_definition_file, genome_parsing.rs:71-141: `genome<TAB>contig [comment]` lines; the contig is the first
+    whitespace-separated token of the second column, the genome name is trimmed, genomes keep file order, a contig given
+    to two genomes or a line without exactly one tab (blank lines included) is fatal.  Returns (genomes, contig->index)."""
     genomes, idx, c2g = [], {}, {}
-    with open(path) as fh:
-        for line in fh:
-            line = line.rstrip("\n").rstrip("\r")
-            if not line:
-                continue
-            f = line.split("\t")
-            if len(f) != 2:
-                raise ValueError("Unexpected line in genome definition: %r" % line)
-            g, c = f
-            if g not in idx:
-                idx[g] = len(genomes)
-                genomes.append(g)
-            c2g[c] = idx[g]
+    with open(path, newline="") as fh:
+        text = fh.read()
+    lines = text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()                                   # BufRead::lines: no empty item after the final newline
+    for line in lines:
+        if line.endswith("\r"):
+            line = line[:-1]
+        f = line.split("\t")
+        if len(f) != 2:
+            raise ValueError('The line "%s" in the genome definition file is not a genome name and contig name separated by a tab' % line)
+        g = f[0].strip()
+        toks = f[1].split()
+        if not toks:
+            raise ValueError("Failed to split contig name by whitespace in genome definition file")
+        c = toks[0]
+        if c in c2g and genomes[c2g[c]] != g:
+            raise ValueError("The contig name '%s' was assigned to multiple genomes" % c)
+        if g not in idx:
+            idx[g] = len(genomes)
+            genomes.append(g)
+        c2g.setdefault(c, idx[g])
     return genomes, c2g
 
 

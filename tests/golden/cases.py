@@ -395,6 +395,51 @@ CLI_CASES = [
          expected="Genome\t2seqs.bad_read.1.with_supplementary ANIr\ngenome1\t0.999\n"),
 ]
 
+# ---- CoverageTaker / CoveragePrinter unit tests (coverage_takers.rs:383-760, coverage_printer.rs:562-720): a script of
+# trait calls ("S" start_stoit, "E" start_entry, "C" add_single_coverage) and what the structure / iterator / printer yields
+_TWO = [("S", "stoit1"), ("E", 0, "contig1"), ("C", 1.1), ("C", 1.2), ("E", 3, "contig2"), ("C", 2.1), ("C", 2.2)]
+_MISMATCH = _TWO + [("S", "stoit2"), ("E", 1, "contig1.5"), ("C", 10.1), ("C", 10.2), ("E", 3, "contig2"), ("C", 20.1), ("C", 20.2),
+                    ("E", 5, "contig5"), ("C", 20.1), ("C", 20.2)]
+_HELLO = [("S", "stoit1"), ("E", 0, "contig1"), ("C", 1.1), ("C", 1.2)]
+TAKER_CASES = [
+    dict(id="taker_cached_hello_world", cite="coverage_takers.rs:383-419", n=2, script=_HELLO,
+         stoits=["stoit1"], entries=["contig1"], coverages=[[(0, 1.1), (0, 1.2)]]),
+    dict(id="taker_cached_two_samples_matching", cite="coverage_takers.rs:421-506", n=2,
+         script=_TWO + [("S", "stoit2"), ("E", 0, "contig1"), ("C", 10.1), ("C", 10.2), ("E", 3, "contig2"), ("C", 20.1), ("C", 20.2)],
+         stoits=["stoit1", "stoit2"], entries=["contig1", None, None, "contig2"],
+         coverages=[[(0, 1.1), (0, 1.2), (3, 2.1), (3, 2.2)], [(0, 10.1), (0, 10.2), (3, 20.1), (3, 20.2)]]),
+    dict(id="taker_cached_two_samples_mismatching", cite="coverage_takers.rs:508-606", n=2, script=_MISMATCH,
+         stoits=["stoit1", "stoit2"], entries=["contig1", "contig1.5", None, "contig2", None, "contig5"],
+         coverages=[[(0, 1.1), (0, 1.2), (3, 2.1), (3, 2.2)],
+                    [(1, 10.1), (1, 10.2), (3, 20.1), (3, 20.2), (5, 20.1), (5, 20.2)]]),
+    dict(id="taker_cached_next", cite="coverage_takers.rs:608-698", n=2, script=_MISMATCH,
+         iterate=[(0, 0, [1.1, 1.2]), (1, 0, [0.0, 0.0]), (3, 0, [2.1, 2.2]), (5, 0, [0.0, 0.0]), (0, 1, [0.0, 0.0]),
+                  (1, 1, [10.1, 10.2]), (3, 1, [20.1, 20.2]), (5, 1, [20.1, 20.2])]),
+    dict(id="taker_cached_next_one_coverage", cite="coverage_takers.rs:700-760", n=1,
+         script=[("S", "stoit1"), ("E", 0, "contig1"), ("C", 1.1), ("E", 3, "contig2"), ("C", 2.1), ("S", "stoit2"),
+                 ("E", 1, "contig1.5"), ("C", 10.1), ("E", 3, "contig2"), ("C", 20.1), ("E", 5, "contig5"), ("C", 20.1)],
+         iterate=[(0, 0, [1.1]), (1, 0, [0.0]), (3, 0, [2.1]), (5, 0, [0.0]), (0, 1, [0.0]), (1, 1, [10.1]), (3, 1, [20.1]),
+                  (5, 1, [20.1])]),
+    dict(id="printer_dense_hello_world", cite="coverage_printer.rs:562-584", n=2, script=_HELLO, printer="dense",
+         headers=["mean", "std"], text="Contig\tstoit1 mean\tstoit1 std\ncontig1\t1.1\t1.2\n"),
+    dict(id="printer_dense_newline", cite="coverage_printer.rs:586-609", n=2,
+         script=[("S", "stoit1"), ("E", 0, "contig1\r"), ("C", 1.1), ("C", 1.2)], printer="dense", headers=["mean", "std"],
+         text="Contig\tstoit1 mean\tstoit1 std\ncontig1\t1.1\t1.2\n"),
+    dict(id="printer_dense_easy_normalised", cite="coverage_printer.rs:611-638", n=2, script=_HELLO, printer="dense",
+         headers=["mean", "std"], reads_mapped=[(1, 2)], normalise=[0],
+         text="Contig\tstoit1 mean\tstoit1 std\nunmapped\t50\tNA\ncontig1\t50\t1.2\n"),
+    dict(id="printer_metabat_easy", cite="coverage_printer.rs:640-680", n=3, printer="metabat", headers=[],
+         script=[("S", "stoit1"), ("E", 0, "contig1"), ("C", 1024.0), ("C", 1.1), ("C", 1.2), ("E", 1, "contig2"), ("C", 1025.0),
+                 ("C", 2.1), ("C", 2.2), ("S", "stoit2"), ("E", 0, "contig1"), ("C", 1024.0), ("C", 21.1), ("C", 21.2),
+                 ("E", 1, "contig2"), ("C", 1025.0), ("C", 22.1), ("C", 22.2)],
+         text="contigName\tcontigLen\ttotalAvgDepth\tstoit1.bam\tstoit1.bam-var\tstoit2.bam\tstoit2.bam-var\n"
+              "contig1\t1024\t11.1\t1.1\t1.2\t21.1\t21.2\ncontig2\t1025\t12.1\t2.1\t2.2\t22.1\t22.2\n"),
+    dict(id="printer_sparse_hello_world", cite="coverage_printer.rs:682-695", n=2, script=_HELLO, printer="sparse", headers=[],
+         text="stoit1\tcontig1\t1.1\t1.2\n"),
+    dict(id="printer_sparse_newline", cite="coverage_printer.rs:697-710", n=2, printer="sparse", headers=[],
+         script=[("S", "stoit1"), ("E", 0, "contig1\r"), ("C", 1.1), ("C", 1.2)], text="stoit1\tcontig1\t1.1\t1.2\n"),
+]
+
 # ---- per-gene coverage (--gff): genes.rs unit tests :621-766 and tests/test_cmdline.rs:134-206
 _G2 = [("gene_seq1", "seq1", 0, 1000), ("gene_seq2", "seq2", 0, 1000)]
 _B1 = "2seqs.reads_for_seq1"

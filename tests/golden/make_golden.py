@@ -38,6 +38,9 @@ def main():
     with open(os.path.join(out, "7seqs.definition"), "w") as fh:
         for n in d.ref_names:
             fh.write("%s\t%s\n" % (n.split("~")[0], n))
+    with open(os.path.join(out, "7seqs.definition_with_comments"), "w") as fh:   # genome_parsing.rs:189-198
+        for k, n in enumerate(d.ref_names):
+            fh.write("%s\t%s %s comment\n" % (n.split("~")[0], n, "a" if k == 0 else "another"))
     # per-gene goldens (genes.rs:621-766, tests/test_cmdline.rs:134-206): three gene lines as the reference's
     # tests/data/2seqs.gff describes them (gene1 = seq1:1-1000, gene2 = seq1:100-200, gene3 = seq2:1-1000, with a
     # directive, a second attribute and a comment line, which the parser must skip) and the two-line genome definition

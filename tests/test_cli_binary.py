@@ -138,3 +138,20 @@ def test_binary_argument_errors():
     p = subprocess.run([BIN, "contig", "-b", "/nonexistent/x.bam", "-m", "metabat", "--gff", "/nonexistent/g.gff"],
                        capture_output=True, text=True)
     assert p.returncode != 0 and "metabat method cannot be used with --gff" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_binary_genome_definition_with_comments(tmp_path):
+    """genome_parsing.rs:189-198: text after the contig name is ignored; the binary's own parser agrees with the plain file."""
+    p = str(tmp_path / "7seqs.reads_for_seq1_and_seq2.bam")
+    bamio.write_bam(p, load_fixture("7seqs.reads_for_seq1_and_seq2.bam"), block=3000)
+    outs = []
+    for d in ("7seqs.definition", "7seqs.definition_with_comments"):
+        r = subprocess.run([BIN, "genome", "-b", p, "--genome-definition", os.path.join(FIXDIR, d)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and "genome2\t53.167923\n" in outs[0]
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("g1\tgenome2~seq1\n\ng2\tgenome5~seq2\n")
+    r = subprocess.run([BIN, "genome", "-b", p, "--genome-definition", str(bad)], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "not a genome name and contig name separated by a tab" in r.stderr

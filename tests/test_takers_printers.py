@@ -1,0 +1,91 @@
+"""CoverageTaker / CoveragePrinter unit tests of the reference (coverage_takers.rs:383-760, coverage_printer.rs:562-720)
+replayed on the oracle's Python restatement and on the product's C++ host layer (through the trait calls of the C API)."""
+import io
+
+import numpy as np
+import pytest
+
+from coverm_amd import host
+from oracle import oracle as O
+from tests.golden import cases
+
+f32 = np.float32
+IDS = [c["id"] for c in cases.TAKER_CASES]
+
+
+def _replay(taker, script):
+    for op in script:
+        if op[0] == "S":
+            taker.start_stoit(op[1])
+        elif op[0] == "E":
+            taker.start_entry(op[1], op[2])
+        else:
+            taker.add_single_coverage(float(f32(op[1])))
+
+
+def _rm(case, cls):
+    return [cls(a, b) for a, b in case["reads_mapped"]] if "reads_mapped" in case else None
+
+
+@pytest.mark.parametrize("case", cases.TAKER_CASES, ids=IDS)
+def test_oracle_takers_printers(case):
+    t = O.CachedTaker(case["n"])
+    _replay(t, case["script"])
+    if "stoits" in case:
+        assert t.stoit_names == case["stoits"] and t.entry_names == case["entries"]
+        assert [[(e, f32(c)) for e, c in lst] for lst in t.coverages] == [[(e, f32(c)) for e, c in lst] for lst in case["coverages"]]
+    if "iterate" in case:
+        assert [(e, s, [f32(x) for x in cv]) for e, s, cv in t.iterate()] == [(e, s, [f32(x) for x in cv]) for e, s, cv in case["iterate"]]
+    if "text" in case:
+        out = io.StringIO()
+        if case["printer"] == "dense":
+            O.print_dense_cached("Contig", case["headers"], t, out, _rm(case, O.ReadsMapped), case.get("normalise", []), None, None)
+        elif case["printer"] == "sparse":
+            O.print_sparse_cached(t, out, _rm(case, O.ReadsMapped), case.get("normalise", []), None, None)
+        else:
+            O.print_metabat(t, out)
+        assert out.getvalue() == case["text"]
+
+
+@pytest.mark.parametrize("case", cases.TAKER_CASES, ids=IDS)
+def test_host_takers_printers(case):
+    t = host.CoverageTaker.new_cached_single_float_coverage_taker(case["n"])
+    _replay(t, case["script"])
+    if "stoits" in case:
+        for si, want in enumerate(case["coverages"]):
+            got = t.cached_coverages(si)
+            np.testing.assert_array_equal(np.asarray(got, np.float32).ravel(), np.asarray([c for _, c in want], np.float32))
+        # names and indices show through the iterator: every named entry appears once per sample, in index order
+        items = t.iterate(case["n"])
+        named = [i for i, n in enumerate(case["entries"]) if n is not None]
+        seen = sorted({e for lst in case["coverages"] for e, _ in lst})
+        assert [e for e, s, _ in items if s == 0] == seen and len(items) == len(seen) * len(case["stoits"])
+        assert set(seen) <= set(named)
+    if "iterate" in case:
+        assert [(e, s, [f32(x) for x in cv]) for e, s, cv in t.iterate(case["n"])] == \
+               [(e, s, [f32(x) for x in cv]) for e, s, cv in case["iterate"]]
+    if "text" in case:
+        printer = {"sparse": 1, "dense": 2, "metabat": 3}[case["printer"]]
+        host.finalise_printing(t, printer, "Contig", case["headers"], _rm(case, host.ReadsMapped), case.get("normalise", []), None, None)
+        assert t.text() == case["text"]
+
+
+# ---- read_genome_definition_file (genome_parsing.rs:178-198) + the parser's rules (:84-124)
+@pytest.mark.parametrize("reader", ["oracle", "product"])
+@pytest.mark.parametrize("name", ["7seqs.definition", "7seqs.definition_with_comments"])
+def test_read_genome_definition_file(name, reader, tmp_path):
+    import os
+    from coverm_amd import cli
+    from tests.fixtures import FIXDIR
+    read = O.read_genome_definition if reader == "oracle" else cli.read_genome_definition
+    genomes, c2g = read(os.path.join(FIXDIR, name))
+    assert genomes[c2g["genome4~random_sequence_length_11002"]] == "genome4" and len(genomes) == 6
+    assert genomes == ["genome%d" % k for k in range(1, 7)]                      # file order is kept (:85-86)
+    bad = tmp_path / "bad.tsv"
+    for text in ("g1\tc1\n\ng2\tc2\n", "g1 c1\n", "g1\tc1\tx\n", "g1\tc1\ng2\tc1\n"):   # blank line, no tab, two tabs, contig in two genomes
+        bad.write_text(text)
+        with pytest.raises((ValueError, SystemExit)):
+            read(str(bad))
+    ok = tmp_path / "ok.tsv"
+    ok.write_text(" g1 \tc1 trailing words\r\ng1\tc1\n")                        # trimmed genome, first token, CRLF, harmless repeat
+    assert read(str(ok)) == (["g1"], {"c1": 0})
