@@ -63,7 +63,8 @@ struct cov_session {
     std::string err;
     int tile = 4096;  // bases per k_pileup workgroup (COVERM_TILE = 4096 | 8192 | 16384)
     int nt = 256;     // k_pileup workgroup size (COVERM_PILEUP_NT)
-    int stream_rows = 4;   // > 0: k_pileup_stream with tiles of rows*256 bases per wave (COVERM_PILEUP=stream|tile, COVERM_ROWS)
+    int stream_rows = 4;   // > 0: wave-per-tile kernels (1024-base tiles); 0: k_pileup workgroup-per-tile (COVERM_PILEUP=tile)
+    bool use_fast = true;  // k_pileup_fast + k_pileup_stream on the slow-tile list (default); COVERM_PILEUP=stream: k_pileup_stream alone
     int chunk_tiles = 8;   // consecutive tiles walked by one wave (COVERM_CHUNK)
     int n_cus = 256;
     uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
@@ -75,6 +76,7 @@ struct cov_session {
     uint32_t n_tiles = 0;
     DevBuf<u32> d_tlen, d_tile_contig, d_tile_start;
     DevBuf<u32> d_tile_first, d_tcnt, d_fov, d_tscan, d_ttop;   // TileIdx (pileup_kernels.hip.h)
+    DevBuf<u32> d_slow_list;                                    // tiles k_ranges leaves to k_pileup_stream
     uint32_t tile_shift = 10;
     DevBuf<u32> d_cx_list, d_cx_cnt, d_cx_cur, d_cx_scan, d_cx_top;   // CxIdx: long-CIGAR buckets
     DevBuf<uint2> d_cx_runs;
@@ -215,8 +217,34 @@ void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
     }
 }
 
+// k_pileup_fast over every tile (it skips the ones k_ranges flagged TILE_F_SLOW)
+template <bool H>
+void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
+    const size_t smem = pileup_fast_smem_bytes(H);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_fast<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    const u32 chunk = (u32)s->chunk_tiles;
+    const u32 n_chunks = (n_tiles + chunk - 1) / chunk;
+    static int occ = 0;
+    if (!occ) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_pileup_fast<H>), 256, smem) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
+        }
+        occ = nb;
+    }
+    const char *wg_env = getenv("COVERM_WG_PER_CU");
+    const u32 wg_per_cu = wg_env && atoi(wg_env) > 0 ? (u32)atoi(wg_env) : 8u * (u32)occ;
+    const u32 grid = std::max(1u, std::min((n_chunks + 3) / 4, (u32)s->n_cus * wg_per_cu));
+    hipLaunchKernelGGL((k_pileup_fast<H>), dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
+}
+
 template <bool H, bool W>
-void launch_stream_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
+void launch_stream_t(cov_session *s, const PileupArgs &a, u32 n_tiles, bool slow_list_only = false) {
     const size_t smem = pileup_stream_smem_bytes();
     static bool attr_set = false;
     if (!attr_set) {
@@ -241,13 +269,22 @@ void launch_stream_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
     }
     const char *wg_env = getenv("COVERM_WG_PER_CU");
     const u32 wg_per_cu = wg_env && atoi(wg_env) > 0 ? (u32)atoi(wg_env) : 8u * (u32)occ;
+    if (slow_list_only) {   // the listed tiles only, one per wave step; the count lives on the device (usually 0: waves exit at once)
+        hipLaunchKernelGGL((k_pileup_stream<H, W>), dim3((u32)s->n_cus), dim3(256), smem, s->stream, a, 0u, 1u,
+                           (const u32 *)s->d_slow_list.p, (const u32 *)&s->d_glob.p->n_slow);
+        return;
+    }
     const u32 grid = std::max(1u, std::min((n_chunks + 3) / 4, (u32)s->n_cus * wg_per_cu));
-    hipLaunchKernelGGL((k_pileup_stream<H, W>), dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
+    hipLaunchKernelGGL((k_pileup_stream<H, W>), dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk, (const u32 *)nullptr,
+                       (const u32 *)nullptr);
 }
 // dispatches to the configured pileup kernel
 template <bool H, bool W>
 void launch_any_pileup(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    if (s->stream_rows) launch_stream_t<H, W>(s, a, n_tiles);
+    if (s->stream_rows && s->use_fast && !W) {
+        launch_fast_t<H>(s, a, n_tiles);
+        launch_stream_t<H, W>(s, a, n_tiles, true);
+    } else if (s->stream_rows) launch_stream_t<H, W>(s, a, n_tiles);
     else launch_pileup<H, W>(s, a, n_tiles);
 }
 
@@ -291,6 +328,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
         else n = (n == 128) ? 128 : 256;
         s->tile = t; s->nt = n;
         const char *mode = getenv("COVERM_PILEUP"), *rows = getenv("COVERM_ROWS"), *chk = getenv("COVERM_CHUNK");
+        if (mode && !strcmp(mode, "stream")) s->use_fast = false;
         if (mode && !strcmp(mode, "tile")) s->stream_rows = 0;
         else {
             (void)rows;
@@ -321,7 +359,7 @@ void cov_destroy(cov_session *s) {
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->d_tlen.release(); s->d_tile_contig.release(); s->d_tile_start.release(); s->d_mask.release();
-    s->d_tile_first.release(); s->d_tcnt.release(); s->d_fov.release(); s->d_tscan.release(); s->d_ttop.release();
+    s->d_tile_first.release(); s->d_tcnt.release(); s->d_fov.release(); s->d_tscan.release(); s->d_ttop.release(); s->d_slow_list.release();
     s->d_ctg_scratch.release(); s->d_depth_all.release(); s->d_depth_off.release(); s->d_iv.release(); s->d_ivst.release(); s->d_ivhist.release();
     s->d_cx_list.release(); s->d_cx_cnt.release(); s->d_cx_cur.release(); s->d_cx_scan.release(); s->d_cx_top.release(); s->d_cx_runs.release();
     s->d_ctg.release(); s->d_glob.release(); s->d_desc.release();
@@ -367,6 +405,7 @@ cov_status cov_set_targets(cov_session *s, uint32_t n_targets, const uint64_t *t
     HIPCHK(s->d_tile_first.reserve((size_t)n_targets + 1, s->stream));
     HIPCHK(s->d_tcnt.reserve(std::max<size_t>(1, nt), s->stream)); HIPCHK(s->d_fov.reserve(std::max<size_t>(1, nt), s->stream));
     HIPCHK(s->d_tscan.reserve(std::max<size_t>(1, nt), s->stream)); HIPCHK(s->d_ttop.reserve(nt / 1024 + 2, s->stream));
+    HIPCHK(s->d_slow_list.reserve(std::max<size_t>(1, nt), s->stream));
     HIPCHK(s->d_cx_cnt.reserve(std::max<size_t>(1, nt), s->stream)); HIPCHK(s->d_cx_cur.reserve(std::max<size_t>(1, nt), s->stream));
     HIPCHK(s->d_cx_scan.reserve(std::max<size_t>(1, nt), s->stream)); HIPCHK(s->d_cx_top.reserve(nt / 1024 + 2, s->stream));
     HIPCHK(hipMemcpyAsync(s->d_tile_first.p, s->h_tile_first.data(), ((size_t)n_targets + 1) * 4, hipMemcpyHostToDevice, s->stream));
@@ -542,14 +581,15 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         hipLaunchKernelGGL(k_tile_scan1, dim3(n_blocks), dim3(1024), 0, st, s->d_cx_cnt.p, s->n_tiles, s->d_cx_scan.p, s->d_cx_top.p);
         hipLaunchKernelGGL(k_tile_scan2, dim3(1), dim3(1024), 0, st, s->d_cx_top.p, n_blocks, &s->d_glob.p->cx_total);
         hipLaunchKernelGGL((k_cx_expand<true>), dim3(cx_grid), dim3(256), 0, st, r, s->d_tlen.p, s->d_glob.p, cx, ti);
+        u32 *slow_list = (s->stream_rows && s->use_fast) ? s->d_slow_list.p : nullptr;
         if (want_hist)
             hipLaunchKernelGGL((k_ranges<true>), dim3((s->n_tiles + 255) / 256), dim3(256), 0, st, s->d_tile_contig.p,
                                s->d_tile_start.p, s->n_tiles, s->d_tlen.p, mask, s->d_ctg.p, s->d_desc.p, ti, s->d_tscan.p,
-                               s->d_ttop.p, cx, s->d_glob.p);
+                               s->d_ttop.p, cx, s->d_glob.p, slow_list);
         else
             hipLaunchKernelGGL((k_ranges<false>), dim3((s->n_tiles + 255) / 256), dim3(256), 0, st, s->d_tile_contig.p,
                                s->d_tile_start.p, s->n_tiles, s->d_tlen.p, mask, s->d_ctg.p, s->d_desc.p, ti, s->d_tscan.p,
-                               s->d_ttop.p, cx, s->d_glob.p);
+                               s->d_ttop.p, cx, s->d_glob.p, slow_list);
         time_end(s, COV_K_RANGES);
         HIPCHK(hipGetLastError());
         if (want_hist) {

@@ -31,6 +31,8 @@ constexpr int hist_bins(int tile) { return tile >= 16384 ? 2048 : 1024; }  // LD
 constexpr u32 F_POS_UNSORTED = 1u;
 // run-word types (top two bits of .y)
 constexpr u32 RW_SINGLE = 0u, RW_DOUBLE = 1u, RW_COMPLEX = 2u, RW_BUCKET = 3u;
+constexpr u32 FAST_MAX_CAND = 32767u;    // tiles with more candidate runs than this go to k_pileup_stream (u16 count tables of k_pileup_fast)
+constexpr u32 TILE_F_GENERIC = 1u, TILE_F_SLOW = 2u;   // tile descriptor flags (desc[2t].w)
 constexpr u32 CX_MIN_OPS = 16;   // RW_COMPLEX records with more CIGAR operations than this go through the per-tile buckets
 
 // Per-contig device accumulators (128 B).
@@ -60,7 +62,9 @@ struct DevGlobal {
     u32 internal_error;  // depth exceeded its proven bound (would indicate a bug), etc.
     u32 n_cx;            // RW_BUCKET records appended to CxIdx::list
     u64 cx_total;        // (operation, tile) pairs they expand to = entries needed in CxIdx::runs
-    u64 pad2[3];
+    u32 n_slow;          // tiles k_ranges left to k_pileup_stream (TILE_F_SLOW), listed in slow_list
+    u32 pad_s;
+    u64 pad2[2];
     u64 prim_slots[COUNTER_SLOTS * 8];  // sum = num_detected_primary_alignments (bam_generator.rs:114-118)
     u64 cons_slots[COUNTER_SLOTS * 8];  // sum = number of considered records
     u32 chunk_ctr[8 * 16];              // k_pileup_stream work queues: one dequeue counter per shard, 64 B apart
@@ -174,7 +178,7 @@ __global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g, TileIdx ti, 
     if (c < ti.n_tiles) { ti.tcnt[c] = 0u; ti.fov[c] = 0xffffffffu; cx.cnt[c] = 0u; cx.cur[c] = 0u; }
     if (c == 0) {
         g->first_error = ~0ull; g->hist_cap_total = 0; g->chist_total = 0; g->internal_error = 0;
-        g->n_cx = 0; g->cx_total = 0;
+        g->n_cx = 0; g->cx_total = 0; g->n_slow = 0;
     }
     if (c < COUNTER_SLOTS * 8) { g->prim_slots[c] = 0; g->cons_slots[c] = 0; }
     if (c < 8 * 16) g->chunk_ctr[c] = 0;
@@ -792,18 +796,18 @@ __global__ __launch_bounds__(256) void k_ranges(const u32 *__restrict__ tile_con
                                                 u32 n_tiles, const u32 *__restrict__ tlen, const uint8_t *__restrict__ mask,
                                                 DevContig *ctg, uint4 *__restrict__ desc, TileIdx ti,
                                                 const u32 *__restrict__ tscan, const u32 *__restrict__ ttop, CxIdx cx,
-                                                const DevGlobal *__restrict__ g) {
+                                                DevGlobal *__restrict__ g, u32 *__restrict__ slow_list) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     const u32 c = tile_contig[t];
     DevContig *C = &ctg[c];
     uint4 out = make_uint4(0u, 0u, tlen[c], 0u);
-    u32 cxn = 0, cxo = 0, nrec = 0;
+    u32 cxn = 0, cxo = 0;
     if (C->n_pass != 0 && (mask == nullptr || mask[c])) {
         const u32 rs = C->rec_start, re = C->rec_end;
         // buckets that did not fit were not filled: this pass is discarded and repeated by the host (cov_finish)
         cxn = g->cx_total <= cx.runs_cap ? cx.cnt[t] : 0u;
-        cxo = cx.cscan[t] + cx.ctop[t >> 10]; nrec = re - rs;
+        cxo = cx.cscan[t] + cx.ctop[t >> 10];
         if (C->n_groups != 1u) out.w = 1u;
         if (C->n_groups != 1u || (C->flags & F_POS_UNSORTED)) {
             out.x = rs; out.y = re;  // generic path: every tile of this contig scans the whole span
@@ -816,8 +820,19 @@ __global__ __launch_bounds__(256) void k_ranges(const u32 *__restrict__ tile_con
             out.x = min(out.x, out.y);
         }
     }
+    // Tiles the default kernel (k_pileup_fast) does not take: records of other contigs interleaved in the range (per-record
+    // tid test), or more candidates than its u16 count tables can hold.
+    if (out.x < out.y || cxn) {
+        if (out.w || out.y - out.x + cxn > FAST_MAX_CAND) {
+            out.w |= TILE_F_SLOW;
+            if (slow_list != nullptr) slow_list[atomicAdd(&g->n_slow, 1u)] = t;
+        }
+    }
     if (WANT_HIST) {   // one atomic per wave when all its tiles belong to one contig (the usual case)
-        const u32 cap = min(out.y - out.x + cxn, nrec);   // depth <= candidates + bucket entries, and <= records of the contig
+        // depth <= candidates + bucket entries, and <= considered records of the contig (the runs of one record are
+        // disjoint); the second bound also keeps the arena within R + n_targets bins when contigs interleave
+        const u32 npass = (u32)min(C->n_pass, (u64)0xffffffffu);
+        const u32 cap = min(out.y - out.x + cxn, npass);
         if (__all(c == (u32)__builtin_amdgcn_readfirstlane((int)c))) {
             const u32 m = wave_max_u32(cap);
             if (lane_id() == 0 && m) atomicMax(&C->hist_cap, m);
@@ -1459,7 +1474,9 @@ __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)
 constexpr int STREAM_TW = 1024, STREAM_HB = 512, STREAM_CAP = 512;
 
 template <bool WANT_HIST, bool WRITE_DEPTH>
-__global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
+__global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles, u32 chunk_tiles,
+                                                       const u32 *__restrict__ tile_list, const u32 *__restrict__ n_list) {
+    if (tile_list != nullptr) n_tiles = *n_list;      // slow-tile mode: only the tiles k_ranges listed (any order)
     constexpr int TW = STREAM_TW, HBW = STREAM_HB, CAP = STREAM_CAP, ROWS = TW / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1546,7 +1563,8 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
     while (ch != 0xffffffffu) {
         const u32 ch_next = dynamic ? dequeue() : (ch + n_waves < n_chunks ? ch + n_waves : 0xffffffffu);
         const u32 t0 = a.tile_base + ch * chunk_tiles, t1 = a.tile_base + min((ch + 1) * chunk_tiles, n_tiles);
-        for (u32 t = t0; t < t1; t++) {
+        for (u32 tq = t0; tq < t1; tq++) {
+            const u32 t = tile_list != nullptr ? tile_list[tq] : tq;
             const uint4 ds = a.desc[2 * (size_t)t], dC1 = a.desc[2 * (size_t)t + 1];
             uint2 rw0, rw1;
             load_runs(ds, rw0, rw1);
@@ -1702,6 +1720,234 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
 }
 
 constexpr size_t pileup_stream_smem_bytes() { return (size_t)4 * ((size_t)STREAM_TW * 4 + STREAM_HB * 4); }
+
+// ------------------------------------------------------------------------------------ k_pileup_fast
+// Default pileup.  Same tile / candidate-range / run-word contract as k_pileup_stream (one wave per 1024-base tile,
+// chunks of consecutive tiles, sums kept in registers across the tiles of a contig), different arithmetic:
+//
+//   * two u16 count tables per wave in LDS, S[p] = runs starting at p (clipped to the tile start: the carry-in),
+//     E[p] = runs ending at p.  2 x 2 KiB; one ds_add_u32 per event; a tile with >= 32768 candidates (a u16 could
+//     wrap) is left to k_pileup_stream through the slow-tile list.
+//   * BLOCKED ownership: lane l owns positions [16 l, 16 l + 16) = 32 contiguous bytes of each table, read with two
+//     ds_read_b128.  Depth is then a lane-serial running sum over 16 packed i16 deltas (v_pk_sub_i16 of the two
+//     tables) started from ONE wave prefix sum of the per-lane net deltas: one cross-lane scan per tile instead of
+//     one per 64 bases, no ballot / mbcnt compaction, no second LDS round trip.  Per tile the only LDS dependency is
+//     zero -> scatter -> read (LDS serves one wave's requests in order, so no s_waitcnt between them).
+//   * the next tile's descriptor (scalar loads) and run words (two 8-byte vector loads) are requested before the
+//     statistics of the current tile, so HBM latency overlaps the VALU work of the same wave.
+//   * interior tiles (wholly inside the contig and its end-exclusion window) with < 512 candidates take a loop with
+//     32-bit per-tile partial sums and no bounds tests; everything else takes the general loop (window / contig-end
+//     masks, 64-bit sums, histogram overflow to the arena).
+//   * histogram: one LDS atomic per constant-depth segment of a lane's 16 positions (depth changes only where a delta
+//     is non-zero).
+constexpr int FAST_TW = 1024, FAST_HB = 512;
+constexpr size_t pileup_fast_smem_bytes(bool hist) { return (size_t)4 * ((size_t)FAST_TW * 4 + (hist ? (size_t)FAST_HB * 4 : 0)); }
+
+typedef short v2i16 __attribute__((ext_vector_type(2)));
+
+template <bool WANT_HIST>
+__global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
+    constexpr int TW = FAST_TW, HBW = FAST_HB;
+    constexpr size_t WB = (size_t)TW * 4 + (WANT_HIST ? (size_t)HBW * 4 : 0);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32 *S = reinterpret_cast<u32 *>(smem + (size_t)w * WB);   // 512 dwords = 1024 u16
+    u32 *E = S + TW / 2;
+    u32 *lhist = E + TW / 2;
+    uint4 *S4 = reinterpret_cast<uint4 *>(S), *E4 = reinterpret_cast<uint4 *>(E);
+    const u32 wave_id = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (u32)w)), n_waves = gridDim.x * 4u;
+    if (WANT_HIST) {
+#pragma unroll
+        for (int b = lane; b < HBW; b += 64) lhist[b] = 0u;
+    }
+    u64 sum_d = 0, sum_d2 = 0, proc_win = 0;
+    u32 cov_w = 0, cov_f = 0, mn = 0xffffffffu, mx = 0;
+    int cur_c = -1;
+    u64 hoff = 0; u32 hcap = 0;
+    const u64 excl = a.excl;
+
+    auto hist_add = [&](u32 d, u32 x) {
+        if (__builtin_expect(d < (u32)HBW, 1)) atomicAdd(&lhist[d], x);
+        else hist_add_overflow(a.hist_arena, hoff, hcap, a.g, d, x);
+    };
+    auto flush = [&]() {
+        if (cur_c >= 0) {
+            const u64 s1 = wave_sum_u64(sum_d), s2 = wave_sum_u64(sum_d2);
+            const u32 c1 = wave_sum_u32(cov_w), c2 = wave_sum_u32(cov_f);
+            const u32 m1 = wave_min_u32(mn), m2 = wave_max_u32(mx);
+            DevContig *C = &a.ctg[cur_c];
+            if (lane == 0) {
+                if (s1) atomicAdd(&C->sum_d, s1);
+                if (s2) atomicAdd(&C->sum_d2, s2);
+                if (c1) atomicAdd(&C->cov_win, (u64)c1);
+                if (c2) atomicAdd(&C->cov_full, (u64)c2);
+                if (proc_win) {
+                    atomicAdd(&C->proc_win, proc_win);
+                    atomicMin(&C->min_d, m1);
+                    atomicMax(&C->max_d, m2);
+                }
+            }
+            if (WANT_HIST && proc_win) {
+                lds_fence();
+                const u32 hi_b = min(m2, (u32)HBW - 1u);
+                for (u32 b = m1 + (u32)lane; b <= hi_b; b += 64) {
+                    const u32 x = lhist[b];
+                    if (x) { atomicAdd(&a.hist_arena[hoff + b], x); lhist[b] = 0u; }
+                }
+                lds_fence();
+            }
+        }
+        sum_d = sum_d2 = 0; proc_win = 0; cov_w = cov_f = 0; mn = 0xffffffffu; mx = 0;
+    };
+    auto load_runs = [&](const uint4 &d, uint2 &r0, uint2 &r1) {
+        const u32 i0 = d.x + (u32)lane, i1 = i0 + 64u;
+        r0 = i0 < d.y ? a.runs[i0] : make_uint2(0u, 0u);
+        r1 = i1 < d.y ? a.runs[i1] : make_uint2(0u, 0u);
+    };
+    // tile sequence of this wave: chunks wave_id, wave_id + n_waves, ... of chunk_tiles consecutive tiles each
+    const u32 n_chunks = (n_tiles + chunk_tiles - 1) / chunk_tiles;
+    if (wave_id >= n_chunks) return;
+    u32 ch = wave_id;
+    u32 t = ch * chunk_tiles, t_end = min(t + chunk_tiles, n_tiles);
+    uint4 ds = a.desc[2 * (size_t)(a.tile_base + t)], dC1 = a.desc[2 * (size_t)(a.tile_base + t) + 1];
+    uint2 rw0, rw1;
+    load_runs(ds, rw0, rw1);
+    for (;;) {
+        // ---- next tile of the sequence (wave-uniform), its descriptor requested now
+        u32 tn = t + 1, tn_end = t_end, chn = ch;
+        bool chunk_end = false;
+        if (tn >= t_end) {
+            chunk_end = true;
+            chn = ch + n_waves;
+            tn = chn < n_chunks ? chn * chunk_tiles : 0xffffffffu;
+            tn_end = chn < n_chunks ? min(tn + chunk_tiles, n_tiles) : 0u;
+        }
+        const bool have_next = tn != 0xffffffffu;
+        uint4 nds = make_uint4(0u, 0u, 0u, 0u), ndC1 = make_uint4(0u, 0u, 0u, 0u);
+        if (have_next) { nds = a.desc[2 * (size_t)(a.tile_base + tn)]; ndC1 = a.desc[2 * (size_t)(a.tile_base + tn) + 1]; }
+
+        const u32 c = dC1.x, lo = dC1.y, L = ds.z, cxo = dC1.z, cxn = dC1.w;
+        const bool live = (ds.x < ds.y || cxn != 0u) && !(ds.w & TILE_F_SLOW);
+        uint4 sv0, sv1, ev0, ev1;
+        if (live) {
+            if ((int)c != cur_c) {
+                flush();
+                cur_c = (int)c;
+                if (WANT_HIST) { hoff = a.ctg[c].hist_off; hcap = a.ctg[c].hist_cap; }
+            }
+            // ---- zero, scatter, read back: three LDS phases of one wave, served in order
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+            S4[2 * lane] = z4; S4[2 * lane + 1] = z4; E4[2 * lane] = z4; E4[2 * lane + 1] = z4;
+            asm volatile("" ::: "memory");
+            const u32 hi = lo + TW;
+            auto add_run = [&](u32 s, u32 e) {
+                if (s < hi && e > lo) {
+                    const u32 s0 = s > lo ? s - lo : 0u;
+                    atomicAdd(&S[s0 >> 1], 1u << ((s0 & 1u) << 4));
+                    if (e < hi) { const u32 e0 = e - lo; atomicAdd(&E[e0 >> 1], 1u << ((e0 & 1u) << 4)); }
+                }
+            };
+            auto apply = [&](const uint2 rw, u32 i) {
+                if (rw.y == 0u) return;
+                const u32 type = rw.y >> 30;
+                if (type <= RW_DOUBLE) {
+                    const bool dbl = type == RW_DOUBLE;
+                    const u32 l1 = dbl ? (rw.y & 1023u) : rw.y;
+                    add_run(rw.x, rw.x + l1);
+                    if (dbl) {
+                        const u32 s2 = rw.x + l1 + ((rw.y >> 10) & 255u);
+                        add_run(s2, s2 + ((rw.y >> 18) & 1023u));
+                    }
+                } else if (type == RW_COMPLEX) {
+                    u32 cursor = (u32)a.r.pos[i];
+                    const u32 c0 = a.r.cigar_off[i], c1 = a.r.cigar_off[i + 1];
+                    for (u32 k = c0; k < c1; k++) {
+                        const u32 wd = a.r.cigar[k];
+                        const u32 op = wd & 15u, len = wd >> 4;
+                        if (op == 0u || op == 7u || op == 8u) { add_run(cursor, cursor + len); cursor += len; }
+                        else if (op == 2u || op == 3u) cursor += len;
+                    }
+                }   // RW_BUCKET: delivered through the tile's bucket
+            };
+            apply(rw0, ds.x + (u32)lane);
+            apply(rw1, ds.x + 64u + (u32)lane);
+            for (u32 i = ds.x + 128u + (u32)lane; i < ds.y; i += 64) apply(a.runs[i], i);   // deep tiles only
+            for (u32 j = (u32)lane; j < cxn; j += 64) { const uint2 q = a.cx_runs[(u64)cxo + j]; add_run(q.x, q.y); }   // long reads
+            asm volatile("" ::: "memory");
+            sv0 = S4[2 * lane]; sv1 = S4[2 * lane + 1]; ev0 = E4[2 * lane]; ev1 = E4[2 * lane + 1];
+        }
+        // ---- next tile's run words: in flight during this tile's statistics
+        uint2 nrw0 = make_uint2(0u, 0u), nrw1 = make_uint2(0u, 0u);
+        if (have_next) load_runs(nds, nrw0, nrw1);
+
+        if (live) {
+            // packed i16 deltas of the 16 positions this lane owns
+            const u32 sw[8] = {sv0.x, sv0.y, sv0.z, sv0.w, sv1.x, sv1.y, sv1.z, sv1.w};
+            const u32 ew[8] = {ev0.x, ev0.y, ev0.z, ev0.w, ev1.x, ev1.y, ev1.z, ev1.w};
+            v2i16 dl[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) dl[k] = __builtin_bit_cast(v2i16, sw[k]) - __builtin_bit_cast(v2i16, ew[k]);
+            int net = 0;
+            const v2i16 one2 = {1, 1};
+#pragma unroll
+            for (int k = 0; k < 8; k++) net = __builtin_amdgcn_sdot2(dl[k], one2, net, false);   // sum of 16 i16 in 32 bits
+            int d = wave_incl_scan(net) - net;       // depth just left of this lane's first position
+
+            const bool has_win = 2 * excl < (u64)L;
+            const u32 tlen_t = min((u32)TW, L - lo);
+            const u32 ws = has_win ? (u32)excl : 0u, we = has_win ? (u32)(L - excl) : 0u;
+            const u32 wst = max(ws, lo), wet = min(we, lo + tlen_t);
+            const bool win_any = has_win && wst < wet;
+            if (win_any) proc_win += (u64)(wet - wst);
+            const bool interior = has_win && lo >= ws && lo + (u32)TW <= we;
+            const u32 cand = ds.y - ds.x + cxn;
+            if (interior && cand < (u32)HBW) {
+                // ---- fast loop: every position is inside the window; depth < 512 so 24-bit multiplies and 32-bit
+                // per-tile sums are exact (16 positions x 2^18 per lane)
+                u32 s1t = 0, s2t = 0, cv = 0;
+                u32 seg0 = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int dj = (j & 1) ? (int)dl[j >> 1].y : (int)dl[j >> 1].x;
+                    if (WANT_HIST && j > 0 && dj != 0) { atomicAdd(&lhist[(u32)d], (u32)j - seg0); seg0 = (u32)j; }
+                    d += dj;
+                    const u32 du = (u32)d;
+                    s1t += du;
+                    s2t = __umul24(du, du) + s2t;
+                    cv += du != 0u ? 1u : 0u;
+                    mn = min(mn, du); mx = max(mx, du);
+                }
+                if (WANT_HIST) atomicAdd(&lhist[(u32)d], 16u - seg0);
+                sum_d += s1t; sum_d2 += s2t; cov_w += cv; cov_f += cv;
+            } else {
+                // ---- general loop: window and contig-end tests per position, 64-bit sums, histogram overflow
+                const u32 p0 = lo + 16u * (u32)lane;
+                u32 seg0 = 0;          // first window position (lane-relative) of the open constant-depth segment
+                bool seg_open = false;
+#pragma unroll 4
+                for (int j = 0; j < 16; j++) {
+                    const int dj = (j & 1) ? (int)dl[j >> 1].y : (int)dl[j >> 1].x;
+                    const u32 p = p0 + (u32)j;
+                    const bool in_w = win_any && p >= wst && p < wet;
+                    if (WANT_HIST && seg_open && (dj != 0 || !in_w)) { hist_add((u32)d, (u32)j - seg0); seg_open = false; }
+                    d += dj;
+                    const u32 du = (u32)d;
+                    if (p < L) cov_f += du != 0u ? 1u : 0u;
+                    if (in_w) {
+                        sum_d += du; sum_d2 += (u64)du * du;
+                        cov_w += du != 0u ? 1u : 0u;
+                        mn = min(mn, du); mx = max(mx, du);
+                        if (WANT_HIST && !seg_open) { seg_open = true; seg0 = (u32)j; }
+                    }
+                }
+                if (WANT_HIST && seg_open) hist_add((u32)d, 16u - seg0);
+            }
+        }
+        if (chunk_end) { flush(); cur_c = -1; }
+        if (!have_next) break;
+        t = tn; t_end = tn_end; ch = chn; ds = nds; dC1 = ndC1; rw0 = nrw0; rw1 = nrw1;
+    }
+}
 
 // ------------------------------------------------------------------------------------ interval statistics
 // Per-interval (per-gene, genes.rs:508-535) statistics over a materialised depth arena: one wave per interval.

@@ -405,6 +405,39 @@ def test_workgroup_per_tile_kernel(tile, monkeypatch):
                 check_depth=range(min(3, len(ref_lens))))
 
 
+def test_stream_kernel_all_tiles(monkeypatch):
+    """COVERM_PILEUP=stream: k_pileup_stream (round 1's default, now the slow-tile kernel behind k_pileup_fast) over every
+    tile must agree with the oracle on the same inputs as the default pair of kernels."""
+    monkeypatch.setenv("COVERM_PILEUP", "stream")
+    for name in ["7seqs.reads_for_seq1_and_seq2.bam", "k141_2005182.bam", "eg2.bam"]:
+        compare(load_fixture(name), ff=(True, True, False), excl=75)
+    ref = synth.make_reference(40, 3_000_000, seed=11, min_len=1500, max_len=400_000)
+    b = to_bamdata(synth.make_reads(ref, 60_000, seed=12), ref.lengths, ref.names)
+    compare(b, ff=(True, True, False), excl=75, check_depth=[0, 1, 39], chunks=2)
+    for seed in range(0, 48, 5):
+        ref_lens, batch, rng = _fuzz_case(seed)
+        compare(to_bamdata(batch, ref_lens), ff=(True, True, False), excl=int(rng.choice([0, 75])),
+                check_depth=range(min(3, len(ref_lens))))
+
+
+def test_fast_kernel_deep_and_interleaved_tiles():
+    """A pile deeper than k_pileup_fast's u16 count tables allow (> 32767 candidate runs in one tile: handed to
+    k_pileup_stream through the slow-tile list) and one just below the limit, which stays on the fast kernel with depths
+    far above its 512-bin LDS histogram (general loop, histogram overflow into the arena)."""
+    rng = np.random.default_rng(77)
+    ref_lens = np.asarray([40_000, 9_000, 25_000], dtype=np.int64)
+    n0 = 40_000
+    tid = np.concatenate([np.zeros(n0, np.int32), np.full(30_000, 1, np.int32), np.full(3_000, 2, np.int32)])
+    pos = np.concatenate([np.sort(rng.integers(5_000, 5_400, n0)), np.sort(rng.integers(2_000, 2_300, 30_000)),
+                          np.sort(rng.integers(0, 24_000, 3_000))]).astype(np.int32)
+    n = len(tid)
+    cig = ((rng.integers(60, 160, n).astype(np.uint32)) << 4)
+    batch = RecordBatch.from_arrays(tid, pos, np.zeros(n, np.uint16), np.full(n, 30, np.uint8), rng.integers(0, 4, n),
+                                    np.ones(n, np.uint8), np.full(n, 150), np.arange(n + 1, dtype=np.uint32), cig)
+    for excl in (0, 75):
+        compare(to_bamdata(batch, ref_lens), ff=(True, True, False), excl=excl, check_depth=[0, 1])
+
+
 @pytest.mark.parametrize("neg_frac", [0.02, 0.6])
 def test_identity_sums_with_negative_identities(neg_frac):
     """NM > aligned length gives a negative per-read identity (the reference adds it all the same, contig.rs:208-211).
