@@ -6,19 +6,28 @@
 Workload (BASELINE.json configs[1] at N = 1; configs[3] shape — one BAM per GPU — at N > 1):
 50 M synthetic 150 bp reads over 5 000 contigs (1.0 Gbp), coordinate sorted, methods
 `mean trimmed_mean covered_fraction variance` (SURVEY.md §8d profile, coverm_amd/synth.py).
-A step = one full pass of the hot path over one sample whose record batch is already resident in
-HBM: filter + CIGAR expansion + LDS pileup + statistics on the GPU (cov_finish), histogram fetch,
-C++ finalisation of every estimator for every contig (coverm_amd.host.contig_coverage) and, for
-N > 1, one RCCL gather of the per-contig coverages to rank 0.  Nothing is cached between steps.
 
-Prints ONE JSON line on rank 0 (see the task contract); `roofline` describes the dominant kernel with
-live HIP-event timings taken on the session's own stream; `cpu_baseline` times the CPU oracle
-(a literal port of the reference's scan + estimators) on this box's host cores.
+`value` is measured on basis (i) below, as the bench contract prescribes (inputs resident in HBM when the clock starts); the same
+JSON line carries the two wider bases, each beside a CPU figure taken on the SAME basis (`bases`):
+
+  (i)   device_resident  one step = cov_finish (filter + CIGAR expansion + LDS pileup + statistics on the GPU) + histogram fetch +
+                         C++ finalisation of every estimator for every contig; CPU = oracle scan over records in host memory
+  (ii)  push_inclusive   records in page-locked HOST memory -> cov_push_batch -> cov_finish -> fetch -> finalise; CPU = the same scan
+  (iii) end_to_end       BAM FILE -> TSV through the coverm-amd binary (streamed ingest) on a realistic-entropy BAM (random bases,
+                         Phred-like qualities) of BASELINE config 5's size and flags; CPU = the same decoder (t threads) + oracle scan
+
+`parity_checked`: the oracle's per-contig output over 100 % of the workload is compared with the GPU step's (every f32 bit-for-bit,
+every integer statistic); the run exits non-zero if they differ.  For N > 1 each rank holds one sample and rank 0 receives the
+per-contig coverages through one RCCL gather.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,11 +37,14 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from coverm_amd import host, native, synth  # noqa: E402
-from coverm_amd.engine import FilterConfig, Session  # noqa: E402
+from coverm_amd.engine import FilterConfig, RecordBatch, Session  # noqa: E402
 from coverm_amd.host import CoverageEstimator as E  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 METHODS = ["mean", "trimmed_mean", "covered_fraction", "variance"]
+ALL_METHODS = ["mean", "trimmed_mean", "covered_fraction", "covered_bases", "variance", "length", "count", "reads_per_base", "rpkm",
+               "tpm", "anir"]
+BIN = os.path.join(ROOT, "coverm_amd", "coverm-amd")
 
 
 def estimators(excl=75):
@@ -40,52 +52,213 @@ def estimators(excl=75):
             E.new_estimator_covered_fraction(0.0), E.new_estimator_variance(0.0, excl)]
 
 
-def cpu_baseline(ref, batch, max_seconds=30.0):
-    """Times the CPU oracle (oracle/coverm_oracle.c: contig.rs scan loop + estimators, one thread like the
-    reference's scan) on a prefix of the same workload sized to finish in roughly max_seconds."""
-    import ctypes as C
+# ---------------------------------------------------------------------------------------------- CPU side (oracle = checker + baseline)
+_ORC = None
 
+
+def oracle_native():
+    """The C oracle rebuilt on THIS box with -O3 -march=native for the cpu_baseline legs."""
+    global _ORC
+    if _ORC is None:
+        from oracle import oracle as O
+        src = os.path.join(ROOT, "oracle", "coverm_oracle.c")
+        out = os.path.join(ROOT, "oracle", "_build", "libcoverm_oracle_native.so")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        try:
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-fno-fast-math", "-shared", "-o", out, src, "-lm"])
+            lib = C.CDLL(out)
+            flags = "-O3 -march=native"
+        except Exception:
+            lib = O.lib()
+            flags = "Makefile default (-O3)"
+        lib.orc_out_free.argtypes = [C.c_void_p]
+        _ORC = (lib, flags)
+    return _ORC
+
+
+EMIT_DTYPE = np.dtype([("type", "<i4"), ("pad", "<i4"), ("a", "<i8"), ("b", "<u8"), ("cov", "<f4"), ("name_tid", "<i4")])
+
+
+def oracle_contig_scan(ref_lens, batch, est_params, ff=(True, True, False), fp=None):
+    """orc_contig_coverage (contig.rs:13-253 restated in C) over `batch`, one thread like the reference's scan.
+    Returns (per-contig f32 coverages [n_contigs x n_est] with zero rows printed, reads mapped, seconds)."""
     from oracle import oracle as O
     from oracle.bamio import BamData
+    lib, _ = oracle_native()
     n = batch.n_records
-    # calibrate on 1/50 of the records (whole contigs), then scale the sample
-    def run(n_rec):
-        n_rec = min(n_rec, n)
-        last_tid = int(batch.tid[n_rec - 1])
-        n_rec = int(np.searchsorted(batch.tid, last_tid, side="left")) if n_rec < n else n
-        if n_rec == 0:
-            n_rec = int(np.searchsorted(batch.tid, last_tid, side="right"))
-        z = np.zeros(n_rec, np.int32)
-        b = BamData(ref.names, ref.lengths, batch.tid[:n_rec], batch.pos[:n_rec], batch.flag[:n_rec],
-                    batch.mapq[:n_rec], batch.l_seq[:n_rec].astype(np.int32), batch.nm[:n_rec], batch.nm_kind[:n_rec],
-                    batch.cigar_off[:n_rec + 1], batch.cigar, z, z, z, [], "")
-        est = [O.est_mean(0.0, 75, False), O.est_trimmed_mean(0.05, 0.95, 0.0, 75), O.est_covered_fraction(0.0),
-               O.est_variance(0.0, 75)]
+    z = np.zeros(1, np.int32)
+    b = BamData([], np.asarray(ref_lens, np.int64), batch.tid, batch.pos, batch.flag, batch.mapq, batch.l_seq, batch.nm, batch.nm_kind,
+                batch.cigar_off, batch.cigar, z, z, z, [], "")
+    order = None
+    prim = int(((batch.flag & 0x900) == 0).sum())
+    t_filter = 0.0
+    if fp is not None:     # single-read reader stage (filter.rs:88-116): the oracle's own implementation, timed as part of the scan
+        tf = time.perf_counter()
+        order, prim = O.reader_stage(b, fp)
+        t_filter = time.perf_counter() - tf
+    r = O._Records()
+    keep = dict(tid=batch.tid, pos=batch.pos, flag=batch.flag, mapq=batch.mapq, nm=batch.nm, nm_kind=batch.nm_kind, l_seq=batch.l_seq,
+                cigar_off=batch.cigar_off, cigar=batch.cigar)
+    for k, v in keep.items():
+        setattr(r, k, v.ctypes.data if v.size else None)
+    r.n_records = n
+    if order is not None:
+        order = np.ascontiguousarray(order, np.uint64)
+        r.order = order.ctypes.data
+        r.n_order = len(order)
+    else:
+        r.n_order = n
+    tl = np.ascontiguousarray(ref_lens, np.int64)
+    out = O._Out()
+    rm = O._ReadsMapped()
+    ffc = O.FlagFilter(*ff).c()
+    t0 = time.perf_counter()
+    rc = lib.orc_contig_coverage(C.byref(r), tl.ctypes.data_as(C.c_void_p), C.c_int32(len(tl)), O._params(est_params), C.c_int32(len(est_params)),
+                                 C.c_int32(1), C.byref(ffc), C.c_uint64(prim), C.byref(out), C.byref(rm))
+    dt = time.perf_counter() - t0 + t_filter
+    assert rc == 0, "oracle error %d" % rc
+    ev = np.ctypeslib.as_array(C.cast(out.e, C.POINTER(C.c_uint8)), shape=(out.n * EMIT_DTYPE.itemsize,)).view(EMIT_DTYPE)
+    cov = ev["cov"][ev["type"] == 1].copy().reshape(len(tl), len(est_params))
+    lib.orc_out_free(C.byref(out))
+    return cov, int(rm.num_mapped_reads), dt
 
-        class Null:
-            def start_stoit(self, n): pass
-        r, keep = O._records(b, None)
-        tl = np.ascontiguousarray(b.ref_lens, np.int64)
-        out = O._Out()
-        rm = O._ReadsMapped()
-        ff = O.FlagFilter(True, True, False).c()
-        prim = int(((b.flag & 0x900) == 0).sum())
+
+def oracle_estimators(excl=75, methods=METHODS):
+    from oracle import oracle as O
+    m = {"mean": lambda: O.est_mean(0.0, excl, False), "trimmed_mean": lambda: O.est_trimmed_mean(0.05, 0.95, 0.0, excl),
+         "covered_fraction": lambda: O.est_covered_fraction(0.0), "covered_bases": lambda: O.est_covered_bases(0.0),
+         "variance": lambda: O.est_variance(0.0, excl), "length": O.est_length, "count": O.est_read_count,
+         "reads_per_base": O.est_reads_per_base, "rpkm": lambda: O.est_rpkm(0.0), "tpm": lambda: O.est_tpm(0.0), "anir": O.est_anir}
+    return [m[k]() for k in methods]
+
+
+def parity_check(ref, batch, gpu_cov, gpu_stats, gpu_hist):
+    """GPU step output == oracle over the FULL workload: per-contig f32 of all four methods bit-for-bit, and the integer
+    sufficient statistics + histograms (oracle's orc_integer_stats)."""
+    from oracle import oracle as O
+    from oracle.bamio import BamData
+    cov, mapped, dt = oracle_contig_scan(ref.lengths, batch, oracle_estimators())
+    n = len(ref.lengths)
+    g = gpu_cov.reshape(n, len(METHODS))
+    f32_equal = bool((g.view(np.uint32) == cov.view(np.uint32)).all())
+    z = np.zeros(1, np.int32)
+    b = BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq, batch.l_seq.astype(np.int32), batch.nm, batch.nm_kind,
+                batch.cigar_off, batch.cigar, z, z, z, [], "")
+    exp, exp_hist, _ = O.integer_stats(b, O.FlagFilter(True, True, False), None, 75)
+    ints_equal = True
+    for fld in ("n_primary", "n_pass", "n_nonsupp", "sum_nm", "sum_indel", "win_sum_d", "win_sum_d2", "win_covered", "full_covered",
+                "win_min_d", "win_max_d", "hist_len"):
+        ints_equal &= bool((gpu_stats[fld] == exp[fld]).all())
+    hist_equal = len(gpu_hist) == len(exp_hist) and bool((gpu_hist == exp_hist).all())
+    ok = f32_equal and ints_equal and hist_equal
+    return dict(contigs=n, methods=METHODS, reads=batch.n_records, equal=ok, f32_bitwise_equal=f32_equal, integer_stats_equal=ints_equal,
+                histograms_equal=hist_equal, oracle_scan_s=dt), (mapped, dt)
+
+
+# ---------------------------------------------------------------------------------------------- pinned host arrays
+def pinned_copy(batch):
+    """The batch copied into page-locked memory from cov_host_alloc (what the decoder fills in the product)."""
+    L = native.lib()
+    L.cov_host_alloc.restype = C.c_void_p
+    L.cov_host_alloc.argtypes = [C.c_size_t]
+    L.cov_host_free.argtypes = [C.c_void_p]
+    out, ptrs = {}, []
+    for k in ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar"):
+        a = getattr(batch, k)
+        p = L.cov_host_alloc(max(a.nbytes, 1))
+        assert p, "cov_host_alloc failed"
+        ptrs.append(p)
+        v = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(a.nbytes, 1),))[:a.nbytes].view(a.dtype)
+        v[:] = a
+        out[k] = v
+    return RecordBatch(**out), ptrs
+
+
+def finalise(ref, est, stats, summ, hist, name="sample0"):
+    taker = host.CoverageTaker.new_cached_single_float_coverage_taker(len(est))
+    sample = host.SampleResult(name, stats, hist, int(summ.num_detected_primary_alignments))
+    rm = host.contig_coverage(ref.names, ref.lengths, [sample], taker, est, True)
+    return taker, rm
+
+
+# ---------------------------------------------------------------------------------------------- end to end
+def end_to_end(a, threads):
+    """Basis (iii): BAM file -> TSV.  Config 5's size and flags (200 M reads, --min-read-percent-identity 95 --min-read-aligned-length 50
+    --proper-pairs-only, all methods) on a realistic-entropy BAM; GPU = the coverm-amd binary (streamed ingest); CPU = the same decoder
+    with the same thread count, then the oracle's scan (one thread, like the reference's).  Output tables must be identical."""
+    from coverm_amd import bam as cbam
+    from oracle import oracle as O
+    res = dict(reads=a.e2e_reads, threads=threads)
+    tmpdir = tempfile.mkdtemp(prefix="covbench", dir=a.tmp)
+    try:
+        free = shutil.disk_usage(tmpdir).free
+        reads = a.e2e_reads
+        if free < reads * 90:
+            reads = max(1_000_000, int(free // 180))
+            res["note_disk"] = "only %.1f GB free under %s: end-to-end leg reduced to %d reads" % (free / 1e9, tmpdir, reads)
+        t0 = time.time()
+        ref = synth.make_reference(a.contigs, a.bp, seed=1)
+        batch = synth.make_reads(ref, reads, seed=3)
+        res["generation_s"] = time.time() - t0
+        path = os.path.join(tmpdir, "config5.bam")
+        t0 = time.time()
+        cbam.write_bam(path, ref.names, ref.lengths, batch, with_seq=2, level=1, threads=threads)
+        res["bam_write_s"] = time.time() - t0
+        size = os.path.getsize(path)
+        res.update(reads=reads, bam_bytes=size, bam_bytes_per_read=size / reads, seq_qual="random bases, Phred-like binned qualities, Illumina-style names")
+        flags = ["--min-read-percent-identity", "95", "--min-read-aligned-length", "50", "--proper-pairs-only"]
+        out_tsv = os.path.join(tmpdir, "gpu.tsv")
+        cmd = [BIN, "contig", "-b", path, "-m"] + ALL_METHODS + flags + ["-t", str(threads), "-o", out_tsv]
+        best = None
+        env = dict(os.environ, COVERM_CLI_TIMING="1")
+        for rep in range(2):        # first run pays the page cache fill of a file just written (it is warm: we wrote it) and HIP start-up
+            t0 = time.perf_counter()
+            p = subprocess.run(["/usr/bin/time", "-f", "MAXRSS_KB %M", ] + cmd, capture_output=True, text=True, env=env)
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                raise RuntimeError("coverm-amd failed: " + p.stderr[-2000:])
+            rss = [int(l.split()[1]) for l in p.stderr.splitlines() if l.startswith("MAXRSS_KB")]
+            if best is None or dt < best[0]:
+                best = (dt, rss[0] * 1024 if rss else None, p.stderr)
+        gpu_s, gpu_rss, gpu_err = best
+        mapped = [l for l in gpu_err.splitlines() if "reads mapped out of" in l]
+        timing = [l for l in gpu_err.splitlines() if "stream read" in l or "ingest (decode+push)" in l]
+        # ---- CPU, same basis: same decoder + oracle scan
+        L = cbam._lib()
+        err = C.create_string_buffer(512)
         t0 = time.perf_counter()
-        rc = O.lib().orc_contig_coverage(C.byref(r), tl.ctypes.data_as(C.c_void_p), C.c_int32(len(tl)), O._params(est),
-                                         C.c_int32(len(est)), C.c_int32(0), C.byref(ff), C.c_uint64(prim),
-                                         C.byref(out), C.byref(rm))
-        dt = time.perf_counter() - t0
-        O.lib().orc_out_free(C.byref(out))
-        assert rc == 0
-        return int(rm.num_mapped_reads), dt, n_rec
-    reads, dt, n_rec = run(max(1000, n // 50))
-    if n_rec < n:
-        scale = min(n / n_rec, max(1.0, 0.6 * max_seconds / max(dt, 1e-3)))
-        reads, dt, n_rec = run(int(n_rec * scale))
-    return dict(value=reads / dt, unit="aligned reads/s", cores=1, kind="port",
-                sample="first %d of %d records (%.0f%% of the workload, whole contigs), %.1f s; oracle/coverm_oracle.c "
-                       "= literal C port of CoverM 0.8.0's scan loop + estimators, not the coverm binary"
-                       % (n_rec, n, 100.0 * n_rec / n, dt))
+        h = L.covh_bam_open(path.encode(), threads, 0, err, 512)      # the decode itself, timed without Python-side copies
+        dec_s = time.perf_counter() - t0
+        assert h, err.value
+        nrec, ncg = int(L.covh_bam_n_records(h)), int(L.covh_bam_n_cigar(h))
+        cb = native.CovBatch()
+        L.covh_bam_batch(h, C.byref(cb))
+        cp = cbam._copy
+        recs = RecordBatch(cp(cb.tid, np.int32, nrec), cp(cb.pos, np.int32, nrec), cp(cb.flag, np.uint16, nrec), cp(cb.mapq, np.uint8, nrec),
+                           cp(cb.nm, np.uint32, nrec), cp(cb.nm_kind, np.uint8, nrec), cp(cb.l_seq, np.uint32, nrec),
+                           cp(cb.cigar_off, np.uint32, nrec + 1), cp(cb.cigar, np.uint32, ncg))
+        L.covh_bam_close(h)
+        fp = O.FilterParameters(O.FlagFilter(False, True, False), 50, float(np.float32(0.95)), 0.0, 255, 0, 0.0, 0.0)
+        est = oracle_estimators(75, ALL_METHODS)
+        cov, cpu_mapped, scan_s = oracle_contig_scan(ref.lengths, recs, est, ff=(False, True, False), fp=fp)
+        # table equality: the oracle's CLI text would take minutes in Python at this size; compare the numbers the tables are made of
+        gpu_tab = np.loadtxt(out_tsv, delimiter="\t", skiprows=1, usecols=range(1, 1 + len(ALL_METHODS)), dtype=np.float64, ndmin=2)
+        rpkm_col, tpm_col = ALL_METHODS.index("rpkm"), ALL_METHODS.index("tpm")
+        plain = [k for k in range(len(ALL_METHODS)) if k not in (rpkm_col, tpm_col)]     # those two are normalised by the printer
+        same = gpu_tab.shape[0] == cov.shape[0] and bool(np.array_equal(gpu_tab[:, plain].astype(np.float32), cov[:, plain]))
+        considered = cpu_mapped
+        res.update(
+            gpu=dict(seconds=gpu_s, reads_per_s=reads / gpu_s, max_rss_bytes=gpu_rss, command=" ".join(["coverm-amd"] + cmd[1:]),
+                     stderr_mapped=mapped[:1], stderr_timing=timing[:4]),
+            cpu=dict(decode_s=dec_s, scan_s=scan_s, reads_per_s_serial=reads / (dec_s + scan_s), reads_per_s_overlapped=reads / max(dec_s, scan_s),
+                     decoder="csrc/host_bam.cpp covh_bam_open, %d threads" % threads, scan="oracle/coverm_oracle.c, 1 thread, %s" % oracle_native()[1],
+                     note="the reference overlaps htslib's inflate pool with its single scan thread: its rate lies between the two figures, "
+                          "at or below the overlapped one"),
+            speedup_vs_cpu_overlapped=(reads / gpu_s) / (reads / max(dec_s, scan_s)), speedup_vs_cpu_serial=(reads / gpu_s) / (reads / (dec_s + scan_s)),
+            target=">= 10x the CPU path (BASELINE.json north_star)", tables_equal=same, considered_reads=considered)
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    return res
 
 
 def main():
@@ -96,7 +269,10 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("COVERM_BENCH_READS", 50_000_000)))
     ap.add_argument("--contigs", type=int, default=5000)
     ap.add_argument("--bp", type=int, default=1_000_000_000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (parity check, CPU baselines) and the end-to-end leg")
+    ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("COVERM_BENCH_E2E_READS", 200_000_000)))
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--tmp", default=os.environ.get("COVERM_BENCH_TMP", tempfile.gettempdir()))
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -141,25 +317,23 @@ def main():
     def step():
         stats, summ = sess.finish()
         hist = sess.hist()
-        taker = host.CoverageTaker.new_cached_single_float_coverage_taker(len(est))
-        sample = host.SampleResult("sample%d" % rank, stats, hist, int(summ.num_detected_primary_alignments))
-        rm = host.contig_coverage(ref.names, ref.lengths, [sample], taker, est, True)
+        taker, rm = finalise(ref, est, stats, summ, hist, "sample%d" % rank)
         if dist:
             # per-contig coverages of this sample -> rank 0 (one gather over RCCL/xGMI)
             cov = taker.cached_coverages(0)   # n_contigs x n_estimators f32, contig order (zeros printed)
             t = torch.from_numpy(cov).to(xdev)
             dist.gather(t, gather_buf, dst=0)
-        return summ, rm, taker
+        return summ, rm, taker, stats, hist
 
     for _ in range(a.warmup):
-        summ, rm, taker = step()
+        summ, rm, taker, stats, hist = step()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kms = {k: 0.0 for k in native.KERNEL_NAMES.values()}
     for _ in range(a.steps):
-        summ, rm, taker = step()
+        summ, rm, taker, stats, hist = step()
         for k, v in sess.kernel_ms().items():
             kms[k] += v[0]
     if dist:
@@ -176,31 +350,52 @@ def main():
         total_reads = int(tt[1].item())
     else:
         total_reads = considered
+    gpu_cov = taker.cached_coverages(0)
+    pipe_bytes = sess.algorithmic_bytes()
+    n_tiles = sess_tiles(sess, ref)
+    sess.close()
+    del dt
+    torch.cuda.empty_cache()
 
+    exit_code = 0
     if rank == 0:
         for k in kms:
             kms[k] /= a.steps
-        dom = max(kms, key=kms.get)
-        kid = {v: k for k, v in native.KERNEL_NAMES.items()}[dom]
         R = batch.n_records
         ncig = int(batch.cigar_off[-1]) - int(batch.cigar_off[0])
         # algorithmic HBM bytes per launch (DESIGN.md "Algorithmic bytes")
         kbytes = {"k_prep": R * 24 + ncig * 4 + R * 8,                    # SoA + CIGAR read once, run words written
-                  "k_pileup": R * 8 + sess_tiles(sess, ref) * 32 + len(ref.lengths) * 160,  # run words + tile descriptors + results
-                  "k_ranges": sess_tiles(sess, ref) * 40, "k_identity": R * 32, "k_hist": 0}
-        achieved = kbytes[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
-        pipe_bytes = sess.algorithmic_bytes()
+                  "k_pileup": R * 8 + n_tiles * 32 + len(ref.lengths) * 160,  # run words + tile descriptors + results
+                  "k_ranges": n_tiles * 40, "k_identity": R * 32, "k_hist": 0}
+        dom = max(kms, key=kms.get)
         pipe_ms = sum(kms.values())
-        # what an arena-in-HBM design would have to move for the same job (SURVEY.md §8d formula)
-        A = int((ref.lengths + 1).sum())
-        E_runs = int((((batch.cigar & 15) == 0) | ((batch.cigar & 15) == 7) | ((batch.cigar & 15) == 8)).sum())
-        arena_bytes = R * 24 + ncig * 4 + E_runs * 16 + A * 4 * 3
         aligned_bp = synth.aligned_bases(batch) * (considered / max(1, R))
+        prof = profile_numbers()
+        per_kernel = {}
+        for k in ("k_prep", "k_pileup"):
+            ach = kbytes[k] / (kms[k] * 1e-3) / 1e9 if kms[k] > 0 else 0.0
+            per_kernel[k] = {"kernel_ms": kms[k], "algorithmic_bytes": kbytes[k], "hbm_achieved_GBps": ach, "hbm_frac_of_8TBps": ach / HBM_PEAK_GBPS,
+                             "hbm_traffic_bytes_from_committed_profile": prof.get("traffic", {}).get(k), "pipes_from_committed_profile": prof.get("pipes", {}).get(k)}
+        domk = per_kernel.get(dom, {})
+        pipes = domk.get("pipes_from_committed_profile") or {}
+        if dom == "k_pileup" and pipes:
+            roof = {"bound": "valu+lds (on-chip: the depth array never leaves LDS)", "kernel": "k_pileup_fast", "achieved": pipes.get("valu_busy_frac"),
+                    "peak": 1.0, "unit": "fraction of VALU issue cycles (wave64 integer op = 2 cycles full rate, 4 cycles for mad_u24 / SDWA / DPP / 3-operand, "
+                    "measured by tools/ubench/valu_rate.hip)", "frac": pipes.get("valu_busy_frac"), "lds_busy_frac": pipes.get("lds_busy_frac"),
+                    "traffic": domk.get("hbm_traffic_bytes_from_committed_profile"), "traffic_source": "committed rocprofv3 PMC profile (profiles/), not this run"}
+        else:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": domk.get("hbm_achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": (domk.get("hbm_achieved_GBps") or 0.0) / HBM_PEAK_GBPS, "traffic": domk.get("hbm_traffic_bytes_from_committed_profile"),
+                    "traffic_source": "committed rocprofv3 PMC profile (profiles/), not this run"}
+        roof.update({"kernel_ms": kms.get(dom), "all_kernels_ms": kms, "kernels": per_kernel,
+                     "pipeline": {"algorithmic_bytes": pipe_bytes, "kernels_ms": pipe_ms, "achieved_GBps": pipe_bytes / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0,
+                                  "frac_of_8TBps": pipe_bytes / (pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if pipe_ms else 0.0}})
         out = {
             "metric": "aligned reads/s through coverm contig (mean trimmed_mean covered_fraction variance)",
             "value": total_reads * a.steps / elapsed, "unit": "aligned reads/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32 depth / u64 sums / f32 estimators", "data": "synthetic",
+            "value_basis": "(i) device_resident: records already in HBM when the clock starts (bench contract); bases (ii) and (iii) below include the host side",
             "config": {"workload": "coverm contig, %d-read synthetic sorted BAM over %d contigs (%.2f Gbp) per GPU, "
                                    "--methods %s, records resident in HBM" % (a.reads, a.contigs,
                                                                              ref.lengths.sum() / 1e9, " ".join(METHODS)),
@@ -208,43 +403,78 @@ def main():
                        "samples": world, "sharding": ("FUNCTIONAL CHECK ONLY: ranks share one GPU, gloo exchange" if share else
                                                        "one sample per GPU, RCCL gather of per-contig coverages") if world > 1 else "single GPU"},
             "gbp_per_s": aligned_bp * world * a.steps / elapsed / 1e9,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": profile_traffic(dom),
-                         "kernel_ms": kms[dom], "algorithmic_bytes": kbytes[dom],
-                         "all_kernels_ms": kms,
-                         "note": "per-base depth lives only in LDS, so the dominant kernel's compulsory HBM bytes are ~0.4 GB "
-                                 "per launch and its HBM fraction is small by construction; it is bound by VALU issue (~55-60 % busy, "
-                                 "4 waves/SIMD) and dependent LDS round trips (DESIGN.md sections 4-5, profiles/r01g_*); "
-                                 "SURVEY 8d's arena-in-HBM byte count for the same job is reported as arena_design_equivalent",
-                         "pipeline": {"algorithmic_bytes": pipe_bytes, "kernels_ms": pipe_ms,
-                                      "achieved_GBps": pipe_bytes / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0},
-                         "arena_design_equivalent": {"bytes": arena_bytes,
-                                                     "GBps_if_moved_in_same_time": arena_bytes / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0}},
+            "roofline": roof,
             "host": {"generation_s": gen_s, "nproc": os.cpu_count()},
         }
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ref, batch)
+            threads = max(1, min(os.cpu_count() or 1, int(os.environ.get("COVERM_BENCH_THREADS", os.cpu_count() or 1))))
+            par, (cpu_mapped, cpu_dt) = parity_check(ref, batch, gpu_cov, stats, hist)
+            out["parity_checked"] = par
+            if not par["equal"]:
+                exit_code = 3
+            cpu_rate = cpu_mapped / cpu_dt
+            out["cpu_baseline"] = dict(value=cpu_rate, unit="aligned reads/s", cores=1, kind="port",
+                                       sample="100%% of the workload (%d records, whole contigs), %.1f s; oracle/coverm_oracle.c (%s) = literal C port of "
+                                              "CoverM 0.8.0's scan loop + estimators, records already decoded in host memory; not the coverm binary"
+                                              % (R, cpu_dt, oracle_native()[1]))
+            # ---- basis (ii): records in page-locked host memory -> push -> finish -> fetch -> finalise
+            hb, ptrs = pinned_copy(batch)
+            s2 = Session(local_rank, FilterConfig(), 75, want_hist, want_id)
+            s2.set_targets(ref.lengths)
+            push_s = []
+            for it in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                s2.reset()
+                s2.push(hb)
+                st2, su2 = s2.finish()
+                h2 = s2.hist()
+                finalise(ref, est, st2, su2, h2)
+                push_s.append(time.perf_counter() - t0)
+            s2.close()
+            L = native.lib()
+            for p in ptrs:
+                L.cov_host_free(p)
+            best = min(push_s[1:])
+            out["bases"] = {
+                "device_resident": {"gpu_reads_per_s": total_reads * a.steps / elapsed, "ms": elapsed / a.steps * 1e3,
+                                    "cpu_reads_per_s": cpu_rate, "cpu": "oracle scan, 1 thread, records in host memory"},
+                "push_inclusive": {"gpu_reads_per_s": considered / best, "ms": best * 1e3, "bytes_over_pcie": int(pipe_bytes - len(ref.lengths) * 160),
+                                   "pcie_GBps": (pipe_bytes - len(ref.lengths) * 160) / best / 1e9,
+                                   "cpu_reads_per_s": cpu_rate, "cpu": "oracle scan, 1 thread, records in host memory (same starting point)",
+                                   "speedup_vs_cpu": considered / best / cpu_rate},
+            }
+            if not a.no_e2e and world == 1:
+                try:
+                    out["bases"]["end_to_end"] = end_to_end(a, threads)
+                    if not out["bases"]["end_to_end"].get("tables_equal", False):
+                        exit_code = 3
+                except Exception as ex:   # the headline legs above stand on their own
+                    out["bases"]["end_to_end"] = {"error": repr(ex)[:1000]}
         print(json.dumps(out), flush=True)
-    sess.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(exit_code)
 
 
 def sess_tiles(sess, ref):
-    """Tiles of the configured pileup kernel: 1024 bases per wave (streaming kernel) unless COVERM_PILEUP=tile."""
+    """Tiles of the configured pileup kernel: 1024 bases per wave (fast / streaming kernels) unless COVERM_PILEUP=tile."""
     tile = int(os.environ.get("COVERM_TILE", 4096)) if os.environ.get("COVERM_PILEUP") == "tile" else 1024
     return int(((ref.lengths + tile - 1) // tile).sum())
 
 
-def profile_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary of this workload, if present."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(p) as fh:
-            return json.load(fh).get(kernel)
-    except Exception:
-        return None
+def profile_numbers():
+    """Per-kernel HBM bytes and pipe utilisation from the committed rocprofv3 PMC summary of this workload (profiles/), if present.
+    They describe the committed build, not this run — labelled as such in the JSON."""
+    out = {}
+    for name, key in (("pmc_traffic.json", "traffic"), ("pmc_pipes.json", "pipes")):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                out[key] = json.load(fh)
+        except Exception:
+            out[key] = {}
+    return out
 
 
 if __name__ == "__main__":

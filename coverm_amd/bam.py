@@ -83,8 +83,84 @@ def read_alignment_file(path: str, threads: int = None, want_names: bool = True)
         L.covh_bam_close(h)
 
 
-def write_bam(path: str, names, lens, batch: RecordBatch, with_seq: bool = True, level: int = 1, threads: int = None):
-    """Threaded BGZF/BAM writer (covh_bam_write) for synthetic inputs."""
+def stream_batches(path: str, threads: int = None, span_index: int = 0, span_count: int = 1, stats: dict = None):
+    """Generator over the streamed reader (covh_bam_stream_*): yields (ref_names, ref_lens) first, then one RecordBatch
+    (copied out of the page-locked ring) per window.  `stats`, if given, receives peak_bytes / n_records / timing."""
+    L = _lib()
+    if not getattr(L, "_stream_bound", False):
+        L.covh_bam_stream_open.restype = C.c_void_p
+        L.covh_bam_stream_open.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
+        L.covh_bam_stream_close.argtypes = [C.c_void_p]
+        L.covh_bam_stream_close.restype = None
+        L.covh_bam_stream_n_targets.restype = C.c_uint32
+        L.covh_bam_stream_n_targets.argtypes = [C.c_void_p]
+        L.covh_bam_stream_target_name.restype = C.c_char_p
+        L.covh_bam_stream_target_name.argtypes = [C.c_void_p, C.c_uint32]
+        L.covh_bam_stream_target_len.restype = C.c_uint64
+        L.covh_bam_stream_target_len.argtypes = [C.c_void_p, C.c_uint32]
+        L.covh_bam_stream_next.argtypes = [C.c_void_p, C.POINTER(CovBatch)]
+        L.covh_bam_stream_error.restype = C.c_char_p
+        L.covh_bam_stream_error.argtypes = [C.c_void_p]
+        L.covh_bam_stream_peak_bytes.restype = C.c_uint64
+        L.covh_bam_stream_peak_bytes.argtypes = [C.c_void_p]
+        L.covh_bam_stream_n_records.restype = C.c_uint64
+        L.covh_bam_stream_n_records.argtypes = [C.c_void_p]
+        L.covh_bam_stream_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.covh_bam_stream_timing.restype = None
+        L._stream_bound = True
+    if threads is None:
+        threads = min(16, os.cpu_count() or 1)
+    err = C.create_string_buffer(512)
+    h = L.covh_bam_stream_open(path.encode(), threads, span_index, span_count, err, 512)
+    if not h:
+        raise IOError(err.value.decode() or "cannot read %s" % path)
+    try:
+        nt = L.covh_bam_stream_n_targets(h)
+        yield ([L.covh_bam_stream_target_name(h, i).decode() for i in range(nt)],
+               np.asarray([L.covh_bam_stream_target_len(h, i) for i in range(nt)], dtype=np.int64))
+        cb = CovBatch()
+        while True:
+            rc = L.covh_bam_stream_next(h, C.byref(cb))
+            if rc < 0:
+                raise IOError(L.covh_bam_stream_error(h).decode())
+            if rc == 0:
+                break
+            n = int(cb.n_records)
+            off = _copy(cb.cigar_off, np.uint32, n + 1)
+            nc = int(off[-1])
+            yield RecordBatch(_copy(cb.tid, np.int32, n), _copy(cb.pos, np.int32, n), _copy(cb.flag, np.uint16, n),
+                              _copy(cb.mapq, np.uint8, n), _copy(cb.nm, np.uint32, n), _copy(cb.nm_kind, np.uint8, n),
+                              _copy(cb.l_seq, np.uint32, n), off, _copy(cb.cigar, np.uint32, nc))
+        if stats is not None:
+            t = (C.c_double * 5)()
+            L.covh_bam_stream_timing(h, t)
+            stats.update(peak_bytes=int(L.covh_bam_stream_peak_bytes(h)), n_records=int(L.covh_bam_stream_n_records(h)),
+                         timing=dict(read=t[0], inflate=t[1], parse=t[2], wait_inflate=t[3], wait_parse=t[4]))
+    finally:
+        L.covh_bam_stream_close(h)
+
+
+def read_streamed(path: str, threads: int = None, span_index: int = 0, span_count: int = 1, stats: dict = None):
+    """All batches of the streamed reader concatenated: (ref_names, ref_lens, RecordBatch)."""
+    it = stream_batches(path, threads, span_index, span_count, stats)
+    names, lens = next(it)
+    parts = list(it)
+    if not parts:
+        z = np.zeros(0, np.uint32)
+        return names, lens, RecordBatch(z.astype(np.int32), z.astype(np.int32), z.astype(np.uint16), z.astype(np.uint8), z,
+                                        z.astype(np.uint8), z, np.zeros(1, np.uint32), z)
+    off = [0]
+    for p_ in parts:
+        off.append(off[-1] + int(p_.cigar_off[-1]))
+    coff = np.concatenate([p_.cigar_off[:-1].astype(np.int64) + o for p_, o in zip(parts, off)] + [[off[-1]]]).astype(np.uint32)
+    cat = lambda k: np.concatenate([getattr(p_, k) for p_ in parts])
+    return names, lens, RecordBatch(cat("tid"), cat("pos"), cat("flag"), cat("mapq"), cat("nm"), cat("nm_kind"), cat("l_seq"),
+                                    coff, cat("cigar"))
+
+
+def write_bam(path: str, names, lens, batch: RecordBatch, with_seq=True, level: int = 1, threads: int = None):
+    """Threaded BGZF/BAM writer (covh_bam_write) for synthetic inputs.  with_seq: False / 0 = SEQ '*', True / 1 = constant
+    SEQ and QUAL, 2 = realistic entropy (random bases, Phred-like qualities, Illumina-style names)."""
     L = _lib()
     if threads is None:
         threads = min(32, os.cpu_count() or 1)

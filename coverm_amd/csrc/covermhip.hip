@@ -5,7 +5,9 @@
 #include "pileup_kernels.hip.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
+#include <dlfcn.h>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -16,6 +18,17 @@
 #include "../../include/covermhip.h"
 
 using namespace covk;
+
+// The C ABI structs are mirrored by hand elsewhere (numpy dtype in coverm_amd/native.py, #[repr(C)] in INTEGRATION.md):
+// pin their layout here so that a change in include/covermhip.h cannot silently diverge from those mirrors.
+static_assert(sizeof(cov_config) == 40 && offsetof(cov_config, min_aligned_length) == 12 && offsetof(cov_config, min_percent_identity) == 16 &&
+              offsetof(cov_config, contig_end_exclusion) == 24 && offsetof(cov_config, want) == 32, "cov_config layout");
+static_assert(sizeof(cov_batch) == 80 && offsetof(cov_batch, cigar) == 64 && offsetof(cov_batch, n_records) == 72, "cov_batch layout");
+static_assert(sizeof(cov_contig_stats) == 128 && offsetof(cov_contig_stats, sum_identity_primary) == 40 && offsetof(cov_contig_stats, win_sum_d) == 56 &&
+              offsetof(cov_contig_stats, first_record) == 88 && offsetof(cov_contig_stats, win_min_d) == 104 && offsetof(cov_contig_stats, hist_len) == 112 &&
+              offsetof(cov_contig_stats, hist_off) == 120, "cov_contig_stats layout");
+static_assert(sizeof(cov_summary) == 32 && offsetof(cov_summary, hist_total) == 24, "cov_summary layout");
+static_assert(sizeof(cov_interval) == 24 && sizeof(cov_interval_stats) == 56, "interval struct layout");
 
 namespace {
 
@@ -86,9 +99,14 @@ struct cov_session {
     DevBuf<DevInterval> d_iv; DevBuf<DevIntervalStats> d_ivst; DevBuf<unsigned long long> d_ivhist; uint64_t ivhist_total = 0;
     DevBuf<uint8_t> d_mask;
     bool have_mask = false;
+    // results of the device pipeline live in ONE block [DevGlobal][DevContig x n_targets] (d_res): one DMA brings them to
+    // the host, and cov_gather sends the same block over RCCL.  d_glob / d_ctg are views into it (never freed themselves).
+    DevBuf<uint8_t> d_res;
     DevBuf<DevContig> d_ctg;
     DevBuf<DevGlobal> d_glob;
     DevBuf<uint4> d_desc;
+    // cov_gather (root session): every rank's block, device and page-locked host copies
+    DevBuf<uint8_t> d_gather; uint8_t *h_gather = nullptr; size_t h_gather_cap = 0; uint32_t gather_n = 0; size_t gather_block = 0;
 
     // record store (owned) or adopted device batch
     DevBuf<int32_t> s_tid, s_pos;
@@ -126,6 +144,15 @@ struct cov_session {
 };
 
 namespace {
+
+size_t result_block_bytes(u32 n_targets) { return sizeof(DevGlobal) + (size_t)std::max<u32>(n_targets, 1) * sizeof(DevContig); }
+hipError_t bind_result_block(cov_session *s, u32 n_targets) {
+    hipError_t e = s->d_res.reserve(result_block_bytes(n_targets), s->stream);
+    if (e != hipSuccess) return e;
+    s->d_glob.p = reinterpret_cast<DevGlobal *>(s->d_res.p); s->d_glob.cap = 1;
+    s->d_ctg.p = reinterpret_cast<DevContig *>(s->d_res.p + sizeof(DevGlobal)); s->d_ctg.cap = std::max<u32>(n_targets, 1);
+    return hipSuccess;
+}
 
 Records records_of(const cov_session *s) {
     Records r{};
@@ -348,7 +375,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete s; return COV_ERR_HIP; }
     for (int k = 0; k < COV_K_COUNT; k++)
         for (int j = 0; j < 2; j++) (void)hipEventCreate(&s->ev[k][j]);
-    e = s->d_glob.reserve(1, s->stream);
+    e = bind_result_block(s, 1);
     if (e != hipSuccess) { g_create_error = std::string("hipMalloc: ") + hipGetErrorString(e); cov_destroy(s); return COV_ERR_HIP; }
     *out = s;
     return COV_OK;
@@ -362,7 +389,9 @@ void cov_destroy(cov_session *s) {
     s->d_tile_first.release(); s->d_tcnt.release(); s->d_fov.release(); s->d_tscan.release(); s->d_ttop.release(); s->d_slow_list.release();
     s->d_ctg_scratch.release(); s->d_depth_all.release(); s->d_depth_off.release(); s->d_iv.release(); s->d_ivst.release(); s->d_ivhist.release();
     s->d_cx_list.release(); s->d_cx_cnt.release(); s->d_cx_cur.release(); s->d_cx_scan.release(); s->d_cx_top.release(); s->d_cx_runs.release();
-    s->d_ctg.release(); s->d_glob.release(); s->d_desc.release();
+    s->d_res.release(); s->d_ctg.p = nullptr; s->d_glob.p = nullptr; s->d_desc.release(); s->d_gather.release();
+    if (s->h_gather) (void)hipHostFree(s->h_gather);
+    s->h_gather = nullptr;
     if (s->h_res) (void)hipHostFree(s->h_res);
     s->h_res = nullptr; s->h_res_cap = 0; s->h_ctg = nullptr;
     s->s_tid.release(); s->s_pos.release(); s->s_flag.release(); s->s_mapq.release(); s->s_nmk.release();
@@ -411,7 +440,7 @@ cov_status cov_set_targets(cov_session *s, uint32_t n_targets, const uint64_t *t
     HIPCHK(hipMemcpyAsync(s->d_tile_first.p, s->h_tile_first.data(), ((size_t)n_targets + 1) * 4, hipMemcpyHostToDevice, s->stream));
     s->tile_shift = 0;
     while ((1u << s->tile_shift) < (uint32_t)s->tile) s->tile_shift++;
-    HIPCHK(s->d_ctg.reserve(std::max<size_t>(1, n_targets), s->stream));
+    HIPCHK(bind_result_block(s, n_targets));
     if (n_targets) HIPCHK(hipMemcpyAsync(s->d_tlen.p, s->h_tlen.data(), (size_t)n_targets * 4, hipMemcpyHostToDevice, s->stream));
     if (nt) {
         HIPCHK(hipMemcpyAsync(s->d_tile_contig.p, tc.data(), nt * 4, hipMemcpyHostToDevice, s->stream));
@@ -475,6 +504,73 @@ cov_status cov_push_batch_device(cov_session *s, const cov_batch *b) {
 cov_status cov_reset(cov_session *s) {
     if (!s) return COV_ERR_INVALID_ARG;
     s->adopted = false; s->n_records = 0; s->n_cigar = 0; s->finished = false; s->depth_all_valid = false;
+    return COV_OK;
+}
+
+// Host side of a finished pipeline: error checks in file order, sortedness, DevContig -> cov_contig_stats.  Used for the
+// session's own results and for the blocks cov_gather collected from other ranks.
+static cov_status convert_results(cov_session *s, const DevGlobal &G, const DevContig *ctg, uint64_t n_records, cov_contig_stats *stats,
+                                  cov_summary *summary) {
+    const u32 nT = s->n_targets;
+    const bool want_hist = s->cfg.want & COV_WANT_HIST;
+    if (G.internal_error) { s->err = "internal error: depth exceeded its proven bound"; return COV_ERR_STATE; }
+    // errors in file order (the reference panics at the first offending record)
+    uint64_t err_rec = ~0ull; int err_code = 0;
+    if (G.first_error != ~0ull) { err_rec = G.first_error >> 8; err_code = (int)(G.first_error & 0xff); }
+    // sortedness: the considered records of successive touched contigs must not interleave
+    // (contig.rs:129-132 panics when a considered record has tid < the previous considered tid)
+    {
+        uint64_t prev_last = 0; bool any = false; uint64_t unsorted_at = ~0ull;
+        for (u32 c = 0; c < nT; c++) {
+            const DevContig &C = ctg[c];
+            if (C.n_pass == 0) continue;
+            if (any && C.first_rec < prev_last) unsorted_at = std::min<uint64_t>(unsorted_at, std::max<uint64_t>(C.first_rec, 0));
+            prev_last = any ? std::max<uint64_t>(prev_last, C.last_rec) : C.last_rec;
+            any = true;
+        }
+        if (unsorted_at != ~0ull && unsorted_at <= err_rec) {
+            s->err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)";
+            return COV_ERR_UNSORTED;
+        }
+    }
+    if (err_code) {
+        char b[256];
+        const char *what = err_code == 2 ? "Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM format"
+                         : err_code == 3 ? "Unexpected data type of NM aux tag"
+                         : err_code == 4 ? "aligned block starts at or beyond the end of its reference sequence"
+                         : err_code == 7 ? "record refers to a reference id outside the header (Corrupt BAM file?)"
+                                         : "invalid CIGAR operation";
+        snprintf(b, sizeof b, "%s (record %llu)", what, (unsigned long long)err_rec);
+        s->err = b;
+        return (cov_status)err_code;
+    }
+    const u64 excl = s->cfg.contig_end_exclusion;
+    uint64_t hist_total = 0;
+    for (u32 c = 0; c < nT; c++) {
+        const DevContig &C = ctg[c];
+        cov_contig_stats &o = stats[c];
+        memset(&o, 0, sizeof o);
+        o.n_primary = C.n_primary; o.n_pass = C.n_pass; o.n_nonsupp = C.n_nonsupp;
+        o.sum_nm = C.sum_nm; o.sum_indel = C.sum_indel;
+        o.sum_identity_primary = C.id_primary; o.sum_identity_nonsupp = C.id_nonsupp;
+        o.win_sum_d = C.sum_d; o.win_sum_d2 = C.sum_d2; o.win_covered = C.cov_win; o.full_covered = C.cov_full;
+        o.first_record = C.first_rec; o.last_record = C.last_rec;
+        const u64 L = s->h_tlen[c];
+        const u64 win_len = 2 * excl < L ? L - 2 * excl : 0;
+        if (C.n_pass && win_len) {
+            o.win_max_d = C.max_d;
+            o.win_min_d = (C.proc_win < win_len || C.min_d == 0xffffffffu) ? 0u : C.min_d;
+        }
+        if (want_hist) { o.hist_len = C.hist_len; o.hist_off = C.chist_off; hist_total += C.hist_len; }
+    }
+    if (summary) {
+        uint64_t prim = 0, cons = 0;
+        for (u32 k = 0; k < COUNTER_SLOTS * 8; k++) { prim += G.prim_slots[k]; cons += G.cons_slots[k]; }
+        summary->num_detected_primary_alignments = prim;
+        summary->n_records = n_records;
+        summary->n_considered = cons;
+        summary->hist_total = hist_total;
+    }
     return COV_OK;
 }
 
@@ -623,8 +719,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         s->h_ctg = (DevContig *)(s->h_res + sizeof(DevGlobal));
     }
     if (want_id && R && nT) HIPCHK(hipStreamWaitEvent(st, s->ev_side_done, 0));
-    if (nT) HIPCHK(hipMemcpyAsync(s->h_ctg, s->d_ctg.p, (size_t)nT * sizeof(DevContig), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(s->h_res, s->d_glob.p, sizeof(DevGlobal), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s->h_res, s->d_res.p, sizeof(DevGlobal) + (size_t)nT * sizeof(DevContig), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     memcpy(&s->h_glob, s->h_res, sizeof(DevGlobal));
     if (s->h_glob.cx_total > s->d_cx_runs.cap) {
@@ -643,67 +738,121 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         s->algo_bytes = (uint64_t)R * 24 + ncig * 4 + (uint64_t)nT * sizeof(DevContig);
     }
 
-    if (s->h_glob.internal_error) { s->err = "internal error: depth exceeded its proven bound"; return COV_ERR_STATE; }
-    // errors in file order (the reference panics at the first offending record)
-    uint64_t err_rec = ~0ull; int err_code = 0;
-    if (s->h_glob.first_error != ~0ull) { err_rec = s->h_glob.first_error >> 8; err_code = (int)(s->h_glob.first_error & 0xff); }
-    // sortedness: the considered records of successive touched contigs must not interleave
-    // (contig.rs:129-132 panics when a considered record has tid < the previous considered tid)
-    {
-        uint64_t prev_last = 0; bool any = false; uint64_t unsorted_at = ~0ull;
-        for (u32 c = 0; c < nT; c++) {
-            const DevContig &C = s->h_ctg[c];
-            if (C.n_pass == 0) continue;
-            if (any && C.first_rec < prev_last) unsorted_at = std::min<uint64_t>(unsorted_at, std::max<uint64_t>(C.first_rec, 0));
-            prev_last = any ? std::max<uint64_t>(prev_last, C.last_rec) : C.last_rec;
-            any = true;
-        }
-        if (unsorted_at != ~0ull && unsorted_at <= err_rec) {
-            s->err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)";
-            return COV_ERR_UNSORTED;
-        }
-    }
-    if (err_code) {
-        char b[256];
-        const char *what = err_code == 2 ? "Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM format"
-                         : err_code == 3 ? "Unexpected data type of NM aux tag"
-                         : err_code == 4 ? "aligned block starts at or beyond the end of its reference sequence"
-                         : err_code == 7 ? "record refers to a reference id outside the header (Corrupt BAM file?)"
-                                         : "invalid CIGAR operation";
-        snprintf(b, sizeof b, "%s (record %llu)", what, (unsigned long long)err_rec);
-        s->err = b;
-        return (cov_status)err_code;
-    }
-
-    const u64 excl = s->cfg.contig_end_exclusion;
-    uint64_t hist_total = 0;
-    for (u32 c = 0; c < nT; c++) {
-        const DevContig &C = s->h_ctg[c];
-        cov_contig_stats &o = stats[c];
-        memset(&o, 0, sizeof o);
-        o.n_primary = C.n_primary; o.n_pass = C.n_pass; o.n_nonsupp = C.n_nonsupp;
-        o.sum_nm = C.sum_nm; o.sum_indel = C.sum_indel;
-        o.sum_identity_primary = C.id_primary; o.sum_identity_nonsupp = C.id_nonsupp;
-        o.win_sum_d = C.sum_d; o.win_sum_d2 = C.sum_d2; o.win_covered = C.cov_win; o.full_covered = C.cov_full;
-        o.first_record = C.first_rec; o.last_record = C.last_rec;
-        const u64 L = s->h_tlen[c];
-        const u64 win_len = 2 * excl < L ? L - 2 * excl : 0;
-        if (C.n_pass && win_len) {
-            o.win_max_d = C.max_d;
-            o.win_min_d = (C.proc_win < win_len || C.min_d == 0xffffffffu) ? 0u : C.min_d;
-        }
-        if (want_hist) { o.hist_len = C.hist_len; o.hist_off = C.chist_off; hist_total += C.hist_len; }
-    }
-    if (summary) {
-        uint64_t prim = 0, cons = 0;
-        for (u32 k = 0; k < COUNTER_SLOTS * 8; k++) { prim += s->h_glob.prim_slots[k]; cons += s->h_glob.cons_slots[k]; }
-        summary->num_detected_primary_alignments = prim;
-        summary->n_records = R;
-        summary->n_considered = cons;
-        summary->hist_total = hist_total;
-    }
+    const cov_status cst = convert_results(s, s->h_glob, s->h_ctg, R, stats, summary);
+    if (cst != COV_OK) return cst;
     s->finished = true;
     return COV_OK;
+}
+
+
+cov_status cov_reserve(cov_session *s, uint64_t n_records, uint64_t n_cigar) {
+    if (!s) return COV_ERR_INVALID_ARG;
+    if (n_records >= 0xfffffff0ull || n_cigar >= 0xfffffff0ull) { s->err = "more than 2^32 records in one session"; return COV_ERR_INVALID_ARG; }
+    HIPCHK(hipSetDevice(s->cfg.device));
+    hipStream_t st = s->stream;
+    const uint64_t R = s->adopted ? 0 : s->n_records, C = s->adopted ? 0 : s->n_cigar;
+    HIPCHK(s->s_tid.reserve(n_records, st, R)); HIPCHK(s->s_pos.reserve(n_records, st, R)); HIPCHK(s->s_flag.reserve(n_records, st, R));
+    HIPCHK(s->s_mapq.reserve(n_records, st, R)); HIPCHK(s->s_nmk.reserve(n_records, st, R)); HIPCHK(s->s_nm.reserve(n_records, st, R));
+    HIPCHK(s->s_lseq.reserve(n_records, st, R)); HIPCHK(s->s_coff.reserve(n_records + 1, st, R ? R + 1 : 0));
+    HIPCHK(s->s_cig.reserve(n_cigar + 1, st, C));
+    return COV_OK;
+}
+
+// ---- cov_gather: ONE RCCL gather of every rank's result block to the root rank's device (north star: "a single RCCL gather
+// of per-contig results over xGMI").  librccl is bound at run time (dlopen), so single-GPU users need no RCCL at all.
+namespace {
+struct Rccl {
+    typedef int (*init_all_t)(void **, int, const int *);
+    typedef int (*gather_t)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    typedef int (*grp_t)();
+    typedef const char *(*errstr_t)(int);
+    init_all_t init_all = nullptr; gather_t gather = nullptr; grp_t group_start = nullptr, group_end = nullptr; errstr_t errstr = nullptr;
+    bool ok = false;
+    Rccl() {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        init_all = (init_all_t)dlsym(h, "ncclCommInitAll"); gather = (gather_t)dlsym(h, "ncclGather");
+        group_start = (grp_t)dlsym(h, "ncclGroupStart"); group_end = (grp_t)dlsym(h, "ncclGroupEnd");
+        errstr = (errstr_t)dlsym(h, "ncclGetErrorString");
+        ok = init_all && gather && group_start && group_end;
+    }
+};
+Rccl *rccl_lib() { static Rccl r; return &r; }
+std::mutex g_comm_mutex;
+std::map<std::vector<int>, std::vector<void *>> g_comms;   // communicators per device list, kept for the process lifetime
+}  // namespace
+
+cov_status cov_gather(cov_session *const *sessions, uint32_t n, uint32_t root) {
+    if (!sessions || n == 0 || root >= n) return COV_ERR_INVALID_ARG;
+    cov_session *s = sessions[root];
+    const u32 nT = s->n_targets;
+    std::vector<int> devs(n);
+    bool distinct = true;
+    for (u32 i = 0; i < n; i++) {
+        if (!sessions[i] || !sessions[i]->finished || sessions[i]->n_targets != nT) { s->err = "cov_gather: every session must be finished over the same targets"; return COV_ERR_STATE; }
+        devs[i] = sessions[i]->cfg.device;
+        for (u32 j = 0; j < i; j++) if (devs[j] == devs[i]) distinct = false;
+    }
+    const size_t block = result_block_bytes(nT);
+    HIPCHK(hipSetDevice(s->cfg.device));
+    HIPCHK(s->d_gather.reserve((size_t)n * block, s->stream));
+    if ((size_t)n * block > s->h_gather_cap) {
+        if (s->h_gather) (void)hipHostFree(s->h_gather);
+        s->h_gather = nullptr; s->h_gather_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&s->h_gather, (size_t)n * block, hipHostMallocDefault));
+        s->h_gather_cap = (size_t)n * block;
+    }
+    for (u32 i = 0; i < n; i++) {   // the record count of each rank travels in its block (a padding word of DevGlobal)
+        HIPCHK(hipSetDevice(devs[i]));
+        const u64 nr = sessions[i]->n_records;
+        HIPCHK(hipMemcpyAsync(&sessions[i]->d_glob.p->pad2[0], &nr, 8, hipMemcpyHostToDevice, sessions[i]->stream));
+        HIPCHK(hipStreamSynchronize(sessions[i]->stream));
+    }
+    if (distinct && (n > 1 || getenv("COVERM_FORCE_RCCL") != nullptr)) {
+        Rccl &R = *rccl_lib();
+        if (!R.ok) { s->err = "cov_gather: librccl.so.1 not available"; return COV_ERR_HIP; }
+        std::vector<void *> comms;
+        {
+            std::lock_guard<std::mutex> lk(g_comm_mutex);
+            auto it = g_comms.find(devs);
+            if (it == g_comms.end()) {
+                std::vector<void *> c(n, nullptr);
+                const int rc = R.init_all(c.data(), (int)n, devs.data());
+                if (rc != 0) { s->err = std::string("ncclCommInitAll: ") + (R.errstr ? R.errstr(rc) : "error"); return COV_ERR_HIP; }
+                it = g_comms.emplace(devs, c).first;
+            }
+            comms = it->second;
+        }
+        int rc = R.group_start();
+        for (u32 i = 0; i < n && rc == 0; i++) {
+            (void)hipSetDevice(devs[i]);
+            rc = R.gather(sessions[i]->d_res.p, i == root ? s->d_gather.p : nullptr, block, /* ncclUint8 */ 1, (int)root, comms[i], sessions[i]->stream);
+        }
+        const int rc2 = R.group_end();
+        if (rc != 0 || rc2 != 0) { s->err = std::string("ncclGather: ") + (R.errstr ? R.errstr(rc ? rc : rc2) : "error"); return COV_ERR_HIP; }
+        for (u32 i = 0; i < n; i++) { HIPCHK(hipSetDevice(devs[i])); HIPCHK(hipStreamSynchronize(sessions[i]->stream)); }
+    } else {
+        // one device given more than once (functional checks on a single-GPU box): RCCL refuses two ranks on one device,
+        // so the blocks move by plain device copies instead
+        for (u32 i = 0; i < n; i++) {
+            HIPCHK(hipSetDevice(devs[i]));
+            HIPCHK(hipStreamSynchronize(sessions[i]->stream));
+            HIPCHK(hipMemcpyPeer(s->d_gather.p + (size_t)i * block, s->cfg.device, sessions[i]->d_res.p, devs[i], block));
+        }
+    }
+    HIPCHK(hipSetDevice(s->cfg.device));
+    HIPCHK(hipMemcpyAsync(s->h_gather, s->d_gather.p, (size_t)n * block, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->gather_n = n; s->gather_block = block;
+    return COV_OK;
+}
+
+cov_status cov_gathered(cov_session *root, uint32_t rank, cov_contig_stats *stats, cov_summary *summary) {
+    if (!root || !root->h_gather || rank >= root->gather_n || (!stats && root->n_targets)) return COV_ERR_INVALID_ARG;
+    const uint8_t *blk = root->h_gather + (size_t)rank * root->gather_block;
+    DevGlobal G; memcpy(&G, blk, sizeof G);
+    return convert_results(root, G, reinterpret_cast<const DevContig *>(blk + sizeof(DevGlobal)), G.pad2[0], stats, summary);
 }
 
 cov_status cov_fetch_hist(cov_session *s, uint64_t *hist) {

@@ -15,12 +15,19 @@
 #include <sys/mman.h>
 #include <zlib.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -105,6 +112,64 @@ void parallel_for(size_t n, int threads, F fn) {
     for (auto &th : pool) th.join();
 }
 
+// Persistent worker pool for the streamed reader: windows are small (tens of MB), so spawning threads per parallel
+// loop (parallel_for above: ~50 us per thread) would cost more than the loop.  run() hands out index ranges from an
+// atomic counter; the calling thread works too.
+class Pool {
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::function<void(size_t)> fn_;
+    size_t n_ = 0, grain_ = 1;
+    std::atomic<size_t> next_{0};
+    uint64_t gen_ = 0;
+    int busy_ = 0;
+    bool stop_ = false;
+    void drain() {
+        for (;;) {
+            const size_t b = next_.fetch_add(grain_);
+            if (b >= n_) break;
+            const size_t e = std::min(n_, b + grain_);
+            for (size_t i = b; i < e; i++) fn_(i);
+        }
+    }
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            drain();
+            { std::lock_guard<std::mutex> lk(m_); if (--busy_ == 0) done_.notify_all(); }
+        }
+    }
+public:
+    explicit Pool(int threads) { for (int t = 1; t < std::max(1, threads); t++) th_.emplace_back([this] { worker(); }); }
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    int size() const { return (int)th_.size() + 1; }
+    template <typename F>
+    void run(size_t n, F f, size_t min_grain = 1) {
+        if (n == 0) return;
+        if (th_.empty() || n <= min_grain) { for (size_t i = 0; i < n; i++) f(i); return; }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = f; n_ = n; grain_ = std::max(min_grain, n / ((th_.size() + 1) * 8)); next_ = 0;
+            busy_ = (int)th_.size(); gen_++;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return busy_ == 0; });
+    }
+};
+
 // ---- uninitialised byte buffer (a std::vector would memset gigabytes before inflate overwrites them)
 // Large buffers come from anonymous mappings advised to use transparent huge pages: dozens of inflate threads
 // first-touching gigabytes of 4 KiB pages otherwise spend most of their time in page faults.  Unmapping gigabytes
@@ -188,7 +253,10 @@ struct LibDeflate {
     int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
     void (*release)(void *) = nullptr;
     uint32_t (*crc32)(uint32_t, const void *, size_t) = nullptr;
-    bool ok = false;
+    void *(*alloc_c)(int) = nullptr;
+    size_t (*compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+    void (*release_c)(void *) = nullptr;
+    bool ok = false, ok_c = false;
     LibDeflate() {
         if (getenv("COVERM_NO_LIBDEFLATE")) return;
         void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
@@ -198,6 +266,10 @@ struct LibDeflate {
         release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
         crc32 = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
         ok = alloc && decompress && release && crc32;
+        alloc_c = (void *(*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        compress = (size_t (*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_deflate_compress");
+        release_c = (void (*)(void *))dlsym(h, "libdeflate_free_compressor");
+        ok_c = ok && alloc_c && compress && release_c;
     }
 };
 const LibDeflate &libdeflate() { static LibDeflate L; return L; }
@@ -207,55 +279,66 @@ struct TlsDecompressor {
 };
 
 // ---- BGZF: block table, parallel inflate
-bool bgzf_inflate_all(const Buf &raw, Buf &out, int threads, std::string &err) {
-    struct Blk { size_t in_off, in_len; size_t out_off; uint32_t isize, crc; };
-    std::vector<Blk> blocks;
-    size_t p = 0, total = 0;
-    while (p < raw.size()) {
-        if (p + 18 > raw.size() || raw[p] != 0x1f || raw[p + 1] != 0x8b || raw[p + 2] != 8 || !(raw[p + 3] & 4)) {
-            err = "not a BGZF block"; return false;
-        }
-        const uint16_t xlen = rd16(&raw[p + 10]);
+struct Blk { size_t in_off, in_len; size_t out_off; uint32_t isize, crc; };
+
+// Parses the BGZF blocks that lie completely inside raw[p, n): `p` advances past them, `total` grows by their ISIZE.
+// Returns false on a malformed block (`err` set).  A block cut off by `n` is an error unless partial_tail_ok (streaming:
+// the tail is re-presented with the next window).  Every header read is bounds-checked against `n`.
+bool bgzf_block_table(const uint8_t *raw, size_t n, size_t &p, std::vector<Blk> &blocks, size_t &total, bool partial_tail_ok,
+                      std::string &err) {
+    while (p < n) {
+        if (p + 18 > n) { if (partial_tail_ok) return true; err = "truncated BGZF block"; return false; }
+        if (raw[p] != 0x1f || raw[p + 1] != 0x8b || raw[p + 2] != 8 || !(raw[p + 3] & 4)) { err = "not a BGZF block"; return false; }
+        const size_t xlen = rd16(&raw[p + 10]);
+        if (p + 12 + xlen > n) { if (partial_tail_ok) return true; err = "truncated BGZF block"; return false; }
         size_t q = p + 12, bsize = 0;
         while (q + 4 <= p + 12 + xlen) {
-            const uint16_t slen = rd16(&raw[q + 2]);
-            if (raw[q] == 66 && raw[q + 1] == 67 && slen == 2) bsize = (size_t)rd16(&raw[q + 4]) + 1;
+            const size_t slen = rd16(&raw[q + 2]);
+            if (raw[q] == 66 && raw[q + 1] == 67 && slen == 2 && q + 6 <= p + 12 + xlen) bsize = (size_t)rd16(&raw[q + 4]) + 1;
             q += 4 + slen;
         }
-        if (bsize == 0 || p + bsize > raw.size()) { err = "truncated BGZF block"; return false; }
+        if (bsize == 0 || bsize < 12 + xlen + 8) { err = "malformed BGZF block header"; return false; }
+        if (p + bsize > n) { if (partial_tail_ok) return true; err = "truncated BGZF block"; return false; }
         Blk b;
         b.in_off = p + 12 + xlen; b.in_len = bsize - 12 - xlen - 8;
         b.crc = rd32(&raw[p + bsize - 8]); b.isize = rd32(&raw[p + bsize - 4]);
+        if (b.isize > 65536) { err = "BGZF block inflates to more than 64 KiB"; return false; }
         b.out_off = total;
         total += b.isize;
         blocks.push_back(b);
         p += bsize;
     }
+    return true;
+}
+
+bool inflate_block(const uint8_t *raw, const Blk &b, uint8_t *dst) {
+    if (b.isize == 0) return true;
+    const LibDeflate &L = libdeflate();
+    if (L.ok) {
+        thread_local TlsDecompressor tls;
+        if (!tls.d) tls.d = L.alloc();
+        size_t got = 0;
+        if (!tls.d || L.decompress(tls.d, raw + b.in_off, b.in_len, dst, b.isize, &got) != 0 || got != b.isize) return false;
+        return L.crc32(0, dst, b.isize) == b.crc;
+    }
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef *>(raw + b.in_off); zs.avail_in = (uInt)b.in_len;
+    zs.next_out = dst; zs.avail_out = b.isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || zs.total_out != b.isize) return false;
+    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.isize) == b.crc;
+}
+
+bool bgzf_inflate_all(const Buf &raw, Buf &out, int threads, std::string &err) {
+    std::vector<Blk> blocks;
+    size_t p = 0, total = 0;
+    if (!bgzf_block_table(raw.p, raw.size(), p, blocks, total, false, err)) return false;
     if (!out.alloc(total)) { err = "out of memory"; return false; }
     std::atomic<bool> ok{true};
-    const LibDeflate &L = libdeflate();
-    parallel_for(blocks.size(), threads, [&](size_t i) {
-        const Blk &b = blocks[i];
-        if (b.isize == 0) return;
-        uint8_t *dst = out.p + b.out_off;
-        if (L.ok) {
-            thread_local TlsDecompressor tls;
-            if (!tls.d) tls.d = L.alloc();
-            size_t got = 0;
-            if (!tls.d || L.decompress(tls.d, raw.p + b.in_off, b.in_len, dst, b.isize, &got) != 0 || got != b.isize) { ok = false; return; }
-            if (L.crc32(0, dst, b.isize) != b.crc) ok = false;
-            return;
-        }
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, -15) != Z_OK) { ok = false; return; }
-        zs.next_in = const_cast<Bytef *>(raw.p + b.in_off); zs.avail_in = (uInt)b.in_len;
-        zs.next_out = dst; zs.avail_out = b.isize;
-        const int rc = inflate(&zs, Z_FINISH);
-        inflateEnd(&zs);
-        if (rc != Z_STREAM_END || zs.total_out != b.isize) { ok = false; return; }
-        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.isize) != b.crc) ok = false;
-    });
+    parallel_for(blocks.size(), threads, [&](size_t i) { if (!inflate_block(raw.p, blocks[i], out.p + blocks[i].out_off)) ok = false; });
     if (!ok) { err = "BGZF inflate / CRC failure"; return false; }
     return true;
 }
@@ -273,10 +356,14 @@ bool read_file(const std::string &path, Buf &out, std::string &err) {
     return true;
 }
 
-// linear aux scan for NM (what htslib's bam_aux_get does); returns nm_kind
-uint8_t scan_nm(const uint8_t *p, const uint8_t *end, uint32_t &nm) {
+// Linear aux scan (what htslib's bam_aux_get does): NM value + how it was typed (returns nm_kind), and the CG:B,I/i
+// array if present (the real CIGAR of a record with more than 65535 operations, SAM spec 4.2.2).
+uint8_t scan_aux(const uint8_t *p, const uint8_t *end, uint32_t &nm, const uint8_t **cg, uint32_t *cg_cnt) {
+    uint8_t kind = COV_NM_ABSENT;
+    bool have_nm = false;
     while (p + 3 <= end) {
-        const bool is_nm = p[0] == 'N' && p[1] == 'M';
+        const bool is_nm = !have_nm && p[0] == 'N' && p[1] == 'M';
+        const bool is_cg = cg != nullptr && p[0] == 'C' && p[1] == 'G';
         const uint8_t t = p[2];
         p += 3;
         size_t sz = 0;
@@ -286,94 +373,142 @@ uint8_t scan_nm(const uint8_t *p, const uint8_t *end, uint32_t &nm) {
         case 'i': case 'I': case 'f': sz = 4; break;
         case 'Z': case 'H': {
             const uint8_t *z = (const uint8_t *)memchr(p, 0, (size_t)(end - p));
-            if (is_nm) return COV_NM_BADTYPE;
-            if (!z) return COV_NM_ABSENT;
+            if (is_nm) { kind = COV_NM_BADTYPE; have_nm = true; }
+            if (!z) return kind;
             p = z + 1;
             continue;
         }
         case 'B': {
-            if (p + 5 > end) return COV_NM_ABSENT;
+            if (p + 5 > end) return kind;
             const uint8_t st = p[0];
             const uint32_t cnt = rd32(p + 1);
             const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
-            if (is_nm) return COV_NM_BADTYPE;
+            if (is_nm) { kind = COV_NM_BADTYPE; have_nm = true; }
+            if ((size_t)(end - p - 5) / es < cnt) return kind;
+            if (is_cg && (st == 'I' || st == 'i') && *cg == nullptr) { *cg = p + 5; *cg_cnt = cnt; }
             p += 5 + (size_t)cnt * es;
             continue;
         }
-        default: return COV_NM_ABSENT;  // malformed aux area
+        default: return kind;  // malformed aux area
         }
+        if (p + sz > end) return kind;
         if (is_nm) {
-            if (p + sz > end) return COV_NM_ABSENT;
-            if (t == 'C') { nm = p[0]; return COV_NM_UNSIGNED; }
-            if (t == 'S') { nm = rd16(p); return COV_NM_UNSIGNED; }
-            if (t == 'I') { nm = rd32(p); return COV_NM_UNSIGNED; }
-            return COV_NM_BADTYPE;   // c / s / i / A / f : the reference panics (lib.rs:144-147)
+            have_nm = true;
+            if (t == 'C') { nm = p[0]; kind = COV_NM_UNSIGNED; }
+            else if (t == 'S') { nm = rd16(p); kind = COV_NM_UNSIGNED; }
+            else if (t == 'I') { nm = rd32(p); kind = COV_NM_UNSIGNED; }
+            else kind = COV_NM_BADTYPE;   // c / s / i / A / f : the reference panics (lib.rs:144-147)
+            if (cg == nullptr) return kind;
         }
         p += sz;
     }
-    return COV_NM_ABSENT;
+    return kind;
 }
 
-bool parse_bam(Bam &b, const Buf &u) {
-    if (u.size() < 12 || memcmp(u.data(), "BAM\1", 4) != 0) { b.err = "bad BAM magic"; return false; }
-    size_t p = 4;
-    const uint32_t l_text = rd32(&u[p]); p += 4;
-    if (p + l_text + 4 > u.size()) { b.err = "truncated BAM header"; return false; }
-    b.header_text.assign((const char *)&u[p], l_text); p += l_text;
-    const uint32_t n_ref = rd32(&u[p]); p += 4;
-    b.names.reserve(n_ref); b.lens.reserve(n_ref);
+// A record whose CIGAR has more than 65535 operations stores `<l_seq>S<ref_len>N` in the CIGAR field and the real one in
+// CG:B,I; htslib swaps it back in while reading (bam_tag2cigar, sam.c), so record.cigar() at contig.rs:168 sees the real
+// CIGAR.  Same conditions here.  Returns the CG payload and count, or nullptr.
+const uint8_t *real_cigar_from_cg(const uint8_t *r, const uint8_t *end, uint32_t &cnt) {
+    const uint32_t n_cig = rd16(r + 16), l_read_name = r[12], l_seq = rd32(r + 20);
+    if (n_cig == 0 || (int32_t)rd32(r + 4) < 0 || (int32_t)rd32(r + 8) < 0) return nullptr;
+    const uint8_t *cg0 = r + 36 + l_read_name;
+    if (cg0 + 4ull * n_cig > end) return nullptr;
+    const uint32_t c0 = rd32(cg0);
+    if ((c0 & 15u) != 4u || (c0 >> 4) != l_seq) return nullptr;
+    const uint8_t *aux = cg0 + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq;
+    if (aux > end) return nullptr;
+    const uint8_t *cg = nullptr; uint32_t nm = 0; cnt = 0;
+    (void)scan_aux(aux, end, nm, &cg, &cnt);
+    if (cg == nullptr || cnt < n_cig || cnt >= (1u << 29)) return nullptr;
+    return cg;
+}
+inline bool maybe_long_cigar(const uint8_t *r) {   // cheap pre-test: the placeholder always has exactly two operations
+    return rd16(r + 16) == 2;
+}
+
+// BAM header (magic, text, reference dictionary) at u[0, N).  Returns 1 and sets `p` to the first record when complete,
+// 0 when more bytes are needed, -1 on error.
+int parse_bam_header(const uint8_t *u, size_t N, size_t &p, std::vector<std::string> &names, std::vector<uint64_t> &lens,
+                     std::string &text, std::string &err) {
+    if (N < 12) return 0;
+    if (memcmp(u, "BAM\1", 4) != 0) { err = "bad BAM magic"; return -1; }
+    size_t q = 4;
+    const uint32_t l_text = rd32(&u[q]); q += 4;
+    if (q + (size_t)l_text + 4 > N) return 0;
+    const size_t text_at = q;
+    q += l_text;
+    const uint32_t n_ref = rd32(&u[q]); q += 4;
+    if ((size_t)n_ref > (N - q) / 9 + 1) return 0;   // every entry takes at least 9 bytes: not all here yet
+    std::vector<std::string> nm; std::vector<uint64_t> ln;
+    nm.reserve(n_ref); ln.reserve(n_ref);
     for (uint32_t i = 0; i < n_ref; i++) {
-        if (p + 4 > u.size()) { b.err = "truncated BAM header"; return false; }
-        const uint32_t l_name = rd32(&u[p]); p += 4;
-        if (p + l_name + 4 > u.size()) { b.err = "truncated BAM header"; return false; }
-        b.names.emplace_back((const char *)&u[p], l_name ? l_name - 1 : 0); p += l_name;
-        b.lens.push_back(rd32(&u[p])); p += 4;
+        if (q + 4 > N) return 0;
+        const uint32_t l_name = rd32(&u[q]); q += 4;
+        if (q + (size_t)l_name + 4 > N) return 0;
+        nm.emplace_back((const char *)&u[q], l_name ? l_name - 1 : 0); q += l_name;
+        ln.push_back(rd32(&u[q])); q += 4;
     }
-    // ---- record boundaries.  Each record only says how long it is, so finding them is a pointer chase; done
-    // serially it is a chain of cache misses (~60 ns per record) and bounds the whole decode.  Parallel scheme:
-    // cut the buffer into segments, let every thread FIND a record start inside its segment (an offset from which
-    // a chain of 8 records is plausible), hop its own segment, and accept the result only if each segment's
-    // chain lands exactly on the start the next segment found — then it equals the serial hop by induction.
-    // Any mismatch falls back to the plain serial hop, so the outcome never depends on the heuristic.
-    const size_t N = u.size();
-    const int32_t n_ref_i = (int32_t)n_ref;
-    auto plausible = [&](size_t o) -> size_t {   // returns record end, or 0 if `o` cannot start a record
-        if (o + 36 > N) return 0;
-        const uint32_t bs = rd32(&u[o]);
-        if (bs < 32 || o + 4 + (size_t)bs > N) return 0;
-        const int32_t rid = (int32_t)rd32(&u[o + 4]), pos = (int32_t)rd32(&u[o + 8]), nrid = (int32_t)rd32(&u[o + 24]);
-        const uint32_t lname = u[o + 12], ncig = rd16(&u[o + 16]), lseq = rd32(&u[o + 20]);
-        if (rid < -1 || rid >= n_ref_i || nrid < -1 || nrid >= n_ref_i || pos < -1 || lname == 0) return 0;
-        if (rid >= 0 && (uint64_t)pos > b.lens[rid]) return 0;
-        const uint64_t fixed = 32ull + lname + 4ull * ncig + (lseq + 1ull) / 2 + lseq;
-        if (fixed > bs) return 0;
-        if (u[o + 36 + lname - 1] != 0) return 0;
-        return o + 4 + bs;
-    };
+    text.assign((const char *)&u[text_at], l_text);
+    names.swap(nm); lens.swap(ln);
+    p = q;
+    return 1;
+}
+
+// Can a record start at offset o?  Returns the record end, or 0.
+inline size_t plausible_record(const uint8_t *u, size_t N, size_t o, int32_t n_ref, const uint64_t *lens) {
+    if (o + 36 > N) return 0;
+    const uint32_t bs = rd32(&u[o]);
+    if (bs < 32 || o + 4 + (size_t)bs > N) return 0;
+    const int32_t rid = (int32_t)rd32(&u[o + 4]), pos = (int32_t)rd32(&u[o + 8]), nrid = (int32_t)rd32(&u[o + 24]);
+    const uint32_t lname = u[o + 12], ncig = rd16(&u[o + 16]), lseq = rd32(&u[o + 20]);
+    if (rid < -1 || rid >= n_ref || nrid < -1 || nrid >= n_ref || pos < -1 || lname == 0) return 0;
+    if (rid >= 0 && (uint64_t)pos > lens[rid]) return 0;
+    const uint64_t fixed = 32ull + lname + 4ull * ncig + (lseq + 1ull) / 2 + lseq;
+    if (fixed > bs) return 0;
+    if (u[o + 36 + lname - 1] != 0) return 0;
+    return o + 4 + bs;
+}
+// First offset in [from, to) from which a chain of 8 plausible records starts (or a shorter chain that ends exactly at N
+// when `n_is_end`); SIZE_MAX if none.
+size_t find_record_start(const uint8_t *u, size_t N, size_t from, size_t to, int32_t n_ref, const uint64_t *lens, bool n_is_end) {
+    for (size_t o = from; o < to; o++) {
+        size_t q = o; int chain = 0;
+        while (chain < 8) { const size_t e = plausible_record(u, N, q, n_ref, lens); if (!e) break; q = e; chain++; if (q == N) break; }
+        if (chain == 8 || (n_is_end && chain > 0 && q == N)) return o;
+    }
+    return (size_t)-1;
+}
+
+// Record boundaries in u[p, N), the first record starting at p.  Each record only says how long it is, so finding them is a
+// pointer chase; done serially it is a chain of cache misses (~60 ns per record) and bounds the whole decode.  Parallel
+// scheme: cut the buffer into segments, let every thread FIND a record start inside its segment (an offset from which a
+// chain of 8 records is plausible), hop its own segment, and accept the result only if each segment's chain lands exactly
+// on the start the next segment found — then it equals the serial hop by induction.  Any mismatch falls back to the plain
+// serial hop, so the outcome never depends on the heuristic.  `end` receives the offset just past the last complete record
+// (== N for a whole file; a streamed window may end inside a record).
+template <typename PF>
+bool find_records(const uint8_t *u, size_t p, size_t N, int32_t n_ref, const uint64_t *lens, int threads, PF &&pfor,
+                  RecVec<size_t> &rec, size_t &end) {
     struct Seg { size_t start = 0, stop = 0; bool found = false; std::vector<size_t> rec; size_t landed = 0; };
-    RecVec<size_t> rec;
     bool parallel_ok = false;
     const size_t body = N - p;
-    int nseg = b.threads > 1 ? std::min<int>(b.threads * 4, (int)(body / (1 << 20))) : 0;
+    int nseg = threads > 1 ? std::min<int>(threads * 4, (int)(body / (1 << 20))) : 0;
+    rec.clear();
     if (nseg >= 2) {
         std::vector<Seg> seg(nseg);
         for (int k = 0; k < nseg; k++) seg[k].stop = p + body * (size_t)(k + 1) / nseg;
         seg[0].start = p; seg[0].found = true;
-        parallel_for((size_t)nseg, b.threads, [&](size_t k) {
+        pfor((size_t)nseg, [&](size_t k) {
             Seg &S = seg[k];
             if (k > 0) {
-                const size_t from = seg[k - 1].stop;
-                for (size_t o = from; o < S.stop && !S.found; o++) {
-                    size_t q = o; int chain = 0;
-                    while (chain < 8) { const size_t e = plausible(q); if (!e) break; q = e; chain++; if (q == N) break; }
-                    if (chain == 8 || (chain > 0 && q == N)) { S.start = o; S.found = true; }
-                }
+                const size_t o = find_record_start(u, N, seg[k - 1].stop, S.stop, n_ref, lens, true);
+                if (o != (size_t)-1) { S.start = o; S.found = true; }
             }
         });
         // a segment without a start (one huge record spans it) is absorbed by its predecessor
         std::vector<int> live;
         for (int k = 0; k < nseg; k++) if (seg[k].found) live.push_back(k);
-        parallel_for(live.size(), b.threads, [&](size_t j) {
+        pfor(live.size(), [&](size_t j) {
             Seg &S = seg[live[j]];
             const size_t limit = j + 1 < live.size() ? seg[live[j + 1]].start : N;
             size_t q = S.start;
@@ -387,18 +522,17 @@ bool parse_bam(Bam &b, const Buf &u) {
             S.landed = q;
         });
         parallel_ok = true;
-        for (size_t j = 0; j < live.size() && parallel_ok; j++) {
-            const size_t want = j + 1 < live.size() ? seg[live[j + 1]].start : N;
-            if (seg[live[j]].landed != want) parallel_ok = false;
-        }
+        for (size_t j = 0; j + 1 < live.size() && parallel_ok; j++)
+            if (seg[live[j]].landed != seg[live[j + 1]].start) parallel_ok = false;
         if (parallel_ok) {
             std::vector<size_t> base(live.size() + 1, 0);
             for (size_t j = 0; j < live.size(); j++) base[j + 1] = base[j] + seg[live[j]].rec.size();
             rec.resize(base.back());
-            parallel_for(live.size(), b.threads, [&](size_t j) {
+            pfor(live.size(), [&](size_t j) {
                 const auto &v = seg[live[j]].rec;
                 if (!v.empty()) memcpy(&rec[base[j]], v.data(), v.size() * sizeof(size_t));
             });
+            end = seg[live.back()].landed;
         }
     }
     if (!parallel_ok) {   // serial hop (small inputs, one thread, or a failed speculation)
@@ -407,66 +541,119 @@ bool parse_bam(Bam &b, const Buf &u) {
         size_t q = p;
         while (q + 4 <= N) {
             const uint32_t bs = rd32(&u[q]);
-            if (bs < 32 || q + 4 + (size_t)bs > N) { b.err = "truncated BAM record"; return false; }
+            if (bs < 32) return false;
+            if (q + 4 + (size_t)bs > N) break;
             rec.push_back(q);
             q += 4 + (size_t)bs;
         }
-        if (q != N) { b.err = "truncated BAM record"; return false; }
+        end = q;
     }
-    // CIGAR / name offsets: per-record counts in parallel, then a prefix sum
-    {
-        const size_t Rn = rec.size();
-        b.cigar_off.resize(Rn + 1); b.cigar_off[0] = 0;
-        if (b.want_names) { b.qname_off.resize(Rn + 1); b.qname_off[0] = 0; }
-        // blocked inclusive scan: per-block counts, serial scan of the block totals, per-block fix-up
-        const size_t nblk = std::max<size_t>(1, std::min<size_t>((size_t)b.threads * 4, Rn / 65536 + 1));
-        std::vector<uint64_t> cs(nblk + 1, 0), qs(nblk + 1, 0);
-        parallel_for(nblk, b.threads, [&](size_t k) {
-            const size_t lo = Rn * k / nblk, hi = Rn * (k + 1) / nblk;
-            uint64_t c = 0, q = 0;
-            for (size_t i = lo; i < hi; i++) {
-                c += rd16(&u[rec[i] + 16]); b.cigar_off[i + 1] = (uint32_t)c;
-                if (b.want_names) { q += u[rec[i] + 12] ? u[rec[i] + 12] - 1u : 0u; b.qname_off[i + 1] = (uint32_t)q; }
-            }
-            cs[k + 1] = c; qs[k + 1] = q;
-        });
-        for (size_t k = 0; k < nblk; k++) { cs[k + 1] += cs[k]; qs[k + 1] += qs[k]; }
-        if (cs[nblk] > 0xffffffffull || qs[nblk] > 0xffffffffull) { b.err = "BAM too large for 32-bit CIGAR/name offsets"; return false; }
-        parallel_for(nblk, b.threads, [&](size_t k) {
-            if (!k) return;
-            const size_t lo = Rn * k / nblk, hi = Rn * (k + 1) / nblk;
-            const uint32_t c = (uint32_t)cs[k], q = (uint32_t)qs[k];
-            for (size_t i = lo; i < hi; i++) { b.cigar_off[i + 1] += c; if (b.want_names) b.qname_off[i + 1] += q; }
-        });
+    return true;
+}
+
+// Destination of the per-record field extraction: the SoA batch of covermhip.h plus mate tid / read names.
+struct SoaOut {
+    int32_t *tid = nullptr, *pos = nullptr, *mtid = nullptr;
+    uint16_t *flag = nullptr;
+    uint8_t *mapq = nullptr, *nm_kind = nullptr;
+    uint32_t *nm = nullptr, *l_seq = nullptr, *cigar_off = nullptr, *cigar = nullptr, *qname_off = nullptr;
+    char *qnames = nullptr;
+};
+
+// Pass 1 of the extraction: cigar_off[0..R] (and qname_off) as prefix sums of the per-record counts.  `ensure` is called
+// once with the totals so the caller can size cigar / qnames.
+template <typename PF, typename EN>
+bool record_offsets(const uint8_t *u, size_t N, const RecVec<size_t> &rec, int threads, PF &&pfor, uint32_t *cigar_off,
+                    uint32_t *qname_off, EN &&ensure, std::string &err) {
+    const size_t Rn = rec.size();
+    cigar_off[0] = 0;
+    if (qname_off) qname_off[0] = 0;
+    const size_t nblk = std::max<size_t>(1, std::min<size_t>((size_t)threads * 4, Rn / 65536 + 1));
+    std::vector<uint64_t> cs(nblk + 1, 0), qs(nblk + 1, 0);
+    pfor(nblk, [&](size_t k) {
+        const size_t lo = Rn * k / nblk, hi = Rn * (k + 1) / nblk;
+        uint64_t c = 0, q = 0;
+        for (size_t i = lo; i < hi; i++) {
+            const uint8_t *r = &u[rec[i]];
+            uint32_t nc = rd16(r + 16);
+            if (maybe_long_cigar(r)) { uint32_t cnt = 0; if (real_cigar_from_cg(r, r + 4 + rd32(r), cnt)) nc = cnt; }
+            c += nc; cigar_off[i + 1] = (uint32_t)c;
+            if (qname_off) { q += r[12] ? r[12] - 1u : 0u; qname_off[i + 1] = (uint32_t)q; }
+        }
+        cs[k + 1] = c; qs[k + 1] = q;
+    });
+    for (size_t k = 0; k < nblk; k++) { cs[k + 1] += cs[k]; qs[k + 1] += qs[k]; }
+    if (cs[nblk] > 0xffffffffull || qs[nblk] > 0xffffffffull) { err = "BAM too large for 32-bit CIGAR/name offsets"; return false; }
+    pfor(nblk, [&](size_t k) {
+        if (!k) return;
+        const size_t lo = Rn * k / nblk, hi = Rn * (k + 1) / nblk;
+        const uint32_t c = (uint32_t)cs[k], q = (uint32_t)qs[k];
+        for (size_t i = lo; i < hi; i++) { cigar_off[i + 1] += c; if (qname_off) qname_off[i + 1] += q; }
+    });
+    (void)N;
+    return ensure(cs[nblk], qs[nblk]);
+}
+
+// Pass 2: every field of record i (cigar_off / qname_off already final).
+inline bool extract_record(const uint8_t *u, size_t at, size_t i, const SoaOut &o) {
+    const uint8_t *r = &u[at];
+    const uint32_t bs = rd32(r);
+    const uint8_t *end = r + 4 + bs;
+    o.tid[i] = (int32_t)rd32(r + 4); o.pos[i] = (int32_t)rd32(r + 8);
+    const uint32_t l_read_name = r[12];
+    o.mapq[i] = r[13];
+    const uint32_t n_cig = rd16(r + 16);
+    o.flag[i] = rd16(r + 18);
+    const uint32_t l_seq = rd32(r + 20);
+    o.l_seq[i] = l_seq;
+    if (o.mtid) o.mtid[i] = (int32_t)rd32(r + 24);
+    const uint8_t *q = r + 36;
+    if (q + l_read_name + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq > end) return false;
+    if (o.qnames && l_read_name) memcpy(&o.qnames[o.qname_off[i]], q, l_read_name - 1);
+    q += l_read_name;
+    const uint32_t want = o.cigar_off[i + 1] - o.cigar_off[i];
+    const uint8_t *aux = q + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq;
+    uint32_t nm = 0;
+    if (want != n_cig) {       // the real CIGAR lives in CG:B,I (record_offsets already verified the conditions)
+        const uint8_t *cg = nullptr; uint32_t cnt = 0;
+        o.nm_kind[i] = scan_aux(aux, end, nm, &cg, &cnt);
+        if (cg == nullptr || cnt != want) return false;
+        memcpy(&o.cigar[o.cigar_off[i]], cg, 4ull * want);
+    } else {
+        if (n_cig) memcpy(&o.cigar[o.cigar_off[i]], q, 4ull * n_cig);
+        o.nm_kind[i] = scan_aux(aux, end, nm, nullptr, nullptr);
+    }
+    o.nm[i] = nm;
+    return true;
+}
+
+bool parse_bam(Bam &b, const Buf &u) {
+    size_t p = 0;
+    const int hrc = parse_bam_header(u.data(), u.size(), p, b.names, b.lens, b.header_text, b.err);
+    if (hrc < 0) return false;
+    if (hrc == 0) { b.err = u.size() < 12 ? "bad BAM magic" : "truncated BAM header"; return false; }
+    const size_t N = u.size();
+    auto pfor = [&](size_t n, auto fn) { parallel_for(n, b.threads, fn); };
+    RecVec<size_t> rec;
+    size_t end = p;
+    if (!find_records(u.data(), p, N, (int32_t)b.names.size(), b.lens.data(), b.threads, pfor, rec, end) || end != N) {
+        b.err = "truncated BAM record"; return false;
     }
     const size_t R = rec.size();
+    b.cigar_off.resize(R + 1);
+    if (b.want_names) b.qname_off.resize(R + 1);
+    auto ensure = [&](uint64_t ncig, uint64_t nq) { b.cigar.resize(ncig); if (b.want_names) b.qnames.resize(nq); return true; };
+    if (!record_offsets(u.data(), N, rec, b.threads, pfor, b.cigar_off.data(), b.want_names ? b.qname_off.data() : nullptr, ensure, b.err))
+        return false;
     b.tid.resize(R); b.pos.resize(R); b.mtid.resize(R); b.flag.resize(R); b.mapq.resize(R); b.nm_kind.resize(R);
     b.nm.resize(R); b.l_seq.resize(R);
-    b.cigar.resize(b.cigar_off[R]);
-    if (b.want_names) b.qnames.resize(b.qname_off[R]);
+    SoaOut o;
+    o.tid = b.tid.data(); o.pos = b.pos.data(); o.mtid = b.mtid.data(); o.flag = b.flag.data(); o.mapq = b.mapq.data();
+    o.nm_kind = b.nm_kind.data(); o.nm = b.nm.data(); o.l_seq = b.l_seq.data(); o.cigar_off = b.cigar_off.data();
+    o.cigar = b.cigar.data(); o.qname_off = b.want_names ? b.qname_off.data() : nullptr;
+    o.qnames = b.want_names ? &b.qnames[0] : nullptr;
     std::atomic<bool> ok{true};
-    parallel_for(R, b.threads, [&](size_t i) {
-        const uint8_t *r = &u[rec[i]];
-        const uint32_t bs = rd32(r);
-        const uint8_t *end = r + 4 + bs;
-        b.tid[i] = (int32_t)rd32(r + 4); b.pos[i] = (int32_t)rd32(r + 8);
-        const uint32_t l_read_name = r[12];
-        b.mapq[i] = r[13];
-        const uint32_t n_cig = rd16(r + 16);
-        b.flag[i] = rd16(r + 18);
-        const uint32_t l_seq = rd32(r + 20);
-        b.l_seq[i] = l_seq;
-        b.mtid[i] = (int32_t)rd32(r + 24);
-        const uint8_t *q = r + 36;
-        if (q + l_read_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq > end) { ok = false; return; }
-        if (b.want_names && l_read_name) memcpy(&b.qnames[b.qname_off[i]], q, l_read_name - 1);
-        q += l_read_name;
-        if (n_cig) memcpy(&b.cigar[b.cigar_off[i]], q, 4ull * n_cig);
-        q += 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
-        uint32_t nm = 0;
-        b.nm_kind[i] = scan_nm(q, end, nm);
-        b.nm[i] = nm;
-    });
+    parallel_for(R, b.threads, [&](size_t i) { if (!extract_record(u.data(), rec[i], i, o)) ok = false; });
     if (!ok) { b.err = "corrupt BAM record"; return false; }
     return true;
 }
@@ -548,6 +735,429 @@ bool parse_sam(Bam &b, const Buf &raw) {
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------- streamed reader
+// covh_bam_stream: the same decode as covh_bam_open, but window by window with bounded memory, so that inflate, record
+// parsing, the H2D copy of finished batches and (for several files) the GPU pipeline overlap inside ONE file:
+//
+//   coordinator I : pread ~32 MiB of compressed bytes -> block table -> inflate pool -> window queue
+//   coordinator P : window (+ the bytes of the record cut off at the end of the previous window) -> record boundaries
+//                   (speculative parallel hop, verified) -> field extraction into a page-locked SoA batch -> batch queue
+//   consumer      : covh_bam_stream_next() hands out one batch at a time (cov_push_batch it, ask for the next)
+//
+// Three windows and three batches circulate; nothing else scales with the file.  A span (tid range) can be selected for
+// multi-GPU runs: the rank's first BGZF block is located by probing the file (no index needed: find a block header,
+// inflate, find a plausible record chain, read its tid), so every rank inflates only its own part of the file.
+struct StreamBatch {
+    void *mem[9] = {};
+    size_t cap_rec = 0, cap_cig = 0;
+    uint64_t n = 0, ncig = 0;
+    static void *grab(size_t bytes) { void *p = cov_host_alloc(bytes); return p ? p : malloc(bytes); }
+    static void drop(void *p) { if (p && !cov_host_free(p)) free(p); }
+    bool ensure_rec(size_t R) {
+        if (R <= cap_rec) return true;
+        const size_t c = std::max(R, cap_rec + cap_rec / 2);
+        static const size_t esz[8] = {4, 4, 2, 1, 4, 1, 4, 4};   // tid pos flag mapq nm nm_kind l_seq cigar_off
+        for (int k = 0; k < 8; k++) { drop(mem[k]); mem[k] = grab((c + 1) * esz[k]); if (!mem[k]) return false; }
+        cap_rec = c;
+        return true;
+    }
+    bool ensure_cig(size_t C) {
+        if (C <= cap_cig) return true;
+        const size_t c = std::max(C, cap_cig + cap_cig / 2);
+        drop(mem[8]); mem[8] = grab((c + 1) * 4);
+        if (!mem[8]) return false;
+        cap_cig = c;
+        return true;
+    }
+    void fill(cov_batch *o) const {
+        o->tid = (const int32_t *)mem[0]; o->pos = (const int32_t *)mem[1]; o->flag = (const uint16_t *)mem[2];
+        o->mapq = (const uint8_t *)mem[3]; o->nm = (const uint32_t *)mem[4]; o->nm_kind = (const uint8_t *)mem[5];
+        o->l_seq = (const uint32_t *)mem[6]; o->cigar_off = (const uint32_t *)mem[7]; o->cigar = (const uint32_t *)mem[8];
+        o->n_records = n;
+    }
+    ~StreamBatch() { for (auto &m : mem) drop(m); }
+};
+
+struct StreamWindow {
+    uint8_t *buf = nullptr; size_t cap = 0;
+    size_t head = 0;   // bytes reserved in front of the inflated data for the previous window's cut-off record
+    size_t len = 0;    // inflated bytes at buf + head
+    bool last = false;
+    bool reserve(size_t head_want, size_t len_want, bool keep) {   // keep: preserve the `len` bytes at buf + head
+        if (head_want <= head && head + len_want <= cap) return true;
+        const size_t nh = std::max(head, head_want), nc = nh + std::max(len_want, len) + (1u << 16);
+        uint8_t *nb = (uint8_t *)malloc(nc);
+        if (!nb) return false;
+        if (keep && buf) memcpy(nb + nh, buf + head, len);
+        free(buf);
+        buf = nb; cap = nc; head = nh;
+        return true;
+    }
+    ~StreamWindow() { free(buf); }
+};
+
+constexpr int64_t KEY_INF = 0x7fffffff;
+inline int64_t tid_key(int32_t tid) { return tid < 0 ? KEY_INF : tid; }
+
+struct Stream {
+    std::string path, err;
+    int fd = -1;
+    uint64_t file_size = 0;
+    std::vector<std::string> names; std::vector<uint64_t> lens; std::string header_text;
+    int threads = 1;
+    size_t window_comp = 32u << 20;
+    // span
+    uint64_t start_off = 0; bool mid_start = false;
+    int64_t key_lo = 0, key_hi = KEY_INF + 1; bool empty_span = false;
+    // machinery
+    std::unique_ptr<Pool> pool_i, pool_p;
+    std::thread th_i, th_p;
+    std::mutex m; std::condition_variable cv;
+    std::deque<StreamWindow *> win_free, win_full;
+    std::deque<StreamBatch *> bat_free, bat_full;
+    std::vector<std::unique_ptr<StreamWindow>> wins;
+    std::vector<std::unique_ptr<StreamBatch>> bats;
+    bool stop = false, i_done = false, p_done = false, failed = false;
+    StreamBatch *held = nullptr;
+    uint64_t n_records = 0;
+    std::atomic<uint64_t> peak_bytes{0};
+    double t_read = 0, t_inflate = 0, t_parse = 0, t_wait_i = 0, t_wait_p = 0;
+
+    void fail(const std::string &e) { std::lock_guard<std::mutex> lk(m); if (!failed) { failed = true; err = e; } stop = true; cv.notify_all(); }
+    void account() {
+        uint64_t b = 0;
+        for (auto &w : wins) b += w->cap;
+        for (auto &x : bats) b += x->cap_rec * 24 + x->cap_cig * 4;
+        b += window_comp + (1u << 20);
+        uint64_t cur = peak_bytes.load();
+        while (b > cur && !peak_bytes.compare_exchange_weak(cur, b)) {}
+    }
+
+    void run_inflate() {
+        std::vector<uint8_t> cbuf(window_comp + (256u << 10));
+        size_t left = 0; uint64_t fpos = start_off;
+        std::vector<Blk> blocks;
+        auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        for (;;) {
+            StreamWindow *w = nullptr;
+            {
+                const double t0 = now();
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || !win_free.empty(); });
+                if (stop) break;
+                w = win_free.front(); win_free.pop_front();
+                t_wait_i += now() - t0;
+            }
+            const double t0 = now();
+            size_t got = 0;
+            while (got < window_comp) {
+                const ssize_t r = pread(fd, cbuf.data() + left + got, window_comp - got, (off_t)(fpos + got));
+                if (r < 0) { fail("read error on " + path); return; }
+                if (r == 0) break;
+                got += (size_t)r;
+            }
+            fpos += got;
+            const bool eof = got < window_comp;
+            const size_t n = left + got;
+            blocks.clear();
+            size_t p = 0, total = 0;
+            std::string e;
+            if (!bgzf_block_table(cbuf.data(), n, p, blocks, total, !eof, e)) { fail(e); return; }
+            if (!eof && blocks.empty() && n > (128u << 10)) { fail("BGZF block larger than 64 KiB"); return; }
+            const double t1 = now();
+            w->len = 0;
+            if (!w->reserve(1u << 20, total, false)) { fail("out of memory"); return; }
+            std::atomic<bool> ok{true};
+            uint8_t *dst = w->buf + w->head;
+            const uint8_t *src = cbuf.data();
+            pool_i->run(blocks.size(), [&](size_t i) { if (!inflate_block(src, blocks[i], dst + blocks[i].out_off)) ok = false; });
+            if (!ok) { fail("BGZF inflate / CRC failure"); return; }
+            w->len = total; w->last = eof;
+            left = n - p;
+            if (left) memmove(cbuf.data(), cbuf.data() + p, left);
+            if (cbuf.size() < left + window_comp) cbuf.resize(left + window_comp);
+            t_read += t1 - t0; t_inflate += now() - t1;
+            account();
+            { std::lock_guard<std::mutex> lk(m); win_full.push_back(w); }
+            cv.notify_all();
+            if (eof) break;
+        }
+        { std::lock_guard<std::mutex> lk(m); i_done = true; }
+        cv.notify_all();
+    }
+
+    void run_parse() {
+        std::vector<uint8_t> carry;
+        bool header_done = mid_start, need_start = mid_start, finished = false;
+        RecVec<size_t> rec;
+        auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        auto pfor = [&](size_t n, auto fn) { pool_p->run(n, fn); };
+        const int32_t n_ref = (int32_t)names.size();
+        while (!finished) {
+            StreamWindow *w = nullptr;
+            {
+                const double t0 = now();
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || !win_full.empty() || i_done; });
+                if (stop) break;
+                if (win_full.empty()) break;   // inflate side ended without a `last` window: only after an error
+                w = win_full.front(); win_full.pop_front();
+                t_wait_p += now() - t0;
+            }
+            const double t0 = now();
+            const size_t c = carry.size();
+            if (c > w->head && !w->reserve(c + (c >> 2), w->len, true)) { fail("out of memory"); return; }
+            uint8_t *base = w->buf + w->head - c;
+            if (c) memcpy(base, carry.data(), c);
+            const size_t N = c + w->len;
+            const bool last = w->last;
+            size_t p = 0, end = 0;
+            bool have = true;
+            if (!header_done) {
+                std::vector<std::string> nm; std::vector<uint64_t> ln; std::string tx, e;
+                const int rc = parse_bam_header(base, N, p, nm, ln, tx, e);
+                if (rc < 0) { fail(e); return; }
+                if (rc == 0) { if (last) { fail("truncated BAM header"); return; } have = false; end = 0; }
+                else header_done = true;   // names/lens were read at open time
+            }
+            if (have && need_start) {   // span starting in the middle of the file: locate the first record of this window
+                const size_t o = find_record_start(base, N, 0, N, n_ref, lens.data(), last);
+                if (o == (size_t)-1) { have = false; end = last ? N : 0; if (!last && N > (64u << 20)) { fail("no record boundary found at the span start"); return; } }
+                else { p = o; need_start = false; }
+            }
+            size_t i0 = 0, i1 = 0;
+            if (have) {
+                if (!find_records(base, p, N, n_ref, lens.data(), pool_p->size(), pfor, rec, end)) { fail("truncated BAM record"); return; }
+                if (last && end != N) { fail("truncated BAM record"); return; }
+                i1 = rec.size();
+                // span: keep records with key_lo <= key(tid) < key_hi (file order; ranges are contiguous in a sorted file)
+                if (key_lo > 0) while (i0 < i1 && tid_key((int32_t)rd32(base + rec[i0] + 4)) < key_lo) i0++;
+                if (key_hi <= KEY_INF) {
+                    size_t j = i0;
+                    while (j < i1 && tid_key((int32_t)rd32(base + rec[j] + 4)) < key_hi) j++;
+                    if (j < i1) { i1 = j; finished = true; }
+                }
+            }
+            StreamBatch *b = nullptr;
+            if (i1 > i0) {
+                {
+                    const double tw = now();
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return stop || !bat_free.empty(); });
+                    if (stop) break;
+                    b = bat_free.front(); bat_free.pop_front();
+                    t_wait_p += now() - tw;
+                }
+                const size_t R = i1 - i0;
+                if (!b->ensure_rec(R)) { fail("out of memory"); return; }
+                RecVec<size_t> sub;   // record_offsets / extraction work on the kept sub-range
+                const RecVec<size_t> *rv = &rec;
+                if (i0 != 0 || i1 != rec.size()) { sub.assign(rec.begin() + i0, rec.begin() + i1); rv = &sub; }
+                std::string e;
+                auto ensure = [&](uint64_t ncig, uint64_t) { b->ncig = ncig; return b->ensure_cig((size_t)ncig); };
+                if (!record_offsets(base, N, *rv, pool_p->size(), pfor, (uint32_t *)b->mem[7], nullptr, ensure, e)) { fail(e.empty() ? "out of memory" : e); return; }
+                SoaOut o;
+                o.tid = (int32_t *)b->mem[0]; o.pos = (int32_t *)b->mem[1]; o.flag = (uint16_t *)b->mem[2]; o.mapq = (uint8_t *)b->mem[3];
+                o.nm = (uint32_t *)b->mem[4]; o.nm_kind = (uint8_t *)b->mem[5]; o.l_seq = (uint32_t *)b->mem[6];
+                o.cigar_off = (uint32_t *)b->mem[7]; o.cigar = (uint32_t *)b->mem[8];
+                std::atomic<bool> ok{true};
+                const RecVec<size_t> &rr = *rv;
+                pool_p->run(R, [&](size_t i) { if (!extract_record(base, rr[i], i, o)) ok = false; }, 256);
+                if (!ok) { fail("corrupt BAM record"); return; }
+                b->n = R;
+            }
+            carry.assign(base + end, base + N);
+            if (last) finished = true;
+            t_parse += now() - t0;
+            account();
+            {
+                std::lock_guard<std::mutex> lk(m);
+                win_free.push_back(w);
+                if (b) bat_full.push_back(b);
+                if (finished) { p_done = true; stop_inflate_locked(); }
+            }
+            cv.notify_all();
+        }
+        { std::lock_guard<std::mutex> lk(m); p_done = true; }
+        cv.notify_all();
+    }
+    void stop_inflate_locked() { if (!i_done) stop = true; }
+
+    ~Stream() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        if (th_i.joinable()) th_i.join();
+        if (th_p.joinable()) th_p.join();
+        if (fd >= 0) close(fd);
+    }
+};
+
+// Inflates blocks from `off` until `want(buffer)` says it has enough; used for the header pre-read and the span probes.
+template <typename W>
+bool inflate_from(int fd, uint64_t file_size, uint64_t off, std::vector<uint8_t> &out, W &&want, std::string &err) {
+    std::vector<uint8_t> c;
+    uint64_t fpos = off;
+    size_t left = 0;
+    out.clear();
+    for (;;) {
+        const size_t chunk = 1u << 20;
+        c.resize(left + chunk);
+        const ssize_t r = fpos < file_size ? pread(fd, c.data() + left, chunk, (off_t)fpos) : 0;
+        if (r < 0) { err = "read error"; return false; }
+        fpos += (uint64_t)r;
+        const size_t n = left + (size_t)r;
+        const bool eof = r == 0 || fpos >= file_size;
+        std::vector<Blk> blocks; size_t p = 0, total = 0;
+        if (!bgzf_block_table(c.data(), n, p, blocks, total, !eof, err)) return false;
+        const size_t base = out.size();
+        out.resize(base + total);
+        for (auto &b : blocks) if (!inflate_block(c.data(), b, out.data() + base + b.out_off)) { err = "BGZF inflate / CRC failure"; return false; }
+        if (want(out)) return true;
+        if (eof) return true;   // caller decides whether what it got is enough
+        left = n - p;
+        memmove(c.data(), c.data() + p, left);
+    }
+}
+
+// First BGZF block at or after file offset `off` (header magic + BC subfield + a second block header right behind it),
+// SIZE_MAX if none before the end of the file.
+uint64_t find_block_start(int fd, uint64_t file_size, uint64_t off) {
+    std::vector<uint8_t> c(192u << 10);
+    while (off < file_size) {
+        const ssize_t r = pread(fd, c.data(), c.size(), (off_t)off);
+        if (r < 28) return (uint64_t)-1;
+        const size_t n = (size_t)r;
+        for (size_t q = 0; q + 18 <= n; q++) {
+            if (c[q] != 0x1f || c[q + 1] != 0x8b || c[q + 2] != 8 || c[q + 3] != 4) continue;
+            if (rd16(&c[q + 10]) != 6 || c[q + 12] != 66 || c[q + 13] != 67 || rd16(&c[q + 14]) != 2) continue;
+            const size_t bsize = (size_t)rd16(&c[q + 16]) + 1;
+            if (bsize < 26) continue;
+            if (off + q + bsize == file_size) return off + q;
+            if (q + bsize + 4 <= n && c[q + bsize] == 0x1f && c[q + bsize + 1] == 0x8b && c[q + bsize + 2] == 8 && c[q + bsize + 3] == 4) return off + q;
+        }
+        off += n - 28;
+    }
+    return (uint64_t)-1;
+}
+
+// Key (tid, or KEY_INF for unmapped-without-reference) of the first record that can be located at or after file offset
+// `off`; *block_off receives the BGZF block the search started in.  KEY_INF + 1 when the file ends first.
+int64_t probe_key(int fd, uint64_t file_size, uint64_t off, int32_t n_ref, const uint64_t *lens, uint64_t *block_off) {
+    const uint64_t b = find_block_start(fd, file_size, off);
+    *block_off = b;
+    if (b == (uint64_t)-1) return KEY_INF + 1;
+    std::vector<uint8_t> u; std::string err;
+    size_t found = (size_t)-1;
+    auto want = [&](std::vector<uint8_t> &buf) {
+        found = find_record_start(buf.data(), buf.size(), 0, buf.size(), n_ref, lens, false);
+        return found != (size_t)-1 || buf.size() > (96u << 20);
+    };
+    if (!inflate_from(fd, file_size, b, u, want, err)) return KEY_INF + 1;
+    if (found == (size_t)-1) found = find_record_start(u.data(), u.size(), 0, u.size(), n_ref, lens, true);
+    if (found == (size_t)-1) return KEY_INF + 1;
+    return tid_key((int32_t)rd32(&u[found + 4]));
+}
+
+}  // namespace
+
+extern "C" {
+
+struct covh_bam_stream { Stream s; };
+
+covh_bam_stream *covh_bam_stream_open(const char *path, int threads, uint32_t span_index, uint32_t span_count, char *err, size_t errcap) {
+    auto bail = [&](covh_bam_stream *h, const std::string &e) -> covh_bam_stream * {
+        if (err && errcap) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; }
+        delete h;
+        return nullptr;
+    };
+    covh_bam_stream *h = new covh_bam_stream();
+    Stream &s = h->s;
+    s.path = path; s.threads = std::max(1, threads);
+    s.fd = open(path, O_RDONLY);
+    if (s.fd < 0) return bail(h, std::string("Unable to find BAM file ") + path);
+    {
+        const off_t e = lseek(s.fd, 0, SEEK_END);
+        s.file_size = e > 0 ? (uint64_t)e : 0;
+    }
+    if (s.file_size == 0) return bail(h, std::string(path) + ": empty file (no BAM/SAM header)");
+    uint8_t magic[2] = {0, 0};
+    if (pread(s.fd, magic, 2, 0) != 2 || magic[0] != 0x1f || magic[1] != 0x8b) return bail(h, "not a BGZF file (the streamed reader takes BAM only)");
+    if (const char *wb = getenv("COVERM_STREAM_WINDOW_KB")) { const long v = atol(wb); if (v >= 64) s.window_comp = (size_t)v << 10; }
+    // header: inflate from the start until the reference dictionary is complete
+    {
+        std::vector<uint8_t> u; std::string e;
+        size_t p = 0; int rc = 0;
+        auto want = [&](std::vector<uint8_t> &buf) {
+            std::string e2;
+            rc = parse_bam_header(buf.data(), buf.size(), p, s.names, s.lens, s.header_text, e2);
+            if (rc < 0) e = e2;
+            return rc != 0;
+        };
+        if (!inflate_from(s.fd, s.file_size, 0, u, want, e)) return bail(h, e);
+        if (rc < 0) return bail(h, e);
+        if (rc == 0) return bail(h, u.size() < 12 ? "bad BAM magic" : "truncated BAM header");
+    }
+    if (span_count > 1) {
+        if (span_index >= span_count) return bail(h, "span index out of range");
+        const int32_t n_ref = (int32_t)s.names.size();
+        // boundaries B[k], k = 1 .. count-1: one past the tid found at k/count of the file; every rank computes the same
+        std::vector<int64_t> B(span_count + 1, 0);
+        std::vector<uint64_t> boff(span_count + 1, 0);
+        for (uint32_t k = 1; k < span_count; k++) {
+            uint64_t bo = 0;
+            const int64_t key = probe_key(s.fd, s.file_size, s.file_size / span_count * k, n_ref, s.lens.data(), &bo);
+            B[k] = std::max(B[k - 1], key >= KEY_INF ? KEY_INF : key + 1);
+            boff[k] = bo;
+        }
+        B[span_count] = KEY_INF + 1;
+        s.key_lo = B[span_index]; s.key_hi = B[span_index + 1];
+        if (span_index > 0) {
+            if (boff[span_index] == (uint64_t)-1 || s.key_lo >= s.key_hi) s.empty_span = true;
+            else { s.start_off = boff[span_index]; s.mid_start = true; }
+        } else if (s.key_hi <= 0) s.empty_span = true;
+    }
+    if (s.empty_span) { s.p_done = true; s.i_done = true; return h; }
+    const int ti = s.threads, tp = std::max(1, s.threads / 2);
+    s.pool_i.reset(new Pool(ti)); s.pool_p.reset(new Pool(tp));
+    for (int k = 0; k < 3; k++) {
+        s.wins.emplace_back(new StreamWindow()); s.win_free.push_back(s.wins.back().get());
+        s.bats.emplace_back(new StreamBatch()); s.bat_free.push_back(s.bats.back().get());
+    }
+    s.th_i = std::thread([h] { h->s.run_inflate(); });
+    s.th_p = std::thread([h] { h->s.run_parse(); });
+    return h;
+}
+
+uint32_t covh_bam_stream_n_targets(const covh_bam_stream *h) { return (uint32_t)h->s.names.size(); }
+const char *covh_bam_stream_target_name(const covh_bam_stream *h, uint32_t i) { return h->s.names[i].c_str(); }
+uint64_t covh_bam_stream_target_len(const covh_bam_stream *h, uint32_t i) { return h->s.lens[i]; }
+const char *covh_bam_stream_error(const covh_bam_stream *h) { return h->s.err.c_str(); }
+uint64_t covh_bam_stream_peak_bytes(const covh_bam_stream *h) { return h->s.peak_bytes.load(); }
+uint64_t covh_bam_stream_n_records(const covh_bam_stream *h) { return h->s.n_records; }
+
+int covh_bam_stream_next(covh_bam_stream *h, cov_batch *out) {
+    Stream &s = h->s;
+    std::unique_lock<std::mutex> lk(s.m);
+    if (s.held) { s.bat_free.push_back(s.held); s.held = nullptr; s.cv.notify_all(); }
+    s.cv.wait(lk, [&] { return !s.bat_full.empty() || s.p_done || s.failed; });
+    if (s.failed) return -1;
+    if (s.bat_full.empty()) return 0;
+    s.held = s.bat_full.front(); s.bat_full.pop_front();
+    s.held->fill(out);
+    s.n_records += s.held->n;
+    return 1;
+}
+
+void covh_bam_stream_timing(const covh_bam_stream *h, double *out5) {
+    const Stream &s = h->s;
+    out5[0] = s.t_read; out5[1] = s.t_inflate; out5[2] = s.t_parse; out5[3] = s.t_wait_i; out5[4] = s.t_wait_p;
+}
+
+void covh_bam_stream_close(covh_bam_stream *h) { delete h; }
+
+}  // extern "C"
+
+namespace {
 }  // namespace
 
 extern "C" {
@@ -602,8 +1212,23 @@ const uint32_t *covh_bam_qname_off(const covh_bam *h) { return h->b.qname_off.em
 const char *covh_bam_qnames(const covh_bam *h) { return h->b.qnames.data(); }
 uint64_t covh_bam_n_cigar(const covh_bam *h) { return h->b.cigar.size(); }
 
-// ---- writer: SoA batch -> BGZF BAM (synthetic benchmark inputs; SEQ is all 'A', QUAL 0xff, or '*' when !with_seq).
-// Records are serialised in parallel slices, cut into <= 0xff00-byte blocks and deflated by the thread pool.
+// ---- writer: SoA batch -> BGZF BAM (synthetic benchmark / test inputs).
+// with_seq: 0 = SEQ '*'; 1 = SEQ all 'A', QUAL 0xff, names r<i> (compresses to ~14 B per read: inflate cost far below any
+// real BAM's); 2 = realistic entropy: uniformly random bases, Phred-like binned qualities (37/25/11/2 with probabilities
+// .88/.08/.03/.01, independent per base, i.e. a little MORE entropy than real instrument output), Illumina-style read
+// names — about 60-70 compressed bytes per 150 bp read, like a real short-read BAM.
+// Records are serialised and deflated chunk by chunk (bounded memory), every stage threaded.
+namespace {
+inline uint64_t mix64(uint64_t z) { z += 0x9e3779b97f4a7c15ull; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }
+inline int synth_name(char *qn, uint64_t i, int mode) {
+    if (mode != 2) return snprintf(qn, 64, "r%llu", (unsigned long long)i) + 1;
+    const uint64_t h = mix64(i * 2 + 1);
+    return snprintf(qn, 64, "A00%03u:%u:HXX%05u:%u:%u:%u:%u", (unsigned)(h % 7), 100 + (unsigned)((h >> 8) % 5), (unsigned)((h >> 16) % 3) + 17000,
+                    1 + (unsigned)((i >> 22) & 3), 1101 + (unsigned)((i >> 14) & 255), (unsigned)((h >> 24) % 32000) + 1000,
+                    (unsigned)((h >> 40) % 36000) + 1000) + 1;
+}
+}  // namespace
+
 int covh_bam_write(const char *path, uint32_t n_targets, const char *const *names, const uint64_t *lens,
                    const cov_batch *b, int with_seq, int level, int threads) {
     std::vector<uint8_t> head;
@@ -617,71 +1242,130 @@ int covh_bam_write(const char *path, uint32_t n_targets, const char *const *name
         const size_t l = strlen(names[i]) + 1;
         put32(head, (uint32_t)l); head.insert(head.end(), names[i], names[i] + l); put32(head, (uint32_t)lens[i]);
     }
-    const uint64_t R = b->n_records;
-    // per-record sizes -> offsets
-    std::vector<uint64_t> off(R + 1, 0);
-    for (uint64_t i = 0; i < R; i++) {
-        const uint32_t nc = b->cigar_off[i + 1] - b->cigar_off[i];
-        const uint32_t ls = with_seq ? b->l_seq[i] : 0;
-        char qn[32]; const int lq = snprintf(qn, sizeof qn, "r%llu", (unsigned long long)i) + 1;
-        const uint32_t aux = b->nm_kind[i] == COV_NM_UNSIGNED ? (b->nm[i] < 256 ? 4 : b->nm[i] < 65536 ? 5 : 7) : b->nm_kind[i] == COV_NM_BADTYPE ? 4 : 0;
-        off[i + 1] = off[i] + 36 + lq + 4ull * nc + (ls + 1) / 2 + ls + aux;
-    }
-    std::vector<uint8_t> raw(head.size() + off[R]);
-    memcpy(raw.data(), head.data(), head.size());
-    uint8_t *base = raw.data() + head.size();
-    parallel_for(R, threads, [&](size_t i) {
-        uint8_t *p = base + off[i];
-        const uint32_t nc = b->cigar_off[i + 1] - b->cigar_off[i];
-        const uint32_t ls = with_seq ? b->l_seq[i] : 0;
-        char qn[32]; const int lq = snprintf(qn, sizeof qn, "r%llu", (unsigned long long)i) + 1;
-        const uint32_t bs = (uint32_t)(off[i + 1] - off[i] - 4);
-        auto w32 = [&](uint32_t x) { memcpy(p, &x, 4); p += 4; };
-        w32(bs); w32((uint32_t)b->tid[i]); w32((uint32_t)b->pos[i]);
-        *p++ = (uint8_t)lq; *p++ = b->mapq[i];
-        const uint16_t bin = 4680, ncg = (uint16_t)nc, fl = b->flag[i];
-        memcpy(p, &bin, 2); p += 2; memcpy(p, &ncg, 2); p += 2; memcpy(p, &fl, 2); p += 2;
-        w32(ls); w32((uint32_t)-1); w32((uint32_t)-1); w32(0);
-        memcpy(p, qn, lq); p += lq;
-        if (nc) { memcpy(p, b->cigar + b->cigar_off[i], 4ull * nc); p += 4ull * nc; }
-        memset(p, 0x11, (ls + 1) / 2); p += (ls + 1) / 2;
-        memset(p, 0xff, ls); p += ls;
-        if (b->nm_kind[i] == COV_NM_UNSIGNED) {
-            *p++ = 'N'; *p++ = 'M';
-            if (b->nm[i] < 256) { *p++ = 'C'; *p++ = (uint8_t)b->nm[i]; }
-            else if (b->nm[i] < 65536) { *p++ = 'S'; const uint16_t v = (uint16_t)b->nm[i]; memcpy(p, &v, 2); p += 2; }
-            else { *p++ = 'I'; memcpy(p, &b->nm[i], 4); p += 4; }
-        } else if (b->nm_kind[i] == COV_NM_BADTYPE) { *p++ = 'N'; *p++ = 'M'; *p++ = 'c'; *p++ = 1; }
-    });
-    const size_t BLK = 0xff00;
-    const size_t nblk = (raw.size() + BLK - 1) / BLK;
-    std::vector<std::vector<uint8_t>> comp(nblk);
-    std::atomic<bool> ok{true};
-    parallel_for(nblk, threads, [&](size_t k) {
-        const size_t s0 = k * BLK, n = std::min(BLK, raw.size() - s0);
-        std::vector<uint8_t> &o = comp[k];
-        o.resize(n + n / 8 + 128);
-        z_stream zs; memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok = false; return; }
-        zs.next_in = &raw[s0]; zs.avail_in = (uInt)n; zs.next_out = o.data() + 18; zs.avail_out = (uInt)(o.size() - 26);
-        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { ok = false; deflateEnd(&zs); return; }
-        const size_t clen = zs.total_out;
-        deflateEnd(&zs);
-        static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-        memcpy(o.data(), hdr, 16);
-        const uint16_t bsz = (uint16_t)(clen + 25);
-        memcpy(o.data() + 16, &bsz, 2);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), &raw[s0], (uInt)n), isz = (uint32_t)n;
-        memcpy(o.data() + 18 + clen, &crc, 4); memcpy(o.data() + 22 + clen, &isz, 4);
-        o.resize(clen + 26);
-    });
-    if (!ok) return 1;
     FILE *f = fopen(path, "wb");
     if (!f) return 2;
-    for (auto &o : comp) fwrite(o.data(), 1, o.size(), f);
+    Pool pool(std::max(1, threads));
+    const uint64_t R = b->n_records;
+    const uint64_t CH = 1u << 21;                      // records per chunk
+    const size_t BLK = 0xff00;
+    std::vector<uint8_t> raw(head);                    // bytes not yet written as blocks (header first)
+    std::vector<uint64_t> off;
+    std::vector<std::vector<uint8_t>> comp;
+    const LibDeflate &LD = libdeflate();
+    std::atomic<bool> ok{true};
+    uint8_t qtab[256];
+    for (int v = 0; v < 256; v++) qtab[v] = v < 225 ? 37 : v < 246 ? 25 : v < 254 ? 11 : 2;
+    static const uint8_t btab[4] = {1, 2, 4, 8};
+    auto flush_blocks = [&](bool final) {
+        const size_t nblk = final ? (raw.size() + BLK - 1) / BLK : raw.size() / BLK;
+        if (comp.size() < nblk) comp.resize(nblk);
+        pool.run(nblk, [&](size_t k) {
+            const size_t s0 = k * BLK, n = std::min(BLK, raw.size() - s0);
+            std::vector<uint8_t> &o = comp[k];
+            o.resize(n + n / 8 + 256);
+            size_t clen = 0;
+            if (LD.ok_c) {
+                thread_local void *cmp = nullptr; thread_local int cmp_level = -1;
+                if (!cmp || cmp_level != level) { if (cmp) LD.release_c(cmp); cmp = LD.alloc_c(std::max(1, std::min(12, level))); cmp_level = level; }
+                clen = cmp ? LD.compress(cmp, &raw[s0], n, o.data() + 18, o.size() - 26) : 0;
+            }
+            if (clen == 0) {
+                z_stream zs; memset(&zs, 0, sizeof zs);
+                if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok = false; return; }
+                zs.next_in = &raw[s0]; zs.avail_in = (uInt)n; zs.next_out = o.data() + 18; zs.avail_out = (uInt)(o.size() - 26);
+                if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { ok = false; deflateEnd(&zs); return; }
+                clen = zs.total_out;
+                deflateEnd(&zs);
+            }
+            static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+            memcpy(o.data(), hdr, 16);
+            const uint16_t bsz = (uint16_t)(clen + 25);
+            memcpy(o.data() + 16, &bsz, 2);
+            const uint32_t crc = LD.ok ? LD.crc32(0, &raw[s0], n) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), &raw[s0], (uInt)n), isz = (uint32_t)n;
+            memcpy(o.data() + 18 + clen, &crc, 4); memcpy(o.data() + 22 + clen, &isz, 4);
+            o.resize(clen + 26);
+        });
+        for (size_t k = 0; k < nblk; k++) fwrite(comp[k].data(), 1, comp[k].size(), f);
+        const size_t used = std::min(raw.size(), nblk * BLK);
+        raw.erase(raw.begin(), raw.begin() + used);
+    };
+    for (uint64_t c0 = 0; c0 < R || c0 == 0; c0 += CH) {
+        const uint64_t c1 = std::min(R, c0 + CH), n = c1 - c0;
+        off.assign(n + 1, 0);
+        // per-record sizes -> offsets (blocked prefix sum)
+        const size_t nb = std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 4, n / 16384 + 1));
+        std::vector<uint64_t> tot(nb + 1, 0);
+        pool.run(nb, [&](size_t k) {
+            const uint64_t lo = n * k / nb, hi = n * (k + 1) / nb;
+            uint64_t acc = 0;
+            for (uint64_t j = lo; j < hi; j++) {
+                const uint64_t i = c0 + j;
+                const uint32_t nc = b->cigar_off[i + 1] - b->cigar_off[i];
+                const uint32_t ls = with_seq ? b->l_seq[i] : 0;
+                char qn[64]; const int lq = synth_name(qn, i, with_seq);
+                const uint32_t aux = b->nm_kind[i] == COV_NM_UNSIGNED ? (b->nm[i] < 256 ? 4 : b->nm[i] < 65536 ? 5 : 7) : b->nm_kind[i] == COV_NM_BADTYPE ? 4 : 0;
+                acc += 36 + lq + 4ull * nc + (ls + 1) / 2 + ls + aux;
+                off[j + 1] = acc;
+            }
+            tot[k + 1] = acc;
+        });
+        for (size_t k = 0; k < nb; k++) tot[k + 1] += tot[k];
+        pool.run(nb, [&](size_t k) {
+            if (!k) return;
+            const uint64_t lo = n * k / nb, hi = n * (k + 1) / nb;
+            for (uint64_t j = lo; j < hi; j++) off[j + 1] += tot[k];
+        });
+        const size_t base0 = raw.size();
+        raw.resize(base0 + off[n]);
+        uint8_t *base = raw.data() + base0;
+        pool.run(n, [&](size_t j) {
+            const uint64_t i = c0 + j;
+            uint8_t *p = base + off[j];
+            const uint32_t nc = b->cigar_off[i + 1] - b->cigar_off[i];
+            const uint32_t ls = with_seq ? b->l_seq[i] : 0;
+            char qn[64]; const int lq = synth_name(qn, i, with_seq);
+            const uint32_t bs = (uint32_t)(off[j + 1] - off[j] - 4);
+            auto w32 = [&](uint32_t x) { memcpy(p, &x, 4); p += 4; };
+            w32(bs); w32((uint32_t)b->tid[i]); w32((uint32_t)b->pos[i]);
+            *p++ = (uint8_t)lq; *p++ = b->mapq[i];
+            const uint16_t bin = 4680, ncg = (uint16_t)nc, fl = b->flag[i];
+            memcpy(p, &bin, 2); p += 2; memcpy(p, &ncg, 2); p += 2; memcpy(p, &fl, 2); p += 2;
+            w32(ls); w32((uint32_t)-1); w32((uint32_t)-1); w32(0);
+            memcpy(p, qn, lq); p += lq;
+            if (nc) { memcpy(p, b->cigar + b->cigar_off[i], 4ull * nc); p += 4ull * nc; }
+            if (with_seq == 2) {
+                uint64_t st = mix64(i ^ 0x5eedull);
+                const uint32_t nb2 = (ls + 1) / 2;
+                for (uint32_t k = 0; k < nb2; k += 16) {         // 16 bytes = 32 bases per 64-bit draw
+                    uint64_t r = st = mix64(st);
+                    for (uint32_t q = k; q < std::min(nb2, k + 16); q++, r >>= 4) p[q] = (uint8_t)((btab[r & 3] << 4) | btab[(r >> 2) & 3]);
+                }
+                if (ls & 1) p[nb2 - 1] &= 0xf0;
+                p += nb2;
+                for (uint32_t k = 0; k < ls; k += 8) {
+                    uint64_t r = st = mix64(st);
+                    for (uint32_t q = k; q < std::min(ls, k + 8); q++, r >>= 8) p[q] = qtab[r & 255];
+                }
+                p += ls;
+            } else {
+                memset(p, 0x11, (ls + 1) / 2); p += (ls + 1) / 2;
+                memset(p, 0xff, ls); p += ls;
+            }
+            if (b->nm_kind[i] == COV_NM_UNSIGNED) {
+                *p++ = 'N'; *p++ = 'M';
+                if (b->nm[i] < 256) { *p++ = 'C'; *p++ = (uint8_t)b->nm[i]; }
+                else if (b->nm[i] < 65536) { *p++ = 'S'; const uint16_t v = (uint16_t)b->nm[i]; memcpy(p, &v, 2); p += 2; }
+                else { *p++ = 'I'; memcpy(p, &b->nm[i], 4); p += 4; }
+            } else if (b->nm_kind[i] == COV_NM_BADTYPE) { *p++ = 'N'; *p++ = 'M'; *p++ = 'c'; *p++ = 1; }
+        }, 64);
+        flush_blocks(c1 >= R);
+        if (!ok) { fclose(f); return 1; }
+        if (R == 0) break;
+    }
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     fwrite(eof, 1, 28, f);
-    fclose(f);
+    const bool werr = ferror(f) != 0;
+    if (fclose(f) != 0 || werr) return 3;
     return 0;
 }
 

@@ -1870,8 +1870,10 @@ __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, 
                 }   // RW_BUCKET: delivered through the tile's bucket
             };
             apply(rw0, ds.x + (u32)lane);
-            apply(rw1, ds.x + 64u + (u32)lane);
-            for (u32 i = ds.x + 128u + (u32)lane; i < ds.y; i += 64) apply(a.runs[i], i);   // deep tiles only
+            if (ds.y - ds.x > 64u) {     // wave-uniform: more than half of the tiles of a 7x-deep sample stop here
+                apply(rw1, ds.x + 64u + (u32)lane);
+                for (u32 i = ds.x + 128u + (u32)lane; i < ds.y; i += 64) apply(a.runs[i], i);   // deep tiles only
+            }
             for (u32 j = (u32)lane; j < cxn; j += 64) { const uint2 q = a.cx_runs[(u64)cxo + j]; add_run(q.x, q.y); }   // long reads
             asm volatile("" ::: "memory");
             sv0 = S4[2 * lane]; sv1 = S4[2 * lane + 1]; ev0 = E4[2 * lane]; ev1 = E4[2 * lane + 1];

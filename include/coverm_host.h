@@ -153,10 +153,33 @@ void covh_bam_batch(const covh_bam *h, cov_batch *out);
 const int32_t *covh_bam_mtid(const covh_bam *h);
 const uint32_t *covh_bam_qname_off(const covh_bam *h); /* n_records + 1, NULL without want_names */
 const char *covh_bam_qnames(const covh_bam *h);
-/* Writes a batch as a coordinate-sorted BGZF BAM (benchmark/test inputs): read names r<i>, SEQ all 'A' (or '*' when
- * !with_seq), NM typed C/S/I by magnitude.  Returns 0 on success. */
+/* Writes a batch as a coordinate-sorted BGZF BAM (benchmark/test inputs), NM typed C/S/I by magnitude.  with_seq: 0 = SEQ
+ * '*'; 1 = read names r<i>, SEQ all 'A', QUAL 0xff (compresses ~18x: inflate cost far below a real BAM's); 2 = realistic
+ * entropy: random bases, Phred-like binned qualities, Illumina-style names (~65 compressed bytes per 150 bp read).
+ * Chunked, bounded memory.  Returns 0 on success. */
 int covh_bam_write(const char *path, uint32_t n_targets, const char *const *names, const uint64_t *lens,
                    const cov_batch *batch, int with_seq, int level, int threads);
+
+/* ---- streamed reader: the same decode window by window with bounded memory (three ~32 MiB-compressed windows and three
+ * page-locked SoA batches circulate), so that inflate, record parsing and the H2D copy of finished batches overlap inside one
+ * file.  BAM only (BGZF); no read names (pair-mode filtering and --gff use covh_bam_open).  span_count > 1 selects the
+ * span_index-th of span_count tid ranges, cut where the tid changes nearest to k/span_count of the file; the rank's first
+ * BGZF block is located by probing the file, so each rank inflates only its own part.  A sorted BAM's records
+ * fall into exactly one span each (records with tid -1 go to the last one).
+ *   h = covh_bam_stream_open(path, threads, 0, 1, err, cap);   header accessors are valid at once
+ *   while (covh_bam_stream_next(h, &batch) == 1) cov_push_batch(session, &batch);   arrays stay valid until the next call
+ * covh_bam_stream_next returns 1 (batch), 0 (end of file / span) or -1 (covh_bam_stream_error). */
+typedef struct covh_bam_stream covh_bam_stream;
+covh_bam_stream *covh_bam_stream_open(const char *path, int threads, uint32_t span_index, uint32_t span_count, char *err, size_t errcap);
+uint32_t covh_bam_stream_n_targets(const covh_bam_stream *h);
+const char *covh_bam_stream_target_name(const covh_bam_stream *h, uint32_t i);
+uint64_t covh_bam_stream_target_len(const covh_bam_stream *h, uint32_t i);
+int covh_bam_stream_next(covh_bam_stream *h, cov_batch *out);
+const char *covh_bam_stream_error(const covh_bam_stream *h);
+uint64_t covh_bam_stream_n_records(const covh_bam_stream *h);  /* records handed out so far */
+uint64_t covh_bam_stream_peak_bytes(const covh_bam_stream *h); /* largest total of window + batch buffers held */
+void covh_bam_stream_timing(const covh_bam_stream *h, double *out5); /* s: read, inflate, parse, inflate-side wait, parse-side wait */
+void covh_bam_stream_close(covh_bam_stream *h);
 
 /* ---- reader-stage PAIR filter (ReferenceSortedBamFilter::read pair branch, filter.rs:117-228, filter_out = true).
  * The single-read branch runs on the device (cov_config.filter_single); the pair branch needs read names, which never
@@ -205,6 +228,11 @@ int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh
                        const cov_batch *records, const cov_config *cfg, cov_session *device_session, covh_depth_fn depth,
                        void *depth_ctx, uint64_t num_detected_primary_alignments, covh_taker *taker, const covh_estimator *est,
                        size_t n_est, int print_zero_coverage_genes, covh_reads_mapped *reads_mapped_out);
+
+/* ---- the orchestrator of `coverm contig|genome --bam-files ...` (src/bin/coverm.rs:1315-1704, 2088-2131, 1539-1628): argv as the
+ * coverm-amd binary takes it (argv[1] = "contig" | "genome", the reference's flag names, plus --device N / --devices a,b,...
+ * and --no-stream).  Writes the table to --output-file or stdout; returns the process exit code (1 after printing an error). */
+int covh_cli_main(int argc, char **argv);
 
 /* calculate_coverage for one entry built from explicit sums (used by unit tests). */
 typedef struct {

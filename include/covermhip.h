@@ -184,6 +184,17 @@ cov_status cov_fetch_hist(cov_session *s, uint64_t *hist);
 /* Bit-exact per-base depth of one contig (target_len[tid] entries), for parity checks. */
 cov_status cov_copy_depth(cov_session *s, uint32_t tid, int32_t *depth_out);
 cov_status cov_reset(cov_session *s);
+/* Optional: size the record store for n_records / n_cigar up front (a streamed ingest that knows roughly what is coming
+ * avoids regrowing the HBM arrays while it pushes). */
+cov_status cov_reserve(cov_session *s, uint64_t n_records, uint64_t n_cigar);
+
+/* Multi-GPU, one process: after cov_finish on every session (one per device, same targets), ONE RCCL gather moves each
+ * rank's per-contig result block (fixed size: 160 B per contig + counters) to the device of sessions[root] over xGMI and
+ * from there to the host in one DMA; cov_gathered then decodes rank r's block exactly as cov_finish decodes its own
+ * (same error reporting).  librccl is bound at run time; COV_ERR_HIP if it is missing.  A device listed more than once
+ * (functional checks on a single-GPU box) is served by plain device copies, since RCCL refuses two ranks on one device. */
+cov_status cov_gather(cov_session *const *sessions, uint32_t n, uint32_t root);
+cov_status cov_gathered(cov_session *root_session, uint32_t rank, cov_contig_stats *stats, cov_summary *summary);
 
 /* Average duration (ms) of one launch of kernel `k` during the last cov_finish, measured with HIP
  * events recorded on the session's stream around that kernel; *launches receives the count. */

@@ -143,3 +143,147 @@ def test_malformed_inputs_are_errors_not_crashes(tmp_path):
         assert str(ei.value), name
     af = cbam.read_alignment_file(good, threads=2)
     assert af.records.n_records == b.n_records
+
+
+# ---------------------------------------------------------------------------------- streamed reader (covh_bam_stream_*)
+def _same_records(a, b):
+    for f in FIELDS + ("l_seq",):
+        np.testing.assert_array_equal(getattr(a, f), getattr(b, f), err_msg=f)
+
+
+@pytest.mark.parametrize("window_kb,threads,with_seq", [(64, 1, 1), (64, 4, 2), (300, 8, 2), (32768, 4, 0)])
+def test_streamed_reader_equals_whole_file_reader(tmp_path, monkeypatch, window_kb, threads, with_seq):
+    """Window by window (windows far smaller than the file, so records and BGZF blocks straddle every boundary) the
+    streamed reader must hand out exactly the records covh_bam_open decodes, in order."""
+    monkeypatch.setenv("COVERM_STREAM_WINDOW_KB", str(window_kb))
+    ref = synth.make_reference(30, 5_000_000, seed=8, min_len=5000, max_len=800_000)
+    b = synth.make_reads(ref, 60_000, seed=9)
+    p = str(tmp_path / "s.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=with_seq, threads=4)
+    whole = cbam.read_alignment_file(p, threads=2, want_names=False)
+    st = {}
+    names, lens, rec = cbam.read_streamed(p, threads=threads, stats=st)
+    assert names == whole.ref_names
+    np.testing.assert_array_equal(lens, whole.ref_lens)
+    _same_records(rec, whole.records)
+    np.testing.assert_array_equal(rec.pos, b.pos)
+    assert st["n_records"] == b.n_records
+    if window_kb < 1000:
+        assert st["peak_bytes"] < 64 << 20     # bounded: nowhere near the inflated size of the file
+
+
+def test_streamed_reader_fixtures_and_big_header(tmp_path, monkeypatch):
+    """Reference fixtures re-encoded (tiny BGZF blocks; eg2 has a 54 579-sequence header that spans many windows)."""
+    monkeypatch.setenv("COVERM_STREAM_WINDOW_KB", "64")
+    for name in ["7seqs.reads_for_seq1_and_seq2.bam", "k141_2005182.bam", "eg2.bam", "2seqs.reads_for_seq1.with_unmapped.bam"]:
+        d = load_fixture(name)
+        p = str(tmp_path / (name + ".re.bam"))
+        bamio.write_bam(p, d, block=1500 if d.n_records < 2000 else 0xFF00)
+        names, lens, rec = cbam.read_streamed(p, threads=3)
+        assert names == d.ref_names
+        for f in FIELDS:
+            np.testing.assert_array_equal(getattr(rec, f), getattr(d, f), err_msg=name + ":" + f)
+
+
+@pytest.mark.parametrize("spans", [2, 3, 8])
+def test_streamed_spans_partition_the_file(tmp_path, monkeypatch, spans):
+    """span k of n: every record in exactly one span, spans cut at tid changes, concatenation == the whole file; records
+    without a reference (tid -1, at the end of a sorted BAM) go to the last span."""
+    monkeypatch.setenv("COVERM_STREAM_WINDOW_KB", "128")
+    ref = synth.make_reference(40, 6_000_000, seed=18, min_len=5000, max_len=800_000)
+    b = synth.make_reads(ref, 80_000, seed=19)
+    n_un = 500                                      # unplaced unmapped reads at the end
+    import dataclasses
+    b = dataclasses.replace(
+        b, tid=np.concatenate([b.tid, np.full(n_un, -1, np.int32)]), pos=np.concatenate([b.pos, np.full(n_un, -1, np.int32)]),
+        flag=np.concatenate([b.flag, np.full(n_un, 4, np.uint16)]), mapq=np.concatenate([b.mapq, np.zeros(n_un, np.uint8)]),
+        nm=np.concatenate([b.nm, np.zeros(n_un, np.uint32)]), nm_kind=np.concatenate([b.nm_kind, np.zeros(n_un, np.uint8)]),
+        l_seq=np.concatenate([b.l_seq, np.full(n_un, 150, np.uint32)]),
+        cigar_off=np.concatenate([b.cigar_off, np.full(n_un, b.cigar_off[-1], np.uint32)]))
+    p = str(tmp_path / "sp.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=2, threads=4)
+    parts = [cbam.read_streamed(p, threads=2, span_index=k, span_count=spans)[2] for k in range(spans)]
+    assert sum(x.n_records for x in parts) == b.n_records
+    np.testing.assert_array_equal(np.concatenate([x.tid for x in parts]), b.tid)
+    np.testing.assert_array_equal(np.concatenate([x.pos for x in parts]), b.pos)
+    np.testing.assert_array_equal(np.concatenate([x.cigar for x in parts]), b.cigar)
+    tids = [set(np.unique(x.tid).tolist()) for x in parts]
+    for i in range(spans):
+        for j in range(i + 1, spans):
+            assert not (tids[i] & tids[j]), "a contig is split between spans %d and %d" % (i, j)
+    assert sum(1 for x in parts if x.n_records) >= 2
+    assert -1 in tids[-1] or all(-1 not in t for t in tids)
+
+
+def test_streamed_reader_errors(tmp_path, monkeypatch):
+    monkeypatch.setenv("COVERM_STREAM_WINDOW_KB", "64")
+    b = load_fixture("7seqs.reads_for_seq1_and_seq2.bam")
+    good = str(tmp_path / "good.bam")
+    bamio.write_bam(good, b, block=700)
+    raw = open(good, "rb").read()
+    for name, data in {"empty": b"", "garbage": bytes(range(256)) * 8, "cut_block": raw[:len(raw) // 2],
+                       "bad_crc": raw[:200] + bytes([raw[200] ^ 0xff]) + raw[201:], "cut_record": None}.items():
+        p = str(tmp_path / (name + ".bam"))
+        if name == "cut_record":      # whole BGZF blocks, but the BAM stream ends inside a record
+            d = bamio.read_bam(good)
+            full = str(tmp_path / "full.bam")
+            bamio.write_bam(full, d, block=300)
+            r2 = open(full, "rb").read()
+            # drop the last data block (keep the EOF marker)
+            blocks, q = [], 0
+            while q < len(r2):
+                bs = int.from_bytes(r2[q + 16:q + 18], "little") + 1
+                blocks.append(r2[q:q + bs]); q += bs
+            data = b"".join(blocks[:-2]) + blocks[-1]
+        open(p, "wb").write(data)
+        with pytest.raises(IOError) as ei:
+            cbam.read_streamed(p, threads=2)
+        assert str(ei.value), name
+    with pytest.raises(IOError):
+        cbam.read_streamed(str(tmp_path / "missing.bam"))
+
+
+def test_long_cigar_restored_from_cg_tag(tmp_path):
+    """A CIGAR of more than 65535 operations is stored as `<l_seq>S<ref_len>N` + CG:B,I; htslib (and so the reference,
+    contig.rs:168) sees the real CIGAR.  Both readers must resolve it."""
+    n_ops = 70_001
+    ops = np.empty(n_ops, np.uint32)
+    ops[0::2] = (3 << 4) | 0          # 3M
+    ops[1::2] = (1 << 4) | 2          # 1D
+    ref_span = int(((ops >> 4)[(ops & 15) != 1]).sum())
+    l_seq = int(((ops >> 4)[(ops & 15) == 0]).sum())
+    names, lens = ["big", "other"], [ref_span + 1000, 5000]
+    import struct
+    import zlib
+    def rec(tid, pos, cigar, lseq, aux, name=b"q"):
+        core = struct.pack("<iiBBHHHiiii", tid, pos, len(name) + 1, 30, 4680, len(cigar), 0, lseq, -1, -1, 0)
+        body = core + name + b"\0" + struct.pack("<%dI" % len(cigar), *cigar) + b"\x11" * ((lseq + 1) // 2) + b"\xff" * lseq + aux
+        return struct.pack("<i", len(body)) + body
+    cg = b"CGBI" + struct.pack("<I", n_ops) + ops.tobytes()
+    placeholder = [(l_seq << 4) | 4, (ref_span << 4) | 3]
+    r1 = rec(0, 100, placeholder, l_seq, b"NMC\x05" + cg)
+    r2 = rec(0, 200, [(50 << 4) | 0], 50, b"NMC\x01", b"plain")
+    r3 = rec(1, 10, [(20 << 4) | 4, (30 << 4) | 3], 20, b"NMC\x02", b"looks_like_it_but_no_CG")   # stays as stored
+    text = b""
+    hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 2)
+    for n, l in zip(names, lens):
+        hdr += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+    data = hdr + r1 + r2 + r3
+    out = b""
+    for s0 in range(0, len(data), 0xff00):
+        chunk = data[s0:s0 + 0xff00]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        out += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp +
+                struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    p = str(tmp_path / "cg.bam")
+    open(p, "wb").write(out)
+    af = cbam.read_alignment_file(p, threads=2)
+    _, _, st = cbam.read_streamed(p, threads=2)
+    for r in (af.records, st):
+        assert r.n_records == 3
+        np.testing.assert_array_equal(r.cigar_off, [0, n_ops, n_ops + 1, n_ops + 3])
+        np.testing.assert_array_equal(r.cigar[:n_ops], ops)
+        np.testing.assert_array_equal(r.nm, [5, 1, 2])
+        np.testing.assert_array_equal(r.nm_kind, [1, 1, 1])

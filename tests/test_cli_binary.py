@@ -155,3 +155,126 @@ def test_cli_binary_genome_definition_with_comments(tmp_path):
     bad.write_text("g1\tgenome2~seq1\n\ng2\tgenome5~seq2\n")
     r = subprocess.run([BIN, "genome", "-b", p, "--genome-definition", str(bad)], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "not a genome name and contig name separated by a tab" in r.stderr
+
+
+def _bamdata(ref, batch):
+    import numpy as np
+    from oracle.bamio import BamData
+    z = np.zeros(batch.n_records, np.int32)
+    return BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq, batch.l_seq.astype(np.int32), batch.nm,
+                   batch.nm_kind, batch.cigar_off, batch.cigar, z, z, z, [], "")
+
+
+@pytest.mark.gpu
+def test_cli_binary_streamed_equals_whole_file_and_oracle(tmp_path):
+    """The streamed ingest (many small windows -> many pushes) gives the same table as --no-stream and as the oracle; all
+    methods incl. histogram- and identity-based ones."""
+    from coverm_amd import bam as cbam, synth
+    from oracle import oracle as O
+    ref = synth.make_reference(60, 6_000_000, seed=31, min_len=1500, max_len=500_000)
+    batch = synth.make_reads(ref, 150_000, seed=32)
+    p = str(tmp_path / "s.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, batch, with_seq=2)
+    methods = ["mean", "trimmed_mean", "covered_fraction", "covered_bases", "variance", "length", "count", "reads_per_base", "rpkm", "tpm", "anir"]
+    env = dict(os.environ, COVERM_STREAM_WINDOW_KB="256", COVERM_CLI_TIMING="1")
+    a = subprocess.run([BIN, "contig", "-b", p, "-t", "6", "-m"] + methods, capture_output=True, text=True, timeout=300, env=env)
+    b = subprocess.run([BIN, "contig", "-b", p, "-t", "6", "--no-stream", "-m"] + methods, capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stderr
+    assert b.returncode == 0, b.stderr
+    assert "streamed" in a.stderr and "whole file" not in a.stderr
+    assert a.stdout == b.stdout
+    assert a.stdout == O.run_cli("contig", [p], bams=[_bamdata(ref, batch)], methods=methods)
+    # single-read filter path, streamed
+    a = subprocess.run([BIN, "contig", "-b", p, "-t", "6", "-m", "mean", "variance", "--min-read-percent-identity", "98", "--min-read-aligned-length", "100"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert a.returncode == 0, a.stderr
+    assert a.stdout == O.run_cli("contig", [p], bams=[_bamdata(ref, batch)], methods=["mean", "variance"], min_read_percent_identity=98,
+                                 min_read_aligned_length=100)
+
+
+@pytest.mark.gpu
+def test_cli_binary_each_bam_uses_its_own_header(tmp_path):
+    """contig.rs:29-32: every BAM is scanned against its own header.  Two BAMs with the same NUMBER of references but
+    different names and lengths: the streaming taker (sparse output) reports each against its own header; the cached taker
+    (dense output) exits with the reference's message (coverage_takers.rs:140-148)."""
+    from coverm_amd import bam as cbam, synth
+    from oracle import oracle as O
+    refa = synth.make_reference(12, 900_000, seed=41, min_len=1500, max_len=200_000)
+    refb = synth.make_reference(12, 1_400_000, seed=42, min_len=1500, max_len=300_000)
+    refb.names = ["other_" + n for n in refb.names]
+    ba, bb = synth.make_reads(refa, 20_000, seed=43), synth.make_reads(refb, 25_000, seed=44)
+    pa, pb = str(tmp_path / "a.bam"), str(tmp_path / "b.bam")
+    cbam.write_bam(pa, refa.names, refa.lengths, ba, with_seq=1)
+    cbam.write_bam(pb, refb.names, refb.lengths, bb, with_seq=0)
+    r = subprocess.run([BIN, "contig", "-b", pa, pb, "-m", "mean", "covered_fraction", "--output-format", "sparse"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == O.run_cli("contig", [pa, pb], bams=[_bamdata(refa, ba), _bamdata(refb, bb)], methods=["mean", "covered_fraction"],
+                                 output_format="sparse")
+    assert "other_" in r.stdout
+    r = subprocess.run([BIN, "contig", "-b", pa, pb, "-m", "mean"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "Found a difference amongst the reference sets used for mapping" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["contig", "genome"])
+def test_cli_binary_span_sharded_devices(tmp_path, mode):
+    """--devices with fewer BAMs than devices: the BAM is cut into tid spans, one session + stream reader per span, result
+    blocks gathered on the first device (cov_gather).  Device 0 listed three times = three ranks on the one GPU of the test
+    box (RCCL refuses that, so the blocks move by device copies; the span / merge logic is the same).  Output == one device."""
+    from coverm_amd import bam as cbam, synth
+    ref = synth.make_reference(90, 8_000_000, seed=51, min_len=1500, max_len=500_000)
+    batch = synth.make_reads(ref, 200_000, seed=52)
+    p = str(tmp_path / "s.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, batch, with_seq=2)
+    extra = ["-m", "mean", "trimmed_mean", "variance", "count", "anir"] if mode == "contig" else ["-s", "~", "-m", "relative_abundance", "mean", "variance"]
+    env = dict(os.environ, COVERM_STREAM_WINDOW_KB="512")
+    one = subprocess.run([BIN, mode, "-b", p, "-t", "4"] + extra, capture_output=True, text=True, timeout=300, env=env)
+    three = subprocess.run([BIN, mode, "-b", p, "-t", "6", "--devices", "0,0,0"] + extra, capture_output=True, text=True, timeout=300, env=env)
+    assert one.returncode == 0, one.stderr
+    assert three.returncode == 0, three.stderr
+    assert three.stdout == one.stdout
+    assert [l for l in three.stderr.splitlines() if "reads mapped out of" in l] == [l for l in one.stderr.splitlines() if "reads mapped out of" in l]
+
+
+@pytest.mark.gpu
+def test_cli_binary_rccl_gather_world_one_and_sample_parallel(tmp_path):
+    """`--devices 0` with COVERM_FORCE_RCCL: the gather runs through librccl (ncclCommInitAll + ncclGather, world size 1) —
+    the code path an 8-GPU node takes, minus the peers.  Several BAMs on a repeated device list = sample-parallel lanes."""
+    from coverm_amd import bam as cbam, synth
+    ref = synth.make_reference(30, 2_000_000, seed=61, min_len=1500, max_len=300_000)
+    paths = []
+    for k in range(3):
+        b = synth.make_reads(ref, 30_000 + 5_000 * k, seed=62 + k)
+        p = str(tmp_path / ("s%d.bam" % k))
+        cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=1)
+        paths.append(p)
+    base = subprocess.run([BIN, "contig", "-b"] + paths + ["-m", "mean", "variance"], capture_output=True, text=True, timeout=300)
+    assert base.returncode == 0, base.stderr
+    lanes = subprocess.run([BIN, "contig", "-b"] + paths + ["-m", "mean", "variance", "--devices", "0,0", "-t", "4"], capture_output=True, text=True, timeout=300)
+    assert lanes.returncode == 0, lanes.stderr
+    assert lanes.stdout == base.stdout
+    # world-size-1 RCCL gather through the span path (one BAM, device list of one, forced)
+    import ctypes as C
+    import numpy as np
+    from coverm_amd import native
+    from coverm_amd.engine import FilterConfig, Session
+    L = native.lib()
+    L.cov_gather.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32]
+    L.cov_gathered.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(native.CovSummary)]
+    b = synth.make_reads(ref, 50_000, seed=70)
+    os.environ["COVERM_FORCE_RCCL"] = "1"
+    try:
+        with Session(0, FilterConfig(), 75, want_hist=True) as s:
+            s.set_targets(ref.lengths)
+            s.push(b)
+            st, summ = s.finish()
+            arr = (C.c_void_p * 1)(s._h)
+            rc = L.cov_gather(arr, 1, 0)
+            assert rc == 0, L.cov_last_error(s._h)
+            st2 = np.zeros(len(ref.lengths), dtype=native.CONTIG_STATS_DTYPE)
+            summ2 = native.CovSummary()
+            assert L.cov_gathered(s._h, 0, st2.ctypes.data, C.byref(summ2)) == 0
+            assert st2.tobytes() == st.tobytes()
+            assert summ2.num_detected_primary_alignments == summ.num_detected_primary_alignments and summ2.n_records == b.n_records
+    finally:
+        del os.environ["COVERM_FORCE_RCCL"]

@@ -11,6 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", "profbench_" + tag)
+if not os.path.isdir(src):
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)      # tools/prof_cmd.sh
 dst = os.path.join(ROOT, "profiles")
 ks = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 assert ks, "no kernel_stats.csv under " + src
@@ -24,7 +26,7 @@ summ = {k: {c: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for 
         for k, cs in sorted(acc.items())}
 json.dump(summ, open(os.path.join(dst, tag + "_bench_pmc_summary.json"), "w"), indent=1)
 traffic = {"_source": tag, "_formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB -> bytes, per launch (MI355X_MICROARCH.md, gfx950 correction)"}
-short = {"k_prep<": "k_prep", "k_ranges<": "k_ranges", "k_pileup": "k_pileup", "k_cx_expand": "k_cx_expand",
+short = {"k_prep<": "k_prep", "k_ranges<": "k_ranges", "k_pileup_fast": "k_pileup", "k_pileup_stream": "k_pileup_slow_tiles", "k_cx_expand": "k_cx_expand",
          "k_tile_scan": "k_tile_scan"}
 for k, cs in summ.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
