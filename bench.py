@@ -213,13 +213,14 @@ def end_to_end(a, threads):
         env = dict(os.environ, COVERM_CLI_TIMING="1")
         for rep in range(2):        # first run pays the page cache fill of a file just written (it is warm: we wrote it) and HIP start-up
             t0 = time.perf_counter()
-            p = subprocess.run(["/usr/bin/time", "-f", "MAXRSS_KB %M", ] + cmd, capture_output=True, text=True, env=env)
+            p = subprocess.run(cmd, capture_output=True, text=True, env=env)
             dt = time.perf_counter() - t0
             if p.returncode != 0:
                 raise RuntimeError("coverm-amd failed: " + p.stderr[-2000:])
-            rss = [int(l.split()[1]) for l in p.stderr.splitlines() if l.startswith("MAXRSS_KB")]
+            import resource
+            rss = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss * 1024    # largest child so far: the bench spawns nothing bigger
             if best is None or dt < best[0]:
-                best = (dt, rss[0] * 1024 if rss else None, p.stderr)
+                best = (dt, rss, p.stderr)
         gpu_s, gpu_rss, gpu_err = best
         mapped = [l for l in gpu_err.splitlines() if "reads mapped out of" in l]
         timing = [l for l in gpu_err.splitlines() if "stream read" in l or "ingest (decode+push)" in l]
@@ -404,10 +405,10 @@ def main():
                                                        "one sample per GPU, RCCL gather of per-contig coverages") if world > 1 else "single GPU"},
             "gbp_per_s": aligned_bp * world * a.steps / elapsed / 1e9,
             "roofline": roof,
-            "host": {"generation_s": gen_s, "nproc": os.cpu_count()},
+            "host": {"generation_s": gen_s, "nproc": os.cpu_count(), "usable_cpus": usable_cpus()},
         }
         if not a.no_cpu_baseline:
-            threads = max(1, min(os.cpu_count() or 1, int(os.environ.get("COVERM_BENCH_THREADS", os.cpu_count() or 1))))
+            threads = max(1, int(os.environ.get("COVERM_BENCH_THREADS", usable_cpus())))
             par, (cpu_mapped, cpu_dt) = parity_check(ref, batch, gpu_cov, stats, hist)
             out["parity_checked"] = par
             if not par["equal"]:
@@ -456,6 +457,19 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(exit_code)
+
+
+def usable_cpus():
+    """CPUs this process may really use: affinity mask and the cgroup CPU quota (the GPU lease boxes show 256 logical CPUs but
+    grant 16 through cpu.max; more decoder threads than that only add contention)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def sess_tiles(sess, ref):
