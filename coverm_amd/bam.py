@@ -158,6 +158,72 @@ def read_streamed(path: str, threads: int = None, span_index: int = 0, span_coun
                                     coff, cat("cigar"))
 
 
+def gpu_ingest(session, path: str, threads: int = None, check_crc: bool = True, mask=None):
+    """Device ingest (covh_bam_read_header + covh_bam_gpu_ingest): the GPU inflates the BGZF blocks, finds the records and fills
+    the session's record store.  Sets the session's targets from the file's header.  Returns (ref_names, ref_lens, n_records,
+    timing dict); raises IngestFallback when the file needs the CPU reader."""
+    L = _lib()
+    if not getattr(L, "_ingest_bound", False):
+        L.covh_bam_read_header.restype = C.c_void_p
+        L.covh_bam_read_header.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.covh_bam_header_free.argtypes = [C.c_void_p]
+        L.covh_bam_header_free.restype = None
+        L.covh_bam_header_n_targets.restype = C.c_uint32
+        L.covh_bam_header_n_targets.argtypes = [C.c_void_p]
+        L.covh_bam_header_target_name.restype = C.c_char_p
+        L.covh_bam_header_target_name.argtypes = [C.c_void_p, C.c_uint32]
+        L.covh_bam_header_target_len.restype = C.c_uint64
+        L.covh_bam_header_target_len.argtypes = [C.c_void_p, C.c_uint32]
+        L.covh_bam_header_first_record.restype = C.c_uint64
+        L.covh_bam_header_first_record.argtypes = [C.c_void_p]
+        L.covh_bam_gpu_ingest.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double),
+                                          C.c_char_p, C.c_size_t]
+        L._ingest_bound = True
+    if threads is None:
+        threads = min(16, os.cpu_count() or 1)
+    err = C.create_string_buffer(512)
+    hd = L.covh_bam_read_header(path.encode(), err, 512)
+    if not hd:
+        raise IOError(err.value.decode() or "cannot read %s" % path)
+    try:
+        nt = L.covh_bam_header_n_targets(hd)
+        names = [L.covh_bam_header_target_name(hd, i).decode() for i in range(nt)]
+        lens = np.asarray([L.covh_bam_header_target_len(hd, i) for i in range(nt)], dtype=np.int64)
+        session.set_targets(lens, mask)
+        n = C.c_uint64(0)
+        t = (C.c_double * 4)()
+        rc = L.covh_bam_gpu_ingest(path.encode(), threads, session._h, hd, int(check_crc), C.byref(n), t, err, 512)
+        if rc == 1:
+            raise IngestFallback(err.value.decode())
+        if rc != 0:
+            raise IOError(err.value.decode())
+        return names, lens, int(n.value), dict(read=t[0], slot_wait=t[1], end=t[2], total=t[3])
+    finally:
+        L.covh_bam_header_free(hd)
+
+
+class IngestFallback(RuntimeError):
+    """The device ingest declined the file (reason in the message): decode it with the CPU reader."""
+
+
+def session_records(session) -> RecordBatch:
+    """Test hook (cov_copy_records): the session's own record store copied back to the host."""
+    L = _lib()
+    L.cov_copy_records.argtypes = [C.c_void_p, C.POINTER(CovBatch), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    n, nc = C.c_uint64(0), C.c_uint64(0)
+    assert L.cov_copy_records(session._h, None, C.byref(n), C.byref(nc)) == 0
+    n, nc = int(n.value), int(nc.value)
+    rb = RecordBatch(np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.uint16), np.zeros(n, np.uint8), np.zeros(n, np.uint32),
+                     np.zeros(n, np.uint8), np.zeros(n, np.uint32), np.zeros(n + 1, np.uint32), np.zeros(nc, np.uint32))
+    cb = CovBatch()
+    for k in ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar"):
+        a = getattr(rb, k)
+        setattr(cb, k, a.ctypes.data if a.size else None)
+    cb.n_records = n
+    assert L.cov_copy_records(session._h, C.byref(cb), None, None) == 0
+    return rb
+
+
 def write_bam(path: str, names, lens, batch: RecordBatch, with_seq=True, level: int = 1, threads: int = None):
     """Threaded BGZF/BAM writer (covh_bam_write) for synthetic inputs.  with_seq: False / 0 = SEQ '*', True / 1 = constant
     SEQ and QUAL, 2 = realistic entropy (random bases, Phred-like qualities, Illumina-style names)."""

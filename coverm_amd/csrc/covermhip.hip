@@ -3,6 +3,7 @@
 // (pileup_kernels.hip.h).  There is deliberately no CPU fallback: without a usable HIP device every
 // entry point fails with COV_ERR_HIP.
 #include "pileup_kernels.hip.h"
+#include "ingest_kernels.hip.h"
 
 #include <algorithm>
 #include <cstddef>
@@ -129,6 +130,21 @@ struct cov_session {
     DevBuf<u32> d_arena;
     DevBuf<u64> d_chist;
     DevBuf<int32_t> d_depth;
+
+    // device ingest (cov_ingest_*): compressed file and inflated stream in HBM, BGZF block table, record-boundary scratch
+    DevBuf<uint8_t> g_comp, g_infl, g_scratch;
+    DevBuf<covi::BgzfBlock> g_blocks;
+    DevBuf<u32> g_status;
+    DevBuf<covi::SegInfo> g_seg;
+    DevBuf<u64> g_recbase, g_cigbase, g_result, g_tok;   // g_result: [0] records [1] CIGAR words [2] status [3] inflate failures (u32) | extract failures (u32) [4..6] first bad segment
+    DevBuf<u32> g_ntok;
+    uint64_t ing_launched = 0;   // blocks already handed to k_inflate (launches are batched so that each fills the GPU)
+    covi::BgzfBlock *h_blocks = nullptr; size_t h_blocks_cap = 0;   // page-locked mirror of the block table (async uploads read from it)
+    uint64_t ing_comp = 0, ing_infl = 0, ing_blocks = 0;
+    bool ing_active = false;
+    hipStream_t ing_copy = nullptr;
+    hipEvent_t ing_ev[2] = {nullptr, nullptr}, ing_fed = nullptr;
+    double ing_ms_inflate = 0, ing_ms_parse = 0;
 
     // results of the last finish
     bool finished = false;
@@ -389,6 +405,13 @@ void cov_destroy(cov_session *s) {
     s->d_tile_first.release(); s->d_tcnt.release(); s->d_fov.release(); s->d_tscan.release(); s->d_ttop.release(); s->d_slow_list.release();
     s->d_ctg_scratch.release(); s->d_depth_all.release(); s->d_depth_off.release(); s->d_iv.release(); s->d_ivst.release(); s->d_ivhist.release();
     s->d_cx_list.release(); s->d_cx_cnt.release(); s->d_cx_cur.release(); s->d_cx_scan.release(); s->d_cx_top.release(); s->d_cx_runs.release();
+    s->g_comp.release(); s->g_infl.release(); s->g_scratch.release(); s->g_blocks.release(); s->g_status.release(); s->g_seg.release();
+    s->g_recbase.release(); s->g_cigbase.release(); s->g_result.release(); s->g_tok.release(); s->g_ntok.release();
+    if (s->h_blocks) (void)hipHostFree(s->h_blocks);
+    s->h_blocks = nullptr;
+    if (s->ing_copy) { (void)hipStreamSynchronize(s->ing_copy); (void)hipStreamDestroy(s->ing_copy); }
+    for (int k = 0; k < 2; k++) if (s->ing_ev[k]) (void)hipEventDestroy(s->ing_ev[k]);
+    if (s->ing_fed) (void)hipEventDestroy(s->ing_fed);
     s->d_res.release(); s->d_ctg.p = nullptr; s->d_glob.p = nullptr; s->d_desc.release(); s->d_gather.release();
     if (s->h_gather) (void)hipHostFree(s->h_gather);
     s->h_gather = nullptr;
@@ -853,6 +876,222 @@ cov_status cov_gathered(cov_session *root, uint32_t rank, cov_contig_stats *stat
     const uint8_t *blk = root->h_gather + (size_t)rank * root->gather_block;
     DevGlobal G; memcpy(&G, blk, sizeof G);
     return convert_results(root, G, reinterpret_cast<const DevContig *>(blk + sizeof(DevGlobal)), G.pad2[0], stats, summary);
+}
+
+
+// ---------------------------------------------------------------------------------------------- device ingest (covermhip.h cov_ingest_*)
+static_assert(sizeof(cov_bgzf_block) == sizeof(covi::BgzfBlock) && offsetof(cov_bgzf_block, in_len) == offsetof(covi::BgzfBlock, in_len) &&
+              offsetof(cov_bgzf_block, out_off) == offsetof(covi::BgzfBlock, out_off), "cov_bgzf_block mirrors the device struct");
+
+cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t inflated_bytes_hint) {
+    if (!s) return COV_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    if (!s->ing_copy) {
+        HIPCHK(hipStreamCreateWithFlags(&s->ing_copy, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ev[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ing_fed, hipEventDisableTiming));
+    }
+    HIPCHK(s->g_comp.reserve(compressed_bytes + 64, s->stream));
+    HIPCHK(s->g_infl.reserve(std::max<uint64_t>(inflated_bytes_hint, 1u << 20) + 64, s->stream));
+    HIPCHK(s->g_result.reserve(8, s->stream));
+    HIPCHK(s->g_blocks.reserve(compressed_bytes / 8192 + 1024, s->stream));
+    HIPCHK(s->g_status.reserve(compressed_bytes / 8192 + 1024, s->stream));
+    HIPCHK(hipMemsetAsync(s->g_result.p, 0, 64, s->stream));
+    { const u64 none = ~0ull; HIPCHK(hipMemcpyAsync(s->g_result.p + 4, &none, 8, hipMemcpyHostToDevice, s->stream)); }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->ing_comp = compressed_bytes; s->ing_infl = 0; s->ing_blocks = 0; s->ing_launched = 0; s->ing_active = true;
+    s->ing_ms_inflate = s->ing_ms_parse = 0;
+    return COV_OK;
+}
+
+// k_inflate + k_lz_resolve over the blocks fed but not yet launched (their bytes and table entries are on the copy stream:
+// the compute stream waits for the event recorded behind the last upload).
+static cov_status launch_inflate(cov_session *s) {
+    const uint64_t b0 = s->ing_launched, n64 = s->ing_blocks - b0;
+    if (n64 == 0) return COV_OK;
+    const u32 n = (u32)n64;
+    HIPCHK(hipStreamWaitEvent(s->stream, s->ing_fed, 0));
+    const u32 grid = (n + 63u) / 64u;
+    HIPCHK(s->g_scratch.reserve((size_t)grid * 64u * covi::INF_SCRATCH_BYTES, s->stream));
+    HIPCHK(s->g_tok.reserve((size_t)n * covi::INF_TOK_CAP, s->stream));
+    HIPCHK(s->g_ntok.reserve(n, s->stream));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)covi::inflate_smem_bytes());
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(covi::k_inflate, dim3(grid), dim3(64), covi::inflate_smem_bytes(), s->stream, (const uint8_t *)s->g_comp.p,
+                       (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, s->g_infl.p, s->g_scratch.p, s->g_tok.p, s->g_ntok.p, s->g_status.p + b0,
+                       reinterpret_cast<u32 *>(s->g_result.p + 3));
+    hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->stream, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, s->g_infl.p,
+                       (const u64 *)s->g_tok.p, (const u32 *)s->g_ntok.p);
+    HIPCHK(hipGetLastError());
+    s->ing_launched = s->ing_blocks;
+    return COV_OK;
+}
+
+cov_status cov_ingest_slot_wait(cov_session *s, int slot) {
+    if (!s || slot < 0 || slot > 1 || !s->ing_active) return COV_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    HIPCHK(hipEventSynchronize(s->ing_ev[slot]));
+    return COV_OK;
+}
+
+cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uint64_t file_offset, uint64_t n_bytes,
+                           const cov_bgzf_block *blocks, uint32_t n_blocks) {
+    if (!s || !s->ing_active || slot < 0 || slot > 1 || (n_bytes && !host_bytes) || (n_blocks && !blocks)) return COV_ERR_INVALID_ARG;
+    if (file_offset + n_bytes > s->ing_comp) { s->err = "cov_ingest_feed: bytes beyond the size given to cov_ingest_begin"; return COV_ERR_INVALID_ARG; }
+    HIPCHK(hipSetDevice(s->cfg.device));
+    if (n_bytes) HIPCHK(hipMemcpyAsync(s->g_comp.p + file_offset, host_bytes, n_bytes, hipMemcpyHostToDevice, s->ing_copy));
+    HIPCHK(hipEventRecord(s->ing_ev[slot], s->ing_copy));
+    if (n_blocks == 0) return COV_OK;
+    // block table: page-locked mirror (the async upload reads it later), then the device copy
+    if (s->ing_blocks + n_blocks > s->h_blocks_cap) {
+        const size_t nc = std::max<size_t>(s->ing_blocks + n_blocks, s->h_blocks_cap * 2 + 4096);
+        covi::BgzfBlock *nb = nullptr;
+        HIPCHK(hipHostMalloc((void **)&nb, nc * sizeof(covi::BgzfBlock), hipHostMallocDefault));
+        HIPCHK(hipStreamSynchronize(s->ing_copy));      // earlier uploads still read the old mirror
+        if (s->h_blocks) { memcpy(nb, s->h_blocks, s->ing_blocks * sizeof(covi::BgzfBlock)); (void)hipHostFree(s->h_blocks); }
+        s->h_blocks = nb; s->h_blocks_cap = nc;
+    }
+    uint64_t infl_end = s->ing_infl;
+    for (uint32_t i = 0; i < n_blocks; i++) {
+        const cov_bgzf_block &b = blocks[i];
+        if (b.in_off + b.in_len > file_offset + n_bytes || b.isize > 65536u) { s->err = "cov_ingest_feed: block outside the bytes fed so far"; return COV_ERR_INVALID_ARG; }
+        covi::BgzfBlock d; d.in_off = b.in_off; d.out_off = b.out_off; d.in_len = b.in_len; d.isize = b.isize; d.crc = b.crc; d.pad = 0;
+        s->h_blocks[s->ing_blocks + i] = d;
+        infl_end = std::max<uint64_t>(infl_end, b.out_off + b.isize);
+    }
+    if (infl_end + 64 > s->g_infl.cap) {     // the hint was too small: grow, keeping what is inflated already
+        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(s->g_infl.reserve(infl_end + infl_end / 2 + 64, s->stream, s->ing_infl));
+    }
+    HIPCHK(s->g_blocks.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
+    HIPCHK(s->g_status.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
+    HIPCHK(hipMemcpyAsync(s->g_blocks.p + s->ing_blocks, s->h_blocks + s->ing_blocks, (size_t)n_blocks * sizeof(covi::BgzfBlock), hipMemcpyHostToDevice, s->ing_copy));
+    HIPCHK(hipEventRecord(s->ing_fed, s->ing_copy));
+    s->ing_blocks += n_blocks; s->ing_infl = infl_end;
+    // k_inflate wants >= 2 waves on every CU (one lane per block): launch once enough blocks have arrived
+    if (s->ing_blocks - s->ing_launched >= (uint64_t)s->n_cus * 2u * 64u) return launch_inflate(s);
+    return COV_OK;
+}
+
+cov_status cov_ingest_end(cov_session *s, uint64_t first_record_offset, int check_crc, uint64_t *n_records_out) {
+    if (!s || !s->ing_active) return COV_ERR_INVALID_ARG;
+    s->ing_active = false;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    hipStream_t st = s->stream;
+    if (n_records_out) *n_records_out = 0;
+    if (s->adopted) {  // materialise an adopted device batch into the owned store first
+        cov_batch ab = s->adopted_batch;
+        s->adopted = false; s->n_records = 0; s->n_cigar = 0;
+        cov_status a = append(s, &ab, true);
+        if (a) return a;
+    }
+    { const cov_status lrc = launch_inflate(s); if (lrc != COV_OK) return lrc; }
+    hipEvent_t e0, e1, e2;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+    struct EvFree { hipEvent_t a, b, c; ~EvFree() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); } } evfree{e0, e1, e2};
+    if (check_crc && s->ing_blocks)
+        hipLaunchKernelGGL(covi::k_crc32, dim3((u32)((s->ing_blocks + 255) / 256)), dim3(256), 0, st, (const covi::BgzfBlock *)s->g_blocks.p, (u32)s->ing_blocks,
+                           (const uint8_t *)s->g_infl.p, s->g_status.p, reinterpret_cast<u32 *>(s->g_result.p + 3));
+    HIPCHK(hipEventRecord(e0, st));
+    const uint64_t N = s->ing_infl;
+    uint64_t res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (first_record_offset > N) { s->err = "device ingest: the BAM header is longer than the inflated stream"; return COV_ERR_INGEST_FALLBACK; }
+    covi::BamScan S{};
+    S.u = s->g_infl.p; S.N = N; S.p0 = first_record_offset; S.seg_bytes = 32768; S.n_ref = (int)s->n_targets; S.ref_len = s->d_tlen.p;
+    const uint64_t body = N - first_record_offset;
+    S.n_seg = (u32)((body + S.seg_bytes - 1) / S.seg_bytes);
+    if (S.n_seg) {
+        HIPCHK(s->g_seg.reserve(S.n_seg, st)); HIPCHK(s->g_recbase.reserve(S.n_seg, st)); HIPCHK(s->g_cigbase.reserve(S.n_seg, st));
+        hipLaunchKernelGGL(covi::k_bam_find, dim3((S.n_seg + 3) / 4), dim3(256), 0, st, S, s->g_seg.p);
+        hipLaunchKernelGGL(covi::k_bam_hop, dim3((S.n_seg + 63) / 64), dim3(64), 0, st, S, s->g_seg.p);
+        hipLaunchKernelGGL(covi::k_bam_verify, dim3(1), dim3(1024), 0, st, S, s->g_seg.p, s->g_recbase.p, s->g_cigbase.p, s->g_result.p);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(res, s->g_result.p, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const u32 inflate_fail = (u32)(res[3] & 0xffffffffu);
+    if (inflate_fail) { s->err = "device ingest: " + std::to_string(inflate_fail) + " BGZF blocks failed to inflate or their CRC-32 (handing the file to the CPU reader)"; return COV_ERR_INGEST_FALLBACK; }
+    if (res[2]) {
+        s->err = (res[2] & 4) ? "device ingest: a record keeps its CIGAR in CG:B,I (handing the file to the CPU reader)"
+               : (res[2] & 2) ? "device ingest: truncated BAM record"
+               : "device ingest: record boundaries did not verify at segment " + std::to_string(res[4]) + " (start " + std::to_string(res[5]) + ", landed " +
+                 std::to_string(res[6]) + "; handing the file to the CPU reader)";
+        return COV_ERR_INGEST_FALLBACK;
+    }
+    const uint64_t nrec = res[0], ncig = res[1];
+    if (s->n_records + nrec >= 0xfffffff0ull || s->n_cigar + ncig >= 0xfffffff0ull) { s->err = "more than 2^32 records in one session"; return COV_ERR_INVALID_ARG; }
+    if (nrec) {
+        const uint64_t R = s->n_records, C = s->n_cigar, Nn = R + nrec;
+        HIPCHK(s->s_tid.reserve(Nn, st, R)); HIPCHK(s->s_pos.reserve(Nn, st, R)); HIPCHK(s->s_flag.reserve(Nn, st, R));
+        HIPCHK(s->s_mapq.reserve(Nn, st, R)); HIPCHK(s->s_nmk.reserve(Nn, st, R)); HIPCHK(s->s_nm.reserve(Nn, st, R));
+        HIPCHK(s->s_lseq.reserve(Nn, st, R)); HIPCHK(s->s_coff.reserve(Nn + 1, st, R + 1));
+        HIPCHK(s->s_cig.reserve(C + ncig + 1, st, C));
+        covi::RecStore RS{};
+        RS.tid = s->s_tid.p; RS.pos = s->s_pos.p; RS.flag = s->s_flag.p; RS.mapq = s->s_mapq.p; RS.nm_kind = s->s_nmk.p; RS.nm = s->s_nm.p;
+        RS.l_seq = s->s_lseq.p; RS.cigar_off = s->s_coff.p; RS.cigar = s->s_cig.p; RS.rec0 = R; RS.cig0 = C;
+        HIPCHK(hipEventRecord(e1, st));
+        hipLaunchKernelGGL(covi::k_bam_extract, dim3((S.n_seg + 63) / 64), dim3(64), 0, st, S, (const covi::SegInfo *)s->g_seg.p, (const u64 *)s->g_recbase.p,
+                           (const u64 *)s->g_cigbase.p, RS, reinterpret_cast<u32 *>(s->g_result.p + 3) + 1);
+        HIPCHK(hipGetLastError());
+        const u32 end_off = (u32)(C + ncig);
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(s->s_coff.p + Nn), (int)end_off, 1, st));
+        HIPCHK(hipEventRecord(e2, st));
+        HIPCHK(hipMemcpyAsync(res, s->g_result.p, 32, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if ((u32)(res[3] >> 32)) { s->err = "device ingest: corrupt BAM record"; return COV_ERR_INGEST_FALLBACK; }
+        s->n_records = Nn; s->n_cigar = C + ncig;
+        s->finished = false;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e1, e2) == hipSuccess) s->ing_ms_parse = ms;
+    }
+    if (n_records_out) *n_records_out = nrec;
+    return COV_OK;
+}
+
+// Test hook: the owned record store copied back to host arrays (cov_batch of writable pointers sized by the caller:
+// n_records entries, n_records + 1 cigar offsets, n_cigar words; *n_cigar receives the word count when words are not wanted).
+cov_status cov_copy_records(cov_session *s, const cov_batch *host, uint64_t *n_records, uint64_t *n_cigar) {
+    if (!s || s->adopted) return COV_ERR_STATE;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    if (n_records) *n_records = s->n_records;
+    if (n_cigar) *n_cigar = s->n_cigar;
+    if (!host) return COV_OK;
+    const uint64_t n = s->n_records;
+    hipStream_t st = s->stream;
+    if (n) {
+        HIPCHK(hipMemcpyAsync((void *)host->tid, s->s_tid.p, n * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync((void *)host->pos, s->s_pos.p, n * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync((void *)host->flag, s->s_flag.p, n * 2, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync((void *)host->mapq, s->s_mapq.p, n, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync((void *)host->nm, s->s_nm.p, n * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync((void *)host->nm_kind, s->s_nmk.p, n, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync((void *)host->l_seq, s->s_lseq.p, n * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync((void *)host->cigar_off, s->s_coff.p, (n + 1) * 4, hipMemcpyDeviceToHost, st));
+        if (s->n_cigar) HIPCHK(hipMemcpyAsync((void *)host->cigar, s->s_cig.p, s->n_cigar * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return COV_OK;
+}
+
+cov_status cov_ingest_release(cov_session *s) {
+    if (!s) return COV_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->g_comp.release(); s->g_infl.release(); s->g_scratch.release(); s->g_blocks.release(); s->g_status.release(); s->g_seg.release();
+    s->g_recbase.release(); s->g_cigbase.release(); s->g_tok.release(); s->g_ntok.release();
+    return COV_OK;
+}
+
+// Test hook: the inflated stream of the last ingest (bytes [offset, offset + n) copied to `out`).
+cov_status cov_ingest_copy_inflated(cov_session *s, uint64_t offset, uint64_t n, void *out) {
+    if (!s || offset + n > s->ing_infl || (n && !out)) return COV_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    HIPCHK(hipMemcpyAsync(out, s->g_infl.p + offset, n, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return COV_OK;
 }
 
 cov_status cov_fetch_hist(cov_session *s, uint64_t *hist) {

@@ -1160,6 +1160,151 @@ void covh_bam_stream_close(covh_bam_stream *h) { delete h; }
 namespace {
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------- device ingest driver
+// Host side of cov_ingest_*: reads the file into two alternating page-locked buffers (parallel pread), hops the BGZF block
+// headers of every piece (18 bytes per block; a header or a block may straddle two pieces) and feeds bytes + completed
+// blocks to the session; the GPU inflates, checks CRCs, finds the records and fills its own record store.
+namespace {
+struct HeaderOnly {
+    std::vector<std::string> names; std::vector<uint64_t> lens; std::string text;
+    uint64_t first_record = 0, file_size = 0;
+};
+}  // namespace
+
+extern "C" {
+
+struct covh_bam_header { HeaderOnly h; };
+
+covh_bam_header *covh_bam_read_header(const char *path, char *err, size_t errcap) {
+    auto bail = [&](covh_bam_header *h, int fd, const std::string &e) -> covh_bam_header * {
+        if (err && errcap) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; }
+        if (fd >= 0) close(fd);
+        delete h;
+        return nullptr;
+    };
+    covh_bam_header *h = new covh_bam_header();
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return bail(h, -1, std::string("Unable to find BAM file ") + path);
+    const off_t e = lseek(fd, 0, SEEK_END);
+    h->h.file_size = e > 0 ? (uint64_t)e : 0;
+    if (h->h.file_size == 0) return bail(h, fd, std::string(path) + ": empty file (no BAM/SAM header)");
+    uint8_t magic[2] = {0, 0};
+    if (pread(fd, magic, 2, 0) != 2 || magic[0] != 0x1f || magic[1] != 0x8b) return bail(h, fd, "not a BGZF file");
+    std::vector<uint8_t> u; std::string msg;
+    size_t p = 0; int rc = 0;
+    auto want = [&](std::vector<uint8_t> &buf) {
+        std::string e2;
+        rc = parse_bam_header(buf.data(), buf.size(), p, h->h.names, h->h.lens, h->h.text, e2);
+        if (rc < 0) msg = e2;
+        return rc != 0;
+    };
+    if (!inflate_from(fd, h->h.file_size, 0, u, want, msg)) return bail(h, fd, msg);
+    if (rc < 0) return bail(h, fd, msg);
+    if (rc == 0) return bail(h, fd, u.size() < 12 ? "bad BAM magic" : "truncated BAM header");
+    h->h.first_record = p;
+    close(fd);
+    return h;
+}
+void covh_bam_header_free(covh_bam_header *h) { delete h; }
+uint32_t covh_bam_header_n_targets(const covh_bam_header *h) { return (uint32_t)h->h.names.size(); }
+const char *covh_bam_header_target_name(const covh_bam_header *h, uint32_t i) { return h->h.names[i].c_str(); }
+uint64_t covh_bam_header_target_len(const covh_bam_header *h, uint32_t i) { return h->h.lens[i]; }
+uint64_t covh_bam_header_first_record(const covh_bam_header *h) { return h->h.first_record; }
+
+// 0 = records are in the session's store; 1 = the file needs the CPU reader (reason in err; nothing appended); -1 = error.
+// timing (optional, 4 doubles): seconds reading the file, waiting for staging slots, in cov_ingest_end, total.
+int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint64_t *n_records,
+                        double *timing, char *err, size_t errcap) {
+    auto fail = [&](int rc, const std::string &e) { if (err && errcap) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; } return rc; };
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(-1, std::string("Unable to find BAM file ") + path);
+    struct FdClose { int fd; ~FdClose() { close(fd); } } fdc{fd};
+    const uint64_t size = hd->h.file_size;
+    size_t piece = (size_t)128 << 20;
+    if (const char *pb = getenv("COVERM_INGEST_PIECE_KB")) { const long v = atol(pb); if (v >= 64) piece = (size_t)v << 10; }
+    uint8_t *buf[2] = {(uint8_t *)cov_host_alloc(piece), (uint8_t *)cov_host_alloc(piece)};
+    struct BufFree { uint8_t **b; ~BufFree() { for (int k = 0; k < 2; k++) if (b[k]) cov_host_free(b[k]); } } bf{buf};
+    if (!buf[0] || !buf[1]) return fail(-1, "no page-locked staging memory (is a HIP device usable?)");
+    if (cov_ingest_begin(s, size, size * 4 + (1u << 20)) != COV_OK) return fail(-1, cov_last_error(s));
+    Pool pool(std::max(1, threads));
+    std::vector<cov_bgzf_block> blocks;
+    uint64_t next_blk = 0, out_off = 0, pending_bsize = 0;     // absolute file offset of the next block header; running inflated size; BSIZE of a block whose header is read but whose end is not here yet
+    uint8_t tail[64]; uint64_t tail_end = 0; size_t tail_len = 0;   // last bytes of the previous piece (a header may straddle)
+    double t_read = 0, t_wait = 0;
+    int slot = 0;
+    for (uint64_t off = 0; off < size; off += piece, slot ^= 1) {
+        const uint64_t n = std::min<uint64_t>(piece, size - off);
+        double t0 = now();
+        if (cov_ingest_slot_wait(s, slot) != COV_OK) return fail(-1, cov_last_error(s));
+        t_wait += now() - t0;
+        t0 = now();
+        const size_t chunk = 4u << 20, nch = (size_t)((n + chunk - 1) / chunk);
+        std::atomic<bool> ok{true};
+        uint8_t *dst = buf[slot];
+        pool.run(nch, [&](size_t c) {
+            size_t o = c * chunk; const size_t e = (size_t)std::min<uint64_t>(n, (uint64_t)o + chunk);
+            while (o < e) {
+                const ssize_t r = pread(fd, dst + o, e - o, (off_t)(off + o));
+                if (r <= 0) { ok = false; return; }
+                o += (size_t)r;
+            }
+        });
+        if (!ok) return fail(-1, std::string("read error on ") + path);
+        t_read += now() - t0;
+        // ---- block headers completed by this piece
+        auto byte_at = [&](uint64_t a) -> uint8_t {   // absolute file offset, within this piece or the saved tail of the previous one
+            if (a >= off) return dst[a - off];
+            return tail[tail_len - (size_t)(tail_end - a)];
+        };
+        blocks.clear();
+        const uint64_t have = off + n;
+        for (;;) {
+            if (pending_bsize == 0) {          // header of the next block (may straddle into the saved tail of the previous piece)
+                if (next_blk + 18 > have) break;
+                uint8_t hb[18];
+                for (int k = 0; k < 18; k++) hb[k] = byte_at(next_blk + (uint64_t)k);
+                if (hb[0] != 0x1f || hb[1] != 0x8b || hb[2] != 8 || !(hb[3] & 4)) return fail(1, "not a BGZF block (device ingest hands the file to the CPU reader)");
+                const uint32_t xlen = hb[10] | (hb[11] << 8);
+                if (xlen != 6 || hb[12] != 66 || hb[13] != 67 || hb[14] != 2 || hb[15] != 0)    // extra subfields besides BC: rare, let the CPU reader take it
+                    return fail(1, "BGZF block with extra subfields (device ingest hands the file to the CPU reader)");
+                pending_bsize = (uint64_t)(hb[16] | (hb[17] << 8)) + 1;
+                if (pending_bsize < 26) return fail(1, "malformed BGZF block header");
+            }
+            const uint64_t bsize = pending_bsize;
+            if (next_blk + bsize > have) break;             // completed by a later piece (its header is not read again)
+            cov_bgzf_block b;
+            b.in_off = next_blk + 18; b.in_len = (uint32_t)(bsize - 26);
+            uint8_t tr[8];
+            for (int k = 0; k < 8; k++) tr[k] = byte_at(next_blk + bsize - 8 + (uint64_t)k);
+            memcpy(&b.crc, tr, 4); memcpy(&b.isize, tr + 4, 4);
+            if (b.isize > 65536u) return fail(1, "BGZF block inflates to more than 64 KiB");
+            b.out_off = out_off; b.pad = 0;
+            out_off += b.isize;
+            blocks.push_back(b);
+            next_blk += bsize;
+            pending_bsize = 0;
+        }
+        tail_len = (size_t)std::min<uint64_t>(sizeof tail, n);
+        memcpy(tail, dst + n - tail_len, tail_len);
+        tail_end = have;
+        if (cov_ingest_feed(s, slot, dst, off, n, blocks.data(), (uint32_t)blocks.size()) != COV_OK) return fail(-1, cov_last_error(s));
+    }
+    if (next_blk != size) return fail(1, "truncated BGZF block at the end of the file");
+    double t0 = now();
+    uint64_t nrec = 0;
+    const cov_status rc = cov_ingest_end(s, hd->h.first_record, check_crc, &nrec);
+    const double t_end = now() - t0;
+    if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; }
+    if (rc == COV_ERR_INGEST_FALLBACK) return fail(1, cov_last_error(s));
+    if (rc != COV_OK) return fail(-1, cov_last_error(s));
+    if (n_records) *n_records = nrec;
+    return 0;
+}
+
+}  // extern "C"
+
 extern "C" {
 
 struct covh_bam { Bam b; };

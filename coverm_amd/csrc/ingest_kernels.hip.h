@@ -1,0 +1,578 @@
+// Device-side ingest: BGZF inflate and BAM record parsing on the GPU.
+//
+// The reference's only parallel stage is htslib's inflate pool (bam_generator.rs:125-129); on a host with few cores that
+// stage bounds the whole path.  Here the compressed file goes to HBM as it is and three groups of kernels replace the
+// host decoder:
+//
+//   k_inflate       one LANE per BGZF block (blocks are independent raw-DEFLATE members of <= 64 KiB, SAM spec 4.1):
+//                   a complete RFC 1951 decoder per lane — stored / fixed / dynamic blocks, Huffman decode through per-lane
+//                   lookup tables in LDS (9-bit literal/length, 6-bit distance primary tables; longer codes resolved
+//                   canonically from per-length counts).  Literals are written in place, LZ77 matches become tokens.
+//                   64 blocks advance per wave instruction; divergence between lanes is what SIMT costs here, HBM
+//                   bandwidth is not the limit.
+//   k_lz_resolve    one WAVE per block executes its match tokens in order (64 lanes per copy)
+//   k_crc32         every inflated block against the CRC-32 of its BGZF trailer
+//   k_bam_find      per segment of the inflated stream: first offset from which a chain of 8 plausible records starts
+//   k_bam_hop       per segment: hop the records (block_size chain), count records and CIGAR words, note where it landed
+//   k_bam_verify    every segment's chain must land exactly on the start the next segment found (then the result equals the
+//                   serial hop by induction, as in csrc/host_bam.cpp); exclusive scans of the counts
+//   k_bam_extract   per segment: second hop, one record at a time per lane, fields written straight into the session's
+//                   record store (tid, pos, flag, mapq, l_seq, NM + its type, CIGAR words)
+//
+// Anything irregular (malformed stream, CRC mismatch, speculation that does not verify, a CG:B,I long-CIGAR record) raises
+// a flag and the host decodes that file with the CPU reader instead: the device path is an accelerator, never a different
+// semantics.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace covi {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+struct BgzfBlock {
+    u64 in_off;    // first byte of the raw DEFLATE stream inside the compressed buffer
+    u64 out_off;   // where the inflated bytes go
+    u32 in_len, isize, crc, pad;
+};
+
+constexpr int INF_LIT_BITS = 9, INF_DIST_BITS = 6;
+constexpr int INF_LIT_N = 1 << INF_LIT_BITS, INF_DIST_N = 1 << INF_DIST_BITS;
+// Per-lane LDS, lane-interleaved u16 entries (entry i of lane l at [i * 64 + l]): primary tables + per-length code counts of both
+// alphabets: 64 lanes x (512 + 64 + 16 + 16) x 2 B = 76 KiB per wave, two waves per CU.
+constexpr size_t inflate_smem_bytes() { return (size_t)64 * (INF_LIT_N + INF_DIST_N + 32) * 2; }
+// Per-lane global scratch: symbols sorted by (code length, value) for codes longer than the primary tables, and the code lengths
+// while a table is being built:  u16 lit_sorted[288], dist_sorted[32], u8 lens[320]
+constexpr u32 INF_SCRATCH_BYTES = 288 * 2 + 32 * 2 + 320;
+// LZ77 matches are not copied by k_inflate (a byte-serial copy by ONE lane would stall the other 63 of its wave on every match):
+// it writes the literals at their final positions and one token per match; k_lz_resolve then executes the tokens of each block in
+// order with a whole wave per block.  Token = pos | len << 16 | dist << 32.
+constexpr u32 INF_TOK_CAP = 21888;   // >= 65536 / 3 matches per block
+
+enum { INF_OK = 0, INF_ERR_FORMAT = 1, INF_ERR_CRC = 2, INF_ERR_SIZE = 3 };
+
+__constant__ unsigned short c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ unsigned char c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ unsigned short c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ unsigned char c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ unsigned char c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// Bit reader over one lane's compressed stream: 64-bit buffer refilled 4 bytes at a time with aligned dword loads.
+struct BitReader {
+    const u32 *words;   // aligned base
+    u64 buf; u32 cnt;   // cnt valid bits in buf
+    u32 next_word, end_word;     // word indices
+    u32 consumed;                // bits consumed so far
+    __device__ __forceinline__ void init(const uint8_t *base, u64 off, u32 len) {
+        const u64 a = (u64)(base + off);
+        const u32 mis = (u32)(a & 3u);
+        words = (const u32 *)(a - mis);
+        next_word = 0; end_word = (mis + len + 3u) >> 2;
+        buf = 0; cnt = 0;
+        refill();
+        if (mis) { buf >>= 8 * mis; cnt -= 8 * mis; }
+        consumed = 0;
+    }
+    __device__ __forceinline__ void refill() {
+        if (cnt <= 32u) {
+            const u32 w = next_word < end_word ? words[next_word] : 0u;   // zero padding past the end: errors surface as format / size errors
+            next_word++;
+            buf |= (u64)w << cnt;
+            cnt += 32u;
+        }
+    }
+    __device__ __forceinline__ u32 peek(u32 n) const { return (u32)buf & ((1u << n) - 1u); }
+    __device__ __forceinline__ void drop(u32 n) { buf >>= n; cnt -= n; consumed += n; }
+    __device__ __forceinline__ u32 take(u32 n) { const u32 v = peek(n); drop(n); return v; }   // n <= 16; caller keeps cnt >= n via refill()
+};
+
+// One alphabet's decoding state of a lane.
+struct Huff {
+    unsigned short *tab;          // LDS primary table (lane-interleaved)
+    unsigned short *cnt;          // LDS per-length code counts (lane-interleaved, 16 entries)
+    const unsigned short *sorted; // global: symbols by (length, value)
+    u32 first_p, index_p;         // canonical state on entering length prim_bits + 1
+};
+
+// Builds the lane's primary lookup table and counts (LDS) and the sorted symbols (global scratch) from code lengths.
+// Primary entry: bits 0-3 code length (0 = longer than prim_bits: resolve canonically), bits 4-15 symbol.
+__device__ __forceinline__ bool build_table(const uint8_t *lens, u32 n_sym, u32 prim_bits, int lane, unsigned short *sorted, Huff &H) {
+    for (u32 l = 0; l < 16; l++) H.cnt[l * 64 + lane] = 0;
+    for (u32 s = 0; s < n_sym; s++) { const u32 l = lens[s]; if (l) H.cnt[l * 64 + lane]++; }
+    // an over-subscribed set is an error; incomplete sets are tolerated (a single distance code is legal, anything else
+    // decodes to -1 when an unassigned code appears and the block's CRC catches the rest)
+    u32 left = 1;
+    for (u32 l = 1; l < 16; l++) { left <<= 1; const u32 c = H.cnt[l * 64 + lane]; if (c > left) return false; left -= c; }
+    // offsets per length: running position kept in the (so far unused) entry 0 of the count array would clobber; use a second pass
+    {
+        u32 off = 0;
+        for (u32 l = 1; l < 16; l++) {     // place the symbols of each length in order of value
+            const u32 c = H.cnt[l * 64 + lane];
+            if (c == 0) continue;
+            u32 k = off;
+            for (u32 s = 0; s < n_sym; s++) if (lens[s] == l) sorted[k++] = (unsigned short)s;
+            off += c;
+        }
+    }
+    const u32 N = 1u << prim_bits;
+    for (u32 i = 0; i < N; i++) H.tab[i * 64 + lane] = 0;
+    // canonical codes in increasing (length, symbol) order; primary entries for lengths <= prim_bits (bit-reversed: DEFLATE
+    // packs Huffman codes MSB first into an LSB-first bit stream)
+    u32 code = 0, idx = 0;
+    for (u32 l = 1; l <= prim_bits; l++) {
+        const u32 c = H.cnt[l * 64 + lane];
+        for (u32 k = 0; k < c; k++, idx++, code++) {
+            const u32 sym = sorted[idx];
+            const u32 rev = __brev(code) >> (32 - l);
+            const unsigned short e = (unsigned short)((sym << 4) | l);
+            for (u32 i = rev; i < N; i += 1u << l) H.tab[i * 64 + lane] = e;
+        }
+        code <<= 1;
+    }
+    H.first_p = code; H.index_p = idx; H.sorted = sorted;
+    return true;
+}
+
+// Decodes one symbol: primary table, else canonical walk over the lengths above prim_bits (counts in LDS; the walk index is the
+// same for all lanes, only the final sorted[] lookup goes to global memory).
+__device__ __forceinline__ int decode_sym(BitReader &br, const Huff &H, int lane, u32 prim_bits) {
+    const u32 pk = br.peek(prim_bits);
+    const u32 e = H.tab[pk * 64 + lane];
+    if (e & 15u) { br.drop(e & 15u); return (int)(e >> 4); }
+    u32 code = __brev(pk) >> (32 - prim_bits), first = H.first_p, index = H.index_p;
+    u64 bits = br.buf >> prim_bits;
+    for (u32 l = prim_bits + 1; l <= 15; l++) {
+        code = (code << 1) | (u32)(bits & 1u); bits >>= 1;
+        const u32 c = H.cnt[l * 64 + lane];
+        if (code < first + c) { br.drop(l); return (int)H.sorted[index + (code - first)]; }
+        index += c; first = (first + c) << 1;
+    }
+    return -1;
+}
+
+// One lane per BGZF block: Huffman decoding only.  Literals go to out + out_off at their final positions, matches become
+// tokens (tok + local block index * INF_TOK_CAP, count in n_tok).  status[b] = INF_*.
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
+                                                uint8_t *__restrict__ out, uint8_t *__restrict__ scratch, u64 *__restrict__ tok,
+                                                u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    const int lane = threadIdx.x & 63;
+    Huff HL, HD;
+    HL.tab = lds; HD.tab = lds + (size_t)64 * INF_LIT_N;
+    HL.cnt = HD.tab + (size_t)64 * INF_DIST_N; HD.cnt = HL.cnt + 64 * 16;
+    HL.sorted = HD.sorted = nullptr; HL.first_p = HL.index_p = HD.first_p = HD.index_p = 0;
+    const u32 b = blockIdx.x * 64u + (u32)lane;
+    if (b >= n_blocks) return;
+    const BgzfBlock B = blocks[b];
+    uint8_t *sc = scratch + (size_t)b * INF_SCRATCH_BYTES;
+    unsigned short *lit_sorted = (unsigned short *)sc, *dist_sorted = lit_sorted + 288;
+    uint8_t *lens = (uint8_t *)(dist_sorted + 32);
+    uint8_t *dst = out + B.out_off;
+    u64 *my_tok = tok + (size_t)b * INF_TOK_CAP;
+    u32 pos = 0, err = INF_OK, nt = 0;
+    if (B.isize != 0u) {
+        BitReader br;
+        br.init(comp, B.in_off, B.in_len);
+        const u32 total_bits = B.in_len * 8u;
+        bool last = false;
+        while (!last && err == INF_OK) {
+            br.refill();
+            last = br.take(1) != 0u;
+            const u32 type = br.take(2);
+            if (type == 0u) {                    // stored
+                br.drop((8u - (br.consumed & 7u)) & 7u);
+                br.refill();
+                const u32 len = br.take(16);
+                br.refill();
+                const u32 nlen = br.take(16);
+                if ((len ^ nlen) != 0xffffu || pos + len > B.isize) { err = INF_ERR_FORMAT; break; }
+                for (u32 k = 0; k < len; k++) { br.refill(); dst[pos++] = (uint8_t)br.take(8); }
+                continue;
+            }
+            if (type == 3u) { err = INF_ERR_FORMAT; break; }
+            u32 hlit, hdist;
+            if (type == 1u) {                    // fixed codes
+                for (u32 s = 0; s < 144; s++) lens[s] = 8;
+                for (u32 s = 144; s < 256; s++) lens[s] = 9;
+                for (u32 s = 256; s < 280; s++) lens[s] = 7;
+                for (u32 s = 280; s < 288; s++) lens[s] = 8;
+                for (u32 s = 0; s < 30; s++) lens[288 + s] = 5;
+                hlit = 288; hdist = 30;
+            } else {                             // dynamic codes
+                br.refill();
+                hlit = br.take(5) + 257u; hdist = br.take(5) + 1u;
+                const u32 hclen = br.take(4) + 4u;
+                if (hlit > 286u || hdist > 30u) { err = INF_ERR_FORMAT; break; }
+                // code-length code (19 symbols, at most 7 bits): lengths packed 3 bits each into one u64, decoded canonically
+                u64 cl = 0;
+                for (u32 i = 0; i < hclen; i++) { br.refill(); cl |= (u64)br.take(3) << (3u * c_clen_order[i]); }
+                u32 ccnt = 0;      // 8 counts of 4 bits... up to 19 codes of one length: 5 bits each
+                u64 ccnt5 = 0;
+                for (u32 sy = 0; sy < 19; sy++) { const u32 l = (u32)(cl >> (3u * sy)) & 7u; if (l) ccnt5 += 1ull << (5u * l); }
+                (void)ccnt;
+                { u32 left = 1; bool bad = false; for (u32 l = 1; l < 8; l++) { left <<= 1; const u32 c = (u32)(ccnt5 >> (5u * l)) & 31u; if (c > left) { bad = true; break; } left -= c; } if (bad) { err = INF_ERR_FORMAT; break; } }
+                u32 n = 0;
+                const u32 want = hlit + hdist;
+                while (n < want && err == INF_OK) {
+                    br.refill();
+                    // canonical decode over lengths 1..7; the symbol of rank r among the codes of length l is the r-th symbol (in
+                    // value order) whose length is l
+                    u32 code = 0, first = 0; int sym = -1;
+                    u64 bits = br.buf;
+                    for (u32 l = 1; l <= 7; l++) {
+                        code |= (u32)(bits & 1u); bits >>= 1;
+                        const u32 c = (u32)(ccnt5 >> (5u * l)) & 31u;
+                        if (code < first + c) {
+                            u32 r = code - first;
+                            for (u32 sy = 0; sy < 19; sy++) if (((u32)(cl >> (3u * sy)) & 7u) == l) { if (r == 0) { sym = (int)sy; break; } r--; }
+                            br.drop(l);
+                            break;
+                        }
+                        first += c; first <<= 1; code <<= 1;
+                    }
+                    if (sym < 0) { err = INF_ERR_FORMAT; break; }
+                    if (sym < 16) lens[n++] = (uint8_t)sym;
+                    else {
+                        u32 rep, val = 0;
+                        if (sym == 16) { if (n == 0) { err = INF_ERR_FORMAT; break; } val = lens[n - 1]; rep = 3u + br.take(2); }
+                        else if (sym == 17) rep = 3u + br.take(3);
+                        else rep = 11u + br.take(7);
+                        if (n + rep > want) { err = INF_ERR_FORMAT; break; }
+                        for (u32 k = 0; k < rep; k++) lens[n++] = (uint8_t)val;
+                    }
+                }
+                if (err != INF_OK) break;
+                if (lens[256] == 0) { err = INF_ERR_FORMAT; break; }
+                // distance lengths follow the literal/length ones: move them to their own place
+                for (u32 s = hdist; s-- > 0;) lens[288 + s] = lens[hlit + s];   // backwards: the two ranges overlap
+                for (u32 s = hlit; s < 288; s++) lens[s] = 0;
+            }
+            if (!build_table(lens, hlit, INF_LIT_BITS, lane, lit_sorted, HL)) { err = INF_ERR_FORMAT; break; }
+            if (!build_table(lens + 288, hdist, INF_DIST_BITS, lane, dist_sorted, HD)) { err = INF_ERR_FORMAT; break; }
+            // ---- symbols of this block
+            for (;;) {
+                br.refill();
+                const int sym = decode_sym(br, HL, lane, INF_LIT_BITS);
+                if (sym < 256) {
+                    if (sym < 0) { err = INF_ERR_FORMAT; break; }
+                    if (pos >= B.isize) { err = INF_ERR_SIZE; break; }
+                    dst[pos++] = (uint8_t)sym;
+                    continue;
+                }
+                if (sym == 256) break;
+                const u32 li = (u32)sym - 257u;
+                if (li >= 29u) { err = INF_ERR_FORMAT; break; }
+                const u32 len = c_len_base[li] + br.take(c_len_extra[li]);
+                br.refill();
+                const int ds = decode_sym(br, HD, lane, INF_DIST_BITS);
+                if (ds < 0 || ds >= 30) { err = INF_ERR_FORMAT; break; }
+                const u32 de = c_dist_extra[ds];
+                br.refill();
+                const u32 dist = c_dist_base[ds] + (de ? br.take(de) : 0u);
+                if (dist > pos || pos + len > B.isize || nt >= INF_TOK_CAP) { err = INF_ERR_FORMAT; break; }
+                my_tok[nt++] = (u64)pos | ((u64)len << 16) | ((u64)dist << 32);
+                pos += len;
+            }
+            if (br.consumed > total_bits) err = INF_ERR_FORMAT;
+        }
+        if (err == INF_OK && pos != B.isize) err = INF_ERR_SIZE;
+    }
+    n_tok[b] = err == INF_OK ? nt : 0u;
+    status[b] = err;
+    if (err != INF_OK) atomicAdd(n_failed, 1u);
+}
+
+// One wave per BGZF block: executes the block's match tokens in order.  64 lanes copy one match (source index wraps inside the
+// match distance, so overlapping matches replicate their pattern as DEFLATE defines).  A token may read bytes a previous token
+// wrote: the stores are drained (s_waitcnt vmcnt(0)) before the next token's loads, which bypass the CU's L1.
+__global__ __launch_bounds__(256) void k_lz_resolve(const BgzfBlock *__restrict__ blocks, u32 n_blocks, uint8_t *__restrict__ out,
+                                                    const u64 *__restrict__ tok, const u32 *__restrict__ n_tok) {
+    const int lane = threadIdx.x & 63;
+    const u32 b = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (b >= n_blocks) return;
+    const u32 nt = n_tok[b];
+    if (nt == 0u) return;
+    uint8_t *dst = out + blocks[b].out_off;
+    const u64 *my = tok + (size_t)b * INF_TOK_CAP;
+    u64 t_next = my[0];
+    for (u32 t = 0; t < nt; t++) {
+        const u64 tk = t_next;
+        if (t + 1 < nt) t_next = my[t + 1];
+        const u32 pos = (u32)(tk & 0xffffu), len = (u32)(tk >> 16) & 0xffffu, dist = (u32)(tk >> 32);
+        const uint8_t *src = dst + pos - dist;
+        for (u32 k = (u32)lane; k < len; k += 64u) {
+            const u32 sk = dist >= len ? k : k % dist;
+            const uint8_t v = __hip_atomic_load(src + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dst[pos + k] = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// CRC-32 of every inflated block against its BGZF trailer (htslib checks it in bgzf.c:inflate_block): one lane per block,
+// slicing-by-4 tables in LDS (4 bytes per dependent step).  Only 4 KiB of LDS per workgroup, so the CU is full of waves and the
+// per-step LDS latency overlaps.
+__global__ __launch_bounds__(256) void k_crc32(const BgzfBlock *__restrict__ blocks, u32 n_blocks, const uint8_t *__restrict__ out,
+                                               u32 *__restrict__ status, u32 *__restrict__ n_failed) {
+    __shared__ u32 T[4][256];
+    for (int i = threadIdx.x; i < 256; i += 256) {
+        u32 c = (u32)i;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+        T[0][i] = c;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += 256) {
+        u32 c = T[0][i];
+        for (int k = 1; k < 4; k++) { c = (c >> 8) ^ T[0][c & 0xffu]; T[k][i] = c; }
+    }
+    __syncthreads();
+    const u32 b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= n_blocks) return;
+    if (status[b] != INF_OK) return;
+    const BgzfBlock B = blocks[b];
+    const uint8_t *p = out + B.out_off;
+    u32 n = B.isize, crc = 0xffffffffu;
+    while (n && ((u64)p & 3u)) { crc = T[0][(crc ^ *p++) & 0xffu] ^ (crc >> 8); n--; }
+    const u32 *w = (const u32 *)p;
+    for (; n >= 4u; n -= 4u) {
+        crc ^= *w++;
+        crc = T[3][crc & 0xffu] ^ T[2][(crc >> 8) & 0xffu] ^ T[1][(crc >> 16) & 0xffu] ^ T[0][crc >> 24];
+    }
+    p = (const uint8_t *)w;
+    while (n) { crc = T[0][(crc ^ *p++) & 0xffu] ^ (crc >> 8); n--; }
+    if ((crc ^ 0xffffffffu) != B.crc) { status[b] = INF_ERR_CRC; atomicAdd(n_failed, 1u); }
+}
+
+// ------------------------------------------------------------------------------------ BAM record parsing on the device
+struct BamScan {
+    const uint8_t *u;      // inflated stream
+    u64 N;                 // its length
+    u64 p0;                // offset of the first record (after the header)
+    u64 seg_bytes;         // segment size
+    u32 n_seg;
+    int n_ref;
+    const u32 *ref_len;    // n_ref entries
+};
+
+__device__ __forceinline__ u32 ld32(const uint8_t *p) {   // unaligned little-endian load
+    const u64 a = (u64)p;
+    const u32 *w = (const u32 *)(a & ~3ull);
+    const u32 sh = (u32)(a & 3u) * 8u;
+    if (sh == 0) return w[0];
+    return (w[0] >> sh) | (w[1] << (32u - sh));
+}
+__device__ __forceinline__ u32 ld16(const uint8_t *p) { return (u32)p[0] | ((u32)p[1] << 8); }
+
+// Can a record start at offset o?  Returns its end offset or 0.  Same tests as csrc/host_bam.cpp plausible_record.
+__device__ __forceinline__ u64 plausible_record(const BamScan &S, u64 o) {
+    if (o + 36 > S.N) return 0;
+    const uint8_t *r = S.u + o;
+    const u32 bs = ld32(r);
+    if (bs < 32u || o + 4 + (u64)bs > S.N) return 0;
+    const int rid = (int)ld32(r + 4), pos = (int)ld32(r + 8), nrid = (int)ld32(r + 24);
+    const u32 lname = r[12], ncig = ld16(r + 16), lseq = ld32(r + 20);
+    if (rid < -1 || rid >= S.n_ref || nrid < -1 || nrid >= S.n_ref || pos < -1 || lname == 0u) return 0;
+    if (rid >= 0 && (u32)pos > S.ref_len[rid]) return 0;
+    const u64 fixed = 32ull + lname + 4ull * ncig + ((u64)lseq + 1ull) / 2 + lseq;
+    if (fixed > bs) return 0;
+    if (r[36 + lname - 1] != 0) return 0;
+    // The aux area must parse as tags that end exactly at the record end.  Without this test a stray offset whose "block_size"
+    // happens to jump onto a real record start far away passes (the next seven records are then real ones): seen once per
+    // ~10^7 tested offsets on a 6 GB stream, where it cost a whole-file fallback to the CPU reader.
+    const uint8_t *p = r + 4 + fixed, *end = r + 4 + bs;
+    for (int t = 0; t < 32 && p < end; t++) {
+        if (p + 3 > end) return 0;
+        const uint8_t ty = p[2];
+        p += 3;
+        if (ty == 'A' || ty == 'c' || ty == 'C') p += 1;
+        else if (ty == 's' || ty == 'S') p += 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') p += 4;
+        else if (ty == 'Z' || ty == 'H') { int g = 0; while (p < end && *p && g < 4096) { p++; g++; } if (p >= end || *p) return 0; p++; }
+        else if (ty == 'B') {
+            if (p + 5 > end) return 0;
+            const uint8_t st = p[0];
+            if (st != 'c' && st != 'C' && st != 's' && st != 'S' && st != 'i' && st != 'I' && st != 'f') return 0;
+            const u32 cnt = ld32(p + 1);
+            const u32 es = (st == 'c' || st == 'C') ? 1u : (st == 's' || st == 'S') ? 2u : 4u;
+            if ((u64)(end - p - 5) / es < cnt) return 0;
+            p += 5 + (u64)cnt * es;
+        } else return 0;
+        if (p > end) return 0;
+    }
+    return o + 4 + bs;
+}
+
+struct SegInfo {
+    u64 start;     // first record start found in the segment (~0 = none)
+    u64 landed;    // where the hop from `start` ended (first record start at or beyond the segment end, or N)
+    u32 n_rec, n_cig;
+    u32 flags;     // bit 0: a record that needs the CPU reader (CG:B,I long CIGAR candidate)
+    u32 pad;
+};
+
+// One wave per segment: lanes test consecutive offsets for an 8-record plausible chain; the lowest hit wins.
+__global__ __launch_bounds__(256) void k_bam_find(BamScan S, SegInfo *__restrict__ seg) {
+    const int lane = threadIdx.x & 63;
+    const u32 k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= S.n_seg) return;
+    const u64 lo = S.p0 + (u64)k * S.seg_bytes, hi = min(S.N, lo + S.seg_bytes);
+    u64 found = ~0ull;
+    if (k == 0) found = S.p0 < S.N ? S.p0 : ~0ull;
+    else {
+        for (u64 base = lo; base < hi && found == ~0ull; base += 64) {
+            const u64 o = base + (u64)lane;
+            bool ok = false;
+            if (o < hi) {
+                u64 q = o; int chain = 0;
+                while (chain < 8) { const u64 e = plausible_record(S, q); if (!e) break; q = e; chain++; if (q == S.N) break; }
+                ok = chain == 8 || (chain > 0 && q == S.N);
+            }
+            const u64 m = __ballot(ok);
+            if (m) found = base + (u64)(__ffsll((long long)m) - 1);
+        }
+    }
+    if (lane == 0) { SegInfo s; s.start = found; s.landed = 0; s.n_rec = 0; s.n_cig = 0; s.flags = 0; s.pad = 0; seg[k] = s; }
+}
+
+// One lane per segment that has a start: hop to the first record at or beyond the next live segment's start (bounded by the
+// segment end of the LAST segment before that one), counting records and CIGAR words.
+__global__ __launch_bounds__(64) void k_bam_hop(BamScan S, SegInfo *__restrict__ seg) {
+    const u32 k = blockIdx.x * 64u + threadIdx.x;
+    if (k >= S.n_seg) return;
+    SegInfo s = seg[k];
+    if (s.start == ~0ull) return;
+    // the hop ends at the start found by the next segment that has one
+    u64 limit = S.N;
+    for (u32 j = k + 1; j < S.n_seg; j++) { const u64 st = seg[j].start; if (st != ~0ull) { limit = st; break; } }
+    u64 q = s.start; u32 nr = 0, nc = 0, fl = 0;
+    while (q < limit && q + 4 <= S.N) {
+        const uint8_t *r = S.u + q;
+        const u32 bs = ld32(r);
+        if (bs < 32u || q + 4 + (u64)bs > S.N) break;
+        const u32 ncig = ld16(r + 16);
+        if (ncig == 2u) {    // `<l_seq>S <n>N` is the placeholder of a CIGAR stored in CG:B,I (SAM spec 4.2.2): leave the file to the CPU reader
+            const u32 c0 = ld32(r + 36 + r[12]);
+            if ((c0 & 15u) == 4u && (c0 >> 4) == ld32(r + 20)) fl |= 1u;
+        }
+        nr++; nc += ncig;
+        q += 4 + (u64)bs;
+    }
+    s.landed = q; s.n_rec = nr; s.n_cig = nc; s.flags = fl;
+    seg[k] = s;
+}
+
+// Single workgroup: chain verification + exclusive scans over segments (records, CIGAR words).
+// result[0] = total records, [1] = total CIGAR words, [2] = status (0 ok, 1 chain mismatch, 2 truncated, 4 needs CPU reader).
+__global__ __launch_bounds__(1024) void k_bam_verify(BamScan S, SegInfo *__restrict__ seg, u64 *__restrict__ rec_base, u64 *__restrict__ cig_base,
+                                                     u64 *__restrict__ result) {
+    __shared__ u64 s_rec[1024], s_cig[1024];
+    __shared__ u32 s_bad;
+    const u32 t = threadIdx.x;
+    if (t == 0) s_bad = 0;
+    __syncthreads();
+    const u32 per = (S.n_seg + 1023u) / 1024u;
+    const u32 k0 = t * per, k1 = min(S.n_seg, k0 + per);
+    u64 nr = 0, nc = 0; u32 bad = 0;
+    for (u32 k = k0; k < k1; k++) {
+        const SegInfo s = seg[k];
+        if (s.start == ~0ull) continue;
+        u64 want = S.N;
+        for (u32 j = k + 1; j < S.n_seg; j++) { const u64 st = seg[j].start; if (st != ~0ull) { want = st; break; } }
+        if (s.landed != want) { bad |= (want == S.N) ? 2u : 1u; atomicMin(&result[4], (u64)k); }
+        if (s.flags & 1u) bad |= 4u;
+        nr += s.n_rec; nc += s.n_cig;
+    }
+    if (bad) atomicOr(&s_bad, bad);
+    s_rec[t] = nr; s_cig[t] = nc;
+    __syncthreads();
+    if (t == 0) {
+        u64 a = 0, c = 0;
+        for (u32 i = 0; i < 1024; i++) { const u64 x = s_rec[i], y = s_cig[i]; s_rec[i] = a; s_cig[i] = c; a += x; c += y; }
+        result[0] = a; result[1] = c; result[2] = s_bad;
+        if (s_bad & 3u) { const u64 kb = result[4]; if (kb < S.n_seg) { result[5] = seg[kb].start; result[6] = seg[kb].landed; } }
+    }
+    __syncthreads();
+    u64 a = s_rec[t], c = s_cig[t];
+    for (u32 k = k0; k < k1; k++) {
+        rec_base[k] = a; cig_base[k] = c;
+        if (seg[k].start != ~0ull) { a += seg[k].n_rec; c += seg[k].n_cig; }
+    }
+}
+
+struct RecStore {
+    int32_t *tid, *pos;
+    uint16_t *flag;
+    uint8_t *mapq, *nm_kind;
+    u32 *nm, *l_seq, *cigar_off, *cigar;
+    u64 rec0, cig0;    // where this file's records / CIGAR words start in the store
+};
+
+// Linear aux scan for NM (csrc/host_bam.cpp scan_aux without the CG part).
+__device__ __forceinline__ u32 scan_nm(const uint8_t *p, const uint8_t *end, u32 &nm) {
+    while (p + 3 <= end) {
+        const bool is_nm = p[0] == 'N' && p[1] == 'M';
+        const uint8_t t = p[2];
+        p += 3;
+        u32 sz;
+        if (t == 'A' || t == 'c' || t == 'C') sz = 1;
+        else if (t == 's' || t == 'S') sz = 2;
+        else if (t == 'i' || t == 'I' || t == 'f') sz = 4;
+        else if (t == 'Z' || t == 'H') {
+            if (is_nm) return 2u;
+            while (p < end && *p) p++;
+            if (p >= end) return 0u;
+            p++;
+            continue;
+        } else if (t == 'B') {
+            if (p + 5 > end) return 0u;
+            const uint8_t st = p[0];
+            const u32 cnt = ld32(p + 1);
+            const u32 es = (st == 'c' || st == 'C') ? 1u : (st == 's' || st == 'S') ? 2u : 4u;
+            if (is_nm) return 2u;
+            if ((u64)(end - p - 5) / es < cnt) return 0u;
+            p += 5 + (u64)cnt * es;
+            continue;
+        } else return 0u;
+        if (p + sz > end) return 0u;
+        if (is_nm) {
+            if (t == 'C') { nm = p[0]; return 1u; }
+            if (t == 'S') { nm = ld16(p); return 1u; }
+            if (t == 'I') { nm = ld32(p); return 1u; }
+            return 2u;
+        }
+        p += sz;
+    }
+    return 0u;
+}
+
+// One lane per segment: second hop; every record's fields go straight into the record store.
+__global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__restrict__ seg, const u64 *__restrict__ rec_base,
+                                                    const u64 *__restrict__ cig_base, RecStore R, u32 *__restrict__ n_bad) {
+    const u32 k = blockIdx.x * 64u + threadIdx.x;
+    if (k >= S.n_seg) return;
+    const SegInfo s = seg[k];
+    if (s.start == ~0ull) return;
+    u64 q = s.start;
+    u64 ri = R.rec0 + rec_base[k], ci = R.cig0 + cig_base[k];
+    for (u32 j = 0; j < s.n_rec; j++) {
+        const uint8_t *r = S.u + q;
+        const u32 bs = ld32(r);
+        const uint8_t *end = r + 4 + bs;
+        const u32 l_read_name = r[12], n_cig = ld16(r + 16), l_seq = ld32(r + 20);
+        R.tid[ri] = (int32_t)ld32(r + 4); R.pos[ri] = (int32_t)ld32(r + 8);
+        R.mapq[ri] = r[13]; R.flag[ri] = (uint16_t)ld16(r + 18); R.l_seq[ri] = l_seq;
+        R.cigar_off[ri] = (u32)ci;
+        const uint8_t *c = r + 36 + l_read_name;
+        const uint8_t *aux = c + 4ull * n_cig + ((u64)l_seq + 1ull) / 2 + l_seq;
+        if (aux > end) { atomicAdd(n_bad, 1u); aux = end; }
+        else for (u32 x = 0; x < n_cig; x++) R.cigar[ci + x] = ld32(c + 4u * x);
+        u32 nm = 0;
+        R.nm_kind[ri] = (uint8_t)scan_nm(aux, end, nm);
+        R.nm[ri] = nm;
+        ri++; ci += n_cig;
+        q += 4 + (u64)bs;
+    }
+}
+
+}  // namespace covi

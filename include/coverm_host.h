@@ -181,6 +181,21 @@ uint64_t covh_bam_stream_peak_bytes(const covh_bam_stream *h); /* largest total 
 void covh_bam_stream_timing(const covh_bam_stream *h, double *out5); /* s: read, inflate, parse, inflate-side wait, parse-side wait */
 void covh_bam_stream_close(covh_bam_stream *h);
 
+/* ---- device ingest driver (cov_ingest_* of covermhip.h): header on the host, everything else on the GPU.
+ *   hd = covh_bam_read_header(path, ...)  -> reference names / lengths (cov_set_targets) and where the records start
+ *   covh_bam_gpu_ingest(path, threads, session, hd, check_crc, &n, timing, err, cap)
+ *       0 = the records are in the session's store; 1 = this file needs the CPU reader (reason in err, nothing appended:
+ *       use covh_bam_stream_* / covh_bam_open); -1 = error.  threads read the file into page-locked staging buffers. */
+typedef struct covh_bam_header covh_bam_header;
+covh_bam_header *covh_bam_read_header(const char *path, char *err, size_t errcap);
+void covh_bam_header_free(covh_bam_header *h);
+uint32_t covh_bam_header_n_targets(const covh_bam_header *h);
+const char *covh_bam_header_target_name(const covh_bam_header *h, uint32_t i);
+uint64_t covh_bam_header_target_len(const covh_bam_header *h, uint32_t i);
+uint64_t covh_bam_header_first_record(const covh_bam_header *h); /* offset in the inflated stream */
+int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint64_t *n_records,
+                        double *timing4, char *err, size_t errcap);
+
 /* ---- reader-stage PAIR filter (ReferenceSortedBamFilter::read pair branch, filter.rs:117-228, filter_out = true).
  * The single-read branch runs on the device (cov_config.filter_single); the pair branch needs read names, which never
  * cross the covermhip ABI, so it runs here, threaded over references.  Thresholds as FilterParameters holds them

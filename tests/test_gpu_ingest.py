@@ -1,0 +1,137 @@
+"""Device ingest (cov_ingest_*, csrc/ingest_kernels.hip.h): the GPU's inflate + BAM parse must put exactly the records into the
+session's store that the CPU reader decodes, for every DEFLATE block type, across staging-piece boundaries, and must hand the
+file back (IngestFallback) rather than guess when something is irregular."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from coverm_amd import bam as cbam
+from coverm_amd import synth
+from coverm_amd.engine import FilterConfig, Session
+from oracle import bamio
+from tests.fixtures import load_fixture
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar")
+
+
+def _check(path, threads=4, **kw):
+    whole = cbam.read_alignment_file(path, threads=2, want_names=False)
+    with Session(0, FilterConfig(), 75, want_hist=True, want_identity=True) as s:
+        names, lens, n, timing = cbam.gpu_ingest(s, path, threads=threads, **kw)
+        assert names == whole.ref_names
+        np.testing.assert_array_equal(lens, whole.ref_lens)
+        assert n == whole.records.n_records
+        got = cbam.session_records(s)
+        for f in FIELDS:
+            np.testing.assert_array_equal(getattr(got, f), getattr(whole.records, f), err_msg=f)
+        st_gpu, su_gpu = s.finish()
+        h_gpu = s.hist()
+    with Session(0, FilterConfig(), 75, want_hist=True, want_identity=True) as s:
+        s.set_targets(whole.ref_lens)
+        s.push(whole.records)
+        st, su = s.finish()
+        h = s.hist()
+    assert st_gpu.tobytes() == st.tobytes() and (h_gpu == h).all()
+    assert su_gpu.num_detected_primary_alignments == su.num_detected_primary_alignments
+    return whole
+
+
+@pytest.mark.parametrize("with_seq,piece_kb", [(2, 0), (2, 64), (1, 200), (0, 64)])
+def test_device_ingest_equals_cpu_reader(tmp_path, monkeypatch, with_seq, piece_kb):
+    """Product writer output (libdeflate / zlib level 1: dynamic-Huffman blocks), whole pieces and 64 KiB pieces (every BGZF
+    block and many headers straddle a staging piece)."""
+    if piece_kb:
+        monkeypatch.setenv("COVERM_INGEST_PIECE_KB", str(piece_kb))
+    ref = synth.make_reference(40, 6_000_000, seed=18, min_len=5000, max_len=800_000)
+    b = synth.make_reads(ref, 120_000, seed=19)
+    p = str(tmp_path / "s.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=with_seq, threads=4)
+    w = _check(p)
+    np.testing.assert_array_equal(w.records.pos, b.pos)
+
+
+@pytest.mark.parametrize("level,block", [(0, 0xFF00), (9, 0xFF00), (6, 700), (1, 90)])
+def test_device_inflate_block_types(tmp_path, level, block):
+    """Stored blocks (level 0), long-match streams (level 9), and tiny BGZF blocks, which zlib emits with FIXED Huffman codes."""
+    d = load_fixture("7seqs.reads_for_seq1_and_seq2.bam") if block < 1000 else load_fixture("eg2.bam")
+    p = str(tmp_path / "x.bam")
+    bamio.write_bam(p, d, level=level, block=block)
+    _check(p)
+
+
+def test_device_ingest_inflated_stream_is_bit_exact(tmp_path):
+    ref = synth.make_reference(12, 900_000, seed=41, min_len=1500, max_len=200_000)
+    b = synth.make_reads(ref, 30_000, seed=43)
+    p = str(tmp_path / "s.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=2, threads=2)
+    raw = open(p, "rb").read()
+    exp, q = b"", 0
+    while q < len(raw):
+        bs = int.from_bytes(raw[q + 16:q + 18], "little") + 1
+        exp += zlib.decompress(raw[q + 18:q + bs - 8], -15)
+        q += bs
+    import ctypes as C
+    from coverm_amd import native
+    with Session(0, FilterConfig(), 75) as s:
+        cbam.gpu_ingest(s, p, threads=2)
+        L = native.lib()
+        L.cov_ingest_copy_inflated.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        out = np.zeros(len(exp), np.uint8)
+        assert L.cov_ingest_copy_inflated(s._h, 0, len(exp), out.ctypes.data) == 0
+        assert out.tobytes() == exp
+
+
+def test_device_ingest_hands_irregular_files_back(tmp_path):
+    """A BGZF block whose CRC-32 does not match (beyond the part the host inflates for the header): IngestFallback and nothing
+    appended; with the check switched off the (intact) payload goes through.  A CG:B,I long-CIGAR placeholder: handed back too."""
+    ref = synth.make_reference(12, 900_000, seed=41, min_len=1500, max_len=200_000)
+    b = synth.make_reads(ref, 60_000, seed=43)
+    good = str(tmp_path / "good.bam")
+    cbam.write_bam(good, ref.names, ref.lengths, b, with_seq=2, threads=2)
+    raw = bytearray(open(good, "rb").read())
+    assert len(raw) > 3 << 20
+    q = 0
+    while q < (2 << 20) + (1 << 19):
+        q += int.from_bytes(raw[q + 16:q + 18], "little") + 1
+    bs = int.from_bytes(raw[q + 16:q + 18], "little") + 1
+    raw[q + bs - 8] ^= 0x5A
+    bad = str(tmp_path / "bad_crc.bam")
+    open(bad, "wb").write(bytes(raw))
+    with Session(0, FilterConfig(), 75) as s:
+        with pytest.raises(cbam.IngestFallback):
+            cbam.gpu_ingest(s, bad, threads=2)
+        assert cbam.session_records(s).n_records == 0
+        cbam.gpu_ingest(s, bad, threads=2, check_crc=False)
+        assert cbam.session_records(s).n_records == b.n_records
+    # long-CIGAR placeholder: `<l_seq>S<ref_len>N` + CG:B,I  (the CPU readers resolve it, tests/test_bam_reader.py)
+    n_ops = 70_001
+    ops = np.empty(n_ops, np.uint32)
+    ops[0::2] = (3 << 4) | 0
+    ops[1::2] = (1 << 4) | 2
+    ref_span = int(((ops >> 4)[(ops & 15) != 1]).sum())
+    l_seq = int(((ops >> 4)[(ops & 15) == 0]).sum())
+
+    def rec(tid, pos, cigar, lseq, aux, name=b"q"):
+        core = struct.pack("<iiBBHHHiiii", tid, pos, len(name) + 1, 30, 4680, len(cigar), 0, lseq, -1, -1, 0)
+        body = core + name + b"\0" + struct.pack("<%dI" % len(cigar), *cigar) + b"\x11" * ((lseq + 1) // 2) + b"\xff" * lseq + aux
+        return struct.pack("<i", len(body)) + body
+    cg = b"CGBI" + struct.pack("<I", n_ops) + ops.tobytes()
+    data = b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", 1) + struct.pack("<i", 4) + b"big\0" + struct.pack("<i", ref_span + 1000)
+    data += rec(0, 100, [(l_seq << 4) | 4, (ref_span << 4) | 3], l_seq, b"NMC\x05" + cg) + rec(0, 200, [(50 << 4) | 0], 50, b"NMC\x01", b"plain")
+    out = b""
+    for s0 in range(0, len(data), 0xff00):
+        chunk = data[s0:s0 + 0xff00]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+    out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    p = str(tmp_path / "cg.bam")
+    open(p, "wb").write(out)
+    with Session(0, FilterConfig(), 75) as s:
+        with pytest.raises(cbam.IngestFallback) as ei:
+            cbam.gpu_ingest(s, p, threads=2)
+        assert "CG:B,I" in str(ei.value)
