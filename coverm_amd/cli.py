@@ -250,9 +250,6 @@ def device_depth(af: AlignmentFile, records, filt, device: int = 0):
 def _run_genes(mode, files, et, fp, contig_end_exclusion, gff, feature_type, separator, single_genome, genome_definition,
                print_zeros, device, depth_provider):
     """run_contig / run_genome with --gff (coverm.rs:1557-1590, 2099-2109)."""
-    for e in et.estimators:
-        if e.kind == 2:
-            raise SystemExit("coverage_histogram is not available per gene in this build")
     genes = host.Genes.read_gff(gff, feature_type)
     namer_mode, genomes, c2g = 0, None, None
     if mode == "genome":

@@ -915,14 +915,25 @@ static cov_status launch_inflate(cov_session *s) {
     HIPCHK(s->g_scratch.reserve((size_t)grid * 64u * covi::INF_SCRATCH_BYTES, s->stream));
     HIPCHK(s->g_tok.reserve((size_t)n * covi::INF_TOK_CAP, s->stream));
     HIPCHK(s->g_ntok.reserve(n, s->stream));
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)covi::inflate_smem_bytes());
-        attr_set = true;
+    static int lit_bits = 0, lds_sorted = 0;
+    if (!lit_bits) {
+        const char *e = getenv("COVERM_INFLATE_BITS");
+        lit_bits = e ? atoi(e) : 8;
+        if (lit_bits != 7 && lit_bits != 9) lit_bits = 8;
+        lds_sorted = getenv("COVERM_INFLATE_LDS_SORTED") ? atoi(getenv("COVERM_INFLATE_LDS_SORTED")) : 0;
+#define COV_INF_ATTR(LB, LS) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, LS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)covi::inflate_smem_bytes(LB, LS))
+        COV_INF_ATTR(7, false); COV_INF_ATTR(8, false); COV_INF_ATTR(9, false); COV_INF_ATTR(7, true); COV_INF_ATTR(8, true);
+#undef COV_INF_ATTR
     }
-    hipLaunchKernelGGL(covi::k_inflate, dim3(grid), dim3(64), covi::inflate_smem_bytes(), s->stream, (const uint8_t *)s->g_comp.p,
-                       (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, s->g_infl.p, s->g_scratch.p, s->g_tok.p, s->g_ntok.p, s->g_status.p + b0,
-                       reinterpret_cast<u32 *>(s->g_result.p + 3));
+#define COV_LAUNCH_INFLATE(LB, LS)                                                                                                              \
+    hipLaunchKernelGGL((covi::k_inflate<LB, LS>), dim3(grid), dim3(64), covi::inflate_smem_bytes(LB, LS), s->stream, (const uint8_t *)s->g_comp.p, \
+                       (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, s->g_infl.p, s->g_scratch.p, s->g_tok.p, s->g_ntok.p,                   \
+                       s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0))
+    if (lds_sorted) { if (lit_bits == 7) COV_LAUNCH_INFLATE(7, true); else COV_LAUNCH_INFLATE(8, true); }
+    else if (lit_bits == 7) COV_LAUNCH_INFLATE(7, false);
+    else if (lit_bits == 9) COV_LAUNCH_INFLATE(9, false);
+    else COV_LAUNCH_INFLATE(8, false);
+#undef COV_LAUNCH_INFLATE
     hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->stream, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, s->g_infl.p,
                        (const u64 *)s->g_tok.p, (const u32 *)s->g_ntok.p);
     HIPCHK(hipGetLastError());
@@ -972,7 +983,13 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
     HIPCHK(hipEventRecord(s->ing_fed, s->ing_copy));
     s->ing_blocks += n_blocks; s->ing_infl = infl_end;
     // k_inflate wants >= 2 waves on every CU (one lane per block): launch once enough blocks have arrived
-    if (s->ing_blocks - s->ing_launched >= (uint64_t)s->n_cus * 2u * 64u) return launch_inflate(s);
+    {
+        const char *e = getenv("COVERM_INFLATE_BITS");
+        const int lb = e ? atoi(e) : 8;
+        const bool ls = getenv("COVERM_INFLATE_LDS_SORTED") && atoi(getenv("COVERM_INFLATE_LDS_SORTED"));
+        const uint64_t waves_per_cu = ls ? (lb == 7 ? 2 : 1) : lb == 7 ? 5 : lb == 9 ? 2 : 3;     // LDS-bound residency of k_inflate
+        if (s->ing_blocks - s->ing_launched >= (uint64_t)s->n_cus * waves_per_cu * 64u) return launch_inflate(s);
+    }
     return COV_OK;
 }
 

@@ -87,7 +87,7 @@ struct Sample {
     std::vector<uint64_t> hist;
     uint64_t prim = 0, n_records = 0;
     covh_reads_mapped gene_rm{0, 0};
-    double t_open = 0, t_ingest = 0, t_finish = 0; uint64_t peak_bytes = 0; bool streamed = false;
+    double t_open = 0, t_ingest = 0, t_finish = 0; uint64_t peak_bytes = 0; bool streamed = false, device_ingest = false;
     covh_header header() const { covh_header h; h.n_targets = (uint32_t)tlen.size(); h.names = names_blob.c_str(); h.name_off = name_off.data(); h.target_len = tlen.data(); return h; }
     std::string target_name(uint32_t t) const { return names_blob.substr(name_off[t], name_off[t + 1] - name_off[t]); }
 };
@@ -153,6 +153,37 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
     const double t0 = now();
     std::vector<uint8_t> mask;
     check(s, cov_reset(s));
+    if (stream && span_count == 1 && !getenv("COVERM_NO_GPU_INGEST")) {
+        // ---- device ingest: the compressed file goes to HBM, the GPU inflates, finds the records and fills its own store
+        char err[512] = {0};
+        covh_bam_header *hd = covh_bam_read_header(S.path.c_str(), err, sizeof err);
+        if (!hd) die(err);
+        struct HdFree { covh_bam_header *p; ~HdFree() { covh_bam_header_free(p); } } hdfree{hd};
+        set_header(S, covh_bam_header_n_targets(hd), [&](uint32_t t) { return covh_bam_header_target_name(hd, t); },
+                   [&](uint32_t t) { return covh_bam_header_target_len(hd, t); });
+        check(s, cov_set_targets(s, (uint32_t)S.tlen.size(), S.tlen.data()));
+        if (R.by_names) { genome_table(R, S, mask); check(s, cov_set_target_mask(s, mask.data())); }
+        S.t_open = now() - t0;
+        uint64_t nrec = 0; double tm[4] = {0, 0, 0, 0};
+        const int rc = covh_bam_gpu_ingest(S.path.c_str(), threads, s, hd, getenv("COVERM_NO_CRC") ? 0 : 1, &nrec, tm, err, sizeof err);
+        if (rc < 0) die(err);
+        if (rc == 0) {
+            S.n_records = nrec; S.device_ingest = true;
+            if (getenv("COVERM_CLI_TIMING"))
+                fprintf(stderr, "[coverm-amd] %s: device ingest: file read %.3fs, staging waits %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records\n",
+                        S.stoit.c_str(), tm[0], tm[1], tm[2], tm[3], (unsigned long long)nrec);
+            S.t_ingest = now() - t0;
+            S.stats.resize(S.tlen.size());
+            cov_summary summ;
+            check(s, cov_finish(s, S.stats.data(), &summ));
+            if (R.want & COV_WANT_HIST) { S.hist.resize(summ.hist_total); check(s, cov_fetch_hist(s, S.hist.data())); }
+            S.prim = summ.num_detected_primary_alignments;
+            S.t_finish = now() - t0 - S.t_ingest;
+            return;
+        }
+        if (getenv("COVERM_CLI_TIMING")) fprintf(stderr, "[coverm-amd] %s: %s\n", S.stoit.c_str(), err);
+        check(s, cov_reset(s));       // the CPU reader takes the file
+    }
     if (stream) {
         char err[512] = {0};
         covh_bam_stream *st = covh_bam_stream_open(S.path.c_str(), threads, span_index, span_count, err, sizeof err);
@@ -517,10 +548,22 @@ int run_cli(int argc, char **argv) {
             }
         }
     }
+    if (timing) {
+        // where the resident set comes from (VmHWM = peak; RssShmem counts page-locked / device-visible mappings of the HIP runtime)
+        if (FILE *ps = fopen("/proc/self/status", "r")) {
+            char ln[256];
+            while (fgets(ln, sizeof ln, ps))
+                if (!strncmp(ln, "VmHWM", 5) || !strncmp(ln, "VmRSS", 5) || !strncmp(ln, "RssAnon", 7) || !strncmp(ln, "RssFile", 7) || !strncmp(ln, "RssShmem", 8)) {
+                    ln[strcspn(ln, "\n")] = 0;
+                    fprintf(stderr, "[coverm-amd] %s\n", ln);
+                }
+            fclose(ps);
+        }
+    }
     if (timing)
         for (auto &S : samples)
             fprintf(stderr, "[coverm-amd] sample %s: %s, open %.3fs, ingest (decode+push) %.3fs, finish+fetch %.3fs, %llu records, reader buffers %.0f MB\n", S.stoit.c_str(),
-                    S.streamed ? "streamed" : "whole file", S.t_open, S.t_ingest, S.t_finish, (unsigned long long)S.n_records, S.peak_bytes / 1e6);
+                    S.device_ingest ? "device ingest" : S.streamed ? "streamed" : "whole file", S.t_open, S.t_ingest, S.t_finish, (unsigned long long)S.n_records, S.peak_bytes / 1e6);
 
     // ---- scan drivers: one call per BAM, each with its own header (contig.rs:29-32)
     std::vector<covh_reads_mapped> rm(nb);

@@ -355,6 +355,40 @@ uint32_t covh_wants(const covh_estimator *est, size_t n_est) {
     return w;
 }
 
+// ---- trait MosdepthGenomeCoverageEstimator (estimators.rs:245-265) over device results: the stateful face a Rust
+// `impl MosdepthGenomeCoverageEstimator for GpuEstimator` forwards to, one call per trait method.
+struct covh_estimator_state {
+    covh_estimator e;
+    EntryAcc acc;
+    u64 num_mapped_reads = 0;     // what num_mapped_reads() reports (estimators.rs:993-1010)
+};
+covh_estimator_state *covh_estimator_new(const covh_estimator *e) {
+    if (!e) return nullptr;
+    covh_estimator_state *s = new covh_estimator_state();
+    s->e = *e; s->acc.reset();
+    return s;
+}
+void covh_estimator_free(covh_estimator_state *s) { delete s; }
+void covh_estimator_setup(covh_estimator_state *s) { s->acc.reset(); s->num_mapped_reads = 0; }          /* fn setup(&mut self) */
+/* fn add_contig(&mut self, ups_and_downs, num_mapped_reads, total_mismatches, sum_identity): the delta array is replaced by the
+ * contig's integer statistics from cov_finish (+ its histogram slice); num_mapped_reads / sum_identity are the values the scan
+ * loop would have passed (n_primary / n_pass / n_nonsupp and the matching identity sum, depending on the loop). */
+void covh_estimator_add_contig_stats(covh_estimator_state *s, const cov_contig_stats *stats, uint64_t target_len, const uint64_t *hist,
+                                     uint64_t num_mapped_reads, double sum_identity) {
+    s->acc.add_contig(*stats, target_len, s->e.contig_end_exclusion, num_mapped_reads, sum_identity, hist);
+    // Mean/ReadCount/... accumulate, the histogram family assigns (estimators.rs:434): EntryAcc keeps the sum, the assignment
+    // only matters to num_mapped_reads()
+    if (s->e.kind == COVH_TRIMMED_MEAN || s->e.kind == COVH_PILEUP_COUNTS || s->e.kind == COVH_VARIANCE) s->num_mapped_reads = num_mapped_reads;
+    else s->num_mapped_reads += num_mapped_reads;
+}
+float covh_estimator_calculate_coverage(covh_estimator_state *s, const uint64_t *unobserved_contig_lengths, size_t n) {
+    return calculate(s->e, s->acc, unobserved_contig_lengths, n);
+}
+void covh_estimator_print_coverage(const covh_estimator_state *s, float coverage, covh_taker *t) { print_coverage(s->e, s->acc, coverage, *t); }
+void covh_estimator_print_zero_coverage(const covh_estimator_state *s, covh_taker *t, uint64_t entry_length) { print_zero_coverage(s->e, *t, entry_length); }
+covh_estimator_state *covh_estimator_copy(const covh_estimator_state *s) { return covh_estimator_new(&s->e); }   /* fn copy(&self): fresh state, same parameters */
+uint64_t covh_estimator_num_mapped_reads(const covh_estimator_state *s) { return s->num_mapped_reads; }
+
 float covh_calculate_coverage(const covh_estimator *e, const covh_entry *en, const uint64_t *unobs, size_t n) {
     EntryAcc a;
     a.win_len = en->win_len; a.win_sum_d = en->win_sum_d; a.win_sum_d2 = en->win_sum_d2; a.win_covered = en->win_covered;
@@ -910,8 +944,6 @@ int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh
                        size_t n_est, int print_zero, covh_reads_mapped *rm_out) {
     if (!h || !genes || !rec || !cfg || (!depth_fn && !device_session) || !taker || (!est && n_est)) return COV_ERR_INVALID_ARG;
     if (!check_excl(est, n_est)) { g_err = "estimators disagree on contig_end_exclusion"; return COV_ERR_INVALID_ARG; }
-    for (size_t k = 0; k < n_est; k++)
-        if (est[k].kind == COVH_PILEUP_COUNTS) { g_err = "coverage_histogram is not available per gene in this build"; return COV_ERR_INVALID_ARG; }
     const u64 excl = session_excl(est, n_est);
     const u64 zero = 0;
     const u32 nT = h->n_targets;
@@ -959,7 +991,7 @@ int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh
         for (u32 t = 0; t < nT; t++)
             for (const ResolvedGene &g : by_tid[t]) { cov_interval iv; iv.tid = t; iv.pad = 0; iv.start = g.start; iv.end = g.end; ivs.push_back(iv); }
         bool want_hist = false;
-        for (size_t k = 0; k < n_est; k++) want_hist |= est[k].kind == COVH_TRIMMED_MEAN;
+        for (size_t k = 0; k < n_est; k++) want_hist |= est[k].kind == COVH_TRIMMED_MEAN || est[k].kind == COVH_PILEUP_COUNTS;
         dstats.resize(ivs.size());
         uint64_t htot = 0;
         int rc = (int)cov_interval_stats_compute(device_session, ivs.data(), ivs.size(), excl, want_hist, dstats.data(), &htot);

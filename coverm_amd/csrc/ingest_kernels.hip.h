@@ -37,11 +37,16 @@ struct BgzfBlock {
     u32 in_len, isize, crc, pad;
 };
 
-constexpr int INF_LIT_BITS = 9, INF_DIST_BITS = 6;
-constexpr int INF_LIT_N = 1 << INF_LIT_BITS, INF_DIST_N = 1 << INF_DIST_BITS;
+constexpr int INF_DIST_BITS = 6, INF_DIST_N = 1 << INF_DIST_BITS;
 // Per-lane LDS, lane-interleaved u16 entries (entry i of lane l at [i * 64 + l]): primary tables + per-length code counts of both
-// alphabets: 64 lanes x (512 + 64 + 16 + 16) x 2 B = 76 KiB per wave, two waves per CU.
-constexpr size_t inflate_smem_bytes() { return (size_t)64 * (INF_LIT_N + INF_DIST_N + 32) * 2; }
+// alphabets.  With LIT_BITS-bit literal/length tables a wave takes 64 x (2^LIT_BITS + 64 + 32) x 2 B: 76 KiB at 9 bits (two waves
+// per CU), 44 KiB at 8 (three), 28 KiB at 7 (five).  In SIMT the canonical walk for longer codes is paid whenever ANY lane needs
+// it — practically every step — so a smaller table costs little and more waves per CU hide more latency (COVERM_INFLATE_BITS).
+// lds_sorted: the symbols-by-code-length arrays (288 + 32 u16 per lane) live in LDS too, so the canonical walk never goes to
+// global memory (+40 KiB per wave).
+// The distance alphabet's sorted symbols (32 u16 per lane) are always in LDS, and so are the four length / distance base and
+// extra-bit tables (shared by the wave): a match then costs no global load at all.
+constexpr size_t inflate_smem_bytes(int lit_bits, bool lds_sorted = false) { return (size_t)64 * ((1u << lit_bits) + INF_DIST_N + 32 + (lds_sorted ? 288 : 0)) * 2 + 256; }
 // Per-lane global scratch: symbols sorted by (code length, value) for codes longer than the primary tables, and the code lengths
 // while a table is being built:  u16 lit_sorted[288], dist_sorted[32], u8 lens[320]
 constexpr u32 INF_SCRATCH_BYTES = 288 * 2 + 32 * 2 + 320;
@@ -58,28 +63,31 @@ __constant__ unsigned short c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 
 __constant__ unsigned char c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ unsigned char c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-// Bit reader over one lane's compressed stream: 64-bit buffer refilled 4 bytes at a time with aligned dword loads.
+// Bit reader over one lane's compressed stream: 64-bit buffer refilled 4 bytes at a time with aligned dword loads.  The word
+// after the one being consumed is always in flight (`ahead`), so a refill seldom waits for memory.
 struct BitReader {
     const u32 *words;   // aligned base
     u64 buf; u32 cnt;   // cnt valid bits in buf
     u32 next_word, end_word;     // word indices
     u32 consumed;                // bits consumed so far
+    u32 ahead;                   // words[next_word], already loaded
+    __device__ __forceinline__ u32 fetch(u32 i) const { return i < end_word ? words[i] : 0u; }   // zero padding past the end: errors surface as format / size errors
     __device__ __forceinline__ void init(const uint8_t *base, u64 off, u32 len) {
         const u64 a = (u64)(base + off);
         const u32 mis = (u32)(a & 3u);
         words = (const u32 *)(a - mis);
-        next_word = 0; end_word = (mis + len + 3u) >> 2;
-        buf = 0; cnt = 0;
-        refill();
+        end_word = (mis + len + 3u) >> 2;
+        buf = (u64)fetch(0) | ((u64)fetch(1) << 32); cnt = 64u;
+        next_word = 2; ahead = fetch(2);
         if (mis) { buf >>= 8 * mis; cnt -= 8 * mis; }
         consumed = 0;
     }
     __device__ __forceinline__ void refill() {
         if (cnt <= 32u) {
-            const u32 w = next_word < end_word ? words[next_word] : 0u;   // zero padding past the end: errors surface as format / size errors
-            next_word++;
-            buf |= (u64)w << cnt;
+            buf |= (u64)ahead << cnt;
             cnt += 32u;
+            next_word++;
+            ahead = fetch(next_word);
         }
     }
     __device__ __forceinline__ u32 peek(u32 n) const { return (u32)buf & ((1u << n) - 1u); }
@@ -87,32 +95,68 @@ struct BitReader {
     __device__ __forceinline__ u32 take(u32 n) { const u32 v = peek(n); drop(n); return v; }   // n <= 16; caller keeps cnt >= n via refill()
 };
 
+// Sixteen 16-bit counters of one lane in four registers (counter l in bits (l & 3) * 16 of word l >> 2): per-length code
+// counts and running offsets while a table is built, without LDS round trips or dynamically indexed register arrays.
+struct Pack16 {
+    u64 w[4];
+    __device__ __forceinline__ void clear() { w[0] = w[1] = w[2] = w[3] = 0; }
+    __device__ __forceinline__ u32 get(u32 l) const {
+        const u64 x = (l & 8u) ? ((l & 4u) ? w[3] : w[2]) : ((l & 4u) ? w[1] : w[0]);
+        return (u32)(x >> ((l & 3u) * 16u)) & 0xffffu;
+    }
+    __device__ __forceinline__ void add(u32 l, u32 v) {
+        const u64 inc = (u64)v << ((l & 3u) * 16u);
+        const u32 k = l >> 2;
+        w[0] += k == 0u ? inc : 0ull; w[1] += k == 1u ? inc : 0ull; w[2] += k == 2u ? inc : 0ull; w[3] += k == 3u ? inc : 0ull;
+    }
+};
+
 // One alphabet's decoding state of a lane.
 struct Huff {
     unsigned short *tab;          // LDS primary table (lane-interleaved)
-    unsigned short *cnt;          // LDS per-length code counts (lane-interleaved, 16 entries)
-    const unsigned short *sorted; // global: symbols by (length, value)
-    u32 first_p, index_p;         // canonical state on entering length prim_bits + 1
+    unsigned short *sorted;       // symbols by (length, value): global scratch (stride 1) or LDS (lane-interleaved, stride 64)
+    u32 sstride;
+    // Codes longer than the primary table, resolved WITHOUT a bit-serial walk: with the next 15 stream bits reversed into v (the
+    // code left-justified, MSB first), canonical codes of length l occupy [.., limit[l]) with limit[l] = (first code of length l
+    // + count[l]) << (15 - l), non-decreasing in l, so l = 1 + #{l' : v >= limit[l']}; the symbol is sorted[off[l] + (v >> (15 - l))]
+    // with off[l] = (index of the first symbol of length l) - (first code of length l)  (mod 2^16).  Both arrays live in registers.
+    Pack16 limit, off;
 };
 
-// Builds the lane's primary lookup table and counts (LDS) and the sorted symbols (global scratch) from code lengths.
+// Builds the lane's primary lookup table and counts (LDS) and the sorted symbols (global scratch) from code lengths
+// (`lens` is 4-byte aligned; one pass for the counts, one for the placement: O(n_sym)).
 // Primary entry: bits 0-3 code length (0 = longer than prim_bits: resolve canonically), bits 4-15 symbol.
-__device__ __forceinline__ bool build_table(const uint8_t *lens, u32 n_sym, u32 prim_bits, int lane, unsigned short *sorted, Huff &H) {
-    for (u32 l = 0; l < 16; l++) H.cnt[l * 64 + lane] = 0;
-    for (u32 s = 0; s < n_sym; s++) { const u32 l = lens[s]; if (l) H.cnt[l * 64 + lane]++; }
+__device__ __forceinline__ bool build_table(const uint8_t *lens, u32 n_sym, u32 prim_bits, int lane, Huff &H) {
+    unsigned short *sorted = H.sorted; const u32 ss = H.sstride;
+    Pack16 cnt; cnt.clear();
+    const u32 *lw = (const u32 *)lens;
+    for (u32 s = 0; s < n_sym; s += 4) {
+        u32 w = lw[s >> 2];
+#pragma unroll
+        for (u32 k = 0; k < 4; k++, w >>= 8) { const u32 l = w & 0xffu; if (s + k < n_sym && l) cnt.add(l & 15u, 1u); }
+    }
     // an over-subscribed set is an error; incomplete sets are tolerated (a single distance code is legal, anything else
     // decodes to -1 when an unassigned code appears and the block's CRC catches the rest)
     u32 left = 1;
-    for (u32 l = 1; l < 16; l++) { left <<= 1; const u32 c = H.cnt[l * 64 + lane]; if (c > left) return false; left -= c; }
-    // offsets per length: running position kept in the (so far unused) entry 0 of the count array would clobber; use a second pass
+    Pack16 offs; offs.clear();
+    H.limit.clear(); H.off.clear();
     {
-        u32 off = 0;
-        for (u32 l = 1; l < 16; l++) {     // place the symbols of each length in order of value
-            const u32 c = H.cnt[l * 64 + lane];
-            if (c == 0) continue;
-            u32 k = off;
-            for (u32 s = 0; s < n_sym; s++) if (lens[s] == l) sorted[k++] = (unsigned short)s;
-            off += c;
+        u32 run = 0, first = 0;
+        for (u32 l = 1; l < 16; l++) {
+            const u32 c = cnt.get(l);
+            left <<= 1; if (c > left) return false; left -= c;
+            offs.add(l, run);
+            H.limit.add(l, min((first + c) << (15u - l), 0xffffu));      // 2^15 at most, except past a complete set (saturate)
+            H.off.add(l, (run - first) & 0xffffu);
+            run += c; first = (first + c) << 1;
+        }
+    }
+    for (u32 s = 0; s < n_sym; s += 4) {      // symbols in increasing value: each length's run comes out sorted by value
+        u32 w = lw[s >> 2];
+#pragma unroll
+        for (u32 k = 0; k < 4; k++, w >>= 8) {
+            const u32 l = w & 0xffu;
+            if (s + k < n_sym && l) { sorted[offs.get(l & 15u) * ss] = (unsigned short)(s + k); offs.add(l & 15u, 1u); }
         }
     }
     const u32 N = 1u << prim_bits;
@@ -121,56 +165,76 @@ __device__ __forceinline__ bool build_table(const uint8_t *lens, u32 n_sym, u32 
     // packs Huffman codes MSB first into an LSB-first bit stream)
     u32 code = 0, idx = 0;
     for (u32 l = 1; l <= prim_bits; l++) {
-        const u32 c = H.cnt[l * 64 + lane];
+        const u32 c = cnt.get(l);
         for (u32 k = 0; k < c; k++, idx++, code++) {
-            const u32 sym = sorted[idx];
+            const u32 sym = sorted[idx * ss];
             const u32 rev = __brev(code) >> (32 - l);
             const unsigned short e = (unsigned short)((sym << 4) | l);
             for (u32 i = rev; i < N; i += 1u << l) H.tab[i * 64 + lane] = e;
         }
         code <<= 1;
     }
-    H.first_p = code; H.index_p = idx; H.sorted = sorted;
     return true;
 }
 
-// Decodes one symbol: primary table, else canonical walk over the lengths above prim_bits (counts in LDS; the walk index is the
-// same for all lanes, only the final sorted[] lookup goes to global memory).
-__device__ __forceinline__ int decode_sym(BitReader &br, const Huff &H, int lane, u32 prim_bits) {
-    const u32 pk = br.peek(prim_bits);
+// Decodes one symbol: primary table, else the parallel length search described at Huff (no loop, no memory until the final
+// sorted[] lookup).
+template <int PRIM>
+__device__ __forceinline__ int decode_sym(BitReader &br, const Huff &H, int lane) {
+    const u32 pk = br.peek(PRIM);
     const u32 e = H.tab[pk * 64 + lane];
     if (e & 15u) { br.drop(e & 15u); return (int)(e >> 4); }
-    u32 code = __brev(pk) >> (32 - prim_bits), first = H.first_p, index = H.index_p;
-    u64 bits = br.buf >> prim_bits;
-    for (u32 l = prim_bits + 1; l <= 15; l++) {
-        code = (code << 1) | (u32)(bits & 1u); bits >>= 1;
-        const u32 c = H.cnt[l * 64 + lane];
-        if (code < first + c) { br.drop(l); return (int)H.sorted[index + (code - first)]; }
-        index += c; first = (first + c) << 1;
-    }
-    return -1;
+    const u32 v = __brev((u32)br.buf) >> 17;          // next 15 bits, first stream bit on top
+    u32 l = PRIM + 1;
+#pragma unroll
+    for (u32 k = PRIM + 1; k < 15; k++) l += v >= ((u32)(H.limit.w[k >> 2] >> ((k & 3u) * 16u)) & 0xffffu) ? 1u : 0u;
+    if (v >= H.limit.get(15)) return -1;               // not a code of this (incomplete) set
+    br.drop(l);
+    return (int)H.sorted[((H.off.get(l) + (v >> (15u - l))) & 0xffffu) * H.sstride];
 }
 
 // One lane per BGZF block: Huffman decoding only.  Literals go to out + out_off at their final positions, matches become
 // tokens (tok + local block index * INF_TOK_CAP, count in n_tok).  status[b] = INF_*.
+template <int INF_LIT_BITS, bool LDS_SORTED>
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                 uint8_t *__restrict__ out, uint8_t *__restrict__ scratch, u64 *__restrict__ tok,
-                                                u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed) {
+                                                u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 ablate) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    constexpr int INF_LIT_N = 1 << INF_LIT_BITS;
     const int lane = threadIdx.x & 63;
     Huff HL, HD;
     HL.tab = lds; HD.tab = lds + (size_t)64 * INF_LIT_N;
-    HL.cnt = HD.tab + (size_t)64 * INF_DIST_N; HD.cnt = HL.cnt + 64 * 16;
-    HL.sorted = HD.sorted = nullptr; HL.first_p = HL.index_p = HD.first_p = HD.index_p = 0;
+    unsigned short *dsorted_lds = HD.tab + (size_t)64 * INF_DIST_N;   // 32 x 64
+    unsigned short *lsorted_lds = dsorted_lds + 64 * 32;             // 288 x 64 when LDS_SORTED
+    unsigned short *ctab = lsorted_lds + (LDS_SORTED ? 64 * 288 : 0);   // len_base[29] len_extra[29] dist_base[30] dist_extra[30] (+ pad): 128 u16
+    if (lane < 29) { ctab[lane] = c_len_base[lane]; ctab[32 + lane] = c_len_extra[lane]; }
+    if (lane < 30) { ctab[64 + lane] = c_dist_base[lane]; ctab[96 + lane] = c_dist_extra[lane]; }
+    __syncthreads();
     const u32 b = blockIdx.x * 64u + (u32)lane;
-    if (b >= n_blocks) return;
+    if (b >= n_blocks) return;      // (after the wave-wide table fill above)
     const BgzfBlock B = blocks[b];
     uint8_t *sc = scratch + (size_t)b * INF_SCRATCH_BYTES;
-    unsigned short *lit_sorted = (unsigned short *)sc, *dist_sorted = lit_sorted + 288;
-    uint8_t *lens = (uint8_t *)(dist_sorted + 32);
+    uint8_t *lens = sc + 640;
+    HD.sorted = dsorted_lds + lane; HD.sstride = 64;
+    if (LDS_SORTED) { HL.sorted = lsorted_lds + lane; HL.sstride = 64; }
+    else { HL.sorted = (unsigned short *)sc; HL.sstride = 1; }
     uint8_t *dst = out + B.out_off;
     u64 *my_tok = tok + (size_t)b * INF_TOK_CAP;
     u32 pos = 0, err = INF_OK, nt = 0;
+    // Literals are gathered eight at a time and leave as one 8-byte store: a byte store per symbol from 64 lanes is 64 separate
+    // L2 transactions, and every wait for an input word also waits for the stores in front of it.
+    u64 obuf = 0; u32 on = 0;
+    auto flush_out = [&]() {       // the pending literals are the `on` bytes that end at dst + pos
+        if (on) {
+            uint8_t *d = dst + pos - on;
+            // one 8-byte store: the zero bytes behind the literals land on positions this lane (later literals) or k_lz_resolve
+            // (the match that follows) writes afterwards; byte stores only where the 8 bytes would leave the block
+            if (ablate & 1u) {}
+            else if (pos - on + 8u <= B.isize) __builtin_memcpy(d, &obuf, 8);
+            else for (u32 k = 0; k < on; k++) d[k] = (uint8_t)(obuf >> (8u * k));
+            obuf = 0; on = 0;
+        }
+    };
     if (B.isize != 0u) {
         BitReader br;
         br.init(comp, B.in_off, B.in_len);
@@ -187,6 +251,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
                 br.refill();
                 const u32 nlen = br.take(16);
                 if ((len ^ nlen) != 0xffffu || pos + len > B.isize) { err = INF_ERR_FORMAT; break; }
+                flush_out();
                 for (u32 k = 0; k < len; k++) { br.refill(); dst[pos++] = (uint8_t)br.take(8); }
                 continue;
             }
@@ -248,34 +313,43 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
                 for (u32 s = hdist; s-- > 0;) lens[288 + s] = lens[hlit + s];   // backwards: the two ranges overlap
                 for (u32 s = hlit; s < 288; s++) lens[s] = 0;
             }
-            if (!build_table(lens, hlit, INF_LIT_BITS, lane, lit_sorted, HL)) { err = INF_ERR_FORMAT; break; }
-            if (!build_table(lens + 288, hdist, INF_DIST_BITS, lane, dist_sorted, HD)) { err = INF_ERR_FORMAT; break; }
+            if (!build_table(lens, hlit, INF_LIT_BITS, lane, HL)) { err = INF_ERR_FORMAT; break; }
+            if (!build_table(lens + 288, hdist, INF_DIST_BITS, lane, HD)) { err = INF_ERR_FORMAT; break; }
             // ---- symbols of this block
             for (;;) {
                 br.refill();
-                const int sym = decode_sym(br, HL, lane, INF_LIT_BITS);
+                const int sym = decode_sym<INF_LIT_BITS>(br, HL, lane);
                 if (sym < 256) {
                     if (sym < 0) { err = INF_ERR_FORMAT; break; }
                     if (pos >= B.isize) { err = INF_ERR_SIZE; break; }
-                    dst[pos++] = (uint8_t)sym;
+                    obuf |= (u64)(u32)sym << (8u * on);
+                    on++; pos++;
+                    if (on == 8u) { if (!(ablate & 1u)) __builtin_memcpy(dst + pos - 8u, &obuf, 8); obuf = 0; on = 0; }
                     continue;
                 }
+                flush_out();
                 if (sym == 256) break;
                 const u32 li = (u32)sym - 257u;
                 if (li >= 29u) { err = INF_ERR_FORMAT; break; }
-                const u32 len = c_len_base[li] + br.take(c_len_extra[li]);
+                // RFC 1951 3.2.5: codes 257-264 are lengths 3-10; then groups of four share e extra bits; 285 = 258
+                const u32 le = li < 8u ? 0u : (li == 28u ? 0u : (li - 4u) >> 2);
+                const u32 lb = li < 8u ? 3u + li : (li == 28u ? 258u : 3u + ((4u + (li & 3u)) << le));
+                const u32 len = lb + br.take(le);
                 br.refill();
-                const int ds = decode_sym(br, HD, lane, INF_DIST_BITS);
+                const int ds = decode_sym<INF_DIST_BITS>(br, HD, lane);
                 if (ds < 0 || ds >= 30) { err = INF_ERR_FORMAT; break; }
-                const u32 de = c_dist_extra[ds];
+                const u32 dsu = (u32)ds;
+                const u32 de = dsu < 4u ? 0u : (dsu - 2u) >> 1;            // distance codes come in pairs sharing e extra bits
                 br.refill();
-                const u32 dist = c_dist_base[ds] + (de ? br.take(de) : 0u);
+                const u32 dist = (dsu < 4u ? 1u + dsu : 1u + ((2u + (dsu & 1u)) << de)) + (de ? br.take(de) : 0u);
                 if (dist > pos || pos + len > B.isize || nt >= INF_TOK_CAP) { err = INF_ERR_FORMAT; break; }
-                my_tok[nt++] = (u64)pos | ((u64)len << 16) | ((u64)dist << 32);
+                if (!(ablate & 2u)) my_tok[nt] = (u64)pos | ((u64)len << 16) | ((u64)dist << 32);
+                nt++;
                 pos += len;
             }
             if (br.consumed > total_bits) err = INF_ERR_FORMAT;
         }
+        flush_out();
         if (err == INF_OK && pos != B.isize) err = INF_ERR_SIZE;
     }
     n_tok[b] = err == INF_OK ? nt : 0u;
@@ -283,9 +357,12 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     if (err != INF_OK) atomicAdd(n_failed, 1u);
 }
 
-// One wave per BGZF block: executes the block's match tokens in order.  64 lanes copy one match (source index wraps inside the
-// match distance, so overlapping matches replicate their pattern as DEFLATE defines).  A token may read bytes a previous token
-// wrote: the stores are drained (s_waitcnt vmcnt(0)) before the next token's loads, which bypass the CU's L1.
+// One wave per BGZF block executes the block's match tokens.  64 tokens are taken at a time, one per lane; a token may only
+// run once every byte it reads is final: everything below the output position of the lowest unfinished token is (literals were
+// written by k_inflate, earlier matches are done), so in each round the lanes whose source range ends at or below that
+// position copy their matches concurrently (byte loops, four loads in flight), the stores are drained, and the frontier moves
+// on.  Matches mostly reach a record or more back while a window of 64 tokens spans a few records, so a window takes a few
+// rounds instead of 64 dependent load-store round trips.
 __global__ __launch_bounds__(256) void k_lz_resolve(const BgzfBlock *__restrict__ blocks, u32 n_blocks, uint8_t *__restrict__ out,
                                                     const u64 *__restrict__ tok, const u32 *__restrict__ n_tok) {
     const int lane = threadIdx.x & 63;
@@ -295,18 +372,47 @@ __global__ __launch_bounds__(256) void k_lz_resolve(const BgzfBlock *__restrict_
     if (nt == 0u) return;
     uint8_t *dst = out + blocks[b].out_off;
     const u64 *my = tok + (size_t)b * INF_TOK_CAP;
-    u64 t_next = my[0];
-    for (u32 t = 0; t < nt; t++) {
-        const u64 tk = t_next;
-        if (t + 1 < nt) t_next = my[t + 1];
-        const u32 pos = (u32)(tk & 0xffffu), len = (u32)(tk >> 16) & 0xffffu, dist = (u32)(tk >> 32);
-        const uint8_t *src = dst + pos - dist;
-        for (u32 k = (u32)lane; k < len; k += 64u) {
-            const u32 sk = dist >= len ? k : k % dist;
-            const uint8_t v = __hip_atomic_load(src + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            dst[pos + k] = v;
+    for (u32 t0 = 0; t0 < nt; t0 += 64u) {
+        const u32 t = t0 + (u32)lane;
+        const bool have = t < nt;
+        const u64 tk = have ? my[t] : 0ull;
+        const u32 pos = have ? (u32)(tk & 0xffffu) : 0xffffffffu, len = (u32)(tk >> 16) & 0xffffu, dist = (u32)(tk >> 32);
+        const u32 src_lo = pos - dist, src_end = pos - dist + min(len, dist), dst_end = pos + len;
+        // Output ranges of the window's tokens are disjoint and increasing with the lane, so the tokens whose output overlaps
+        // this lane's source range form a contiguous lane interval [dep_lo, dep_hi): dep_hi = lanes with pos < src_end,
+        // dep_lo = lanes with dst_end <= src_lo.  Two binary searches over the lanes (6 shuffles each), once per window.
+        u32 dep_hi = 0, dep_lo = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            const u32 p_hi = (u32)__shfl((int)pos, (int)(dep_hi + step - 1)), e_lo = (u32)__shfl((int)dst_end, (int)(dep_lo + step - 1));
+            const bool v_hi = dep_hi + step <= 64u, v_lo = dep_lo + step <= 64u;
+            if (v_hi && p_hi < src_end) dep_hi += step;
+            const bool lo_have = (u32)__shfl((int)(have ? 1 : 0), (int)(dep_lo + step - 1)) != 0u;
+            if (v_lo && lo_have && e_lo <= src_lo) dep_lo += step;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dep_hi = min(dep_hi, (u32)lane);            // only earlier tokens matter
+        const u64 dep_mask = dep_hi > dep_lo ? ((dep_hi - dep_lo >= 64u ? ~0ull : ((1ull << (dep_hi - dep_lo)) - 1ull)) << dep_lo) : 0ull;
+        u64 todo = __ballot(have);
+        while (todo) {
+            const bool go = have && ((todo >> lane) & 1ull) && (todo & dep_mask) == 0ull;
+            if (go) {
+                const uint8_t *src = dst + src_lo;
+                uint8_t *d = dst + pos;
+                if (dist >= len) {
+                    u32 k = 0;
+                    for (; k + 4u <= len; k += 4u) {
+                        const uint8_t a0 = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a1 = __hip_atomic_load(src + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                      a2 = __hip_atomic_load(src + k + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a3 = __hip_atomic_load(src + k + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        d[k] = a0; d[k + 1] = a1; d[k + 2] = a2; d[k + 3] = a3;
+                    }
+                    for (; k < len; k++) d[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {        // overlapping match: the first `dist` bytes are final, the rest repeats them
+                    for (u32 k = 0; k < len; k++) d[k] = __hip_atomic_load(src + (k % dist), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            todo &= ~__ballot(go);
+        }
     }
 }
 

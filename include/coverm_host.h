@@ -249,6 +249,22 @@ int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh
  * and --no-stream).  Writes the table to --output-file or stdout; returns the process exit code (1 after printing an error). */
 int covh_cli_main(int argc, char **argv);
 
+/* ---- trait MosdepthGenomeCoverageEstimator (estimators.rs:245-265), one export per method, for hosts that keep the reference's
+ * scan-loop shape (a Rust `impl MosdepthGenomeCoverageEstimator` forwards 1:1).  add_contig takes the contig's
+ * integer statistics from cov_finish where the reference passes the delta array. */
+typedef struct covh_estimator_state covh_estimator_state;
+covh_estimator_state *covh_estimator_new(const covh_estimator *params);                 /* CoverageEstimator::new_estimator_* */
+void covh_estimator_free(covh_estimator_state *s);
+void covh_estimator_setup(covh_estimator_state *s);                                     /* fn setup(&mut self) */
+void covh_estimator_add_contig_stats(covh_estimator_state *s, const cov_contig_stats *stats, uint64_t target_len,
+                                     const uint64_t *hist /* cov_fetch_hist array or NULL */, uint64_t num_mapped_reads,
+                                     double sum_identity);                              /* fn add_contig(&mut self, ...) */
+float covh_estimator_calculate_coverage(covh_estimator_state *s, const uint64_t *unobserved_contig_lengths, size_t n);
+void covh_estimator_print_coverage(const covh_estimator_state *s, float coverage, covh_taker *t);
+void covh_estimator_print_zero_coverage(const covh_estimator_state *s, covh_taker *t, uint64_t entry_length);
+covh_estimator_state *covh_estimator_copy(const covh_estimator_state *s);               /* fn copy(&self) */
+uint64_t covh_estimator_num_mapped_reads(const covh_estimator_state *s);
+
 /* calculate_coverage for one entry built from explicit sums (used by unit tests). */
 typedef struct {
     uint64_t win_len, win_sum_d, win_sum_d2, win_covered, full_len, full_covered, n_reads, mismatches;

@@ -922,6 +922,18 @@ float orc_estimate_one(const orc_est_param *p, const int32_t *ud, u64 len, u64 n
     return c;
 }
 
+/* As orc_estimate_one, but through print_coverage (estimators.rs:936-969), so that PileupCounts emits its (depth, bases)
+ * entries: what genes.rs:536-549 does for every gene.  Returns the coverage; `out` receives the emits. */
+float orc_estimate_emit(const orc_est_param *p, const int32_t *ud, u64 len, u64 n_reads, u64 mismatches,
+                        double sum_identity, const u64 *unobs, u64 n_unobs, orc_out *out) {
+    orc_est *e = est_new(p, 1);
+    est_add_contig(e, ud, (size_t)len, n_reads, mismatches, sum_identity);
+    float c = est_calculate(e, unobs, (size_t)n_unobs);
+    est_print_coverage(e, c, out);
+    est_free(e, 1);
+    return c;
+}
+
 /* ------------------------------------------------------------------ integer sufficient statistics
  * What the device must return per contig (covermhip.h cov_contig_stats), computed the reference's way:
  * one delta array per contig built by the CIGAR walk (contig.rs:144-202), then a sequential prefix sum

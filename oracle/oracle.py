@@ -771,6 +771,19 @@ def estimate_one(p: EstParam, ud: np.ndarray, n_reads=0, mismatches=0, sum_ident
                                         un.ctypes.data_as(C.c_void_p), C.c_uint64(len(un))))
 
 
+def estimate_emit(p: EstParam, ud: np.ndarray, n_reads=0, mismatches=0, sum_identity=0.0, unobserved=(0,)):
+    """add_contig + calculate_coverage + print_coverage on one delta array: (coverage, emitted taker calls)."""
+    ud = np.ascontiguousarray(ud, np.int32)
+    un = np.asarray(unobserved, dtype=np.uint64)
+    out = _Out()
+    L = lib()
+    L.orc_estimate_emit.restype = C.c_float
+    c = float(L.orc_estimate_emit(C.byref(p), ud.ctypes.data_as(C.c_void_p), C.c_uint64(len(ud)), C.c_uint64(n_reads),
+                                  C.c_uint64(mismatches), C.c_double(sum_identity), un.ctypes.data_as(C.c_void_p),
+                                  C.c_uint64(len(un)), C.byref(out)))
+    return c, _collect(out)
+
+
 # ------------------------------------------------------------------ per-gene coverage (src/genes.rs)
 import re as _re
 
@@ -858,9 +871,6 @@ def gene_coverage(bams: Sequence[BamData], stoit_names: Sequence[str], taker, es
     """gene_coverage, genes.rs:182-344 (+ emit_genes_for_contig :462-552).  Depth deltas of a contig come from the C
     restatement of the contig scan (same CIGAR walk, :258-290); per-gene estimator values from orc_estimate_one fed with
     the gene's delta array exactly as :508-535 builds it."""
-    for e in estimators:
-        if e.kind == 2:
-            raise NotImplementedError("coverage_histogram with --gff is not restated")
     out_rm = []
     for b, name in zip(bams, stoit_names):
         order, prim = reader_stage(b, filter_params)
@@ -895,11 +905,15 @@ def gene_coverage(bams: Sequence[BamData], stoit_names: Sequence[str], taker, es
                 gud[1:] = ud[s + 1:e]
                 lo = int(np.searchsorted(st, s, side="left")); hi = int(np.searchsorted(st, e, side="left"))
                 n_reads = int(pp[hi] - pp[lo]); mm = int(pm[hi] - pm[lo]); sid = float(pi[hi] - pi[lo])
-                covs = [estimate_one(p, gud, n_reads, mm, sid) for p in estimators]
-                if print_zero_coverage_genes or any(c > 0.0 for c in covs):
+                res = [estimate_emit(p, gud, n_reads, mm, sid) for p in estimators]     # (coverage, emits): genes.rs:536-549
+                if print_zero_coverage_genes or any(c > 0.0 for c, _ in res):
                     taker.start_entry(eid, gname)
-                    for c in covs:
-                        taker.add_single_coverage(c)
+                    for c, ems in res:
+                        for typ, a, bb, cv, _t in ems:
+                            if typ == 1:
+                                taker.add_single_coverage(f32(cv))
+                            elif typ == 2:
+                                taker.add_coverage_entry(int(a), int(bb))
                     taker.finish_entry()
 
         last_tid = -2

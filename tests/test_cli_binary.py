@@ -176,7 +176,7 @@ def test_cli_binary_streamed_equals_whole_file_and_oracle(tmp_path):
     p = str(tmp_path / "s.bam")
     cbam.write_bam(p, ref.names, ref.lengths, batch, with_seq=2)
     methods = ["mean", "trimmed_mean", "covered_fraction", "covered_bases", "variance", "length", "count", "reads_per_base", "rpkm", "tpm", "anir"]
-    env = dict(os.environ, COVERM_STREAM_WINDOW_KB="256", COVERM_CLI_TIMING="1")
+    env = dict(os.environ, COVERM_STREAM_WINDOW_KB="256", COVERM_CLI_TIMING="1", COVERM_NO_GPU_INGEST="1")
     a = subprocess.run([BIN, "contig", "-b", p, "-t", "6", "-m"] + methods, capture_output=True, text=True, timeout=300, env=env)
     b = subprocess.run([BIN, "contig", "-b", p, "-t", "6", "--no-stream", "-m"] + methods, capture_output=True, text=True, timeout=300)
     assert a.returncode == 0, a.stderr
@@ -184,6 +184,11 @@ def test_cli_binary_streamed_equals_whole_file_and_oracle(tmp_path):
     assert "streamed" in a.stderr and "whole file" not in a.stderr
     assert a.stdout == b.stdout
     assert a.stdout == O.run_cli("contig", [p], bams=[_bamdata(ref, batch)], methods=methods)
+    # default: device ingest (GPU inflate + parse), small staging pieces so that blocks straddle them
+    env2 = dict(os.environ, COVERM_INGEST_PIECE_KB="512", COVERM_CLI_TIMING="1")
+    c = subprocess.run([BIN, "contig", "-b", p, "-t", "6", "-m"] + methods, capture_output=True, text=True, timeout=300, env=env2)
+    assert c.returncode == 0, c.stderr
+    assert "device ingest" in c.stderr and c.stdout == a.stdout
     # single-read filter path, streamed
     a = subprocess.run([BIN, "contig", "-b", p, "-t", "6", "-m", "mean", "variance", "--min-read-percent-identity", "98", "--min-read-aligned-length", "100"],
                        capture_output=True, text=True, timeout=300, env=env)

@@ -171,7 +171,10 @@ def _synthetic_cases(tmp_path, depth_provider_of):
                dict(mode="genome", methods=["mean", "covered_fraction", "count"], separator="~", min_covered_fraction=0),
                dict(mode="genome", methods=["relative_abundance", "tpm"], single_genome=True, output_format="sparse"),
                dict(mode="contig", methods=["mean", "anir"], min_read_percent_identity=97, min_read_aligned_length=60,
-                    proper_pairs_only=True, output_format="sparse")):
+                    proper_pairs_only=True, output_format="sparse"),
+               # per-gene depth histograms (PileupCounts through genes.rs like any other estimator, coverm.rs:1358,1438-1446)
+               dict(mode="contig", methods=["coverage_histogram"]),
+               dict(mode="genome", methods=["coverage_histogram"], separator="~", contig_end_exclusion=10, min_covered_fraction=0)):
         kw = dict(kw)
         mode = kw.pop("mode")
         got = cli.run(mode, [af], gff=gff, depth_provider=prov, **kw)
