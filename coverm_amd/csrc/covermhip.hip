@@ -663,12 +663,23 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
 
     if (R) {
         time_begin(s, COV_K_PREP);
-        if (want_id)
-            hipLaunchKernelGGL((k_prep<true>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
-                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, idp, idn, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap);
-        else
-            hipLaunchKernelGGL((k_prep<false>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f,
-                               s->d_ctg.p, s->d_glob.p, s->d_runs.p, (double *)nullptr, (double *)nullptr, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap);
+#define COV_LAUNCH_PREP(ID, FI, MA)                                                                                                       \
+        hipLaunchKernelGGL((k_prep<ID, FI, MA>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f, s->d_ctg.p, s->d_glob.p, \
+                           s->d_runs.p, idp, idn, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap)
+        {
+            const int key = (want_id ? 4 : 0) | (s->cfg.filter_single ? 2 : 0) | (mask != nullptr ? 1 : 0);
+            switch (key) {
+            case 0: COV_LAUNCH_PREP(false, false, false); break;
+            case 1: COV_LAUNCH_PREP(false, false, true); break;
+            case 2: COV_LAUNCH_PREP(false, true, false); break;
+            case 3: COV_LAUNCH_PREP(false, true, true); break;
+            case 4: COV_LAUNCH_PREP(true, false, false); break;
+            case 5: COV_LAUNCH_PREP(true, false, true); break;
+            case 6: COV_LAUNCH_PREP(true, true, false); break;
+            default: COV_LAUNCH_PREP(true, true, true); break;
+            }
+        }
+#undef COV_LAUNCH_PREP
         if (nT) hipLaunchKernelGGL(k_prep_reduce, dim3(nT), dim3(64), 0, st, s->d_ctg.p, nT, s->d_part.p, prep_grid, prep_chunk);
         time_end(s, COV_K_PREP);
         HIPCHK(hipGetLastError());

@@ -346,7 +346,9 @@ __device__ __forceinline__ void prep_flush(DevContig *ctg, int cur, PrepAcc &a) 
     a.reset();
 }
 
-template <bool WANT_IDENTITY>
+// FILTER: the reader-stage single-read filter is on (filter.rs:88-116); MASKED: a target mask is set (genome.rs:170-171).
+// Both are compile-time so that the common `coverm contig` shape carries neither the loads (mapq, l_seq, mask) nor the code.
+template <bool WANT_IDENTITY, bool FILTER, bool MASKED>
 __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__ tlen, u32 n_targets,
                                               const uint8_t *__restrict__ mask, FilterCfg f, DevContig *ctg,
                                               DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ identp,
@@ -386,8 +388,8 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
         for (int k = 0; k < PREP_B; k++) {
             const u32 lc = min(l0 + (u32)k * 256u, lmax) & (u32)(PREP_CHUNK - 1);   // the mask is a no-op that bounds lc for the compiler
             const u32 ic = chunk + lc;
-            fl[k] = flag_c[lc]; td[k] = tid_c[lc]; ps_[k] = pos_c[lc]; mq[k] = mapq_c[lc]; nmk[k] = nmk_c[lc];
-            nmv32[k] = nm_c[lc]; lsq[k] = lseq_c[lc]; co0[k] = coff_c[lc]; co1[k] = coff_c[lc + 1u];
+            fl[k] = flag_c[lc]; td[k] = tid_c[lc]; ps_[k] = pos_c[lc]; mq[k] = FILTER ? mapq_c[lc] : 0u; nmk[k] = nmk_c[lc];
+            nmv32[k] = nm_c[lc]; lsq[k] = FILTER ? lseq_c[lc] : 0u; co0[k] = coff_c[lc]; co1[k] = coff_c[lc + 1u];
             const u32 lp = (lc + (ic > 0u ? 0u : 1u)) & (u32)(2 * PREP_CHUNK - 1), ln = (lc + (ic < nlast ? 1u : 0u)) & (u32)(2 * PREP_CHUNK - 1);
             ptid[k] = tid_m[lp]; ppos[k] = pos_m[lp]; ntid[k] = tid_c[ln];
         }
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
             const bool tok = td[k] >= 0 && (u32)td[k] < n_targets;
             Lc[k] = tok ? tlen[td[k]] : 0u;
             t0[k] = tok ? ti.tile_first[td[k]] : 0u;
-            mk[k] = (tok && mask != nullptr) ? mask[td[k]] : 1u;
+            mk[k] = (MASKED && tok) ? mask[td[k]] : 1u;
 #pragma unroll
             for (int c = 0; c < 3; c++) cw[k][c] = r.cigar_end ? r.cigar[min(co0[k] + (u32)c, cig_last)] : 0u;
         }
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
             // reader stage: ReferenceSortedBamFilter::read single-read branch, filter_out = true (filter.rs:88-116)
             bool survives = in;
             bool need_filter_eval = false;
-            if (f.filter_single) {
+            if (FILTER) {
                 survives = false;
                 const bool p1 = in && !unmapped && (f.include_supplementary || !supp) && (f.include_secondary || !sec);
                 if (p1 && !(f.min_mapq != 255u && (mq[k] < f.min_mapq || mq[k] == 255u))) need_filter_eval = true;  // :250-254
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
             u32 run_start = 0, run_len = 0, run2_start = 0, run2_len = 0, n_runs = 0, span = 0;
             bool oob = false, badcig = false;
             // with the reader-stage filter on, only records that reach single_read_passes_filter can survive
-            const bool do_walk = f.filter_single ? need_filter_eval : scan_gate;
+            const bool do_walk = FILTER ? need_filter_eval : scan_gate;
             const u32 nops_all = do_walk ? co1[k] - co0[k] : 0u;
             // Fast walk: branch-free, 32-bit, trip count uniform over the wave.  Valid while nothing can overflow
             // 32 bits: at most CIG_FAST_OPS ops of < 2^24 each (sum < 2^31); anything else (long reads, absurd
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                     }
                 }
             }
-            if (need_filter_eval) {  // single_read_passes_filter, filter.rs:256-278
+            if (FILTER && need_filter_eval) {  // single_read_passes_filter, filter.rs:256-278
                 if (nmk[k] != 1u) report_error(g, i, nmk[k] == 0u ? 2u : 3u);
                 else {
                     const u32 al = (u32)aligned;  // u32 accumulation in the reference

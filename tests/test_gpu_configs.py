@@ -115,3 +115,89 @@ def test_large_size_properties():
             parts.append(s.finish()[0])
     for f in ("n_pass", "win_sum_d", "win_sum_d2", "win_covered", "full_covered", "sum_nm"):
         np.testing.assert_array_equal(parts[0][f] + parts[1][f], st[f], err_msg=f)
+
+
+# ---------------------------------------------------------------------------------- parity at BASELINE sizes, oracle as checker
+def _oracle_arrays(ref, batch):
+    z = np.zeros(1, np.int32)
+    return BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq, batch.l_seq.astype(np.int32), batch.nm,
+                   batch.nm_kind, batch.cigar_off, batch.cigar, z, z, z, [], "")
+
+
+@pytest.fixture(scope="module")
+def big():
+    """20 M reads over 2 000 contigs / 200 genomes (0.4x of config 2's sample, same depth profile)."""
+    ref = synth.make_reference(2000, 400_000_000, seed=1)
+    batch = synth.make_reads(ref, 20_000_000, seed=2)
+    return ref, batch, _oracle_arrays(ref, batch)
+
+
+def test_config3_full_size_genome_definition_vs_oracle(big, tmp_path):
+    """`coverm genome --genome-definition … -m relative_abundance rpkm tpm` at 20 M reads: the whole product path (C ABI ->
+    kernels -> C++ genome scan -> printer) against the oracle's C scan (genome.rs:17-322) — text equality, dense and sparse."""
+    ref, batch, b = big
+    gd = tmp_path / "genomes.tsv"
+    keep = [n for i, n in enumerate(ref.names) if i % 11 != 3]          # some contigs in no genome (genome.rs:170-171)
+    gd.write_text("".join("%s\t%s\n" % (n.split("~")[0], n) for n in keep))
+    af = AlignmentFile("data/big.bam", ref.names, ref.lengths, batch)
+    for fmt in ("dense", "sparse"):
+        args = dict(methods=["relative_abundance", "rpkm", "tpm"], genome_definition=str(gd), output_format=fmt)
+        got = cli.run("genome", [af], **args)
+        assert got == O.run_cli("genome", ["data/big.bam"], bams=[b], **args)
+        assert got.count("\n") >= 200
+
+
+def test_config5_full_size_filters_all_methods_vs_oracle(big):
+    """Config 5's flags (--min-read-percent-identity 95 --min-read-aligned-length 50 --proper-pairs-only) and every method at
+    20 M reads: per-contig integer statistics, histograms and f64 identity sums bit-exact against the oracle, then the text."""
+    ref, batch, b = big
+    ff = O.FlagFilter(False, True, False)
+    fp = O.FilterParameters(ff, 50, float(np.float32(0.95)), 0.0, 255, 0, 0.0, 0.0)
+    exp, exp_hist, prim = O.integer_stats(b, ff, fp, 75)
+    filt = FilterConfig(False, True, False, filter_single=True, min_mapq=255, min_aligned_length=50,
+                        min_percent_identity=float(np.float32(0.95)), min_aligned_percent=0.0)
+    with Session(0, filt, 75, want_hist=True, want_identity=True) as s:
+        s.set_targets(ref.lengths)
+        for lo in range(0, batch.n_records, 6_000_000):              # several pushes, as a streamed ingest delivers them
+            s.push(batch.slice(lo, min(batch.n_records, lo + 6_000_000)))
+        st, summ = s.finish()
+        hist = s.hist()
+    assert summ.num_detected_primary_alignments == prim
+    for f in ("n_primary", "n_pass", "n_nonsupp", "sum_nm", "sum_indel", "win_sum_d", "win_sum_d2", "win_covered", "full_covered",
+              "win_min_d", "win_max_d", "hist_len"):
+        np.testing.assert_array_equal(st[f], exp[f], err_msg=f)
+    np.testing.assert_array_equal(st["sum_identity_primary"].view(np.uint64), exp["id_primary"].view(np.uint64))
+    np.testing.assert_array_equal(hist, exp_hist)
+    af = AlignmentFile("data/big.bam", ref.names, ref.lengths, batch)
+    args = dict(methods=ALL_CONTIG_METHODS, min_read_percent_identity=95, min_read_aligned_length=50, proper_pairs_only=True)
+    assert cli.run("contig", [af], **args) == O.run_cli("contig", ["data/big.bam"], bams=[b], **args)
+
+
+def test_unsorted_input_with_histograms_is_a_clean_error():
+    """Records of several contigs interleaved (a name-sorted BAM) with a histogram-based method: the histogram arena is sized by
+    R + n_targets bins, and every contig's bound must stay within its own considered-record count — the reference's panic
+    ('BAM file appears to be unsorted') must come back as COV_ERR_UNSORTED, not as a memory fault."""
+    from coverm_amd.native import CovError, ERR_UNSORTED
+    ref = synth.make_reference(300, 20_000_000, seed=5, min_len=1500, max_len=300_000)
+    batch = synth.make_reads(ref, 400_000, seed=6)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(batch.n_records)                      # destroy the order completely
+    nops = (batch.cigar_off[1:] - batch.cigar_off[:-1])[perm]
+    off = np.zeros(batch.n_records + 1, np.uint32)
+    np.cumsum(nops, out=off[1:])
+    src = np.repeat(batch.cigar_off[:-1][perm].astype(np.int64) - off[:-1], nops) + np.arange(int(off[-1]))
+    from coverm_amd.engine import RecordBatch
+    shuf = RecordBatch(batch.tid[perm], batch.pos[perm], batch.flag[perm], batch.mapq[perm], batch.nm[perm], batch.nm_kind[perm],
+                       batch.l_seq[perm], off, batch.cigar[src])
+    for want_hist in (True, False):
+        with Session(0, FilterConfig(), 75, want_hist=want_hist) as s:
+            s.set_targets(ref.lengths)
+            s.push(shuf)
+            with pytest.raises(CovError) as ei:
+                s.finish()
+            assert ei.value.status == ERR_UNSORTED
+            # the session is still usable
+            s.reset()
+            s.push(batch)
+            st, _ = s.finish()
+            assert int(st["n_pass"].sum()) > 0
