@@ -872,8 +872,10 @@ cov_status cov_gather(cov_session *const *sessions, uint32_t n, uint32_t root) {
         for (u32 i = 0; i < n; i++) {
             HIPCHK(hipSetDevice(devs[i]));
             HIPCHK(hipStreamSynchronize(sessions[i]->stream));
-            HIPCHK(hipMemcpyPeer(s->d_gather.p + (size_t)i * block, s->cfg.device, sessions[i]->d_res.p, devs[i], block));
         }
+        HIPCHK(hipSetDevice(s->cfg.device));
+        for (u32 i = 0; i < n; i++)    // on the root's stream: ordered before the copy to the host below (a device-to-device hipMemcpyPeer may return early)
+            HIPCHK(hipMemcpyPeerAsync(s->d_gather.p + (size_t)i * block, s->cfg.device, sessions[i]->d_res.p, devs[i], block, s->stream));
     }
     HIPCHK(hipSetDevice(s->cfg.device));
     HIPCHK(hipMemcpyAsync(s->h_gather, s->d_gather.p, (size_t)n * block, hipMemcpyDeviceToHost, s->stream));

@@ -8,8 +8,9 @@ Two ways the path shards, neither needs a data-path collective:
   per-contig statistics of different ranks are disjoint rows, merged on rank 0 after the same single gather,
   and `num_detected_primary_alignments` is the sum of the shards' counts.
 
-The gathered payload is the raw `cov_contig_stats` array (128 B per contig) plus the compact histograms, moved as
-byte tensors so that integers stay exact.
+The gathered payload is ONE packed byte buffer per rank (a 288-byte header + the raw `cov_contig_stats` array, 128 B per
+contig): its size is the same on every rank, so a single `gather` moves it with no size exchange.  Compact histograms, when a
+method needs them, follow point to point (their sizes are in the gathered headers).  Bytes, so that integers stay exact.
 """
 from typing import List, Optional, Tuple
 
@@ -56,55 +57,78 @@ def shard_records(batch: RecordBatch, lo_tid: int, hi_tid: int, include_unplaced
     return batch.slice(lo, hi)
 
 
-def _gather_bytes(payload: np.ndarray, dist, device, dst=0) -> Optional[List[np.ndarray]]:
-    """Variable-length byte gather: sizes first (all_gather of one int64), then one padded gather."""
-    world = dist.get_world_size()
-    rank = dist.get_rank()
-    raw = np.ascontiguousarray(payload).view(np.uint8).reshape(-1)
-    size = torch.tensor([raw.size], dtype=torch.int64, device=device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, size)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(max(sizes), 1)
-    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
-    if raw.size:
-        buf[:raw.size] = torch.from_numpy(raw.copy()).to(device)
-    out = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, out, dst=dst)
+_NAME_BYTES = 256
+_HEADER_BYTES = _NAME_BYTES + 8 + 16 + 8     # stoit name | num_detected_primary_alignments | tid range lo, hi | histogram bins
+
+
+def _pack(local: SampleResult, tid_range: Tuple[int, int]) -> np.ndarray:
+    """The fixed-size part of one rank's result: header + the raw cov_contig_stats rows (128 B per contig).  Its size depends
+    only on the number of targets, which every rank knows, so ONE gather moves it without any size exchange."""
+    name = local.stoit_name.encode()[:_NAME_BYTES]
+    head = np.zeros(_HEADER_BYTES, np.uint8)
+    head[:len(name)] = np.frombuffer(name, np.uint8)
+    head[_NAME_BYTES:_NAME_BYTES + 8] = np.asarray([local.num_detected_primary_alignments], np.uint64).view(np.uint8)
+    head[_NAME_BYTES + 8:_NAME_BYTES + 24] = np.asarray(tid_range, np.int64).view(np.uint8)
+    head[_NAME_BYTES + 24:] = np.asarray([0 if local.hist is None else len(local.hist)], np.uint64).view(np.uint8)
+    return np.concatenate([head, np.ascontiguousarray(local.stats).view(np.uint8).reshape(-1)])
+
+
+def _unpack(raw: np.ndarray):
+    name = bytes(raw[:_NAME_BYTES]).rstrip(b"\0").decode()
+    prim = int(raw[_NAME_BYTES:_NAME_BYTES + 8].view(np.uint64)[0])
+    lo, hi = (int(x) for x in raw[_NAME_BYTES + 8:_NAME_BYTES + 24].view(np.int64))
+    n_hist = int(raw[_NAME_BYTES + 24:_HEADER_BYTES].view(np.uint64)[0])
+    stats = raw[_HEADER_BYTES:].view(native.CONTIG_STATS_DTYPE).copy()
+    return name, prim, (lo, hi), n_hist, stats
+
+
+def gather_packed(local: SampleResult, tid_range: Tuple[int, int], dist, device="cpu", dst=0):
+    """ONE gather of every rank's packed (header + per-contig statistics) buffer to rank `dst`.  Histograms (only present for
+    trimmed_mean / coverage_histogram) have a data-dependent size: rank `dst` learns every size from the gathered headers and
+    the other ranks send theirs point to point — no collective, no size exchange.
+    Returns, on `dst`, a list of (SampleResult, (lo, hi)) in rank order; None elsewhere."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    packed = torch.from_numpy(_pack(local, tid_range)).to(device)
+    out = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+    dist.gather(packed, out, dst=dst)
+    has_hist = local.hist is not None
     if rank != dst:
+        if has_hist and len(local.hist):
+            dist.send(torch.from_numpy(np.ascontiguousarray(local.hist).view(np.uint8).copy()).to(device), dst=dst)
         return None
-    return [o[:sizes[r]].cpu().numpy() for r, o in enumerate(out)]
+    res = []
+    for r, o in enumerate(out):
+        name, prim, rng, n_hist, stats = _unpack(o.cpu().numpy())
+        hist = None
+        if has_hist:
+            if r == dst:
+                hist = np.ascontiguousarray(local.hist, np.uint64).copy()
+            elif n_hist:
+                t = torch.empty(n_hist * 8, dtype=torch.uint8, device=device)
+                dist.recv(t, src=r)
+                hist = t.cpu().numpy().view(np.uint64).copy()
+            else:
+                hist = np.zeros(0, np.uint64)
+        res.append((SampleResult(name, stats, hist, prim), rng))
+    return res
 
 
 def gather_samples(local: SampleResult, dist, device="cpu", dst=0) -> Optional[List[SampleResult]]:
     """By-sample sharding: every rank contributes one whole SampleResult; rank `dst` gets them in rank order."""
-    stats = _gather_bytes(local.stats, dist, device, dst)
-    hist = _gather_bytes(local.hist if local.hist is not None else np.zeros(0, np.uint64), dist, device, dst)
-    meta = np.frombuffer(local.stoit_name.encode(), dtype=np.uint8)
-    names = _gather_bytes(meta, dist, device, dst)
-    prim = _gather_bytes(np.asarray([local.num_detected_primary_alignments], dtype=np.uint64), dist, device, dst)
-    if stats is None:
-        return None
-    res = []
-    for r in range(len(stats)):
-        st = stats[r].view(native.CONTIG_STATS_DTYPE).copy()
-        h = hist[r].view(np.uint64).copy() if local.hist is not None else None
-        res.append(SampleResult(bytes(names[r]).decode(), st, h, int(prim[r].view(np.uint64)[0])))
-    return res
+    got = gather_packed(local, (0, len(local.stats)), dist, device, dst)
+    return None if got is None else [g[0] for g in got]
 
 
 def gather_tid_shards(local: SampleResult, tid_range: Tuple[int, int], dist, device="cpu", dst=0
                       ) -> Optional[SampleResult]:
     """By-tid-range sharding of ONE sample: rows [lo, hi) of each rank's statistics are authoritative; histogram
     slices are re-based into one concatenated array; primaries are summed."""
-    parts = gather_samples(local, dist, device, dst)
-    rng = _gather_bytes(np.asarray(tid_range, dtype=np.int64), dist, device, dst)
-    if parts is None:
+    got = gather_packed(local, tid_range, dist, device, dst)
+    if got is None:
         return None
-    merged = np.zeros_like(parts[0].stats)
+    merged = np.zeros_like(got[0][0].stats)
     hists, base, prim = [], 0, 0
-    for r, p in enumerate(parts):
-        lo, hi = (int(x) for x in rng[r].view(np.int64))
+    for p, (lo, hi) in got:
         rows = p.stats[lo:hi].copy()
         if p.hist is not None:
             rows["hist_off"] += base
@@ -113,4 +137,4 @@ def gather_tid_shards(local: SampleResult, tid_range: Tuple[int, int], dist, dev
         merged[lo:hi] = rows
         prim += p.num_detected_primary_alignments
     hist = np.concatenate(hists) if hists else None
-    return SampleResult(parts[0].stoit_name, merged, hist, prim)
+    return SampleResult(got[0][0].stoit_name, merged, hist, prim)

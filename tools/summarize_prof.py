@@ -35,5 +35,37 @@ for k, cs in summ.items():
             if pat in k:
                 traffic[key] = traffic.get(key, 0) + int(b)
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+# pipe utilisation of the two big kernels (bench.py reports these as the on-chip roofline of k_pileup_fast)
+pipes = {"_source": tag, "_units": "SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES count quad-cycles; SQ_BUSY_CU_CYCLES counts cycles per CU "
+         "(x4 SIMDs = SIMD-cycles); wave64 VALU ops issue in 2 cycles at full rate and 4 cycles for mad_u24 / SDWA / DPP / 3-operand "
+         "forms (tools/ubench/valu_rate.hip)"}
+for k, cs in summ.items():
+    key = "k_pileup" if "k_pileup_fast" in k else "k_prep" if "k_prep<" in k else None
+    if not key or "SQ_BUSY_CU_CYCLES" not in cs:
+        continue
+    g = lambda c: cs.get(c, {}).get("mean_per_dispatch")
+    simd_cycles = 4.0 * g("SQ_BUSY_CU_CYCLES")
+    p_ = {"kernel": k}
+    if g("SQ_ACTIVE_INST_VALU"):
+        p_["valu_busy_frac"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / simd_cycles          # issue slots (quad-cycles) the VALU was claimed
+    if g("SQ_INSTS_VALU"):
+        p_["valu_insts"] = g("SQ_INSTS_VALU")
+        p_["valu_frac_if_all_full_rate"] = 2.0 * g("SQ_INSTS_VALU") / simd_cycles
+        p_["valu_frac_if_all_half_rate"] = 4.0 * g("SQ_INSTS_VALU") / simd_cycles
+    if g("SQ_LDS_IDX_ACTIVE"):
+        p_["lds_busy_frac"] = g("SQ_LDS_IDX_ACTIVE") / g("SQ_BUSY_CU_CYCLES")
+        p_["lds_bank_conflict_frac_of_lds_cycles"] = (g("SQ_LDS_BANK_CONFLICT") or 0.0) / g("SQ_LDS_IDX_ACTIVE")
+    if g("SQ_ACTIVE_INST_SCA"):
+        p_["scalar_busy_frac"] = 4.0 * g("SQ_ACTIVE_INST_SCA") / simd_cycles
+    if g("SQ_WAVE_CYCLES"):
+        for c, n in (("SQ_WAIT_ANY", "wave_time_waiting_on_waitcnt"), ("SQ_WAIT_INST_ANY", "wave_time_issue_stalled"), ("SQ_ACTIVE_INST_ANY", "wave_time_issuing")):
+            if g(c) is not None:
+                p_[n] = g(c) / g("SQ_WAVE_CYCLES")
+        p_["waves_per_simd_avg"] = 4.0 * g("SQ_WAVE_CYCLES") / simd_cycles
+    for c in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_LDS_ATOMIC"):
+        if g(c) is not None:
+            p_[c.lower()] = g(c)
+    pipes[key] = p_
+json.dump(pipes, open(os.path.join(dst, "pmc_pipes.json"), "w"), indent=1)
 print(open(os.path.join(dst, tag + "_bench_kernel_stats.csv")).read()[:3000])
 print(json.dumps(traffic, indent=1))
