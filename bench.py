@@ -212,7 +212,7 @@ def end_to_end(a, threads):
         cmd = [BIN, "contig", "-b", path, "-m"] + ALL_METHODS + flags + ["-t", str(threads), "-o", out_tsv]
         best = None
         env = dict(os.environ, COVERM_CLI_TIMING="1")
-        for rep in range(2):        # first run pays the page cache fill of a file just written (it is warm: we wrote it) and HIP start-up
+        for rep in range(3):        # best of three: the lease boxes share their host CPUs with other tenants (load average ~20-30), wall times scatter
             t0 = time.perf_counter()
             p = subprocess.run(cmd, capture_output=True, text=True, env=env)
             dt = time.perf_counter() - t0

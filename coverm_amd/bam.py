@@ -191,13 +191,13 @@ def gpu_ingest(session, path: str, threads: int = None, check_crc: bool = True, 
         lens = np.asarray([L.covh_bam_header_target_len(hd, i) for i in range(nt)], dtype=np.int64)
         session.set_targets(lens, mask)
         n = C.c_uint64(0)
-        t = (C.c_double * 4)()
+        t = (C.c_double * 5)()
         rc = L.covh_bam_gpu_ingest(path.encode(), threads, session._h, hd, int(check_crc), C.byref(n), t, err, 512)
         if rc == 1:
             raise IngestFallback(err.value.decode())
         if rc != 0:
             raise IOError(err.value.decode())
-        return names, lens, int(n.value), dict(read=t[0], slot_wait=t[1], end=t[2], total=t[3])
+        return names, lens, int(n.value), dict(read=t[0], slot_wait=t[1], end=t[2], total=t[3], begin=t[4])
     finally:
         L.covh_bam_header_free(hd)
 

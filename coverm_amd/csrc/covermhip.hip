@@ -136,8 +136,11 @@ struct cov_session {
     DevBuf<covi::BgzfBlock> g_blocks;
     DevBuf<u32> g_status;
     DevBuf<covi::SegInfo> g_seg;
-    DevBuf<u64> g_recbase, g_cigbase, g_result, g_tok;   // g_result: [0] records [1] CIGAR words [2] status [3] inflate failures (u32) | extract failures (u32) [4..6] first bad segment
-    DevBuf<u32> g_ntok;
+    DevBuf<u64> g_recbase, g_cigbase, g_result, g_tok, g_tok2;   // g_result: [0] records [1] CIGAR words [2] status [3] inflate failures (u32) | extract failures (u32) [4..6] first bad segment
+    DevBuf<u32> g_ntok, g_ntok2;
+    hipStream_t ing_aux = nullptr;                         // k_lz_resolve / k_crc32 of batch i run beside k_inflate of batch i + 1
+    hipEvent_t ing_inf_done[2] = {nullptr, nullptr}, ing_lz_done[2] = {nullptr, nullptr};
+    uint32_t ing_batch = 0; int ing_check_crc = 1;
     uint64_t ing_launched = 0;   // blocks already handed to k_inflate (launches are batched so that each fills the GPU)
     covi::BgzfBlock *h_blocks = nullptr; size_t h_blocks_cap = 0;   // page-locked mirror of the block table (async uploads read from it)
     uint64_t ing_comp = 0, ing_infl = 0, ing_blocks = 0;
@@ -406,7 +409,9 @@ void cov_destroy(cov_session *s) {
     s->d_ctg_scratch.release(); s->d_depth_all.release(); s->d_depth_off.release(); s->d_iv.release(); s->d_ivst.release(); s->d_ivhist.release();
     s->d_cx_list.release(); s->d_cx_cnt.release(); s->d_cx_cur.release(); s->d_cx_scan.release(); s->d_cx_top.release(); s->d_cx_runs.release();
     s->g_comp.release(); s->g_infl.release(); s->g_scratch.release(); s->g_blocks.release(); s->g_status.release(); s->g_seg.release();
-    s->g_recbase.release(); s->g_cigbase.release(); s->g_result.release(); s->g_tok.release(); s->g_ntok.release();
+    s->g_recbase.release(); s->g_cigbase.release(); s->g_result.release(); s->g_tok.release(); s->g_ntok.release(); s->g_tok2.release(); s->g_ntok2.release();
+    if (s->ing_aux) { (void)hipStreamSynchronize(s->ing_aux); (void)hipStreamDestroy(s->ing_aux); }
+    for (int k = 0; k < 2; k++) { if (s->ing_inf_done[k]) (void)hipEventDestroy(s->ing_inf_done[k]); if (s->ing_lz_done[k]) (void)hipEventDestroy(s->ing_lz_done[k]); }
     if (s->h_blocks) (void)hipHostFree(s->h_blocks);
     s->h_blocks = nullptr;
     if (s->ing_copy) { (void)hipStreamSynchronize(s->ing_copy); (void)hipStreamDestroy(s->ing_copy); }
@@ -896,14 +901,17 @@ cov_status cov_gathered(cov_session *root, uint32_t rank, cov_contig_stats *stat
 static_assert(sizeof(cov_bgzf_block) == sizeof(covi::BgzfBlock) && offsetof(cov_bgzf_block, in_len) == offsetof(covi::BgzfBlock, in_len) &&
               offsetof(cov_bgzf_block, out_off) == offsetof(covi::BgzfBlock, out_off), "cov_bgzf_block mirrors the device struct");
 
-cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t inflated_bytes_hint) {
+cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t inflated_bytes_hint, int check_crc) {
     if (!s) return COV_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(s->cfg.device));
     if (!s->ing_copy) {
         HIPCHK(hipStreamCreateWithFlags(&s->ing_copy, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ev[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ing_fed, hipEventDisableTiming));
+        HIPCHK(hipStreamCreateWithFlags(&s->ing_aux, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_inf_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_lz_done[k], hipEventDisableTiming)); }
     }
+    s->ing_batch = 0; s->ing_check_crc = (check_crc && !getenv("COVERM_NO_CRC")) ? 1 : 0;
     HIPCHK(s->g_comp.reserve(compressed_bytes + 64, s->stream));
     HIPCHK(s->g_infl.reserve(std::max<uint64_t>(inflated_bytes_hint, 1u << 20) + 64, s->stream));
     HIPCHK(s->g_result.reserve(8, s->stream));
@@ -925,9 +933,19 @@ static cov_status launch_inflate(cov_session *s) {
     const u32 n = (u32)n64;
     HIPCHK(hipStreamWaitEvent(s->stream, s->ing_fed, 0));
     const u32 grid = (n + 63u) / 64u;
+    // token buffers alternate between batches: k_inflate of this batch may not start before k_lz_resolve of the batch that used the
+    // same buffer two launches ago has finished
+    const int bb = (int)(s->ing_batch & 1u);
+    DevBuf<u64> &tokb = bb ? s->g_tok2 : s->g_tok;
+    DevBuf<u32> &ntokb = bb ? s->g_ntok2 : s->g_ntok;
+    if (s->ing_batch >= 2) HIPCHK(hipStreamWaitEvent(s->stream, s->ing_lz_done[bb], 0));
+    if ((size_t)n * covi::INF_TOK_CAP > tokb.cap || n > ntokb.cap || (size_t)grid * 64u * covi::INF_SCRATCH_BYTES > s->g_scratch.cap) {
+        HIPCHK(hipStreamSynchronize(s->ing_aux));     // a buffer is about to be replaced: nothing may still be reading it
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
     HIPCHK(s->g_scratch.reserve((size_t)grid * 64u * covi::INF_SCRATCH_BYTES, s->stream));
-    HIPCHK(s->g_tok.reserve((size_t)n * covi::INF_TOK_CAP, s->stream));
-    HIPCHK(s->g_ntok.reserve(n, s->stream));
+    HIPCHK(tokb.reserve((size_t)n * covi::INF_TOK_CAP, s->stream));
+    HIPCHK(ntokb.reserve(n, s->stream));
     static int lit_bits = 0, lds_sorted = 0;
     if (!lit_bits) {
         const char *e = getenv("COVERM_INFLATE_BITS");
@@ -940,17 +958,24 @@ static cov_status launch_inflate(cov_session *s) {
     }
 #define COV_LAUNCH_INFLATE(LB, LS)                                                                                                              \
     hipLaunchKernelGGL((covi::k_inflate<LB, LS>), dim3(grid), dim3(64), covi::inflate_smem_bytes(LB, LS), s->stream, (const uint8_t *)s->g_comp.p, \
-                       (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, s->g_infl.p, s->g_scratch.p, s->g_tok.p, s->g_ntok.p,                   \
+                       (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, s->g_infl.p, s->g_scratch.p, tokb.p, ntokb.p,                             \
                        s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0))
     if (lds_sorted) { if (lit_bits == 7) COV_LAUNCH_INFLATE(7, true); else COV_LAUNCH_INFLATE(8, true); }
     else if (lit_bits == 7) COV_LAUNCH_INFLATE(7, false);
     else if (lit_bits == 9) COV_LAUNCH_INFLATE(9, false);
     else COV_LAUNCH_INFLATE(8, false);
 #undef COV_LAUNCH_INFLATE
-    hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->stream, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, s->g_infl.p,
-                       (const u64 *)s->g_tok.p, (const u32 *)s->g_ntok.p);
+    HIPCHK(hipEventRecord(s->ing_inf_done[bb], s->stream));
+    HIPCHK(hipStreamWaitEvent(s->ing_aux, s->ing_inf_done[bb], 0));
+    hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, s->g_infl.p,
+                       (const u64 *)tokb.p, (const u32 *)ntokb.p);
+    if (s->ing_check_crc)
+        hipLaunchKernelGGL(covi::k_crc32, dim3((n + 255u) / 256u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n,
+                           (const uint8_t *)s->g_infl.p, s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
+    HIPCHK(hipEventRecord(s->ing_lz_done[bb], s->ing_aux));
     HIPCHK(hipGetLastError());
     s->ing_launched = s->ing_blocks;
+    s->ing_batch++;
     return COV_OK;
 }
 
@@ -987,9 +1012,11 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
         infl_end = std::max<uint64_t>(infl_end, b.out_off + b.isize);
     }
     if (infl_end + 64 > s->g_infl.cap) {     // the hint was too small: grow, keeping what is inflated already
+        HIPCHK(hipStreamSynchronize(s->ing_aux));
         HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(s->g_infl.reserve(infl_end + infl_end / 2 + 64, s->stream, s->ing_infl));
     }
+    if (s->ing_blocks + n_blocks > s->g_blocks.cap || s->ing_blocks + n_blocks > s->g_status.cap) HIPCHK(hipStreamSynchronize(s->ing_aux));
     HIPCHK(s->g_blocks.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
     HIPCHK(s->g_status.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
     HIPCHK(hipMemcpyAsync(s->g_blocks.p + s->ing_blocks, s->h_blocks + s->ing_blocks, (size_t)n_blocks * sizeof(covi::BgzfBlock), hipMemcpyHostToDevice, s->ing_copy));
@@ -1006,7 +1033,7 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
     return COV_OK;
 }
 
-cov_status cov_ingest_end(cov_session *s, uint64_t first_record_offset, int check_crc, uint64_t *n_records_out) {
+cov_status cov_ingest_end(cov_session *s, uint64_t first_record_offset, uint64_t *n_records_out) {
     if (!s || !s->ing_active) return COV_ERR_INVALID_ARG;
     s->ing_active = false;
     HIPCHK(hipSetDevice(s->cfg.device));
@@ -1019,12 +1046,10 @@ cov_status cov_ingest_end(cov_session *s, uint64_t first_record_offset, int chec
         if (a) return a;
     }
     { const cov_status lrc = launch_inflate(s); if (lrc != COV_OK) return lrc; }
+    for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(s->stream, s->ing_lz_done[k], 0));    // both token buffers' resolves (and CRCs) are behind us
     hipEvent_t e0, e1, e2;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
     struct EvFree { hipEvent_t a, b, c; ~EvFree() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); } } evfree{e0, e1, e2};
-    if (check_crc && s->ing_blocks)
-        hipLaunchKernelGGL(covi::k_crc32, dim3((u32)((s->ing_blocks + 255) / 256)), dim3(256), 0, st, (const covi::BgzfBlock *)s->g_blocks.p, (u32)s->ing_blocks,
-                           (const uint8_t *)s->g_infl.p, s->g_status.p, reinterpret_cast<u32 *>(s->g_result.p + 3));
     HIPCHK(hipEventRecord(e0, st));
     const uint64_t N = s->ing_infl;
     uint64_t res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1111,7 +1136,7 @@ cov_status cov_ingest_release(cov_session *s) {
     HIPCHK(hipSetDevice(s->cfg.device));
     HIPCHK(hipStreamSynchronize(s->stream));
     s->g_comp.release(); s->g_infl.release(); s->g_scratch.release(); s->g_blocks.release(); s->g_status.release(); s->g_seg.release();
-    s->g_recbase.release(); s->g_cigbase.release(); s->g_tok.release(); s->g_ntok.release();
+    s->g_recbase.release(); s->g_cigbase.release(); s->g_tok.release(); s->g_ntok.release(); s->g_tok2.release(); s->g_ntok2.release();
     return COV_OK;
 }
 

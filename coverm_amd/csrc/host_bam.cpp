@@ -1212,7 +1212,7 @@ uint64_t covh_bam_header_target_len(const covh_bam_header *h, uint32_t i) { retu
 uint64_t covh_bam_header_first_record(const covh_bam_header *h) { return h->h.first_record; }
 
 // 0 = records are in the session's store; 1 = the file needs the CPU reader (reason in err; nothing appended); -1 = error.
-// timing (optional, 4 doubles): seconds reading the file, waiting for staging slots, in cov_ingest_end, total.
+// timing (optional, 5 doubles): seconds reading the file, waiting for staging slots, in cov_ingest_end, total, in cov_ingest_begin (allocation).
 int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint64_t *n_records,
                         double *timing, char *err, size_t errcap) {
     auto fail = [&](int rc, const std::string &e) { if (err && errcap) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; } return rc; };
@@ -1227,7 +1227,8 @@ int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const cov
     uint8_t *buf[2] = {(uint8_t *)cov_host_alloc(piece), (uint8_t *)cov_host_alloc(piece)};
     struct BufFree { uint8_t **b; ~BufFree() { for (int k = 0; k < 2; k++) if (b[k]) cov_host_free(b[k]); } } bf{buf};
     if (!buf[0] || !buf[1]) return fail(-1, "no page-locked staging memory (is a HIP device usable?)");
-    if (cov_ingest_begin(s, size, size * 4 + (1u << 20)) != COV_OK) return fail(-1, cov_last_error(s));
+    if (cov_ingest_begin(s, size, size * 4 + (1u << 20), check_crc) != COV_OK) return fail(-1, cov_last_error(s));
+    const double t_begin = now() - t_start;
     Pool pool(std::max(1, threads));
     std::vector<cov_bgzf_block> blocks;
     uint64_t next_blk = 0, out_off = 0, pending_bsize = 0;     // absolute file offset of the next block header; running inflated size; BSIZE of a block whose header is read but whose end is not here yet
@@ -1294,9 +1295,9 @@ int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const cov
     if (next_blk != size) return fail(1, "truncated BGZF block at the end of the file");
     double t0 = now();
     uint64_t nrec = 0;
-    const cov_status rc = cov_ingest_end(s, hd->h.first_record, check_crc, &nrec);
+    const cov_status rc = cov_ingest_end(s, hd->h.first_record, &nrec);
     const double t_end = now() - t0;
-    if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; }
+    if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; timing[4] = t_begin; }
     if (rc == COV_ERR_INGEST_FALLBACK) return fail(1, cov_last_error(s));
     if (rc != COV_OK) return fail(-1, cov_last_error(s));
     if (n_records) *n_records = nrec;

@@ -35,6 +35,8 @@
 
 namespace {
 
+std::atomic<bool> g_skip_teardown{false};   // covh_cli_set_fast_exit: a process about to exit need not hand ~100 GB of HBM back allocation by allocation
+
 struct Fatal : std::runtime_error { using std::runtime_error::runtime_error; };
 [[noreturn]] void die(const std::string &m) { throw Fatal(m); }
 
@@ -164,14 +166,14 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         check(s, cov_set_targets(s, (uint32_t)S.tlen.size(), S.tlen.data()));
         if (R.by_names) { genome_table(R, S, mask); check(s, cov_set_target_mask(s, mask.data())); }
         S.t_open = now() - t0;
-        uint64_t nrec = 0; double tm[4] = {0, 0, 0, 0};
+        uint64_t nrec = 0; double tm[5] = {0, 0, 0, 0, 0};
         const int rc = covh_bam_gpu_ingest(S.path.c_str(), threads, s, hd, getenv("COVERM_NO_CRC") ? 0 : 1, &nrec, tm, err, sizeof err);
         if (rc < 0) die(err);
         if (rc == 0) {
             S.n_records = nrec; S.device_ingest = true;
             if (getenv("COVERM_CLI_TIMING"))
-                fprintf(stderr, "[coverm-amd] %s: device ingest: file read %.3fs, staging waits %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records\n",
-                        S.stoit.c_str(), tm[0], tm[1], tm[2], tm[3], (unsigned long long)nrec);
+                fprintf(stderr, "[coverm-amd] %s: device ingest: buffers %.3fs, file read %.3fs, staging waits %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records\n",
+                        S.stoit.c_str(), tm[4], tm[0], tm[1], tm[2], tm[3], (unsigned long long)nrec);
             S.t_ingest = now() - t0;
             S.stats.resize(S.tlen.size());
             cov_summary summ;
@@ -462,7 +464,7 @@ int run_cli(int argc, char **argv) {
     }
     const size_t nd = a.devices.size(), nb = a.bams.size();
     std::vector<cov_session *> sess(nd, nullptr);
-    struct SessFree { std::vector<cov_session *> &v; ~SessFree() { for (auto *s : v) if (s) cov_destroy(s); } } sess_free{sess};
+    struct SessFree { std::vector<cov_session *> &v; ~SessFree() { if (!g_skip_teardown.load()) for (auto *s : v) if (s) cov_destroy(s); } } sess_free{sess};
     {
         std::vector<std::thread> th;
         std::vector<cov_status> rc(nd, COV_OK);
@@ -604,6 +606,8 @@ int run_cli(int argc, char **argv) {
 }
 
 }  // namespace
+
+extern "C" void covh_cli_set_fast_exit(int on) { g_skip_teardown.store(on != 0); }
 
 extern "C" int covh_cli_main(int argc, char **argv) {
     try {

@@ -194,7 +194,7 @@ const char *covh_bam_header_target_name(const covh_bam_header *h, uint32_t i);
 uint64_t covh_bam_header_target_len(const covh_bam_header *h, uint32_t i);
 uint64_t covh_bam_header_first_record(const covh_bam_header *h); /* offset in the inflated stream */
 int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint64_t *n_records,
-                        double *timing4, char *err, size_t errcap);
+                        double *timing5, char *err, size_t errcap);
 
 /* ---- reader-stage PAIR filter (ReferenceSortedBamFilter::read pair branch, filter.rs:117-228, filter_out = true).
  * The single-read branch runs on the device (cov_config.filter_single); the pair branch needs read names, which never
@@ -248,6 +248,9 @@ int covh_gene_coverage(const covh_header *h, const covh_genes *genes, const covh
  * coverm-amd binary takes it (argv[1] = "contig" | "genome", the reference's flag names, plus --device N / --devices a,b,...
  * and --no-stream).  Writes the table to --output-file or stdout; returns the process exit code (1 after printing an error). */
 int covh_cli_main(int argc, char **argv);
+/* For a process that exits right after covh_cli_main (the coverm-amd binary): leave the sessions to the OS instead of
+ * destroying them one allocation at a time. */
+void covh_cli_set_fast_exit(int on);
 
 /* ---- trait MosdepthGenomeCoverageEstimator (estimators.rs:245-265), one export per method, for hosts that keep the reference's
  * scan-loop shape (a Rust `impl MosdepthGenomeCoverageEstimator` forwards 1:1).  add_contig takes the contig's

@@ -197,11 +197,11 @@ cov_status cov_reserve(cov_session *s, uint64_t n_records, uint64_t n_cigar);
  * file into page-locked buffers, hops the 18-byte BGZF block headers and parses the BAM header (reference names / lengths,
  * offset of the first record in the inflated stream).
  *   cov_set_targets(s, ...)                         reference lengths: the record-boundary test uses them
- *   cov_ingest_begin(s, file_bytes, inflated_hint)
+ *   cov_ingest_begin(s, file_bytes, inflated_hint, check_crc)
  *   loop: cov_ingest_slot_wait(s, slot) -> fill the slot's buffer -> cov_ingest_feed(s, slot, buf, file_offset, n, blocks, n_blocks)
  *         (two slots alternate; `blocks` = the BGZF blocks COMPLETED by this piece: offsets are absolute in the file / the
  *          inflated stream; the copy is asynchronous, the inflate kernel of these blocks runs behind it)
- *   cov_ingest_end(s, first_record_offset, check_crc, &n_records)
+ *   cov_ingest_end(s, first_record_offset, &n_records)
  * Anything irregular (inflate or CRC failure, boundaries that do not verify, a CG:B,I long-CIGAR placeholder) makes
  * cov_ingest_end return COV_ERR_INGEST_FALLBACK with nothing appended: decode that file on the host and cov_push_batch it.
  */
@@ -210,11 +210,11 @@ typedef struct {
     uint64_t out_off; /* offset of its inflated bytes in the inflated stream (running sum of ISIZE) */
     uint32_t in_len, isize, crc, pad;
 } cov_bgzf_block;
-cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t inflated_bytes_hint);
+cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t inflated_bytes_hint, int check_crc);
 cov_status cov_ingest_slot_wait(cov_session *s, int slot);
 cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uint64_t file_offset, uint64_t n_bytes,
                            const cov_bgzf_block *blocks, uint32_t n_blocks);
-cov_status cov_ingest_end(cov_session *s, uint64_t first_record_offset, int check_crc, uint64_t *n_records);
+cov_status cov_ingest_end(cov_session *s, uint64_t first_record_offset, uint64_t *n_records);
 cov_status cov_ingest_release(cov_session *s); /* frees the compressed / inflated buffers (kept between files otherwise) */
 cov_status cov_ingest_copy_inflated(cov_session *s, uint64_t offset, uint64_t n, void *out); /* test hook */
 /* Test hook: the session's own record store copied back into caller-sized host arrays (host == NULL: only the counts). */
