@@ -132,7 +132,7 @@ def stream_batches(path: str, threads: int = None, span_index: int = 0, span_cou
                               _copy(cb.mapq, np.uint8, n), _copy(cb.nm, np.uint32, n), _copy(cb.nm_kind, np.uint8, n),
                               _copy(cb.l_seq, np.uint32, n), off, _copy(cb.cigar, np.uint32, nc))
         if stats is not None:
-            t = (C.c_double * 5)()
+            t = (C.c_double * 8)()
             L.covh_bam_stream_timing(h, t)
             stats.update(peak_bytes=int(L.covh_bam_stream_peak_bytes(h)), n_records=int(L.covh_bam_stream_n_records(h)),
                          timing=dict(read=t[0], inflate=t[1], parse=t[2], wait_inflate=t[3], wait_parse=t[4]))
@@ -191,13 +191,13 @@ def gpu_ingest(session, path: str, threads: int = None, check_crc: bool = True, 
         lens = np.asarray([L.covh_bam_header_target_len(hd, i) for i in range(nt)], dtype=np.int64)
         session.set_targets(lens, mask)
         n = C.c_uint64(0)
-        t = (C.c_double * 5)()
+        t = (C.c_double * 8)()
         rc = L.covh_bam_gpu_ingest(path.encode(), threads, session._h, hd, int(check_crc), C.byref(n), t, err, 512)
         if rc == 1:
             raise IngestFallback(err.value.decode())
         if rc != 0:
             raise IOError(err.value.decode())
-        return names, lens, int(n.value), dict(read=t[0], slot_wait=t[1], end=t[2], total=t[3], begin=t[4])
+        return names, lens, int(n.value), dict(read=t[0], slot_wait=t[1], end=t[2], total=t[3], begin=t[4], walk=t[5], feed=t[6])
     finally:
         L.covh_bam_header_free(hd)
 

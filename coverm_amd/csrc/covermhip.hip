@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstddef>
+#include <chrono>
 #include <cstdio>
 #include <dlfcn.h>
 #include <cstdlib>
@@ -146,8 +147,9 @@ struct cov_session {
     uint64_t ing_comp = 0, ing_infl = 0, ing_blocks = 0;
     bool ing_active = false;
     hipStream_t ing_copy = nullptr;
-    hipEvent_t ing_ev[2] = {nullptr, nullptr}, ing_fed = nullptr;
+    hipEvent_t ing_ev[COV_INGEST_SLOTS] = {}, ing_fed = nullptr;
     double ing_ms_inflate = 0, ing_ms_parse = 0;
+    double ing_s_alloc = 0, ing_s_endwait = 0;     // host seconds inside device allocations of the ingest / waiting for the device at its end
 
     // results of the last finish
     bool finished = false;
@@ -415,7 +417,7 @@ void cov_destroy(cov_session *s) {
     if (s->h_blocks) (void)hipHostFree(s->h_blocks);
     s->h_blocks = nullptr;
     if (s->ing_copy) { (void)hipStreamSynchronize(s->ing_copy); (void)hipStreamDestroy(s->ing_copy); }
-    for (int k = 0; k < 2; k++) if (s->ing_ev[k]) (void)hipEventDestroy(s->ing_ev[k]);
+    for (int k = 0; k < COV_INGEST_SLOTS; k++) if (s->ing_ev[k]) (void)hipEventDestroy(s->ing_ev[k]);
     if (s->ing_fed) (void)hipEventDestroy(s->ing_fed);
     s->d_res.release(); s->d_ctg.p = nullptr; s->d_glob.p = nullptr; s->d_desc.release(); s->d_gather.release();
     if (s->h_gather) (void)hipHostFree(s->h_gather);
@@ -906,7 +908,7 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     HIPCHK(hipSetDevice(s->cfg.device));
     if (!s->ing_copy) {
         HIPCHK(hipStreamCreateWithFlags(&s->ing_copy, hipStreamNonBlocking));
-        for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ev[k], hipEventDisableTiming));
+        for (int k = 0; k < COV_INGEST_SLOTS; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ev[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ing_fed, hipEventDisableTiming));
         HIPCHK(hipStreamCreateWithFlags(&s->ing_aux, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_inf_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_lz_done[k], hipEventDisableTiming)); }
@@ -917,19 +919,58 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     HIPCHK(s->g_result.reserve(8, s->stream));
     HIPCHK(s->g_blocks.reserve(compressed_bytes / 8192 + 1024, s->stream));
     HIPCHK(s->g_status.reserve(compressed_bytes / 8192 + 1024, s->stream));
+    if (compressed_bytes / 8192 + 1024 > s->h_blocks_cap) {     // page-locked mirror of the block table: sized once for ordinary ~20 KB blocks
+        if (s->h_blocks) { (void)hipHostFree(s->h_blocks); s->h_blocks = nullptr; s->h_blocks_cap = 0; }
+        const size_t nc = compressed_bytes / 8192 + 1024;
+        HIPCHK(hipHostMalloc((void **)&s->h_blocks, nc * sizeof(covi::BgzfBlock), hipHostMallocDefault));
+        s->h_blocks_cap = nc;
+    }
     HIPCHK(hipMemsetAsync(s->g_result.p, 0, 64, s->stream));
     { const u64 none = ~0ull; HIPCHK(hipMemcpyAsync(s->g_result.p + 4, &none, 8, hipMemcpyHostToDevice, s->stream)); }
     HIPCHK(hipStreamSynchronize(s->stream));
     s->ing_comp = compressed_bytes; s->ing_infl = 0; s->ing_blocks = 0; s->ing_launched = 0; s->ing_active = true;
-    s->ing_ms_inflate = s->ing_ms_parse = 0;
+    s->ing_ms_inflate = s->ing_ms_parse = 0; s->ing_s_alloc = s->ing_s_endwait = 0;
     return COV_OK;
 }
 
-// k_inflate + k_lz_resolve over the blocks fed but not yet launched (their bytes and table entries are on the copy stream:
-// the compute stream waits for the event recorded behind the last upload).
-static cov_status launch_inflate(cov_session *s) {
-    const uint64_t b0 = s->ing_launched, n64 = s->ing_blocks - b0;
+// Which k_inflate instantiation runs (COVERM_INFLATE_BITS / COVERM_INFLATE_LDS_SORTED: experiment switches) and how many of its
+// one-wave workgroups the device holds at once.
+struct InflateKernel { int lit_bits = 8; bool lds_sorted = false; u32 resident_blocks = 0; };
+static const InflateKernel &inflate_kernel(cov_session *s) {
+    static InflateKernel K;
+    static std::once_flag once;
+    std::call_once(once, [&]() {
+        const char *e = getenv("COVERM_INFLATE_BITS");
+        K.lit_bits = e ? atoi(e) : 8;
+        if (K.lit_bits != 7 && K.lit_bits != 9) K.lit_bits = 8;
+        K.lds_sorted = getenv("COVERM_INFLATE_LDS_SORTED") && atoi(getenv("COVERM_INFLATE_LDS_SORTED")) && K.lit_bits != 9;
+        int per_cu = 0;
+#define COV_INF_SETUP(LB, LS)                                                                                                                  \
+        do {                                                                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, LS>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                      (int)covi::inflate_smem_bytes(LB, LS));                                                                  \
+            if (K.lit_bits == LB && K.lds_sorted == LS)                                                                                        \
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate<LB, LS>, 64, covi::inflate_smem_bytes(LB, LS));    \
+        } while (0)
+        COV_INF_SETUP(7, false); COV_INF_SETUP(8, false); COV_INF_SETUP(9, false); COV_INF_SETUP(7, true); COV_INF_SETUP(8, true);
+#undef COV_INF_SETUP
+        if (per_cu <= 0) per_cu = 2;
+        if (const char *w = getenv("COVERM_INFLATE_WAVES_PER_CU")) { const int v = atoi(w); if (v > 0) per_cu = v; }
+        K.resident_blocks = (u32)s->n_cus * (u32)per_cu * 64u;
+    });
+    return K;
+}
+
+// k_inflate + k_lz_resolve (+ k_crc32) over the next `n` blocks fed but not yet launched (their bytes and table entries are on
+// the copy stream: the compute stream waits for the event recorded behind the last upload).
+// A lane decodes a whole block serially and every block takes about the same time T, so a launch costs T per started ROUND
+// of resident waves: launches are cut to exactly the number of blocks the device holds at once (a launch of 1.05 rounds
+// would cost 2 T — measured: 46 ms per launch of ~51 k blocks against 23.5 ms per round of 49 152).
+static cov_status launch_inflate(cov_session *s, uint64_t n64) {
+    const uint64_t b0 = s->ing_launched;
+    n64 = std::min<uint64_t>(n64, s->ing_blocks - b0);
     if (n64 == 0) return COV_OK;
+    const InflateKernel &K = inflate_kernel(s);
     const u32 n = (u32)n64;
     HIPCHK(hipStreamWaitEvent(s->stream, s->ing_fed, 0));
     const u32 grid = (n + 63u) / 64u;
@@ -943,26 +984,20 @@ static cov_status launch_inflate(cov_session *s) {
         HIPCHK(hipStreamSynchronize(s->ing_aux));     // a buffer is about to be replaced: nothing may still be reading it
         HIPCHK(hipStreamSynchronize(s->stream));
     }
-    HIPCHK(s->g_scratch.reserve((size_t)grid * 64u * covi::INF_SCRATCH_BYTES, s->stream));
-    HIPCHK(tokb.reserve((size_t)n * covi::INF_TOK_CAP, s->stream));
-    HIPCHK(ntokb.reserve(n, s->stream));
-    static int lit_bits = 0, lds_sorted = 0;
-    if (!lit_bits) {
-        const char *e = getenv("COVERM_INFLATE_BITS");
-        lit_bits = e ? atoi(e) : 8;
-        if (lit_bits != 7 && lit_bits != 9) lit_bits = 8;
-        lds_sorted = getenv("COVERM_INFLATE_LDS_SORTED") ? atoi(getenv("COVERM_INFLATE_LDS_SORTED")) : 0;
-#define COV_INF_ATTR(LB, LS) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, LS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)covi::inflate_smem_bytes(LB, LS))
-        COV_INF_ATTR(7, false); COV_INF_ATTR(8, false); COV_INF_ATTR(9, false); COV_INF_ATTR(7, true); COV_INF_ATTR(8, true);
-#undef COV_INF_ATTR
-    }
+    const auto ta0 = std::chrono::steady_clock::now();
+    const size_t full = std::max<size_t>(n, K.resident_blocks);      // sized for a full round at once: no regrowth between launches
+    HIPCHK(s->g_scratch.reserve((full + 63) / 64 * 64u * covi::INF_SCRATCH_BYTES, s->stream));
+    HIPCHK(tokb.reserve(full * covi::INF_TOK_CAP, s->stream));
+    HIPCHK(ntokb.reserve(full, s->stream));
+    s->ing_s_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta0).count();
+    static const u32 ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);
 #define COV_LAUNCH_INFLATE(LB, LS)                                                                                                              \
     hipLaunchKernelGGL((covi::k_inflate<LB, LS>), dim3(grid), dim3(64), covi::inflate_smem_bytes(LB, LS), s->stream, (const uint8_t *)s->g_comp.p, \
                        (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, s->g_infl.p, s->g_scratch.p, tokb.p, ntokb.p,                             \
-                       s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0))
-    if (lds_sorted) { if (lit_bits == 7) COV_LAUNCH_INFLATE(7, true); else COV_LAUNCH_INFLATE(8, true); }
-    else if (lit_bits == 7) COV_LAUNCH_INFLATE(7, false);
-    else if (lit_bits == 9) COV_LAUNCH_INFLATE(9, false);
+                       s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate)
+    if (K.lds_sorted) { if (K.lit_bits == 7) COV_LAUNCH_INFLATE(7, true); else COV_LAUNCH_INFLATE(8, true); }
+    else if (K.lit_bits == 7) COV_LAUNCH_INFLATE(7, false);
+    else if (K.lit_bits == 9) COV_LAUNCH_INFLATE(9, false);
     else COV_LAUNCH_INFLATE(8, false);
 #undef COV_LAUNCH_INFLATE
     HIPCHK(hipEventRecord(s->ing_inf_done[bb], s->stream));
@@ -974,13 +1009,13 @@ static cov_status launch_inflate(cov_session *s) {
                            (const uint8_t *)s->g_infl.p, s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
     HIPCHK(hipEventRecord(s->ing_lz_done[bb], s->ing_aux));
     HIPCHK(hipGetLastError());
-    s->ing_launched = s->ing_blocks;
+    s->ing_launched += n;
     s->ing_batch++;
     return COV_OK;
 }
 
 cov_status cov_ingest_slot_wait(cov_session *s, int slot) {
-    if (!s || slot < 0 || slot > 1 || !s->ing_active) return COV_ERR_INVALID_ARG;
+    if (!s || slot < 0 || slot >= COV_INGEST_SLOTS || !s->ing_active) return COV_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(s->cfg.device));
     HIPCHK(hipEventSynchronize(s->ing_ev[slot]));
     return COV_OK;
@@ -988,7 +1023,7 @@ cov_status cov_ingest_slot_wait(cov_session *s, int slot) {
 
 cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uint64_t file_offset, uint64_t n_bytes,
                            const cov_bgzf_block *blocks, uint32_t n_blocks) {
-    if (!s || !s->ing_active || slot < 0 || slot > 1 || (n_bytes && !host_bytes) || (n_blocks && !blocks)) return COV_ERR_INVALID_ARG;
+    if (!s || !s->ing_active || slot < 0 || slot >= COV_INGEST_SLOTS || (n_bytes && !host_bytes) || (n_blocks && !blocks)) return COV_ERR_INVALID_ARG;
     if (file_offset + n_bytes > s->ing_comp) { s->err = "cov_ingest_feed: bytes beyond the size given to cov_ingest_begin"; return COV_ERR_INVALID_ARG; }
     HIPCHK(hipSetDevice(s->cfg.device));
     if (n_bytes) HIPCHK(hipMemcpyAsync(s->g_comp.p + file_offset, host_bytes, n_bytes, hipMemcpyHostToDevice, s->ing_copy));
@@ -1022,13 +1057,10 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
     HIPCHK(hipMemcpyAsync(s->g_blocks.p + s->ing_blocks, s->h_blocks + s->ing_blocks, (size_t)n_blocks * sizeof(covi::BgzfBlock), hipMemcpyHostToDevice, s->ing_copy));
     HIPCHK(hipEventRecord(s->ing_fed, s->ing_copy));
     s->ing_blocks += n_blocks; s->ing_infl = infl_end;
-    // k_inflate wants >= 2 waves on every CU (one lane per block): launch once enough blocks have arrived
+    // full rounds of resident waves leave as soon as their blocks are here; the remainder goes with cov_ingest_end
     {
-        const char *e = getenv("COVERM_INFLATE_BITS");
-        const int lb = e ? atoi(e) : 8;
-        const bool ls = getenv("COVERM_INFLATE_LDS_SORTED") && atoi(getenv("COVERM_INFLATE_LDS_SORTED"));
-        const uint64_t waves_per_cu = ls ? (lb == 7 ? 2 : 1) : lb == 7 ? 5 : lb == 9 ? 2 : 3;     // LDS-bound residency of k_inflate
-        if (s->ing_blocks - s->ing_launched >= (uint64_t)s->n_cus * waves_per_cu * 64u) return launch_inflate(s);
+        const uint64_t round = inflate_kernel(s).resident_blocks;
+        while (s->ing_blocks - s->ing_launched >= round) { const cov_status lrc = launch_inflate(s, round); if (lrc != COV_OK) return lrc; }
     }
     return COV_OK;
 }
@@ -1045,7 +1077,7 @@ cov_status cov_ingest_end(cov_session *s, uint64_t first_record_offset, uint64_t
         cov_status a = append(s, &ab, true);
         if (a) return a;
     }
-    { const cov_status lrc = launch_inflate(s); if (lrc != COV_OK) return lrc; }
+    { const cov_status lrc = launch_inflate(s, s->ing_blocks - s->ing_launched); if (lrc != COV_OK) return lrc; }
     for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(s->stream, s->ing_lz_done[k], 0));    // both token buffers' resolves (and CRCs) are behind us
     hipEvent_t e0, e1, e2;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
@@ -1066,7 +1098,14 @@ cov_status cov_ingest_end(cov_session *s, uint64_t first_record_offset, uint64_t
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemcpyAsync(res, s->g_result.p, 64, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    {
+        const auto tw0 = std::chrono::steady_clock::now();
+        HIPCHK(hipStreamSynchronize(st));
+        s->ing_s_endwait = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+        if (getenv("COVERM_CLI_TIMING"))
+            fprintf(stderr, "[covermhip] ingest: %llu blocks in %llu launches, token/scratch allocations %.3fs, device drained %.3fs after the last feed\n",
+                    (unsigned long long)s->ing_blocks, (unsigned long long)s->ing_batch, s->ing_s_alloc, s->ing_s_endwait);
+    }
     const u32 inflate_fail = (u32)(res[3] & 0xffffffffu);
     if (inflate_fail) { s->err = "device ingest: " + std::to_string(inflate_fail) + " BGZF blocks failed to inflate or their CRC-32 (handing the file to the CPU reader)"; return COV_ERR_INGEST_FALLBACK; }
     if (res[2]) {

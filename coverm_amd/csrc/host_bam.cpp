@@ -1222,38 +1222,73 @@ int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const cov
     if (fd < 0) return fail(-1, std::string("Unable to find BAM file ") + path);
     struct FdClose { int fd; ~FdClose() { close(fd); } } fdc{fd};
     const uint64_t size = hd->h.file_size;
-    size_t piece = (size_t)128 << 20;
+    size_t piece = (size_t)64 << 20;
     if (const char *pb = getenv("COVERM_INGEST_PIECE_KB")) { const long v = atol(pb); if (v >= 64) piece = (size_t)v << 10; }
-    uint8_t *buf[2] = {(uint8_t *)cov_host_alloc(piece), (uint8_t *)cov_host_alloc(piece)};
-    struct BufFree { uint8_t **b; ~BufFree() { for (int k = 0; k < 2; k++) if (b[k]) cov_host_free(b[k]); } } bf{buf};
-    if (!buf[0] || !buf[1]) return fail(-1, "no page-locked staging memory (is a HIP device usable?)");
+    constexpr int NS = COV_INGEST_SLOTS;
+    uint8_t *buf[NS];
+    for (int k = 0; k < NS; k++) buf[k] = (uint8_t *)cov_host_alloc(piece);
+    struct BufFree { uint8_t **b; ~BufFree() { for (int k = 0; k < NS; k++) if (b[k]) cov_host_free(b[k]); } } bf{buf};
+    for (int k = 0; k < NS; k++) if (!buf[k]) return fail(-1, "no page-locked staging memory (is a HIP device usable?)");
     if (cov_ingest_begin(s, size, size * 4 + (1u << 20), check_crc) != COV_OK) return fail(-1, cov_last_error(s));
     const double t_begin = now() - t_start;
-    Pool pool(std::max(1, threads));
     std::vector<cov_bgzf_block> blocks;
     uint64_t next_blk = 0, out_off = 0, pending_bsize = 0;     // absolute file offset of the next block header; running inflated size; BSIZE of a block whose header is read but whose end is not here yet
     uint8_t tail[64]; uint64_t tail_end = 0; size_t tail_len = 0;   // last bytes of the previous piece (a header may straddle)
-    double t_read = 0, t_wait = 0;
-    int slot = 0;
-    for (uint64_t off = 0; off < size; off += piece, slot ^= 1) {
-        const uint64_t n = std::min<uint64_t>(piece, size - off);
-        double t0 = now();
-        if (cov_ingest_slot_wait(s, slot) != COV_OK) return fail(-1, cov_last_error(s));
-        t_wait += now() - t0;
-        t0 = now();
-        const size_t chunk = 4u << 20, nch = (size_t)((n + chunk - 1) / chunk);
-        std::atomic<bool> ok{true};
-        uint8_t *dst = buf[slot];
-        pool.run(nch, [&](size_t c) {
-            size_t o = c * chunk; const size_t e = (size_t)std::min<uint64_t>(n, (uint64_t)o + chunk);
-            while (o < e) {
-                const ssize_t r = pread(fd, dst + o, e - o, (off_t)(off + o));
-                if (r <= 0) { ok = false; return; }
-                o += (size_t)r;
+    double t_read = 0, t_wait = 0, t_walk = 0, t_feed = 0;
+    const uint64_t n_pieces = (size + piece - 1) / piece;
+    // The reader thread fills staging slot k % NS with piece k (threaded preads) as soon as the upload of piece k - NS has left
+    // the slot; this thread walks the block headers of the pieces in order and feeds them: file reading, the serial header walk
+    // and the device never wait for one another in turn.
+    std::mutex mu; std::condition_variable cv;
+    uint64_t ready = 0, fed = 0;        // pieces read so far / pieces handed to cov_ingest_feed so far
+    bool reader_failed = false, stop = false;
+    std::string reader_err;
+    std::thread reader([&]() {
+        Pool pool(std::max(1, threads));
+        for (uint64_t k = 0; k < n_pieces; k++) {
+            const int slot = (int)(k % NS);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || k < NS || fed + NS > k; });      // piece k - NS has been fed: its upload is on the copy stream
+                if (stop) return;
             }
-        });
-        if (!ok) return fail(-1, std::string("read error on ") + path);
-        t_read += now() - t0;
+            double t0 = now();
+            if (k >= NS && cov_ingest_slot_wait(s, slot) != COV_OK) {
+                std::lock_guard<std::mutex> lk(mu); reader_failed = true; reader_err = cov_last_error(s); cv.notify_all(); return;
+            }
+            t_wait += now() - t0;
+            t0 = now();
+            const uint64_t off = k * piece, n = std::min<uint64_t>(piece, size - off);
+            const size_t chunk = 4u << 20, nch = (size_t)((n + chunk - 1) / chunk);
+            std::atomic<bool> ok{true};
+            uint8_t *dst = buf[slot];
+            pool.run(nch, [&](size_t c) {
+                size_t o = c * chunk; const size_t e = (size_t)std::min<uint64_t>(n, (uint64_t)o + chunk);
+                while (o < e) {
+                    const ssize_t r = pread(fd, dst + o, e - o, (off_t)(off + o));
+                    if (r <= 0) { ok = false; return; }
+                    o += (size_t)r;
+                }
+            });
+            t_read += now() - t0;
+            std::lock_guard<std::mutex> lk(mu);
+            if (!ok) { reader_failed = true; reader_err = std::string("read error on ") + path; cv.notify_all(); return; }
+            ready = k + 1;
+            cv.notify_all();
+        }
+    });
+    struct Join { std::thread &t; std::mutex &mu; std::condition_variable &cv; bool &stop;
+                  ~Join() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); } } joiner{reader, mu, cv, stop};
+    for (uint64_t k = 0; k < n_pieces; k++) {
+        const int slot = (int)(k % NS);
+        const uint64_t off = k * piece, n = std::min<uint64_t>(piece, size - off);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return reader_failed || ready > k; });
+            if (reader_failed) return fail(-1, reader_err);
+        }
+        uint8_t *dst = buf[slot];
+        double t0 = now();
         // ---- block headers completed by this piece
         auto byte_at = [&](uint64_t a) -> uint8_t {   // absolute file offset, within this piece or the saved tail of the previous one
             if (a >= off) return dst[a - off];
@@ -1265,7 +1300,7 @@ int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const cov
             if (pending_bsize == 0) {          // header of the next block (may straddle into the saved tail of the previous piece)
                 if (next_blk + 18 > have) break;
                 uint8_t hb[18];
-                for (int k = 0; k < 18; k++) hb[k] = byte_at(next_blk + (uint64_t)k);
+                for (int q = 0; q < 18; q++) hb[q] = byte_at(next_blk + (uint64_t)q);
                 if (hb[0] != 0x1f || hb[1] != 0x8b || hb[2] != 8 || !(hb[3] & 4)) return fail(1, "not a BGZF block (device ingest hands the file to the CPU reader)");
                 const uint32_t xlen = hb[10] | (hb[11] << 8);
                 if (xlen != 6 || hb[12] != 66 || hb[13] != 67 || hb[14] != 2 || hb[15] != 0)    // extra subfields besides BC: rare, let the CPU reader take it
@@ -1278,7 +1313,7 @@ int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const cov
             cov_bgzf_block b;
             b.in_off = next_blk + 18; b.in_len = (uint32_t)(bsize - 26);
             uint8_t tr[8];
-            for (int k = 0; k < 8; k++) tr[k] = byte_at(next_blk + bsize - 8 + (uint64_t)k);
+            for (int q = 0; q < 8; q++) tr[q] = byte_at(next_blk + bsize - 8 + (uint64_t)q);
             memcpy(&b.crc, tr, 4); memcpy(&b.isize, tr + 4, 4);
             if (b.isize > 65536u) return fail(1, "BGZF block inflates to more than 64 KiB");
             b.out_off = out_off; b.pad = 0;
@@ -1290,14 +1325,20 @@ int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const cov
         tail_len = (size_t)std::min<uint64_t>(sizeof tail, n);
         memcpy(tail, dst + n - tail_len, tail_len);
         tail_end = have;
+        t_walk += now() - t0;
+        t0 = now();
         if (cov_ingest_feed(s, slot, dst, off, n, blocks.data(), (uint32_t)blocks.size()) != COV_OK) return fail(-1, cov_last_error(s));
+        t_feed += now() - t0;
+        { std::lock_guard<std::mutex> lk(mu); fed = k + 1; }
+        cv.notify_all();
     }
+    reader.join();
     if (next_blk != size) return fail(1, "truncated BGZF block at the end of the file");
     double t0 = now();
     uint64_t nrec = 0;
     const cov_status rc = cov_ingest_end(s, hd->h.first_record, &nrec);
     const double t_end = now() - t0;
-    if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; timing[4] = t_begin; }
+    if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; timing[4] = t_begin; timing[5] = t_walk; timing[6] = t_feed; timing[7] = 0; }
     if (rc == COV_ERR_INGEST_FALLBACK) return fail(1, cov_last_error(s));
     if (rc != COV_OK) return fail(-1, cov_last_error(s));
     if (n_records) *n_records = nrec;

@@ -166,14 +166,14 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         check(s, cov_set_targets(s, (uint32_t)S.tlen.size(), S.tlen.data()));
         if (R.by_names) { genome_table(R, S, mask); check(s, cov_set_target_mask(s, mask.data())); }
         S.t_open = now() - t0;
-        uint64_t nrec = 0; double tm[5] = {0, 0, 0, 0, 0};
+        uint64_t nrec = 0; double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const int rc = covh_bam_gpu_ingest(S.path.c_str(), threads, s, hd, getenv("COVERM_NO_CRC") ? 0 : 1, &nrec, tm, err, sizeof err);
         if (rc < 0) die(err);
         if (rc == 0) {
             S.n_records = nrec; S.device_ingest = true;
             if (getenv("COVERM_CLI_TIMING"))
-                fprintf(stderr, "[coverm-amd] %s: device ingest: buffers %.3fs, file read %.3fs, staging waits %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records\n",
-                        S.stoit.c_str(), tm[4], tm[0], tm[1], tm[2], tm[3], (unsigned long long)nrec);
+                fprintf(stderr, "[coverm-amd] %s: device ingest: buffers %.3fs, file read %.3fs, staging waits %.3fs, header walk %.3fs, feed calls %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records\n",
+                        S.stoit.c_str(), tm[4], tm[0], tm[1], tm[5], tm[6], tm[2], tm[3], (unsigned long long)nrec);
             S.t_ingest = now() - t0;
             S.stats.resize(S.tlen.size());
             cov_summary summ;
@@ -276,6 +276,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
 }
 
 int run_cli(int argc, char **argv) {
+    const double t_main0 = now();
     Run R;
     Args &a = R.a;
     if (argc < 2 || (strcmp(argv[1], "contig") && strcmp(argv[1], "genome"))) {
@@ -479,6 +480,7 @@ int run_cli(int argc, char **argv) {
         for (auto &t : th) t.join();
         for (size_t d = 0; d < nd; d++) if (rc[d] != COV_OK) die(emsg[d]);
     }
+    const double t_sessions = now();
     covh_bam_set_pinned(1);
     if (nb > 1) covh_bam_set_buffer_cache(1);
     const bool timing = getenv("COVERM_CLI_TIMING") != nullptr;
@@ -550,6 +552,7 @@ int run_cli(int argc, char **argv) {
             }
         }
     }
+    const double t_ingested = now();
     if (timing) {
         // where the resident set comes from (VmHWM = peak; RssShmem counts page-locked / device-visible mappings of the HIP runtime)
         if (FILE *ps = fopen("/proc/self/status", "r")) {
@@ -602,6 +605,9 @@ int run_cli(int argc, char **argv) {
     if (!out) die("Failed to create output file: " + a.output_file);
     fwrite(txt, 1, len, out);
     if (out != stdout) fclose(out); else fflush(stdout);
+    if (timing)
+        fprintf(stderr, "[coverm-amd] main: arguments + device sessions %.3fs, samples %.3fs, scan drivers + table %.3fs (process start-up and exit are outside)\n",
+                t_sessions - t_main0, t_ingested - t_sessions, now() - t_ingested);
     return 0;
 }
 

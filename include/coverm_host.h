@@ -194,7 +194,7 @@ const char *covh_bam_header_target_name(const covh_bam_header *h, uint32_t i);
 uint64_t covh_bam_header_target_len(const covh_bam_header *h, uint32_t i);
 uint64_t covh_bam_header_first_record(const covh_bam_header *h); /* offset in the inflated stream */
 int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint64_t *n_records,
-                        double *timing5, char *err, size_t errcap);
+                        double *timing8, char *err, size_t errcap);   /* s: file read, staging waits, cov_ingest_end, total, buffers, block-header walk, cov_ingest_feed, 0 */
 
 /* ---- reader-stage PAIR filter (ReferenceSortedBamFilter::read pair branch, filter.rs:117-228, filter_out = true).
  * The single-read branch runs on the device (cov_config.filter_single); the pair branch needs read names, which never

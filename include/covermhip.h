@@ -199,12 +199,14 @@ cov_status cov_reserve(cov_session *s, uint64_t n_records, uint64_t n_cigar);
  *   cov_set_targets(s, ...)                         reference lengths: the record-boundary test uses them
  *   cov_ingest_begin(s, file_bytes, inflated_hint, check_crc)
  *   loop: cov_ingest_slot_wait(s, slot) -> fill the slot's buffer -> cov_ingest_feed(s, slot, buf, file_offset, n, blocks, n_blocks)
- *         (two slots alternate; `blocks` = the BGZF blocks COMPLETED by this piece: offsets are absolute in the file / the
- *          inflated stream; the copy is asynchronous, the inflate kernel of these blocks runs behind it)
+ *         (COV_INGEST_SLOTS staging buffers rotate; slot_wait may be called from a reader thread while another thread feeds;
+ *          `blocks` = the BGZF blocks COMPLETED by this piece: offsets are absolute in the file / the inflated stream; the
+ *          copy is asynchronous, the inflate kernels of these blocks run behind it)
  *   cov_ingest_end(s, first_record_offset, &n_records)
  * Anything irregular (inflate or CRC failure, boundaries that do not verify, a CG:B,I long-CIGAR placeholder) makes
  * cov_ingest_end return COV_ERR_INGEST_FALLBACK with nothing appended: decode that file on the host and cov_push_batch it.
  */
+#define COV_INGEST_SLOTS 4
 typedef struct {
     uint64_t in_off;  /* first byte of the block's raw DEFLATE data, offset in the file */
     uint64_t out_off; /* offset of its inflated bytes in the inflated stream (running sum of ISIZE) */

@@ -18,12 +18,15 @@ cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=2, threads=threads)
 print("write %.1fs %.2f GB" % (time.time() - t, os.path.getsize(p) / 1e9), flush=True)
 BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "coverm_amd", "coverm-amd")
 cmd = [BIN, "contig", "-b", p, "-m", "mean", "trimmed_mean", "covered_fraction", "variance", "-t", str(threads), "-o", os.path.join(d, "out.tsv")]
-for name, env in (("device ingest", {}), ("device ingest", {}), ("device ingest no crc", {"COVERM_NO_CRC": "1"}), ("cpu stream", {"COVERM_NO_GPU_INGEST": "1"})):
+runs = [("device ingest", {})] * int(os.environ.get("PROBE_REPS", "2")) + [("device ingest no crc", {"COVERM_NO_CRC": "1"})]
+if not os.environ.get("PROBE_NO_CPU"):
+    runs.append(("cpu stream", {"COVERM_NO_GPU_INGEST": "1"}))
+for name, env in runs:
     t = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, COVERM_CLI_TIMING="1", **env))
     dt = time.time() - t
     print("%s: wall %.3fs = %.1f M reads/s (rc %d)" % (name, dt, reads / dt / 1e6, r.returncode), flush=True)
     for l in r.stderr.splitlines():
-        if "ingest" in l or "Rss" in l or "VmHWM" in l or "stream read" in l:
+        if "ingest" in l or "VmHWM" in l or "stream read" in l or "main:" in l:
             print("    " + l)
 os.remove(p)
