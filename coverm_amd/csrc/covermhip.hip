@@ -133,23 +133,36 @@ struct cov_session {
     DevBuf<int32_t> d_depth;
 
     // device ingest (cov_ingest_*): compressed file and inflated stream in HBM, BGZF block table, record-boundary scratch
-    DevBuf<uint8_t> g_comp, g_infl, g_scratch;
+    DevBuf<uint8_t> g_comp, g_scratch, g_carry;
+    DevBuf<uint8_t> g_win[3];                              // inflated windows (one k_inflate round each): [carry area | blocks]
     DevBuf<covi::BgzfBlock> g_blocks;
     DevBuf<u32> g_status;
-    DevBuf<covi::SegInfo> g_seg;
-    DevBuf<u64> g_recbase, g_cigbase, g_result, g_tok, g_tok2;   // g_result: [0] records [1] CIGAR words [2] status [3] inflate failures (u32) | extract failures (u32) [4..6] first bad segment
+    DevBuf<covi::SegInfo> g_seg[4];                        // per-window parse state: extract of window w runs up to three windows later
+    DevBuf<u64> g_recbase[4], g_cigbase[4];
+    // g_result: [3] inflate failures (u32) | extract failures (u32), [5] bytes in g_carry, [6] p0 of the window being parsed,
+    // [8 + 8 * (w % 4) ..] result block of window w (k_bam_verify)
+    DevBuf<u64> g_result, g_tok, g_tok2;
     DevBuf<u32> g_ntok, g_ntok2;
-    hipStream_t ing_aux = nullptr;                         // k_lz_resolve / k_crc32 of batch i run beside k_inflate of batch i + 1
+    hipStream_t ing_aux = nullptr;                         // k_lz_resolve / k_crc32 of round i run beside k_inflate of round i + 1
+    hipStream_t ing_parse = nullptr;                       // record boundaries + extraction of window i run beside both
     hipEvent_t ing_inf_done[2] = {nullptr, nullptr}, ing_lz_done[2] = {nullptr, nullptr};
-    uint32_t ing_batch = 0; int ing_check_crc = 1;
-    uint64_t ing_launched = 0;   // blocks already handed to k_inflate (launches are batched so that each fills the GPU)
+    hipEvent_t ing_ver_done[4] = {}, ing_ext_done[3] = {};
+    u64 *h_winres = nullptr;                               // page-locked: 4 x 8 words, the windows' result blocks
+    struct WinInfo { u64 N = 0; u32 n_seg = 0; u64 comp_end = 0; };
+    WinInfo ing_win[4];
+    uint32_t ing_batch = 0; int ing_check_crc = 1;         // ing_batch = rounds (= windows) launched so far
+    uint32_t ing_extracted = 0;                            // windows whose records are in the store (or skipped after a failure)
+    uint64_t ing_rec_total = 0, ing_cig_total = 0;         // records / CIGAR words extracted so far (not committed before cov_ingest_end)
+    uint32_t ing_fail = 0;                                 // sticky status bits of k_bam_verify
+    uint64_t ing_fail_dbg[3] = {0, 0, 0};
+    uint64_t ing_first_record = 0;
+    uint64_t ing_launched = 0;   // blocks already handed to k_inflate
     covi::BgzfBlock *h_blocks = nullptr; size_t h_blocks_cap = 0;   // page-locked mirror of the block table (async uploads read from it)
     uint64_t ing_comp = 0, ing_infl = 0, ing_blocks = 0;
     bool ing_active = false;
     hipStream_t ing_copy = nullptr;
     hipEvent_t ing_ev[COV_INGEST_SLOTS] = {}, ing_fed = nullptr;
-    double ing_ms_inflate = 0, ing_ms_parse = 0;
-    double ing_s_alloc = 0, ing_s_endwait = 0;     // host seconds inside device allocations of the ingest / waiting for the device at its end
+    double ing_s_alloc = 0;     // host seconds inside device allocations of the ingest
 
     // results of the last finish
     bool finished = false;
@@ -402,6 +415,13 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     return COV_OK;
 }
 
+static void ingest_free_buffers(cov_session *s) {
+    s->g_comp.release(); s->g_scratch.release(); s->g_carry.release(); s->g_blocks.release(); s->g_status.release();
+    for (int k = 0; k < 3; k++) s->g_win[k].release();
+    for (int k = 0; k < 4; k++) { s->g_seg[k].release(); s->g_recbase[k].release(); s->g_cigbase[k].release(); }
+    s->g_tok.release(); s->g_ntok.release(); s->g_tok2.release(); s->g_ntok2.release();
+}
+
 void cov_destroy(cov_session *s) {
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
@@ -410,10 +430,17 @@ void cov_destroy(cov_session *s) {
     s->d_tile_first.release(); s->d_tcnt.release(); s->d_fov.release(); s->d_tscan.release(); s->d_ttop.release(); s->d_slow_list.release();
     s->d_ctg_scratch.release(); s->d_depth_all.release(); s->d_depth_off.release(); s->d_iv.release(); s->d_ivst.release(); s->d_ivhist.release();
     s->d_cx_list.release(); s->d_cx_cnt.release(); s->d_cx_cur.release(); s->d_cx_scan.release(); s->d_cx_top.release(); s->d_cx_runs.release();
-    s->g_comp.release(); s->g_infl.release(); s->g_scratch.release(); s->g_blocks.release(); s->g_status.release(); s->g_seg.release();
-    s->g_recbase.release(); s->g_cigbase.release(); s->g_result.release(); s->g_tok.release(); s->g_ntok.release(); s->g_tok2.release(); s->g_ntok2.release();
-    if (s->ing_aux) { (void)hipStreamSynchronize(s->ing_aux); (void)hipStreamDestroy(s->ing_aux); }
+    if (s->ing_aux) (void)hipStreamSynchronize(s->ing_aux);
+    if (s->ing_parse) (void)hipStreamSynchronize(s->ing_parse);
+    ingest_free_buffers(s);
+    s->g_result.release();
+    if (s->ing_aux) (void)hipStreamDestroy(s->ing_aux);
+    if (s->ing_parse) (void)hipStreamDestroy(s->ing_parse);
     for (int k = 0; k < 2; k++) { if (s->ing_inf_done[k]) (void)hipEventDestroy(s->ing_inf_done[k]); if (s->ing_lz_done[k]) (void)hipEventDestroy(s->ing_lz_done[k]); }
+    for (int k = 0; k < 4; k++) if (s->ing_ver_done[k]) (void)hipEventDestroy(s->ing_ver_done[k]);
+    for (int k = 0; k < 3; k++) if (s->ing_ext_done[k]) (void)hipEventDestroy(s->ing_ext_done[k]);
+    if (s->h_winres) (void)hipHostFree(s->h_winres);
+    s->h_winres = nullptr;
     if (s->h_blocks) (void)hipHostFree(s->h_blocks);
     s->h_blocks = nullptr;
     if (s->ing_copy) { (void)hipStreamSynchronize(s->ing_copy); (void)hipStreamDestroy(s->ing_copy); }
@@ -903,39 +930,9 @@ cov_status cov_gathered(cov_session *root, uint32_t rank, cov_contig_stats *stat
 static_assert(sizeof(cov_bgzf_block) == sizeof(covi::BgzfBlock) && offsetof(cov_bgzf_block, in_len) == offsetof(covi::BgzfBlock, in_len) &&
               offsetof(cov_bgzf_block, out_off) == offsetof(covi::BgzfBlock, out_off), "cov_bgzf_block mirrors the device struct");
 
-cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t inflated_bytes_hint, int check_crc) {
-    if (!s) return COV_ERR_INVALID_ARG;
-    HIPCHK(hipSetDevice(s->cfg.device));
-    if (!s->ing_copy) {
-        HIPCHK(hipStreamCreateWithFlags(&s->ing_copy, hipStreamNonBlocking));
-        for (int k = 0; k < COV_INGEST_SLOTS; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ev[k], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&s->ing_fed, hipEventDisableTiming));
-        HIPCHK(hipStreamCreateWithFlags(&s->ing_aux, hipStreamNonBlocking));
-        for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_inf_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_lz_done[k], hipEventDisableTiming)); }
-    }
-    s->ing_batch = 0; s->ing_check_crc = (check_crc && !getenv("COVERM_NO_CRC")) ? 1 : 0;
-    HIPCHK(s->g_comp.reserve(compressed_bytes + 64, s->stream));
-    HIPCHK(s->g_infl.reserve(std::max<uint64_t>(inflated_bytes_hint, 1u << 20) + 64, s->stream));
-    HIPCHK(s->g_result.reserve(8, s->stream));
-    HIPCHK(s->g_blocks.reserve(compressed_bytes / 8192 + 1024, s->stream));
-    HIPCHK(s->g_status.reserve(compressed_bytes / 8192 + 1024, s->stream));
-    if (compressed_bytes / 8192 + 1024 > s->h_blocks_cap) {     // page-locked mirror of the block table: sized once for ordinary ~20 KB blocks
-        if (s->h_blocks) { (void)hipHostFree(s->h_blocks); s->h_blocks = nullptr; s->h_blocks_cap = 0; }
-        const size_t nc = compressed_bytes / 8192 + 1024;
-        HIPCHK(hipHostMalloc((void **)&s->h_blocks, nc * sizeof(covi::BgzfBlock), hipHostMallocDefault));
-        s->h_blocks_cap = nc;
-    }
-    HIPCHK(hipMemsetAsync(s->g_result.p, 0, 64, s->stream));
-    { const u64 none = ~0ull; HIPCHK(hipMemcpyAsync(s->g_result.p + 4, &none, 8, hipMemcpyHostToDevice, s->stream)); }
-    HIPCHK(hipStreamSynchronize(s->stream));
-    s->ing_comp = compressed_bytes; s->ing_infl = 0; s->ing_blocks = 0; s->ing_launched = 0; s->ing_active = true;
-    s->ing_ms_inflate = s->ing_ms_parse = 0; s->ing_s_alloc = s->ing_s_endwait = 0;
-    return COV_OK;
-}
-
-// Which k_inflate instantiation runs (COVERM_INFLATE_BITS / COVERM_INFLATE_LDS_SORTED: experiment switches) and how many of its
-// one-wave workgroups the device holds at once.
-struct InflateKernel { int lit_bits = 8; bool lds_sorted = false; u32 resident_blocks = 0; };
+// Which k_inflate instantiation runs (COVERM_INFLATE_BITS / COVERM_INFLATE_LDS_SORTED: experiment switches), how many of its
+// one-wave workgroups the device holds at once (= blocks per round = blocks per window), and the size of the carry area.
+struct InflateKernel { int lit_bits = 8; bool lds_sorted = false; u32 round_blocks = 0; u64 carry = 16ull << 20; };
 static const InflateKernel &inflate_kernel(cov_session *s) {
     static InflateKernel K;
     static std::once_flag once;
@@ -955,63 +952,180 @@ static const InflateKernel &inflate_kernel(cov_session *s) {
         COV_INF_SETUP(7, false); COV_INF_SETUP(8, false); COV_INF_SETUP(9, false); COV_INF_SETUP(7, true); COV_INF_SETUP(8, true);
 #undef COV_INF_SETUP
         if (per_cu <= 0) per_cu = 2;
-        if (const char *w = getenv("COVERM_INFLATE_WAVES_PER_CU")) { const int v = atoi(w); if (v > 0) per_cu = v; }
-        K.resident_blocks = (u32)s->n_cus * (u32)per_cu * 64u;
+        K.round_blocks = (u32)s->n_cus * (u32)per_cu * 64u;
+        if (const char *w = getenv("COVERM_INGEST_ROUND_BLOCKS")) { const long v = atol(w); if (v >= 64) K.round_blocks = (u32)v / 64u * 64u; }   // tests: many small windows
+        if (const char *c = getenv("COVERM_INGEST_CARRY_KB")) { const long v = atol(c); if (v >= 1) K.carry = (u64)v << 10; }
+        K.carry = (K.carry + 63u) & ~63ull;
     });
     return K;
 }
 
-// k_inflate + k_lz_resolve (+ k_crc32) over the next `n` blocks fed but not yet launched (their bytes and table entries are on
-// the copy stream: the compute stream waits for the event recorded behind the last upload).
+cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t first_record_offset, int check_crc) {
+    if (!s) return COV_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    if (!s->ing_copy) {
+        HIPCHK(hipStreamCreateWithFlags(&s->ing_copy, hipStreamNonBlocking));
+        for (int k = 0; k < COV_INGEST_SLOTS; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ev[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ing_fed, hipEventDisableTiming));
+        HIPCHK(hipStreamCreateWithFlags(&s->ing_aux, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&s->ing_parse, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_inf_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_lz_done[k], hipEventDisableTiming)); }
+        for (int k = 0; k < 4; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ver_done[k], hipEventDisableTiming));
+        for (int k = 0; k < 3; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ext_done[k], hipEventDisableTiming));
+        HIPCHK(hipHostMalloc((void **)&s->h_winres, 4 * 8 * sizeof(u64), hipHostMallocDefault));
+    }
+    if (s->adopted) {  // materialise an adopted device batch into the owned store first
+        cov_batch ab = s->adopted_batch;
+        s->adopted = false; s->n_records = 0; s->n_cigar = 0;
+        cov_status a = append(s, &ab, true);
+        if (a) return a;
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));     // the record store is about to be written from the parse stream
+    s->ing_batch = 0; s->ing_extracted = 0; s->ing_rec_total = s->ing_cig_total = 0; s->ing_fail = 0;
+    s->ing_first_record = first_record_offset;
+    s->ing_check_crc = (check_crc && !getenv("COVERM_NO_CRC")) ? 1 : 0;
+    HIPCHK(s->g_comp.reserve(compressed_bytes + 64, s->stream));
+    HIPCHK(s->g_result.reserve(8 + 4 * 8, s->stream));
+    HIPCHK(s->g_carry.reserve(inflate_kernel(s).carry, s->stream));
+    HIPCHK(s->g_blocks.reserve(compressed_bytes / 8192 + 1024, s->stream));
+    HIPCHK(s->g_status.reserve(compressed_bytes / 8192 + 1024, s->stream));
+    if (compressed_bytes / 8192 + 1024 > s->h_blocks_cap) {     // page-locked mirror of the block table: sized once for ordinary ~20 KB blocks
+        if (s->h_blocks) { (void)hipHostFree(s->h_blocks); s->h_blocks = nullptr; s->h_blocks_cap = 0; }
+        const size_t nc = compressed_bytes / 8192 + 1024;
+        HIPCHK(hipHostMalloc((void **)&s->h_blocks, nc * sizeof(covi::BgzfBlock), hipHostMallocDefault));
+        s->h_blocks_cap = nc;
+    }
+    HIPCHK(hipMemsetAsync(s->g_result.p, 0, (8 + 4 * 8) * sizeof(u64), s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->ing_comp = compressed_bytes; s->ing_infl = 0; s->ing_blocks = 0; s->ing_launched = 0; s->ing_active = true;
+    s->ing_s_alloc = 0;
+    return COV_OK;
+}
+
+// Records of the windows whose boundaries are verified go into the store: all windows up to `must_upto` (waiting for their
+// k_bam_verify if need be), later ones only if their result is already here.
+static cov_status ingest_drain(cov_session *s, int64_t must_upto) {
+    hipStream_t ps = s->ing_parse;
+    while (s->ing_extracted < s->ing_batch) {
+        const u32 w = s->ing_extracted, q = w & 3u;
+        if ((int64_t)w > must_upto) { if (hipEventQuery(s->ing_ver_done[q]) != hipSuccess) break; }
+        else HIPCHK(hipEventSynchronize(s->ing_ver_done[q]));
+        const u64 *res = s->h_winres + 8 * q;
+        const u64 nrec = res[0], ncig = res[1];
+        const u32 st = (u32)res[2];
+        if (st && !s->ing_fail) { s->ing_fail = st; s->ing_fail_dbg[0] = res[4]; s->ing_fail_dbg[1] = res[5]; s->ing_fail_dbg[2] = res[6]; }
+        const u64 R = s->n_records + s->ing_rec_total, Cg = s->n_cigar + s->ing_cig_total;
+        if (!s->ing_fail && (R + nrec >= 0xfffffff0ull || Cg + ncig >= 0xfffffff0ull)) s->ing_fail = 16u;
+        if (!s->ing_fail && nrec) {
+            u64 Nn = R + nrec, Cn = Cg + ncig + 1;
+            if (w == 0 && s->ing_batch > 1 && s->ing_win[0].comp_end) {    // first of several windows: size the store for the whole file at once
+                const double scale = (double)s->ing_comp / (double)s->ing_win[0].comp_end * 1.1;
+                Nn = std::max<u64>(Nn, R + (u64)((double)nrec * scale) + 1024); Cn = std::max<u64>(Cn, Cg + (u64)((double)ncig * scale) + 1024);
+                Nn = std::min<u64>(Nn, 0xfffffff0ull); Cn = std::min<u64>(Cn, 0xfffffff0ull);
+            }
+            const auto ta0 = std::chrono::steady_clock::now();
+            HIPCHK(s->s_tid.reserve(Nn, ps, R)); HIPCHK(s->s_pos.reserve(Nn, ps, R)); HIPCHK(s->s_flag.reserve(Nn, ps, R));
+            HIPCHK(s->s_mapq.reserve(Nn, ps, R)); HIPCHK(s->s_nmk.reserve(Nn, ps, R)); HIPCHK(s->s_nm.reserve(Nn, ps, R));
+            HIPCHK(s->s_lseq.reserve(Nn, ps, R)); HIPCHK(s->s_coff.reserve(Nn + 1, ps, R + 1));
+            HIPCHK(s->s_cig.reserve(Cn, ps, Cg));
+            s->ing_s_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta0).count();
+            covi::RecStore RS{};
+            RS.tid = s->s_tid.p; RS.pos = s->s_pos.p; RS.flag = s->s_flag.p; RS.mapq = s->s_mapq.p; RS.nm_kind = s->s_nmk.p; RS.nm = s->s_nm.p;
+            RS.l_seq = s->s_lseq.p; RS.cigar_off = s->s_coff.p; RS.cigar = s->s_cig.p; RS.rec0 = R; RS.cig0 = Cg;
+            covi::BamScan S{};
+            S.u = s->g_win[w % 3u].p; S.N = s->ing_win[q].N; S.p0 = s->g_result.p + 6; S.seg_bytes = 32768; S.n_seg = s->ing_win[q].n_seg;
+            S.n_ref = (int)s->n_targets; S.ref_len = s->d_tlen.p; S.final = 0;
+            hipLaunchKernelGGL(covi::k_bam_extract, dim3((S.n_seg + 63) / 64), dim3(64), 0, ps, S, (const covi::SegInfo *)s->g_seg[q].p, (const u64 *)s->g_recbase[q].p,
+                               (const u64 *)s->g_cigbase[q].p, RS, reinterpret_cast<u32 *>(s->g_result.p + 3) + 1);
+            HIPCHK(hipGetLastError());
+            s->ing_rec_total += nrec; s->ing_cig_total += ncig;
+        }
+        HIPCHK(hipEventRecord(s->ing_ext_done[w % 3u], ps));
+        s->ing_extracted++;
+    }
+    return COV_OK;
+}
+
+// One round = one window: k_inflate over the next `n` blocks fed but not yet launched (main stream), k_lz_resolve + k_crc32
+// behind it (aux stream, beside the next round's k_inflate), then the window's record boundaries (parse stream).
 // A lane decodes a whole block serially and every block takes about the same time T, so a launch costs T per started ROUND
 // of resident waves: launches are cut to exactly the number of blocks the device holds at once (a launch of 1.05 rounds
-// would cost 2 T — measured: 46 ms per launch of ~51 k blocks against 23.5 ms per round of 49 152).
-static cov_status launch_inflate(cov_session *s, uint64_t n64) {
+// costs 2 T — measured: 46 ms per launch of ~51 k blocks against 23.5 ms per round of 49 152).
+// Windows bound the memory: the inflated stream of a 200 M-read BAM is 62 GB, and device allocations cost ~30 ms per GB.
+static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
     const uint64_t b0 = s->ing_launched;
     n64 = std::min<uint64_t>(n64, s->ing_blocks - b0);
-    if (n64 == 0) return COV_OK;
     const InflateKernel &K = inflate_kernel(s);
-    const u32 n = (u32)n64;
-    HIPCHK(hipStreamWaitEvent(s->stream, s->ing_fed, 0));
-    const u32 grid = (n + 63u) / 64u;
-    // token buffers alternate between batches: k_inflate of this batch may not start before k_lz_resolve of the batch that used the
-    // same buffer two launches ago has finished
-    const int bb = (int)(s->ing_batch & 1u);
+    const u32 n = (u32)n64, w = s->ing_batch, q = w & 3u;
+    if (w >= 3) { const cov_status d = ingest_drain(s, (int64_t)w - 3); if (d != COV_OK) return d; }   // this window's buffer and parse state are free again
+    const int bb = (int)(w & 1u);
     DevBuf<u64> &tokb = bb ? s->g_tok2 : s->g_tok;
     DevBuf<u32> &ntokb = bb ? s->g_ntok2 : s->g_ntok;
-    if (s->ing_batch >= 2) HIPCHK(hipStreamWaitEvent(s->stream, s->ing_lz_done[bb], 0));
-    if ((size_t)n * covi::INF_TOK_CAP > tokb.cap || n > ntokb.cap || (size_t)grid * 64u * covi::INF_SCRATCH_BYTES > s->g_scratch.cap) {
-        HIPCHK(hipStreamSynchronize(s->ing_aux));     // a buffer is about to be replaced: nothing may still be reading it
-        HIPCHK(hipStreamSynchronize(s->stream));
+    DevBuf<uint8_t> &win = s->g_win[w % 3u];
+    const size_t full = std::max<size_t>(n, K.round_blocks);      // sized for a full round at once: no regrowth between rounds
+    const size_t win_bytes = (size_t)K.carry + full * 65536u + 64u;
+    const u32 seg_cap = (u32)((win_bytes + 32767u) / 32768u);
+    if (full * covi::INF_TOK_CAP > tokb.cap || full > ntokb.cap || (full + 63) / 64 * 64u * covi::INF_SCRATCH_BYTES > s->g_scratch.cap || win_bytes > win.cap ||
+        seg_cap > s->g_seg[q].cap) {
+        HIPCHK(hipStreamSynchronize(s->ing_aux)); HIPCHK(hipStreamSynchronize(s->ing_parse)); HIPCHK(hipStreamSynchronize(s->stream));   // a buffer is about to be replaced
+        const auto ta0 = std::chrono::steady_clock::now();
+        HIPCHK(s->g_scratch.reserve((full + 63) / 64 * 64u * covi::INF_SCRATCH_BYTES, s->stream));
+        HIPCHK(tokb.reserve(full * covi::INF_TOK_CAP, s->stream));
+        HIPCHK(ntokb.reserve(full, s->stream));
+        HIPCHK(win.reserve(win_bytes, s->stream));
+        HIPCHK(s->g_seg[q].reserve(seg_cap, s->stream)); HIPCHK(s->g_recbase[q].reserve(seg_cap, s->stream)); HIPCHK(s->g_cigbase[q].reserve(seg_cap, s->stream));
+        s->ing_s_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta0).count();
     }
-    const auto ta0 = std::chrono::steady_clock::now();
-    const size_t full = std::max<size_t>(n, K.resident_blocks);      // sized for a full round at once: no regrowth between launches
-    HIPCHK(s->g_scratch.reserve((full + 63) / 64 * 64u * covi::INF_SCRATCH_BYTES, s->stream));
-    HIPCHK(tokb.reserve(full * covi::INF_TOK_CAP, s->stream));
-    HIPCHK(ntokb.reserve(full, s->stream));
-    s->ing_s_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta0).count();
-    static const u32 ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);
+    const u64 out_off0 = n ? s->h_blocks[b0].out_off : s->ing_infl;
+    const u64 wbytes = n ? s->h_blocks[b0 + n - 1].out_off + s->h_blocks[b0 + n - 1].isize - out_off0 : 0;
+    uint8_t *out_bias = win.p + K.carry - out_off0;     // blocks carry absolute offsets of the inflated stream
+    if (w == 0 && s->ing_first_record > wbytes && !s->ing_fail) s->ing_fail = 32u;    // the BAM header does not end inside the first window
+    if (n) {
+        HIPCHK(hipStreamWaitEvent(s->stream, s->ing_fed, 0));
+        // token buffers alternate: this k_inflate may not start before the k_lz_resolve that read the same buffer two rounds ago is done;
+        // the window buffer is free once the extraction of the window three rounds ago is done
+        if (w >= 2) HIPCHK(hipStreamWaitEvent(s->stream, s->ing_lz_done[bb], 0));
+        if (w >= 3) HIPCHK(hipStreamWaitEvent(s->stream, s->ing_ext_done[w % 3u], 0));
+        const u32 grid = (n + 63u) / 64u;
+        static const u32 ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);
 #define COV_LAUNCH_INFLATE(LB, LS)                                                                                                              \
-    hipLaunchKernelGGL((covi::k_inflate<LB, LS>), dim3(grid), dim3(64), covi::inflate_smem_bytes(LB, LS), s->stream, (const uint8_t *)s->g_comp.p, \
-                       (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, s->g_infl.p, s->g_scratch.p, tokb.p, ntokb.p,                             \
-                       s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate)
-    if (K.lds_sorted) { if (K.lit_bits == 7) COV_LAUNCH_INFLATE(7, true); else COV_LAUNCH_INFLATE(8, true); }
-    else if (K.lit_bits == 7) COV_LAUNCH_INFLATE(7, false);
-    else if (K.lit_bits == 9) COV_LAUNCH_INFLATE(9, false);
-    else COV_LAUNCH_INFLATE(8, false);
+        hipLaunchKernelGGL((covi::k_inflate<LB, LS>), dim3(grid), dim3(64), covi::inflate_smem_bytes(LB, LS), s->stream, (const uint8_t *)s->g_comp.p, \
+                           (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, s->g_scratch.p, tokb.p, ntokb.p,                                 \
+                           s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate)
+        if (K.lds_sorted) { if (K.lit_bits == 7) COV_LAUNCH_INFLATE(7, true); else COV_LAUNCH_INFLATE(8, true); }
+        else if (K.lit_bits == 7) COV_LAUNCH_INFLATE(7, false);
+        else if (K.lit_bits == 9) COV_LAUNCH_INFLATE(9, false);
+        else COV_LAUNCH_INFLATE(8, false);
 #undef COV_LAUNCH_INFLATE
-    HIPCHK(hipEventRecord(s->ing_inf_done[bb], s->stream));
-    HIPCHK(hipStreamWaitEvent(s->ing_aux, s->ing_inf_done[bb], 0));
-    hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, s->g_infl.p,
-                       (const u64 *)tokb.p, (const u32 *)ntokb.p);
-    if (s->ing_check_crc)
-        hipLaunchKernelGGL(covi::k_crc32, dim3((n + 255u) / 256u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n,
-                           (const uint8_t *)s->g_infl.p, s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
-    HIPCHK(hipEventRecord(s->ing_lz_done[bb], s->ing_aux));
+        HIPCHK(hipEventRecord(s->ing_inf_done[bb], s->stream));
+        HIPCHK(hipStreamWaitEvent(s->ing_aux, s->ing_inf_done[bb], 0));
+        hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
+                           (const u64 *)tokb.p, (const u32 *)ntokb.p);
+        if (s->ing_check_crc)
+            hipLaunchKernelGGL(covi::k_crc32, dim3((n + 255u) / 256u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n,
+                               (const uint8_t *)out_bias, s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
+        HIPCHK(hipEventRecord(s->ing_lz_done[bb], s->ing_aux));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamWaitEvent(s->ing_parse, s->ing_lz_done[bb], 0));
+    }
+    // ---- the window's records: tail of the previous window in front, boundaries, counts, the new tail
+    covi::BamScan S{};
+    S.u = win.p; S.N = K.carry + wbytes; S.p0 = s->g_result.p + 6; S.seg_bytes = 32768; S.n_seg = (u32)((S.N + S.seg_bytes - 1) / S.seg_bytes);
+    S.n_ref = (int)s->n_targets; S.ref_len = s->d_tlen.p; S.final = final ? 1 : 0;
+    s->ing_win[q].N = S.N; s->ing_win[q].n_seg = S.n_seg; s->ing_win[q].comp_end = n ? s->h_blocks[b0 + n - 1].in_off + s->h_blocks[b0 + n - 1].in_len + 8 : s->ing_comp;
+    hipStream_t ps = s->ing_parse;
+    hipLaunchKernelGGL(covi::k_carry_in, dim3(1), dim3(1024), 0, ps, win.p, K.carry, (const uint8_t *)s->g_carry.p, (const u64 *)(s->g_result.p + 5),
+                       w == 0 ? s->ing_first_record : 0ull, s->g_result.p + 6);
+    hipLaunchKernelGGL(covi::k_bam_find, dim3((S.n_seg + 3) / 4), dim3(256), 0, ps, S, s->g_seg[q].p);
+    hipLaunchKernelGGL(covi::k_bam_hop, dim3((S.n_seg + 63) / 64), dim3(64), 0, ps, S, s->g_seg[q].p);
+    hipLaunchKernelGGL(covi::k_bam_verify, dim3(1), dim3(1024), 0, ps, S, s->g_seg[q].p, s->g_recbase[q].p, s->g_cigbase[q].p, s->g_result.p + 8 + 8 * q,
+                       s->g_carry.p, (u64)K.carry, s->g_result.p + 5);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(s->h_winres + 8 * q, s->g_result.p + 8 + 8 * q, 8 * sizeof(u64), hipMemcpyDeviceToHost, ps));
+    HIPCHK(hipEventRecord(s->ing_ver_done[q], ps));
     s->ing_launched += n;
     s->ing_batch++;
-    return COV_OK;
+    return ingest_drain(s, -1);      // whatever is verified already
 }
 
 cov_status cov_ingest_slot_wait(cov_session *s, int slot) {
@@ -1041,17 +1155,16 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
     uint64_t infl_end = s->ing_infl;
     for (uint32_t i = 0; i < n_blocks; i++) {
         const cov_bgzf_block &b = blocks[i];
-        if (b.in_off + b.in_len > file_offset + n_bytes || b.isize > 65536u) { s->err = "cov_ingest_feed: block outside the bytes fed so far"; return COV_ERR_INVALID_ARG; }
+        if (b.in_off + b.in_len > file_offset + n_bytes || b.isize > 65536u || b.out_off != infl_end) {
+            s->err = "cov_ingest_feed: block outside the bytes fed so far, or not contiguous in the inflated stream"; return COV_ERR_INVALID_ARG;
+        }
         covi::BgzfBlock d; d.in_off = b.in_off; d.out_off = b.out_off; d.in_len = b.in_len; d.isize = b.isize; d.crc = b.crc; d.pad = 0;
         s->h_blocks[s->ing_blocks + i] = d;
-        infl_end = std::max<uint64_t>(infl_end, b.out_off + b.isize);
+        infl_end = b.out_off + b.isize;
     }
-    if (infl_end + 64 > s->g_infl.cap) {     // the hint was too small: grow, keeping what is inflated already
-        HIPCHK(hipStreamSynchronize(s->ing_aux));
-        HIPCHK(hipStreamSynchronize(s->stream));
-        HIPCHK(s->g_infl.reserve(infl_end + infl_end / 2 + 64, s->stream, s->ing_infl));
+    if (s->ing_blocks + n_blocks > s->g_blocks.cap || s->ing_blocks + n_blocks > s->g_status.cap) {
+        HIPCHK(hipStreamSynchronize(s->ing_aux)); HIPCHK(hipStreamSynchronize(s->stream));
     }
-    if (s->ing_blocks + n_blocks > s->g_blocks.cap || s->ing_blocks + n_blocks > s->g_status.cap) HIPCHK(hipStreamSynchronize(s->ing_aux));
     HIPCHK(s->g_blocks.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
     HIPCHK(s->g_status.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
     HIPCHK(hipMemcpyAsync(s->g_blocks.p + s->ing_blocks, s->h_blocks + s->ing_blocks, (size_t)n_blocks * sizeof(covi::BgzfBlock), hipMemcpyHostToDevice, s->ing_copy));
@@ -1059,89 +1172,52 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
     s->ing_blocks += n_blocks; s->ing_infl = infl_end;
     // full rounds of resident waves leave as soon as their blocks are here; the remainder goes with cov_ingest_end
     {
-        const uint64_t round = inflate_kernel(s).resident_blocks;
-        while (s->ing_blocks - s->ing_launched >= round) { const cov_status lrc = launch_inflate(s, round); if (lrc != COV_OK) return lrc; }
+        const uint64_t round = inflate_kernel(s).round_blocks;
+        while (s->ing_blocks - s->ing_launched > round) { const cov_status lrc = launch_round(s, round, false); if (lrc != COV_OK) return lrc; }
     }
     return COV_OK;
 }
 
-cov_status cov_ingest_end(cov_session *s, uint64_t first_record_offset, uint64_t *n_records_out) {
+cov_status cov_ingest_end(cov_session *s, uint64_t *n_records_out) {
     if (!s || !s->ing_active) return COV_ERR_INVALID_ARG;
     s->ing_active = false;
     HIPCHK(hipSetDevice(s->cfg.device));
-    hipStream_t st = s->stream;
     if (n_records_out) *n_records_out = 0;
-    if (s->adopted) {  // materialise an adopted device batch into the owned store first
-        cov_batch ab = s->adopted_batch;
-        s->adopted = false; s->n_records = 0; s->n_cigar = 0;
-        cov_status a = append(s, &ab, true);
-        if (a) return a;
-    }
-    { const cov_status lrc = launch_inflate(s, s->ing_blocks - s->ing_launched); if (lrc != COV_OK) return lrc; }
-    for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(s->stream, s->ing_lz_done[k], 0));    // both token buffers' resolves (and CRCs) are behind us
-    hipEvent_t e0, e1, e2;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
-    struct EvFree { hipEvent_t a, b, c; ~EvFree() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); } } evfree{e0, e1, e2};
-    HIPCHK(hipEventRecord(e0, st));
-    const uint64_t N = s->ing_infl;
-    uint64_t res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (first_record_offset > N) { s->err = "device ingest: the BAM header is longer than the inflated stream"; return COV_ERR_INGEST_FALLBACK; }
-    covi::BamScan S{};
-    S.u = s->g_infl.p; S.N = N; S.p0 = first_record_offset; S.seg_bytes = 32768; S.n_ref = (int)s->n_targets; S.ref_len = s->d_tlen.p;
-    const uint64_t body = N - first_record_offset;
-    S.n_seg = (u32)((body + S.seg_bytes - 1) / S.seg_bytes);
-    if (S.n_seg) {
-        HIPCHK(s->g_seg.reserve(S.n_seg, st)); HIPCHK(s->g_recbase.reserve(S.n_seg, st)); HIPCHK(s->g_cigbase.reserve(S.n_seg, st));
-        hipLaunchKernelGGL(covi::k_bam_find, dim3((S.n_seg + 3) / 4), dim3(256), 0, st, S, s->g_seg.p);
-        hipLaunchKernelGGL(covi::k_bam_hop, dim3((S.n_seg + 63) / 64), dim3(64), 0, st, S, s->g_seg.p);
-        hipLaunchKernelGGL(covi::k_bam_verify, dim3(1), dim3(1024), 0, st, S, s->g_seg.p, s->g_recbase.p, s->g_cigbase.p, s->g_result.p);
-        HIPCHK(hipGetLastError());
-    }
-    HIPCHK(hipMemcpyAsync(res, s->g_result.p, 64, hipMemcpyDeviceToHost, st));
-    {
-        const auto tw0 = std::chrono::steady_clock::now();
-        HIPCHK(hipStreamSynchronize(st));
-        s->ing_s_endwait = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
-        if (getenv("COVERM_CLI_TIMING"))
-            fprintf(stderr, "[covermhip] ingest: %llu blocks in %llu launches, token/scratch allocations %.3fs, device drained %.3fs after the last feed\n",
-                    (unsigned long long)s->ing_blocks, (unsigned long long)s->ing_batch, s->ing_s_alloc, s->ing_s_endwait);
-    }
-    const u32 inflate_fail = (u32)(res[3] & 0xffffffffu);
+    const InflateKernel &K = inflate_kernel(s);
+    while (s->ing_blocks - s->ing_launched > K.round_blocks) { const cov_status lrc = launch_round(s, K.round_blocks, false); if (lrc != COV_OK) return lrc; }
+    { const cov_status lrc = launch_round(s, s->ing_blocks - s->ing_launched, true); if (lrc != COV_OK) return lrc; }     // the last window (possibly only the carried tail)
+    { const cov_status d = ingest_drain(s, (int64_t)s->ing_batch); if (d != COV_OK) return d; }
+    u64 glob[8];
+    HIPCHK(hipMemcpyAsync(glob, s->g_result.p, sizeof glob, hipMemcpyDeviceToHost, s->ing_parse));
+    HIPCHK(hipStreamSynchronize(s->ing_parse));
+    HIPCHK(hipStreamSynchronize(s->ing_aux));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (getenv("COVERM_CLI_TIMING"))
+        fprintf(stderr, "[covermhip] ingest: %llu blocks in %u windows of %u, device allocations %.3fs\n", (unsigned long long)s->ing_blocks, s->ing_batch,
+                K.round_blocks, s->ing_s_alloc);
+    const u32 inflate_fail = (u32)(glob[3] & 0xffffffffu);
     if (inflate_fail) { s->err = "device ingest: " + std::to_string(inflate_fail) + " BGZF blocks failed to inflate or their CRC-32 (handing the file to the CPU reader)"; return COV_ERR_INGEST_FALLBACK; }
-    if (res[2]) {
-        s->err = (res[2] & 4) ? "device ingest: a record keeps its CIGAR in CG:B,I (handing the file to the CPU reader)"
-               : (res[2] & 2) ? "device ingest: truncated BAM record"
-               : "device ingest: record boundaries did not verify at segment " + std::to_string(res[4]) + " (start " + std::to_string(res[5]) + ", landed " +
-                 std::to_string(res[6]) + "; handing the file to the CPU reader)";
-        return COV_ERR_INGEST_FALLBACK;
+    if (s->ing_fail) {
+        const u32 f = s->ing_fail;
+        s->err = (f & 16u) ? "more than 2^32 records in one session"
+               : (f & 32u) ? "device ingest: the BAM header is longer than the first window of the inflated stream (handing the file to the CPU reader)"
+               : (f & 4u) ? "device ingest: a record keeps its CIGAR in CG:B,I (handing the file to the CPU reader)"
+               : (f & 8u) ? "device ingest: a record larger than the carry buffer between windows (handing the file to the CPU reader)"
+               : (f & 2u) ? "device ingest: truncated BAM record"
+               : "device ingest: record boundaries did not verify at segment " + std::to_string(s->ing_fail_dbg[0]) + " (start " + std::to_string(s->ing_fail_dbg[1]) +
+                 ", landed " + std::to_string(s->ing_fail_dbg[2]) + "; handing the file to the CPU reader)";
+        return (f & 16u) ? COV_ERR_INVALID_ARG : COV_ERR_INGEST_FALLBACK;
     }
-    const uint64_t nrec = res[0], ncig = res[1];
-    if (s->n_records + nrec >= 0xfffffff0ull || s->n_cigar + ncig >= 0xfffffff0ull) { s->err = "more than 2^32 records in one session"; return COV_ERR_INVALID_ARG; }
-    if (nrec) {
-        const uint64_t R = s->n_records, C = s->n_cigar, Nn = R + nrec;
-        HIPCHK(s->s_tid.reserve(Nn, st, R)); HIPCHK(s->s_pos.reserve(Nn, st, R)); HIPCHK(s->s_flag.reserve(Nn, st, R));
-        HIPCHK(s->s_mapq.reserve(Nn, st, R)); HIPCHK(s->s_nmk.reserve(Nn, st, R)); HIPCHK(s->s_nm.reserve(Nn, st, R));
-        HIPCHK(s->s_lseq.reserve(Nn, st, R)); HIPCHK(s->s_coff.reserve(Nn + 1, st, R + 1));
-        HIPCHK(s->s_cig.reserve(C + ncig + 1, st, C));
-        covi::RecStore RS{};
-        RS.tid = s->s_tid.p; RS.pos = s->s_pos.p; RS.flag = s->s_flag.p; RS.mapq = s->s_mapq.p; RS.nm_kind = s->s_nmk.p; RS.nm = s->s_nm.p;
-        RS.l_seq = s->s_lseq.p; RS.cigar_off = s->s_coff.p; RS.cigar = s->s_cig.p; RS.rec0 = R; RS.cig0 = C;
-        HIPCHK(hipEventRecord(e1, st));
-        hipLaunchKernelGGL(covi::k_bam_extract, dim3((S.n_seg + 63) / 64), dim3(64), 0, st, S, (const covi::SegInfo *)s->g_seg.p, (const u64 *)s->g_recbase.p,
-                           (const u64 *)s->g_cigbase.p, RS, reinterpret_cast<u32 *>(s->g_result.p + 3) + 1);
-        HIPCHK(hipGetLastError());
-        const u32 end_off = (u32)(C + ncig);
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(s->s_coff.p + Nn), (int)end_off, 1, st));
-        HIPCHK(hipEventRecord(e2, st));
-        HIPCHK(hipMemcpyAsync(res, s->g_result.p, 32, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if ((u32)(res[3] >> 32)) { s->err = "device ingest: corrupt BAM record"; return COV_ERR_INGEST_FALLBACK; }
-        s->n_records = Nn; s->n_cigar = C + ncig;
+    if ((u32)(glob[3] >> 32)) { s->err = "device ingest: corrupt BAM record"; return COV_ERR_INGEST_FALLBACK; }
+    if (s->ing_rec_total) {
+        const u64 Nn = s->n_records + s->ing_rec_total, Cn = s->n_cigar + s->ing_cig_total;
+        const u32 end_off = (u32)Cn;
+        HIPCHK(hipMemcpyAsync(s->s_coff.p + Nn, &end_off, sizeof end_off, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        s->n_records = Nn; s->n_cigar = Cn;
         s->finished = false;
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, e1, e2) == hipSuccess) s->ing_ms_parse = ms;
     }
-    if (n_records_out) *n_records_out = nrec;
+    if (n_records_out) *n_records_out = s->ing_rec_total;
     return COV_OK;
 }
 
@@ -1174,16 +1250,19 @@ cov_status cov_ingest_release(cov_session *s) {
     if (!s) return COV_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(s->cfg.device));
     HIPCHK(hipStreamSynchronize(s->stream));
-    s->g_comp.release(); s->g_infl.release(); s->g_scratch.release(); s->g_blocks.release(); s->g_status.release(); s->g_seg.release();
-    s->g_recbase.release(); s->g_cigbase.release(); s->g_tok.release(); s->g_ntok.release(); s->g_tok2.release(); s->g_ntok2.release();
+    if (s->ing_aux) HIPCHK(hipStreamSynchronize(s->ing_aux));
+    if (s->ing_parse) HIPCHK(hipStreamSynchronize(s->ing_parse));
+    ingest_free_buffers(s);
     return COV_OK;
 }
 
-// Test hook: the inflated stream of the last ingest (bytes [offset, offset + n) copied to `out`).
+// Test hook: the inflated stream of the last ingest (bytes [offset, offset + n) copied to `out`) — kept only when the whole file
+// was a single window.
 cov_status cov_ingest_copy_inflated(cov_session *s, uint64_t offset, uint64_t n, void *out) {
     if (!s || offset + n > s->ing_infl || (n && !out)) return COV_ERR_INVALID_ARG;
+    if (s->ing_batch != 1) { s->err = "cov_ingest_copy_inflated: the file was parsed in several windows, the stream is gone"; return COV_ERR_STATE; }
     HIPCHK(hipSetDevice(s->cfg.device));
-    HIPCHK(hipMemcpyAsync(out, s->g_infl.p + offset, n, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(out, s->g_win[0].p + inflate_kernel(s).carry + offset, n, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return COV_OK;
 }

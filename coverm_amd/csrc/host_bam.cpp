@@ -1229,7 +1229,7 @@ int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const cov
     for (int k = 0; k < NS; k++) buf[k] = (uint8_t *)cov_host_alloc(piece);
     struct BufFree { uint8_t **b; ~BufFree() { for (int k = 0; k < NS; k++) if (b[k]) cov_host_free(b[k]); } } bf{buf};
     for (int k = 0; k < NS; k++) if (!buf[k]) return fail(-1, "no page-locked staging memory (is a HIP device usable?)");
-    if (cov_ingest_begin(s, size, size * 4 + (1u << 20), check_crc) != COV_OK) return fail(-1, cov_last_error(s));
+    if (cov_ingest_begin(s, size, hd->h.first_record, check_crc) != COV_OK) return fail(-1, cov_last_error(s));
     const double t_begin = now() - t_start;
     std::vector<cov_bgzf_block> blocks;
     uint64_t next_blk = 0, out_off = 0, pending_bsize = 0;     // absolute file offset of the next block header; running inflated size; BSIZE of a block whose header is read but whose end is not here yet
@@ -1336,7 +1336,7 @@ int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const cov
     if (next_blk != size) return fail(1, "truncated BGZF block at the end of the file");
     double t0 = now();
     uint64_t nrec = 0;
-    const cov_status rc = cov_ingest_end(s, hd->h.first_record, &nrec);
+    const cov_status rc = cov_ingest_end(s, &nrec);
     const double t_end = now() - t0;
     if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; timing[4] = t_begin; timing[5] = t_walk; timing[6] = t_feed; timing[7] = 0; }
     if (rc == COV_ERR_INGEST_FALLBACK) return fail(1, cov_last_error(s));

@@ -451,14 +451,18 @@ __global__ __launch_bounds__(256) void k_crc32(const BgzfBlock *__restrict__ blo
 }
 
 // ------------------------------------------------------------------------------------ BAM record parsing on the device
+// The inflated stream is parsed window by window (one window = the blocks of one k_inflate round, in its own buffer): the bytes
+// of a record cut by the window's end (the "tail") are carried in front of the next window's bytes, so a window always starts
+// on a record boundary at *p0 (device memory: it depends on the previous window's parse) and is parsed like a whole file.
 struct BamScan {
-    const uint8_t *u;      // inflated stream
-    u64 N;                 // its length
-    u64 p0;                // offset of the first record (after the header)
-    u64 seg_bytes;         // segment size
+    const uint8_t *u;      // window buffer: [carry - tail, carry) bytes carried over, [carry, N) this window's inflated blocks
+    u64 N;                 // end of the valid bytes
+    const u64 *p0;         // device: offset of the first record of this window (written by k_carry_in)
+    u64 seg_bytes;         // segment size; segment k covers [k * seg_bytes, (k + 1) * seg_bytes)
     u32 n_seg;
     int n_ref;
     const u32 *ref_len;    // n_ref entries
+    int final;             // last window of the file: a cut record is an error instead of a tail
 };
 
 __device__ __forceinline__ u32 ld32(const uint8_t *p) {   // unaligned little-endian load
@@ -517,14 +521,17 @@ struct SegInfo {
     u32 pad;
 };
 
-// One wave per segment: lanes test consecutive offsets for an 8-record plausible chain; the lowest hit wins.
+// One wave per segment: lanes test consecutive offsets for an 8-record plausible chain; the lowest hit wins.  The segment that
+// holds *p0 starts there by definition; segments below it are dead.
 __global__ __launch_bounds__(256) void k_bam_find(BamScan S, SegInfo *__restrict__ seg) {
     const int lane = threadIdx.x & 63;
     const u32 k = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (k >= S.n_seg) return;
-    const u64 lo = S.p0 + (u64)k * S.seg_bytes, hi = min(S.N, lo + S.seg_bytes);
+    const u64 p0 = *S.p0;
+    const u64 lo = (u64)k * S.seg_bytes, hi = min(S.N, lo + S.seg_bytes);
     u64 found = ~0ull;
-    if (k == 0) found = S.p0 < S.N ? S.p0 : ~0ull;
+    if (hi <= p0) {}
+    else if (lo <= p0) found = p0 < S.N ? p0 : ~0ull;
     else {
         for (u64 base = lo; base < hi && found == ~0ull; base += 64) {
             const u64 o = base + (u64)lane;
@@ -568,14 +575,17 @@ __global__ __launch_bounds__(64) void k_bam_hop(BamScan S, SegInfo *__restrict__
     seg[k] = s;
 }
 
-// Single workgroup: chain verification + exclusive scans over segments (records, CIGAR words).
-// result[0] = total records, [1] = total CIGAR words, [2] = status (0 ok, 1 chain mismatch, 2 truncated, 4 needs CPU reader).
+// Single workgroup: chain verification + exclusive scans over segments (records, CIGAR words) + the tail.
+// result[0] = records of this window, [1] = CIGAR words, [2] = status (0 ok, 1 chain mismatch, 2 truncated, 4 needs the CPU
+// reader, 8 tail larger than the carry buffer), [3] = offset where the tail starts (first byte no record of this window owns),
+// [4..6] = first bad segment / its start / where its hop landed.  The tail [result[3], N) goes to `carry`, its length to *carry_len.
 __global__ __launch_bounds__(1024) void k_bam_verify(BamScan S, SegInfo *__restrict__ seg, u64 *__restrict__ rec_base, u64 *__restrict__ cig_base,
-                                                     u64 *__restrict__ result) {
+                                                     u64 *__restrict__ result, uint8_t *__restrict__ carry, u64 carry_cap, u64 *__restrict__ carry_len) {
     __shared__ u64 s_rec[1024], s_cig[1024];
     __shared__ u32 s_bad;
+    __shared__ u64 s_tail, s_badk;
     const u32 t = threadIdx.x;
-    if (t == 0) s_bad = 0;
+    if (t == 0) { s_bad = 0; s_tail = min(*S.p0, S.N); s_badk = ~0ull; }    // no live segment: everything from p0 on is tail
     __syncthreads();
     const u32 per = (S.n_seg + 1023u) / 1024u;
     const u32 k0 = t * per, k1 = min(S.n_seg, k0 + per);
@@ -583,20 +593,31 @@ __global__ __launch_bounds__(1024) void k_bam_verify(BamScan S, SegInfo *__restr
     for (u32 k = k0; k < k1; k++) {
         const SegInfo s = seg[k];
         if (s.start == ~0ull) continue;
-        u64 want = S.N;
-        for (u32 j = k + 1; j < S.n_seg; j++) { const u64 st = seg[j].start; if (st != ~0ull) { want = st; break; } }
-        if (s.landed != want) { bad |= (want == S.N) ? 2u : 1u; atomicMin(&result[4], (u64)k); }
+        u64 want = S.N; bool last_live = true;
+        for (u32 j = k + 1; j < S.n_seg; j++) { const u64 st = seg[j].start; if (st != ~0ull) { want = st; last_live = false; break; } }
+        if (last_live) {
+            s_tail = s.landed;                                  // exactly one segment is the last live one
+            if (S.final && s.landed != S.N) { bad |= 2u; atomicMin(&s_badk, (u64)k); }
+        } else if (s.landed != want) { bad |= 1u; atomicMin(&s_badk, (u64)k); }
         if (s.flags & 1u) bad |= 4u;
         nr += s.n_rec; nc += s.n_cig;
     }
     if (bad) atomicOr(&s_bad, bad);
     s_rec[t] = nr; s_cig[t] = nc;
     __syncthreads();
+    const u64 tail = min(s_tail, S.N), tail_len = S.N - tail;
+    const bool tail_fits = tail_len <= carry_cap;
     if (t == 0) {
         u64 a = 0, c = 0;
         for (u32 i = 0; i < 1024; i++) { const u64 x = s_rec[i], y = s_cig[i]; s_rec[i] = a; s_cig[i] = c; a += x; c += y; }
-        result[0] = a; result[1] = c; result[2] = s_bad;
-        if (s_bad & 3u) { const u64 kb = result[4]; if (kb < S.n_seg) { result[5] = seg[kb].start; result[6] = seg[kb].landed; } }
+        u32 st = s_bad;
+        if (S.final && tail_len != 0) st |= 2u;
+        if (!tail_fits) st |= 8u;
+        result[0] = a; result[1] = c; result[2] = st; result[3] = tail;
+        const u64 kb = s_badk;
+        result[4] = kb;
+        if (kb < S.n_seg) { result[5] = seg[kb].start; result[6] = seg[kb].landed; }
+        *carry_len = tail_fits ? tail_len : 0ull;
     }
     __syncthreads();
     u64 a = s_rec[t], c = s_cig[t];
@@ -604,6 +625,17 @@ __global__ __launch_bounds__(1024) void k_bam_verify(BamScan S, SegInfo *__restr
         rec_base[k] = a; cig_base[k] = c;
         if (seg[k].start != ~0ull) { a += seg[k].n_rec; c += seg[k].n_cig; }
     }
+    if (tail_fits) for (u64 i = t; i < tail_len; i += 1024) carry[i] = S.u[tail + i];
+}
+
+// The previous window's tail goes in front of this window's bytes; *p0 = where this window's first record starts.
+// `first_off` = offset of the first record behind the BAM header (window 0 only).
+__global__ __launch_bounds__(1024) void k_carry_in(uint8_t *__restrict__ win, u64 carry_area, const uint8_t *__restrict__ carry,
+                                                   const u64 *__restrict__ carry_len, u64 first_off, u64 *__restrict__ p0) {
+    const u64 len = *carry_len;
+    uint8_t *d = win + carry_area - len;
+    for (u64 i = threadIdx.x; i < len; i += 1024) d[i] = carry[i];
+    if (threadIdx.x == 0) *p0 = carry_area - len + first_off;
 }
 
 struct RecStore {

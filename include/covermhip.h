@@ -193,16 +193,18 @@ cov_status cov_reserve(cov_session *s, uint64_t n_records, uint64_t n_cigar);
  * Device ingest (optional accelerator for hosts with few cores): the BGZF-compressed BAM goes to HBM as it is; the GPU inflates
  * every block (one lane per block, RFC 1951 decoder with LDS tables), checks its CRC-32, finds the record boundaries
  * (speculative per segment, verified to equal the serial hop) and writes the records straight into the session's record store —
- * the same store cov_push_batch appends to, so cov_finish does not care where the records came from.  The host only reads the
+ * the same store cov_push_batch appends to, so cov_finish does not care where the records came from.  The inflated stream
+ * exists only one window at a time (the blocks one inflate launch holds, ~3 GB; a record cut by a window's end is carried
+ * into the next), so device memory stays bounded whatever the file size.  The host only reads the
  * file into page-locked buffers, hops the 18-byte BGZF block headers and parses the BAM header (reference names / lengths,
  * offset of the first record in the inflated stream).
  *   cov_set_targets(s, ...)                         reference lengths: the record-boundary test uses them
- *   cov_ingest_begin(s, file_bytes, inflated_hint, check_crc)
+ *   cov_ingest_begin(s, file_bytes, first_record_offset, check_crc)       first_record_offset: in the inflated stream, behind the BAM header
  *   loop: cov_ingest_slot_wait(s, slot) -> fill the slot's buffer -> cov_ingest_feed(s, slot, buf, file_offset, n, blocks, n_blocks)
  *         (COV_INGEST_SLOTS staging buffers rotate; slot_wait may be called from a reader thread while another thread feeds;
  *          `blocks` = the BGZF blocks COMPLETED by this piece: offsets are absolute in the file / the inflated stream; the
  *          copy is asynchronous, the inflate kernels of these blocks run behind it)
- *   cov_ingest_end(s, first_record_offset, &n_records)
+ *   cov_ingest_end(s, &n_records)
  * Anything irregular (inflate or CRC failure, boundaries that do not verify, a CG:B,I long-CIGAR placeholder) makes
  * cov_ingest_end return COV_ERR_INGEST_FALLBACK with nothing appended: decode that file on the host and cov_push_batch it.
  */
@@ -212,13 +214,13 @@ typedef struct {
     uint64_t out_off; /* offset of its inflated bytes in the inflated stream (running sum of ISIZE) */
     uint32_t in_len, isize, crc, pad;
 } cov_bgzf_block;
-cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t inflated_bytes_hint, int check_crc);
+cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t first_record_offset, int check_crc);
 cov_status cov_ingest_slot_wait(cov_session *s, int slot);
 cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uint64_t file_offset, uint64_t n_bytes,
                            const cov_bgzf_block *blocks, uint32_t n_blocks);
-cov_status cov_ingest_end(cov_session *s, uint64_t first_record_offset, uint64_t *n_records);
+cov_status cov_ingest_end(cov_session *s, uint64_t *n_records);
 cov_status cov_ingest_release(cov_session *s); /* frees the compressed / inflated buffers (kept between files otherwise) */
-cov_status cov_ingest_copy_inflated(cov_session *s, uint64_t offset, uint64_t n, void *out); /* test hook */
+cov_status cov_ingest_copy_inflated(cov_session *s, uint64_t offset, uint64_t n, void *out); /* test hook; single-window files only */
 /* Test hook: the session's own record store copied back into caller-sized host arrays (host == NULL: only the counts). */
 cov_status cov_copy_records(cov_session *s, const cov_batch *host, uint64_t *n_records, uint64_t *n_cigar);
 

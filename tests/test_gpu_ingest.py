@@ -135,3 +135,19 @@ def test_device_ingest_hands_irregular_files_back(tmp_path):
         with pytest.raises(cbam.IngestFallback) as ei:
             cbam.gpu_ingest(s, p, threads=2)
         assert "CG:B,I" in str(ei.value)
+
+
+@pytest.mark.parametrize("mode,round_blocks,carry_kb", [("short", 64, 64), ("long", 64, 1024), ("short", 128, 4), ("carry_overflow", 64, 8)])
+def test_device_ingest_in_many_windows(tmp_path, mode, round_blocks, carry_kb):
+    """The inflated stream exists one window (= one inflate round) at a time; records cut by a window's end are carried into
+    the next.  With 64-block windows a 10 MB file takes ~10 windows (the three window buffers, four parse-state sets and both
+    token buffers all come round several times); long reads make nearly every window end inside a record; a record larger than
+    the carry buffer hands the file back."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, COVERM_INGEST_ROUND_BLOCKS=str(round_blocks), COVERM_INGEST_CARRY_KB=str(carry_kb))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "ingest_windows_worker.py"), mode, str(tmp_path)], capture_output=True, text=True,
+                       env=env, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "WINDOWS_OK " + mode in r.stdout
