@@ -133,7 +133,8 @@ struct cov_session {
     DevBuf<int32_t> d_depth;
 
     // device ingest (cov_ingest_*): compressed file and inflated stream in HBM, BGZF block table, record-boundary scratch
-    DevBuf<uint8_t> g_comp, g_scratch, g_carry;
+    DevBuf<uint8_t> g_scratch, g_carry;
+    DevBuf<uint8_t> g_cwin[3];                             // compressed bytes, one buffer per round in flight (file offsets biased by the round's origin)
     DevBuf<uint8_t> g_win[3];                              // inflated windows (one k_inflate round each): [carry area | blocks]
     DevBuf<covi::BgzfBlock> g_blocks;
     DevBuf<u32> g_status;
@@ -141,12 +142,17 @@ struct cov_session {
     DevBuf<u64> g_recbase[4], g_cigbase[4];
     // g_result: [3] inflate failures (u32) | extract failures (u32), [5] bytes in g_carry, [6] p0 of the window being parsed,
     // [8 + 8 * (w % 4) ..] result block of window w (k_bam_verify)
-    DevBuf<u64> g_result, g_tok, g_tok2;
+    DevBuf<u64> g_result;
+    DevBuf<covi::tokpos_t> g_tok, g_tok2;
     DevBuf<u32> g_ntok, g_ntok2;
     hipStream_t ing_aux = nullptr;                         // k_lz_resolve / k_crc32 of round i run beside k_inflate of round i + 1
-    hipStream_t ing_parse = nullptr;                       // record boundaries + extraction of window i run beside both
+    hipStream_t ing_parse = nullptr;                       // record boundaries of window i run beside both
+    hipStream_t ing_ext = nullptr;                         // extraction of verified windows: behind nothing but its own predecessors
     hipEvent_t ing_inf_done[2] = {nullptr, nullptr}, ing_lz_done[2] = {nullptr, nullptr};
-    hipEvent_t ing_ver_done[4] = {}, ing_ext_done[3] = {};
+    hipEvent_t ing_ver_done[4] = {}, ing_ext_done[3] = {}, ing_cdone[3] = {};
+    uint64_t ing_round_start = 0, ing_prev_end = 0, ing_ccap = 0;   // accumulating round: file offset its buffer starts at; end of the last payload seen; bytes a round may span
+    uint32_t ing_round_n = 0;                              // blocks of the accumulating round
+    int64_t ing_copy_cleared = -1;                         // highest round whose compressed buffer the copy stream may already write
     u64 *h_winres = nullptr;                               // page-locked: 4 x 8 words, the windows' result blocks
     struct WinInfo { u64 N = 0; u32 n_seg = 0; u64 comp_end = 0; };
     WinInfo ing_win[4];
@@ -416,8 +422,8 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
 }
 
 static void ingest_free_buffers(cov_session *s) {
-    s->g_comp.release(); s->g_scratch.release(); s->g_carry.release(); s->g_blocks.release(); s->g_status.release();
-    for (int k = 0; k < 3; k++) s->g_win[k].release();
+    s->g_scratch.release(); s->g_carry.release(); s->g_blocks.release(); s->g_status.release();
+    for (int k = 0; k < 3; k++) { s->g_win[k].release(); s->g_cwin[k].release(); }
     for (int k = 0; k < 4; k++) { s->g_seg[k].release(); s->g_recbase[k].release(); s->g_cigbase[k].release(); }
     s->g_tok.release(); s->g_ntok.release(); s->g_tok2.release(); s->g_ntok2.release();
 }
@@ -432,13 +438,14 @@ void cov_destroy(cov_session *s) {
     s->d_cx_list.release(); s->d_cx_cnt.release(); s->d_cx_cur.release(); s->d_cx_scan.release(); s->d_cx_top.release(); s->d_cx_runs.release();
     if (s->ing_aux) (void)hipStreamSynchronize(s->ing_aux);
     if (s->ing_parse) (void)hipStreamSynchronize(s->ing_parse);
+    if (s->ing_ext) { (void)hipStreamSynchronize(s->ing_ext); (void)hipStreamDestroy(s->ing_ext); }
     ingest_free_buffers(s);
     s->g_result.release();
     if (s->ing_aux) (void)hipStreamDestroy(s->ing_aux);
     if (s->ing_parse) (void)hipStreamDestroy(s->ing_parse);
     for (int k = 0; k < 2; k++) { if (s->ing_inf_done[k]) (void)hipEventDestroy(s->ing_inf_done[k]); if (s->ing_lz_done[k]) (void)hipEventDestroy(s->ing_lz_done[k]); }
     for (int k = 0; k < 4; k++) if (s->ing_ver_done[k]) (void)hipEventDestroy(s->ing_ver_done[k]);
-    for (int k = 0; k < 3; k++) if (s->ing_ext_done[k]) (void)hipEventDestroy(s->ing_ext_done[k]);
+    for (int k = 0; k < 3; k++) { if (s->ing_ext_done[k]) (void)hipEventDestroy(s->ing_ext_done[k]); if (s->ing_cdone[k]) (void)hipEventDestroy(s->ing_cdone[k]); }
     if (s->h_winres) (void)hipHostFree(s->h_winres);
     s->h_winres = nullptr;
     if (s->h_blocks) (void)hipHostFree(s->h_blocks);
@@ -930,32 +937,41 @@ cov_status cov_gathered(cov_session *root, uint32_t rank, cov_contig_stats *stat
 static_assert(sizeof(cov_bgzf_block) == sizeof(covi::BgzfBlock) && offsetof(cov_bgzf_block, in_len) == offsetof(covi::BgzfBlock, in_len) &&
               offsetof(cov_bgzf_block, out_off) == offsetof(covi::BgzfBlock, out_off), "cov_bgzf_block mirrors the device struct");
 
-// Which k_inflate instantiation runs (COVERM_INFLATE_BITS / COVERM_INFLATE_LDS_SORTED: experiment switches), how many of its
+// Which k_inflate instantiation runs (COVERM_INFLATE_BITS / COVERM_INFLATE_DIST_BITS: primary table sizes), how many of its
 // one-wave workgroups the device holds at once (= blocks per round = blocks per window), and the size of the carry area.
-struct InflateKernel { int lit_bits = 8; bool lds_sorted = false; u32 round_blocks = 0; u64 carry = 16ull << 20; };
+struct InflateKernel { int lit_bits = 8, dist_bits = 6; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; };
+#define COV_INFLATE_VARIANTS(X) X(9, 6) X(8, 6) X(7, 6) X(7, 5) X(6, 5)
 static const InflateKernel &inflate_kernel(cov_session *s) {
     static InflateKernel K;
     static std::once_flag once;
     std::call_once(once, [&]() {
-        const char *e = getenv("COVERM_INFLATE_BITS");
-        K.lit_bits = e ? atoi(e) : 8;
-        if (K.lit_bits != 7 && K.lit_bits != 9) K.lit_bits = 8;
-        K.lds_sorted = getenv("COVERM_INFLATE_LDS_SORTED") && atoi(getenv("COVERM_INFLATE_LDS_SORTED")) && K.lit_bits != 9;
+        const char *e = getenv("COVERM_INFLATE_BITS"), *d = getenv("COVERM_INFLATE_DIST_BITS");
+        const int lb = e ? atoi(e) : 7, db = d ? atoi(d) : (lb <= 6 ? 5 : 6);     // 7 + 6 bits: five waves per CU, the fastest measured (200 M reads: 0.71 s against 0.87 s at 8 + 6, 0.84 s at 6 + 5)
         int per_cu = 0;
-#define COV_INF_SETUP(LB, LS)                                                                                                                  \
-        do {                                                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, LS>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                      (int)covi::inflate_smem_bytes(LB, LS));                                                                  \
-            if (K.lit_bits == LB && K.lds_sorted == LS)                                                                                        \
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate<LB, LS>, 64, covi::inflate_smem_bytes(LB, LS));    \
-        } while (0)
-        COV_INF_SETUP(7, false); COV_INF_SETUP(8, false); COV_INF_SETUP(9, false); COV_INF_SETUP(7, true); COV_INF_SETUP(8, true);
+        bool found = false;
+#define COV_INF_SETUP(LB, DB)                                                                                                                  \
+        if (lb == LB && db == DB) {                                                                                                            \
+            found = true; K.lit_bits = LB; K.dist_bits = DB;                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, DB>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                      (int)covi::inflate_smem_bytes(LB, DB));                                                                  \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate<LB, DB>, 64, covi::inflate_smem_bytes(LB, DB));        \
+        }
+        COV_INFLATE_VARIANTS(COV_INF_SETUP)
 #undef COV_INF_SETUP
+        if (!found) {
+            K.lit_bits = 7; K.dist_bits = 6;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<7, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)covi::inflate_smem_bytes(7, 6));
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate<7, 6>, 64, covi::inflate_smem_bytes(7, 6));
+        }
         if (per_cu <= 0) per_cu = 2;
         K.round_blocks = (u32)s->n_cus * (u32)per_cu * 64u;
         if (const char *w = getenv("COVERM_INGEST_ROUND_BLOCKS")) { const long v = atol(w); if (v >= 64) K.round_blocks = (u32)v / 64u * 64u; }   // tests: many small windows
         if (const char *c = getenv("COVERM_INGEST_CARRY_KB")) { const long v = atol(c); if (v >= 1) K.carry = (u64)v << 10; }
         K.carry = (K.carry + 63u) & ~63ull;
+        // compressed bytes one round may span: 32 KiB per block on average (BGZF blocks of BAM files compress to 15-25 KiB); a round of
+        // less compressible blocks simply closes earlier
+        K.cwin = std::max<u64>((u64)K.round_blocks * 32768u, 1ull << 20);
+        if (const char *c = getenv("COVERM_INGEST_CWIN_KB")) { const long v = atol(c); if (v >= 256) K.cwin = (u64)v << 10; }
     });
     return K;
 }
@@ -969,9 +985,10 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
         HIPCHK(hipEventCreateWithFlags(&s->ing_fed, hipEventDisableTiming));
         HIPCHK(hipStreamCreateWithFlags(&s->ing_aux, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&s->ing_parse, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&s->ing_ext, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_inf_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_lz_done[k], hipEventDisableTiming)); }
         for (int k = 0; k < 4; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ver_done[k], hipEventDisableTiming));
-        for (int k = 0; k < 3; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ext_done[k], hipEventDisableTiming));
+        for (int k = 0; k < 3; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_ext_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_cdone[k], hipEventDisableTiming)); }
         HIPCHK(hipHostMalloc((void **)&s->h_winres, 4 * 8 * sizeof(u64), hipHostMallocDefault));
     }
     if (s->adopted) {  // materialise an adopted device batch into the owned store first
@@ -984,7 +1001,6 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     s->ing_batch = 0; s->ing_extracted = 0; s->ing_rec_total = s->ing_cig_total = 0; s->ing_fail = 0;
     s->ing_first_record = first_record_offset;
     s->ing_check_crc = (check_crc && !getenv("COVERM_NO_CRC")) ? 1 : 0;
-    HIPCHK(s->g_comp.reserve(compressed_bytes + 64, s->stream));
     HIPCHK(s->g_result.reserve(8 + 4 * 8, s->stream));
     HIPCHK(s->g_carry.reserve(inflate_kernel(s).carry, s->stream));
     HIPCHK(s->g_blocks.reserve(compressed_bytes / 8192 + 1024, s->stream));
@@ -998,6 +1014,8 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     HIPCHK(hipMemsetAsync(s->g_result.p, 0, (8 + 4 * 8) * sizeof(u64), s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     s->ing_comp = compressed_bytes; s->ing_infl = 0; s->ing_blocks = 0; s->ing_launched = 0; s->ing_active = true;
+    s->ing_round_start = 0; s->ing_prev_end = 0; s->ing_round_n = 0; s->ing_copy_cleared = -1;
+    s->ing_ccap = std::min<u64>(inflate_kernel(s).cwin, compressed_bytes + 65536u + 128u);     // a small file is one buffer: the byte rule never fires
     s->ing_s_alloc = 0;
     return COV_OK;
 }
@@ -1005,10 +1023,10 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
 // Records of the windows whose boundaries are verified go into the store: all windows up to `must_upto` (waiting for their
 // k_bam_verify if need be), later ones only if their result is already here.
 static cov_status ingest_drain(cov_session *s, int64_t must_upto) {
-    hipStream_t ps = s->ing_parse;
+    hipStream_t ps = s->ing_ext;     // the host has seen the window's verification finish: nothing on the device to wait for
     while (s->ing_extracted < s->ing_batch) {
         const u32 w = s->ing_extracted, q = w & 3u;
-        if ((int64_t)w > must_upto) { if (hipEventQuery(s->ing_ver_done[q]) != hipSuccess) break; }
+        if ((int64_t)w > must_upto) { if (hipEventQuery(s->ing_ver_done[q]) != hipSuccess) { (void)hipGetLastError(); break; } }   // not ready is not an error
         else HIPCHK(hipEventSynchronize(s->ing_ver_done[q]));
         const u64 *res = s->h_winres + 8 * q;
         const u64 nrec = res[0], ncig = res[1];
@@ -1059,17 +1077,23 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
     const u32 n = (u32)n64, w = s->ing_batch, q = w & 3u;
     if (w >= 3) { const cov_status d = ingest_drain(s, (int64_t)w - 3); if (d != COV_OK) return d; }   // this window's buffer and parse state are free again
     const int bb = (int)(w & 1u);
-    DevBuf<u64> &tokb = bb ? s->g_tok2 : s->g_tok;
+    DevBuf<covi::tokpos_t> &tokb = bb ? s->g_tok2 : s->g_tok;
     DevBuf<u32> &ntokb = bb ? s->g_ntok2 : s->g_ntok;
     DevBuf<uint8_t> &win = s->g_win[w % 3u];
     const size_t full = std::max<size_t>(n, K.round_blocks);      // sized for a full round at once: no regrowth between rounds
     const size_t win_bytes = (size_t)K.carry + full * 65536u + 64u;
     const u32 seg_cap = (u32)((win_bytes + 32767u) / 32768u);
-    if (full * covi::INF_TOK_CAP > tokb.cap || full > ntokb.cap || (full + 63) / 64 * 64u * covi::INF_SCRATCH_BYTES > s->g_scratch.cap || win_bytes > win.cap ||
-        seg_cap > s->g_seg[q].cap) {
-        HIPCHK(hipStreamSynchronize(s->ing_aux)); HIPCHK(hipStreamSynchronize(s->ing_parse)); HIPCHK(hipStreamSynchronize(s->stream));   // a buffer is about to be replaced
+    {
+        // A buffer that has to GROW may still be in use: drain the device first.  First-time allocations need no such thing —
+        // and must not wait, or the first four windows (three window buffers, four parse-state sets) would run one after the other.
+        const size_t scr = (full + 63) / 64 * 64u * covi::INF_SCRATCH_BYTES;
+        auto grows = [](size_t need, size_t cap) { return cap != 0 && need > cap; };
+        if (grows(full * covi::INF_TOK_CAP, tokb.cap) || grows(full, ntokb.cap) || grows(scr, s->g_scratch.cap) || grows(win_bytes, win.cap) ||
+            grows(seg_cap, s->g_seg[q].cap)) {
+            HIPCHK(hipStreamSynchronize(s->ing_aux)); HIPCHK(hipStreamSynchronize(s->ing_parse)); HIPCHK(hipStreamSynchronize(s->ing_ext)); HIPCHK(hipStreamSynchronize(s->stream));
+        }
         const auto ta0 = std::chrono::steady_clock::now();
-        HIPCHK(s->g_scratch.reserve((full + 63) / 64 * 64u * covi::INF_SCRATCH_BYTES, s->stream));
+        HIPCHK(s->g_scratch.reserve(scr, s->stream));
         HIPCHK(tokb.reserve(full * covi::INF_TOK_CAP, s->stream));
         HIPCHK(ntokb.reserve(full, s->stream));
         HIPCHK(win.reserve(win_bytes, s->stream));
@@ -1087,20 +1111,20 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
         if (w >= 2) HIPCHK(hipStreamWaitEvent(s->stream, s->ing_lz_done[bb], 0));
         if (w >= 3) HIPCHK(hipStreamWaitEvent(s->stream, s->ing_ext_done[w % 3u], 0));
         const u32 grid = (n + 63u) / 64u;
+        const uint8_t *comp_bias = s->g_cwin[w % 3u].p - s->ing_round_start;     // blocks carry absolute file offsets
         static const u32 ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);
-#define COV_LAUNCH_INFLATE(LB, LS)                                                                                                              \
-        hipLaunchKernelGGL((covi::k_inflate<LB, LS>), dim3(grid), dim3(64), covi::inflate_smem_bytes(LB, LS), s->stream, (const uint8_t *)s->g_comp.p, \
-                           (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, s->g_scratch.p, tokb.p, ntokb.p,                                 \
-                           s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate)
-        if (K.lds_sorted) { if (K.lit_bits == 7) COV_LAUNCH_INFLATE(7, true); else COV_LAUNCH_INFLATE(8, true); }
-        else if (K.lit_bits == 7) COV_LAUNCH_INFLATE(7, false);
-        else if (K.lit_bits == 9) COV_LAUNCH_INFLATE(9, false);
-        else COV_LAUNCH_INFLATE(8, false);
+#define COV_LAUNCH_INFLATE(LB, DB)                                                                                                              \
+        if (K.lit_bits == LB && K.dist_bits == DB)                                                                                                  \
+            hipLaunchKernelGGL((covi::k_inflate<LB, DB>), dim3(grid), dim3(64), covi::inflate_smem_bytes(LB, DB), s->stream, comp_bias, \
+                               (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, s->g_scratch.p, tokb.p, ntokb.p,                             \
+                               s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
+        COV_INFLATE_VARIANTS(COV_LAUNCH_INFLATE)
 #undef COV_LAUNCH_INFLATE
         HIPCHK(hipEventRecord(s->ing_inf_done[bb], s->stream));
+        HIPCHK(hipEventRecord(s->ing_cdone[w % 3u], s->stream));      // this round's compressed buffer may be overwritten (three rounds on)
         HIPCHK(hipStreamWaitEvent(s->ing_aux, s->ing_inf_done[bb], 0));
         hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
-                           (const u64 *)tokb.p, (const u32 *)ntokb.p);
+                           (const covi::tokpos_t *)tokb.p, (const u32 *)ntokb.p);
         if (s->ing_check_crc)
             hipLaunchKernelGGL(covi::k_crc32, dim3((n + 255u) / 256u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n,
                                (const uint8_t *)out_bias, s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
@@ -1114,6 +1138,7 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
     S.n_ref = (int)s->n_targets; S.ref_len = s->d_tlen.p; S.final = final ? 1 : 0;
     s->ing_win[q].N = S.N; s->ing_win[q].n_seg = S.n_seg; s->ing_win[q].comp_end = n ? s->h_blocks[b0 + n - 1].in_off + s->h_blocks[b0 + n - 1].in_len + 8 : s->ing_comp;
     hipStream_t ps = s->ing_parse;
+    if (w >= 3) HIPCHK(hipStreamWaitEvent(ps, s->ing_ext_done[w % 3u], 0));     // the carried tail goes in front of a buffer whose records must be out
     hipLaunchKernelGGL(covi::k_carry_in, dim3(1), dim3(1024), 0, ps, win.p, K.carry, (const uint8_t *)s->g_carry.p, (const u64 *)(s->g_result.p + 5),
                        w == 0 ? s->ing_first_record : 0ull, s->g_result.p + 6);
     hipLaunchKernelGGL(covi::k_bam_find, dim3((S.n_seg + 3) / 4), dim3(256), 0, ps, S, s->g_seg[q].p);
@@ -1135,14 +1160,43 @@ cov_status cov_ingest_slot_wait(cov_session *s, int slot) {
     return COV_OK;
 }
 
+// Bytes [a, b) of the file (present in the staging piece that starts at file offset `piece_off`) go to the compressed buffer of
+// round r, whose first byte is file offset `origin`.
+static cov_status ingest_copy_range(cov_session *s, u32 r, u64 origin, u64 a, u64 b, const uint8_t *piece, u64 piece_off) {
+    if (b <= a) return COV_OK;
+    DevBuf<uint8_t> &cw = s->g_cwin[r % 3u];
+    const size_t need = (size_t)s->ing_ccap + 2 * 65536u + 256u;
+    if (cw.cap < need) {
+        if (cw.cap) { HIPCHK(hipStreamSynchronize(s->ing_copy)); HIPCHK(hipStreamSynchronize(s->stream)); }      // replaced while possibly in use
+        const auto ta0 = std::chrono::steady_clock::now();
+        HIPCHK(cw.reserve(need, s->stream));
+        s->ing_s_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta0).count();
+    }
+    if ((int64_t)r > s->ing_copy_cleared) {     // first bytes of this round: the k_inflate that read this buffer three rounds ago must be done
+        if (r >= 3) HIPCHK(hipStreamWaitEvent(s->ing_copy, s->ing_cdone[r % 3u], 0));
+        s->ing_copy_cleared = (int64_t)r;
+    }
+    if (a < origin || b - origin > cw.cap) { s->err = "cov_ingest_feed: internal error, bytes outside their round's buffer"; return COV_ERR_STATE; }
+    HIPCHK(hipMemcpyAsync(cw.p + (a - origin), piece + (a - piece_off), b - a, hipMemcpyHostToDevice, s->ing_copy));
+    return COV_OK;
+}
+
+// Table entries [from, ing_blocks) follow the bytes on the copy stream; ing_fed marks "everything fed so far is on the device"
+// (recorded even without new entries: the bytes in front of it may complete a round).
+static cov_status ingest_upload_table(cov_session *s, u64 from) {
+    if (from < s->ing_blocks)
+        HIPCHK(hipMemcpyAsync(s->g_blocks.p + from, s->h_blocks + from, (size_t)(s->ing_blocks - from) * sizeof(covi::BgzfBlock), hipMemcpyHostToDevice, s->ing_copy));
+    HIPCHK(hipEventRecord(s->ing_fed, s->ing_copy));
+    return COV_OK;
+}
+
 cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uint64_t file_offset, uint64_t n_bytes,
                            const cov_bgzf_block *blocks, uint32_t n_blocks) {
     if (!s || !s->ing_active || slot < 0 || slot >= COV_INGEST_SLOTS || (n_bytes && !host_bytes) || (n_blocks && !blocks)) return COV_ERR_INVALID_ARG;
     if (file_offset + n_bytes > s->ing_comp) { s->err = "cov_ingest_feed: bytes beyond the size given to cov_ingest_begin"; return COV_ERR_INVALID_ARG; }
     HIPCHK(hipSetDevice(s->cfg.device));
-    if (n_bytes) HIPCHK(hipMemcpyAsync(s->g_comp.p + file_offset, host_bytes, n_bytes, hipMemcpyHostToDevice, s->ing_copy));
-    HIPCHK(hipEventRecord(s->ing_ev[slot], s->ing_copy));
-    if (n_blocks == 0) return COV_OK;
+    { const cov_status d = ingest_drain(s, -1); if (d != COV_OK) return d; }      // extraction of whatever got verified meanwhile
+    const InflateKernel &K = inflate_kernel(s);
     // block table: page-locked mirror (the async upload reads it later), then the device copy
     if (s->ing_blocks + n_blocks > s->h_blocks_cap) {
         const size_t nc = std::max<size_t>(s->ing_blocks + n_blocks, s->h_blocks_cap * 2 + 4096);
@@ -1152,29 +1206,51 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
         if (s->h_blocks) { memcpy(nb, s->h_blocks, s->ing_blocks * sizeof(covi::BgzfBlock)); (void)hipHostFree(s->h_blocks); }
         s->h_blocks = nb; s->h_blocks_cap = nc;
     }
-    uint64_t infl_end = s->ing_infl;
+    if (s->ing_blocks + n_blocks > s->g_blocks.cap || s->ing_blocks + n_blocks > s->g_status.cap) {
+        HIPCHK(hipStreamSynchronize(s->ing_copy)); HIPCHK(hipStreamSynchronize(s->ing_aux)); HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(s->g_blocks.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
+        HIPCHK(s->g_status.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
+    }
+    // A round (= the blocks of one k_inflate launch, decoded into one window) closes when it holds as many blocks as the device
+    // keeps resident, or when the next block might no longer fit its compressed buffer.  The decision only looks at where the
+    // previous payload ended, so the bytes of a block that is still incomplete at the end of a piece already go to the buffer of
+    // the round the block will join.
+    const uint8_t *piece = (const uint8_t *)host_bytes;
+    const u64 piece_end = file_offset + n_bytes;
+    u64 cursor = file_offset, tbl_from = s->ing_blocks;
+    auto round_full = [&](u64 proxy) { return s->ing_round_n > 0 && (s->ing_round_n >= K.round_blocks || proxy + 65536u + 64u - s->ing_round_start > s->ing_ccap); };
     for (uint32_t i = 0; i < n_blocks; i++) {
         const cov_bgzf_block &b = blocks[i];
-        if (b.in_off + b.in_len > file_offset + n_bytes || b.isize > 65536u || b.out_off != infl_end) {
-            s->err = "cov_ingest_feed: block outside the bytes fed so far, or not contiguous in the inflated stream"; return COV_ERR_INVALID_ARG;
+        if (b.in_off < s->ing_prev_end || b.in_off + b.in_len > piece_end || b.isize > 65536u || b.in_len > 65536u || b.out_off != s->ing_infl) {
+            s->err = "cov_ingest_feed: block outside the bytes fed so far, out of order, or not contiguous in the inflated stream"; return COV_ERR_INVALID_ARG;
+        }
+        const u64 proxy = s->ing_prev_end;
+        if (round_full(proxy)) {
+            if (proxy > cursor) { const cov_status c = ingest_copy_range(s, s->ing_batch, s->ing_round_start, cursor, proxy, piece, file_offset); if (c != COV_OK) return c; cursor = proxy; }
+            { const cov_status c = ingest_upload_table(s, tbl_from); if (c != COV_OK) return c; tbl_from = s->ing_blocks; }
+            const cov_status lrc = launch_round(s, s->ing_round_n, false);
+            if (lrc != COV_OK) return lrc;
+            s->ing_round_start = proxy; s->ing_round_n = 0;
         }
         covi::BgzfBlock d; d.in_off = b.in_off; d.out_off = b.out_off; d.in_len = b.in_len; d.isize = b.isize; d.crc = b.crc; d.pad = 0;
-        s->h_blocks[s->ing_blocks + i] = d;
-        infl_end = b.out_off + b.isize;
+        s->h_blocks[s->ing_blocks] = d;
+        s->ing_blocks++; s->ing_round_n++;
+        s->ing_prev_end = b.in_off + b.in_len; s->ing_infl = b.out_off + b.isize;
     }
-    if (s->ing_blocks + n_blocks > s->g_blocks.cap || s->ing_blocks + n_blocks > s->g_status.cap) {
-        HIPCHK(hipStreamSynchronize(s->ing_aux)); HIPCHK(hipStreamSynchronize(s->stream));
+    {   // what is left of the piece: the rest of the current round, and the beginning of a block that may open the next one
+        const u64 proxy = s->ing_prev_end;
+        if (round_full(proxy)) {
+            const u64 cut = std::min(std::max(cursor, proxy), piece_end);
+            cov_status c = ingest_copy_range(s, s->ing_batch, s->ing_round_start, cursor, cut, piece, file_offset);
+            if (c == COV_OK) c = ingest_copy_range(s, s->ing_batch + 1u, proxy, cut, piece_end, piece, file_offset);
+            if (c != COV_OK) return c;
+        } else {
+            const cov_status c = ingest_copy_range(s, s->ing_batch, s->ing_round_start, cursor, piece_end, piece, file_offset);
+            if (c != COV_OK) return c;
+        }
     }
-    HIPCHK(s->g_blocks.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
-    HIPCHK(s->g_status.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
-    HIPCHK(hipMemcpyAsync(s->g_blocks.p + s->ing_blocks, s->h_blocks + s->ing_blocks, (size_t)n_blocks * sizeof(covi::BgzfBlock), hipMemcpyHostToDevice, s->ing_copy));
-    HIPCHK(hipEventRecord(s->ing_fed, s->ing_copy));
-    s->ing_blocks += n_blocks; s->ing_infl = infl_end;
-    // full rounds of resident waves leave as soon as their blocks are here; the remainder goes with cov_ingest_end
-    {
-        const uint64_t round = inflate_kernel(s).round_blocks;
-        while (s->ing_blocks - s->ing_launched > round) { const cov_status lrc = launch_round(s, round, false); if (lrc != COV_OK) return lrc; }
-    }
+    { const cov_status c = ingest_upload_table(s, tbl_from); if (c != COV_OK) return c; }
+    HIPCHK(hipEventRecord(s->ing_ev[slot], s->ing_copy));
     return COV_OK;
 }
 
@@ -1184,10 +1260,10 @@ cov_status cov_ingest_end(cov_session *s, uint64_t *n_records_out) {
     HIPCHK(hipSetDevice(s->cfg.device));
     if (n_records_out) *n_records_out = 0;
     const InflateKernel &K = inflate_kernel(s);
-    while (s->ing_blocks - s->ing_launched > K.round_blocks) { const cov_status lrc = launch_round(s, K.round_blocks, false); if (lrc != COV_OK) return lrc; }
-    { const cov_status lrc = launch_round(s, s->ing_blocks - s->ing_launched, true); if (lrc != COV_OK) return lrc; }     // the last window (possibly only the carried tail)
+    { const cov_status lrc = launch_round(s, s->ing_round_n, true); if (lrc != COV_OK) return lrc; }     // the last round: whatever the open one holds
     { const cov_status d = ingest_drain(s, (int64_t)s->ing_batch); if (d != COV_OK) return d; }
     u64 glob[8];
+    HIPCHK(hipStreamSynchronize(s->ing_ext));
     HIPCHK(hipMemcpyAsync(glob, s->g_result.p, sizeof glob, hipMemcpyDeviceToHost, s->ing_parse));
     HIPCHK(hipStreamSynchronize(s->ing_parse));
     HIPCHK(hipStreamSynchronize(s->ing_aux));
@@ -1252,6 +1328,7 @@ cov_status cov_ingest_release(cov_session *s) {
     HIPCHK(hipStreamSynchronize(s->stream));
     if (s->ing_aux) HIPCHK(hipStreamSynchronize(s->ing_aux));
     if (s->ing_parse) HIPCHK(hipStreamSynchronize(s->ing_parse));
+    if (s->ing_ext) HIPCHK(hipStreamSynchronize(s->ing_ext));
     ingest_free_buffers(s);
     return COV_OK;
 }

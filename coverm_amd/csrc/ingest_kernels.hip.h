@@ -37,23 +37,24 @@ struct BgzfBlock {
     u32 in_len, isize, crc, pad;
 };
 
-constexpr int INF_DIST_BITS = 6, INF_DIST_N = 1 << INF_DIST_BITS;
-// Per-lane LDS, lane-interleaved u16 entries (entry i of lane l at [i * 64 + l]): primary tables + per-length code counts of both
-// alphabets.  With LIT_BITS-bit literal/length tables a wave takes 64 x (2^LIT_BITS + 64 + 32) x 2 B: 76 KiB at 9 bits (two waves
-// per CU), 44 KiB at 8 (three), 28 KiB at 7 (five).  In SIMT the canonical walk for longer codes is paid whenever ANY lane needs
-// it — practically every step — so a smaller table costs little and more waves per CU hide more latency (COVERM_INFLATE_BITS).
-// lds_sorted: the symbols-by-code-length arrays (288 + 32 u16 per lane) live in LDS too, so the canonical walk never goes to
-// global memory (+40 KiB per wave).
-// The distance alphabet's sorted symbols (32 u16 per lane) are always in LDS, and so are the four length / distance base and
-// extra-bit tables (shared by the wave): a match then costs no global load at all.
-constexpr size_t inflate_smem_bytes(int lit_bits, bool lds_sorted = false) { return (size_t)64 * ((1u << lit_bits) + INF_DIST_N + 32 + (lds_sorted ? 288 : 0)) * 2 + 256; }
+// Per-lane LDS, lane-interleaved u16 entries (entry i of lane l at [i * 64 + l]): the primary tables of both alphabets and the
+// distance alphabet's symbols sorted by (length, value).  A wave takes 64 x (2^LIT_BITS + 2^DIST_BITS + 32) x 2 B: 44 KiB at
+// 8 + 6 bits (three waves per CU), 28 KiB at 7 + 6 (five), 24 KiB at 7 + 5 (six), 16 KiB at 6 + 5 (nine).  In SIMT the
+// canonical search for longer codes is paid whenever ANY lane needs it — practically every step — so a smaller table costs
+// little by itself, and a lane decodes its block serially at the latency of a dependent instruction chain: more resident
+// waves are what raises throughput (COVERM_INFLATE_BITS / COVERM_INFLATE_DIST_BITS).
+constexpr size_t inflate_smem_bytes(int lit_bits, int dist_bits) { return (size_t)64 * ((1u << lit_bits) + (1u << dist_bits) + 32) * 2; }
 // Per-lane global scratch: symbols sorted by (code length, value) for codes longer than the primary tables, and the code lengths
 // while a table is being built:  u16 lit_sorted[288], dist_sorted[32], u8 lens[320]
 constexpr u32 INF_SCRATCH_BYTES = 288 * 2 + 32 * 2 + 320;
 // LZ77 matches are not copied by k_inflate (a byte-serial copy by ONE lane would stall the other 63 of its wave on every match):
 // it writes the literals at their final positions and one token per match; k_lz_resolve then executes the tokens of each block in
-// order with a whole wave per block.  Token = pos | len << 16 | dist << 32.
+// order with a whole wave per block.  A token lives IN PLACE, in the first three output bytes of its own match (a match is at
+// least three bytes long: (dist - 1) | (len - 3) << 15 takes 23 bits); only its 16-bit output position goes to a side list.
+// 43 KiB of list per block instead of 171 KiB of 64-bit tokens: the side buffers of a round stay small however many blocks a
+// round holds (device allocations beyond ~60 GB in total were measured to cost seconds).
 constexpr u32 INF_TOK_CAP = 21888;   // >= 65536 / 3 matches per block
+typedef unsigned short tokpos_t;
 
 enum { INF_OK = 0, INF_ERR_FORMAT = 1, INF_ERR_CRC = 2, INF_ERR_SIZE = 3 };
 
@@ -195,31 +196,25 @@ __device__ __forceinline__ int decode_sym(BitReader &br, const Huff &H, int lane
 
 // One lane per BGZF block: Huffman decoding only.  Literals go to out + out_off at their final positions, matches become
 // tokens (tok + local block index * INF_TOK_CAP, count in n_tok).  status[b] = INF_*.
-template <int INF_LIT_BITS, bool LDS_SORTED>
+template <int INF_LIT_BITS, int INF_DIST_BITS>
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
-                                                uint8_t *__restrict__ out, uint8_t *__restrict__ scratch, u64 *__restrict__ tok,
+                                                uint8_t *__restrict__ out, uint8_t *__restrict__ scratch, tokpos_t *__restrict__ tok,
                                                 u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 ablate) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     constexpr int INF_LIT_N = 1 << INF_LIT_BITS;
     const int lane = threadIdx.x & 63;
     Huff HL, HD;
     HL.tab = lds; HD.tab = lds + (size_t)64 * INF_LIT_N;
-    unsigned short *dsorted_lds = HD.tab + (size_t)64 * INF_DIST_N;   // 32 x 64
-    unsigned short *lsorted_lds = dsorted_lds + 64 * 32;             // 288 x 64 when LDS_SORTED
-    unsigned short *ctab = lsorted_lds + (LDS_SORTED ? 64 * 288 : 0);   // len_base[29] len_extra[29] dist_base[30] dist_extra[30] (+ pad): 128 u16
-    if (lane < 29) { ctab[lane] = c_len_base[lane]; ctab[32 + lane] = c_len_extra[lane]; }
-    if (lane < 30) { ctab[64 + lane] = c_dist_base[lane]; ctab[96 + lane] = c_dist_extra[lane]; }
-    __syncthreads();
+    unsigned short *dsorted_lds = HD.tab + (size_t)64 * (1 << INF_DIST_BITS);   // 32 x 64
     const u32 b = blockIdx.x * 64u + (u32)lane;
     if (b >= n_blocks) return;      // (after the wave-wide table fill above)
     const BgzfBlock B = blocks[b];
     uint8_t *sc = scratch + (size_t)b * INF_SCRATCH_BYTES;
     uint8_t *lens = sc + 640;
     HD.sorted = dsorted_lds + lane; HD.sstride = 64;
-    if (LDS_SORTED) { HL.sorted = lsorted_lds + lane; HL.sstride = 64; }
-    else { HL.sorted = (unsigned short *)sc; HL.sstride = 1; }
+    HL.sorted = (unsigned short *)sc; HL.sstride = 1;
     uint8_t *dst = out + B.out_off;
-    u64 *my_tok = tok + (size_t)b * INF_TOK_CAP;
+    tokpos_t *my_tok = tok + (size_t)b * INF_TOK_CAP;
     u32 pos = 0, err = INF_OK, nt = 0;
     // Literals are gathered eight at a time and leave as one 8-byte store: a byte store per symbol from 64 lanes is 64 separate
     // L2 transactions, and every wait for an input word also waits for the stores in front of it.
@@ -343,7 +338,14 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
                 br.refill();
                 const u32 dist = (dsu < 4u ? 1u + dsu : 1u + ((2u + (dsu & 1u)) << de)) + (de ? br.take(de) : 0u);
                 if (dist > pos || pos + len > B.isize || nt >= INF_TOK_CAP) { err = INF_ERR_FORMAT; break; }
-                if (!(ablate & 2u)) my_tok[nt] = (u64)pos | ((u64)len << 16) | ((u64)dist << 32);
+                if (!(ablate & 2u)) {
+                    my_tok[nt] = (tokpos_t)pos;
+                    const u32 t24 = (dist - 1u) | ((len - 3u) << 15);
+                    uint8_t *d = dst + pos;
+                    // one 4-byte store where it fits: the byte behind the token is this match's own or is written later by this lane
+                    if (pos + 4u <= B.isize) __builtin_memcpy(d, &t24, 4);
+                    else { d[0] = (uint8_t)t24; d[1] = (uint8_t)(t24 >> 8); d[2] = (uint8_t)(t24 >> 16); }
+                }
                 nt++;
                 pos += len;
             }
@@ -357,26 +359,40 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     if (err != INF_OK) atomicAdd(n_failed, 1u);
 }
 
+// Inclusive wave64 prefix sum (DPP row shifts + row broadcasts; VALU latency only).
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return (u32)v;
+}
+
 // One wave per BGZF block executes the block's match tokens.  64 tokens are taken at a time, one per lane; a token may only
 // run once every byte it reads is final: everything below the output position of the lowest unfinished token is (literals were
 // written by k_inflate, earlier matches are done), so in each round the lanes whose source range ends at or below that
-// position copy their matches concurrently (byte loops, four loads in flight), the stores are drained, and the frontier moves
+// position are copied concurrently (their bytes spread over the 64 lanes), the stores are drained, and the frontier moves
 // on.  Matches mostly reach a record or more back while a window of 64 tokens spans a few records, so a window takes a few
 // rounds instead of 64 dependent load-store round trips.
 __global__ __launch_bounds__(256) void k_lz_resolve(const BgzfBlock *__restrict__ blocks, u32 n_blocks, uint8_t *__restrict__ out,
-                                                    const u64 *__restrict__ tok, const u32 *__restrict__ n_tok) {
+                                                    const tokpos_t *__restrict__ tok, const u32 *__restrict__ n_tok) {
     const int lane = threadIdx.x & 63;
     const u32 b = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (b >= n_blocks) return;
     const u32 nt = n_tok[b];
     if (nt == 0u) return;
     uint8_t *dst = out + blocks[b].out_off;
-    const u64 *my = tok + (size_t)b * INF_TOK_CAP;
+    const tokpos_t *my = tok + (size_t)b * INF_TOK_CAP;
     for (u32 t0 = 0; t0 < nt; t0 += 64u) {
         const u32 t = t0 + (u32)lane;
         const bool have = t < nt;
-        const u64 tk = have ? my[t] : 0ull;
-        const u32 pos = have ? (u32)(tk & 0xffffu) : 0xffffffffu, len = (u32)(tk >> 16) & 0xffffu, dist = (u32)(tk >> 32);
+        const u32 pos = have ? (u32)my[t] : 0xffffffffu;
+        u32 t24 = 0;
+        if (have) { const uint8_t *tp = dst + pos; t24 = (u32)tp[0] | ((u32)tp[1] << 8) | ((u32)tp[2] << 16); }    // written by k_inflate (the kernel before this one)
+        const u32 len = have ? ((t24 >> 15) & 0xffu) + 3u : 0u, dist = have ? (t24 & 0x7fffu) + 1u : 0u;
         const u32 src_lo = pos - dist, src_end = pos - dist + min(len, dist), dst_end = pos + len;
         // Output ranges of the window's tokens are disjoint and increasing with the lane, so the tokens whose output overlaps
         // this lane's source range form a contiguous lane interval [dep_lo, dep_hi): dep_hi = lanes with pos < src_end,
@@ -395,19 +411,27 @@ __global__ __launch_bounds__(256) void k_lz_resolve(const BgzfBlock *__restrict_
         u64 todo = __ballot(have);
         while (todo) {
             const bool go = have && ((todo >> lane) & 1ull) && (todo & dep_mask) == 0ull;
-            if (go) {
-                const uint8_t *src = dst + src_lo;
-                uint8_t *d = dst + pos;
-                if (dist >= len) {
-                    u32 k = 0;
-                    for (; k + 4u <= len; k += 4u) {
-                        const uint8_t a0 = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a1 = __hip_atomic_load(src + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                      a2 = __hip_atomic_load(src + k + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a3 = __hip_atomic_load(src + k + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        d[k] = a0; d[k + 1] = a1; d[k + 2] = a2; d[k + 3] = a3;
-                    }
-                    for (; k < len; k++) d[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {        // overlapping match: the first `dist` bytes are final, the rest repeats them
-                    for (u32 k = 0; k < len; k++) d[k] = __hip_atomic_load(src + (k % dist), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // The bytes of all ready matches of this round, concatenated, are copied 64 at a time, one byte per lane: a match of
+            // 200 bytes costs four wave steps, not 200 dependent round trips of its one lane.  Owner of byte x = the lane whose
+            // running length first exceeds x (binary search over the lanes' inclusive prefix sums, 6 shuffles).
+            const u32 glen = go ? len : 0u;
+            const u32 incl = wave_incl_scan_u32(glen), excl = incl - glen;
+            const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            for (u32 base = 0; base < total; base += 64u) {
+                const u32 x = base + (u32)lane;
+                u32 o = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const u32 v = (u32)__shfl((int)incl, (int)(o + step - 1));
+                    if (v <= x) o += step;             // o + step <= 64 always: o grows by distinct powers of two below 64
+                }
+                const u32 oc = min(o, 63u);
+                const u32 po = (u32)__shfl((int)pos, (int)oc), dd = (u32)__shfl((int)dist, (int)oc), ex = (u32)__shfl((int)excl, (int)oc),
+                          ln = (u32)__shfl((int)len, (int)oc);
+                if (x < total) {
+                    const u32 k = x - ex;
+                    const u32 sk = dd >= ln ? k : k % dd;      // overlapping match: its first `dist` bytes are final, the rest repeats them
+                    dst[po + k] = __hip_atomic_load(dst + po - dd + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -137,16 +137,23 @@ def test_device_ingest_hands_irregular_files_back(tmp_path):
         assert "CG:B,I" in str(ei.value)
 
 
-@pytest.mark.parametrize("mode,round_blocks,carry_kb", [("short", 64, 64), ("long", 64, 1024), ("short", 128, 4), ("carry_overflow", 64, 8)])
-def test_device_ingest_in_many_windows(tmp_path, mode, round_blocks, carry_kb):
+@pytest.mark.parametrize("mode,round_blocks,carry_kb,cwin_kb,piece_kb", [("short", 64, 64, 0, 0), ("long", 64, 1024, 0, 0), ("short", 128, 4, 0, 0),
+                                                                         ("carry_overflow", 64, 8, 0, 0), ("short", 256, 64, 512, 64),
+                                                                         ("long", 4096, 1024, 300, 200)])
+def test_device_ingest_in_many_windows(tmp_path, mode, round_blocks, carry_kb, cwin_kb, piece_kb):
     """The inflated stream exists one window (= one inflate round) at a time; records cut by a window's end are carried into
     the next.  With 64-block windows a 10 MB file takes ~10 windows (the three window buffers, four parse-state sets and both
     token buffers all come round several times); long reads make nearly every window end inside a record; a record larger than
-    the carry buffer hands the file back."""
+    the carry buffer hands the file back.  cwin_kb bounds the compressed bytes of a round instead (rounds then close on bytes, not
+    on block counts), with 64 KiB staging pieces so that blocks complete several feeds after their first bytes arrived."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, COVERM_INGEST_ROUND_BLOCKS=str(round_blocks), COVERM_INGEST_CARRY_KB=str(carry_kb))
+    if cwin_kb:
+        env["COVERM_INGEST_CWIN_KB"] = str(cwin_kb)
+    if piece_kb:
+        env["COVERM_INGEST_PIECE_KB"] = str(piece_kb)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "ingest_windows_worker.py"), mode, str(tmp_path)], capture_output=True, text=True,
                        env=env, cwd=root, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]

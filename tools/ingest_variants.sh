@@ -1,0 +1,17 @@
+#!/bin/bash
+# coverm-amd wall time over one synthetic BAM on tmpfs for several k_inflate table sizes: tools/ingest_variants.sh <reads> "<lb,db> ..." [reps]
+R=$GRAFT_REPO_ROOT
+READS=${1:-50000000}; VARS=${2:-"8,6 7,6 7,5 6,5"}; REPS=${3:-2}
+python $R/tools/make_bam.py /dev/shm/variants.bam $READS 16
+CMD="$R/coverm_amd/coverm-amd contig -b /dev/shm/variants.bam -m mean trimmed_mean covered_fraction variance -t 16 -o /dev/shm/variants.tsv"
+for v in $VARS; do
+  lb=${v%,*}; db=${v#*,}
+  for r in $(seq $REPS); do
+    s=$(date +%s.%N)
+    COVERM_INFLATE_BITS=$lb COVERM_INFLATE_DIST_BITS=$db COVERM_CLI_TIMING=1 $CMD 2> /tmp/variants.err
+    e=$(date +%s.%N)
+    echo "lit $lb dist $db: wall $(python -c "print(round($e - $s, 3))") s | $(grep -h 'windows of' /tmp/variants.err | sed 's/.*ingest: //') | $(grep -h 'device ingest: buffers' /tmp/variants.err | sed 's/.*device ingest: //')"
+    md5sum /dev/shm/variants.tsv | cut -c1-12
+  done
+done
+rm -f /dev/shm/variants.bam /dev/shm/variants.tsv
