@@ -22,10 +22,14 @@ runs = [("device ingest", {})] * int(os.environ.get("PROBE_REPS", "2")) + [("dev
 if not os.environ.get("PROBE_NO_CPU"):
     runs.append(("cpu stream", {"COVERM_NO_GPU_INGEST": "1"}))
 for name, env in runs:
+    time.sleep(float(os.environ.get("PROBE_SLEEP", "0")))
     t = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, COVERM_CLI_TIMING="1", **env))
     dt = time.time() - t
     print("%s: wall %.3fs = %.1f M reads/s (rc %d)" % (name, dt, reads / dt / 1e6, r.returncode), flush=True)
+    stamps = [float(l.split()[-1]) for l in r.stderr.splitlines() if "wall clock at" in l]
+    if len(stamps) == 2:
+        print("    spawn -> main() %.3fs, main() %.3fs, exit -> reaped %.3fs" % (stamps[0] - t, stamps[1] - stamps[0], t + dt - stamps[1]))
     for l in r.stderr.splitlines():
         if "ingest" in l or "VmHWM" in l or "stream read" in l or "main:" in l:
             print("    " + l)
