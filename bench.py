@@ -230,6 +230,9 @@ def end_to_end(a, threads):
                 best = (dt, rss, p.stderr)
         gpu_s, gpu_rss, gpu_err = best
         mapped = [l for l in gpu_err.splitlines() if "reads mapped out of" in l]
+        hwm = [l for l in gpu_err.splitlines() if "VmHWM" in l]
+        if hwm:     # the process's own peak resident set; getrusage(RUSAGE_CHILDREN) starts from this (large) parent's image at fork time
+            gpu_rss = int(hwm[0].split()[-2]) * 1024
         timing = [l for l in gpu_err.splitlines() if "stream read" in l or "ingest" in l or "VmHWM" in l or "main:" in l]
         # ---- CPU, same basis: same decoder + oracle scan
         L = cbam._lib()
