@@ -418,7 +418,7 @@ def main():
             "roofline": roof,
             "host": {"generation_s": gen_s, "nproc": os.cpu_count(), "usable_cpus": usable_cpus()},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:     # CPU legs (parity at full size, baselines, end to end) on rank 0 at N = 1 only
             threads = max(1, int(os.environ.get("COVERM_BENCH_THREADS", usable_cpus())))
             par, (cpu_mapped, cpu_dt) = parity_check(ref, batch, gpu_cov, stats, hist)
             out["parity_checked"] = par
