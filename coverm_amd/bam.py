@@ -158,10 +158,11 @@ def read_streamed(path: str, threads: int = None, span_index: int = 0, span_coun
                                     coff, cat("cigar"))
 
 
-def gpu_ingest(session, path: str, threads: int = None, check_crc: bool = True, mask=None):
+def gpu_ingest(session, path: str, threads: int = None, check_crc: bool = True, mask=None, span=(0, 1)):
     """Device ingest (covh_bam_read_header + covh_bam_gpu_ingest): the GPU inflates the BGZF blocks, finds the records and fills
     the session's record store.  Sets the session's targets from the file's header.  Returns (ref_names, ref_lens, n_records,
-    timing dict); raises IngestFallback when the file needs the CPU reader."""
+    timing dict); raises IngestFallback when the file needs the CPU reader.  span = (index, count): one tid span of the file
+    (covh_bam_gpu_ingest_span; the spans of a file partition its records in order)."""
     L = _lib()
     if not getattr(L, "_ingest_bound", False):
         L.covh_bam_read_header.restype = C.c_void_p
@@ -176,8 +177,8 @@ def gpu_ingest(session, path: str, threads: int = None, check_crc: bool = True, 
         L.covh_bam_header_target_len.argtypes = [C.c_void_p, C.c_uint32]
         L.covh_bam_header_first_record.restype = C.c_uint64
         L.covh_bam_header_first_record.argtypes = [C.c_void_p]
-        L.covh_bam_gpu_ingest.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double),
-                                          C.c_char_p, C.c_size_t]
+        L.covh_bam_gpu_ingest_span.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
+                                               C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
         L._ingest_bound = True
     if threads is None:
         threads = min(16, os.cpu_count() or 1)
@@ -192,7 +193,7 @@ def gpu_ingest(session, path: str, threads: int = None, check_crc: bool = True, 
         session.set_targets(lens, mask)
         n = C.c_uint64(0)
         t = (C.c_double * 8)()
-        rc = L.covh_bam_gpu_ingest(path.encode(), threads, session._h, hd, int(check_crc), C.byref(n), t, err, 512)
+        rc = L.covh_bam_gpu_ingest_span(path.encode(), threads, session._h, hd, int(check_crc), int(span[0]), int(span[1]), C.byref(n), t, err, 512)
         if rc == 1:
             raise IngestFallback(err.value.decode())
         if rc != 0:

@@ -153,6 +153,10 @@ struct cov_session {
     uint64_t ing_round_start = 0, ing_prev_end = 0, ing_ccap = 0;   // accumulating round: file offset its buffer starts at; end of the last payload seen; bytes a round may span
     uint32_t ing_round_n = 0;                              // blocks of the accumulating round
     int64_t ing_copy_cleared = -1;                         // highest round whose compressed buffer the copy stream may already write
+    long long ing_key_lo = 0, ing_key_hi = 0x80000000ll;   // cov_ingest_span: records outside [key_lo, key_hi) are not taken
+    bool ing_search_first = false, ing_open_end = false, ing_fed_any = false;
+    uint64_t ing_span_lo = 0, ing_span_hi = 0;             // file bytes the span covers (store size estimate)
+    uint64_t ing_tail_key = ~0ull;                         // key of the record cut by the end of the last window (~0: none)
     u64 *h_winres = nullptr;                               // page-locked: 4 x 8 words, the windows' result blocks
     struct WinInfo { u64 N = 0; u32 n_seg = 0; u64 comp_end = 0; };
     WinInfo ing_win[4];
@@ -1015,8 +1019,17 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     HIPCHK(hipStreamSynchronize(s->stream));
     s->ing_comp = compressed_bytes; s->ing_infl = 0; s->ing_blocks = 0; s->ing_launched = 0; s->ing_active = true;
     s->ing_round_start = 0; s->ing_prev_end = 0; s->ing_round_n = 0; s->ing_copy_cleared = -1;
+    s->ing_key_lo = 0; s->ing_key_hi = 0x80000000ll; s->ing_search_first = false; s->ing_open_end = false; s->ing_fed_any = false;
+    s->ing_span_lo = 0; s->ing_span_hi = compressed_bytes; s->ing_tail_key = ~0ull;
     s->ing_ccap = std::min<u64>(inflate_kernel(s).cwin, compressed_bytes + 65536u + 128u);     // a small file is one buffer: the byte rule never fires
     s->ing_s_alloc = 0;
+    return COV_OK;
+}
+
+cov_status cov_ingest_span(cov_session *s, int64_t key_lo, int64_t key_hi, int search_first_record, int open_end, uint64_t file_lo, uint64_t file_hi) {
+    if (!s || !s->ing_active || s->ing_fed_any || key_lo < 0 || key_hi < key_lo || file_hi < file_lo || file_hi > s->ing_comp) return COV_ERR_INVALID_ARG;
+    s->ing_key_lo = key_lo; s->ing_key_hi = key_hi; s->ing_search_first = search_first_record != 0; s->ing_open_end = open_end != 0;
+    s->ing_span_lo = file_lo; s->ing_span_hi = file_hi;
     return COV_OK;
 }
 
@@ -1031,13 +1044,14 @@ static cov_status ingest_drain(cov_session *s, int64_t must_upto) {
         const u64 *res = s->h_winres + 8 * q;
         const u64 nrec = res[0], ncig = res[1];
         const u32 st = (u32)res[2];
+        s->ing_tail_key = res[7];
         if (st && !s->ing_fail) { s->ing_fail = st; s->ing_fail_dbg[0] = res[4]; s->ing_fail_dbg[1] = res[5]; s->ing_fail_dbg[2] = res[6]; }
         const u64 R = s->n_records + s->ing_rec_total, Cg = s->n_cigar + s->ing_cig_total;
         if (!s->ing_fail && (R + nrec >= 0xfffffff0ull || Cg + ncig >= 0xfffffff0ull)) s->ing_fail = 16u;
         if (!s->ing_fail && nrec) {
             u64 Nn = R + nrec, Cn = Cg + ncig + 1;
             if (w == 0 && s->ing_batch > 1 && s->ing_win[0].comp_end) {    // first of several windows: size the store for the whole file at once
-                const double scale = (double)s->ing_comp / (double)s->ing_win[0].comp_end * 1.1;
+                const double scale = (double)(s->ing_span_hi - s->ing_span_lo) / (double)std::max<u64>(1, s->ing_win[0].comp_end - std::min<u64>(s->ing_win[0].comp_end, s->ing_span_lo)) * 1.1;
                 Nn = std::max<u64>(Nn, R + (u64)((double)nrec * scale) + 1024); Cn = std::max<u64>(Cn, Cg + (u64)((double)ncig * scale) + 1024);
                 Nn = std::min<u64>(Nn, 0xfffffff0ull); Cn = std::min<u64>(Cn, 0xfffffff0ull);
             }
@@ -1052,7 +1066,7 @@ static cov_status ingest_drain(cov_session *s, int64_t must_upto) {
             RS.l_seq = s->s_lseq.p; RS.cigar_off = s->s_coff.p; RS.cigar = s->s_cig.p; RS.rec0 = R; RS.cig0 = Cg;
             covi::BamScan S{};
             S.u = s->g_win[w % 3u].p; S.N = s->ing_win[q].N; S.p0 = s->g_result.p + 6; S.seg_bytes = 32768; S.n_seg = s->ing_win[q].n_seg;
-            S.n_ref = (int)s->n_targets; S.ref_len = s->d_tlen.p; S.final = 0;
+            S.n_ref = (int)s->n_targets; S.ref_len = s->d_tlen.p; S.final = 0; S.key_lo = s->ing_key_lo; S.key_hi = s->ing_key_hi; S.search_first = 0;
             hipLaunchKernelGGL(covi::k_bam_extract, dim3((S.n_seg + 63) / 64), dim3(64), 0, ps, S, (const covi::SegInfo *)s->g_seg[q].p, (const u64 *)s->g_recbase[q].p,
                                (const u64 *)s->g_cigbase[q].p, RS, reinterpret_cast<u32 *>(s->g_result.p + 3) + 1);
             HIPCHK(hipGetLastError());
@@ -1135,7 +1149,8 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
     // ---- the window's records: tail of the previous window in front, boundaries, counts, the new tail
     covi::BamScan S{};
     S.u = win.p; S.N = K.carry + wbytes; S.p0 = s->g_result.p + 6; S.seg_bytes = 32768; S.n_seg = (u32)((S.N + S.seg_bytes - 1) / S.seg_bytes);
-    S.n_ref = (int)s->n_targets; S.ref_len = s->d_tlen.p; S.final = final ? 1 : 0;
+    S.n_ref = (int)s->n_targets; S.ref_len = s->d_tlen.p; S.final = (final && !s->ing_open_end) ? 1 : 0;
+    S.key_lo = s->ing_key_lo; S.key_hi = s->ing_key_hi; S.search_first = (w == 0 && s->ing_search_first) ? 1 : 0;
     s->ing_win[q].N = S.N; s->ing_win[q].n_seg = S.n_seg; s->ing_win[q].comp_end = n ? s->h_blocks[b0 + n - 1].in_off + s->h_blocks[b0 + n - 1].in_len + 8 : s->ing_comp;
     hipStream_t ps = s->ing_parse;
     if (w >= 3) HIPCHK(hipStreamWaitEvent(ps, s->ing_ext_done[w % 3u], 0));     // the carried tail goes in front of a buffer whose records must be out
@@ -1215,6 +1230,7 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
     // keeps resident, or when the next block might no longer fit its compressed buffer.  The decision only looks at where the
     // previous payload ended, so the bytes of a block that is still incomplete at the end of a piece already go to the buffer of
     // the round the block will join.
+    if (!s->ing_fed_any) { s->ing_fed_any = true; s->ing_round_start = file_offset; s->ing_prev_end = file_offset; }     // a span starts somewhere inside the file
     const uint8_t *piece = (const uint8_t *)host_bytes;
     const u64 piece_end = file_offset + n_bytes;
     u64 cursor = file_offset, tbl_from = s->ing_blocks;
@@ -1285,6 +1301,9 @@ cov_status cov_ingest_end(cov_session *s, uint64_t *n_records_out) {
         return (f & 16u) ? COV_ERR_INVALID_ARG : COV_ERR_INGEST_FALLBACK;
     }
     if ((u32)(glob[3] >> 32)) { s->err = "device ingest: corrupt BAM record"; return COV_ERR_INGEST_FALLBACK; }
+    if (s->ing_open_end && s->ing_tail_key != ~0ull && (long long)s->ing_tail_key < s->ing_key_hi) {
+        s->err = "device ingest: the bytes fed for this span end inside one of its own records (handing the span to the CPU reader)"; return COV_ERR_INGEST_FALLBACK;
+    }
     if (s->ing_rec_total) {
         const u64 Nn = s->n_records + s->ing_rec_total, Cn = s->n_cigar + s->ing_cig_total;
         const u32 end_off = (u32)Cn;

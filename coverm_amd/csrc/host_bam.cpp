@@ -1215,13 +1215,57 @@ uint64_t covh_bam_header_first_record(const covh_bam_header *h) { return h->h.fi
 // timing (optional, 5 doubles): seconds reading the file, waiting for staging slots, in cov_ingest_end, total, in cov_ingest_begin (allocation).
 int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint64_t *n_records,
                         double *timing, char *err, size_t errcap) {
+    return covh_bam_gpu_ingest_span(path, threads, s, hd, check_crc, 0, 1, n_records, timing, err, errcap);
+}
+
+// One tid span of the file through the device ingest (same span definition as covh_bam_stream_open: boundaries one past the
+// tid found at k / count of the file).  The bytes fed run from the BGZF block at the span's probe point to a margin behind the
+// first block that begins with a record of a later span (found by bisection over file offsets: the keys are sorted); the
+// device drops the records of the neighbouring spans at both ends.
+int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint32_t span_index,
+                             uint32_t span_count, uint64_t *n_records, double *timing, char *err, size_t errcap) {
     auto fail = [&](int rc, const std::string &e) { if (err && errcap) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; } return rc; };
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
+    if (n_records) *n_records = 0;
+    if (span_count == 0 || span_index >= span_count) return fail(-1, "span index out of range");
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(-1, std::string("Unable to find BAM file ") + path);
     struct FdClose { int fd; ~FdClose() { close(fd); } } fdc{fd};
-    const uint64_t size = hd->h.file_size;
+    const uint64_t file_size = hd->h.file_size;
+    uint64_t f_lo = 0, size = file_size;          // bytes [f_lo, size) are fed
+    int64_t key_lo = 0, key_hi = KEY_INF + 1;
+    uint64_t first_record = hd->h.first_record;
+    if (span_count > 1) {
+        const int32_t n_ref = (int32_t)hd->h.names.size();
+        std::vector<int64_t> B(span_count + 1, 0);
+        std::vector<uint64_t> boff(span_count + 1, 0);
+        for (uint32_t k = 1; k < span_count; k++) {
+            uint64_t bo = 0;
+            const int64_t key = probe_key(fd, file_size, file_size / span_count * k, n_ref, hd->h.lens.data(), &bo);
+            B[k] = std::max(B[k - 1], key >= KEY_INF ? KEY_INF : key + 1);
+            boff[k] = bo;
+        }
+        B[span_count] = KEY_INF + 1;
+        key_lo = B[span_index]; key_hi = B[span_index + 1];
+        if (span_index > 0) {
+            if (boff[span_index] == (uint64_t)-1 || key_lo >= key_hi) return 0;          // empty span: nothing to read
+            f_lo = boff[span_index]; first_record = 0;
+        } else if (key_hi <= 0) return 0;
+        if (span_index + 1 < span_count && boff[span_index + 1] != (uint64_t)-1) {
+            // smallest offset from which the first record found has a key >= key_hi
+            uint64_t lo = boff[span_index + 1], hi = file_size;
+            while (hi - lo > 65536) {
+                const uint64_t mid = lo + (hi - lo) / 2;
+                uint64_t bo = 0;
+                if (probe_key(fd, file_size, mid, n_ref, hd->h.lens.data(), &bo) >= key_hi) hi = mid; else lo = mid;
+            }
+            // every record of this span starts before that point and may run on for up to the carry size of the device ingest
+            const uint64_t want = hi + ((uint64_t)17 << 20);
+            if (want < file_size) { const uint64_t e = find_block_start(fd, file_size, want); if (e != (uint64_t)-1) size = e; }
+        }
+    }
+    const bool mid_start = f_lo != 0, open_end = size != file_size;
     size_t piece = (size_t)64 << 20;
     if (const char *pb = getenv("COVERM_INGEST_PIECE_KB")) { const long v = atol(pb); if (v >= 64) piece = (size_t)v << 10; }
     constexpr int NS = COV_INGEST_SLOTS;
@@ -1229,13 +1273,14 @@ int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const cov
     for (int k = 0; k < NS; k++) buf[k] = (uint8_t *)cov_host_alloc(piece);
     struct BufFree { uint8_t **b; ~BufFree() { for (int k = 0; k < NS; k++) if (b[k]) cov_host_free(b[k]); } } bf{buf};
     for (int k = 0; k < NS; k++) if (!buf[k]) return fail(-1, "no page-locked staging memory (is a HIP device usable?)");
-    if (cov_ingest_begin(s, size, hd->h.first_record, check_crc) != COV_OK) return fail(-1, cov_last_error(s));
+    if (cov_ingest_begin(s, file_size, first_record, check_crc) != COV_OK) return fail(-1, cov_last_error(s));
+    if (span_count > 1 && cov_ingest_span(s, key_lo, key_hi, mid_start ? 1 : 0, open_end ? 1 : 0, f_lo, size) != COV_OK) return fail(-1, cov_last_error(s));
     const double t_begin = now() - t_start;
     std::vector<cov_bgzf_block> blocks;
-    uint64_t next_blk = 0, out_off = 0, pending_bsize = 0;     // absolute file offset of the next block header; running inflated size; BSIZE of a block whose header is read but whose end is not here yet
+    uint64_t next_blk = f_lo, out_off = 0, pending_bsize = 0;     // absolute file offset of the next block header; running inflated size; BSIZE of a block whose header is read but whose end is not here yet
     uint8_t tail[64]; uint64_t tail_end = 0; size_t tail_len = 0;   // last bytes of the previous piece (a header may straddle)
     double t_read = 0, t_wait = 0, t_walk = 0, t_feed = 0;
-    const uint64_t n_pieces = (size + piece - 1) / piece;
+    const uint64_t n_pieces = (size - f_lo + piece - 1) / piece;
     // Hopping the block headers is a chain of dependent cache misses (~0.3 us per block, 0.28 s for the 944 k blocks of a 200 M-read
     // file) if one thread does it after the fact.  The pool thread that has just read a 4 MiB chunk hops the blocks that lie
     // entirely inside it while the bytes are still in its cache (first header found by its 16-byte signature); the coordinator
@@ -1294,7 +1339,7 @@ int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const cov
             }
             t_wait += now() - t0;
             t0 = now();
-            const uint64_t off = k * piece, n = std::min<uint64_t>(piece, size - off);
+            const uint64_t off = f_lo + k * piece, n = std::min<uint64_t>(piece, size - off);
             const size_t nch = (size_t)((n + chunk - 1) / chunk);
             std::atomic<bool> ok{true};
             uint8_t *dst = buf[slot];
@@ -1319,7 +1364,7 @@ int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const cov
                   ~Join() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); } } joiner{reader, mu, cv, stop};
     for (uint64_t k = 0; k < n_pieces; k++) {
         const int slot = (int)(k % NS);
-        const uint64_t off = k * piece, n = std::min<uint64_t>(piece, size - off);
+        const uint64_t off = f_lo + k * piece, n = std::min<uint64_t>(piece, size - off);
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return reader_failed || ready > k; });

@@ -155,7 +155,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
     const double t0 = now();
     std::vector<uint8_t> mask;
     check(s, cov_reset(s));
-    if (stream && span_count == 1 && !getenv("COVERM_NO_GPU_INGEST")) {
+    if (stream && !getenv("COVERM_NO_GPU_INGEST")) {
         // ---- device ingest: the compressed file goes to HBM, the GPU inflates, finds the records and fills its own store
         char err[512] = {0};
         covh_bam_header *hd = covh_bam_read_header(S.path.c_str(), err, sizeof err);
@@ -167,13 +167,13 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         if (R.by_names) { genome_table(R, S, mask); check(s, cov_set_target_mask(s, mask.data())); }
         S.t_open = now() - t0;
         uint64_t nrec = 0; double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int rc = covh_bam_gpu_ingest(S.path.c_str(), threads, s, hd, getenv("COVERM_NO_CRC") ? 0 : 1, &nrec, tm, err, sizeof err);
+        const int rc = covh_bam_gpu_ingest_span(S.path.c_str(), threads, s, hd, getenv("COVERM_NO_CRC") ? 0 : 1, span_index, span_count, &nrec, tm, err, sizeof err);
         if (rc < 0) die(err);
         if (rc == 0) {
             S.n_records = nrec; S.device_ingest = true;
             if (getenv("COVERM_CLI_TIMING"))
-                fprintf(stderr, "[coverm-amd] %s: device ingest: buffers %.3fs, file read %.3fs, staging waits %.3fs, header walk %.3fs, feed calls %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records\n",
-                        S.stoit.c_str(), tm[4], tm[0], tm[1], tm[5], tm[6], tm[2], tm[3], (unsigned long long)nrec);
+                fprintf(stderr, "[coverm-amd] %s span %u/%u: device ingest: buffers %.3fs, file read %.3fs, staging waits %.3fs, header walk %.3fs, feed calls %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records\n",
+                        S.stoit.c_str(), span_index, span_count, tm[4], tm[0], tm[1], tm[5], tm[6], tm[2], tm[3], (unsigned long long)nrec);
             S.t_ingest = now() - t0;
             S.stats.resize(S.tlen.size());
             cov_summary summ;

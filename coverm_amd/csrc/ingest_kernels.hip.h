@@ -487,7 +487,13 @@ struct BamScan {
     int n_ref;
     const u32 *ref_len;    // n_ref entries
     int final;             // last window of the file: a cut record is an error instead of a tail
+    // tid span (one rank of a span-sharded file): only records with key_lo <= key < key_hi are counted and extracted
+    // (key = tid, or 0x7fffffff for records without a reference, which sort last); search_first: the first window starts
+    // somewhere inside the file, its first record boundary is searched like any other segment's
+    long long key_lo, key_hi;
+    int search_first;
 };
+__device__ __forceinline__ long long rec_key(int tid) { return tid < 0 ? 0x7fffffffll : (long long)tid; }
 
 __device__ __forceinline__ u32 ld32(const uint8_t *p) {   // unaligned little-endian load
     const u64 a = (u64)p;
@@ -555,9 +561,9 @@ __global__ __launch_bounds__(256) void k_bam_find(BamScan S, SegInfo *__restrict
     const u64 lo = (u64)k * S.seg_bytes, hi = min(S.N, lo + S.seg_bytes);
     u64 found = ~0ull;
     if (hi <= p0) {}
-    else if (lo <= p0) found = p0 < S.N ? p0 : ~0ull;
+    else if (lo <= p0 && !S.search_first) found = p0 < S.N ? p0 : ~0ull;
     else {
-        for (u64 base = lo; base < hi && found == ~0ull; base += 64) {
+        for (u64 base = max(lo, p0); base < hi && found == ~0ull; base += 64) {
             const u64 o = base + (u64)lane;
             bool ok = false;
             if (o < hi) {
@@ -588,11 +594,14 @@ __global__ __launch_bounds__(64) void k_bam_hop(BamScan S, SegInfo *__restrict__
         const u32 bs = ld32(r);
         if (bs < 32u || q + 4 + (u64)bs > S.N) break;
         const u32 ncig = ld16(r + 16);
-        if (ncig == 2u) {    // `<l_seq>S <n>N` is the placeholder of a CIGAR stored in CG:B,I (SAM spec 4.2.2): leave the file to the CPU reader
-            const u32 c0 = ld32(r + 36 + r[12]);
-            if ((c0 & 15u) == 4u && (c0 >> 4) == ld32(r + 20)) fl |= 1u;
+        const long long key = rec_key((int)ld32(r + 4));
+        if (key >= S.key_lo && key < S.key_hi) {
+            if (ncig == 2u) {    // `<l_seq>S <n>N` is the placeholder of a CIGAR stored in CG:B,I (SAM spec 4.2.2): leave the file to the CPU reader
+                const u32 c0 = ld32(r + 36 + r[12]);
+                if ((c0 & 15u) == 4u && (c0 >> 4) == ld32(r + 20)) fl |= 1u;
+            }
+            nr++; nc += ncig;
         }
-        nr++; nc += ncig;
         q += 4 + (u64)bs;
     }
     s.landed = q; s.n_rec = nr; s.n_cig = nc; s.flags = fl;
@@ -641,6 +650,9 @@ __global__ __launch_bounds__(1024) void k_bam_verify(BamScan S, SegInfo *__restr
         const u64 kb = s_badk;
         result[4] = kb;
         if (kb < S.n_seg) { result[5] = seg[kb].start; result[6] = seg[kb].landed; }
+        // key of the record the tail begins with (~0 when there is no tail or its tid is not here yet): a span's reader checks
+        // that the record cut by the end of its bytes lies beyond its key range
+        result[7] = (tail_len >= 8) ? (u64)rec_key((int)ld32(S.u + tail + 4)) : ~0ull;
         *carry_len = tail_fits ? tail_len : 0ull;
     }
     __syncthreads();
@@ -717,10 +729,13 @@ __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__
     if (s.start == ~0ull) return;
     u64 q = s.start;
     u64 ri = R.rec0 + rec_base[k], ci = R.cig0 + cig_base[k];
-    for (u32 j = 0; j < s.n_rec; j++) {
+    for (u32 j = 0; j < s.n_rec && q < s.landed;) {
         const uint8_t *r = S.u + q;
         const u32 bs = ld32(r);
         const uint8_t *end = r + 4 + bs;
+        const long long key = rec_key((int)ld32(r + 4));
+        if (key < S.key_lo || key >= S.key_hi) { q += 4 + (u64)bs; continue; }
+        j++;
         const u32 l_read_name = r[12], n_cig = ld16(r + 16), l_seq = ld32(r + 20);
         R.tid[ri] = (int32_t)ld32(r + 4); R.pos[ri] = (int32_t)ld32(r + 8);
         R.mapq[ri] = r[13]; R.flag[ri] = (uint16_t)ld16(r + 18); R.l_seq[ri] = l_seq;

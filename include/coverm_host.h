@@ -193,6 +193,10 @@ uint32_t covh_bam_header_n_targets(const covh_bam_header *h);
 const char *covh_bam_header_target_name(const covh_bam_header *h, uint32_t i);
 uint64_t covh_bam_header_target_len(const covh_bam_header *h, uint32_t i);
 uint64_t covh_bam_header_first_record(const covh_bam_header *h); /* offset in the inflated stream */
+/* covh_bam_gpu_ingest_span: one tid span of the file (span definition of covh_bam_stream_open): only the span's part of the file
+ * is read and fed; 0 with *n_records = 0 for an empty span. */
+int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint32_t span_index,
+                             uint32_t span_count, uint64_t *n_records, double *timing8, char *err, size_t errcap);
 int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint64_t *n_records,
                         double *timing8, char *err, size_t errcap);   /* s: file read, staging waits, cov_ingest_end, total, buffers, block-header walk, cov_ingest_feed, 0 */
 

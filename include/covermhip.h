@@ -215,6 +215,12 @@ typedef struct {
     uint32_t in_len, isize, crc, pad;
 } cov_bgzf_block;
 cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t first_record_offset, int check_crc);
+/* Optional, between cov_ingest_begin and the first feed — one rank of a span-sharded file: only records with key_lo <= key < key_hi
+ * are taken (key = tid; 0x7fffffff for records without a reference, which sort last); search_first_record: the bytes fed start
+ * at a BGZF block somewhere inside the file (first_record_offset is then 0 and the first record boundary is searched);
+ * open_end: the bytes fed end before the file does, so a record cut by their end is expected — it must lie beyond key_hi,
+ * else COV_ERR_INGEST_FALLBACK; [file_lo, file_hi) = the file bytes that will be fed (sizes the record store once). */
+cov_status cov_ingest_span(cov_session *s, int64_t key_lo, int64_t key_hi, int search_first_record, int open_end, uint64_t file_lo, uint64_t file_hi);
 cov_status cov_ingest_slot_wait(cov_session *s, int slot);
 cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uint64_t file_offset, uint64_t n_bytes,
                            const cov_bgzf_block *blocks, uint32_t n_blocks);

@@ -158,3 +158,31 @@ def test_device_ingest_in_many_windows(tmp_path, mode, round_blocks, carry_kb, c
                        env=env, cwd=root, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "WINDOWS_OK " + mode in r.stdout
+
+
+@pytest.mark.parametrize("count", [2, 3, 5])
+def test_device_ingest_of_tid_spans_partitions_the_file(tmp_path, count):
+    """covh_bam_gpu_ingest_span: each span reads only its part of the file (bisection for its end), the device drops the neighbours'
+    records at both ends; the spans' records, in span order, are exactly the file's records, and equal the CPU span reader's."""
+    ref = synth.make_reference(40, 6_000_000, seed=18, min_len=5000, max_len=800_000)
+    b = synth.make_reads(ref, 150_000, seed=31)
+    p = str(tmp_path / "s.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=2, threads=4)
+    whole = cbam.read_alignment_file(p, threads=2, want_names=False).records
+    parts = []
+    for i in range(count):
+        with Session(0, FilterConfig(), 75) as s:
+            names, lens, n, _ = cbam.gpu_ingest(s, p, threads=3, span=(i, count))
+            got = cbam.session_records(s)
+            assert got.n_records == n
+            cpu = list(cbam.stream_batches(p, 2, span_index=i, span_count=count))[1:]
+            assert sum(x.n_records for x in cpu) == n
+            if n:
+                np.testing.assert_array_equal(got.pos, np.concatenate([x.pos for x in cpu]))
+            parts.append(got)
+    assert sum(x.n_records for x in parts) == whole.n_records
+    nonempty = [x for x in parts if x.n_records]
+    assert len(nonempty) >= 2
+    for f in ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq"):
+        np.testing.assert_array_equal(np.concatenate([getattr(x, f) for x in nonempty]), getattr(whole, f), err_msg=f)
+    np.testing.assert_array_equal(np.concatenate([x.cigar for x in nonempty]), whole.cigar)
