@@ -943,29 +943,30 @@ static_assert(sizeof(cov_bgzf_block) == sizeof(covi::BgzfBlock) && offsetof(cov_
 
 // Which k_inflate instantiation runs (COVERM_INFLATE_BITS / COVERM_INFLATE_DIST_BITS: primary table sizes), how many of its
 // one-wave workgroups the device holds at once (= blocks per round = blocks per window), and the size of the carry area.
-struct InflateKernel { int lit_bits = 8, dist_bits = 6; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; };
-#define COV_INFLATE_VARIANTS(X) X(9, 6) X(8, 6) X(7, 6) X(7, 5) X(6, 5)
+struct InflateKernel { int lit_bits = 8, dist_bits = 6; bool sort8 = false; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; };
+#define COV_INFLATE_VARIANTS(X) X(9, 6, false) X(8, 6, false) X(7, 6, false) X(7, 5, false) X(6, 5, false) X(7, 6, true) X(6, 5, true) X(5, 5, true)
 static const InflateKernel &inflate_kernel(cov_session *s) {
     static InflateKernel K;
     static std::once_flag once;
     std::call_once(once, [&]() {
         const char *e = getenv("COVERM_INFLATE_BITS"), *d = getenv("COVERM_INFLATE_DIST_BITS");
+        const bool s8 = getenv("COVERM_INFLATE_SORT8") && atoi(getenv("COVERM_INFLATE_SORT8"));
         const int lb = e ? atoi(e) : 7, db = d ? atoi(d) : (lb <= 6 ? 5 : 6);     // 7 + 6 bits: five waves per CU, the fastest measured (200 M reads: 0.71 s against 0.87 s at 8 + 6, 0.84 s at 6 + 5)
         int per_cu = 0;
         bool found = false;
-#define COV_INF_SETUP(LB, DB)                                                                                                                  \
-        if (lb == LB && db == DB) {                                                                                                            \
-            found = true; K.lit_bits = LB; K.dist_bits = DB;                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, DB>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                      (int)covi::inflate_smem_bytes(LB, DB));                                                                  \
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate<LB, DB>, 64, covi::inflate_smem_bytes(LB, DB));        \
+#define COV_INF_SETUP(LB, DB, S8)                                                                                                              \
+        if (lb == LB && db == DB && s8 == S8) {                                                                                                \
+            found = true; K.lit_bits = LB; K.dist_bits = DB; K.sort8 = S8;                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, DB, S8>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)covi::inflate_smem_bytes(LB, DB, S8));                                                              \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate<LB, DB, S8>, 64, covi::inflate_smem_bytes(LB, DB, S8)); \
         }
         COV_INFLATE_VARIANTS(COV_INF_SETUP)
 #undef COV_INF_SETUP
         if (!found) {
-            K.lit_bits = 7; K.dist_bits = 6;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<7, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)covi::inflate_smem_bytes(7, 6));
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate<7, 6>, 64, covi::inflate_smem_bytes(7, 6));
+            K.lit_bits = 7; K.dist_bits = 6; K.sort8 = false;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<7, 6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)covi::inflate_smem_bytes(7, 6));
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate<7, 6, false>, 64, covi::inflate_smem_bytes(7, 6));
         }
         if (per_cu <= 0) per_cu = 2;
         K.round_blocks = (u32)s->n_cus * (u32)per_cu * 64u;
@@ -1127,9 +1128,9 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
         const u32 grid = (n + 63u) / 64u;
         const uint8_t *comp_bias = s->g_cwin[w % 3u].p - s->ing_round_start;     // blocks carry absolute file offsets
         static const u32 ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);
-#define COV_LAUNCH_INFLATE(LB, DB)                                                                                                              \
-        if (K.lit_bits == LB && K.dist_bits == DB)                                                                                                  \
-            hipLaunchKernelGGL((covi::k_inflate<LB, DB>), dim3(grid), dim3(64), covi::inflate_smem_bytes(LB, DB), s->stream, comp_bias, \
+#define COV_LAUNCH_INFLATE(LB, DB, S8)                                                                                                          \
+        if (K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                                                 \
+            hipLaunchKernelGGL((covi::k_inflate<LB, DB, S8>), dim3(grid), dim3(64), covi::inflate_smem_bytes(LB, DB, S8), s->stream, comp_bias, \
                                (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, s->g_scratch.p, tokb.p, ntokb.p,                             \
                                s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
         COV_INFLATE_VARIANTS(COV_LAUNCH_INFLATE)

@@ -43,7 +43,10 @@ struct BgzfBlock {
 // canonical search for longer codes is paid whenever ANY lane needs it — practically every step — so a smaller table costs
 // little by itself, and a lane decodes its block serially at the latency of a dependent instruction chain: more resident
 // waves are what raises throughput (COVERM_INFLATE_BITS / COVERM_INFLATE_DIST_BITS).
-constexpr size_t inflate_smem_bytes(int lit_bits, int dist_bits) { return (size_t)64 * ((1u << lit_bits) + (1u << dist_bits) + 32) * 2; }
+// sort8: the literal/length alphabet's symbols sorted by (length, value) live in LDS too, one BYTE each (bit 8 of a symbol follows
+// from its rank: within a length the symbols >= 256 come last) — +18 KiB per wave, and the canonical path never goes to global
+// memory: a global load per symbol step (some lane of 64 always has a long code) was what each step waited for.
+constexpr size_t inflate_smem_bytes(int lit_bits, int dist_bits, bool sort8 = false) { return (size_t)64 * ((1u << lit_bits) + (1u << dist_bits) + 32) * 2 + (sort8 ? (size_t)64 * 288 : 0) + (size_t)64 * 8 * 4; }
 // Per-lane global scratch: symbols sorted by (code length, value) for codes longer than the primary tables, and the code lengths
 // while a table is being built:  u16 lit_sorted[288], dist_sorted[32], u8 lens[320]
 constexpr u32 INF_SCRATCH_BYTES = 288 * 2 + 32 * 2 + 320;
@@ -64,32 +67,49 @@ __constant__ unsigned short c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 
 __constant__ unsigned char c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ unsigned char c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-// Bit reader over one lane's compressed stream: 64-bit buffer refilled 4 bytes at a time with aligned dword loads.  The word
-// after the one being consumed is always in flight (`ahead`), so a refill seldom waits for memory.
+// Bit reader over one lane's compressed stream: 64-bit buffer refilled 4 bytes at a time — from a per-lane RESERVOIR of INF_RES
+// words in LDS, not from global memory.  A global load inside refill() is waited for on the spot (the refill is conditional per
+// lane, so its result is selected right behind it), and in SIMT some lane of the 64 needs a word at almost every refill: three
+// global round trips per symbol step, 67 % of the kernel's wave time.  The reservoir is topped up for ALL active lanes at once
+// (eight words each, two 16-byte loads) whenever any lane runs low: one wait per four to five symbol steps, and the word for the
+// next refill is read from LDS ahead of its use.
+constexpr u32 INF_RES = 8;
+struct __attribute__((packed, aligned(4))) Words4 { u32 a, b, c, d; };
 struct BitReader {
     const u32 *words;   // aligned base
+    u32 *res;           // LDS reservoir, word j of this lane at res[j * 64]
     u64 buf; u32 cnt;   // cnt valid bits in buf
-    u32 next_word, end_word;     // word indices
-    u32 consumed;                // bits consumed so far
-    u32 ahead;                   // words[next_word], already loaded
-    __device__ __forceinline__ u32 fetch(u32 i) const { return i < end_word ? words[i] : 0u; }   // zero padding past the end: errors surface as format / size errors
-    __device__ __forceinline__ void init(const uint8_t *base, u64 off, u32 len) {
-        const u64 a = (u64)(base + off);
-        const u32 mis = (u32)(a & 3u);
-        words = (const u32 *)(a - mis);
-        end_word = (mis + len + 3u) >> 2;
-        buf = (u64)fetch(0) | ((u64)fetch(1) << 32); cnt = 64u;
-        next_word = 2; ahead = fetch(2);
+    u32 next_word;      // index of the next word to enter buf
+    u32 rbase;          // index of the word in reservoir slot 0
+    u32 consumed;       // bits consumed so far
+    u32 ahead;          // words[next_word], already read from the reservoir
+    // Bytes behind the stream's end come from whatever follows it in the buffer (the buffers carry slack for this): a stream that
+    // runs past its end is caught by the consumed-bits / size / CRC checks, as the zero padding of earlier versions was.
+    __device__ __forceinline__ void reload() {
+        const Words4 x = *reinterpret_cast<const Words4 *>(words + next_word), y = *reinterpret_cast<const Words4 *>(words + next_word + 4);
+        res[0 * 64] = x.a; res[1 * 64] = x.b; res[2 * 64] = x.c; res[3 * 64] = x.d;
+        res[4 * 64] = y.a; res[5 * 64] = y.b; res[6 * 64] = y.c; res[7 * 64] = y.d;
+        rbase = next_word;
+    }
+    __device__ __forceinline__ void init(const uint8_t *base, u64 off, u32 len, u32 *reservoir) {
+        const u32 mis = (u32)((u64)(base + off) & 3u);
+        words = (const u32 *)(base + off - mis);        // derived from the kernel argument: stays a global (not flat) pointer
+        res = reservoir;
+        next_word = 0; reload();
+        buf = (u64)res[0] | ((u64)res[64] << 32); cnt = 64u;
+        next_word = 2; ahead = res[2 * 64];
         if (mis) { buf >>= 8 * mis; cnt -= 8 * mis; }
         consumed = 0;
+        (void)len;
     }
     __device__ __forceinline__ void refill() {
         if (cnt <= 32u) {
             buf |= (u64)ahead << cnt;
             cnt += 32u;
             next_word++;
-            ahead = fetch(next_word);
         }
+        if (__any(next_word - rbase >= INF_RES - 1u)) reload();      // decided for the active lanes together; a lane with words left just reloads early
+        ahead = res[(next_word - rbase) * 64u];
     }
     __device__ __forceinline__ u32 peek(u32 n) const { return (u32)buf & ((1u << n) - 1u); }
     __device__ __forceinline__ void drop(u32 n) { buf >>= n; cnt -= n; consumed += n; }
@@ -99,16 +119,23 @@ struct BitReader {
 // Sixteen 16-bit counters of one lane in four registers (counter l in bits (l & 3) * 16 of word l >> 2): per-length code
 // counts and running offsets while a table is built, without LDS round trips or dynamically indexed register arrays.
 struct Pack16 {
-    u64 w[4];
-    __device__ __forceinline__ void clear() { w[0] = w[1] = w[2] = w[3] = 0; }
+    // four named words, not an array: with an array the compiler turns get()'s select chain into a dynamically indexed load from
+    // scratch memory — a memory round trip (and a full s_waitcnt vmcnt(0)) in every symbol step
+    u64 w0, w1, w2, w3;
+    __device__ __forceinline__ void clear() { w0 = w1 = w2 = w3 = 0; }
     __device__ __forceinline__ u32 get(u32 l) const {
-        const u64 x = (l & 8u) ? ((l & 4u) ? w[3] : w[2]) : ((l & 4u) ? w[1] : w[0]);
+        const u64 lo = (l & 4u) ? w1 : w0, hi = (l & 4u) ? w3 : w2;
+        const u64 x = (l & 8u) ? hi : lo;
         return (u32)(x >> ((l & 3u) * 16u)) & 0xffffu;
+    }
+    template <u32 L> __device__ __forceinline__ u32 at() const {     // compile-time index
+        const u64 x = (L >> 2) == 0 ? w0 : (L >> 2) == 1 ? w1 : (L >> 2) == 2 ? w2 : w3;
+        return (u32)(x >> ((L & 3u) * 16u)) & 0xffffu;
     }
     __device__ __forceinline__ void add(u32 l, u32 v) {
         const u64 inc = (u64)v << ((l & 3u) * 16u);
         const u32 k = l >> 2;
-        w[0] += k == 0u ? inc : 0ull; w[1] += k == 1u ? inc : 0ull; w[2] += k == 2u ? inc : 0ull; w[3] += k == 3u ? inc : 0ull;
+        w0 += k == 0u ? inc : 0ull; w1 += k == 1u ? inc : 0ull; w2 += k == 2u ? inc : 0ull; w3 += k == 3u ? inc : 0ull;
     }
 };
 
@@ -122,25 +149,34 @@ struct Huff {
     // + count[l]) << (15 - l), non-decreasing in l, so l = 1 + #{l' : v >= limit[l']}; the symbol is sorted[off[l] + (v >> (15 - l))]
     // with off[l] = (index of the first symbol of length l) - (first code of length l)  (mod 2^16).  Both arrays live in registers.
     Pack16 limit, off;
+    // SORT8 (literal/length alphabet in LDS as bytes): sorted8[j * 64] = low byte of the j-th symbol; thr[l] = index of the first
+    // symbol >= 256 among those of length l (= end of the length's run when there is none)
+    uint8_t *sorted8;
+    Pack16 thr;
 };
 
 // Builds the lane's primary lookup table and counts (LDS) and the sorted symbols (global scratch) from code lengths
 // (`lens` is 4-byte aligned; one pass for the counts, one for the placement: O(n_sym)).
 // Primary entry: bits 0-3 code length (0 = longer than prim_bits: resolve canonically), bits 4-15 symbol.
+template <bool SORT8>
 __device__ __forceinline__ bool build_table(const uint8_t *lens, u32 n_sym, u32 prim_bits, int lane, Huff &H) {
     unsigned short *sorted = H.sorted; const u32 ss = H.sstride;
     Pack16 cnt; cnt.clear();
+    Pack16 cntlit; cntlit.clear();
     const u32 *lw = (const u32 *)lens;
     for (u32 s = 0; s < n_sym; s += 4) {
         u32 w = lw[s >> 2];
 #pragma unroll
-        for (u32 k = 0; k < 4; k++, w >>= 8) { const u32 l = w & 0xffu; if (s + k < n_sym && l) cnt.add(l & 15u, 1u); }
+        for (u32 k = 0; k < 4; k++, w >>= 8) {
+            const u32 l = w & 0xffu;
+            if (s + k < n_sym && l) { cnt.add(l & 15u, 1u); if (SORT8 && s + k < 256u) cntlit.add(l & 15u, 1u); }
+        }
     }
     // an over-subscribed set is an error; incomplete sets are tolerated (a single distance code is legal, anything else
     // decodes to -1 when an unassigned code appears and the block's CRC catches the rest)
     u32 left = 1;
     Pack16 offs; offs.clear();
-    H.limit.clear(); H.off.clear();
+    H.limit.clear(); H.off.clear(); H.thr.clear();
     {
         u32 run = 0, first = 0;
         for (u32 l = 1; l < 16; l++) {
@@ -149,6 +185,7 @@ __device__ __forceinline__ bool build_table(const uint8_t *lens, u32 n_sym, u32 
             offs.add(l, run);
             H.limit.add(l, min((first + c) << (15u - l), 0xffffu));      // 2^15 at most, except past a complete set (saturate)
             H.off.add(l, (run - first) & 0xffffu);
+            if (SORT8) H.thr.add(l, run + cntlit.get(l));
             run += c; first = (first + c) << 1;
         }
     }
@@ -157,7 +194,10 @@ __device__ __forceinline__ bool build_table(const uint8_t *lens, u32 n_sym, u32 
 #pragma unroll
         for (u32 k = 0; k < 4; k++, w >>= 8) {
             const u32 l = w & 0xffu;
-            if (s + k < n_sym && l) { sorted[offs.get(l & 15u) * ss] = (unsigned short)(s + k); offs.add(l & 15u, 1u); }
+            if (s + k < n_sym && l) {
+                if (SORT8) H.sorted8[offs.get(l & 15u) * 64u] = (uint8_t)(s + k); else sorted[offs.get(l & 15u) * ss] = (unsigned short)(s + k);
+                offs.add(l & 15u, 1u);
+            }
         }
     }
     const u32 N = 1u << prim_bits;
@@ -166,9 +206,9 @@ __device__ __forceinline__ bool build_table(const uint8_t *lens, u32 n_sym, u32 
     // packs Huffman codes MSB first into an LSB-first bit stream)
     u32 code = 0, idx = 0;
     for (u32 l = 1; l <= prim_bits; l++) {
-        const u32 c = cnt.get(l);
+        const u32 c = cnt.get(l), th = SORT8 ? H.thr.get(l) : 0u;
         for (u32 k = 0; k < c; k++, idx++, code++) {
-            const u32 sym = sorted[idx * ss];
+            const u32 sym = SORT8 ? (u32)H.sorted8[idx * 64u] + (idx >= th ? 256u : 0u) : (u32)sorted[idx * ss];
             const u32 rev = __brev(code) >> (32 - l);
             const unsigned short e = (unsigned short)((sym << 4) | l);
             for (u32 i = rev; i < N; i += 1u << l) H.tab[i * 64 + lane] = e;
@@ -178,25 +218,35 @@ __device__ __forceinline__ bool build_table(const uint8_t *lens, u32 n_sym, u32 
     return true;
 }
 
+// l += #{k in [K, 15) : v >= limit[k]}  (compile-time unrolled over the packed limits)
+template <u32 K>
+__device__ __forceinline__ void count_ge(const Pack16 &lim, u32 v, u32 &l) {
+    if constexpr (K < 15u) {
+        l += v >= lim.at<K>() ? 1u : 0u;
+        count_ge<K + 1u>(lim, v, l);
+    }
+}
+
 // Decodes one symbol: primary table, else the parallel length search described at Huff (no loop, no memory until the final
 // sorted[] lookup).
-template <int PRIM>
+template <int PRIM, bool SORT8>
 __device__ __forceinline__ int decode_sym(BitReader &br, const Huff &H, int lane) {
     const u32 pk = br.peek(PRIM);
     const u32 e = H.tab[pk * 64 + lane];
     if (e & 15u) { br.drop(e & 15u); return (int)(e >> 4); }
     const u32 v = __brev((u32)br.buf) >> 17;          // next 15 bits, first stream bit on top
     u32 l = PRIM + 1;
-#pragma unroll
-    for (u32 k = PRIM + 1; k < 15; k++) l += v >= ((u32)(H.limit.w[k >> 2] >> ((k & 3u) * 16u)) & 0xffffu) ? 1u : 0u;
+    count_ge<PRIM + 1>(H.limit, v, l);
     if (v >= H.limit.get(15)) return -1;               // not a code of this (incomplete) set
     br.drop(l);
-    return (int)H.sorted[((H.off.get(l) + (v >> (15u - l))) & 0xffffu) * H.sstride];
+    const u32 idx = (H.off.get(l) + (v >> (15u - l))) & 0xffffu;
+    if (SORT8) { const u32 ic = min(idx, 287u); return (int)((u32)H.sorted8[ic * 64u] + (ic >= H.thr.get(l) ? 256u : 0u)); }
+    return (int)H.sorted[idx * H.sstride];
 }
 
 // One lane per BGZF block: Huffman decoding only.  Literals go to out + out_off at their final positions, matches become
 // tokens (tok + local block index * INF_TOK_CAP, count in n_tok).  status[b] = INF_*.
-template <int INF_LIT_BITS, int INF_DIST_BITS>
+template <int INF_LIT_BITS, int INF_DIST_BITS, bool SORT8>
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                 uint8_t *__restrict__ out, uint8_t *__restrict__ scratch, tokpos_t *__restrict__ tok,
                                                 u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 ablate) {
@@ -206,6 +256,9 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     Huff HL, HD;
     HL.tab = lds; HD.tab = lds + (size_t)64 * INF_LIT_N;
     unsigned short *dsorted_lds = HD.tab + (size_t)64 * (1 << INF_DIST_BITS);   // 32 x 64
+    HL.sorted8 = reinterpret_cast<uint8_t *>(dsorted_lds + 64 * 32) + lane;        // 288 x 64 bytes when SORT8
+    unsigned short *lds_res = dsorted_lds + 64 * 32 + (SORT8 ? 32 * 288 : 0);     // INF_RES x 64 words: the bit readers' reservoirs
+    HD.sorted8 = nullptr;
     const u32 b = blockIdx.x * 64u + (u32)lane;
     if (b >= n_blocks) return;      // (after the wave-wide table fill above)
     const BgzfBlock B = blocks[b];
@@ -232,7 +285,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     };
     if (B.isize != 0u) {
         BitReader br;
-        br.init(comp, B.in_off, B.in_len);
+        br.init(comp, B.in_off, B.in_len, reinterpret_cast<u32 *>(lds_res) + lane);
         const u32 total_bits = B.in_len * 8u;
         bool last = false;
         while (!last && err == INF_OK) {
@@ -308,12 +361,12 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
                 for (u32 s = hdist; s-- > 0;) lens[288 + s] = lens[hlit + s];   // backwards: the two ranges overlap
                 for (u32 s = hlit; s < 288; s++) lens[s] = 0;
             }
-            if (!build_table(lens, hlit, INF_LIT_BITS, lane, HL)) { err = INF_ERR_FORMAT; break; }
-            if (!build_table(lens + 288, hdist, INF_DIST_BITS, lane, HD)) { err = INF_ERR_FORMAT; break; }
+            if (!build_table<SORT8>(lens, hlit, INF_LIT_BITS, lane, HL)) { err = INF_ERR_FORMAT; break; }
+            if (!build_table<false>(lens + 288, hdist, INF_DIST_BITS, lane, HD)) { err = INF_ERR_FORMAT; break; }
             // ---- symbols of this block
             for (;;) {
                 br.refill();
-                const int sym = decode_sym<INF_LIT_BITS>(br, HL, lane);
+                const int sym = decode_sym<INF_LIT_BITS, SORT8>(br, HL, lane);
                 if (sym < 256) {
                     if (sym < 0) { err = INF_ERR_FORMAT; break; }
                     if (pos >= B.isize) { err = INF_ERR_SIZE; break; }
@@ -331,7 +384,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
                 const u32 lb = li < 8u ? 3u + li : (li == 28u ? 258u : 3u + ((4u + (li & 3u)) << le));
                 const u32 len = lb + br.take(le);
                 br.refill();
-                const int ds = decode_sym<INF_DIST_BITS>(br, HD, lane);
+                const int ds = decode_sym<INF_DIST_BITS, false>(br, HD, lane);
                 if (ds < 0 || ds >= 30) { err = INF_ERR_FORMAT; break; }
                 const u32 dsu = (u32)ds;
                 const u32 de = dsu < 4u ? 0u : (dsu - 2u) >> 1;            // distance codes come in pairs sharing e extra bits
