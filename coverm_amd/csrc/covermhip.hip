@@ -1010,9 +1010,9 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     HIPCHK(s->g_carry.reserve(inflate_kernel(s).carry, s->stream));
     HIPCHK(s->g_blocks.reserve(compressed_bytes / 8192 + 1024, s->stream));
     HIPCHK(s->g_status.reserve(compressed_bytes / 8192 + 1024, s->stream));
-    if (compressed_bytes / 8192 + 1024 > s->h_blocks_cap) {     // page-locked mirror of the block table: sized once for ordinary ~20 KB blocks
+    if (compressed_bytes / 16384 + 1024 > s->h_blocks_cap) {     // page-locked mirror of the block table: sized once for ordinary ~20 KB blocks (it grows if they are smaller)
         if (s->h_blocks) { (void)hipHostFree(s->h_blocks); s->h_blocks = nullptr; s->h_blocks_cap = 0; }
-        const size_t nc = compressed_bytes / 8192 + 1024;
+        const size_t nc = compressed_bytes / 16384 + 1024;
         HIPCHK(hipHostMalloc((void **)&s->h_blocks, nc * sizeof(covi::BgzfBlock), hipHostMallocDefault));
         s->h_blocks_cap = nc;
     }
