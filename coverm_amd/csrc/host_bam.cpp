@@ -1270,9 +1270,8 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     if (const char *pb = getenv("COVERM_INGEST_PIECE_KB")) { const long v = atol(pb); if (v >= 64) piece = (size_t)v << 10; }
     constexpr int NS = COV_INGEST_SLOTS;
     uint8_t *buf[NS];
-    for (int k = 0; k < NS; k++) buf[k] = (uint8_t *)cov_host_alloc(piece);
+    for (int k = 0; k < NS; k++) buf[k] = nullptr;       // page-locked on first use by the reader thread: slots 1.. are pinned while piece 0 is already on its way
     struct BufFree { uint8_t **b; ~BufFree() { for (int k = 0; k < NS; k++) if (b[k]) cov_host_free(b[k]); } } bf{buf};
-    for (int k = 0; k < NS; k++) if (!buf[k]) return fail(-1, "no page-locked staging memory (is a HIP device usable?)");
     if (cov_ingest_begin(s, file_size, first_record, check_crc) != COV_OK) return fail(-1, cov_last_error(s));
     if (span_count > 1 && cov_ingest_span(s, key_lo, key_hi, mid_start ? 1 : 0, open_end ? 1 : 0, f_lo, size) != COV_OK) return fail(-1, cov_last_error(s));
     const double t_begin = now() - t_start;
@@ -1338,6 +1337,10 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
                 std::lock_guard<std::mutex> lk(mu); reader_failed = true; reader_err = cov_last_error(s); cv.notify_all(); return;
             }
             t_wait += now() - t0;
+            if (!buf[slot]) {
+                buf[slot] = (uint8_t *)cov_host_alloc(std::min<uint64_t>(piece, size - f_lo));
+                if (!buf[slot]) { std::lock_guard<std::mutex> lk(mu); reader_failed = true; reader_err = "no page-locked staging memory (is a HIP device usable?)"; cv.notify_all(); return; }
+            }
             t0 = now();
             const uint64_t off = f_lo + k * piece, n = std::min<uint64_t>(piece, size - off);
             const size_t nch = (size_t)((n + chunk - 1) / chunk);
