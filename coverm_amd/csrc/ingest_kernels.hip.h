@@ -6,11 +6,12 @@
 //
 //   k_inflate       one LANE per BGZF block (blocks are independent raw-DEFLATE members of <= 64 KiB, SAM spec 4.1):
 //                   a complete RFC 1951 decoder per lane — stored / fixed / dynamic blocks, Huffman decode through per-lane
-//                   lookup tables in LDS (9-bit literal/length, 6-bit distance primary tables; longer codes resolved
+//                   lookup tables in LDS (7-bit literal/length, 6-bit distance primary tables by default; longer codes resolved
 //                   canonically from per-length counts).  Literals are written in place, LZ77 matches become tokens.
 //                   64 blocks advance per wave instruction; divergence between lanes is what SIMT costs here, HBM
 //                   bandwidth is not the limit.
-//   k_lz_resolve    one WAVE per block executes its match tokens in order (64 lanes per copy)
+//   k_lz_resolve    one WAVE per block executes its match tokens (kept in place, in the first bytes of their own match), the
+//                   bytes of all matches that are ready spread over the 64 lanes
 //   k_crc32         every inflated block against the CRC-32 of its BGZF trailer
 //   k_bam_find      per segment of the inflated stream: first offset from which a chain of 8 plausible records starts
 //   k_bam_hop       per segment: hop the records (block_size chain), count records and CIGAR words, note where it landed
@@ -61,10 +62,6 @@ typedef unsigned short tokpos_t;
 
 enum { INF_OK = 0, INF_ERR_FORMAT = 1, INF_ERR_CRC = 2, INF_ERR_SIZE = 3 };
 
-__constant__ unsigned short c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ unsigned char c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ unsigned short c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ unsigned char c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ unsigned char c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // Bit reader over one lane's compressed stream: 64-bit buffer refilled 4 bytes at a time — from a per-lane RESERVOIR of INF_RES
