@@ -266,12 +266,9 @@ void time_end(cov_session *s, int k) { (void)hipEventRecord(s->ev[k][1], s->stre
 template <int TL, int NT, bool H, bool W>
 void launch_pileup_t(cov_session *s, const PileupArgs &a, u32 grid) {
     const size_t smem = pileup_smem_bytes(TL, NT, H);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup<TL, NT, H, W>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    // per launch, not once per process: the limit is a per-device attribute and this (non-default) kernel is the only one that
+    // can need more than the 64 KiB every device grants without it
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup<TL, NT, H, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL((k_pileup<TL, NT, H, W>), dim3(grid), dim3(NT), smem, s->stream, a);
 }
 // (tile, workgroup) geometries compiled in; session picks one (default 4096 x 256)
@@ -981,6 +978,17 @@ static const InflateKernel &inflate_kernel(cov_session *s) {
     return K;
 }
 
+// The dynamic-LDS limit of a kernel is a per-device attribute: every session's device gets it (inflate_kernel's own call only
+// reaches the device of the first session of the process).
+static void inflate_prepare_device(const InflateKernel &K) {
+#define COV_INF_ATTR(LB, DB, S8)                                                                                                                \
+    if (K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, DB, S8>), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                  (int)covi::inflate_smem_bytes(LB, DB, S8));
+    COV_INFLATE_VARIANTS(COV_INF_ATTR)
+#undef COV_INF_ATTR
+}
+
 cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t first_record_offset, int check_crc) {
     if (!s) return COV_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(s->cfg.device));
@@ -1004,6 +1012,7 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     }
     HIPCHK(hipStreamSynchronize(s->stream));     // the record store is about to be written from the parse stream
     s->ing_batch = 0; s->ing_extracted = 0; s->ing_rec_total = s->ing_cig_total = 0; s->ing_fail = 0;
+    inflate_prepare_device(inflate_kernel(s));
     s->ing_first_record = first_record_offset;
     s->ing_check_crc = (check_crc && !getenv("COVERM_NO_CRC")) ? 1 : 0;
     HIPCHK(s->g_result.reserve(8 + 4 * 8, s->stream));
