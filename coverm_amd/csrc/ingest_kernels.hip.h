@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     // Literals are gathered eight at a time and leave as one 8-byte store: a byte store per symbol from 64 lanes is 64 separate
     // L2 transactions, and every wait for an input word also waits for the stores in front of it.
     u64 obuf = 0; u32 on = 0;
+    u64 tbuf = 0;      // token positions leave four at a time too (one 8-byte store per four matches)
     auto flush_out = [&]() {       // the pending literals are the `on` bytes that end at dst + pos
         if (on) {
             uint8_t *d = dst + pos - on;
@@ -385,11 +386,12 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
                 if (ds < 0 || ds >= 30) { err = INF_ERR_FORMAT; break; }
                 const u32 dsu = (u32)ds;
                 const u32 de = dsu < 4u ? 0u : (dsu - 2u) >> 1;            // distance codes come in pairs sharing e extra bits
-                br.refill();
+                // (no refill here: the one in front of the distance code left >= 33 bits, a code and its extra bits take <= 28)
                 const u32 dist = (dsu < 4u ? 1u + dsu : 1u + ((2u + (dsu & 1u)) << de)) + (de ? br.take(de) : 0u);
                 if (dist > pos || pos + len > B.isize || nt >= INF_TOK_CAP) { err = INF_ERR_FORMAT; break; }
                 if (!(ablate & 2u)) {
-                    my_tok[nt] = (tokpos_t)pos;
+                    tbuf |= (u64)pos << (16u * (nt & 3u));
+                    if ((nt & 3u) == 3u) { __builtin_memcpy(my_tok + (nt - 3u), &tbuf, 8); tbuf = 0; }
                     const u32 t24 = (dist - 1u) | ((len - 3u) << 15);
                     uint8_t *d = dst + pos;
                     // one 4-byte store where it fits: the byte behind the token is this match's own or is written later by this lane
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
         flush_out();
         if (err == INF_OK && pos != B.isize) err = INF_ERR_SIZE;
     }
+    if ((nt & 3u) && !(ablate & 2u)) __builtin_memcpy(my_tok + (nt & ~3u), &tbuf, 8);     // INF_TOK_CAP is a multiple of four: the store stays inside the block's list
     n_tok[b] = err == INF_OK ? nt : 0u;
     status[b] = err;
     if (err != INF_OK) atomicAdd(n_failed, 1u);
