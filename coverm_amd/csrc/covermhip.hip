@@ -6,6 +6,7 @@
 #include "ingest_kernels.hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <chrono>
 #include <cstdio>
@@ -141,6 +142,7 @@ struct cov_session {
     DevBuf<covi::SegInfo> g_seg[4];                        // per-window parse state: extract of window w runs up to three windows later
     DevBuf<u64> g_recbase[4], g_cigbase[4];
     // g_result: [3] inflate failures (u32) | extract failures (u32), [5] bytes in g_carry, [6] p0 of the window being parsed,
+    // [7] key of the last record of the previous window (bit 63: there is one),
     // [8 + 8 * (w % 4) ..] result block of window w (k_bam_verify)
     DevBuf<u64> g_result;
     DevBuf<covi::tokpos_t> g_tok, g_tok2;
@@ -289,21 +291,21 @@ void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
 template <bool H>
 void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
     const size_t smem = pileup_fast_smem_bytes(H);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_fast<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    // the dynamic-LDS limit and the occupancy are per-device facts, and span mode launches from one thread per device: cached per
+    // device id, in atomics (two threads racing for the same device compute the same value)
+    static std::atomic<int> occ_dev[64];
+    std::atomic<int> &occ_slot = occ_dev[(unsigned)s->cfg.device & 63u];
+    int occ = occ_slot.load(std::memory_order_relaxed);
     const u32 chunk = (u32)s->chunk_tiles;
     const u32 n_chunks = (n_tiles + chunk - 1) / chunk;
-    static int occ = 0;
     if (!occ) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_fast<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_pileup_fast<H>), 256, smem) != hipSuccess || nb < 1) {
             (void)hipGetLastError();
             nb = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
         }
-        occ = nb;
+        occ = nb; occ_slot.store(nb, std::memory_order_relaxed);
     }
     const char *wg_env = getenv("COVERM_WG_PER_CU");
     const u32 wg_per_cu = wg_env && atoi(wg_env) > 0 ? (u32)atoi(wg_env) : 8u * (u32)occ;
@@ -314,26 +316,23 @@ void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
 template <bool H, bool W>
 void launch_stream_t(cov_session *s, const PileupArgs &a, u32 n_tiles, bool slow_list_only = false) {
     const size_t smem = pileup_stream_smem_bytes();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_stream<H, W>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static std::atomic<int> occ_dev[64];       // per device id, as in launch_fast_t
+    std::atomic<int> &occ_slot = occ_dev[(unsigned)s->cfg.device & 63u];
+    int occ = occ_slot.load(std::memory_order_relaxed);
     const u32 chunk = (u32)s->chunk_tiles;
     const u32 n_chunks = (n_tiles + chunk - 1) / chunk;
     // Grid = 8x the resident workgroups (registers, not LDS, bound residency): each wave still walks several chunks
     // and keeps its sums in registers across them, but the hardware dispatcher hands out the 8 successive "rounds",
     // which evens out the heavy-tailed per-chunk cost far better than a purely persistent grid (measured, 50 M reads:
     // 1.06 ms at 1x, 0.905 ms at 8x, 0.956 ms at one chunk per wave).
-    static int occ = 0;
     if (!occ) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_stream<H, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_pileup_stream<H, W>), 256, smem) != hipSuccess || nb < 1) {
             (void)hipGetLastError();
             nb = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
         }
-        occ = nb;
+        occ = nb; occ_slot.store(nb, std::memory_order_relaxed);
     }
     const char *wg_env = getenv("COVERM_WG_PER_CU");
     const u32 wg_per_cu = wg_env && atoi(wg_env) > 0 ? (u32)atoi(wg_env) : 8u * (u32)occ;
@@ -532,6 +531,7 @@ cov_status cov_set_target_mask(cov_session *s, const uint8_t *mask) {
 cov_status cov_push_batch(cov_session *s, const cov_batch *b) {
     if (!s || !b) return COV_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(s->cfg.device));
+    if (s->ing_active) { const cov_status a = cov_ingest_abort(s); if (a != COV_OK) return a; }   // an ingest left open: its queued work may still write the store
     if (s->adopted) {  // materialise the adopted device batch into the owned store first
         cov_batch ab = s->adopted_batch;
         s->adopted = false; s->n_records = 0; s->n_cigar = 0;
@@ -566,8 +566,24 @@ cov_status cov_push_batch_device(cov_session *s, const cov_batch *b) {
     return append(s, b, true);
 }
 
+// Abandons an ingest between cov_ingest_begin and cov_ingest_end: everything queued on the ingest streams (uploads, inflate
+// rounds, boundary search, extraction) is waited for, then the session is as if the ingest had never begun — the record
+// store holds what it held before (extraction only ever writes behind n_records) and may be pushed to again.
+cov_status cov_ingest_abort(cov_session *s) {
+    if (!s) return COV_ERR_INVALID_ARG;
+    if (!s->ing_active) return COV_OK;
+    HIPCHK(hipSetDevice(s->cfg.device));
+    s->ing_active = false;
+    for (hipStream_t st : {s->ing_copy, s->stream, s->ing_aux, s->ing_parse, s->ing_ext})
+        if (st) HIPCHK(hipStreamSynchronize(st));
+    s->ing_rec_total = s->ing_cig_total = 0; s->ing_round_n = 0; s->ing_fail = 0;
+    s->ing_extracted = s->ing_batch;
+    return COV_OK;
+}
+
 cov_status cov_reset(cov_session *s) {
     if (!s) return COV_ERR_INVALID_ARG;
+    if (s->ing_active) { const cov_status a = cov_ingest_abort(s); if (a != COV_OK) return a; }
     s->adopted = false; s->n_records = 0; s->n_cigar = 0; s->finished = false; s->depth_all_valid = false;
     return COV_OK;
 }
@@ -1053,8 +1069,10 @@ static cov_status ingest_drain(cov_session *s, int64_t must_upto) {
         else HIPCHK(hipEventSynchronize(s->ing_ver_done[q]));
         const u64 *res = s->h_winres + 8 * q;
         const u64 nrec = res[0], ncig = res[1];
-        const u32 st = (u32)res[2];
+        u32 st = (u32)res[2];
         s->ing_tail_key = res[7];
+        const bool span = s->ing_key_lo > 0 || s->ing_key_hi < 0x80000000ll || s->ing_search_first || s->ing_open_end;
+        if (!span) st &= ~64u;       // whole file: cov_finish reports disorder in file order, beside the other per-record errors
         if (st && !s->ing_fail) { s->ing_fail = st; s->ing_fail_dbg[0] = res[4]; s->ing_fail_dbg[1] = res[5]; s->ing_fail_dbg[2] = res[6]; }
         const u64 R = s->n_records + s->ing_rec_total, Cg = s->n_cigar + s->ing_cig_total;
         if (!s->ing_fail && (R + nrec >= 0xfffffff0ull || Cg + ncig >= 0xfffffff0ull)) s->ing_fail = 16u;
@@ -1169,7 +1187,7 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
     hipLaunchKernelGGL(covi::k_bam_find, dim3((S.n_seg + 3) / 4), dim3(256), 0, ps, S, s->g_seg[q].p);
     hipLaunchKernelGGL(covi::k_bam_hop, dim3((S.n_seg + 63) / 64), dim3(64), 0, ps, S, s->g_seg[q].p);
     hipLaunchKernelGGL(covi::k_bam_verify, dim3(1), dim3(1024), 0, ps, S, s->g_seg[q].p, s->g_recbase[q].p, s->g_cigbase[q].p, s->g_result.p + 8 + 8 * q,
-                       s->g_carry.p, (u64)K.carry, s->g_result.p + 5);
+                       s->g_carry.p, (u64)K.carry, s->g_result.p + 5, s->g_result.p + 7);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(s->h_winres + 8 * q, s->g_result.p + 8 + 8 * q, 8 * sizeof(u64), hipMemcpyDeviceToHost, ps));
     HIPCHK(hipEventRecord(s->ing_ver_done[q], ps));
@@ -1301,6 +1319,10 @@ cov_status cov_ingest_end(cov_session *s, uint64_t *n_records_out) {
     if (inflate_fail) { s->err = "device ingest: " + std::to_string(inflate_fail) + " BGZF blocks failed to inflate or their CRC-32 (handing the file to the CPU reader)"; return COV_ERR_INGEST_FALLBACK; }
     if (s->ing_fail) {
         const u32 f = s->ing_fail;
+        if (f & 64u) {    // contig.rs:129-132: the reference stops at the first record whose tid is lower than its predecessor's
+            s->err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)";
+            return COV_ERR_UNSORTED;
+        }
         s->err = (f & 16u) ? "more than 2^32 records in one session"
                : (f & 32u) ? "device ingest: the BAM header is longer than the first window of the inflated stream (handing the file to the CPU reader)"
                : (f & 4u) ? "device ingest: a record keeps its CIGAR in CG:B,I (handing the file to the CPU reader)"
@@ -1313,6 +1335,12 @@ cov_status cov_ingest_end(cov_session *s, uint64_t *n_records_out) {
     if ((u32)(glob[3] >> 32)) { s->err = "device ingest: corrupt BAM record"; return COV_ERR_INGEST_FALLBACK; }
     if (s->ing_open_end && s->ing_tail_key != ~0ull && (long long)s->ing_tail_key < s->ing_key_hi) {
         s->err = "device ingest: the bytes fed for this span end inside one of its own records (handing the span to the CPU reader)"; return COV_ERR_INGEST_FALLBACK;
+    }
+    if (s->ing_open_end) {
+        // an open end is only trusted when a record from beyond the span was actually seen (complete, or cut by the end of the bytes):
+        // otherwise the span's last records may lie behind the bytes that were fed
+        const bool seen_beyond = ((glob[7] >> 63) && (long long)(u32)glob[7] >= s->ing_key_hi) || (s->ing_tail_key != ~0ull && (long long)s->ing_tail_key >= s->ing_key_hi);
+        if (!seen_beyond) { s->err = "device ingest: the bytes fed for this span end before a record of the next span (handing the span to the CPU reader)"; return COV_ERR_INGEST_FALLBACK; }
     }
     if (s->ing_rec_total) {
         const u64 Nn = s->n_records + s->ing_rec_total, Cn = s->n_cigar + s->ing_cig_total;

@@ -889,6 +889,7 @@ struct Stream {
     void run_parse() {
         std::vector<uint8_t> carry;
         bool header_done = mid_start, need_start = mid_start, finished = false;
+        int64_t span_last_key = -1;
         RecVec<size_t> rec;
         auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         auto pfor = [&](size_t n, auto fn) { pool_p->run(n, fn); };
@@ -930,6 +931,18 @@ struct Stream {
                 if (!find_records(base, p, N, n_ref, lens.data(), pool_p->size(), pfor, rec, end)) { fail("truncated BAM record"); return; }
                 if (last && end != N) { fail("truncated BAM record"); return; }
                 i1 = rec.size();
+                if (key_lo > 0 || key_hi <= KEY_INF || mid_start) {
+                    // A span trusts the file's order when it drops its neighbours' records, so it checks that order over everything
+                    // it parses (the spans' byte ranges overlap: together they cover the file).  contig.rs:129-132 stops at the first
+                    // record whose tid is lower than its predecessor's; the whole-file path reports that from cov_finish.
+                    int64_t prev = span_last_key;
+                    for (size_t i = 0; i < i1; i++) {
+                        const int64_t k = tid_key((int32_t)rd32(base + rec[i] + 4));
+                        if (k < prev) { fail("BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)"); return; }
+                        prev = k;
+                    }
+                    span_last_key = prev;
+                }
                 // span: keep records with key_lo <= key(tid) < key_hi (file order; ranges are contiguous in a sorted file)
                 if (key_lo > 0) while (i0 < i1 && tid_key((int32_t)rd32(base + rec[i0] + 4)) < key_lo) i0++;
                 if (key_hi <= KEY_INF) {
@@ -1041,21 +1054,48 @@ uint64_t find_block_start(int fd, uint64_t file_size, uint64_t off) {
 }
 
 // Key (tid, or KEY_INF for unmapped-without-reference) of the first record that can be located at or after file offset
-// `off`; *block_off receives the BGZF block the search started in.  KEY_INF + 1 when the file ends first.
+// `off`; *block_off receives the BGZF block the search started in.  KEY_INF + 1 when the file ends first; PROBE_FAILED when
+// nothing could be decided (a header signature inside compressed data that does not inflate, even after moving on a few times;
+// no record boundary within 96 MB) — callers must not read that as "beyond every key".
+constexpr int64_t PROBE_FAILED = -2;
 int64_t probe_key(int fd, uint64_t file_size, uint64_t off, int32_t n_ref, const uint64_t *lens, uint64_t *block_off) {
-    const uint64_t b = find_block_start(fd, file_size, off);
-    *block_off = b;
-    if (b == (uint64_t)-1) return KEY_INF + 1;
-    std::vector<uint8_t> u; std::string err;
-    size_t found = (size_t)-1;
-    auto want = [&](std::vector<uint8_t> &buf) {
-        found = find_record_start(buf.data(), buf.size(), 0, buf.size(), n_ref, lens, false);
-        return found != (size_t)-1 || buf.size() > (96u << 20);
-    };
-    if (!inflate_from(fd, file_size, b, u, want, err)) return KEY_INF + 1;
-    if (found == (size_t)-1) found = find_record_start(u.data(), u.size(), 0, u.size(), n_ref, lens, true);
-    if (found == (size_t)-1) return KEY_INF + 1;
-    return tid_key((int32_t)rd32(&u[found + 4]));
+    for (int attempt = 0; attempt < 8; attempt++) {
+        const uint64_t b = find_block_start(fd, file_size, off);
+        *block_off = b;
+        if (b == (uint64_t)-1) return KEY_INF + 1;
+        std::vector<uint8_t> u; std::string err;
+        size_t found = (size_t)-1;
+        bool gave_up = false;
+        auto want = [&](std::vector<uint8_t> &buf) {
+            found = find_record_start(buf.data(), buf.size(), 0, buf.size(), n_ref, lens, false);
+            gave_up = found == (size_t)-1 && buf.size() > (96u << 20);
+            return found != (size_t)-1 || gave_up;
+        };
+        if (!inflate_from(fd, file_size, b, u, want, err)) { off = b + 1; continue; }     // a false signature: the next candidate
+        if (found == (size_t)-1 && !gave_up) found = find_record_start(u.data(), u.size(), 0, u.size(), n_ref, lens, true);   // read to the end of the file
+        if (found == (size_t)-1) return gave_up ? PROBE_FAILED : KEY_INF + 1;
+        return tid_key((int32_t)rd32(&u[found + 4]));
+    }
+    return PROBE_FAILED;
+}
+
+// Span boundaries of a file cut into `span_count` tid spans: B[k] = one past the key found at k / count of the file, boff[k] the
+// BGZF block that probe started in.  Every rank computes the same.  A probe that cannot be decided makes the whole file ONE
+// span (span 0 takes everything, the others are empty): slower, never wrong.
+bool span_boundaries(int fd, uint64_t file_size, uint32_t span_count, int32_t n_ref, const uint64_t *lens, std::vector<int64_t> &B,
+                     std::vector<uint64_t> &boff) {
+    B.assign(span_count + 1, 0); boff.assign(span_count + 1, 0);
+    bool ok = true;
+    for (uint32_t k = 1; k < span_count && ok; k++) {
+        uint64_t bo = 0;
+        const int64_t key = probe_key(fd, file_size, file_size / span_count * k, n_ref, lens, &bo);
+        if (key == PROBE_FAILED) { ok = false; break; }
+        B[k] = std::max(B[k - 1], key >= KEY_INF ? KEY_INF : key + 1);
+        boff[k] = bo;
+    }
+    B[span_count] = KEY_INF + 1;
+    if (!ok) for (uint32_t k = 1; k < span_count; k++) { B[k] = KEY_INF + 1; boff[k] = (uint64_t)-1; }
+    return ok;
 }
 
 }  // namespace
@@ -1101,15 +1141,8 @@ covh_bam_stream *covh_bam_stream_open(const char *path, int threads, uint32_t sp
         if (span_index >= span_count) return bail(h, "span index out of range");
         const int32_t n_ref = (int32_t)s.names.size();
         // boundaries B[k], k = 1 .. count-1: one past the tid found at k/count of the file; every rank computes the same
-        std::vector<int64_t> B(span_count + 1, 0);
-        std::vector<uint64_t> boff(span_count + 1, 0);
-        for (uint32_t k = 1; k < span_count; k++) {
-            uint64_t bo = 0;
-            const int64_t key = probe_key(s.fd, s.file_size, s.file_size / span_count * k, n_ref, s.lens.data(), &bo);
-            B[k] = std::max(B[k - 1], key >= KEY_INF ? KEY_INF : key + 1);
-            boff[k] = bo;
-        }
-        B[span_count] = KEY_INF + 1;
+        std::vector<int64_t> B; std::vector<uint64_t> boff;
+        span_boundaries(s.fd, s.file_size, span_count, n_ref, s.lens.data(), B, boff);
         s.key_lo = B[span_index]; s.key_hi = B[span_index + 1];
         if (span_index > 0) {
             if (boff[span_index] == (uint64_t)-1 || s.key_lo >= s.key_hi) s.empty_span = true;
@@ -1238,15 +1271,8 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     uint64_t first_record = hd->h.first_record;
     if (span_count > 1) {
         const int32_t n_ref = (int32_t)hd->h.names.size();
-        std::vector<int64_t> B(span_count + 1, 0);
-        std::vector<uint64_t> boff(span_count + 1, 0);
-        for (uint32_t k = 1; k < span_count; k++) {
-            uint64_t bo = 0;
-            const int64_t key = probe_key(fd, file_size, file_size / span_count * k, n_ref, hd->h.lens.data(), &bo);
-            B[k] = std::max(B[k - 1], key >= KEY_INF ? KEY_INF : key + 1);
-            boff[k] = bo;
-        }
-        B[span_count] = KEY_INF + 1;
+        std::vector<int64_t> B; std::vector<uint64_t> boff;
+        span_boundaries(fd, file_size, span_count, n_ref, hd->h.lens.data(), B, boff);
         key_lo = B[span_index]; key_hi = B[span_index + 1];
         if (span_index > 0) {
             if (boff[span_index] == (uint64_t)-1 || key_lo >= key_hi) return 0;          // empty span: nothing to read
@@ -1255,14 +1281,17 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
         if (span_index + 1 < span_count && boff[span_index + 1] != (uint64_t)-1) {
             // smallest offset from which the first record found has a key >= key_hi
             uint64_t lo = boff[span_index + 1], hi = file_size;
-            while (hi - lo > 65536) {
+            bool decided = true;
+            while (hi - lo > 65536 && decided) {
                 const uint64_t mid = lo + (hi - lo) / 2;
                 uint64_t bo = 0;
-                if (probe_key(fd, file_size, mid, n_ref, hd->h.lens.data(), &bo) >= key_hi) hi = mid; else lo = mid;
+                const int64_t key = probe_key(fd, file_size, mid, n_ref, hd->h.lens.data(), &bo);
+                if (key == PROBE_FAILED) decided = false;        // not "beyond the span": feed up to the end of the file instead
+                else if (key >= key_hi) hi = mid; else lo = mid;
             }
             // every record of this span starts before that point and may run on for up to the carry size of the device ingest
             const uint64_t want = hi + ((uint64_t)17 << 20);
-            if (want < file_size) { const uint64_t e = find_block_start(fd, file_size, want); if (e != (uint64_t)-1) size = e; }
+            if (decided && want < file_size) { const uint64_t e = find_block_start(fd, file_size, want); if (e != (uint64_t)-1) size = e; }
         }
     }
     const bool mid_start = f_lo != 0, open_end = size != file_size;
@@ -1271,7 +1300,10 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     constexpr int NS = COV_INGEST_SLOTS;
     uint8_t *buf[NS];
     for (int k = 0; k < NS; k++) buf[k] = nullptr;       // page-locked on first use by the reader thread: slots 1.. are pinned while piece 0 is already on its way
-    struct BufFree { uint8_t **b; ~BufFree() { for (int k = 0; k < NS; k++) if (b[k]) cov_host_free(b[k]); } } bf{buf};
+    // Every way out of this function after cov_ingest_begin first gives up whatever is still queued on the device (no-op once
+    // cov_ingest_end has run), and only then parks the staging buffers: an upload may still be reading them, and an extraction
+    // still writing the store the CPU reader is about to push into.
+    struct BufFree { cov_session *s; uint8_t **b; ~BufFree() { (void)cov_ingest_abort(s); for (int k = 0; k < NS; k++) if (b[k]) cov_host_free(b[k]); } } bf{s, buf};
     if (cov_ingest_begin(s, file_size, first_record, check_crc) != COV_OK) return fail(-1, cov_last_error(s));
     if (span_count > 1 && cov_ingest_span(s, key_lo, key_hi, mid_start ? 1 : 0, open_end ? 1 : 0, f_lo, size) != COV_OK) return fail(-1, cov_last_error(s));
     const double t_begin = now() - t_start;

@@ -287,6 +287,9 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
         const u32 total_bits = B.in_len * 8u;
         bool last = false;
         while (!last && err == INF_OK) {
+            // checked in front of every DEFLATE block (stored blocks `continue` past the check at the bottom): a payload of empty
+            // stored blocks cannot walk on behind its own end for longer than one block
+            if (br.consumed > total_bits) { err = INF_ERR_FORMAT; break; }
             br.refill();
             last = br.take(1) != 0u;
             const u32 type = br.take(2);
@@ -600,8 +603,9 @@ struct SegInfo {
     u64 start;     // first record start found in the segment (~0 = none)
     u64 landed;    // where the hop from `start` ended (first record start at or beyond the segment end, or N)
     u32 n_rec, n_cig;
-    u32 flags;     // bit 0: a record that needs the CPU reader (CG:B,I long CIGAR candidate)
-    u32 pad;
+    u32 flags;     // bit 0: a record that needs the CPU reader (CG:B,I long CIGAR candidate); bit 1: keys decrease inside the hop
+    u32 first_key, last_key;     // keys of the first / last record hopped over (any record, not only the span's); valid when n_hop != 0
+    u32 n_hop;                   // records hopped over
 };
 
 // One wave per segment: lanes test consecutive offsets for an 8-record plausible chain; the lowest hit wins.  The segment that
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(256) void k_bam_find(BamScan S, SegInfo *__restrict
             if (m) found = base + (u64)(__ffsll((long long)m) - 1);
         }
     }
-    if (lane == 0) { SegInfo s; s.start = found; s.landed = 0; s.n_rec = 0; s.n_cig = 0; s.flags = 0; s.pad = 0; seg[k] = s; }
+    if (lane == 0) { SegInfo s; s.start = found; s.landed = 0; s.n_rec = 0; s.n_cig = 0; s.flags = 0; s.first_key = s.last_key = 0; s.n_hop = 0; seg[k] = s; }
 }
 
 // One lane per segment that has a start: hop to the first record at or beyond the next live segment's start (bounded by the
@@ -641,13 +645,15 @@ __global__ __launch_bounds__(64) void k_bam_hop(BamScan S, SegInfo *__restrict__
     // the hop ends at the start found by the next segment that has one
     u64 limit = S.N;
     for (u32 j = k + 1; j < S.n_seg; j++) { const u64 st = seg[j].start; if (st != ~0ull) { limit = st; break; } }
-    u64 q = s.start; u32 nr = 0, nc = 0, fl = 0;
+    u64 q = s.start; u32 nr = 0, nc = 0, fl = 0, nh = 0, k_first = 0, k_last = 0;
     while (q < limit && q + 4 <= S.N) {
         const uint8_t *r = S.u + q;
         const u32 bs = ld32(r);
         if (bs < 32u || q + 4 + (u64)bs > S.N) break;
         const u32 ncig = ld16(r + 16);
         const long long key = rec_key((int)ld32(r + 4));
+        if (nh == 0u) k_first = (u32)key; else if ((u32)key < k_last) fl |= 2u;
+        k_last = (u32)key; nh++;
         if (key >= S.key_lo && key < S.key_hi) {
             if (ncig == 2u) {    // `<l_seq>S <n>N` is the placeholder of a CIGAR stored in CG:B,I (SAM spec 4.2.2): leave the file to the CPU reader
                 const u32 c0 = ld32(r + 36 + r[12]);
@@ -657,17 +663,21 @@ __global__ __launch_bounds__(64) void k_bam_hop(BamScan S, SegInfo *__restrict__
         }
         q += 4 + (u64)bs;
     }
-    s.landed = q; s.n_rec = nr; s.n_cig = nc; s.flags = fl;
+    s.landed = q; s.n_rec = nr; s.n_cig = nc; s.flags = fl; s.first_key = k_first; s.last_key = k_last; s.n_hop = nh;
     seg[k] = s;
 }
 
 // Single workgroup: chain verification + exclusive scans over segments (records, CIGAR words) + the tail.
 // result[0] = records of this window, [1] = CIGAR words, [2] = status (0 ok, 1 chain mismatch, 2 truncated, 4 needs the CPU
-// reader, 8 tail larger than the carry buffer), [3] = offset where the tail starts (first byte no record of this window owns),
+// reader, 8 tail larger than the carry buffer, 64 record keys (tid) decrease somewhere in the window — looked at for spans
+// only: a span trusts the file's order when it drops its neighbours' records, the whole-file path reports disorder from
+// cov_finish in file order with the other per-record errors), [3] = offset where the tail starts (first byte no record of this window owns),
 // [4..6] = first bad segment / its start / where its hop landed.  The tail [result[3], N) goes to `carry`, its length to *carry_len.
 __global__ __launch_bounds__(1024) void k_bam_verify(BamScan S, SegInfo *__restrict__ seg, u64 *__restrict__ rec_base, u64 *__restrict__ cig_base,
-                                                     u64 *__restrict__ result, uint8_t *__restrict__ carry, u64 carry_cap, u64 *__restrict__ carry_len) {
+                                                     u64 *__restrict__ result, uint8_t *__restrict__ carry, u64 carry_cap, u64 *__restrict__ carry_len,
+                                                     u64 *__restrict__ prev_key) {
     __shared__ u64 s_rec[1024], s_cig[1024];
+    __shared__ u32 s_kfirst[1024], s_klast[1024], s_khave[1024];
     __shared__ u32 s_bad;
     __shared__ u64 s_tail, s_badk;
     const u32 t = threadIdx.x;
@@ -676,9 +686,16 @@ __global__ __launch_bounds__(1024) void k_bam_verify(BamScan S, SegInfo *__restr
     const u32 per = (S.n_seg + 1023u) / 1024u;
     const u32 k0 = t * per, k1 = min(S.n_seg, k0 + per);
     u64 nr = 0, nc = 0; u32 bad = 0;
+    u32 kf = 0, kl = 0, khave = 0;      // first / last key over this thread's segments
     for (u32 k = k0; k < k1; k++) {
         const SegInfo s = seg[k];
         if (s.start == ~0ull) continue;
+        if (s.n_hop) {
+            if (s.flags & 2u) bad |= 64u;
+            if (khave && s.first_key < kl) bad |= 64u;
+            if (!khave) kf = s.first_key;
+            kl = s.last_key; khave = 1u;
+        }
         u64 want = S.N; bool last_live = true;
         for (u32 j = k + 1; j < S.n_seg; j++) { const u64 st = seg[j].start; if (st != ~0ull) { want = st; last_live = false; break; } }
         if (last_live) {
@@ -689,7 +706,7 @@ __global__ __launch_bounds__(1024) void k_bam_verify(BamScan S, SegInfo *__restr
         nr += s.n_rec; nc += s.n_cig;
     }
     if (bad) atomicOr(&s_bad, bad);
-    s_rec[t] = nr; s_cig[t] = nc;
+    s_rec[t] = nr; s_cig[t] = nc; s_kfirst[t] = kf; s_klast[t] = kl; s_khave[t] = khave;
     __syncthreads();
     const u64 tail = min(s_tail, S.N), tail_len = S.N - tail;
     const bool tail_fits = tail_len <= carry_cap;
@@ -697,6 +714,12 @@ __global__ __launch_bounds__(1024) void k_bam_verify(BamScan S, SegInfo *__restr
         u64 a = 0, c = 0;
         for (u32 i = 0; i < 1024; i++) { const u64 x = s_rec[i], y = s_cig[i]; s_rec[i] = a; s_cig[i] = c; a += x; c += y; }
         u32 st = s_bad;
+        {   // order across the threads' runs of segments, and against the last key of the previous window (*prev_key, bit 63 = valid)
+            const u64 pk = *prev_key;
+            u32 prev = (u32)pk, have = (u32)(pk >> 63);
+            for (u32 i = 0; i < 1024; i++) if (s_khave[i]) { if (have && s_kfirst[i] < prev) st |= 64u; prev = s_klast[i]; have = 1u; }
+            *prev_key = (u64)prev | ((u64)have << 63);
+        }
         if (S.final && tail_len != 0) st |= 2u;
         if (!tail_fits) st |= 8u;
         result[0] = a; result[1] = c; result[2] = st; result[3] = tail;

@@ -8,8 +8,9 @@ Two ways the path shards, neither needs a data-path collective:
   per-contig statistics of different ranks are disjoint rows, merged on rank 0 after the same single gather,
   and `num_detected_primary_alignments` is the sum of the shards' counts.
 
-The gathered payload is ONE packed byte buffer per rank (a 288-byte header + the raw `cov_contig_stats` array, 128 B per
-contig): its size is the same on every rank, so a single `gather` moves it with no size exchange.  Compact histograms, when a
+The gathered payload is ONE packed byte buffer per rank (a 304-byte header + the raw `cov_contig_stats` array, 128 B per
+contig): for tid shards its size is the same on every rank, so a single `gather` moves it with no size exchange; samples
+with different reference sets agree on the largest target count first and pad.  Compact histograms, when a
 method needs them, follow point to point (their sizes are in the gathered headers).  Bytes, so that integers stay exact.
 """
 from typing import List, Optional, Tuple
@@ -58,47 +59,61 @@ def shard_records(batch: RecordBatch, lo_tid: int, hi_tid: int, include_unplaced
 
 
 _NAME_BYTES = 256
-_HEADER_BYTES = _NAME_BYTES + 8 + 16 + 8     # stoit name | num_detected_primary_alignments | tid range lo, hi | histogram bins
+# stoit name | name length (u32) + has-histogram flag (u32) | num_detected_primary_alignments | tid range lo, hi | histogram bins | contigs
+_HEADER_BYTES = _NAME_BYTES + 8 + 8 + 16 + 8 + 8
 
 
-def _pack(local: SampleResult, tid_range: Tuple[int, int]) -> np.ndarray:
-    """The fixed-size part of one rank's result: header + the raw cov_contig_stats rows (128 B per contig).  Its size depends
-    only on the number of targets, which every rank knows, so ONE gather moves it without any size exchange."""
-    name = local.stoit_name.encode()[:_NAME_BYTES]
+def _pack(local: SampleResult, tid_range: Tuple[int, int], pad_to: Optional[int] = None) -> np.ndarray:
+    """The fixed-size part of one rank's result: header + the raw cov_contig_stats rows (128 B per contig), padded with zero
+    rows up to `pad_to` contigs.  For tid shards of ONE file every rank has the same number of targets, so ONE gather moves
+    the buffers without any size exchange; by-sample sharding agrees on `pad_to` first (gather_samples)."""
+    name = local.stoit_name.encode()
+    if len(name) > _NAME_BYTES:                         # cut on a character boundary, never inside a UTF-8 sequence
+        name = name[:_NAME_BYTES].decode(errors="ignore").encode()
+    n = len(local.stats)
     head = np.zeros(_HEADER_BYTES, np.uint8)
     head[:len(name)] = np.frombuffer(name, np.uint8)
-    head[_NAME_BYTES:_NAME_BYTES + 8] = np.asarray([local.num_detected_primary_alignments], np.uint64).view(np.uint8)
-    head[_NAME_BYTES + 8:_NAME_BYTES + 24] = np.asarray(tid_range, np.int64).view(np.uint8)
-    head[_NAME_BYTES + 24:] = np.asarray([0 if local.hist is None else len(local.hist)], np.uint64).view(np.uint8)
-    return np.concatenate([head, np.ascontiguousarray(local.stats).view(np.uint8).reshape(-1)])
+    o = _NAME_BYTES
+    head[o:o + 8] = np.asarray([len(name), 0 if local.hist is None else 1], np.uint32).view(np.uint8)
+    head[o + 8:o + 16] = np.asarray([local.num_detected_primary_alignments], np.uint64).view(np.uint8)
+    head[o + 16:o + 32] = np.asarray(tid_range, np.int64).view(np.uint8)
+    head[o + 32:o + 40] = np.asarray([0 if local.hist is None else len(local.hist)], np.uint64).view(np.uint8)
+    head[o + 40:o + 48] = np.asarray([n], np.uint64).view(np.uint8)
+    rows = np.ascontiguousarray(local.stats).view(np.uint8).reshape(-1)
+    if pad_to is not None and pad_to > n:
+        rows = np.concatenate([rows, np.zeros((pad_to - n) * native.CONTIG_STATS_DTYPE.itemsize, np.uint8)])
+    return np.concatenate([head, rows])
 
 
 def _unpack(raw: np.ndarray):
-    name = bytes(raw[:_NAME_BYTES]).rstrip(b"\0").decode()
-    prim = int(raw[_NAME_BYTES:_NAME_BYTES + 8].view(np.uint64)[0])
-    lo, hi = (int(x) for x in raw[_NAME_BYTES + 8:_NAME_BYTES + 24].view(np.int64))
-    n_hist = int(raw[_NAME_BYTES + 24:_HEADER_BYTES].view(np.uint64)[0])
-    stats = raw[_HEADER_BYTES:].view(native.CONTIG_STATS_DTYPE).copy()
-    return name, prim, (lo, hi), n_hist, stats
+    o = _NAME_BYTES
+    name_len, has_hist = (int(x) for x in raw[o:o + 8].view(np.uint32))
+    name = bytes(raw[:min(name_len, _NAME_BYTES)]).decode(errors="replace")
+    prim = int(raw[o + 8:o + 16].view(np.uint64)[0])
+    lo, hi = (int(x) for x in raw[o + 16:o + 32].view(np.int64))
+    n_hist = int(raw[o + 32:o + 40].view(np.uint64)[0])
+    n = int(raw[o + 40:o + 48].view(np.uint64)[0])
+    stats = raw[_HEADER_BYTES:_HEADER_BYTES + n * native.CONTIG_STATS_DTYPE.itemsize].view(native.CONTIG_STATS_DTYPE).copy()
+    return name, prim, (lo, hi), n_hist, stats, bool(has_hist)
 
 
-def gather_packed(local: SampleResult, tid_range: Tuple[int, int], dist, device="cpu", dst=0):
-    """ONE gather of every rank's packed (header + per-contig statistics) buffer to rank `dst`.  Histograms (only present for
-    trimmed_mean / coverage_histogram) have a data-dependent size: rank `dst` learns every size from the gathered headers and
-    the other ranks send theirs point to point — no collective, no size exchange.
+def gather_packed(local: SampleResult, tid_range: Tuple[int, int], dist, device="cpu", dst=0, pad_to: Optional[int] = None):
+    """ONE gather of every rank's packed (header + per-contig statistics) buffer to rank `dst`; the buffers must have one size
+    (same number of targets, or padded to `pad_to`).  Histograms (only present for trimmed_mean / coverage_histogram) have a
+    data-dependent size: rank `dst` learns every size — and whether a rank has one at all — from the gathered headers and the
+    other ranks send theirs point to point — no collective, no size exchange.
     Returns, on `dst`, a list of (SampleResult, (lo, hi)) in rank order; None elsewhere."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    packed = torch.from_numpy(_pack(local, tid_range)).to(device)
+    packed = torch.from_numpy(_pack(local, tid_range, pad_to)).to(device)
     out = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
     dist.gather(packed, out, dst=dst)
-    has_hist = local.hist is not None
     if rank != dst:
-        if has_hist and len(local.hist):
+        if local.hist is not None and len(local.hist):
             dist.send(torch.from_numpy(np.ascontiguousarray(local.hist).view(np.uint8).copy()).to(device), dst=dst)
         return None
     res = []
     for r, o in enumerate(out):
-        name, prim, rng, n_hist, stats = _unpack(o.cpu().numpy())
+        name, prim, rng, n_hist, stats, has_hist = _unpack(o.cpu().numpy())
         hist = None
         if has_hist:
             if r == dst:
@@ -114,8 +129,15 @@ def gather_packed(local: SampleResult, tid_range: Tuple[int, int], dist, device=
 
 
 def gather_samples(local: SampleResult, dist, device="cpu", dst=0) -> Optional[List[SampleResult]]:
-    """By-sample sharding: every rank contributes one whole SampleResult; rank `dst` gets them in rank order."""
-    got = gather_packed(local, (0, len(local.stats)), dist, device, dst)
+    """By-sample sharding: every rank contributes one whole SampleResult; rank `dst` gets them in rank order.  Different BAMs may
+    bring different reference sets (contig.rs:29-32 reads each file's own header), so the ranks first agree on the largest
+    number of targets (one 8-byte all_gather) and pad their rows to it; the single gather then moves equal-sized buffers."""
+    world = dist.get_world_size()
+    mine = torch.tensor([len(local.stats)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine)
+    pad_to = max(int(t.item()) for t in sizes)
+    got = gather_packed(local, (0, len(local.stats)), dist, device, dst, pad_to=pad_to)
     return None if got is None else [g[0] for g in got]
 
 
@@ -126,6 +148,8 @@ def gather_tid_shards(local: SampleResult, tid_range: Tuple[int, int], dist, dev
     got = gather_packed(local, tid_range, dist, device, dst)
     if got is None:
         return None
+    if any(len(p.stats) != len(got[0][0].stats) for p, _ in got):
+        raise ValueError("gather_tid_shards: the ranks hold different numbers of targets (tid shards must come from one file)")
     merged = np.zeros_like(got[0][0].stats)
     hists, base, prim = [], 0, 0
     for p, (lo, hi) in got:

@@ -225,6 +225,10 @@ cov_status cov_ingest_slot_wait(cov_session *s, int slot);
 cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uint64_t file_offset, uint64_t n_bytes,
                            const cov_bgzf_block *blocks, uint32_t n_blocks);
 cov_status cov_ingest_end(cov_session *s, uint64_t *n_records);
+/* Gives up an ingest that was begun but cannot be ended (a malformed block header met by the driver, a read error): waits for
+ * everything queued on the device, appends nothing, leaves the session ready for cov_push_batch.  cov_reset and cov_push_batch
+ * call it themselves when an ingest is still open. */
+cov_status cov_ingest_abort(cov_session *s);
 cov_status cov_ingest_release(cov_session *s); /* frees the compressed / inflated buffers (kept between files otherwise) */
 cov_status cov_ingest_copy_inflated(cov_session *s, uint64_t offset, uint64_t n, void *out); /* test hook; single-window files only */
 /* Test hook: the session's own record store copied back into caller-sized host arrays (host == NULL: only the counts). */

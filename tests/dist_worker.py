@@ -80,6 +80,23 @@ def main():
         assert taker.text() == t2.text(), "by-sample sharding changed the output"
         assert [(r.num_mapped_reads, r.num_reads) for r in rm] == [(r.num_mapped_reads, r.num_reads) for r in rm2]
 
+    # ---- mode 1b: samples with DIFFERENT reference sets (each BAM brings its own header, contig.rs:29-32) and a stoit name that
+    # is longer than the header field and would be cut inside a UTF-8 sequence
+    def odd_sample(r):
+        ref_r = synth.make_reference(11 + 5 * r, 400_000, seed=40 + r, min_len=1200, max_len=90_000)
+        name = "s%d_" % r + "\u00e9" * 140          # 2 bytes per character: the 256-byte cut falls inside one
+        return prov(AlignmentFile(name + ".bam", ref_r.names, ref_r.lengths, synth.make_reads(ref_r, 5_000, seed=60 + r)), fp, 75,
+                    want_hist if r % 2 == 0 else False, want_id, device=int(os.environ.get("LOCAL_RANK", 0)))
+    local = odd_sample(rank)
+    gathered = distributed.gather_samples(local, dist, device)
+    if rank == 0:
+        for r, g in enumerate(gathered):
+            e = odd_sample(r)
+            assert len(g.stats) == len(e.stats) == 11 + 5 * r and g.stats.tobytes() == e.stats.tobytes(), "unequal reference sets: rows changed"
+            assert (g.hist is None) == (e.hist is None) and (g.hist is None or (g.hist == e.hist).all())
+            assert g.num_detected_primary_alignments == e.num_detected_primary_alignments
+            assert e.stoit_name.startswith(g.stoit_name) and len(g.stoit_name.encode()) in (255, 256), g.stoit_name
+
     # ---- mode 2: one sample split by tid range
     whole = synth.make_reads(ref, 50_000, seed=7)
     shards = distributed.tid_range_shards(ref.lengths, world)

@@ -287,3 +287,25 @@ def test_long_cigar_restored_from_cg_tag(tmp_path):
         np.testing.assert_array_equal(r.cigar[:n_ops], ops)
         np.testing.assert_array_equal(r.nm, [5, 1, 2])
         np.testing.assert_array_equal(r.nm_kind, [1, 1, 1])
+
+
+def test_cpu_span_reader_refuses_a_file_that_is_not_sorted_by_reference(tmp_path):
+    """A span drops its neighbours' records trusting the file's order: tids that decrease must end in the reference's error
+    (contig.rs:129-132), not in silently missing records."""
+    from coverm_amd import synth
+    from tests.fixtures import swap_halves
+    ref = synth.make_reference(40, 6_000_000, seed=18, min_len=5000, max_len=800_000)
+    b = synth.make_reads(ref, 60_000, seed=31)
+    cut = int(np.searchsorted(b.tid, 20))
+    p = str(tmp_path / "unsorted.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, swap_halves(b, cut), with_seq=1, threads=2)
+    seen = 0
+    for i in range(2):
+        try:
+            list(cbam.stream_batches(p, 2, span_index=i, span_count=2))
+        except IOError as e:
+            assert "appears to be unsorted" in str(e)
+            seen += 1
+    assert seen >= 1
+    # the whole-file reader does not judge the order (cov_finish does, in file order with the other per-record errors)
+    assert sum(x.n_records for x in list(cbam.stream_batches(p, 2))[1:]) == b.n_records

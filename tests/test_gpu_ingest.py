@@ -12,7 +12,7 @@ from coverm_amd import bam as cbam
 from coverm_amd import synth
 from coverm_amd.engine import FilterConfig, Session
 from oracle import bamio
-from tests.fixtures import load_fixture
+from tests.fixtures import load_fixture, swap_halves
 
 pytestmark = pytest.mark.gpu
 FIELDS = ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar")
@@ -186,3 +186,70 @@ def test_device_ingest_of_tid_spans_partitions_the_file(tmp_path, count):
     for f in ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq"):
         np.testing.assert_array_equal(np.concatenate([getattr(x, f) for x in nonempty]), getattr(whole, f), err_msg=f)
     np.testing.assert_array_equal(np.concatenate([x.cigar for x in nonempty]), whole.cigar)
+
+
+def test_device_ingest_given_up_midway_leaves_the_session_usable(tmp_path):
+    """A BGZF block with an extra subfield besides BC, megabytes into the file: the driver stops feeding after uploads, inflate rounds
+    and extractions are already queued (cov_ingest_abort waits for them), reports IngestFallback, and the same session then takes the
+    CPU reader's records and produces what a fresh session produces (the queued work must not race the push)."""
+    ref = synth.make_reference(12, 900_000, seed=41, min_len=1500, max_len=200_000)
+    b = synth.make_reads(ref, 90_000, seed=47)
+    good = str(tmp_path / "good.bam")
+    cbam.write_bam(good, ref.names, ref.lengths, b, with_seq=2, threads=2)
+    raw = open(good, "rb").read()
+    q = 0
+    while q < (3 << 20):
+        q += int.from_bytes(raw[q + 16:q + 18], "little") + 1
+    bs = int.from_bytes(raw[q + 16:q + 18], "little") + 1
+    # same block with a second (empty) subfield "XX": XLEN 6 -> 10, BSIZE + 4
+    blk = raw[q:q + 10] + struct.pack("<H", 10) + b"BC\x02\0" + struct.pack("<H", bs + 4 - 1) + b"XX\0\0" + raw[q + 18:q + bs]
+    odd = str(tmp_path / "extra_subfield.bam")
+    open(odd, "wb").write(raw[:q] + blk + raw[q + bs:])
+    whole = cbam.read_alignment_file(odd, threads=2, want_names=False)
+    assert whole.records.n_records == b.n_records
+    with Session(0, FilterConfig(), 75, want_hist=True, want_identity=True) as s:
+        with pytest.raises(cbam.IngestFallback) as ei:
+            cbam.gpu_ingest(s, odd, threads=2)
+        assert "subfield" in str(ei.value)
+        assert cbam.session_records(s).n_records == 0
+        s.push(whole.records)
+        st, su = s.finish()
+        h = s.hist()
+        # and the session still ingests a regular file afterwards
+        s.reset()
+        cbam.gpu_ingest(s, good, threads=2)
+        st3, su3 = s.finish()
+        h3 = s.hist()
+    with Session(0, FilterConfig(), 75, want_hist=True, want_identity=True) as s:
+        s.set_targets(whole.ref_lens)
+        s.push(whole.records)
+        st2, su2 = s.finish()
+        h2 = s.hist()
+    assert st.tobytes() == st2.tobytes() == st3.tobytes() and (h == h2).all() and (h == h3).all()
+
+
+def test_spans_of_a_file_that_is_not_sorted_by_reference_are_refused(tmp_path):
+    """A span drops its neighbours' records trusting the file's order; a file whose tids decrease must end in the reference's
+    "appears to be unsorted" error (contig.rs:129-132) in span mode too, from the device ingest and from the CPU span reader —
+    never in silently missing records."""
+    ref = synth.make_reference(40, 6_000_000, seed=18, min_len=5000, max_len=800_000)
+    b = synth.make_reads(ref, 150_000, seed=31)
+    cut = int(np.searchsorted(b.tid, 20))
+    assert 0 < cut < b.n_records
+    swapped = swap_halves(b, cut)
+    p = str(tmp_path / "unsorted.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, swapped, with_seq=2, threads=4)
+    seen_dev = seen_cpu = 0
+    for i in range(2):
+        with Session(0, FilterConfig(), 75) as s:
+            try:
+                cbam.gpu_ingest(s, p, threads=3, span=(i, 2))
+            except IOError as e:
+                assert "appears to be unsorted" in str(e)
+                seen_dev += 1
+        try:
+            list(cbam.stream_batches(p, 2, span_index=i, span_count=2))
+        except IOError as e:
+            assert "appears to be unsorted" in str(e)
+            seen_cpu += 1
+    assert seen_dev >= 1 and seen_cpu >= 1
