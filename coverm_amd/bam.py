@@ -158,7 +158,7 @@ def read_streamed(path: str, threads: int = None, span_index: int = 0, span_coun
                                     coff, cat("cigar"))
 
 
-def gpu_ingest(session, path: str, threads: int = None, check_crc: bool = True, mask=None, span=(0, 1)):
+def gpu_ingest(session, path: str, threads: int = None, check_crc: bool = True, mask=None, span=(0, 1), want_mates: bool = False):
     """Device ingest (covh_bam_read_header + covh_bam_gpu_ingest): the GPU inflates the BGZF blocks, finds the records and fills
     the session's record store.  Sets the session's targets from the file's header.  Returns (ref_names, ref_lens, n_records,
     timing dict); raises IngestFallback when the file needs the CPU reader.  span = (index, count): one tid span of the file
@@ -191,6 +191,9 @@ def gpu_ingest(session, path: str, threads: int = None, check_crc: bool = True, 
         names = [L.covh_bam_header_target_name(hd, i).decode() for i in range(nt)]
         lens = np.asarray([L.covh_bam_header_target_len(hd, i) for i in range(nt)], dtype=np.int64)
         session.set_targets(lens, mask)
+        L.cov_ingest_want_mates.argtypes = [C.c_void_p, C.c_int]
+        if L.cov_ingest_want_mates(session._h, int(want_mates)) != 0:
+            raise RuntimeError("cov_ingest_want_mates failed")
         n = C.c_uint64(0)
         t = (C.c_double * 8)()
         rc = L.covh_bam_gpu_ingest_span(path.encode(), threads, session._h, hd, int(check_crc), int(span[0]), int(span[1]), C.byref(n), t, err, 512)
@@ -201,6 +204,31 @@ def gpu_ingest(session, path: str, threads: int = None, check_crc: bool = True, 
         return names, lens, int(n.value), dict(read=t[0], slot_wait=t[1], end=t[2], total=t[3], begin=t[4], walk=t[5], feed=t[6])
     finally:
         L.covh_bam_header_free(hd)
+
+
+class _DevPairFilter(C.Structure):   # cov_pair_filter
+    _fields_ = [("filter_single", C.c_int32), ("min_mapq", C.c_uint8), ("pad", C.c_uint8 * 3), ("min_aligned_length_single", C.c_uint32),
+                ("min_percent_identity_single", C.c_float), ("min_aligned_percent_single", C.c_float), ("min_aligned_length_pair", C.c_uint32),
+                ("min_percent_identity_pair", C.c_float), ("min_aligned_percent_pair", C.c_float)]
+
+
+def pair_filter_apply(session, filter_single: bool, min_mapq: int, single=(0, 0.0, 0.0), pair=(0, 0.0, 0.0)):
+    """cov_pair_filter_apply: the reader-stage pair filter (filter.rs:117-228) over the store a device ingest with want_mates filled.
+    single / pair = (min_aligned_length, min_percent_identity, min_aligned_percent).  Returns (n_selected, n_primary); raises
+    IngestFallback when the device declines, NativeError-like RuntimeError with the reference's message on NM errors."""
+    L = _lib()
+    L.cov_pair_filter_apply.argtypes = [C.c_void_p, C.POINTER(_DevPairFilter), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.cov_last_error.restype = C.c_char_p
+    L.cov_last_error.argtypes = [C.c_void_p]
+    f = _DevPairFilter(int(filter_single), int(min_mapq), (C.c_uint8 * 3)(), int(single[0]), float(single[1]), float(single[2]),
+                       int(pair[0]), float(pair[1]), float(pair[2]))
+    nsel, nprim = C.c_uint64(0), C.c_uint64(0)
+    rc = L.cov_pair_filter_apply(session._h, C.byref(f), C.byref(nsel), C.byref(nprim))
+    if rc == 19:
+        raise IngestFallback(L.cov_last_error(session._h).decode())
+    if rc != 0:
+        raise RuntimeError("cov_pair_filter_apply: %d: %s" % (rc, L.cov_last_error(session._h).decode()))
+    return int(nsel.value), int(nprim.value)
 
 
 class IngestFallback(RuntimeError):

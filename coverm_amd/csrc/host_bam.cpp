@@ -1295,17 +1295,53 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
         }
     }
     const bool mid_start = f_lo != 0, open_end = size != file_size;
-    size_t piece = (size_t)64 << 20;
-    if (const char *pb = getenv("COVERM_INGEST_PIECE_KB")) { const long v = atol(pb); if (v >= 64) piece = (size_t)v << 10; }
+    // Where the DMA engine takes the compressed bytes from (COVERM_INGEST_IO = mmap | pread):
+    //   mmap  (default) the file is mapped and its pages are registered with the device piece by piece, ahead of the uploads: the
+    //         bytes go from the page cache to HBM with no copy by the CPU (tools/ubench/io_probe on the lease box: 57 GB/s, the
+    //         link's rate; the threaded pread into 64 MiB staging slots delivered 42-44 GB/s and kept 16 threads busy);
+    //   pread staging slots in page-locked memory filled by threaded preads — also what is used when the runtime refuses to
+    //         register the mapping.
+    const char *io = getenv("COVERM_INGEST_IO");
+    bool use_map = !(io && !strcmp(io, "pread"));
+    uint8_t *map = nullptr;
+    const uint64_t PG = 4096, map_len = (file_size + PG - 1) / PG * PG;
+    if (use_map) {
+        void *m = mmap(nullptr, (size_t)file_size, PROT_READ, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) use_map = false; else map = (uint8_t *)m;
+    }
     constexpr int NS = COV_INGEST_SLOTS;
     uint8_t *buf[NS];
     for (int k = 0; k < NS; k++) buf[k] = nullptr;       // page-locked on first use by the reader thread: slots 1.. are pinned while piece 0 is already on its way
     // Every way out of this function after cov_ingest_begin first gives up whatever is still queued on the device (no-op once
-    // cov_ingest_end has run), and only then parks the staging buffers: an upload may still be reading them, and an extraction
-    // still writing the store the CPU reader is about to push into.
-    struct BufFree { cov_session *s; uint8_t **b; ~BufFree() { (void)cov_ingest_abort(s); for (int k = 0; k < NS; k++) if (b[k]) cov_host_free(b[k]); } } bf{s, buf};
+    // cov_ingest_end has run), and only then parks the staging buffers / unregisters the mapping: an upload may still be reading
+    // them, and an extraction still writing the store the CPU reader is about to push into.
+    struct BufFree {
+        cov_session *s; uint8_t **b; uint8_t *&map; uint64_t file_size; std::vector<std::pair<uint8_t *, uint64_t>> regs; std::mutex m;
+        ~BufFree() {
+            (void)cov_ingest_abort(s);
+            for (int k = 0; k < NS; k++) if (b[k]) cov_host_free(b[k]);
+            for (auto &r : regs) (void)cov_host_unregister(s, r.first);
+            if (map) munmap(map, (size_t)file_size);
+        }
+    } bf{s, buf, map, file_size, {}, {}};
     if (cov_ingest_begin(s, file_size, first_record, check_crc) != COV_OK) return fail(-1, cov_last_error(s));
     if (span_count > 1 && cov_ingest_span(s, key_lo, key_hi, mid_start ? 1 : 0, open_end ? 1 : 0, f_lo, size) != COV_OK) return fail(-1, cov_last_error(s));
+    size_t piece = use_map ? (size_t)256 << 20 : (size_t)64 << 20;
+    if (const char *pb = getenv("COVERM_INGEST_PIECE_KB")) { const long v = atol(pb); if (v >= 64) piece = (size_t)v << 10; }
+    // registered so far: [reg_lo0, reg_hi) of the mapping, in whole pages; a piece registers what of its pages is not registered yet
+    uint64_t reg_hi = f_lo / PG * PG;
+    auto register_piece = [&](uint64_t off, uint64_t n) -> bool {
+        const uint64_t hi = std::min<uint64_t>(map_len, (off + n + PG - 1) / PG * PG);
+        if (hi <= reg_hi) return true;
+        if (cov_host_register(s, map + reg_hi, (size_t)(hi - reg_hi)) != COV_OK) return false;
+        { std::lock_guard<std::mutex> lk(bf.m); bf.regs.emplace_back(map + reg_hi, hi - reg_hi); }
+        reg_hi = hi;
+        return true;
+    };
+    if (use_map && !register_piece(f_lo, std::min<uint64_t>(piece, size - f_lo))) {     // refused: staging slots instead
+        use_map = false;
+        if (!getenv("COVERM_INGEST_PIECE_KB")) piece = (size_t)64 << 20;
+    }
     const double t_begin = now() - t_start;
     std::vector<cov_bgzf_block> blocks;
     uint64_t next_blk = f_lo, out_off = 0, pending_bsize = 0;     // absolute file offset of the next block header; running inflated size; BSIZE of a block whose header is read but whose end is not here yet
@@ -1353,7 +1389,7 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     // and the device never wait for one another in turn.
     std::mutex mu; std::condition_variable cv;
     uint64_t ready = 0, fed = 0;        // pieces read so far / pieces handed to cov_ingest_feed so far
-    bool reader_failed = false, stop = false;
+    bool reader_failed = false, reader_soft = false, stop = false;      // soft: the file can still go to the CPU reader
     std::string reader_err;
     std::thread reader([&]() {
         Pool pool(std::max(1, threads));
@@ -1365,6 +1401,21 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
                 if (stop) return;
             }
             double t0 = now();
+            const uint64_t off = f_lo + k * piece, n = std::min<uint64_t>(piece, size - off);
+            const size_t nch = (size_t)((n + chunk - 1) / chunk);
+            std::atomic<bool> ok{true};
+            if (use_map) {
+                // the piece's pages become device-readable (a few ms per 256 MiB), the pool hops its block headers in the mapping
+                if (!register_piece(off, n)) { std::lock_guard<std::mutex> lk(mu); reader_failed = true; reader_soft = true; reader_err = cov_last_error(s); cv.notify_all(); return; }
+                t_wait += now() - t0;
+                t0 = now();
+                const uint8_t *src = map + off;
+                pool.run(nch, [&](size_t c) {
+                    const size_t o0 = c * chunk, e = (size_t)std::min<uint64_t>(n, (uint64_t)o0 + chunk);
+                    prewalk(src + o0, e - o0, off + o0, pre[(size_t)slot * chunks_per_piece + c]);
+                });
+                t_read += now() - t0;
+            } else {
             if (k >= NS && cov_ingest_slot_wait(s, slot) != COV_OK) {
                 std::lock_guard<std::mutex> lk(mu); reader_failed = true; reader_err = cov_last_error(s); cv.notify_all(); return;
             }
@@ -1374,9 +1425,6 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
                 if (!buf[slot]) { std::lock_guard<std::mutex> lk(mu); reader_failed = true; reader_err = "no page-locked staging memory (is a HIP device usable?)"; cv.notify_all(); return; }
             }
             t0 = now();
-            const uint64_t off = f_lo + k * piece, n = std::min<uint64_t>(piece, size - off);
-            const size_t nch = (size_t)((n + chunk - 1) / chunk);
-            std::atomic<bool> ok{true};
             uint8_t *dst = buf[slot];
             pool.run(nch, [&](size_t c) {
                 const size_t o0 = c * chunk;
@@ -1389,6 +1437,7 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
                 prewalk(dst + o0, e - o0, off + o0, pre[(size_t)slot * chunks_per_piece + c]);
             });
             t_read += now() - t0;
+            }
             std::lock_guard<std::mutex> lk(mu);
             if (!ok) { reader_failed = true; reader_err = std::string("read error on ") + path; cv.notify_all(); return; }
             ready = k + 1;
@@ -1403,9 +1452,9 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return reader_failed || ready > k; });
-            if (reader_failed) return fail(-1, reader_err);
+            if (reader_failed) return fail(reader_soft ? 1 : -1, reader_err);
         }
-        uint8_t *dst = buf[slot];
+        const uint8_t *dst = use_map ? map + off : buf[slot];
         double t0 = now();
         // ---- block headers completed by this piece
         auto byte_at = [&](uint64_t a) -> uint8_t {   // absolute file offset, within this piece or the saved tail of the previous one

@@ -95,6 +95,7 @@ struct Sample {
 };
 
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+bool timing_on() { static const bool on = getenv("COVERM_CLI_TIMING") != nullptr; return on; }
 
 struct Run {
     Args a;
@@ -149,9 +150,13 @@ bool is_bgzf(const std::string &path) {
 // Decode + push + finish of one BAM (or one tid span of it) on one session.  Leaves the session finished.
 void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index, uint32_t span_count) {
     const Args &a = R.a;
-    const bool stream = !a.no_stream && !R.fp && !R.per_gene && is_bgzf(S.path);
-    if (span_count > 1 && !stream) die("--devices with fewer BAM files than devices needs streamable input (BAM, no pair-mode filter, no --gff)");
-    S.stoit = stoit_of(S.path); S.streamed = stream;
+    // pair-mode filtering (filter.rs:117-228) runs on the device over what the device ingest extracted (mate reference + read-name
+    // hash per record, cov_pair_filter_apply); only when that path declines the file does the whole file come to the host
+    const bool bgzf = is_bgzf(S.path);
+    const bool pair_dev = R.fp && !a.no_stream && !R.per_gene && bgzf && !getenv("COVERM_NO_GPU_INGEST") && !getenv("COVERM_PAIR_ON_HOST");
+    const bool stream = !a.no_stream && (!R.fp || pair_dev) && !R.per_gene && bgzf;
+    if (span_count > 1 && !stream) die("--devices with fewer BAM files than devices needs streamable input (BAM, no --gff)");
+    S.stoit = stoit_of(S.path); S.streamed = stream && !R.fp;
     const double t0 = now();
     std::vector<uint8_t> mask;
     check(s, cov_reset(s));
@@ -167,8 +172,23 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         if (R.by_names) { genome_table(R, S, mask); check(s, cov_set_target_mask(s, mask.data())); }
         S.t_open = now() - t0;
         uint64_t nrec = 0; double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int rc = covh_bam_gpu_ingest_span(S.path.c_str(), threads, s, hd, getenv("COVERM_NO_CRC") ? 0 : 1, span_index, span_count, &nrec, tm, err, sizeof err);
+        check(s, cov_ingest_want_mates(s, R.fp ? 1 : 0));
+        int rc = covh_bam_gpu_ingest_span(S.path.c_str(), threads, s, hd, getenv("COVERM_NO_CRC") ? 0 : 1, span_index, span_count, &nrec, tm, err, sizeof err);
         if (rc < 0) die(err);
+        uint64_t pair_prim = 0; double t_pair = 0;
+        if (rc == 0 && R.fp) {     // the reader-stage pair filter, on the device
+            const double tp0 = now();
+            cov_pair_filter pf; memset(&pf, 0, sizeof pf);
+            pf.filter_single = R.fs; pf.min_mapq = (uint8_t)R.f.mapq; pf.min_aligned_length_single = R.f.len_single;
+            pf.min_percent_identity_single = R.f.pid_single; pf.min_aligned_percent_single = R.f.pct_single;
+            pf.min_aligned_length_pair = R.f.len_pair; pf.min_percent_identity_pair = R.f.pid_pair; pf.min_aligned_percent_pair = R.f.pct_pair;
+            uint64_t nsel = 0;
+            const cov_status prc = cov_pair_filter_apply(s, &pf, &nsel, &pair_prim);
+            if (prc == COV_ERR_INGEST_FALLBACK) { rc = 1; snprintf(err, sizeof err, "%s", cov_last_error(s)); }
+            else check(s, prc);
+            t_pair = now() - tp0;
+            if (timing_on() && rc == 0) fprintf(stderr, "[coverm-amd] %s: pair filter on the device: %llu of %llu records selected, %.3fs\n", S.stoit.c_str(), (unsigned long long)nsel, (unsigned long long)nrec, t_pair);
+        }
         if (rc == 0) {
             S.n_records = nrec; S.device_ingest = true;
             if (getenv("COVERM_CLI_TIMING"))
@@ -179,14 +199,15 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
             cov_summary summ;
             check(s, cov_finish(s, S.stats.data(), &summ));
             if (R.want & COV_WANT_HIST) { S.hist.resize(summ.hist_total); check(s, cov_fetch_hist(s, S.hist.data())); }
-            S.prim = summ.num_detected_primary_alignments;
+            S.prim = R.fp ? pair_prim : summ.num_detected_primary_alignments;      // filter.rs:129-131 counts every primary record of the input
             S.t_finish = now() - t0 - S.t_ingest;
             return;
         }
         if (getenv("COVERM_CLI_TIMING")) fprintf(stderr, "[coverm-amd] %s: %s\n", S.stoit.c_str(), err);
         check(s, cov_reset(s));       // the CPU reader takes the file
+        if (R.fp && span_count > 1) die(std::string("--devices with fewer BAM files than devices and a pair-mode filter needs the device ingest, which declined this file: ") + err);
     }
-    if (stream) {
+    if (stream && !R.fp) {
         char err[512] = {0};
         covh_bam_stream *st = covh_bam_stream_open(S.path.c_str(), threads, span_index, span_count, err, sizeof err);
         if (!st) die(err);

@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pair_kernels.hip.h"
+
 namespace covi {
 
 typedef unsigned long long u64;
@@ -756,6 +758,8 @@ struct RecStore {
     uint8_t *mapq, *nm_kind;
     u32 *nm, *l_seq, *cigar_off, *cigar;
     u64 rec0, cig0;    // where this file's records / CIGAR words start in the store
+    // mates (pair-mode reader filter, csrc/pair_kernels.hip.h): next_refID and a 96-bit hash of the read name; null = not kept
+    int32_t *mtid; u64 *qh1; u32 *qh2;
 };
 
 // Linear aux scan for NM (csrc/host_bam.cpp scan_aux without the CG part).
@@ -816,6 +820,12 @@ __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__
         R.tid[ri] = (int32_t)ld32(r + 4); R.pos[ri] = (int32_t)ld32(r + 8);
         R.mapq[ri] = r[13]; R.flag[ri] = (uint16_t)ld16(r + 18); R.l_seq[ri] = l_seq;
         R.cigar_off[ri] = (u32)ci;
+        if (R.mtid) {      // filter.rs:164-176 needs the mate's reference and the read name (without its NUL)
+            R.mtid[ri] = (int32_t)ld32(r + 24);
+            u64 k1; u32 k2;
+            covp::name_hash(r + 36, l_read_name ? l_read_name - 1u : 0u, k1, k2);
+            R.qh1[ri] = k1; R.qh2[ri] = k2;
+        }
         const uint8_t *c = r + 36 + l_read_name;
         const uint8_t *aux = c + 4ull * n_cig + ((u64)l_seq + 1ull) / 2 + l_seq;
         if (aux > end) { atomicAdd(n_bad, 1u); aux = end; }

@@ -231,6 +231,28 @@ cov_status cov_ingest_end(cov_session *s, uint64_t *n_records);
 cov_status cov_ingest_abort(cov_session *s);
 cov_status cov_ingest_release(cov_session *s); /* frees the compressed / inflated buffers (kept between files otherwise) */
 cov_status cov_ingest_copy_inflated(cov_session *s, uint64_t offset, uint64_t n, void *out); /* test hook; single-window files only */
+/* ---- reader-stage PAIR filter on the device: ReferenceSortedBamFilter::read, pair branch (src/filter.rs:117-228, filter_out = true) +
+ * read_pair_passes_filter (:281-336) over the records the device ingest put into the session's store.
+ *   cov_ingest_want_mates(s, 1)      before cov_ingest_begin: the extraction also keeps next_refID and a 96-bit hash of each read name
+ *   ... ingest one or more files ...
+ *   cov_pair_filter_apply(s, &f, &n_selected, &n_primary)
+ * replaces the store by the records the reference's filter would return, in its order (pairs by their second record; first record,
+ * then second); *n_primary = num_detected_primary_alignments (filter.rs:129-131: every primary record of the input).  cov_finish then
+ * runs with cov_config.filter_single = 0.  COV_ERR_NM_MISSING / COV_ERR_NM_BADTYPE where the reference's nm() would have panicked;
+ * COV_ERR_INGEST_FALLBACK (store untouched) when more than 2^20 records carry a read name that occurs more than twice among the
+ * primary proper-pair records of one reference (fewer are replayed exactly): run the host filter (covh_pair_mode_order) on the CPU
+ * reader's records then.  Same layout as covh_pair_filter. */
+typedef struct {
+    int32_t filter_single;     /* single-read thresholds apply to both mates as well (filter.rs:48-55) */
+    uint8_t min_mapq;          /* 255 = off */
+    uint8_t pad[3];
+    uint32_t min_aligned_length_single;
+    float min_percent_identity_single, min_aligned_percent_single;
+    uint32_t min_aligned_length_pair;
+    float min_percent_identity_pair, min_aligned_percent_pair;
+} cov_pair_filter;
+cov_status cov_ingest_want_mates(cov_session *s, int on);
+cov_status cov_pair_filter_apply(cov_session *s, const cov_pair_filter *f, uint64_t *n_selected, uint64_t *n_primary);
 /* Test hook: the session's own record store copied back into caller-sized host arrays (host == NULL: only the counts). */
 cov_status cov_copy_records(cov_session *s, const cov_batch *host, uint64_t *n_records, uint64_t *n_cigar);
 
@@ -270,6 +292,11 @@ cov_status cov_fetch_interval_hist(cov_session *s, uint64_t *hist);
  * when no HIP device is usable; cov_host_free returns 0 if `p` did not come from cov_host_alloc; cov_host_trim
  * gives the parked blocks back to the system. */
 void *cov_host_alloc(size_t bytes);
+/* Host memory the caller owns (e.g. an mmap of the BAM file, page aligned) made readable by the session's device, so that
+ * cov_ingest_feed can take its bytes from there without a staging copy; unregister once the session has synchronised
+ * (after cov_ingest_end / cov_ingest_abort).  COV_ERR_HIP when the runtime refuses the range: use staging buffers then. */
+cov_status cov_host_register(cov_session *s, void *p, size_t bytes);
+cov_status cov_host_unregister(cov_session *s, void *p);
 int cov_host_free(void *p);
 void cov_host_trim(void);
 

@@ -58,12 +58,19 @@ print("MOCK_OK", mode, n.value)
 '''
 
 
+@pytest.mark.parametrize("io", ["mmap", "pread", "mmap_refused"])
 @pytest.mark.parametrize("mode,piece_kb", [("synth", 0), ("synth", 64), ("synth", 200), ("tiny_blocks", 64), ("tiny_blocks", 0)])
-def test_ingest_driver_feeds_consistent_blocks(tmp_path, mode, piece_kb):
+def test_ingest_driver_feeds_consistent_blocks(tmp_path, mode, piece_kb, io):
+    """io: the bytes come from the registered mapping of the file (default), from staging slots filled by pread, or the mapping is
+    refused by the runtime and the driver switches to staging slots by itself."""
     if not _has_mock():
         pytest.skip("needs the sanitizer build's CPU mock of cov_ingest_* (tools/asan_host.sh); the GPU suite covers the driver otherwise")
     env = dict(os.environ)
     if piece_kb:
         env["COVERM_INGEST_PIECE_KB"] = str(piece_kb)
+    if io == "pread":
+        env["COVERM_INGEST_IO"] = "pread"
+    if io == "mmap_refused":
+        env["COVERM_MOCK_NO_REGISTER"] = "1"
     r = subprocess.run([sys.executable, "-c", WORKER % ROOT, mode, str(tmp_path)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0 and "MOCK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -80,6 +80,19 @@ cov_status cov_ingest_end(cov_session *s, uint64_t *n_records) {
     return COV_OK;
 }
 cov_status cov_ingest_release(cov_session *) { return COV_OK; }
+cov_status cov_ingest_abort(cov_session *s) { if (s) s->active = false; return COV_OK; }
+// registration of the mapped file: accepted (the mock's feed reads the mapping like any host memory), or refused to exercise the
+// driver's switch to staging slots; every registered range must be unregistered exactly once, after the ingest ended
+static std::set<void *> g_reg;
+cov_status cov_host_register(cov_session *s, void *p, size_t n) {
+    if (getenv("COVERM_MOCK_NO_REGISTER") || !p || !n || ((uintptr_t)p & 4095u)) { if (s) s->err = "mock: registration refused"; return COV_ERR_HIP; }
+    std::lock_guard<std::mutex> lk(g_hm); if (!g_reg.insert(p).second) { s->err = "mock: range registered twice"; return COV_ERR_HIP; } return COV_OK;
+}
+cov_status cov_host_unregister(cov_session *s, void *p) {
+    std::lock_guard<std::mutex> lk(g_hm);
+    if (s->active || !g_reg.erase(p)) { s->err = "mock: unregister of an unknown range or during the ingest"; abort(); }
+    return COV_OK;
+}
 }
 EOS
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -shared -fPIC -I$R/include \
