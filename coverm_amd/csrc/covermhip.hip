@@ -266,6 +266,11 @@ cov_status append(cov_session *s, const cov_batch *b, bool from_device) {
     return COV_OK;
 }
 
+void timing_events(cov_session *s) {
+    if (s->ev[0][0]) return;
+    for (int k = 0; k < COV_K_COUNT; k++)
+        for (int j = 0; j < 2; j++) (void)hipEventCreate(&s->ev[k][j]);
+}
 void time_begin(cov_session *s, int k) { (void)hipEventRecord(s->ev[k][0], s->stream); }
 void time_end(cov_session *s, int k) { (void)hipEventRecord(s->ev[k][1], s->stream); s->k_launches[k]++; }
 
@@ -378,8 +383,12 @@ const char *cov_last_error(const cov_session *s) { return s ? s->err.c_str() : g
 cov_status cov_create(const cov_config *cfg, cov_session **out) {
     if (!cfg || !out) { g_create_error = "null argument"; return COV_ERR_INVALID_ARG; }
     *out = nullptr;
+    const bool timing = getenv("COVERM_CLI_TIMING") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) { if (timing) fprintf(stderr, "[covermhip] cov_create: %s at %.4fs\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count()); };
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
+    stamp("hipGetDeviceCount (runtime initialised)");
     if (e != hipSuccess || ndev <= 0) {
         g_create_error = std::string("no usable HIP device: ") + hipGetErrorString(e) +
                          " (the engine has no CPU fallback)";
@@ -407,8 +416,10 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
             s->tile = STREAM_TW;
         }
         if (chk && atoi(chk) > 0) s->chunk_tiles = atoi(chk);
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
+        stamp("hipSetDevice");
+        int cus = 0;      // (hipGetDeviceProperties fills a kilobyte of fields from many driver queries; one attribute is all that is needed)
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) s->n_cus = cus;
+        stamp("device attribute");
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
@@ -417,10 +428,10 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_side_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete s; return COV_ERR_HIP; }
-    for (int k = 0; k < COV_K_COUNT; k++)
-        for (int j = 0; j < 2; j++) (void)hipEventCreate(&s->ev[k][j]);
+    stamp("streams and events");      // (the kernels' timing events are created by the first cov_finish: a run that ingests a file needs them half a second later)
     e = bind_result_block(s, 1);
     if (e != hipSuccess) { g_create_error = std::string("hipMalloc: ") + hipGetErrorString(e); cov_destroy(s); return COV_ERR_HIP; }
+    stamp("first hipMalloc");
     *out = s;
     return COV_OK;
 }
@@ -677,6 +688,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     if (!s || (!stats && s->n_targets)) return COV_ERR_INVALID_ARG;
     s->depth_all_valid = false;
     HIPCHK(hipSetDevice(s->cfg.device));
+    timing_events(s);
     hipStream_t st = s->stream;
     const u32 nT = s->n_targets;
     const u32 R = (u32)s->n_records;
@@ -961,7 +973,9 @@ static_assert(sizeof(cov_bgzf_block) == sizeof(covi::BgzfBlock) && offsetof(cov_
 
 // Which k_inflate instantiation runs (COVERM_INFLATE_BITS / COVERM_INFLATE_DIST_BITS: primary table sizes), how many of its
 // one-wave workgroups the device holds at once (= blocks per round = blocks per window), and the size of the carry area.
-struct InflateKernel { int lit_bits = 8, dist_bits = 6; bool sort8 = false; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; };
+struct InflateKernel { int version = 1; int lit_bits = 8, dist_bits = 6; bool sort8 = false; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; };
+// k_inflate2 instantiations (COVERM_INFLATE_V=2; the default is k_inflate)
+#define COV_INFLATE2_VARIANTS(X) X(8, 6, false) X(8, 5, false) X(7, 6, false) X(7, 5, false) X(6, 5, false) X(7, 6, true) X(7, 5, true) X(6, 5, true)
 #define COV_INFLATE_VARIANTS(X) X(9, 6, false) X(8, 6, false) X(7, 6, false) X(7, 5, false) X(6, 5, false) X(7, 6, true) X(6, 5, true) X(5, 5, true)
 static const InflateKernel &inflate_kernel(cov_session *s) {
     static InflateKernel K;
@@ -969,11 +983,27 @@ static const InflateKernel &inflate_kernel(cov_session *s) {
     std::call_once(once, [&]() {
         const char *e = getenv("COVERM_INFLATE_BITS"), *d = getenv("COVERM_INFLATE_DIST_BITS");
         const bool s8 = getenv("COVERM_INFLATE_SORT8") && atoi(getenv("COVERM_INFLATE_SORT8"));
-        const int lb = e ? atoi(e) : 7, db = d ? atoi(d) : (lb <= 6 ? 5 : 6);     // 7 + 6 bits: five waves per CU, the fastest measured (200 M reads: 0.71 s against 0.87 s at 8 + 6, 0.84 s at 6 + 5)
+        const char *ve = getenv("COVERM_INFLATE_V");
+        K.version = ve && atoi(ve) == 2 ? 2 : 1;      // k_inflate2 is correct but not faster yet (profiles/r03_inflate2_variants.log): opt-in
+        const int lb = e ? atoi(e) : 7, db = d ? atoi(d) : (K.version == 2 ? 5 : (lb <= 6 ? 5 : 6));     // k_inflate: 7 + 6 bits, five waves per CU, the fastest measured (200 M reads: 0.71 s against 0.87 s at 8 + 6, 0.84 s at 6 + 5); k_inflate2: 7 + 5 = 32 KiB, five waves per CU
         int per_cu = 0;
         bool found = false;
+#define COV_INF2_SETUP(LB, DB, S8)                                                                                                             \
+        if (K.version == 2 && lb == LB && db == DB && s8 == S8) {                                                                              \
+            found = true; K.lit_bits = LB; K.dist_bits = DB; K.sort8 = S8;                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate2<LB, DB, S8>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)covi::inflate2_smem_bytes(LB, DB, S8));                                                             \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate2<LB, DB, S8>, 64, covi::inflate2_smem_bytes(LB, DB, S8)); \
+        }
+        COV_INFLATE2_VARIANTS(COV_INF2_SETUP)
+#undef COV_INF2_SETUP
+        if (K.version == 2 && !found) {
+            found = true; K.lit_bits = 7; K.dist_bits = 5;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate2<7, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)covi::inflate2_smem_bytes(7, 5));
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate2<7, 5, false>, 64, covi::inflate2_smem_bytes(7, 5));
+        }
 #define COV_INF_SETUP(LB, DB, S8)                                                                                                              \
-        if (lb == LB && db == DB && s8 == S8) {                                                                                                \
+        if (K.version == 1 && lb == LB && db == DB && s8 == S8) {                                                                                                \
             found = true; K.lit_bits = LB; K.dist_bits = DB; K.sort8 = S8;                                                                     \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, DB, S8>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)covi::inflate_smem_bytes(LB, DB, S8));                                                              \
@@ -1002,6 +1032,13 @@ static const InflateKernel &inflate_kernel(cov_session *s) {
 // The dynamic-LDS limit of a kernel is a per-device attribute: every session's device gets it (inflate_kernel's own call only
 // reaches the device of the first session of the process).
 static void inflate_prepare_device(const InflateKernel &K) {
+#define COV_INF2_ATTR(LB, DB, S8)                                                                                                               \
+    if (K.version == 2 && K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate2<LB, DB, S8>), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                  (int)covi::inflate2_smem_bytes(LB, DB, S8));
+    COV_INFLATE2_VARIANTS(COV_INF2_ATTR)
+#undef COV_INF2_ATTR
+    if (K.version == 2) return;
 #define COV_INF_ATTR(LB, DB, S8)                                                                                                                \
     if (K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                                                 \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, DB, S8>), hipFuncAttributeMaxDynamicSharedMemorySize,     \
@@ -1162,8 +1199,15 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
         const u32 grid = (n + 63u) / 64u;
         const uint8_t *comp_bias = s->g_cwin[w % 3u].p - s->ing_round_start;     // blocks carry absolute file offsets
         static const u32 ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);
+#define COV_LAUNCH_INFLATE2(LB, DB, S8)                                                                                                         \
+        if (K.version == 2 && K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                               \
+            hipLaunchKernelGGL((covi::k_inflate2<LB, DB, S8>), dim3(grid), dim3(64), covi::inflate2_smem_bytes(LB, DB, S8), s->stream, comp_bias,   \
+                               (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, s->g_scratch.p, tokb.p, ntokb.p,                         \
+                               s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
+        COV_INFLATE2_VARIANTS(COV_LAUNCH_INFLATE2)
+#undef COV_LAUNCH_INFLATE2
 #define COV_LAUNCH_INFLATE(LB, DB, S8)                                                                                                          \
-        if (K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                                                 \
+        if (K.version == 1 && K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                                                 \
             hipLaunchKernelGGL((covi::k_inflate<LB, DB, S8>), dim3(grid), dim3(64), covi::inflate_smem_bytes(LB, DB, S8), s->stream, comp_bias, \
                                (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, s->g_scratch.p, tokb.p, ntokb.p,                             \
                                s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);

@@ -1295,14 +1295,15 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
         }
     }
     const bool mid_start = f_lo != 0, open_end = size != file_size;
-    // Where the DMA engine takes the compressed bytes from (COVERM_INGEST_IO = mmap | pread):
-    //   mmap  (default) the file is mapped and its pages are registered with the device piece by piece, ahead of the uploads: the
-    //         bytes go from the page cache to HBM with no copy by the CPU (tools/ubench/io_probe on the lease box: 57 GB/s, the
-    //         link's rate; the threaded pread into 64 MiB staging slots delivered 42-44 GB/s and kept 16 threads busy);
-    //   pread staging slots in page-locked memory filled by threaded preads — also what is used when the runtime refuses to
-    //         register the mapping.
+    // Where the DMA engine takes the compressed bytes from (COVERM_INGEST_IO = pread | mmap):
+    //   pread (default) staging slots in page-locked memory filled by threaded preads;
+    //   mmap  the file is mapped and its pages are registered with the device piece by piece, ahead of the uploads, so that the
+    //         bytes go from the page cache to HBM with no copy by the CPU.  Alone on an idle device this reaches the link's rate
+    //         (tools/ubench/io_probe: 57 GB/s against 42-54 GB/s through staging slots), but inside the running pipeline
+    //         hipHostRegister drops to ~20 GB/s, the copies take longer to enqueue and unregistering 20 GB at the end costs
+    //         another 0.4 s (profiles/r03_io_modes.log: 200 M reads 1.78 s against 0.98 s): kept as an option, not the default.
     const char *io = getenv("COVERM_INGEST_IO");
-    bool use_map = !(io && !strcmp(io, "pread"));
+    bool use_map = io && !strcmp(io, "mmap");
     uint8_t *map = nullptr;
     const uint64_t PG = 4096, map_len = (file_size + PG - 1) / PG * PG;
     if (use_map) {
@@ -1326,7 +1327,10 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     } bf{s, buf, map, file_size, {}, {}};
     if (cov_ingest_begin(s, file_size, first_record, check_crc) != COV_OK) return fail(-1, cov_last_error(s));
     if (span_count > 1 && cov_ingest_span(s, key_lo, key_hi, mid_start ? 1 : 0, open_end ? 1 : 0, f_lo, size) != COV_OK) return fail(-1, cov_last_error(s));
-    size_t piece = use_map ? (size_t)256 << 20 : (size_t)64 << 20;
+    // staging slots: page-locked memory costs ~0.17 s per GiB to obtain and ~0.13 s per GiB to give back when the process ends
+    // (tools/ubench/exit_probe), so the slots are as small as the reader's rate allows: 4 x 32 MiB in 2 MiB chunks read 5 GB in
+    // 0.098 s inside the pipeline, 4 x 64 MiB in 4 MiB chunks in 0.114 s (profiles/r03_reader_sweep_50M.log)
+    size_t piece = use_map ? (size_t)256 << 20 : (size_t)32 << 20;
     if (const char *pb = getenv("COVERM_INGEST_PIECE_KB")) { const long v = atol(pb); if (v >= 64) piece = (size_t)v << 10; }
     // registered so far: [reg_lo0, reg_hi) of the mapping, in whole pages; a piece registers what of its pages is not registered yet
     uint64_t reg_hi = f_lo / PG * PG;
@@ -1340,7 +1344,7 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     };
     if (use_map && !register_piece(f_lo, std::min<uint64_t>(piece, size - f_lo))) {     // refused: staging slots instead
         use_map = false;
-        if (!getenv("COVERM_INGEST_PIECE_KB")) piece = (size_t)64 << 20;
+        if (!getenv("COVERM_INGEST_PIECE_KB")) piece = (size_t)32 << 20;
     }
     const double t_begin = now() - t_start;
     std::vector<cov_bgzf_block> blocks;
@@ -1353,7 +1357,8 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     // entirely inside it while the bytes are still in its cache (first header found by its 16-byte signature); the coordinator
     // takes over a chunk's list when the chain arrives exactly at the list's first header, and hops by itself otherwise (the blocks
     // that straddle chunks, or a chunk whose first signature was a coincidence inside compressed data).
-    const size_t chunk = 4u << 20;
+    size_t chunk = 2u << 20;
+    if (const char *cb = getenv("COVERM_INGEST_CHUNK_KB")) { const long v = atol(cb); if (v >= 64) chunk = (size_t)v << 10; }
     struct PreBlock { uint64_t hdr; uint32_t bsize, crc, isize; };
     struct PreChunk { uint64_t first = ~0ull, next = 0; std::vector<PreBlock> blocks; };
     const size_t chunks_per_piece = (piece + chunk - 1) / chunk;
@@ -1588,7 +1593,7 @@ uint64_t covh_bam_n_cigar(const covh_bam *h) { return h->b.cigar.size(); }
 namespace {
 inline uint64_t mix64(uint64_t z) { z += 0x9e3779b97f4a7c15ull; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }
 inline int synth_name(char *qn, uint64_t i, int mode) {
-    if (mode != 2) return snprintf(qn, 64, "r%llu", (unsigned long long)i) + 1;
+    if (mode < 2) return snprintf(qn, 64, "r%llu", (unsigned long long)i) + 1;
     const uint64_t h = mix64(i * 2 + 1);
     return snprintf(qn, 64, "A00%03u:%u:HXX%05u:%u:%u:%u:%u", (unsigned)(h % 7), 100 + (unsigned)((h >> 8) % 5), (unsigned)((h >> 16) % 3) + 17000,
                     1 + (unsigned)((i >> 22) & 3), 1101 + (unsigned)((i >> 14) & 255), (unsigned)((h >> 24) % 32000) + 1000,
@@ -1613,6 +1618,10 @@ int covh_bam_write(const char *path, uint32_t n_targets, const char *const *name
     if (!f) return 2;
     Pool pool(std::max(1, threads));
     const uint64_t R = b->n_records;
+    // with_seq = 3: as 2, and records 2k / 2k + 1 that lie on the same reference are MATES: one read name, next_refID = their
+    // reference, next_pos = the other's position (the pair-mode filter's input; every other record keeps a name of its own)
+    const bool paired = with_seq == 3;
+    auto name_id = [&](uint64_t i) -> uint64_t { if (!paired) return i; const uint64_t m = i ^ 1ull; return (m < R && b->tid[m] == b->tid[i]) ? (i & ~1ull) : i; };
     const uint64_t CH = 1u << 21;                      // records per chunk
     const size_t BLK = 0xff00;
     std::vector<uint8_t> raw(head);                    // bytes not yet written as blocks (header first)
@@ -1669,7 +1678,7 @@ int covh_bam_write(const char *path, uint32_t n_targets, const char *const *name
                 const uint64_t i = c0 + j;
                 const uint32_t nc = b->cigar_off[i + 1] - b->cigar_off[i];
                 const uint32_t ls = with_seq ? b->l_seq[i] : 0;
-                char qn[64]; const int lq = synth_name(qn, i, with_seq);
+                char qn[64]; const int lq = synth_name(qn, name_id(i), with_seq);
                 const uint32_t aux = b->nm_kind[i] == COV_NM_UNSIGNED ? (b->nm[i] < 256 ? 4 : b->nm[i] < 65536 ? 5 : 7) : b->nm_kind[i] == COV_NM_BADTYPE ? 4 : 0;
                 acc += 36 + lq + 4ull * nc + (ls + 1) / 2 + ls + aux;
                 off[j + 1] = acc;
@@ -1690,17 +1699,18 @@ int covh_bam_write(const char *path, uint32_t n_targets, const char *const *name
             uint8_t *p = base + off[j];
             const uint32_t nc = b->cigar_off[i + 1] - b->cigar_off[i];
             const uint32_t ls = with_seq ? b->l_seq[i] : 0;
-            char qn[64]; const int lq = synth_name(qn, i, with_seq);
+            char qn[64]; const int lq = synth_name(qn, name_id(i), with_seq);
             const uint32_t bs = (uint32_t)(off[j + 1] - off[j] - 4);
             auto w32 = [&](uint32_t x) { memcpy(p, &x, 4); p += 4; };
             w32(bs); w32((uint32_t)b->tid[i]); w32((uint32_t)b->pos[i]);
             *p++ = (uint8_t)lq; *p++ = b->mapq[i];
             const uint16_t bin = 4680, ncg = (uint16_t)nc, fl = b->flag[i];
             memcpy(p, &bin, 2); p += 2; memcpy(p, &ncg, 2); p += 2; memcpy(p, &fl, 2); p += 2;
-            w32(ls); w32((uint32_t)-1); w32((uint32_t)-1); w32(0);
+            if (paired) { const uint64_t m = i ^ 1ull; const bool has = m < R && b->tid[m] == b->tid[i]; w32(ls); w32((uint32_t)b->tid[i]); w32(has ? (uint32_t)b->pos[m] : (uint32_t)b->pos[i]); w32(0); }
+            else { w32(ls); w32((uint32_t)-1); w32((uint32_t)-1); w32(0); }
             memcpy(p, qn, lq); p += lq;
             if (nc) { memcpy(p, b->cigar + b->cigar_off[i], 4ull * nc); p += 4ull * nc; }
-            if (with_seq == 2) {
+            if (with_seq >= 2) {
                 uint64_t st = mix64(i ^ 0x5eedull);
                 const uint32_t nb2 = (ls + 1) / 2;
                 for (uint32_t k = 0; k < nb2; k += 16) {         // 16 bytes = 32 bases per 64-bit draw

@@ -101,6 +101,15 @@ struct BitReader {
         consumed = 0;
         (void)len;
     }
+    // continue at absolute bit position `bitpos` (counted from the aligned base, i.e. stream bit + 8 * mis)
+    __device__ __forceinline__ void seek(u32 bitpos, u32 mis) {
+        next_word = bitpos >> 5; reload();
+        buf = (u64)res[0] | ((u64)res[64] << 32); cnt = 64u;
+        next_word += 2u; ahead = res[2 * 64];
+        const u32 d = bitpos & 31u;
+        buf >>= d; cnt -= d;
+        consumed = bitpos - 8u * mis;
+    }
     __device__ __forceinline__ void refill() {
         if (cnt <= 32u) {
             buf |= (u64)ahead << cnt;
@@ -151,6 +160,7 @@ struct Huff {
     // SORT8 (literal/length alphabet in LDS as bytes): sorted8[j * 64] = low byte of the j-th symbol; thr[l] = index of the first
     // symbol >= 256 among those of length l (= end of the length's run when there is none)
     uint8_t *sorted8;
+    u32 s8stride = 64;            // distance between consecutive entries of sorted8 (64: lane-interleaved LDS; 1: the lane's own global scratch)
     Pack16 thr;
 };
 
@@ -194,7 +204,7 @@ __device__ __forceinline__ bool build_table(const uint8_t *lens, u32 n_sym, u32 
         for (u32 k = 0; k < 4; k++, w >>= 8) {
             const u32 l = w & 0xffu;
             if (s + k < n_sym && l) {
-                if (SORT8) H.sorted8[offs.get(l & 15u) * 64u] = (uint8_t)(s + k); else sorted[offs.get(l & 15u) * ss] = (unsigned short)(s + k);
+                if (SORT8) H.sorted8[offs.get(l & 15u) * H.s8stride] = (uint8_t)(s + k); else sorted[offs.get(l & 15u) * ss] = (unsigned short)(s + k);
                 offs.add(l & 15u, 1u);
             }
         }
@@ -207,7 +217,7 @@ __device__ __forceinline__ bool build_table(const uint8_t *lens, u32 n_sym, u32 
     for (u32 l = 1; l <= prim_bits; l++) {
         const u32 c = cnt.get(l), th = SORT8 ? H.thr.get(l) : 0u;
         for (u32 k = 0; k < c; k++, idx++, code++) {
-            const u32 sym = SORT8 ? (u32)H.sorted8[idx * 64u] + (idx >= th ? 256u : 0u) : (u32)sorted[idx * ss];
+            const u32 sym = SORT8 ? (u32)H.sorted8[idx * H.s8stride] + (idx >= th ? 256u : 0u) : (u32)sorted[idx * ss];
             const u32 rev = __brev(code) >> (32 - l);
             const unsigned short e = (unsigned short)((sym << 4) | l);
             for (u32 i = rev; i < N; i += 1u << l) H.tab[i * 64 + lane] = e;
@@ -412,6 +422,277 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
         if (err == INF_OK && pos != B.isize) err = INF_ERR_SIZE;
     }
     if ((nt & 3u) && !(ablate & 2u)) __builtin_memcpy(my_tok + (nt & ~3u), &tbuf, 8);     // INF_TOK_CAP is a multiple of four: the store stays inside the block's list
+    n_tok[b] = err == INF_OK ? nt : 0u;
+    status[b] = err;
+    if (err != INF_OK) atomicAdd(n_failed, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------- k_inflate2
+// Same contract as k_inflate (one lane per BGZF block, literals in place, matches as in-place tokens), with the symbol loop
+// rebuilt around what the counters of round 2 showed (192 VALU instructions and one exposed global load per symbol step, 53 % of
+// wave time in s_waitcnt, 1.2 waves per SIMD):
+//   * bit reader in 32-bit arithmetic: the lane keeps a bit POSITION; the 32-bit window at that position is one v_alignbit over
+//     two words read from the LDS reservoir (three are read per step, so the distance code needs no second round trip).  No
+//     64-bit shifts, no conditional refill;
+//   * the reservoir holds 16 words per lane and is refilled for all lanes when any lane is within two words of its end — one
+//     exposed global round trip per ~10 steps instead of ~4;
+//   * per-length limits of the canonical search live unpacked in registers (occupancy is bound by LDS, not by VGPRs: the
+//     kernel may use 256), per-length offsets in LDS;
+//   * a long-code LITERAL does not wait for its symbol: which length the code has, and that it is a literal (its rank within the
+//     length lies below the first length/EOB symbol of that length), follow from registers; the byte itself is loaded from the
+//     lane's sorted-symbol scratch and joins the output one step later, while the next symbol is already being decoded;
+//   * primary-table entries of length symbols carry base and extra-bit count, so a match costs no arithmetic on the symbol.
+// LDS per wave: 64 x (2^LB + 2^DB) x 2 (primary tables) + 2 KiB (distance symbols, bytes) + 4 KiB (literal/length per-length
+// offset | first non-literal rank) + 2 KiB (distance per-length offsets) + 4 KiB (reservoir): 36 KiB at 7 + 6, 32 KiB at 7 + 5.
+constexpr u32 INF2_RES = 16;
+constexpr size_t inflate2_smem_bytes(int lit_bits, int dist_bits, bool s8l = false) {
+    return (size_t)64 * ((1u << lit_bits) + (1u << dist_bits)) * 2 + (size_t)64 * 32 + (size_t)64 * 16 * 4 + (size_t)64 * 16 * 2 + (size_t)64 * INF2_RES * 4 + (s8l ? (size_t)64 * 288 : 0);
+}
+// Per-lane global scratch of k_inflate2: u8 lit_sorted8[288] (low byte of the symbols sorted by (length, value)), u8 pad[32], u8 lens[320]
+constexpr u32 INF2_SCRATCH_BYTES = 320 + 320;
+
+// primary entry of the literal/length table: bits 0-3 code length (0: longer than the table), then
+//   literal / end of block:  bit 15 = 0, bits 4-12 = symbol (0 .. 256)
+//   length symbol:           bit 15 = 1, bits 4-11 = base length - 3, bits 12-14 = extra bits
+__device__ __forceinline__ u32 len_entry(u32 sym) {      // sym in 257 .. 285  (RFC 1951 3.2.5)
+    const u32 li = sym - 257u;
+    const u32 le = li < 8u ? 0u : (li == 28u ? 0u : (li - 4u) >> 2);
+    const u32 lb = li < 8u ? 3u + li : (li == 28u ? 258u : 3u + ((4u + (li & 3u)) << le));
+    return 0x8000u | (le << 12) | ((lb - 3u) << 4);
+}
+
+template <int LB, int DB, bool S8L>
+__global__ __launch_bounds__(64) void k_inflate2(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
+                                                 uint8_t *__restrict__ out, uint8_t *__restrict__ scratch, tokpos_t *__restrict__ tok,
+                                                 u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    constexpr u32 NL = 1u << LB, ND = 1u << DB;
+    const int lane = threadIdx.x & 63;
+    unsigned short *tabL = lds, *tabD = lds + 64 * NL;
+    uint8_t *dsort = reinterpret_cast<uint8_t *>(tabD + 64 * ND);                       // 32 x 64 bytes
+    u32 *lit_ot = reinterpret_cast<u32 *>(dsort + 64 * 32);                             // 16 x 64 words: off | thr << 16
+    unsigned short *dist_off = reinterpret_cast<unsigned short *>(lit_ot + 64 * 16);    // 16 x 64
+    u32 *res = reinterpret_cast<u32 *>(dist_off + 64 * 16) + lane;                      // INF2_RES x 64 words
+    uint8_t *lsort = reinterpret_cast<uint8_t *>(res - lane + 64 * INF2_RES);            // S8L: 288 x 64 bytes, the literal/length symbols' low bytes
+    const u32 b = blockIdx.x * 64u + (u32)lane;
+    if (b >= n_blocks) return;
+    const BgzfBlock B = blocks[b];
+    uint8_t *sc = scratch + (size_t)b * INF2_SCRATCH_BYTES;
+    uint8_t *lens = sc + 320;
+    Huff HL, HD;
+    HL.tab = tabL; HD.tab = tabD;
+    HL.sorted = nullptr; HL.sstride = 0; HL.sorted8 = S8L ? lsort + lane : sc; HL.s8stride = S8L ? 64 : 1;
+    HD.sorted = nullptr; HD.sstride = 0; HD.sorted8 = dsort + lane; HD.s8stride = 64;
+    uint8_t *dst = out + B.out_off;
+    tokpos_t *my_tok = tok + (size_t)b * INF_TOK_CAP;
+    u32 pos = 0, err = INF_OK, nt = 0;
+    u64 tbuf = 0;
+    if (B.isize != 0u) {
+        const u32 mis = (u32)((u64)(comp + B.in_off) & 3u);
+        BitReader br;
+        br.init(comp, B.in_off, B.in_len, res);
+        const u32 total_bits = B.in_len * 8u;
+        bool last = false;
+        while (!last && err == INF_OK) {
+            if (br.consumed > total_bits) { err = INF_ERR_FORMAT; break; }
+            br.refill();
+            last = br.take(1) != 0u;
+            const u32 type = br.take(2);
+            if (type == 0u) {                    // stored
+                br.drop((8u - (br.consumed & 7u)) & 7u);
+                br.refill();
+                const u32 len = br.take(16);
+                br.refill();
+                const u32 nlen = br.take(16);
+                if ((len ^ nlen) != 0xffffu || pos + len > B.isize) { err = INF_ERR_FORMAT; break; }
+                for (u32 k = 0; k < len; k++) { br.refill(); dst[pos++] = (uint8_t)br.take(8); }
+                continue;
+            }
+            if (type == 3u) { err = INF_ERR_FORMAT; break; }
+            u32 hlit, hdist;
+            if (type == 1u) {                    // fixed codes
+                for (u32 s = 0; s < 144; s++) lens[s] = 8;
+                for (u32 s = 144; s < 256; s++) lens[s] = 9;
+                for (u32 s = 256; s < 280; s++) lens[s] = 7;
+                for (u32 s = 280; s < 288; s++) lens[s] = 8;
+                for (u32 s = 0; s < 30; s++) lens[288 + s] = 5;
+                hlit = 288; hdist = 30;
+            } else {                             // dynamic codes: the code-length code as in k_inflate
+                br.refill();
+                hlit = br.take(5) + 257u; hdist = br.take(5) + 1u;
+                const u32 hclen = br.take(4) + 4u;
+                if (hlit > 286u || hdist > 30u) { err = INF_ERR_FORMAT; break; }
+                u64 cl = 0;
+                for (u32 i = 0; i < hclen; i++) { br.refill(); cl |= (u64)br.take(3) << (3u * c_clen_order[i]); }
+                u64 ccnt5 = 0;
+                for (u32 sy = 0; sy < 19; sy++) { const u32 l = (u32)(cl >> (3u * sy)) & 7u; if (l) ccnt5 += 1ull << (5u * l); }
+                { u32 left = 1; bool bad = false; for (u32 l = 1; l < 8; l++) { left <<= 1; const u32 c = (u32)(ccnt5 >> (5u * l)) & 31u; if (c > left) { bad = true; break; } left -= c; } if (bad) { err = INF_ERR_FORMAT; break; } }
+                u32 n = 0;
+                const u32 want = hlit + hdist;
+                while (n < want && err == INF_OK) {
+                    br.refill();
+                    u32 code = 0, first = 0; int sym = -1;
+                    u64 bits = br.buf;
+                    for (u32 l = 1; l <= 7; l++) {
+                        code |= (u32)(bits & 1u); bits >>= 1;
+                        const u32 c = (u32)(ccnt5 >> (5u * l)) & 31u;
+                        if (code < first + c) {
+                            u32 r = code - first;
+                            for (u32 sy = 0; sy < 19; sy++) if (((u32)(cl >> (3u * sy)) & 7u) == l) { if (r == 0) { sym = (int)sy; break; } r--; }
+                            br.drop(l);
+                            break;
+                        }
+                        first += c; first <<= 1; code <<= 1;
+                    }
+                    if (sym < 0) { err = INF_ERR_FORMAT; break; }
+                    if (sym < 16) lens[n++] = (uint8_t)sym;
+                    else {
+                        u32 rep, val = 0;
+                        if (sym == 16) { if (n == 0) { err = INF_ERR_FORMAT; break; } val = lens[n - 1]; rep = 3u + br.take(2); }
+                        else if (sym == 17) rep = 3u + br.take(3);
+                        else rep = 11u + br.take(7);
+                        if (n + rep > want) { err = INF_ERR_FORMAT; break; }
+                        for (u32 k = 0; k < rep; k++) lens[n++] = (uint8_t)val;
+                    }
+                }
+                if (err != INF_OK) break;
+                if (lens[256] == 0) { err = INF_ERR_FORMAT; break; }
+                for (u32 s = hdist; s-- > 0;) lens[288 + s] = lens[hlit + s];
+                for (u32 s = hlit; s < 288; s++) lens[s] = 0;
+            }
+            if (!build_table<true>(lens, hlit, LB, lane, HL)) { err = INF_ERR_FORMAT; break; }
+            if (!build_table<true>(lens + 288, hdist, DB, lane, HD)) { err = INF_ERR_FORMAT; break; }
+            // primary entries of length symbols carry base and extra-bit count; symbols 286 / 287 (fixed code only) stay invalid
+            for (u32 i = 0; i < NL; i++) {
+                const u32 e = tabL[i * 64 + lane];
+                const u32 sym = e >> 4;
+                if ((e & 15u) && sym > 256u) tabL[i * 64 + lane] = (unsigned short)(sym <= 285u ? (len_entry(sym) | (e & 15u)) : 0xfff0u | (e & 15u));
+            }
+            // per-length constants of the canonical search: limits into registers, offsets into LDS
+            u32 limL[16], limD[16];
+#pragma unroll
+            for (u32 l = 1; l < 16; l++) { limL[l] = HL.limit.get(l); limD[l] = HD.limit.get(l); }
+#pragma unroll
+            for (u32 l = 1; l < 16; l++) { lit_ot[l * 64 + lane] = HL.off.get(l) | (HL.thr.get(l) << 16); dist_off[l * 64 + lane] = (unsigned short)HD.off.get(l); }
+            // ---- symbols of this block
+            u32 bitpos = br.consumed + 8u * mis;
+            u32 rbase = 0xffff0000u;                       // forces the first fill
+            u32 olo = 0, ohi = 0, on = 0;                  // pending output bytes: the top `on` bytes of ohi:olo, oldest lowest
+            u32 pend = 0, pend_direct = 0; uint8_t pend_loaded = 0;      // pend: 0 none, 1 byte in pend_direct, 2 byte arriving in pend_loaded
+            auto append = [&](u32 byte) {                 // the byte belongs at output position pos_w; flush every eighth
+                olo = __builtin_amdgcn_alignbit(ohi, olo, 8);
+                ohi = (ohi >> 8) | (byte << 24);
+                on++;
+            };
+            u32 wpos = pos;                                // output position of the next byte to enter ohi:olo (pos minus a pending literal)
+            auto flush8 = [&]() { const u64 v = ((u64)ohi << 32) | olo; __builtin_memcpy(dst + wpos - 8u, &v, 8); on = 0; };
+            auto flush_part = [&]() {                     // the `on` pending bytes end at dst + wpos
+                if (on) {
+                    const u64 v = (((u64)ohi << 32) | olo) >> (8u * (8u - on));
+                    uint8_t *d = dst + wpos - on;
+                    if (wpos - on + 8u <= B.isize) __builtin_memcpy(d, &v, 8);
+                    else for (u32 k = 0; k < on; k++) d[k] = (uint8_t)(v >> (8u * k));
+                    on = 0; olo = 0; ohi = 0;
+                }
+            };
+            auto settle = [&]() {                          // a pending literal joins the output
+                if (pend) { append(pend == 2u ? (u32)pend_loaded : pend_direct); wpos++; pend = 0; if (on == 8u) flush8(); }
+            };
+            for (;;) {
+                const u32 cur = bitpos >> 5;
+                if (__any(cur - rbase >= INF2_RES - 2u)) {           // (also true for the initial rbase)
+                    const u32 *w = br.words + cur;
+                    const Words4 x0 = *reinterpret_cast<const Words4 *>(w), x1 = *reinterpret_cast<const Words4 *>(w + 4),
+                                 x2 = *reinterpret_cast<const Words4 *>(w + 8), x3 = *reinterpret_cast<const Words4 *>(w + 12);
+                    res[0 * 64] = x0.a; res[1 * 64] = x0.b; res[2 * 64] = x0.c; res[3 * 64] = x0.d;
+                    res[4 * 64] = x1.a; res[5 * 64] = x1.b; res[6 * 64] = x1.c; res[7 * 64] = x1.d;
+                    res[8 * 64] = x2.a; res[9 * 64] = x2.b; res[10 * 64] = x2.c; res[11 * 64] = x2.d;
+                    res[12 * 64] = x3.a; res[13 * 64] = x3.b; res[14 * 64] = x3.c; res[15 * 64] = x3.d;
+                    rbase = cur;
+                }
+                const u32 j = cur - rbase;
+                const u32 w0 = res[j * 64u], w1 = res[(j + 1u) * 64u], w2 = res[(j + 2u) * 64u];
+                const u32 sh = bitpos & 31u;
+                const u32 win = __builtin_amdgcn_alignbit(w1, w0, sh);
+                u32 e = tabL[(win & (NL - 1u)) * 64u + (u32)lane];
+                u32 clen = e & 15u;
+                u32 load_idx = 0xffffffffu;                 // long-code literal: rank of its symbol in the sorted list
+                if (clen == 0u) {                           // longer than the primary table: parallel search over the per-length limits
+                    const u32 v = __brev(win) >> 17;
+                    u32 l = LB + 1;
+#pragma unroll
+                    for (u32 k = LB + 1; k < 15; k++) l += v >= limL[k] ? 1u : 0u;
+                    if (v >= limL[15]) { err = INF_ERR_FORMAT; break; }
+                    const u32 ot = lit_ot[l * 64u + (u32)lane];
+                    const u32 idx = ((ot & 0xffffu) + (v >> (15u - l))) & 0xffffu;
+                    clen = l;
+                    if (idx < (ot >> 16)) { load_idx = idx; e = 0; }                     // a literal: its byte follows
+                    else {                                                               // length symbol or end of block: needed now
+                        const u32 sym = 256u + (u32)HL.sorted8[min(idx, 287u) * HL.s8stride];
+                        e = sym == 256u ? (256u << 4) : (sym <= 285u ? len_entry(sym) : 0xfff0u);
+                    }
+                }
+                bitpos += clen;
+                if (!(e & 0x8000u)) {
+                    const u32 sym = (e >> 4) & 0x1ffu;
+                    if (load_idx == 0xffffffffu && sym == 256u) { settle(); break; }     // end of block
+                    if (pos >= B.isize) { err = INF_ERR_SIZE; break; }
+                    settle();                                                            // the previous literal first (its load has had a step to arrive)
+                    if (load_idx != 0xffffffffu) { pend_loaded = HL.sorted8[load_idx * HL.s8stride]; pend = 2u; }
+                    else { pend_direct = sym; pend = 1u; }
+                    pos++;
+                    continue;
+                }
+                // ---- a match: everything pending goes out first
+                settle();
+                flush_part();
+                if ((e & 0xfff0u) == 0xfff0u) { err = INF_ERR_FORMAT; break; }           // symbols 286 / 287
+                const u32 le = (e >> 12) & 7u;
+                // window at the new position from the three words already here
+                const u32 sh1 = sh + clen;
+                const u32 winl = sh1 >= 32u ? __builtin_amdgcn_alignbit(w2, w1, sh1 & 31u) : __builtin_amdgcn_alignbit(w1, w0, sh1);
+                const u32 len = 3u + ((e >> 4) & 0xffu) + (winl & ((1u << le) - 1u));
+                bitpos += le;
+                // distance code: the words may have moved on by one
+                const u32 cur2 = bitpos >> 5;
+                const u32 j2 = cur2 - rbase;
+                const u32 d0 = res[j2 * 64u], d1 = res[(j2 + 1u) * 64u];
+                const u32 wind = __builtin_amdgcn_alignbit(d1, d0, bitpos & 31u);
+                const u32 ed = tabD[(wind & (ND - 1u)) * 64u + (u32)lane];
+                u32 dl = ed & 15u, ds = ed >> 4;
+                if (dl == 0u) {
+                    const u32 v = __brev(wind) >> 17;
+                    u32 l = DB + 1;
+#pragma unroll
+                    for (u32 k = DB + 1; k < 15; k++) l += v >= limD[k] ? 1u : 0u;
+                    if (v >= limD[15]) { err = INF_ERR_FORMAT; break; }
+                    const u32 idx = ((u32)dist_off[l * 64u + (u32)lane] + (v >> (15u - l))) & 0xffffu;
+                    ds = (u32)dsort[min(idx, 31u) * 64u + (u32)lane];
+                    dl = l;
+                }
+                if (ds >= 30u) { err = INF_ERR_FORMAT; break; }
+                const u32 de = ds < 4u ? 0u : (ds - 2u) >> 1;
+                const u32 dx = (wind >> dl) & ((1u << de) - 1u);                         // dl + de <= 15 + 13 = 28 bits of the window
+                const u32 dist = (ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << de)) + dx;
+                bitpos += dl + de;
+                if (dist > pos || pos + len > B.isize || nt >= INF_TOK_CAP) { err = INF_ERR_FORMAT; break; }
+                tbuf |= (u64)pos << (16u * (nt & 3u));
+                if ((nt & 3u) == 3u) { __builtin_memcpy(my_tok + (nt - 3u), &tbuf, 8); tbuf = 0; }
+                const u32 t24 = (dist - 1u) | ((len - 3u) << 15);
+                uint8_t *d = dst + pos;
+                if (pos + 4u <= B.isize) __builtin_memcpy(d, &t24, 4);
+                else { d[0] = (uint8_t)t24; d[1] = (uint8_t)(t24 >> 8); d[2] = (uint8_t)(t24 >> 16); }
+                nt++;
+                pos += len; wpos = pos;
+            }
+            if (err != INF_OK) break;
+            flush_part();
+            if (bitpos - 8u * mis > total_bits) { err = INF_ERR_FORMAT; break; }
+            br.seek(bitpos, mis);
+        }
+        if (err == INF_OK && pos != B.isize) err = INF_ERR_SIZE;
+    }
+    if (nt & 3u) __builtin_memcpy(my_tok + (nt & ~3u), &tbuf, 8);
     n_tok[b] = err == INF_OK ? nt : 0u;
     status[b] = err;
     if (err != INF_OK) atomicAdd(n_failed, 1u);
