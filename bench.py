@@ -120,7 +120,28 @@ def oracle_contig_scan(ref_lens, batch, est_params, ff=(True, True, False), fp=N
     ev = np.ctypeslib.as_array(C.cast(out.e, C.POINTER(C.c_uint8)), shape=(out.n * EMIT_DTYPE.itemsize,)).view(EMIT_DTYPE)
     cov = ev["cov"][ev["type"] == 1].copy().reshape(len(tl), len(est_params))
     lib.orc_out_free(C.byref(out))
-    return cov, int(rm.num_mapped_reads), dt
+    return cov, (int(rm.num_mapped_reads), int(rm.num_reads)), dt
+
+
+def oracle_dense_text(names, cov, reads_mapped, methods, stoit):
+    """The oracle's dense table (coverage_printer.rs:359-553 restated in oracle.py) over per-contig coverages `cov`
+    [n_contigs x n_methods]: header row, then one row per contig, RPKM / TPM normalised by the printer — the text `coverm contig`
+    writes for one sample."""
+    import io
+    from oracle import oracle as O
+    stream = io.StringIO()
+    et = O.estimators_and_taker(methods, 0, 75, 5, 95, "dense", stream)
+    headers = [h for e in et["estimators"] for h in O.COLUMN_HEADERS[e.kind]]
+    taker = et["taker"]
+    taker.start_stoit(stoit)
+    for i, n in enumerate(names):
+        taker.start_entry(i, n)
+        for v in cov[i]:
+            taker.add_single_coverage(v)
+        taker.finish_entry()
+    O.print_headers(et["printer"], "Contig", headers, stream)
+    O.print_dense_cached("Contig", headers, taker, stream, [O.ReadsMapped(reads_mapped[0], reads_mapped[1])], et["columns_to_normalise"], et["rpkm"], et["tpm"])
+    return stream.getvalue()
 
 
 def oracle_estimators(excl=75, methods=METHODS):
@@ -137,7 +158,8 @@ def parity_check(ref, batch, gpu_cov, gpu_stats, gpu_hist):
     sufficient statistics + histograms (oracle's orc_integer_stats)."""
     from oracle import oracle as O
     from oracle.bamio import BamData
-    cov, mapped, dt = oracle_contig_scan(ref.lengths, batch, oracle_estimators())
+    cov, rmp, dt = oracle_contig_scan(ref.lengths, batch, oracle_estimators())
+    mapped = rmp[0]
     n = len(ref.lengths)
     g = gpu_cov.reshape(n, len(METHODS))
     f32_equal = bool((g.view(np.uint32) == cov.view(np.uint32)).all())
@@ -152,7 +174,7 @@ def parity_check(ref, batch, gpu_cov, gpu_stats, gpu_hist):
     hist_equal = len(gpu_hist) == len(exp_hist) and bool((gpu_hist == exp_hist).all())
     ok = f32_equal and ints_equal and hist_equal
     return dict(contigs=n, methods=METHODS, reads=batch.n_records, equal=ok, f32_bitwise_equal=f32_equal, integer_stats_equal=ints_equal,
-                histograms_equal=hist_equal, oracle_scan_s=dt), (mapped, dt)
+                histograms_equal=hist_equal, oracle_scan_s=dt), (mapped, dt), (cov, rmp)
 
 
 # ---------------------------------------------------------------------------------------------- pinned host arrays
@@ -182,10 +204,66 @@ def finalise(ref, est, stats, summ, hist, name="sample0"):
 
 
 # ---------------------------------------------------------------------------------------------- end to end
+E2E_FLAGS = ["--min-read-percent-identity", "95", "--min-read-aligned-length", "50", "--proper-pairs-only"]
+
+
+def run_binary(cmd, reps, sleep_s=4.0, env=None):
+    """`reps` runs of the product binary; (median seconds, every run's seconds, stderr of the median run, its VmHWM bytes).
+    A process that starts within a second of another one that just released tens of GB of device memory stalls ~1 s in its
+    first large allocations (measured: 2.1 s against 1.1 s after a pause): repetitions start on an idle device."""
+    runs = []
+    e = dict(os.environ, COVERM_CLI_TIMING="1", **(env or {}))
+    for rep in range(reps):
+        if rep:
+            time.sleep(sleep_s)
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, capture_output=True, text=True, env=e)
+        dt = time.perf_counter() - t0
+        if p.returncode != 0:
+            raise RuntimeError("coverm-amd failed: " + p.stderr[-2000:])
+        runs.append((dt, p.stderr))
+    order = sorted(range(len(runs)), key=lambda k: runs[k][0])
+    med = runs[order[len(order) // 2]]
+    hwm = [l for l in med[1].splitlines() if "VmHWM" in l]
+    rss = int(hwm[0].split()[-2]) * 1024 if hwm else None
+    return med[0], [round(r[0], 3) for r in runs], med[1], rss
+
+
+def timing_lines(stderr, n=8):
+    return [l for l in stderr.splitlines() if "stream read" in l or "ingest" in l or "VmHWM" in l or "main:" in l or "pair filter" in l][:n]
+
+
+def cpu_decode(path, threads, reps):
+    """The CPU side's decoder (csrc/host_bam.cpp covh_bam_open: threaded libdeflate inflate + parse) `reps` times; (best seconds,
+    every run's seconds, records of the last run)."""
+    from coverm_amd import bam as cbam
+    L = cbam._lib()
+    secs, recs = [], None
+    for rep in range(reps):
+        err = C.create_string_buffer(512)
+        t0 = time.perf_counter()
+        h = L.covh_bam_open(path.encode(), threads, 0, err, 512)      # the decode itself, timed without Python-side copies
+        secs.append(time.perf_counter() - t0)
+        assert h, err.value
+        if rep == reps - 1:
+            nrec, ncg = int(L.covh_bam_n_records(h)), int(L.covh_bam_n_cigar(h))
+            cb = native.CovBatch()
+            L.covh_bam_batch(h, C.byref(cb))
+            cp = cbam._copy
+            recs = RecordBatch(cp(cb.tid, np.int32, nrec), cp(cb.pos, np.int32, nrec), cp(cb.flag, np.uint16, nrec), cp(cb.mapq, np.uint8, nrec),
+                               cp(cb.nm, np.uint32, nrec), cp(cb.nm_kind, np.uint8, nrec), cp(cb.l_seq, np.uint32, nrec),
+                               cp(cb.cigar_off, np.uint32, nrec + 1), cp(cb.cigar, np.uint32, ncg))
+        L.covh_bam_close(h)
+    return min(secs), [round(x, 3) for x in secs], recs
+
+
 def end_to_end(a, threads):
-    """Basis (iii): BAM file -> TSV.  Config 5's size and flags (200 M reads, --min-read-percent-identity 95 --min-read-aligned-length 50
-    --proper-pairs-only, all methods) on a realistic-entropy BAM; GPU = the coverm-amd binary (streamed ingest); CPU = the same decoder
-    with the same thread count, then the oracle's scan (one thread, like the reference's).  Output tables must be identical."""
+    """Basis (iii): BAM FILE -> TSV.  Config 5's size and flags (200 M reads, --min-read-percent-identity 95 --min-read-aligned-length 50
+    --proper-pairs-only, all eleven methods) on a realistic-entropy BAM; GPU = the coverm-amd binary (device ingest), MEDIAN of three
+    runs; CPU = the same decoder with the same thread count, then the oracle's scan (one thread, like the reference's), BEST of three
+    each.  The binary's table must equal the oracle's dense table character for character (all eleven columns, RPKM and TPM
+    normalised by the oracle's printer).  A second line repeats the GPU side on the same records written at BGZF level 6 (what
+    samtools writes)."""
     from coverm_amd import bam as cbam
     from oracle import oracle as O
     res = dict(reads=a.e2e_reads, threads=threads)
@@ -193,8 +271,8 @@ def end_to_end(a, threads):
     try:
         free = shutil.disk_usage(tmpdir).free
         reads = a.e2e_reads
-        if free < reads * 90:
-            reads = max(1_000_000, int(free // 180))
+        if free < reads * 190:
+            reads = max(1_000_000, int(free // 380))
             res["note_disk"] = "only %.1f GB free under %s: end-to-end leg reduced to %d reads" % (free / 1e9, tmpdir, reads)
         t0 = time.time()
         ref = synth.make_reference(a.contigs, a.bp, seed=1)
@@ -207,66 +285,146 @@ def end_to_end(a, threads):
         size = os.path.getsize(path)
         res.update(reads=reads, bam_bytes=size, bam_bytes_per_read=size / reads, seq_qual="random bases, Phred-like binned qualities, Illumina-style names",
                    bam_location=tmpdir + (" (tmpfs: storage speed excluded, as with a warm page cache)" if tmpdir.startswith("/dev/shm") else ""))
-        flags = ["--min-read-percent-identity", "95", "--min-read-aligned-length", "50", "--proper-pairs-only"]
         out_tsv = os.path.join(tmpdir, "gpu.tsv")
-        cmd = [BIN, "contig", "-b", path, "-m"] + ALL_METHODS + flags + ["-t", str(threads), "-o", out_tsv]
-        best = None
-        rep_seconds = []
-        env = dict(os.environ, COVERM_CLI_TIMING="1")
-        for rep in range(3):        # best of three: the lease boxes share their host CPUs with other tenants (load average ~20-30), wall times scatter
-            if rep:
-                # a process that starts within a second of another one that just released tens of GB of device memory stalls ~1 s in its
-                # first large allocations (measured: 2.1 s against 1.1 s for the same run after a pause): repetitions start on an idle device
-                time.sleep(4.0)
-            t0 = time.perf_counter()
-            p = subprocess.run(cmd, capture_output=True, text=True, env=env)
-            dt = time.perf_counter() - t0
-            if p.returncode != 0:
-                raise RuntimeError("coverm-amd failed: " + p.stderr[-2000:])
-            import resource
-            rss = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss * 1024    # largest child so far: the bench spawns nothing bigger
-            rep_seconds.append(round(dt, 3))
-            if best is None or dt < best[0]:
-                best = (dt, rss, p.stderr)
-        gpu_s, gpu_rss, gpu_err = best
+        cmd = [BIN, "contig", "-b", path, "-m"] + ALL_METHODS + E2E_FLAGS + ["-t", str(threads), "-o", out_tsv]
+        gpu_s, rep_seconds, gpu_err, gpu_rss = run_binary(cmd, 3)
+        gpu_text = open(out_tsv).read()
         mapped = [l for l in gpu_err.splitlines() if "reads mapped out of" in l]
-        hwm = [l for l in gpu_err.splitlines() if "VmHWM" in l]
-        if hwm:     # the process's own peak resident set; getrusage(RUSAGE_CHILDREN) starts from this (large) parent's image at fork time
-            gpu_rss = int(hwm[0].split()[-2]) * 1024
-        timing = [l for l in gpu_err.splitlines() if "stream read" in l or "ingest" in l or "VmHWM" in l or "main:" in l]
-        # ---- CPU, same basis: same decoder + oracle scan
-        L = cbam._lib()
-        err = C.create_string_buffer(512)
-        t0 = time.perf_counter()
-        h = L.covh_bam_open(path.encode(), threads, 0, err, 512)      # the decode itself, timed without Python-side copies
-        dec_s = time.perf_counter() - t0
-        assert h, err.value
-        nrec, ncg = int(L.covh_bam_n_records(h)), int(L.covh_bam_n_cigar(h))
-        cb = native.CovBatch()
-        L.covh_bam_batch(h, C.byref(cb))
-        cp = cbam._copy
-        recs = RecordBatch(cp(cb.tid, np.int32, nrec), cp(cb.pos, np.int32, nrec), cp(cb.flag, np.uint16, nrec), cp(cb.mapq, np.uint8, nrec),
-                           cp(cb.nm, np.uint32, nrec), cp(cb.nm_kind, np.uint8, nrec), cp(cb.l_seq, np.uint32, nrec),
-                           cp(cb.cigar_off, np.uint32, nrec + 1), cp(cb.cigar, np.uint32, ncg))
-        L.covh_bam_close(h)
+        # ---- CPU, same basis: same decoder + oracle scan, best of three each
+        dec_s, dec_all, recs = cpu_decode(path, threads, 3)
         fp = O.FilterParameters(O.FlagFilter(False, True, False), 50, float(np.float32(0.95)), 0.0, 255, 0, 0.0, 0.0)
         est = oracle_estimators(75, ALL_METHODS)
-        cov, cpu_mapped, scan_s = oracle_contig_scan(ref.lengths, recs, est, ff=(False, True, False), fp=fp)
-        # table equality: the oracle's CLI text would take minutes in Python at this size; compare the numbers the tables are made of
-        gpu_tab = np.loadtxt(out_tsv, delimiter="\t", skiprows=1, usecols=range(1, 1 + len(ALL_METHODS)), dtype=np.float64, ndmin=2)
-        rpkm_col, tpm_col = ALL_METHODS.index("rpkm"), ALL_METHODS.index("tpm")
-        plain = [k for k in range(len(ALL_METHODS)) if k not in (rpkm_col, tpm_col)]     # those two are normalised by the printer
-        same = gpu_tab.shape[0] == cov.shape[0] and bool(np.array_equal(gpu_tab[:, plain].astype(np.float32), cov[:, plain]))
-        considered = cpu_mapped
+        scans = []
+        for rep in range(3):
+            cov, rmp, scan_s = oracle_contig_scan(ref.lengths, recs, est, ff=(False, True, False), fp=fp)
+            scans.append(scan_s)
+        scan_s = min(scans)
+        want_text = oracle_dense_text(ref.names, cov, rmp, ALL_METHODS, "config5")
+        same = gpu_text == want_text
         res.update(
-            gpu=dict(seconds=gpu_s, reads_per_s=reads / gpu_s, rep_seconds=rep_seconds, max_rss_bytes=gpu_rss, command=" ".join(["coverm-amd"] + cmd[1:]),
-                     stderr_mapped=mapped[:1], stderr_timing=timing[:8]),
-            cpu=dict(decode_s=dec_s, scan_s=scan_s, reads_per_s_serial=reads / (dec_s + scan_s), reads_per_s_overlapped=reads / max(dec_s, scan_s),
+            gpu=dict(seconds=gpu_s, seconds_is="median of three runs", reads_per_s=reads / gpu_s, rep_seconds=rep_seconds, max_rss_bytes=gpu_rss,
+                     command=" ".join(["coverm-amd"] + cmd[1:]), stderr_mapped=mapped[:1], stderr_timing=timing_lines(gpu_err)),
+            cpu=dict(decode_s=dec_s, decode_runs=dec_all, scan_s=scan_s, scan_runs=[round(x, 3) for x in scans], seconds_is="best of three runs each",
+                     reads_per_s_serial=reads / (dec_s + scan_s), reads_per_s_overlapped=reads / max(dec_s, scan_s),
                      decoder="csrc/host_bam.cpp covh_bam_open, %d threads" % threads, scan="oracle/coverm_oracle.c, 1 thread, %s" % oracle_native()[1],
                      note="the reference overlaps htslib's inflate pool with its single scan thread: its rate lies between the two figures, "
                           "at or below the overlapped one"),
             speedup_vs_cpu_overlapped=(reads / gpu_s) / (reads / max(dec_s, scan_s)), speedup_vs_cpu_serial=(reads / gpu_s) / (reads / (dec_s + scan_s)),
-            target=">= 10x the CPU path (BASELINE.json north_star)", tables_equal=same, considered_reads=considered)
+            target=">= 10x the CPU path (BASELINE.json north_star)", tables_equal=same,
+            tables_compared="the binary's TSV == the oracle's dense table, text equality over all %d columns x %d contigs" % (len(ALL_METHODS), len(ref.names)),
+            considered_reads=rmp[0])
+        del recs
+        # ---- the same records at BGZF level 6 (what samtools / htslib write): fewer bytes over PCIe, longer matches for the device's LZ stage
+        if not a.no_level6:
+            os.remove(path)
+            p6 = os.path.join(tmpdir, "config5.bam")       # same stem: same sample name in the table
+            t0 = time.time()
+            cbam.write_bam(p6, ref.names, ref.lengths, batch, with_seq=2, level=6, threads=threads)
+            w6 = time.time() - t0
+            size6 = os.path.getsize(p6)
+            g6, reps6, err6, rss6 = run_binary(cmd, 3)
+            same6 = open(out_tsv).read() == want_text
+            d6, d6_all, _ = cpu_decode(p6, threads, 1)
+            res["level6"] = dict(bam_bytes=size6, bam_bytes_per_read=size6 / reads, bam_write_s=w6, gpu_seconds=g6, seconds_is="median of three runs", rep_seconds=reps6,
+                                 reads_per_s=reads / g6, max_rss_bytes=rss6, stderr_timing=timing_lines(err6), cpu_decode_s=d6, cpu_scan_s=scan_s,
+                                 speedup_vs_cpu_overlapped=(reads / g6) / (reads / max(d6, scan_s)), speedup_vs_cpu_serial=(reads / g6) / (reads / (d6 + scan_s)),
+                                 tables_equal=same6)
+            res["tables_equal"] = res["tables_equal"] and same6
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    return res
+
+
+def binary_config_legs(a, threads, ref, batch, oracle_cfg2):
+    """BASELINE configs 2, 3 and (one device's share of) 4 at FULL size through the product binary: the headline's own 50 M-read
+    sample written as a BAM file, `coverm-amd contig` (config 2 / 4: the four methods) and `coverm-amd genome --genome-definition`
+    (config 3: 500 genomes, relative_abundance rpkm tpm), each table compared with the oracle's text."""
+    from coverm_amd import bam as cbam
+    from oracle import oracle as O
+    from oracle.bamio import BamData
+    res = {}
+    tmpdir = tempfile.mkdtemp(prefix="covbench", dir=a.tmp)
+    try:
+        path = os.path.join(tmpdir, "sample0.bam")
+        t0 = time.time()
+        cbam.write_bam(path, ref.names, ref.lengths, batch, with_seq=2, level=1, threads=threads)
+        res["bam_write_s"] = time.time() - t0
+        res["bam_bytes"] = os.path.getsize(path)
+        out = os.path.join(tmpdir, "out.tsv")
+        cmd2 = [BIN, "contig", "-b", path, "-m"] + METHODS + ["-t", str(threads), "-o", out]
+        s2, reps2, err2, rss2 = run_binary(cmd2, 3, sleep_s=2.0)
+        cov, rmp = oracle_cfg2
+        same2 = open(out).read() == oracle_dense_text(ref.names, cov, rmp, METHODS, "sample0")
+        res["config2_contig"] = dict(seconds=s2, seconds_is="median of three runs", rep_seconds=reps2, reads_per_s=batch.n_records / s2, max_rss_bytes=rss2,
+                                     tables_equal=same2, stderr_timing=timing_lines(err2, 4),
+                                     note="also config 4's per-device share (one 50 M-read BAM per device)")
+        gd = os.path.join(tmpdir, "genomes.tsv")
+        with open(gd, "w") as fh:
+            fh.write("".join("%s\t%s\n" % (ref.genomes[g], n) for n, g in zip(ref.names, ref.genome_of_contig)))
+        cmd3 = [BIN, "genome", "-b", path, "--genome-definition", gd, "-m", "relative_abundance", "rpkm", "tpm", "-t", str(threads), "-o", out]
+        s3, reps3, err3, rss3 = run_binary(cmd3, 3, sleep_s=2.0)
+        got3 = open(out).read()
+        z = np.zeros(1, np.int32)
+        b = BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq, batch.l_seq.astype(np.int32), batch.nm, batch.nm_kind,
+                    batch.cigar_off, batch.cigar, z, z, z, [], "")
+        t0 = time.perf_counter()
+        want3 = O.run_cli("genome", [path], bams=[b], methods=["relative_abundance", "rpkm", "tpm"], genome_definition=gd)
+        res["config3_genome"] = dict(seconds=s3, seconds_is="median of three runs", rep_seconds=reps3, reads_per_s=batch.n_records / s3, max_rss_bytes=rss3,
+                                     genomes=len(ref.genomes), tables_equal=got3 == want3, oracle_cli_s=time.perf_counter() - t0, stderr_timing=timing_lines(err3, 4))
+        res["tables_equal"] = bool(same2 and got3 == want3)
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    return res
+
+
+def multi_device_legs(a, threads, world):
+    """The PRODUCT's multi-GPU path (coverm-amd --devices 0..N-1, one process, one reader + session per device) at N > 1:
+    config 4 (N BAMs x 50 M reads, one per device) and config 5 (one 200 M-read BAM cut into N tid spans, RCCL gather of the
+    per-contig blocks), reads/s and per-device ingest stamps, each table compared with the single-device run of the same command."""
+    from coverm_amd import bam as cbam
+    res = dict(devices=world)
+    tmpdir = tempfile.mkdtemp(prefix="covbench", dir=a.tmp)
+    devs = "0-%d" % (world - 1)
+    try:
+        ref = synth.make_reference(a.contigs, a.bp, seed=1)
+        # ---- config 4: N samples (the same 50 M reads under N names: hard links), one per device
+        batch = synth.make_reads(ref, a.reads, seed=2)
+        first = os.path.join(tmpdir, "sample0.bam")
+        cbam.write_bam(first, ref.names, ref.lengths, batch, with_seq=2, level=1, threads=threads)
+        paths = [first]
+        for k in range(1, world):
+            paths.append(os.path.join(tmpdir, "sample%d.bam" % k))
+            os.link(first, paths[-1])
+        out = os.path.join(tmpdir, "out.tsv")
+        cmd1 = [BIN, "contig", "-b", first, "-m"] + METHODS + ["-t", str(threads), "-o", out]
+        s1, _, _, _ = run_binary(cmd1, 1)
+        one = [l.split("\t") for l in open(out).read().splitlines()]
+        cmdn = [BIN, "contig", "-b"] + paths + ["-m"] + METHODS + ["-t", str(threads), "--devices", devs, "-o", out]
+        sn, repsn, errn, rssn = run_binary(cmdn, 3)
+        many = [l.split("\t") for l in open(out).read().splitlines()]
+        nm = len(METHODS)
+        same4 = len(one) == len(many) and all(r[0] == q[0] and all(r[1 + k * nm:1 + (k + 1) * nm] == q[1:1 + nm] for k in range(world)) for r, q in zip(many[1:], one[1:]))
+        res["config4_samples"] = dict(bams=world, reads_per_bam=batch.n_records, seconds=sn, seconds_is="median of three runs", rep_seconds=repsn,
+                                      reads_per_s=world * batch.n_records / sn, single_device_one_bam_seconds=s1, max_rss_bytes=rssn,
+                                      tables_equal=bool(same4), stderr_timing=[l for l in errn.splitlines() if "device ingest:" in l][:world],
+                                      note="the N files are hard links of one BAM (same bytes, N sample names): what is measured is N readers + N devices sharing the host")
+        del batch
+        for q in paths:
+            os.remove(q)
+        # ---- config 5: one big BAM, N tid spans
+        big = synth.make_reads(ref, a.e2e_reads, seed=3)
+        path = os.path.join(tmpdir, "config5.bam")
+        cbam.write_bam(path, ref.names, ref.lengths, big, with_seq=2, level=1, threads=threads)
+        nbig = big.n_records
+        del big
+        cmd1 = [BIN, "contig", "-b", path, "-m"] + ALL_METHODS + E2E_FLAGS + ["-t", str(threads), "-o", out]
+        s1, reps1, _, _ = run_binary(cmd1, 3)
+        text1 = open(out).read()
+        sn, repsn, errn, rssn = run_binary(cmd1 + ["--devices", devs], 3)
+        res["config5_spans"] = dict(reads=nbig, bam_bytes=os.path.getsize(path), seconds=sn, seconds_is="median of three runs", rep_seconds=repsn, reads_per_s=nbig / sn,
+                                    single_device_seconds=s1, single_device_rep_seconds=reps1, speedup_vs_single_device=s1 / sn, max_rss_bytes=rssn,
+                                    tables_equal=open(out).read() == text1, stderr_timing=[l for l in errn.splitlines() if "device ingest:" in l][:world])
+        res["tables_equal"] = bool(same4 and res["config5_spans"]["tables_equal"])
     finally:
         shutil.rmtree(tmpdir, ignore_errors=True)
     return res
@@ -283,6 +441,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (parity check, CPU baselines) and the end-to-end leg")
     ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("COVERM_BENCH_E2E_READS", 200_000_000)))
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-level6", action="store_true", help="skip the second end-to-end line (same records written at BGZF level 6)")
+    ap.add_argument("--no-binary-legs", action="store_true", help="skip configs 2 / 3 at full size through the coverm-amd binary")
+    ap.add_argument("--no-multi-device-e2e", action="store_true", help="N > 1: skip the coverm-amd --devices legs (configs 4 and 5 through the product's multi-GPU path)")
     ap.add_argument("--tmp", default=os.environ.get("COVERM_BENCH_TMP", default_tmp()),
                     help="where the end-to-end leg writes its BAM (default: /dev/shm when it has room, so that storage speed is not part of the figure)")
     a = ap.parse_args()
@@ -307,7 +468,8 @@ def main():
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            import datetime
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(minutes=45))   # ranks > 0 wait while rank 0 runs the binary's legs
 
     # ---- synthetic sample of this rank (one BAM per GPU; seed 2 at N=1, 10+rank otherwise)
     t0 = time.time()
@@ -420,7 +582,7 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:     # CPU legs (parity at full size, baselines, end to end) on rank 0 at N = 1 only
             threads = max(1, int(os.environ.get("COVERM_BENCH_THREADS", usable_cpus())))
-            par, (cpu_mapped, cpu_dt) = parity_check(ref, batch, gpu_cov, stats, hist)
+            par, (cpu_mapped, cpu_dt), oracle_cfg2 = parity_check(ref, batch, gpu_cov, stats, hist)
             out["parity_checked"] = par
             if not par["equal"]:
                 exit_code = 3
@@ -456,6 +618,13 @@ def main():
                                    "cpu_reads_per_s": cpu_rate, "cpu": "oracle scan, 1 thread, records in host memory (same starting point)",
                                    "speedup_vs_cpu": considered / best / cpu_rate},
             }
+            if not a.no_binary_legs:
+                try:
+                    out["binary_configs"] = binary_config_legs(a, threads, ref, batch, oracle_cfg2)
+                    if not out["binary_configs"].get("tables_equal", False):
+                        exit_code = 3
+                except Exception as ex:
+                    out["binary_configs"] = {"error": repr(ex)[:1000]}
             if not a.no_e2e and world == 1:
                 try:
                     out["bases"]["end_to_end"] = end_to_end(a, threads)
@@ -463,6 +632,15 @@ def main():
                         exit_code = 3
                 except Exception as ex:   # the headline legs above stand on their own
                     out["bases"]["end_to_end"] = {"error": repr(ex)[:1000]}
+        if world > 1 and not a.no_multi_device_e2e and not share:
+            # the product's own multi-GPU path (one process, N devices): run by rank 0 while the other ranks wait at the barrier below
+            try:
+                threads = max(1, int(os.environ.get("COVERM_BENCH_THREADS", usable_cpus())))
+                out["multi_device_end_to_end"] = multi_device_legs(a, threads, world)
+                if not out["multi_device_end_to_end"].get("tables_equal", False):
+                    exit_code = 3
+            except Exception as ex:
+                out["multi_device_end_to_end"] = {"error": repr(ex)[:1000]}
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

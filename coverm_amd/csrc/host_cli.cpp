@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <future>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -97,7 +98,11 @@ struct Sample {
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 bool timing_on() { static const bool on = getenv("COVERM_CLI_TIMING") != nullptr; return on; }
 
+struct HeaderAhead { covh_bam_header *hd = nullptr; std::string err; };
+
 struct Run {
+    std::mutex hdr_mutex;
+    std::map<std::string, std::future<HeaderAhead>> hdr_ahead;   // headers of the first BAM files, read beside the runtime's start-up
     Args a;
     Filter f;
     bool contig = true, by_names = false, per_gene = false, fs = false, fp = false;
@@ -163,7 +168,20 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
     if (stream && !getenv("COVERM_NO_GPU_INGEST")) {
         // ---- device ingest: the compressed file goes to HBM, the GPU inflates, finds the records and fills its own store
         char err[512] = {0};
-        covh_bam_header *hd = covh_bam_read_header(S.path.c_str(), err, sizeof err);
+        covh_bam_header *hd = nullptr;
+        {   // the first files' headers were read while the HIP runtime came up
+            std::unique_lock<std::mutex> lk(R.hdr_mutex);
+            auto it = R.hdr_ahead.find(S.path);
+            if (it != R.hdr_ahead.end()) {
+                std::future<HeaderAhead> fut = std::move(it->second);
+                R.hdr_ahead.erase(it);
+                lk.unlock();
+                HeaderAhead ha = fut.get();
+                hd = ha.hd;
+                if (!hd) snprintf(err, sizeof err, "%s", ha.err.c_str());
+            }
+        }
+        if (!hd && !err[0]) hd = covh_bam_read_header(S.path.c_str(), err, sizeof err);
         if (!hd) die(err);
         struct HdFree { covh_bam_header *p; ~HdFree() { covh_bam_header_free(p); } } hdfree{hd};
         set_header(S, covh_bam_header_n_targets(hd), [&](uint32_t t) { return covh_bam_header_target_name(hd, t); },
@@ -485,6 +503,18 @@ int run_cli(int argc, char **argv) {
         cfg.min_percent_identity = f.pid_single; cfg.min_aligned_percent = f.pct_single;
     }
     const size_t nd = a.devices.size(), nb = a.bams.size();
+    if (!a.no_stream && !R.per_gene && !getenv("COVERM_NO_GPU_INGEST"))
+        for (size_t i = 0; i < std::min<size_t>(nb, std::max<size_t>(nd, 2)); i++) {      // (the file type is checked by covh_bam_read_header itself)
+            const std::string path = a.bams[i];
+            if (R.hdr_ahead.count(path) || !is_bgzf(path)) continue;
+            R.hdr_ahead.emplace(path, std::async(std::launch::async, [path] {
+                HeaderAhead h; char e[512] = {0};
+                h.hd = covh_bam_read_header(path.c_str(), e, sizeof e);
+                if (!h.hd) h.err = e;
+                return h;
+            }));
+        }
+    struct HdrDrain { Run &R; ~HdrDrain() { for (auto &kv : R.hdr_ahead) { HeaderAhead h = kv.second.get(); if (h.hd) covh_bam_header_free(h.hd); } } } hdr_drain{R};
     std::vector<cov_session *> sess(nd, nullptr);
     struct SessFree { std::vector<cov_session *> &v; ~SessFree() { if (!g_skip_teardown.load()) for (auto *s : v) if (s) cov_destroy(s); } } sess_free{sess};
     {
@@ -522,6 +552,7 @@ int run_cli(int argc, char **argv) {
         std::vector<std::thread> th;
         for (size_t d = 0; d < lanes; d++)
             th.emplace_back([&, d] {
+                (void)cov_bind_thread_to_device_node(a.devices[d]);
                 guarded([&] {
                     for (;;) {
                         const size_t bi = next.fetch_add(1);
@@ -544,7 +575,7 @@ int run_cli(int argc, char **argv) {
             std::vector<std::thread> th;
             for (size_t d = 0; d < nd; d++) {
                 part[d].path = a.bams[bi];
-                th.emplace_back([&, d] { guarded([&] { ingest(R, sess[d], part[d], thr, (uint32_t)d, (uint32_t)nd); }); });
+                th.emplace_back([&, d] { (void)cov_bind_thread_to_device_node(a.devices[d]); guarded([&] { ingest(R, sess[d], part[d], thr, (uint32_t)d, (uint32_t)nd); }); });
             }
             for (auto &t : th) t.join();
             if (!first_error.empty()) die(first_error);

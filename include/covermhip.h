@@ -291,6 +291,9 @@ cov_status cov_fetch_interval_hist(cov_session *s, uint64_t *hist);
  * (a decoder filling one batch per BAM file gets its arrays back without re-pinning).  cov_host_alloc returns NULL
  * when no HIP device is usable; cov_host_free returns 0 if `p` did not come from cov_host_alloc; cov_host_trim
  * gives the parked blocks back to the system. */
+/* Binds the CALLING THREAD (and the threads it creates afterwards) to the CPUs of the NUMA node device `device` is attached to;
+ * returns that node, or -1 when nothing was changed.  Call it in the thread that is going to read and feed a file for that device. */
+int cov_bind_thread_to_device_node(int device);
 void *cov_host_alloc(size_t bytes);
 /* Host memory the caller owns (e.g. an mmap of the BAM file, page aligned) made readable by the session's device, so that
  * cov_ingest_feed can take its bytes from there without a staging copy; unregister once the session has synchronised

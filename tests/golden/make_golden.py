@@ -59,3 +59,8 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# tests/golden/raw/*.bam: the reference's own small fixture files (htslib-written BGZF: zlib level-6 streams, its block sizes, its
+# EOF markers), byte for byte — `cp /root/reference/tests/data/<name> tests/golden/raw/` for every file under 6 kB plus eg2.bam.
+# tests/test_gpu_ingest.py feeds them UNMODIFIED to the device ingest on the GPU box, where /root/reference does not exist.

@@ -33,14 +33,27 @@ def test_binary_exists_and_prints_usage():
     assert p.returncode == 2 and "usage" in p.stderr
 
 
+RAW = os.path.join(ROOT, "tests", "golden", "raw")
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("source", ["reference_file", "reencoded"])
 @pytest.mark.parametrize("case", cases.CLI_CASES, ids=[c["id"] for c in cases.CLI_CASES])
-def test_cli_binary_golden(case, tmp_path):
+def test_cli_binary_golden(case, tmp_path, source):
+    """source = reference_file: the reference's own fixture BAMs byte for byte (tests/golden/raw: htslib's zlib-6 BGZF streams);
+    reencoded: the decoded fixture written again in 3000-byte BGZF blocks (many blocks, records straddling them)."""
     paths = []
     for b in case["bams"]:
         stem = os.path.splitext(b)[0]
         p = str(tmp_path / (stem + ".bam"))     # the stoit name is the file stem
-        bamio.write_bam(p, load_fixture(b), block=3000)
+        raw = os.path.join(RAW, b)
+        if source == "reference_file":
+            if not os.path.exists(raw):
+                pytest.skip("%s is not among the raw fixture files" % b)
+            import shutil
+            shutil.copy(raw, p)
+        else:
+            bamio.write_bam(p, load_fixture(b), block=3000)
         paths.append(p)
     r = subprocess.run(argv_of(case, paths), capture_output=True, text=True, timeout=300)
     if case["match"] == "error":

@@ -1,13 +1,17 @@
-"""BASELINE.json configs as parity cases (product CLI text == oracle CLI text on seeded synthetic data), and
-size-independent properties at a large size where the oracle would be too slow to be the checker."""
+"""BASELINE.json configs as parity cases: the PRODUCT BINARY's text (coverm-amd: BAM file -> device ingest -> kernels -> C++ host
+layer -> printer) == the oracle's CLI text on seeded synthetic data written to real BAM files, and size-independent properties at a
+large size where the oracle would be too slow to be the checker."""
+import os
+
 import numpy as np
 import pytest
 
-from coverm_amd import cli, synth
-from coverm_amd.cli import AlignmentFile
+from coverm_amd import bam as cbam
+from coverm_amd import synth
 from coverm_amd.engine import FilterConfig, Session
 from oracle import oracle as O
 from oracle.bamio import BamData
+from tests import binary
 
 pytestmark = pytest.mark.gpu
 
@@ -15,58 +19,62 @@ ALL_CONTIG_METHODS = ["mean", "trimmed_mean", "covered_fraction", "covered_bases
                       "reads_per_base", "anir", "rpkm", "tpm"]
 
 
-def make(n_contigs, total, n_reads, seed, name="synth"):
+def make(tmp_path, n_contigs, total, n_reads, seed, name="synth", with_seq=1):
+    """Synthetic sample as (reference, records, oracle view, path of the BAM file the binary reads)."""
     ref = synth.make_reference(n_contigs, total, seed=seed, min_len=1500, max_len=400_000)
     batch = synth.make_reads(ref, n_reads, seed=seed + 1)
     z = np.zeros(batch.n_records, np.int32)
     b = BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq, batch.l_seq.astype(np.int32),
                 batch.nm, batch.nm_kind, batch.cigar_off, batch.cigar, z, z, z, [], "")
-    return ref, batch, b, AlignmentFile("data/%s.bam" % name, ref.names, ref.lengths, batch)
+    path = os.path.join(str(tmp_path), name + ".bam")
+    cbam.write_bam(path, ref.names, ref.lengths, batch, with_seq=with_seq, threads=8)
+    return ref, batch, b, path
 
 
 @pytest.mark.parametrize("fmt", ["dense", "sparse"])
-def test_config2_contig_four_methods(fmt):
-    ref, batch, b, af = make(120, 8_000_000, 150_000, seed=41)
+def test_config2_contig_four_methods(tmp_path, fmt):
+    ref, batch, b, path = make(tmp_path, 120, 8_000_000, 150_000, seed=41)
     args = dict(methods=["mean", "trimmed_mean", "covered_fraction", "variance"], output_format=fmt)
-    assert cli.run("contig", [af], **args) == O.run_cli("contig", ["data/synth.bam"], bams=[b], **args)
+    assert binary.run("contig", [path], **args) == O.run_cli("contig", [path], bams=[b], **args)
 
 
 def test_config3_genome_definition_relative_abundance_rpkm_tpm(tmp_path):
-    ref, batch, b, af = make(200, 10_000_000, 200_000, seed=43)
+    ref, batch, b, path = make(tmp_path, 200, 10_000_000, 200_000, seed=43)
     gd = tmp_path / "genomes.tsv"
     gd.write_text("".join("%s\t%s\n" % (n.split("~")[0], n) for n in ref.names[:170]))   # 30 contigs in no genome
     for fmt in ("dense", "sparse"):
         args = dict(methods=["relative_abundance", "rpkm", "tpm"], genome_definition=str(gd), output_format=fmt)
-        assert cli.run("genome", [af], **args) == O.run_cli("genome", ["data/synth.bam"], bams=[b], **args)
+        assert binary.run("genome", [path], **args) == O.run_cli("genome", [path], bams=[b], **args)
     args = dict(methods=["relative_abundance", "mean", "covered_bases"], separator="~", output_format="sparse")
-    assert cli.run("genome", [af], **args) == O.run_cli("genome", ["data/synth.bam"], bams=[b], **args)
+    assert binary.run("genome", [path], **args) == O.run_cli("genome", [path], bams=[b], **args)
 
 
-def test_config4_multi_sample_dense_table():
+def test_config4_multi_sample_dense_table(tmp_path):
     ref = synth.make_reference(60, 4_000_000, seed=45, min_len=1500, max_len=300_000)
-    afs, bs = [], []
+    paths, bs = [], []
     for k in range(3):
         batch = synth.make_reads(ref, 60_000, seed=50 + k)
         z = np.zeros(batch.n_records, np.int32)
         bs.append(BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq,
                           batch.l_seq.astype(np.int32), batch.nm, batch.nm_kind, batch.cigar_off, batch.cigar, z, z,
                           z, [], ""))
-        afs.append(AlignmentFile("data/s%d.bam" % k, ref.names, ref.lengths, batch))
+        paths.append(str(tmp_path / ("s%d.bam" % k)))
+        cbam.write_bam(paths[-1], ref.names, ref.lengths, batch, with_seq=2, threads=4)
     args = dict(methods=["mean", "variance", "rpkm"])
-    assert cli.run("contig", afs, **args) == O.run_cli("contig", ["data/s%d.bam" % k for k in range(3)], bams=bs, **args)
+    assert binary.run("contig", paths, **args) == O.run_cli("contig", paths, bams=bs, **args)
 
 
-def test_config5_full_filter_path_all_methods():
-    ref, batch, b, af = make(150, 9_000_000, 250_000, seed=47)
+def test_config5_full_filter_path_all_methods(tmp_path):
+    ref, batch, b, path = make(tmp_path, 150, 9_000_000, 250_000, seed=47, with_seq=2)
     args = dict(methods=ALL_CONTIG_METHODS, min_read_percent_identity=95, min_read_aligned_length=50,
                 proper_pairs_only=True, output_format="sparse")
-    got = cli.run("contig", [af], **args)
-    assert got == O.run_cli("contig", ["data/synth.bam"], bams=[b], **args)
+    got = binary.run("contig", [path], **args)
+    assert got == O.run_cli("contig", [path], bams=[b], **args)
     assert got.count("\n") == 151
     # coverage_histogram has its own printer and cannot be combined (coverm.rs:1438-1446)
     args = dict(methods=["coverage_histogram"], min_read_percent_identity=95, min_read_aligned_length=50,
                 proper_pairs_only=True)
-    assert cli.run("contig", [af], **args) == O.run_cli("contig", ["data/synth.bam"], bams=[b], **args)
+    assert binary.run("contig", [path], **args) == O.run_cli("contig", [path], bams=[b], **args)
 
 
 def test_large_size_properties():
@@ -125,32 +133,36 @@ def _oracle_arrays(ref, batch):
 
 
 @pytest.fixture(scope="module")
-def big():
-    """20 M reads over 2 000 contigs / 200 genomes (0.4x of config 2's sample, same depth profile)."""
+def big(tmp_path_factory):
+    """20 M reads over 2 000 contigs / 200 genomes (0.4x of config 2's sample, same depth profile), also as a BAM file (realistic
+    entropy, ~2 GB) for the binary."""
     ref = synth.make_reference(2000, 400_000_000, seed=1)
     batch = synth.make_reads(ref, 20_000_000, seed=2)
-    return ref, batch, _oracle_arrays(ref, batch)
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path_factory.mktemp("big"))
+    path = os.path.join(d, "coverm_amd_test_big_%d.bam" % os.getpid())
+    cbam.write_bam(path, ref.names, ref.lengths, batch, with_seq=2, threads=16)
+    yield ref, batch, _oracle_arrays(ref, batch), path
+    os.remove(path)
 
 
 def test_config3_full_size_genome_definition_vs_oracle(big, tmp_path):
-    """`coverm genome --genome-definition … -m relative_abundance rpkm tpm` at 20 M reads: the whole product path (C ABI ->
-    kernels -> C++ genome scan -> printer) against the oracle's C scan (genome.rs:17-322) — text equality, dense and sparse."""
-    ref, batch, b = big
+    """`coverm genome --genome-definition … -m relative_abundance rpkm tpm` at 20 M reads: the whole product path (file -> device
+    ingest -> kernels -> C++ genome scan -> printer) against the oracle's C scan (genome.rs:17-322) — text equality, dense and sparse."""
+    ref, batch, b, path = big
     gd = tmp_path / "genomes.tsv"
     keep = [n for i, n in enumerate(ref.names) if i % 11 != 3]          # some contigs in no genome (genome.rs:170-171)
     gd.write_text("".join("%s\t%s\n" % (n.split("~")[0], n) for n in keep))
-    af = AlignmentFile("data/big.bam", ref.names, ref.lengths, batch)
     for fmt in ("dense", "sparse"):
         args = dict(methods=["relative_abundance", "rpkm", "tpm"], genome_definition=str(gd), output_format=fmt)
-        got = cli.run("genome", [af], **args)
-        assert got == O.run_cli("genome", ["data/big.bam"], bams=[b], **args)
+        got = binary.run("genome", [path], threads=16, **args)
+        assert got == O.run_cli("genome", [path], bams=[b], **args)
         assert got.count("\n") >= 200
 
 
 def test_config5_full_size_filters_all_methods_vs_oracle(big):
     """Config 5's flags (--min-read-percent-identity 95 --min-read-aligned-length 50 --proper-pairs-only) and every method at
     20 M reads: per-contig integer statistics, histograms and f64 identity sums bit-exact against the oracle, then the text."""
-    ref, batch, b = big
+    ref, batch, b, path = big
     ff = O.FlagFilter(False, True, False)
     fp = O.FilterParameters(ff, 50, float(np.float32(0.95)), 0.0, 255, 0, 0.0, 0.0)
     exp, exp_hist, prim = O.integer_stats(b, ff, fp, 75)
@@ -168,9 +180,8 @@ def test_config5_full_size_filters_all_methods_vs_oracle(big):
         np.testing.assert_array_equal(st[f], exp[f], err_msg=f)
     np.testing.assert_array_equal(st["sum_identity_primary"].view(np.uint64), exp["id_primary"].view(np.uint64))
     np.testing.assert_array_equal(hist, exp_hist)
-    af = AlignmentFile("data/big.bam", ref.names, ref.lengths, batch)
     args = dict(methods=ALL_CONTIG_METHODS, min_read_percent_identity=95, min_read_aligned_length=50, proper_pairs_only=True)
-    assert cli.run("contig", [af], **args) == O.run_cli("contig", ["data/big.bam"], bams=[b], **args)
+    assert binary.run("contig", [path], threads=16, **args) == O.run_cli("contig", [path], bams=[b], **args)
 
 
 def test_unsorted_input_with_histograms_is_a_clean_error():
@@ -201,3 +212,37 @@ def test_unsorted_input_with_histograms_is_a_clean_error():
             s.push(batch)
             st, _ = s.finish()
             assert int(st["n_pass"].sum()) > 0
+
+
+def _paired_view(ref, batch):
+    """The oracle's view of what the writer's with_seq = 3 puts into the file: records 2k / 2k + 1 on one reference are mates (one
+    name, next_refID = their reference); every other record has a name of its own."""
+    n = batch.n_records
+    i = np.arange(n, dtype=np.int64)
+    m = i ^ 1
+    same = (m < n) & (batch.tid[np.minimum(m, n - 1)] == batch.tid)
+    name_id = np.where(same, i & ~1, i)
+    z = np.zeros(n, np.int32)
+    return BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq, batch.l_seq.astype(np.int32), batch.nm, batch.nm_kind,
+                   batch.cigar_off, batch.cigar, batch.tid.copy(), z, z, [b"n%d" % k for k in name_id], "")
+
+
+@pytest.mark.parametrize("args", [dict(min_read_percent_identity_pair=95, min_read_aligned_length_pair=200, proper_pairs_only=True),
+                                  dict(min_mapq=20, proper_pairs_only=True),
+                                  dict(min_read_percent_identity=97, min_read_aligned_percent_pair=90)])
+def test_pair_mode_filters_through_the_binary_use_the_device_join(tmp_path, args):
+    """Pair-mode reader filters (filter.rs:117-228; --min-mapq with --proper-pairs-only selects the pair branch, filter.rs:48-61) on
+    a paired file: the binary keeps mates on the device (device ingest + cov_pair_filter_apply, no whole-file host decode) and its
+    text equals the oracle's; the host path (COVERM_PAIR_ON_HOST=1) gives the same text."""
+    ref = synth.make_reference(150, 9_000_000, seed=47, min_len=1500, max_len=400_000)
+    batch = synth.make_reads(ref, 300_000, seed=48)
+    path = str(tmp_path / "pairs.bam")
+    cbam.write_bam(path, ref.names, ref.lengths, batch, with_seq=3, threads=8)
+    b = _paired_view(ref, batch)
+    kw = dict(methods=["mean", "trimmed_mean", "covered_fraction", "variance", "count", "anir"], **args)
+    want = O.run_cli("contig", [path], bams=[b], **kw)
+    r = __import__("subprocess").run(binary.argv("contig", [path], **kw), capture_output=True, text=True, env=dict(os.environ, COVERM_CLI_TIMING="1"))
+    assert r.returncode == 0, r.stderr
+    assert "pair filter on the device" in r.stderr
+    assert r.stdout == want
+    assert binary.run("contig", [path], env={"COVERM_PAIR_ON_HOST": "1"}, **kw) == want

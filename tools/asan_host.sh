@@ -81,6 +81,9 @@ cov_status cov_ingest_end(cov_session *s, uint64_t *n_records) {
 }
 cov_status cov_ingest_release(cov_session *) { return COV_OK; }
 cov_status cov_ingest_abort(cov_session *s) { if (s) s->active = false; return COV_OK; }
+int cov_bind_thread_to_device_node(int) { return -1; }
+cov_status cov_ingest_want_mates(cov_session *, int) { return COV_OK; }
+cov_status cov_pair_filter_apply(cov_session *, const cov_pair_filter *, uint64_t *, uint64_t *) { return COV_ERR_HIP; }
 // registration of the mapped file: accepted (the mock's feed reads the mapping like any host memory), or refused to exercise the
 // driver's switch to staging slots; every registered range must be unregistered exactly once, after the ingest ended
 static std::set<void *> g_reg;
