@@ -136,6 +136,7 @@ struct cov_session {
     hipEvent_t ev_prep_done = nullptr, ev_side_done = nullptr;
     DevBuf<u32> d_arena;
     DevBuf<u64> d_chist;
+    u64 *h_chist = nullptr; u64 h_chist_cap = 0, hist_prefetched = 0, last_chist_total = 0; bool hist_compacted = false;
     DevBuf<int32_t> d_depth;
 
     // device ingest (cov_ingest_*): compressed file and inflated stream in HBM, BGZF block table, record-boundary scratch
@@ -178,6 +179,9 @@ struct cov_session {
     uint64_t ing_comp = 0, ing_infl = 0, ing_blocks = 0;
     bool ing_active = false;
     hipStream_t ing_copy = nullptr;
+    // second upload queue: the halves of a large piece go to HBM through two DMA engines at once (one queue moved ~42 GB/s of
+    // 32 MiB pieces between table uploads; the link does 57); joined into ing_copy before anything is recorded there
+    hipStream_t ing_copy2 = nullptr; hipEvent_t ing_c2_done = nullptr; bool ing_c2_dirty = false; int64_t ing_copy2_cleared = -1;
     hipEvent_t ing_ev[COV_INGEST_SLOTS] = {}, ing_fed = nullptr;
     double ing_s_alloc = 0;     // host seconds inside device allocations of the ingest
 
@@ -466,6 +470,8 @@ void cov_destroy(cov_session *s) {
     s->h_winres = nullptr;
     if (s->h_blocks) (void)hipHostFree(s->h_blocks);
     s->h_blocks = nullptr;
+    if (s->ing_copy2) { (void)hipStreamSynchronize(s->ing_copy2); (void)hipStreamDestroy(s->ing_copy2); }
+    if (s->ing_c2_done) (void)hipEventDestroy(s->ing_c2_done);
     if (s->ing_copy) { (void)hipStreamSynchronize(s->ing_copy); (void)hipStreamDestroy(s->ing_copy); }
     for (int k = 0; k < COV_INGEST_SLOTS; k++) if (s->ing_ev[k]) (void)hipEventDestroy(s->ing_ev[k]);
     if (s->ing_fed) (void)hipEventDestroy(s->ing_fed);
@@ -474,6 +480,8 @@ void cov_destroy(cov_session *s) {
     s->h_gather = nullptr;
     if (s->h_res) (void)hipHostFree(s->h_res);
     s->h_res = nullptr; s->h_res_cap = 0; s->h_ctg = nullptr;
+    if (s->h_chist) (void)hipHostFree(s->h_chist);
+    s->h_chist = nullptr; s->h_chist_cap = 0;
     s->s_tid.release(); s->s_pos.release(); s->s_flag.release(); s->s_mapq.release(); s->s_nmk.release();
     s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
     s->s_mtid.release(); s->s_qh1.release(); s->s_qh2.release();
@@ -591,7 +599,7 @@ cov_status cov_ingest_abort(cov_session *s) {
     if (!s->ing_active) return COV_OK;
     HIPCHK(hipSetDevice(s->cfg.device));
     s->ing_active = false;
-    for (hipStream_t st : {s->ing_copy, s->stream, s->ing_aux, s->ing_parse, s->ing_ext})
+    for (hipStream_t st : {s->ing_copy2, s->ing_copy, s->stream, s->ing_aux, s->ing_parse, s->ing_ext})
         if (st) HIPCHK(hipStreamSynchronize(st));
     s->ing_rec_total = s->ing_cig_total = 0; s->ing_round_n = 0; s->ing_fail = 0;
     s->ing_extracted = s->ing_batch;
@@ -815,7 +823,24 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         if (want_hist) {
             hipLaunchKernelGGL((k_hist_layout<1>), dim3(1), dim3(1024), 0, st, s->d_ctg.p, nT, s->d_tlen.p, mask,
                                (u64)s->cfg.contig_end_exclusion, s->d_glob.p);
+            // the compact histogram right behind its layout (its size is only known on the device: the buffer takes the arena's
+            // bound), and as many of its bins as the previous finish had already on their way to page-locked memory, so that
+            // cov_fetch_hist is no second launch + round trip (0.08 ms of a 1.9 ms step at BASELINE config 2)
+            HIPCHK(s->d_chist.reserve((size_t)R + nT + 1, st));
+            hipLaunchKernelGGL(k_hist_compact, dim3(nT), dim3(256), 0, st, s->d_ctg.p, nT, s->d_tlen.p, (u64)s->cfg.contig_end_exclusion, s->d_arena.p, s->d_chist.p);
             HIPCHK(hipGetLastError());
+            s->hist_prefetched = 0;
+            const u64 guess = std::min<u64>({s->last_chist_total + s->last_chist_total / 16, (u64)R + nT + 1, (u64)(64u << 20) / 8});
+            if (guess) {
+                if (guess > s->h_chist_cap) {
+                    if (s->h_chist) (void)hipHostFree(s->h_chist);
+                    s->h_chist = nullptr; s->h_chist_cap = 0;
+                    HIPCHK(hipHostMalloc((void **)&s->h_chist, (size_t)guess * 8, hipHostMallocDefault));
+                    s->h_chist_cap = guess;
+                }
+                HIPCHK(hipMemcpyAsync(s->h_chist, s->d_chist.p, (size_t)guess * 8, hipMemcpyDeviceToHost, st));
+                s->hist_prefetched = guess;
+            }
         }
     }
     {
@@ -850,6 +875,8 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
 
     const cov_status cst = convert_results(s, s->h_glob, s->h_ctg, R, stats, summary);
     if (cst != COV_OK) return cst;
+    s->last_chist_total = want_hist ? s->h_glob.chist_total : 0;
+    s->hist_compacted = want_hist && R != 0;
     s->finished = true;
     return COV_OK;
 }
@@ -1053,6 +1080,10 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     HIPCHK(hipSetDevice(s->cfg.device));
     if (!s->ing_copy) {
         HIPCHK(hipStreamCreateWithFlags(&s->ing_copy, hipStreamNonBlocking));
+        if (getenv("COVERM_INGEST_COPY_QUEUES") && atoi(getenv("COVERM_INGEST_COPY_QUEUES")) >= 2) {      // opt-in until measured
+            HIPCHK(hipStreamCreateWithFlags(&s->ing_copy2, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&s->ing_c2_done, hipEventDisableTiming));
+        }
         for (int k = 0; k < COV_INGEST_SLOTS; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ev[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ing_fed, hipEventDisableTiming));
         HIPCHK(hipStreamCreateWithFlags(&s->ing_aux, hipStreamNonBlocking));
@@ -1087,7 +1118,7 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     HIPCHK(hipMemsetAsync(s->g_result.p, 0, (8 + 4 * 8) * sizeof(u64), s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     s->ing_comp = compressed_bytes; s->ing_infl = 0; s->ing_blocks = 0; s->ing_launched = 0; s->ing_active = true;
-    s->ing_round_start = 0; s->ing_prev_end = 0; s->ing_round_n = 0; s->ing_copy_cleared = -1;
+    s->ing_round_start = 0; s->ing_prev_end = 0; s->ing_round_n = 0; s->ing_copy_cleared = -1; s->ing_copy2_cleared = -1; s->ing_c2_dirty = false;
     s->ing_key_lo = 0; s->ing_key_hi = 0x80000000ll; s->ing_search_first = false; s->ing_open_end = false; s->ing_fed_any = false;
     s->ing_span_lo = 0; s->ing_span_hi = compressed_bytes; s->ing_tail_key = ~0ull;
     s->ing_ccap = std::min<u64>(inflate_kernel(s).cwin, compressed_bytes + 65536u + 128u);     // a small file is one buffer: the byte rule never fires
@@ -1219,10 +1250,13 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
         HIPCHK(hipStreamWaitEvent(s->ing_aux, s->ing_inf_done[bb], 0));
         hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
                            (const covi::tokpos_t *)tokb.p, (const u32 *)ntokb.p);
+        // the window's bytes are final once the matches are resolved: the boundary search (parse stream) starts here, beside the
+        // CRC-32 pass, whose verdict is only looked at in cov_ingest_end (the aux stream is in order, so CRC(w) is done before LZ(w + 1)
+        // and with it before anything may overwrite window w)
+        HIPCHK(hipEventRecord(s->ing_lz_done[bb], s->ing_aux));
         if (s->ing_check_crc)
             hipLaunchKernelGGL(covi::k_crc32, dim3((n + 255u) / 256u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n,
                                (const uint8_t *)out_bias, s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
-        HIPCHK(hipEventRecord(s->ing_lz_done[bb], s->ing_aux));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamWaitEvent(s->ing_parse, s->ing_lz_done[bb], 0));
     }
@@ -1262,7 +1296,7 @@ static cov_status ingest_copy_range(cov_session *s, u32 r, u64 origin, u64 a, u6
     DevBuf<uint8_t> &cw = s->g_cwin[r % 3u];
     const size_t need = (size_t)s->ing_ccap + 2 * 65536u + 256u;
     if (cw.cap < need) {
-        if (cw.cap) { HIPCHK(hipStreamSynchronize(s->ing_copy)); HIPCHK(hipStreamSynchronize(s->stream)); }      // replaced while possibly in use
+        if (cw.cap) { if (s->ing_copy2) HIPCHK(hipStreamSynchronize(s->ing_copy2)); HIPCHK(hipStreamSynchronize(s->ing_copy)); HIPCHK(hipStreamSynchronize(s->stream)); }      // replaced while possibly in use
         const auto ta0 = std::chrono::steady_clock::now();
         HIPCHK(cw.reserve(need, s->stream));
         s->ing_s_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta0).count();
@@ -1272,13 +1306,30 @@ static cov_status ingest_copy_range(cov_session *s, u32 r, u64 origin, u64 a, u6
         s->ing_copy_cleared = (int64_t)r;
     }
     if (a < origin || b - origin > cw.cap) { s->err = "cov_ingest_feed: internal error, bytes outside their round's buffer"; return COV_ERR_STATE; }
-    HIPCHK(hipMemcpyAsync(cw.p + (a - origin), piece + (a - piece_off), b - a, hipMemcpyHostToDevice, s->ing_copy));
+    const u64 len = b - a;
+    if (s->ing_copy2 && len >= (8u << 20)) {        // two halves, two queues
+        if ((int64_t)r > s->ing_copy2_cleared) {
+            if (r >= 3) HIPCHK(hipStreamWaitEvent(s->ing_copy2, s->ing_cdone[r % 3u], 0));
+            s->ing_copy2_cleared = (int64_t)r;
+        }
+        const u64 h = (len / 2 + 4095u) & ~4095ull;
+        HIPCHK(hipMemcpyAsync(cw.p + (a - origin), piece + (a - piece_off), h, hipMemcpyHostToDevice, s->ing_copy));
+        HIPCHK(hipMemcpyAsync(cw.p + (a - origin) + h, piece + (a - piece_off) + h, len - h, hipMemcpyHostToDevice, s->ing_copy2));
+        s->ing_c2_dirty = true;
+        return COV_OK;
+    }
+    HIPCHK(hipMemcpyAsync(cw.p + (a - origin), piece + (a - piece_off), len, hipMemcpyHostToDevice, s->ing_copy));
     return COV_OK;
 }
 
 // Table entries [from, ing_blocks) follow the bytes on the copy stream; ing_fed marks "everything fed so far is on the device"
 // (recorded even without new entries: the bytes in front of it may complete a round).
 static cov_status ingest_upload_table(cov_session *s, u64 from) {
+    if (s->ing_c2_dirty) {       // what the second queue carries belongs in front of everything recorded on the first from here on
+        HIPCHK(hipEventRecord(s->ing_c2_done, s->ing_copy2));
+        HIPCHK(hipStreamWaitEvent(s->ing_copy, s->ing_c2_done, 0));
+        s->ing_c2_dirty = false;
+    }
     if (from < s->ing_blocks)
         HIPCHK(hipMemcpyAsync(s->g_blocks.p + from, s->h_blocks + from, (size_t)(s->ing_blocks - from) * sizeof(covi::BgzfBlock), hipMemcpyHostToDevice, s->ing_copy));
     HIPCHK(hipEventRecord(s->ing_fed, s->ing_copy));
@@ -1297,11 +1348,13 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
         const size_t nc = std::max<size_t>(s->ing_blocks + n_blocks, s->h_blocks_cap * 2 + 4096);
         covi::BgzfBlock *nb = nullptr;
         HIPCHK(hipHostMalloc((void **)&nb, nc * sizeof(covi::BgzfBlock), hipHostMallocDefault));
+        if (s->ing_copy2) HIPCHK(hipStreamSynchronize(s->ing_copy2));
         HIPCHK(hipStreamSynchronize(s->ing_copy));      // earlier uploads still read the old mirror
         if (s->h_blocks) { memcpy(nb, s->h_blocks, s->ing_blocks * sizeof(covi::BgzfBlock)); (void)hipHostFree(s->h_blocks); }
         s->h_blocks = nb; s->h_blocks_cap = nc;
     }
     if (s->ing_blocks + n_blocks > s->g_blocks.cap || s->ing_blocks + n_blocks > s->g_status.cap) {
+        if (s->ing_copy2) HIPCHK(hipStreamSynchronize(s->ing_copy2));
         HIPCHK(hipStreamSynchronize(s->ing_copy)); HIPCHK(hipStreamSynchronize(s->ing_aux)); HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(s->g_blocks.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
         HIPCHK(s->g_status.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
@@ -1360,9 +1413,9 @@ cov_status cov_ingest_end(cov_session *s, uint64_t *n_records_out) {
     { const cov_status d = ingest_drain(s, (int64_t)s->ing_batch); if (d != COV_OK) return d; }
     u64 glob[8];
     HIPCHK(hipStreamSynchronize(s->ing_ext));
+    HIPCHK(hipStreamSynchronize(s->ing_aux));        // the CRC pass of the last window runs beside its boundary search: its failure count is read below
     HIPCHK(hipMemcpyAsync(glob, s->g_result.p, sizeof glob, hipMemcpyDeviceToHost, s->ing_parse));
     HIPCHK(hipStreamSynchronize(s->ing_parse));
-    HIPCHK(hipStreamSynchronize(s->ing_aux));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (getenv("COVERM_CLI_TIMING"))
         fprintf(stderr, "[covermhip] ingest: %llu blocks in %u windows of %u, device allocations %.3fs\n", (unsigned long long)s->ing_blocks, s->ing_batch,
@@ -1631,14 +1684,19 @@ cov_status cov_fetch_hist(cov_session *s, uint64_t *hist) {
     const uint64_t total = s->h_glob.chist_total;
     if (total == 0) return COV_OK;
     if (!hist) return COV_ERR_INVALID_ARG;
-    HIPCHK(s->d_chist.reserve(total, s->stream));
-    time_begin(s, COV_K_HIST);
-    hipLaunchKernelGGL(k_hist_compact, dim3(s->n_targets), dim3(256), 0, s->stream, s->d_ctg.p, s->n_targets, s->d_tlen.p,
-                       (u64)s->cfg.contig_end_exclusion, s->d_arena.p, s->d_chist.p);
-    time_end(s, COV_K_HIST);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(hist, s->d_chist.p, total * 8, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
+    if (!s->hist_compacted) {      // (a finish that had nothing to launch)
+        HIPCHK(s->d_chist.reserve(total, s->stream));
+        hipLaunchKernelGGL(k_hist_compact, dim3(s->n_targets), dim3(256), 0, s->stream, s->d_ctg.p, s->n_targets, s->d_tlen.p,
+                           (u64)s->cfg.contig_end_exclusion, s->d_arena.p, s->d_chist.p);
+        HIPCHK(hipGetLastError());
+        s->hist_prefetched = 0;
+    }
+    const u64 have = std::min<u64>(total, s->hist_prefetched);      // arrived with cov_finish's own synchronisation
+    if (have) memcpy(hist, s->h_chist, (size_t)have * 8);
+    if (have < total) {
+        HIPCHK(hipMemcpyAsync(hist + have, s->d_chist.p + have, (size_t)(total - have) * 8, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
     return COV_OK;
 }
 

@@ -4,6 +4,10 @@
 #include "../../include/coverm_host.h"
 
 #include <algorithm>
+#include <mutex>
+#include <functional>
+#include <condition_variable>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstring>
@@ -399,18 +403,112 @@ float covh_calculate_coverage(const covh_estimator *e, const covh_entry *en, con
 }
 
 // ------------------------------------------------------------------ contig.rs:13-253
+extern "C++" {
+namespace {
+// A few persistent workers for loops over contigs whose iterations are independent (the float expressions of calculate_coverage
+// are pure functions of one contig's integer statistics): 5 000 contigs x 4 estimators are 0.33 ms on one thread, a third of the
+// kernels' time at BASELINE config 2.  Threads are started on first use and sleep on a condition variable in between.
+class ContigWorkers {
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::function<void(size_t, size_t)> fn_;
+    size_t n_ = 0, parts_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t gen_ = 0;
+    int busy_ = 0;
+    bool stop_ = false;
+    void drain() {
+        for (;;) {
+            const size_t p = next_.fetch_add(1);
+            if (p >= parts_) break;
+            fn_(n_ * p / parts_, n_ * (p + 1) / parts_);
+        }
+    }
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return stop_ || gen_ != seen; }); if (stop_) return; seen = gen_; }
+            drain();
+            { std::lock_guard<std::mutex> lk(m_); if (--busy_ == 0) done_.notify_all(); }
+        }
+    }
+public:
+    ~ContigWorkers() { { std::lock_guard<std::mutex> lk(m_); stop_ = true; } cv_.notify_all(); for (auto &t : th_) t.join(); }
+    // fn(lo, hi) over [0, n) in `parts` ranges; the caller works too.  One run at a time (run_m_ serialises callers).
+    std::mutex run_m_;
+    void run(size_t n, std::function<void(size_t, size_t)> fn) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        size_t want = std::min<size_t>({(size_t)4, (size_t)hw, n / 512 + 1});
+        if (const char *e = getenv("COVERM_FINALISE_THREADS")) want = std::max(1, atoi(e));
+        if (want <= 1) { fn(0, n); return; }
+        std::lock_guard<std::mutex> rl(run_m_);
+        while (th_.size() + 1 < want) th_.emplace_back([this] { worker(); });
+        { std::lock_guard<std::mutex> lk(m_); fn_ = std::move(fn); n_ = n; parts_ = want * 2; next_ = 0; busy_ = (int)th_.size(); gen_++; }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return busy_ == 0; });
+    }
+};
+ContigWorkers &contig_workers() { static ContigWorkers w; return w; }
+}  // namespace
+}  // extern "C++"
+
 int covh_contig_coverage(const covh_header *h, const covh_sample *samples, size_t n_samples, covh_taker *taker,
                          const covh_estimator *est, size_t n_est, int print_zero, covh_reads_mapped *rm_out) {
     if (!check_excl(est, n_est)) { g_err = "estimators disagree on contig_end_exclusion"; return COV_ERR_INVALID_ARG; }
     const u64 excl = session_excl(est, n_est);
     const u64 zero = 0;
     std::vector<float> cov(n_est);
+    bool needs_acc_to_print = false;       // coverage_histogram prints the histogram itself: keeps the one-pass loop
+    for (size_t k = 0; k < n_est; k++) needs_acc_to_print |= est[k].kind == COVH_PILEUP_COUNTS;
+    std::vector<float> all;
     for (size_t si = 0; si < n_samples; si++) {
         const covh_sample &S = samples[si];
         taker->start_stoit(S.stoit_name);
         taker->reserve(h->n_targets, n_est, h->name_off[h->n_targets]);
         u64 mapped_total = 0;
         int64_t prev = -1;
+        if (!needs_acc_to_print && h->n_targets >= 1024) {
+            // phase 1 (contigs in parallel): the coverages; phase 2 (in order): zero rows, reads mapped, the taker
+            all.resize((size_t)h->n_targets * n_est);
+            contig_workers().run(h->n_targets, [&](size_t lo, size_t hi) {
+                EntryAcc acc;
+                for (size_t t = lo; t < hi; t++) {
+                    const cov_contig_stats &s = S.stats[t];
+                    if (s.n_pass == 0) continue;
+                    acc.reset();
+                    acc.add_contig(s, h->target_len[t], excl, s.n_primary, s.sum_identity_primary, S.hist);
+                    for (size_t k = 0; k < n_est; k++) all[t * n_est + k] = calculate(est[k], acc, &zero, 1);
+                }
+            });
+            auto zero_rows2 = [&](int64_t from, int64_t to) {
+                for (int64_t t = from + 1; t < to; t++) {
+                    taker->start_entry((size_t)t, target_name(h, (u32)t));
+                    for (size_t k = 0; k < n_est; k++) print_zero_coverage(est[k], *taker, h->target_len[t]);
+                    taker->finish_entry();
+                }
+            };
+            for (u32 t = 0; t < h->n_targets; t++) {
+                const cov_contig_stats &s = S.stats[t];
+                if (s.n_pass == 0) continue;
+                if (print_zero) zero_rows2(prev, t);
+                const float *c = &all[(size_t)t * n_est];
+                bool nonzero = false;
+                for (size_t k = 0; k < n_est; k++) nonzero |= c[k] > 0.0f;
+                if (nonzero) mapped_total += s.n_primary;           // :67-72
+                if (print_zero || nonzero) {
+                    taker->start_entry(t, target_name(h, t));
+                    for (size_t k = 0; k < n_est; k++) taker->add_single_coverage(c[k]);
+                    taker->finish_entry();
+                }
+                prev = t;
+            }
+            if (print_zero) zero_rows2(prev, h->n_targets);
+            if (rm_out) { rm_out[si].num_mapped_reads = mapped_total; rm_out[si].num_reads = S.num_detected_primary_alignments; }
+            continue;
+        }
         auto zero_rows = [&](int64_t from, int64_t to) {   // print_previous_zero_coverage_contigs, :255-277
             for (int64_t t = from + 1; t < to; t++) {
                 taker->start_entry((size_t)t, target_name(h, (u32)t));

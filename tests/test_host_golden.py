@@ -257,3 +257,34 @@ def test_pair_stage_cpp_matches_oracle_at_scale(params, threads):
     got = cli.pair_mode_order(af, fp, threads=threads)
     assert len(got) > 1000
     np.testing.assert_array_equal(got, np.asarray(want, dtype=np.int64))
+
+
+def test_contig_scan_over_thousands_of_contigs_is_the_same_in_parallel(monkeypatch):
+    """covh_contig_coverage computes the coverages of >= 1024 contigs on a few worker threads and feeds the taker in order afterwards:
+    the text must equal the one-thread result and the oracle's CLI text (zero rows, reads-mapped line inputs, RPKM / TPM included)."""
+    from coverm_amd import synth
+    from oracle.bamio import BamData
+    ref = synth.make_reference(2600, 9_000_000, seed=9, min_len=1500, max_len=20_000)
+    batch = synth.make_reads(ref, 40_000, seed=10)
+    z = np.zeros(batch.n_records, np.int32)
+    b = BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq, batch.l_seq.astype(np.int32), batch.nm, batch.nm_kind,
+                batch.cigar_off, batch.cigar, z, z, z, [], "")
+    af = AlignmentFile("data/many.bam", ref.names, ref.lengths, batch)
+
+    def provider(af_, fp, excl, want_hist, want_identity, mask=None, device=0):
+        off = O.FlagFilter(fp.flag_filters.include_improper_pairs, fp.flag_filters.include_supplementary, fp.flag_filters.include_secondary)
+        st, hist, prim = O.integer_stats(b, off, None, excl, mask)
+        out = np.zeros(len(st), dtype=native.CONTIG_STATS_DTYPE)
+        for f in ("n_primary", "n_pass", "n_nonsupp", "sum_nm", "sum_indel", "win_sum_d", "win_sum_d2", "win_covered", "full_covered", "first_record",
+                  "last_record", "win_min_d", "win_max_d", "hist_len", "hist_off"):
+            out[f] = st[f]
+        out["sum_identity_primary"] = st["id_primary"]; out["sum_identity_nonsupp"] = st["id_nonsupp"]
+        return SampleResult(af_.stoit_name, out, hist if want_hist else None, prim)
+    for kw in (dict(methods=["mean", "trimmed_mean", "covered_fraction", "variance", "rpkm", "tpm", "anir", "count"]),
+               dict(methods=["mean", "variance"], no_zeros=True, output_format="sparse")):
+        monkeypatch.setenv("COVERM_FINALISE_THREADS", "4")
+        par = cli.run("contig", [af], sample_provider=provider, **kw)
+        monkeypatch.setenv("COVERM_FINALISE_THREADS", "1")
+        ser = cli.run("contig", [af], sample_provider=provider, **kw)
+        assert par == ser == O.run_cli("contig", ["data/many.bam"], bams=[b], **kw)
+        assert par.count("\n") > 1000

@@ -1,0 +1,28 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r03_call8; mkdir -p $OUT
+cd $R
+( timeout 900 python -m pytest tests/test_gpu_ingest.py tests/test_gpu_pair_filter.py -m gpu -x -q 2>&1 | tail -4 ) > $OUT/pytest.log 2>&1; cat $OUT/pytest.log
+python tools/valu_rate_json.py $OUT/valu_rate.json 4
+python tools/make_bam.py /dev/shm/p.bam 200000000 16 > $OUT/make.log 2>&1
+python tools/make_bam.py /dev/shm/tiny.bam 100000 4 >> $OUT/make.log 2>&1
+CMD="$R/coverm_amd/coverm-amd contig -b /dev/shm/p.bam -m mean trimmed_mean covered_fraction covered_bases variance length count reads_per_base rpkm tpm anir --min-read-percent-identity 95 --min-read-aligned-length 50 --proper-pairs-only -t 16 -o /dev/shm/p.tsv"
+python - > $OUT/e2e.log 2>&1 <<PY
+import subprocess, time, os
+def go(label, cmd, env, reps):
+    rows = []
+    for rep in range(reps):
+        time.sleep(3)
+        t = time.time(); r = subprocess.run(cmd.split(), capture_output=True, text=True, env=dict(os.environ, COVERM_CLI_TIMING="1", **env)); dt = time.time() - t
+        st = [float(l.split()[-1]) for l in r.stderr.splitlines() if "wall clock at" in l]
+        ing = [l.split("device ingest: ")[1] for l in r.stderr.splitlines() if "device ingest: buffers" in l]
+        rows.append((dt, "spawn %.3f main %.3f exit %.3f | %s" % (st[0] - t, st[1] - st[0], t + dt - st[1], ing[0] if ing else "?")))
+    rows.sort()
+    print("%-22s walls %s" % (label, " ".join("%.3f" % x[0] for x in rows)))
+    for x in rows: print("      %.3f  %s" % x)
+go("two copy queues", "$CMD", {}, 5)
+go("one copy queue", "$CMD", {"COVERM_INGEST_COPY_QUEUES": "1"}, 5)
+go("two copy queues", "$CMD", {}, 5)
+go("tiny file", "$CMD".replace("/dev/shm/p.bam", "/dev/shm/tiny.bam"), {}, 3)
+PY
+cat $OUT/e2e.log
+rm -f /dev/shm/p.bam /dev/shm/p.tsv /dev/shm/tiny.bam
