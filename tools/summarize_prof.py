@@ -36,18 +36,24 @@ for k, cs in summ.items():
                 traffic[key] = traffic.get(key, 0) + int(b)
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 # pipe utilisation of the two big kernels (bench.py reports these as the on-chip roofline of k_pileup_fast)
-pipes = {"_source": tag, "_units": "SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES count quad-cycles; SQ_BUSY_CU_CYCLES counts cycles per CU "
-         "(x4 SIMDs = SIMD-cycles); wave64 VALU ops issue in 2 cycles at full rate and 4 cycles for mad_u24 / SDWA / DPP / 3-operand "
-         "forms (tools/ubench/valu_rate.hip)"}
+pipes = {"_source": tag, "_units": "SQ_WAIT_* / SQ_WAVE_CYCLES count quad-cycles; SQ_BUSY_CU_CYCLES counts cycles per CU (x4 SIMDs = SIMD-cycles); "
+         "the VALU issue fraction is NOT taken from SQ_ACTIVE_INST_VALU (it ticks once per instruction, VERDICT round 2): tools/valu_mix.py derives it "
+         "from SQ_INSTS_VALU, the kernel's instruction classes and the measured per-class issue costs; the two valu_frac_if_* entries are its bounds"}
+kstats = {}
+for row in csv.DictReader(open(ks[0])):
+    kstats[row["Name"].split("(")[0].replace("void ", "").strip()] = float(row["AverageNs"]) / 1e6
 for k, cs in summ.items():
     key = "k_pileup" if "k_pileup_fast" in k else "k_prep" if "k_prep<" in k else None
     if not key or "SQ_BUSY_CU_CYCLES" not in cs:
         continue
     g = lambda c: cs.get(c, {}).get("mean_per_dispatch")
     simd_cycles = 4.0 * g("SQ_BUSY_CU_CYCLES")
-    p_ = {"kernel": k}
-    if g("SQ_ACTIVE_INST_VALU"):
-        p_["valu_busy_frac"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / simd_cycles          # issue slots (quad-cycles) the VALU was claimed
+    p_ = {"kernel": k, "simd_cycles": simd_cycles}
+    for kn, ms in kstats.items():
+        if kn.split("<")[0] in k and (("<" not in kn) or kn == k):
+            p_["kernel_ms"] = ms
+    if g("SQ_THREAD_CYCLES_VALU") and g("SQ_INSTS_VALU"):
+        p_["lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_INSTS_VALU"))      # active lanes per VALU instruction / 64
     if g("SQ_INSTS_VALU"):
         p_["valu_insts"] = g("SQ_INSTS_VALU")
         p_["valu_frac_if_all_full_rate"] = 2.0 * g("SQ_INSTS_VALU") / simd_cycles

@@ -178,7 +178,12 @@ def main():
             insts = float(p["valu_insts"])
             ghz = a.clock_ghz or rates.get("clock_ghz", 2.4)
             ms = a.kernel_ms or p.get("kernel_ms")
-            if ms:
+            if p.get("simd_cycles"):      # 4 x SQ_BUSY_CU_CYCLES of the same launch: no clock assumed
+                simd_cycles = float(p["simd_cycles"])
+                res.update(valu_insts_per_launch=insts, kernel_ms=ms, simd_cycles=simd_cycles, simd_cycles_source="4 x SQ_BUSY_CU_CYCLES",
+                           valu_issue_frac=insts * mean / simd_cycles, valu_issue_frac_if_all_full_rate=insts * full / simd_cycles,
+                           valu_issue_frac_if_all_half_rate=insts * half / simd_cycles, lane_utilisation=p.get("lane_utilisation"))
+            elif ms:
                 simd_cycles = ms * 1e-3 * ghz * 1e9 * 4 * a.cus
                 res.update(valu_insts_per_launch=insts, kernel_ms=ms, clock_ghz=ghz, simd_cycles=simd_cycles,
                            valu_issue_frac=insts * mean / simd_cycles, valu_issue_frac_if_all_full_rate=insts * full / simd_cycles,
