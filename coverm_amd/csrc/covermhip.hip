@@ -155,7 +155,7 @@ struct cov_session {
     DevBuf<u32> g_ntok, g_ntok2;
     hipStream_t ing_aux = nullptr;                         // k_lz_resolve / k_crc32 of round i run beside k_inflate of round i + 1
     hipStream_t ing_parse = nullptr;                       // record boundaries of window i run beside both
-    hipStream_t ing_ext = nullptr;                         // extraction of verified windows: behind nothing but its own predecessors
+    hipStream_t ing_ext = nullptr; bool ing_ext_owned = false;   // extraction of verified windows: its own stream (behind nothing but its own predecessors) or the parse stream
     hipEvent_t ing_inf_done[2] = {nullptr, nullptr}, ing_lz_done[2] = {nullptr, nullptr};
     hipEvent_t ing_ver_done[4] = {}, ing_ext_done[3] = {}, ing_cdone[3] = {};
     uint64_t ing_round_start = 0, ing_prev_end = 0, ing_ccap = 0;   // accumulating round: file offset its buffer starts at; end of the last payload seen; bytes a round may span
@@ -458,7 +458,7 @@ void cov_destroy(cov_session *s) {
     s->d_cx_list.release(); s->d_cx_cnt.release(); s->d_cx_cur.release(); s->d_cx_scan.release(); s->d_cx_top.release(); s->d_cx_runs.release();
     if (s->ing_aux) (void)hipStreamSynchronize(s->ing_aux);
     if (s->ing_parse) (void)hipStreamSynchronize(s->ing_parse);
-    if (s->ing_ext) { (void)hipStreamSynchronize(s->ing_ext); (void)hipStreamDestroy(s->ing_ext); }
+    if (s->ing_ext) { (void)hipStreamSynchronize(s->ing_ext); if (s->ing_ext_owned) (void)hipStreamDestroy(s->ing_ext); }
     ingest_free_buffers(s);
     s->g_result.release();
     if (s->ing_aux) (void)hipStreamDestroy(s->ing_aux);
@@ -1088,7 +1088,10 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
         HIPCHK(hipEventCreateWithFlags(&s->ing_fed, hipEventDisableTiming));
         HIPCHK(hipStreamCreateWithFlags(&s->ing_aux, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&s->ing_parse, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&s->ing_ext, hipStreamNonBlocking));
+        // extraction shares the parse stream unless asked otherwise: a stream costs ~6 ms to create and as much again when the process
+        // ends, and extract(w) queued behind the boundary search of w + 1 still finishes long before window w's buffer is needed again
+        if (getenv("COVERM_INGEST_EXT_STREAM") && atoi(getenv("COVERM_INGEST_EXT_STREAM"))) { HIPCHK(hipStreamCreateWithFlags(&s->ing_ext, hipStreamNonBlocking)); s->ing_ext_owned = true; }
+        else { s->ing_ext = s->ing_parse; s->ing_ext_owned = false; }
         for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_inf_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_lz_done[k], hipEventDisableTiming)); }
         for (int k = 0; k < 4; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ver_done[k], hipEventDisableTiming));
         for (int k = 0; k < 3; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_ext_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_cdone[k], hipEventDisableTiming)); }
@@ -1283,7 +1286,7 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
 }
 
 cov_status cov_ingest_slot_wait(cov_session *s, int slot) {
-    if (!s || slot < 0 || slot >= COV_INGEST_SLOTS || !s->ing_active) return COV_ERR_INVALID_ARG;
+    if (!s || slot < 0 || slot >= COV_INGEST_SLOTS || !s->ing_ev[slot]) return COV_ERR_INVALID_ARG;      // (also valid after cov_ingest_end: the slot's last upload)
     HIPCHK(hipSetDevice(s->cfg.device));
     HIPCHK(hipEventSynchronize(s->ing_ev[slot]));
     return COV_OK;

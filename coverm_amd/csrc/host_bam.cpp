@@ -42,6 +42,7 @@ namespace {
 // first touch, so page faults are spread over the threads instead of a serial zero-fill), and large arrays come
 // from anonymous mappings advised to use transparent huge pages.
 std::atomic<bool> g_pinned_records{false};   // covh_bam_set_pinned
+std::atomic<bool> g_release_staging{false};  // covh_bam_set_release_staging
 
 template <class T>
 struct RecAlloc {
@@ -1522,8 +1523,20 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     reader.join();
     if (next_blk != size) return fail(1, "truncated BGZF block at the end of the file");
     double t0 = now();
+    // The staging slots have done their work once their last uploads are through.  When this session reads no further file
+    // (covh_bam_set_release_staging) they go back to the system NOW, beside the device's last rounds: page-locked memory still held
+    // when the process ends costs ~0.13 s per GiB of exit time (tools/ubench/exit_probe).
+    std::thread releaser;
+    struct JoinRel { std::thread &t; ~JoinRel() { if (t.joinable()) t.join(); } } join_rel{releaser};
+    if (g_release_staging.load() && !use_map)
+        releaser = std::thread([&] {
+            for (int k = 0; k < NS; k++)
+                if (buf[k] && cov_ingest_slot_wait(s, k) == COV_OK) { cov_host_free(buf[k]); buf[k] = nullptr; }
+            cov_host_trim();
+        });
     uint64_t nrec = 0;
     const cov_status rc = cov_ingest_end(s, &nrec);
+    if (releaser.joinable()) releaser.join();
     const double t_end = now() - t0;
     if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; timing[4] = t_begin; timing[5] = t_walk; timing[6] = t_feed; timing[7] = 0; }
     if (rc == COV_ERR_INGEST_FALLBACK) return fail(1, cov_last_error(s));
@@ -1571,6 +1584,7 @@ covh_bam *covh_bam_open(const char *path, int threads, int want_names, char *err
 void covh_bam_close(covh_bam *h) { delete h; }
 void covh_bam_set_buffer_cache(int on) { g_map_cache.set(on != 0); }
 void covh_bam_set_pinned(int on) { g_pinned_records.store(on != 0); }
+void covh_bam_set_release_staging(int on) { g_release_staging.store(on != 0); }
 uint32_t covh_bam_n_targets(const covh_bam *h) { return (uint32_t)h->b.names.size(); }
 const char *covh_bam_target_name(const covh_bam *h, uint32_t i) { return h->b.names[i].c_str(); }
 uint64_t covh_bam_target_len(const covh_bam *h, uint32_t i) { return h->b.lens[i]; }

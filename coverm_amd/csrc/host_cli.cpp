@@ -533,6 +533,7 @@ int run_cli(int argc, char **argv) {
     }
     const double t_sessions = now();
     covh_bam_set_pinned(1);
+    covh_bam_set_release_staging(nb <= nd ? 1 : 0);      // every session reads one file: its staging slots are released beside the last rounds
     if (nb > 1) covh_bam_set_buffer_cache(1);
     const bool timing = getenv("COVERM_CLI_TIMING") != nullptr;
     std::vector<Sample> samples(nb);

@@ -144,6 +144,10 @@ void covh_bam_set_buffer_cache(int on);
 /* Decode record arrays into page-locked memory from cov_host_alloc (off by default; falls back to ordinary memory
  * when no device is usable), so that cov_push_batch is a plain DMA. */
 void covh_bam_set_pinned(int on);
+/* 1: covh_bam_gpu_ingest* gives its page-locked staging slots back to the system as soon as their last uploads are through (a session
+ * that reads no further file; page-locked memory still held at process exit costs ~0.13 s per GiB).  Default 0: the slots are parked for
+ * the next file. */
+void covh_bam_set_release_staging(int on);
 uint32_t covh_bam_n_targets(const covh_bam *h);
 const char *covh_bam_target_name(const covh_bam *h, uint32_t i);
 uint64_t covh_bam_target_len(const covh_bam *h, uint32_t i);
