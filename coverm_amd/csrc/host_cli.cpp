@@ -255,39 +255,88 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         S.t_finish = now() - t0 - S.t_ingest;
         return;
     }
-    // ---- whole file on the host: pair-mode reader stage, per-gene coverage, SAM text
+    // ---- --gff over a BAM the device can ingest: the device inflates and parses (and applies a pair-mode filter), then the records
+    // the gene driver needs on the host (per-read vectors, genes.rs:182-344) come BACK from the session's store — 24 B per record
+    // + CIGAR words over PCIe instead of a whole-file decode on the host
     char err[512] = {0};
-    covh_bam *bam = covh_bam_open(S.path.c_str(), threads, R.fp ? 1 : 0, err, sizeof err);
-    if (!bam) die(err);
-    struct Closer { covh_bam *p; ~Closer() { covh_bam_close(p); } } closer{bam};
-    set_header(S, covh_bam_n_targets(bam), [&](uint32_t t) { return covh_bam_target_name(bam, t); }, [&](uint32_t t) { return covh_bam_target_len(bam, t); });
-    const uint32_t nt = (uint32_t)S.tlen.size();
-    if (R.by_names) genome_table(R, S, mask);
-    cov_batch batch; covh_bam_batch(bam, &batch);
-    S.n_records = batch.n_records;
+    cov_batch batch; memset(&batch, 0, sizeof batch);
+    struct HostRecords { std::vector<int32_t> tid, pos; std::vector<uint16_t> flag; std::vector<uint8_t> mapq, nmk; std::vector<uint32_t> nm, lseq, coff, cig; } hr;
+    bool have_records = false, prim_from_host = false;
+    if (R.per_gene && bgzf && !a.no_stream && span_count == 1 && !getenv("COVERM_NO_GPU_INGEST") && !getenv("COVERM_GENES_DECODE_ON_HOST") && !getenv("COVERM_PAIR_ON_HOST")) {
+        covh_bam_header *hd = covh_bam_read_header(S.path.c_str(), err, sizeof err);
+        if (!hd) die(err);
+        struct HdFree { covh_bam_header *p; ~HdFree() { covh_bam_header_free(p); } } hdfree{hd};
+        set_header(S, covh_bam_header_n_targets(hd), [&](uint32_t t) { return covh_bam_header_target_name(hd, t); },
+                   [&](uint32_t t) { return covh_bam_header_target_len(hd, t); });
+        check(s, cov_set_targets(s, (uint32_t)S.tlen.size(), S.tlen.data()));
+        if (R.by_names) { genome_table(R, S, mask); check(s, cov_set_target_mask(s, mask.data())); }
+        check(s, cov_ingest_want_mates(s, R.fp ? 1 : 0));
+        uint64_t nrec = 0; double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int rc = covh_bam_gpu_ingest_span(S.path.c_str(), threads, s, hd, getenv("COVERM_NO_CRC") ? 0 : 1, 0, 1, &nrec, tm, err, sizeof err);
+        if (rc < 0) die(err);
+        S.n_records = nrec;
+        if (rc == 0 && R.fp) {
+            cov_pair_filter pf; memset(&pf, 0, sizeof pf);
+            pf.filter_single = R.fs; pf.min_mapq = (uint8_t)R.f.mapq; pf.min_aligned_length_single = R.f.len_single;
+            pf.min_percent_identity_single = R.f.pid_single; pf.min_aligned_percent_single = R.f.pct_single;
+            pf.min_aligned_length_pair = R.f.len_pair; pf.min_percent_identity_pair = R.f.pid_pair; pf.min_aligned_percent_pair = R.f.pct_pair;
+            uint64_t nsel = 0, prim = 0;
+            const cov_status prc = cov_pair_filter_apply(s, &pf, &nsel, &prim);
+            if (prc == COV_ERR_INGEST_FALLBACK) rc = 1;
+            else { check(s, prc); S.prim = prim; prim_from_host = true; }
+        }
+        if (rc == 0) {
+            uint64_t n = 0, nc = 0;
+            check(s, cov_copy_records(s, nullptr, &n, &nc));
+            hr.tid.resize(n); hr.pos.resize(n); hr.flag.resize(n); hr.mapq.resize(n); hr.nmk.resize(n); hr.nm.resize(n); hr.lseq.resize(n);
+            hr.coff.resize(n + 1); hr.cig.resize(nc + 1);
+            batch.tid = hr.tid.data(); batch.pos = hr.pos.data(); batch.flag = hr.flag.data(); batch.mapq = hr.mapq.data(); batch.nm = hr.nm.data();
+            batch.nm_kind = hr.nmk.data(); batch.l_seq = hr.lseq.data(); batch.cigar_off = hr.coff.data(); batch.cigar = hr.cig.data(); batch.n_records = n;
+            check(s, cov_copy_records(s, &batch, nullptr, nullptr));
+            if (n == 0) hr.coff[0] = 0;
+            have_records = true; S.device_ingest = true;
+            if (timing_on()) fprintf(stderr, "[coverm-amd] %s: --gff over the device ingest: %llu records came back from the store\n", S.stoit.c_str(), (unsigned long long)n);
+        } else {
+            if (timing_on()) fprintf(stderr, "[coverm-amd] %s: %s\n", S.stoit.c_str(), err[0] ? err : cov_last_error(s));
+            check(s, cov_reset(s)); S.prim = 0; prim_from_host = false;
+        }
+    }
+    // ---- whole file on the host: SAM text, files the device ingest declined, --no-stream
+    covh_bam *bam = nullptr;
+    struct Closer { covh_bam *&p; ~Closer() { if (p) covh_bam_close(p); } } closer{bam};
     cov_batch selected; memset(&selected, 0, sizeof selected);
     struct Freer { cov_batch *b; ~Freer() { if (b->tid) covh_batch_free(b); } } freer{&selected};
-    bool prim_from_host = false;
-    if (R.f.doing_filtering() && !(R.fs && !R.fp)) {
-        for (uint64_t i = 0; i < batch.n_records; i++) if (!(batch.flag[i] & 0x900)) S.prim++;   // filter.rs:129-131
-        prim_from_host = true;
-        covh_pair_filter pf; memset(&pf, 0, sizeof pf);
-        pf.filter_single = R.fs; pf.min_mapq = (uint8_t)R.f.mapq; pf.min_aligned_length_single = R.f.len_single;
-        pf.min_percent_identity_single = R.f.pid_single; pf.min_aligned_percent_single = R.f.pct_single;
-        pf.min_aligned_length_pair = R.f.len_pair; pf.min_percent_identity_pair = R.f.pid_pair; pf.min_aligned_percent_pair = R.f.pct_pair;
-        uint64_t *order = nullptr, n_order = 0;
-        const int prc = covh_pair_mode_order(&batch, covh_bam_mtid(bam), covh_bam_qname_off(bam), covh_bam_qnames(bam), &pf, threads, &order, &n_order);
-        if (prc == COV_ERR_NM_MISSING) die("Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM format");
-        if (prc != COV_OK) die(prc == COV_ERR_NM_BADTYPE ? "Unexpected data type of NM aux tag" : "pair filter failed");
-        const int src = covh_batch_select(&batch, order, n_order, threads, &selected);
-        covh_free(order);
-        if (src != COV_OK) die("pair filter: selection failed");
-        batch = selected;
+    if (!have_records) {
+        bam = covh_bam_open(S.path.c_str(), threads, R.fp ? 1 : 0, err, sizeof err);
+        if (!bam) die(err);
+        set_header(S, covh_bam_n_targets(bam), [&](uint32_t t) { return covh_bam_target_name(bam, t); }, [&](uint32_t t) { return covh_bam_target_len(bam, t); });
+        if (R.by_names) genome_table(R, S, mask);
+        covh_bam_batch(bam, &batch);
+        S.n_records = batch.n_records;
+        if (R.f.doing_filtering() && !(R.fs && !R.fp)) {
+            for (uint64_t i = 0; i < batch.n_records; i++) if (!(batch.flag[i] & 0x900)) S.prim++;   // filter.rs:129-131
+            prim_from_host = true;
+            covh_pair_filter pf; memset(&pf, 0, sizeof pf);
+            pf.filter_single = R.fs; pf.min_mapq = (uint8_t)R.f.mapq; pf.min_aligned_length_single = R.f.len_single;
+            pf.min_percent_identity_single = R.f.pid_single; pf.min_aligned_percent_single = R.f.pct_single;
+            pf.min_aligned_length_pair = R.f.len_pair; pf.min_percent_identity_pair = R.f.pid_pair; pf.min_aligned_percent_pair = R.f.pct_pair;
+            uint64_t *order = nullptr, n_order = 0;
+            const int prc = covh_pair_mode_order(&batch, covh_bam_mtid(bam), covh_bam_qname_off(bam), covh_bam_qnames(bam), &pf, threads, &order, &n_order);
+            if (prc == COV_ERR_NM_MISSING) die("Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM format");
+            if (prc != COV_OK) die(prc == COV_ERR_NM_BADTYPE ? "Unexpected data type of NM aux tag" : "pair filter failed");
+            const int src = covh_batch_select(&batch, order, n_order, threads, &selected);
+            covh_free(order);
+            if (src != COV_OK) die("pair filter: selection failed");
+            batch = selected;
+        }
     }
+    const uint32_t nt = (uint32_t)S.tlen.size();
     S.t_open = now() - t0;
-    check(s, cov_set_targets(s, nt, S.tlen.data()));
-    if (R.by_names) check(s, cov_set_target_mask(s, mask.data()));
-    check(s, cov_push_batch(s, &batch));
+    if (!have_records) {
+        check(s, cov_set_targets(s, nt, S.tlen.data()));
+        if (R.by_names) check(s, cov_set_target_mask(s, mask.data()));
+        check(s, cov_push_batch(s, &batch));
+    }
     S.t_ingest = now() - t0;
     S.stats.resize(nt);
     cov_summary summ;
@@ -533,7 +582,9 @@ int run_cli(int argc, char **argv) {
     }
     const double t_sessions = now();
     covh_bam_set_pinned(1);
-    covh_bam_set_release_staging(nb <= nd ? 1 : 0);      // every session reads one file: its staging slots are released beside the last rounds
+    // (measured, profiles/r03_tail_variants.log: releasing the staging slots beside the last rounds shortens the exit by ~0.03 s and
+    // lengthens the tail by as much — hipHostFree waits for the device — so it stays opt-in)
+    covh_bam_set_release_staging(getenv("COVERM_RELEASE_STAGING") && atoi(getenv("COVERM_RELEASE_STAGING")) && nb <= nd ? 1 : 0);
     if (nb > 1) covh_bam_set_buffer_cache(1);
     const bool timing = getenv("COVERM_CLI_TIMING") != nullptr;
     std::vector<Sample> samples(nb);
