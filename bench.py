@@ -377,14 +377,15 @@ def binary_config_legs(a, threads, ref, batch, oracle_cfg2):
     return res
 
 
-def multi_device_legs(a, threads, world):
+def multi_device_legs(a, threads, world, devs=None):
     """The PRODUCT's multi-GPU path (coverm-amd --devices 0..N-1, one process, one reader + session per device) at N > 1:
     config 4 (N BAMs x 50 M reads, one per device) and config 5 (one 200 M-read BAM cut into N tid spans, RCCL gather of the
     per-contig blocks), reads/s and per-device ingest stamps, each table compared with the single-device run of the same command."""
     from coverm_amd import bam as cbam
     res = dict(devices=world)
     tmpdir = tempfile.mkdtemp(prefix="covbench", dir=a.tmp)
-    devs = "0-%d" % (world - 1)
+    devs = devs or "0-%d" % (world - 1)
+    res["devices_arg"] = devs
     try:
         ref = synth.make_reference(a.contigs, a.bp, seed=1)
         # ---- config 4: N samples (the same 50 M reads under N names: hard links), one per device
@@ -642,6 +643,15 @@ def main():
                         exit_code = 3
                 except Exception as ex:   # the headline legs above stand on their own
                     out["bases"]["end_to_end"] = {"error": repr(ex)[:1000]}
+        fake = os.environ.get("COVERM_BENCH_MULTI_DEVICE_CHECK")     # e.g. "0,0": the --devices legs on a single-GPU box (functional check, not a measurement)
+        if fake and world == 1:
+            try:
+                out["multi_device_end_to_end_functional_check"] = multi_device_legs(a, max(1, usable_cpus()), len(fake.split(",")), devs=fake)
+                if not out["multi_device_end_to_end_functional_check"].get("tables_equal", False):
+                    exit_code = 3
+            except Exception as ex:
+                out["multi_device_end_to_end_functional_check"] = {"error": repr(ex)[:1000]}
+                exit_code = 3
         if world > 1 and not a.no_multi_device_e2e and not share:
             # the product's own multi-GPU path (one process, N devices): run by rank 0 while the other ranks wait at the barrier below
             try:
