@@ -27,6 +27,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -1326,8 +1327,15 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
             if (map) munmap(map, (size_t)file_size);
         }
     } bf{s, buf, map, file_size, {}, {}};
-    if (cov_ingest_begin(s, file_size, first_record, check_crc) != COV_OK) return fail(-1, cov_last_error(s));
-    if (span_count > 1 && cov_ingest_span(s, key_lo, key_hi, mid_start ? 1 : 0, open_end ? 1 : 0, f_lo, size) != COV_OK) return fail(-1, cov_last_error(s));
+    // cov_ingest_begin (four streams, a dozen events, two page-locked tables: ~25 ms) runs BESIDE the reader's first pieces (their
+    // page-locked slots cost ~5 ms each to obtain): the coordinator waits for it in front of the first feed.
+    std::future<int> begun = std::async(std::launch::async, [&]() -> int {
+        if (cov_ingest_begin(s, file_size, first_record, check_crc) != COV_OK) return 1;
+        if (span_count > 1 && cov_ingest_span(s, key_lo, key_hi, mid_start ? 1 : 0, open_end ? 1 : 0, f_lo, size) != COV_OK) return 1;
+        return 0;
+    });
+    struct BegunWait { std::future<int> &f; ~BegunWait() { if (f.valid()) (void)f.get(); } } begun_wait{begun};     // (destroyed before bf: abort sees a finished begin)
+    if (use_map && begun.get() != 0) return fail(-1, cov_last_error(s));      // registering the mapping needs the session's device set up
     // staging slots: page-locked memory costs ~0.17 s per GiB to obtain and ~0.13 s per GiB to give back when the process ends
     // (tools/ubench/exit_probe), so the slots are as small as the reader's rate allows: 4 x 32 MiB in 2 MiB chunks read 5 GB in
     // 0.098 s inside the pipeline, 4 x 64 MiB in 4 MiB chunks in 0.114 s (profiles/r03_reader_sweep_50M.log)
@@ -1515,12 +1523,14 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
         tail_end = have;
         t_walk += now() - t0;
         t0 = now();
+        if (begun.valid() && begun.get() != 0) return fail(-1, cov_last_error(s));
         if (cov_ingest_feed(s, slot, dst, off, n, blocks.data(), (uint32_t)blocks.size()) != COV_OK) return fail(-1, cov_last_error(s));
         t_feed += now() - t0;
         { std::lock_guard<std::mutex> lk(mu); fed = k + 1; }
         cv.notify_all();
     }
     reader.join();
+    if (begun.valid() && begun.get() != 0) return fail(-1, cov_last_error(s));      // (a span without pieces)
     if (next_blk != size) return fail(1, "truncated BGZF block at the end of the file");
     double t0 = now();
     // The staging slots have done their work once their last uploads are through.  When this session reads no further file
