@@ -252,3 +252,42 @@ def test_interval_stats_abi(tmp_path):
             s.reset()
             s.push(batch)
     assert max(int(x.max()) for x in depth) > 1000
+
+
+@pytest.mark.gpu
+def test_gene_coverage_through_the_binary_takes_the_device_ingest(tmp_path):
+    """`coverm-amd --gff` over a BAM file: the device inflates and parses the file, the records the gene driver needs come back from
+    the session's store (no whole-file decode on the host) — text == the oracle's, and == the run that decodes on the host
+    (COVERM_GENES_DECODE_ON_HOST=1).  240 k reads in several BGZF blocks per contig; single-read and pair-mode filters included."""
+    import subprocess
+    from coverm_amd import bam as cbam
+    from tests import binary
+    ref = synth.make_reference(25, 1_500_000, seed=83, min_len=1500, max_len=200_000)
+    batch = synth.make_reads(ref, 240_000, seed=84)
+    n = batch.n_records
+    i = np.arange(n, dtype=np.int64)
+    m = i ^ 1
+    same = (m < n) & (batch.tid[np.minimum(m, n - 1)] == batch.tid)          # what the writer's with_seq = 3 makes mates of
+    b = BamData(ref.names, ref.lengths, batch.tid, batch.pos, batch.flag, batch.mapq, batch.l_seq.astype(np.int32), batch.nm, batch.nm_kind,
+                batch.cigar_off, batch.cigar, batch.tid.copy(), np.zeros(n, np.int32), np.zeros(n, np.int32),
+                [b"n%d" % k for k in np.where(same, i & ~1, i)], "")
+    path = str(tmp_path / "syn.bam")
+    cbam.write_bam(path, ref.names, ref.lengths, batch, with_seq=3, threads=4)
+    rng = np.random.default_rng(5)
+    lines = ["##gff-version 3"]
+    for c, (name, L) in enumerate(zip(ref.names, ref.lengths)):
+        for k in range(int(rng.integers(1, 9))):
+            s = int(rng.integers(1, L))
+            lines.append("%s\tsyn\tgene\t%d\t%d\t.\t+\t.\tID=%s_g%d" % (name, s, min(int(L), s + int(rng.integers(1, 3000))), name.replace("~", "_"), k))
+    gff = tmp_path / "syn.gff"
+    gff.write_text("\n".join(lines) + "\n")
+    for kw in (dict(methods=["mean", "variance", "covered_fraction", "count", "anir"]),
+               dict(methods=["mean", "trimmed_mean"], min_read_percent_identity=97, proper_pairs_only=True, output_format="sparse"),
+               dict(methods=["mean", "count"], min_read_percent_identity_pair=95, proper_pairs_only=True)):
+        want = O.run_cli("contig", [path], bams=[b], gff=str(gff), **kw)
+        r = subprocess.run(binary.argv("contig", [path], gff=str(gff), **kw), capture_output=True, text=True, env=dict(os.environ, COVERM_CLI_TIMING="1"), timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert "--gff over the device ingest" in r.stderr
+        assert r.stdout == want, kw
+        assert binary.run("contig", [path], gff=str(gff), env={"COVERM_GENES_DECODE_ON_HOST": "1"}, **kw) == want
+        assert want.count("\n") > 20
