@@ -425,8 +425,7 @@ class ContigWorkers {
             fn_(n_ * p / parts_, n_ * (p + 1) / parts_);
         }
     }
-    void worker() {
-        uint64_t seen = 0;
+    void worker(uint64_t seen) {        // seen = the generation current when the thread was created: a thread added later must not replay it
         for (;;) {
             { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return stop_ || gen_ != seen; }); if (stop_) return; seen = gen_; }
             drain();
@@ -443,7 +442,7 @@ public:
         if (const char *e = getenv("COVERM_FINALISE_THREADS")) want = std::max(1, atoi(e));
         if (want <= 1) { fn(0, n); return; }
         std::lock_guard<std::mutex> rl(run_m_);
-        while (th_.size() + 1 < want) th_.emplace_back([this] { worker(); });
+        while (th_.size() + 1 < want) { uint64_t g; { std::lock_guard<std::mutex> lk(m_); g = gen_; } th_.emplace_back([this, g] { worker(g); }); }
         { std::lock_guard<std::mutex> lk(m_); fn_ = std::move(fn); n_ = n; parts_ = want * 2; next_ = 0; busy_ = (int)th_.size(); gen_++; }
         cv_.notify_all();
         drain();
