@@ -1012,8 +1012,10 @@ static const InflateKernel &inflate_kernel(cov_session *s) {
         const char *e = getenv("COVERM_INFLATE_BITS"), *d = getenv("COVERM_INFLATE_DIST_BITS");
         const bool s8 = getenv("COVERM_INFLATE_SORT8") && atoi(getenv("COVERM_INFLATE_SORT8"));
         const char *ve = getenv("COVERM_INFLATE_V");
-        K.version = ve && atoi(ve) == 2 ? 2 : 1;      // k_inflate2 is correct but not faster yet (profiles/r03_inflate2_variants.log): opt-in
-        const int lb = e ? atoi(e) : 7, db = d ? atoi(d) : (K.version == 2 ? 5 : (lb <= 6 ? 5 : 6));     // k_inflate: 7 + 6 bits, five waves per CU, the fastest measured (200 M reads: 0.71 s against 0.87 s at 8 + 6, 0.84 s at 6 + 5); k_inflate2: 7 + 5 = 32 KiB, five waves per CU
+        K.version = ve && atoi(ve) == 2 ? 2 : (ve && atoi(ve) == 3 ? 3 : 1);      // k_inflate2 is correct but not faster (profiles/r03_inflate2_variants.log), k_inflate_wave is not measured yet: opt-in
+        const bool wave = K.version == 3;     // k_inflate_wave has no table-size variants; its rounds (= windows) are those of the default k_inflate
+        if (wave) K.version = 1;
+        const int lb = e && !wave ? atoi(e) : 7, db = d && !wave ? atoi(d) : (K.version == 2 ? 5 : (lb <= 6 ? 5 : 6));     // k_inflate: 7 + 6 bits, five waves per CU, the fastest measured (200 M reads: 0.71 s against 0.87 s at 8 + 6, 0.84 s at 6 + 5); k_inflate2: 7 + 5 = 32 KiB, five waves per CU
         int per_cu = 0;
         bool found = false;
 #define COV_INF2_SETUP(LB, DB, S8)                                                                                                             \
@@ -1045,6 +1047,7 @@ static const InflateKernel &inflate_kernel(cov_session *s) {
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate<7, 6, false>, 64, covi::inflate_smem_bytes(7, 6));
         }
         if (per_cu <= 0) per_cu = 2;
+        if (wave) K.version = 3;
         K.round_blocks = (u32)s->n_cus * (u32)per_cu * 64u;
         if (const char *w = getenv("COVERM_INGEST_ROUND_BLOCKS")) { const long v = atol(w); if (v >= 64) K.round_blocks = (u32)v / 64u * 64u; }   // tests: many small windows
         if (const char *c = getenv("COVERM_INGEST_CARRY_KB")) { const long v = atol(c); if (v >= 1) K.carry = (u64)v << 10; }
@@ -1066,7 +1069,7 @@ static void inflate_prepare_device(const InflateKernel &K) {
                                   (int)covi::inflate2_smem_bytes(LB, DB, S8));
     COV_INFLATE2_VARIANTS(COV_INF2_ATTR)
 #undef COV_INF2_ATTR
-    if (K.version == 2) return;
+    if (K.version != 1) return;
 #define COV_INF_ATTR(LB, DB, S8)                                                                                                                \
     if (K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                                                 \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, DB, S8>), hipFuncAttributeMaxDynamicSharedMemorySize,     \
@@ -1234,6 +1237,9 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
         const u32 grid = (n + 63u) / 64u;
         const uint8_t *comp_bias = s->g_cwin[w % 3u].p - s->ing_round_start;     // blocks carry absolute file offsets
         static const u32 ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);
+        if (K.version == 3)
+            hipLaunchKernelGGL(covi::k_inflate_wave, dim3(n), dim3(64), 0, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, tokb.p, ntokb.p,
+                               s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
 #define COV_LAUNCH_INFLATE2(LB, DB, S8)                                                                                                         \
         if (K.version == 2 && K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                               \
             hipLaunchKernelGGL((covi::k_inflate2<LB, DB, S8>), dim3(grid), dim3(64), covi::inflate2_smem_bytes(LB, DB, S8), s->stream, comp_bias,   \

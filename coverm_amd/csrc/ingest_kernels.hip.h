@@ -698,6 +698,39 @@ __global__ __launch_bounds__(64) void k_inflate2(const uint8_t *__restrict__ com
     if (err != INF_OK) atomicAdd(n_failed, 1u);
 }
 
+// ---------------------------------------------------------------------------------------------- k_inflate_wave
+// One WAVE per BGZF block (COVERM_INFLATE_V=3, opt-in until it is measured on the device): the 64 lanes share one set of Huffman
+// tables in LDS (8.2 KiB per wave against 28 KiB of per-lane tables: 16+ waves per CU instead of five) and each decodes 1/64 of the
+// block's bit stream — three passes, described with the code in csrc/inflate_wave_core.h, which is plain C++ and runs lane by lane on
+// the CPU in tests/test_inflate_wave_core.py.  Same contract as k_inflate: literals in place, matches as in-place tokens for
+// k_lz_resolve, n_tok / status per block.
+}  // namespace covi
+#define COVW_FN __device__ __forceinline__
+#define COVW_PARFOR(lane) for (unsigned lane = threadIdx.x & 63u, covw_once = 1u; covw_once; covw_once = 0u)
+#define COVW_SYNC() __syncthreads()
+#define covw_brev32(x) __brev(x)
+#include "inflate_wave_core.h"
+namespace covi {
+static_assert(covw::TOK_CAP == INF_TOK_CAP && covw::OK == INF_OK && covw::ERR_FORMAT == INF_ERR_FORMAT && covw::ERR_SIZE == INF_ERR_SIZE, "the core mirrors k_inflate's contract");
+__global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
+                                                     uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
+                                                     u32 *__restrict__ status, u32 *__restrict__ n_failed) {
+    __shared__ covw::Wave W;
+    const u32 b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const BgzfBlock B = blocks[b];
+    u32 st = INF_OK, nt = 0;
+    if (B.isize != 0u) {
+        const u32 mis = (u32)((u64)(comp + B.in_off) & 3u);
+        covw::inflate_block(W, reinterpret_cast<const u32 *>(comp + B.in_off - mis), 8u * mis, 8u * B.in_len, out + B.out_off, B.isize,
+                            tok + (size_t)b * INF_TOK_CAP, &nt, &st);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        n_tok[b] = nt; status[b] = st;
+        if (st != INF_OK) atomicAdd(n_failed, 1u);
+    }
+}
+
 // Inclusive wave64 prefix sum (DPP row shifts + row broadcasts; VALU latency only).
 __device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {
     int v = (int)x;
