@@ -1237,9 +1237,13 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
         const u32 grid = (n + 63u) / 64u;
         const uint8_t *comp_bias = s->g_cwin[w % 3u].p - s->ing_round_start;     // blocks carry absolute file offsets
         static const u32 ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);
-        if (K.version == 3)
-            hipLaunchKernelGGL(covi::k_inflate_wave, dim3(n), dim3(64), 0, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, tokb.p, ntokb.p,
-                               s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
+        if (K.version == 3) {
+            // measurements: COVERM_INFLATE_WAVE_PAD_KB of unused dynamic LDS lowers the resident waves per CU, COVERM_INFLATE_ABLATE = 1..3 stops
+            // every block after the tables / pass 1 / pass 2 (the file then falls back to the host reader)
+            static const u32 pad = (u32)(getenv("COVERM_INFLATE_WAVE_PAD_KB") ? atoi(getenv("COVERM_INFLATE_WAVE_PAD_KB")) : 0) << 10;
+            hipLaunchKernelGGL(covi::k_inflate_wave, dim3(n), dim3(64), pad, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, tokb.p, ntokb.p,
+                               s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
+        }
 #define COV_LAUNCH_INFLATE2(LB, DB, S8)                                                                                                         \
         if (K.version == 2 && K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                               \
             hipLaunchKernelGGL((covi::k_inflate2<LB, DB, S8>), dim3(grid), dim3(64), covi::inflate2_smem_bytes(LB, DB, S8), s->stream, comp_bias,   \

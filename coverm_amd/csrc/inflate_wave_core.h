@@ -294,7 +294,8 @@ COVW_FN u32 share_end_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
 
 // One BGZF block.  comp_words: aligned words holding the raw DEFLATE payload from bit `bit0` on; out: the block's `isize` output
 // bytes; tok: its token-position list.  *status = OK / ERR_*, *n_tok = matches written (0 unless OK).
-COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status) {
+// stop_after (measurements only, 0 in production): 1 = give up after the tables are built, 2 = after pass 1, 3 = after pass 2.
+COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0) {
     Src s; s.w = comp_words; s.total_bits = bit0 + payload_bits;
     u32 pos = bit0, opos = 0, ntok = 0, err = OK;
     bool last = false;
@@ -327,6 +328,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
             for (u32 i = lane; i < (1u << DB); i += 64u) fill_dist_index(W.T, i);
         }
         COVW_SYNC();
+        if (stop_after == 1u) { err = ERR_FORMAT; break; }
         const u32 B0 = W.hdr[4];
         const u32 span = s.total_bits > B0 ? s.total_bits - B0 : 0u;
         // a share shorter than the distance over which a decoder falls in step (p99: 50 units, ~480 bits) makes pass 1 guess wrong and
@@ -340,6 +342,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                                             : run_share<0>(W.T, s, (u32)g, share_end_of(B0, S, lane, s.total_bits), &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr);
         }
         COVW_SYNC();
+        if (stop_after == 2u) { err = ERR_FORMAT; break; }
         // ---- pass 2: from the left neighbour's end, until no end moves (lane k is exact after round k)
         for (u32 round = 0;; round++) {
             COVW_PARFOR(lane) {
@@ -368,6 +371,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
             if (round >= 65u) { err = ERR_FORMAT; break; }
         }
         if (err != OK) break;
+        if (stop_after == 3u) { err = ERR_FORMAT; break; }
         // ---- the Huffman block = the lanes up to the first one that met end-of-block (or an invalid code); prefix sums
         COVW_PARFOR(lane) {
             if (lane == 0u) {

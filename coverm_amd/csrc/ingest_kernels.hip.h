@@ -714,7 +714,7 @@ namespace covi {
 static_assert(covw::TOK_CAP == INF_TOK_CAP && covw::OK == INF_OK && covw::ERR_FORMAT == INF_ERR_FORMAT && covw::ERR_SIZE == INF_ERR_SIZE, "the core mirrors k_inflate's contract");
 __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                      uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
-                                                     u32 *__restrict__ status, u32 *__restrict__ n_failed) {
+                                                     u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
     __shared__ covw::Wave W;
     const u32 b = blockIdx.x;
     if (b >= n_blocks) return;
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__
     if (B.isize != 0u) {
         const u32 mis = (u32)((u64)(comp + B.in_off) & 3u);
         covw::inflate_block(W, reinterpret_cast<const u32 *>(comp + B.in_off - mis), 8u * mis, 8u * B.in_len, out + B.out_off, B.isize,
-                            tok + (size_t)b * INF_TOK_CAP, &nt, &st);
+                            tok + (size_t)b * INF_TOK_CAP, &nt, &st, stop_after);
     }
     if ((threadIdx.x & 63u) == 0u) {
         n_tok[b] = nt; status[b] = st;
