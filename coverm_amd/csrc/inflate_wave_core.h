@@ -2,20 +2,21 @@
 //
 // Lane-per-block inflate (k_inflate) keeps a private Huffman table per lane in LDS, which bounds the resident lanes, and decodes a
 // block serially, which sets the latency of a round.  Here the 64 lanes of a wave share ONE set of tables and each decodes 1/64 of
-// the block's bit stream:
-//   pass 1  lane i starts at the GUESSED offset B0 + i * S as if a unit (literal | length + extra + distance + extra | end of block)
-//           began there and decodes to the end of its share: Huffman streams self-synchronise — on BAM blocks a decoder started at an
-//           arbitrary bit is in step with the true sequence after a median of 6 units, 70 at most (profiles/r03_deflate_sync_probe.log)
-//           — so the position where it leaves its share is, almost always, a true unit boundary;
-//   pass 2  lane i starts where lane i - 1 ended (lane 0 at the true first unit) and decodes exactly its units, counting output bytes
-//           and matches; repeated while any end moves (normally once; lane k is exact after round k whatever pass 1 guessed).  The
-//           lanes up to the first end-of-block symbol are the Huffman block; the rest of the wave decoded what belongs to the next
-//           DEFLATE block with the wrong tables and is discarded;
+// the block's bit stream (share i = bits [B0 + i * S, B0 + (i + 1) * S) behind the block header):
+//   pass 1  where does the first unit (literal | length + extra + distance + extra | end of block) of share i begin?  Lane i starts
+//           OVERLAP bits in front of its share as if a unit began there and decodes up to the share: Huffman streams self-synchronise
+//           — on BAM blocks a decoder started at an arbitrary bit is in step with the true sequence after a median of 6 units, 70 at most
+//           (profiles/r03_deflate_sync_probe.log) — so where it crosses into its share is, almost always, a true unit boundary;
+//   pass 2  lane i decodes exactly the units that begin in its share, from where pass 1 says they begin, and counts output bytes and
+//           matches.  Where it ends must be where lane i + 1 began: if not, lane i + 1 takes the end as its beginning and the pass is
+//           repeated (lane k is exact after round k whatever pass 1 guessed; normally there is one round).  The lanes up to the first
+//           end-of-block symbol are the Huffman block; the rest of the wave decoded what belongs to the next DEFLATE block with the wrong
+//           tables and is discarded;
 //   pass 3  output offsets = prefix sums of the counts; every lane decodes its units once more and writes: literals at their final
 //           positions, a match as a 3-byte token in place + its 16-bit position in the block's token list (k_lz_resolve's contract,
-//           unchanged).  No store touches a byte that another lane owns: literals leave as exact 8/4/2/1-byte stores, a token as
-//           2 + 1 bytes (4 when the match is longer than three bytes: the fourth byte is the match's own).
-// Header parsing and the per-length tables are serial (lane 0); the primary tables are filled in parallel, one INDEX per lane step
+//           unchanged).  No store touches a byte that another lane owns: pending literals and the token behind them leave as ONE store
+//           where the padding falls into the match's own bytes (which k_lz_resolve writes later), as exact 4/2/1-byte stores otherwise.
+// Header parsing and the per-length tables are serial (lane 0); the lookup tables are filled in parallel, one INDEX per lane step
 // (an index is decoded canonically like a long code), so no lane writes more entries than another.
 //
 // This file contains no HIP: it is a sequence of `COVW_PARFOR(lane) { ... }` regions over wave-shared state, separated by wave
@@ -30,6 +31,10 @@
 #pragma once
 #include <stdint.h>
 
+#ifndef COVW_TRACE_UNIT
+#define COVW_TRACE_UNIT(mode, flags) do { } while (0)      // tools/proto/wave_cost_model.cpp: lock-step cost model
+#endif
+
 namespace covw {
 
 typedef unsigned int u32;
@@ -37,26 +42,33 @@ typedef unsigned long long u64;
 typedef unsigned short u16;
 typedef unsigned char u8;
 
-constexpr u32 LB = 11, DB = 9;            // primary table bits of the literal/length and the distance alphabet
+#ifndef COVW_LB
+#define COVW_LB 10      // 2 KiB + 1 KiB of lookup tables: some lane of 64 meets a longer literal code in 67 % of the steps (62 % at 11 bits), a longer
+#define COVW_DB 8       // distance code in 6 % (1 % at 9 bits) — tools/proto/wave_cost_model.cpp — and the wave state stays at 6.2 KiB: 25 waves per CU
+#endif
+constexpr u32 LB = COVW_LB, DB = COVW_DB;  // index bits of the lookup tables of the literal/length and the distance alphabet
 constexpr u32 TOK_CAP = 21888;            // = covi::INF_TOK_CAP
 enum { OK = 0, ERR_FORMAT = 1, ERR_CRC = 2, ERR_SIZE = 3 };       // = covi::INF_*
 constexpr u32 NO_EOB = 0xffffffffu;
-constexpr u32 MIN_SHARE_BITS = 512;
+// A share shorter than the distance over which a decoder falls in step makes pass 1 guess wrong and pass 2 repeat: small blocks use
+// fewer lanes.  OVERLAP: p99 of that distance is 50 units (~480 bits), the largest seen 670 bits.
+constexpr u32 MIN_SHARE_BITS = 512, OVERLAP_BITS = 768;
+constexpr u32 DIST_INVALID = 0x80000000u;
 
 struct Tables {
     u16 lit[1u << LB];                    // bits 0-3 code length (0: not decidable from LB bits); literal / end of block: bit 15 = 0, bits 4-12 symbol;
                                           // length symbol: bit 15 = 1, bits 4-11 base - 3, bits 12-14 extra bits; 0xfff0 | length: symbols 286 / 287
-    u16 dist[1u << DB];                   // bits 0-3 code length, bits 4-8 symbol
+    u32 dist[1u << DB];                   // bits 0-3 code length, bits 4-7 extra bits, bits 8-22 base; bit 31: symbols 30 / 31
     u16 lit_limit[16], dist_limit[16];    // limit[l] = (first code of length l + count[l]) << (15 - l)
     u16 lit_off[16], dist_off[16];        // (index of the first symbol of length l in sorted[]) - (first code of length l)  (mod 2^16)
-    u16 lit_sorted[288];
+    u16 lit_sorted[288];                  // the symbols sorted by (code length, value) — as table entries without the length once the tables are built
     u8 dist_sorted[32];
     u8 lens[320];                         // code lengths: [0, 288) literal/length, [288, 320) distance
 };
 
-struct Wave {                             // wave-shared state (LDS on the device): 8.2 KiB
+struct Wave {                             // wave-shared state (LDS on the device)
     Tables T;
-    u32 end[64];                          // bit position where lane i's units end (the first unit boundary at or behind its share's end, or where it stopped)
+    u32 end[64];                          // bit position where lane i's units end = where lane i + 1's begin
     u32 tmp[64];
     u32 flags[64];                        // bit 0: the lane met end-of-block, bit 1: it met an invalid code / ran off the payload
     u32 nbytes[64], ntok[64];             // output bytes / matches of the lane's units
@@ -65,11 +77,14 @@ struct Wave {                             // wave-shared state (LDS on the devic
                                           // [6] error, [7] bytes
     u32 changed, n_valid, eob_at, rounds; // rounds: pass-2 rounds of the last Huffman block (statistics)
     u32 cnt[16], start[16];               // build_lengths' scratch (indexed dynamically: in LDS, not in private memory)
-    u16 climit[16], coff[16];             // the code-length code
+    u16 climit[16], coff[16];             // the code-length code ...
     u8 csorted[32], cl[32];
+    u8 cltab[128];                        // ... and its lookup table: (symbol << 3) | code length by the next 7 bits, 0 = no code
 };
 
 struct Src { const u32 *w; u32 total_bits; };     // aligned words of the payload (readable 16 bytes past its end); bit 0 = bit 0 of w[0]
+
+COVW_FN u32 bits_at(u32 x, u32 off, u32 n) { return (x >> off) & ((1u << n) - 1u); }      // off + n <= 31
 
 // Bit cursor of one lane: `cnt` valid bits of the stream at `pos` in buf, the next word already requested.
 struct Cursor {
@@ -83,7 +98,6 @@ struct Cursor {
     COVW_FN void refill() {               // afterwards cnt >= 33
         if (cnt <= 32u) { buf |= (u64)ahead << cnt; cnt += 32u; wi++; ahead = w[wi]; }
     }
-    COVW_FN u32 peek(u32 n) const { return (u32)buf & ((1u << n) - 1u); }
     COVW_FN u32 low32() const { return (u32)buf; }
     COVW_FN void drop(u32 n) { buf >>= n; cnt -= n; pos += n; }
 };
@@ -115,44 +129,53 @@ COVW_FN bool build_lengths(Wave &W, const u8 *lens, u32 n, u16 *limit, u16 *off,
     return true;
 }
 
-// Code length and sorted-symbol index of the code that begins the left-justified 15-bit value v; 0 when v starts no code of the set.
+// Code length and sorted-symbol index of the code that begins the left-justified 15-bit value v, for a code known to be longer than
+// FROM bits (FROM = 0: any code); 0 when v starts no code of the set.
+template <u32 FROM>
 COVW_FN u32 canonical(const u16 *limit, const u16 *off, u32 v, u32 &idx) {
-    u32 l = 1;
-    for (u32 k = 1; k < 15; k++) l += v >= (u32)limit[k] ? 1u : 0u;      // limits do not decrease with the length
+    u32 l = FROM + 1u;
+    for (u32 k = FROM + 1u; k < 15u; k++) l += v >= (u32)limit[k] ? 1u : 0u;      // limits do not decrease with the length
     if (v >= (u32)limit[15]) return 0;
     idx = ((u32)off[l] + (v >> (15u - l))) & 0xffffu;
     return l;
 }
 
-COVW_FN u32 lit_entry(u32 sym, u32 len) {          // table entry of a literal/length symbol
-    if (sym <= 256u) return (sym << 4) | len;
-    if (sym > 285u) return 0xfff0u | len;
+COVW_FN u32 lit_entry(u32 sym) {                   // table entry of a literal/length symbol, without the code length
+    if (sym <= 256u) return sym << 4;
+    if (sym > 285u) return 0xfff0u;
     const u32 li = sym - 257u;                     // RFC 1951 3.2.5: 257-264 are lengths 3-10, then groups of four share e extra bits, 285 = 258
     const u32 le = li < 8u ? 0u : (li == 28u ? 0u : (li - 4u) >> 2);
     const u32 lb = li < 8u ? 3u + li : (li == 28u ? 258u : 3u + ((4u + (li & 3u)) << le));
-    return 0x8000u | (le << 12) | ((lb - 3u) << 4) | len;
+    return 0x8000u | (le << 12) | ((lb - 3u) << 4);
+}
+COVW_FN u32 dist_entry(u32 ds) {                   // ... of a distance symbol: distance codes come in pairs sharing e extra bits
+    if (ds >= 30u) return DIST_INVALID;
+    const u32 de = ds < 4u ? 0u : (ds - 2u) >> 1;
+    const u32 base = ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << de);
+    return (base << 8) | (de << 4);
 }
 
-// Primary entries by INDEX: the code that starts the index's bits, if it is decidable from them.
+// Lookup entries by INDEX: the code that starts the index's bits, if it is decidable from them.
 COVW_FN void fill_lit_index(Tables &T, u32 i) {
     u32 idx = 0;
-    const u32 l = canonical(T.lit_limit, T.lit_off, covw_brev32(i) >> 17, idx);
-    T.lit[i] = (u16)((l == 0 || l > LB) ? 0u : lit_entry(T.lit_sorted[idx < 288u ? idx : 287u], l));
+    const u32 l = canonical<0>(T.lit_limit, T.lit_off, covw_brev32(i) >> 17, idx);
+    T.lit[i] = (u16)((l == 0 || l > LB) ? 0u : ((u32)T.lit_sorted[idx < 288u ? idx : 287u] | l));
 }
 COVW_FN void fill_dist_index(Tables &T, u32 i) {
     u32 idx = 0;
-    const u32 l = canonical(T.dist_limit, T.dist_off, covw_brev32(i) >> 17, idx);
-    T.dist[i] = (u16)((l == 0 || l > DB) ? 0u : (((u32)T.dist_sorted[idx & 31u] << 4) | l));
+    const u32 l = canonical<0>(T.dist_limit, T.dist_off, covw_brev32(i) >> 17, idx);
+    T.dist[i] = (l == 0 || l > DB) ? 0u : (dist_entry(T.dist_sorted[idx & 31u]) | l);
 }
 
-// ---- header of the DEFLATE block at `pos` (serial): fills W.hdr and, for Huffman blocks, W.T.lens.
+// ---- header of the DEFLATE block at `pos` (serial): fills W.hdr; fixed codes: W.T.lens; dynamic codes: the code-length code (W.cl and its
+// canonical tables), hdr[4] = where the code lengths begin.
 COVW_FN void parse_header(Wave &W, const Src &s, u32 pos) {
     u32 *h = W.hdr;
     h[6] = OK;
     if (pos + 3u > s.total_bits) { h[6] = ERR_FORMAT; return; }
     Cursor c; c.init(s, pos);
-    h[1] = c.peek(1); c.drop(1);
-    h[0] = c.peek(2); c.drop(2);
+    h[1] = c.low32() & 1u; h[0] = (c.low32() >> 1) & 3u;
+    c.drop(3);
     if (h[0] == 3u) { h[6] = ERR_FORMAT; return; }
     if (h[0] == 0u) {                                   // stored: LEN, NLEN at the next byte boundary
         c.drop((8u - (c.pos & 7u)) & 7u);
@@ -177,9 +200,9 @@ COVW_FN void parse_header(Wave &W, const Src &s, u32 pos) {
     }
     if (c.pos + 14u > s.total_bits) { h[6] = ERR_FORMAT; return; }
     c.refill();
-    const u32 hlit = c.peek(5) + 257u; c.drop(5);
-    const u32 hdist = c.peek(5) + 1u; c.drop(5);
-    const u32 hclen = c.peek(4) + 4u; c.drop(4);
+    const u32 x = c.low32();
+    const u32 hlit = (x & 31u) + 257u, hdist = ((x >> 5) & 31u) + 1u, hclen = ((x >> 10) & 15u) + 4u;
+    c.drop(14);
     if (hlit > 286u || hdist > 30u) { h[6] = ERR_FORMAT; return; }
     u8 *cl = W.cl;
     for (u32 k = 0; k < 19; k++) cl[k] = 0;
@@ -187,24 +210,30 @@ COVW_FN void parse_header(Wave &W, const Src &s, u32 pos) {
         // the order in which the code-length code's own lengths are sent: 16 17 18 0 | 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
         const u32 sym = k < 3u ? 16u + k : (k == 3u ? 0u : ((k & 1u) ? 8u - ((k - 3u) >> 1) : 8u + ((k - 4u) >> 1)));
         c.refill();
-        cl[sym] = (u8)c.peek(3); c.drop(3);
+        cl[sym] = (u8)(c.low32() & 7u); c.drop(3);
     }
     if (!build_lengths(W, cl, 19, W.climit, W.coff, nullptr, W.csorted)) { h[6] = ERR_FORMAT; return; }
-    const u32 want = hlit + hdist;
+    h[2] = hlit; h[3] = hdist; h[4] = c.pos;
+}
+
+// ---- the code lengths of a dynamic block (serial, through W.cltab): fills W.T.lens, hdr[4] = first unit bit
+COVW_FN void parse_code_lengths(Wave &W, const Src &s) {
+    u32 *h = W.hdr;
+    u8 *lens = W.T.lens;
+    const u32 hlit = h[2], hdist = h[3], want = hlit + hdist;
+    Cursor c; c.init(s, h[4]);
     u32 n = 0;
     while (n < want) {
         if (c.pos >= s.total_bits) { h[6] = ERR_FORMAT; return; }
         c.refill();
-        u32 idx = 0;
-        const u32 l = canonical(W.climit, W.coff, covw_brev32(c.low32()) >> 17, idx);
-        if (l == 0 || l > 7u) { h[6] = ERR_FORMAT; return; }
-        const u32 sym = W.csorted[idx & 31u];
-        c.drop(l);
-        if (sym < 16u) { lens[n++] = (u8)sym; continue; }
+        const u32 x = c.low32();
+        const u32 e = W.cltab[x & 127u], l = e & 7u, sym = e >> 3;
+        if (l == 0u) { h[6] = ERR_FORMAT; return; }
+        if (sym < 16u) { lens[n++] = (u8)sym; c.drop(l); continue; }
         u32 rep, val = 0;
-        if (sym == 16u) { if (n == 0) { h[6] = ERR_FORMAT; return; } val = lens[n - 1]; rep = 3u + c.peek(2); c.drop(2); }
-        else if (sym == 17u) { rep = 3u + c.peek(3); c.drop(3); }
-        else { rep = 11u + c.peek(7); c.drop(7); }
+        if (sym == 16u) { if (n == 0) { h[6] = ERR_FORMAT; return; } val = lens[n - 1]; rep = 3u + bits_at(x, l, 2); c.drop(l + 2u); }
+        else if (sym == 17u) { rep = 3u + bits_at(x, l, 3); c.drop(l + 3u); }
+        else { rep = 11u + bits_at(x, l, 7); c.drop(l + 7u); }
         if (n + rep > want) { h[6] = ERR_FORMAT; return; }
         for (u32 k = 0; k < rep; k++) lens[n++] = (u8)val;
     }
@@ -212,84 +241,112 @@ COVW_FN void parse_header(Wave &W, const Src &s, u32 pos) {
     for (u32 k = hdist; k-- > 0;) lens[288 + k] = lens[hlit + k];      // backwards: the ranges overlap
     for (u32 k = hlit; k < 288; k++) lens[k] = 0;
     for (u32 k = 288 + hdist; k < 320; k++) lens[k] = 0;
-    h[2] = hlit; h[3] = hdist; h[4] = c.pos;
+    h[4] = c.pos;
 }
 
+COVW_FN void store8(u8 *d, u64 v) { __builtin_memcpy(d, &v, 8); }
+COVW_FN void store4(u8 *d, u32 v) { __builtin_memcpy(d, &v, 4); }
 COVW_FN void store_bytes(u8 *d, u64 v, u32 n) {        // exactly n <= 8 bytes of v
-    if (n == 8u) { __builtin_memcpy(d, &v, 8); return; }
-    if (n & 4u) { const u32 x = (u32)v; __builtin_memcpy(d, &x, 4); d += 4; v >>= 32; }
+    if (n == 8u) { store8(d, v); return; }
+    if (n & 4u) { store4(d, (u32)v); d += 4; v >>= 32; }
     if (n & 2u) { const u16 x = (u16)v; __builtin_memcpy(d, &x, 2); d += 2; v >>= 16; }
     if (n & 1u) *d = (u8)v;
 }
+// n <= 8 bytes of v (zero above them); up to `room` bytes behind them may be overwritten
+COVW_FN void store_padded(u8 *d, u64 v, u32 n, u32 room) {
+    if (n > 4u) { if (n + room >= 8u) store8(d, v); else store_bytes(d, v, n); }
+    else { if (n + room >= 4u) store4(d, (u32)v); else store_bytes(d, v, n); }
+}
 
-// Decodes one lane's units from `from` up to the end of its share.  MODE 0: positions only; 1: also counts output bytes and matches;
-// 2: writes them (out + opos = where the lane's first byte goes, tok + tpos = its first token position; *err receives what went wrong).
+// Decodes one lane's units from `from` until the position reaches `until`.  MODE 0: positions only, and an invalid code is skipped over
+// bit by bit (the start is a guess); 1: also counts output bytes and matches; 2: writes them (out + opos = where the lane's first
+// byte goes, tok + tpos = its first token position; *err receives what went wrong).
 // Returns the end position; *flags: bit 0 end of block met, bit 1 invalid code / ran off the payload.
 template <int MODE>
-COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 share_end, u32 *flags, u32 *nb, u32 *nt, u8 *out, u32 opos, u32 isize, u16 *tok, u32 tpos,
+COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, u8 *out, u32 opos, u32 isize, u16 *tok, u32 tpos,
                       u32 *err) {
     Cursor c; c.init(s, from);
-    u32 f = 0, bytes = 0, toks = 0, on = 0;
-    u64 obuf = 0;
-    while (c.pos < share_end) {
+    u32 f = 0, bytes = 0, toks = 0, on = 0, tn = 0;
+    u64 obuf = 0, tbuf = 0;        // pending literals (the `on` bytes in front of out + opos + bytes) and token positions (the last tn)
+    // (Bounds in MODE 2: pass 2 counted this lane's bytes and matches with the same decoder and inflate_block checked the block's totals
+    // against isize and TOK_CAP before pass 3, so only a match's distance is left to check here.)
+    while (c.pos < until) {
+        const u32 unit_at = c.pos;
+        u32 trace = 0;
+        (void)trace; (void)unit_at; (void)isize;
         c.refill();
-        u32 e = T.lit[c.peek(LB)];
+        u32 x = c.low32();
+        u32 e = T.lit[x & ((1u << LB) - 1u)];
         if ((e & 15u) == 0u) {
+            trace |= 1u;
             u32 idx = 0;
-            const u32 l = canonical(T.lit_limit, T.lit_off, covw_brev32(c.low32()) >> 17, idx);
-            if (l == 0) { f |= 2u; break; }
-            e = lit_entry(T.lit_sorted[idx < 288u ? idx : 287u], l);
+            const u32 l = canonical<LB>(T.lit_limit, T.lit_off, covw_brev32(x) >> 17, idx);
+            e = l ? ((u32)T.lit_sorted[idx < 288u ? idx : 287u] | l) : 0xfff0u;
         }
-        c.drop(e & 15u);
+        const u32 n = e & 15u;
         if (!(e & 0x8000u)) {
-            const u32 sym = (e >> 4) & 0x1ffu;
-            if (sym == 256u) { f |= 1u; break; }
-            if (c.pos > s.total_bits) { f |= 2u; break; }
+            COVW_TRACE_UNIT(MODE, trace);
+            c.drop(n);
+            if (e == ((256u << 4) | n)) {
+                if (MODE == 0) continue;           // (a guessed start may see an end-of-block that is none; a true one ends what anybody uses of this lane)
+                f |= 1u; break;
+            }
             if (MODE == 2) {
-                if (opos + bytes >= isize) { *err = ERR_SIZE; break; }
-                obuf |= (u64)sym << (8u * on);
-                if (++on == 8u) { store_bytes(out + opos + bytes - 7u, obuf, 8); obuf = 0; on = 0; }
+                obuf |= (u64)(e >> 4) << (8u * on);
+                if (++on == 8u) { store8(out + opos + bytes - 7u, obuf); obuf = 0; on = 0; }
             }
             bytes++;
             continue;
         }
-        if ((e & 0xfff0u) == 0xfff0u) { f |= 2u; break; }
         const u32 le = (e >> 12) & 7u;
-        const u32 len = 3u + ((e >> 4) & 0xffu) + c.peek(le);
-        c.drop(le);
+        const u32 len = 3u + ((e >> 4) & 0xffu) + bits_at(x, n, le);      // n + le <= 22 of the >= 33 bits
+        c.drop(n + le);
         c.refill();
-        u32 ed = T.dist[c.peek(DB)];
+        x = c.low32();
+        u32 ed = T.dist[x & ((1u << DB) - 1u)];
+        trace |= 2u;
         if ((ed & 15u) == 0u) {
+            trace |= 4u;
             u32 idx = 0;
-            const u32 l = canonical(T.dist_limit, T.dist_off, covw_brev32(c.low32()) >> 17, idx);
-            if (l == 0) { f |= 2u; break; }
-            ed = ((u32)T.dist_sorted[idx & 31u] << 4) | l;
+            const u32 l = canonical<DB>(T.dist_limit, T.dist_off, covw_brev32(x) >> 17, idx);
+            ed = l ? (dist_entry(T.dist_sorted[idx & 31u]) | l) : DIST_INVALID;
         }
-        const u32 ds = ed >> 4;
-        if (ds >= 30u) { f |= 2u; break; }
-        c.drop(ed & 15u);
-        const u32 de = ds < 4u ? 0u : (ds - 2u) >> 1;                  // distance codes come in pairs sharing e extra bits
-        const u32 dist = (ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << de)) + c.peek(de);    // (>= 33 bits after the refill: code + extra <= 28)
-        c.drop(de);
-        if (c.pos > s.total_bits) { f |= 2u; break; }
+        COVW_TRACE_UNIT(MODE, trace);
+        const u32 dl = ed & 15u, de = (ed >> 4) & 15u;
+        const u32 dist = ((ed >> 8) & 0x7fffu) + bits_at(x, dl, de);      // dl + de <= 28
+        c.drop(dl + de);
+        if ((e & 0xfff0u) == 0xfff0u || (ed & DIST_INVALID) != 0u) {      // no code of the set / symbols 286, 287, 30, 31
+            if (MODE == 0 && unit_at + 1u < until) { c.init(s, unit_at + 1u); continue; }
+            f |= 2u; break;
+        }
         if (MODE == 2) {
             const u32 p = opos + bytes;
-            if (on) { store_bytes(out + p - on, obuf, on); obuf = 0; on = 0; }
-            if (dist > p || p + len > isize || tpos + toks >= TOK_CAP) { *err = ERR_FORMAT; break; }
-            const u32 t24 = (dist - 1u) | ((len - 3u) << 15);          // k_lz_resolve's token: in the first three bytes of the match's own destination
-            store_bytes(out + p, t24, len > 3u ? 4u : 3u);
-            tok[tpos + toks] = (u16)p;
+            if (dist > p) { *err = ERR_FORMAT; break; }
+            // k_lz_resolve's token sits in the first three bytes of the match's own destination; the match's other len - 3 bytes are
+            // written by k_lz_resolve later, so a store may run over them
+            const u32 t24 = (dist - 1u) | ((len - 3u) << 15), room = len - 3u;
+            u8 *d = out + p - on;
+            const u64 v = obuf | ((u64)t24 << (8u * on));                // on <= 7: at least one token byte fits
+            if (on <= 5u) store_padded(d, v, on + 3u, room);
+            else { store8(d, v); store_padded(d + 8, t24 >> (8u * (8u - on)), on - 5u, room); }
+            obuf = 0; on = 0;
+            tbuf |= (u64)p << (16u * tn);
+            if (++tn == 4u) { store8(reinterpret_cast<u8 *>(tok + tpos + toks - 3u), tbuf); tbuf = 0; tn = 0; }
         }
         bytes += len; toks++;
     }
-    if (MODE == 2 && on) store_bytes(out + opos + bytes - on, obuf, on);
+    if (MODE != 0 && c.pos > s.total_bits) f |= 2u;      // only a lane's last unit can run off the payload: `until` lies inside it
+    if (MODE == 2) {
+        if (on) store_bytes(out + opos + bytes - on, obuf, on);
+        if (tn) store_bytes(reinterpret_cast<u8 *>(tok + tpos + toks - tn), tbuf, 2u * tn);
+    }
     *flags = f; *nb = bytes; *nt = toks;
     return c.pos;
 }
 
-COVW_FN u32 share_end_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
-    const u64 e = (u64)B0 + (u64)(lane + 1u) * S;
-    return e < total_bits ? (u32)e : total_bits;
+COVW_FN u32 share_begin_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
+    const u64 b = (u64)B0 + (u64)lane * S;
+    return b < total_bits ? (u32)b : total_bits;
 }
 
 // One BGZF block.  comp_words: aligned words holding the raw DEFLATE payload from bit `bit0` on; out: the block's `isize` output
@@ -313,6 +370,19 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
             COVW_SYNC();
             continue;
         }
+        if (W.hdr[0] == 2u) {                       // dynamic codes: the code-length code's lookup table, then the code lengths
+            COVW_PARFOR(lane) {
+                for (u32 i = lane; i < 128u; i += 64u) {
+                    u32 idx = 0;
+                    const u32 l = canonical<0>(W.climit, W.coff, covw_brev32(i) >> 17, idx);
+                    W.cltab[i] = (u8)((l == 0u || l > 7u) ? 0u : (((u32)W.csorted[idx & 31u] << 3) | l));
+                }
+            }
+            COVW_SYNC();
+            COVW_PARFOR(lane) { if (lane == 0u) parse_code_lengths(W, s); }
+            COVW_SYNC();
+            if (W.hdr[6] != OK) { err = W.hdr[6]; break; }
+        }
         COVW_PARFOR(lane) {
             if (lane == 0u) {
                 Tables &T = W.T;
@@ -323,6 +393,8 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
         }
         COVW_SYNC();
         if (W.hdr[6] != OK) { err = W.hdr[6]; break; }
+        COVW_PARFOR(lane) { for (u32 i = lane; i < 288u; i += 64u) W.T.lit_sorted[i] = (u16)lit_entry(W.T.lit_sorted[i]); }      // symbols -> entries
+        COVW_SYNC();
         COVW_PARFOR(lane) {
             for (u32 i = lane; i < (1u << LB); i += 64u) fill_lit_index(W.T, i);
             for (u32 i = lane; i < (1u << DB); i += 64u) fill_dist_index(W.T, i);
@@ -331,36 +403,35 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
         if (stop_after == 1u) { err = ERR_FORMAT; break; }
         const u32 B0 = W.hdr[4];
         const u32 span = s.total_bits > B0 ? s.total_bits - B0 : 0u;
-        // a share shorter than the distance over which a decoder falls in step (p99: 50 units, ~480 bits) makes pass 1 guess wrong and
-        // pass 2 repeat: small blocks use fewer lanes
         const u32 S = span > 64u * MIN_SHARE_BITS ? (span + 63u) / 64u : MIN_SHARE_BITS;
-        // ---- pass 1: from the guessed offsets
+        // ---- pass 1: where lane i's units begin = end[i - 1]
         COVW_PARFOR(lane) {
             u32 f, nb, nt;
-            const u64 g = (u64)B0 + (u64)lane * S;
-            W.end[lane] = g >= s.total_bits ? s.total_bits
-                                            : run_share<0>(W.T, s, (u32)g, share_end_of(B0, S, lane, s.total_bits), &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr);
+            const u32 g = share_begin_of(B0, S, lane, s.total_bits);
+            if (lane) W.end[lane - 1u] = g >= s.total_bits ? s.total_bits
+                                                           : run_share<0>(W.T, s, g - B0 > OVERLAP_BITS ? g - OVERLAP_BITS : B0, g, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr);
+            if (lane == 63u) W.end[63] = s.total_bits;
         }
         COVW_SYNC();
         if (stop_after == 2u) { err = ERR_FORMAT; break; }
-        // ---- pass 2: from the left neighbour's end, until no end moves (lane k is exact after round k)
+        // ---- pass 2: from the left neighbour's end, until no end moves
         for (u32 round = 0;; round++) {
             COVW_PARFOR(lane) {
                 if (lane == 0u) W.rounds = round + 1u;
                 const u32 from = lane ? W.end[lane - 1u] : B0;
-                const u32 ge = share_end_of(B0, S, lane, s.total_bits);
+                const u32 ge = share_begin_of(B0, S, lane + 1u, s.total_bits);
                 u32 f = 0, nb = 0, nt = 0, e = from;
                 if (from < ge) e = run_share<1>(W.T, s, from, ge, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr);
                 W.flags[lane] = f; W.nbytes[lane] = nb; W.ntok[lane] = nt; W.tmp[lane] = e;
             }
             COVW_SYNC();          // every lane has read its neighbour's old end
-            // Lanes 0 .. F (F = the first lane that stopped at end-of-block or an invalid code) decide: when none of their ends moved, they are
-            // a fixed point of the chain that starts at the exact B0, i.e. exact.  What the lanes behind F decode belongs to the next DEFLATE
-            // block (other tables): it never settles and nobody uses it.
+            // The lanes in front of F (F = the first lane that stopped at end-of-block or an invalid code) decide: when none of their ends
+            // moved, they are a fixed point of the chain that starts at the exact B0, i.e. exact — and with them lane F's start.  What
+            // the lanes behind F decode belongs to the next DEFLATE block (other tables): it never settles and nobody uses it.
             COVW_PARFOR(lane) {
                 if (lane == 0u) {
                     u32 ch = 0;
-                    for (u32 i = 0; i < 64u; i++) { ch |= W.tmp[i] != W.end[i] ? 1u : 0u; if (W.flags[i]) break; }
+                    for (u32 i = 0; i < 63u && !W.flags[i]; i++) ch |= W.tmp[i] != W.end[i] ? 1u : 0u;
                     W.changed = ch;
                 }
             }
@@ -393,7 +464,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
         COVW_PARFOR(lane) {
             if (lane < W.n_valid) {
                 const u32 from = lane ? W.end[lane - 1u] : B0;
-                const u32 ge = share_end_of(B0, S, lane, s.total_bits);
+                const u32 ge = share_begin_of(B0, S, lane + 1u, s.total_bits);
                 u32 f, nb, nt, e2 = OK;
                 if (from < ge) (void)run_share<2>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], isize, tok, ntok + W.tbase[lane], &e2);
                 if (e2 != OK) W.hdr[6] = e2;

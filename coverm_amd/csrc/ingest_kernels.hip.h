@@ -712,9 +712,12 @@ __global__ __launch_bounds__(64) void k_inflate2(const uint8_t *__restrict__ com
 #include "inflate_wave_core.h"
 namespace covi {
 static_assert(covw::TOK_CAP == INF_TOK_CAP && covw::OK == INF_OK && covw::ERR_FORMAT == INF_ERR_FORMAT && covw::ERR_SIZE == INF_ERR_SIZE, "the core mirrors k_inflate's contract");
-__global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
-                                                     uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
-                                                     u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
+// WPE: waves per SIMD the register allocation is held to (5: 96 VGPRs, 6: 80, 7: 72 — a handful of spilled dwords each; 0: what the
+// compiler takes, 98 = four waves).  Which one is fastest is a measurement (COVERM_INFLATE_WAVE_WPE).
+template <int WPE>
+__device__ __forceinline__ void inflate_wave_body(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks, uint8_t *__restrict__ out,
+                                                  tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed,
+                                                  u32 stop_after) {
     __shared__ covw::Wave W;
     const u32 b = blockIdx.x;
     if (b >= n_blocks) return;
@@ -730,6 +733,17 @@ __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__
         if (st != INF_OK) atomicAdd(n_failed, 1u);
     }
 }
+#define COV_INFLATE_WAVE_KERNEL(NAME, ATTR)                                                                                                              \
+    __global__ __launch_bounds__(64) ATTR void NAME(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,             \
+                                                    uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,                      \
+                                                    u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {                              \
+        inflate_wave_body<0>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);                                                     \
+    }
+COV_INFLATE_WAVE_KERNEL(k_inflate_wave, )
+COV_INFLATE_WAVE_KERNEL(k_inflate_wave5, __attribute__((amdgpu_waves_per_eu(5, 5))))
+COV_INFLATE_WAVE_KERNEL(k_inflate_wave6, __attribute__((amdgpu_waves_per_eu(6, 6))))
+COV_INFLATE_WAVE_KERNEL(k_inflate_wave7, __attribute__((amdgpu_waves_per_eu(7, 7))))
+#undef COV_INFLATE_WAVE_KERNEL
 
 // Inclusive wave64 prefix sum (DPP row shifts + row broadcasts; VALU latency only).
 __device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {

@@ -1,0 +1,100 @@
+// AddressSanitizer + UBSan run of csrc/inflate_wave_core.h over valid and damaged DEFLATE streams: the buffers are exactly as large as the
+// kernel's contract says (payload + 16 readable bytes, isize output bytes, TOK_CAP token positions), so any access outside them aborts.
+//   g++ -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -o fuzz tests/c/inflate_wave_fuzz.cpp -lz && ./fuzz [rounds] [seed]
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <vector>
+
+#define COVW_FN inline
+#define COVW_PARFOR(lane) for (unsigned lane = 0; lane < 64u; lane++)
+#define COVW_SYNC() do { } while (0)
+static inline unsigned covw_brev32(unsigned x) {
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+    return __builtin_bswap32(x);
+}
+#include "../../coverm_amd/csrc/inflate_wave_core.h"
+
+static uint64_t rng_state = 88172645463325252ull;
+static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
+
+static std::vector<uint8_t> deflate_raw(const std::vector<uint8_t> &in, int level, int strategy) {
+    z_stream z; memset(&z, 0, sizeof z);
+    deflateInit2(&z, level, Z_DEFLATED, -15, 8, strategy);
+    std::vector<uint8_t> out(in.size() * 2 + 4096);      // (deflateBound does not cover Z_FIXED on incompressible input)
+    z.next_in = const_cast<uint8_t *>(in.data()); z.avail_in = (uInt)in.size();
+    z.next_out = out.data(); z.avail_out = (uInt)out.size();
+    if (deflate(&z, Z_FINISH) != Z_STREAM_END) { fprintf(stderr, "deflate did not finish\n"); exit(2); }
+    out.resize(z.total_out);
+    deflateEnd(&z);
+    return out;
+}
+
+// -> status; `want` non-null: the resolved bytes must equal it when the status is OK
+static int run(const std::vector<uint8_t> &payload, uint32_t misalign, uint32_t isize, const std::vector<uint8_t> *want) {
+    const size_t nbytes = misalign + payload.size() + 16;                    // the contract: 16 readable bytes behind the payload
+    uint32_t *words = static_cast<uint32_t *>(malloc((nbytes + 3) / 4 * 4));
+    for (size_t k = 0; k < (nbytes + 3) / 4; k++) words[k] = rnd();
+    memcpy(reinterpret_cast<uint8_t *>(words) + misalign, payload.data(), payload.size());
+    uint8_t *out = static_cast<uint8_t *>(malloc(isize ? isize : 1));
+    uint16_t *tok = static_cast<uint16_t *>(malloc(covw::TOK_CAP * 2));
+    static covw::Wave W;
+    uint32_t nt = 0, st = 0;
+    covw::inflate_block(W, words, 8u * misalign, 8u * (uint32_t)payload.size(), out, isize, tok, &nt, &st);
+    int rc = (int)st;
+    if (st == covw::OK) {
+        for (uint32_t t = 0; t < nt; t++) {                                  // k_lz_resolve, serially
+            const uint32_t p = tok[t];
+            if (p + 3 > isize) { rc = -2; break; }
+            const uint32_t t24 = (uint32_t)out[p] | ((uint32_t)out[p + 1] << 8) | ((uint32_t)out[p + 2] << 16);
+            const uint32_t dist = (t24 & 0x7fffu) + 1u, len = (t24 >> 15) + 3u;
+            if (dist > p || p + len > isize) { rc = -2; break; }
+            for (uint32_t k = 0; k < len; k++) out[p + k] = out[p + k - dist];
+        }
+        if (rc == 0 && want && (want->size() != isize || memcmp(want->data(), out, isize) != 0)) rc = -3;
+    }
+    free(words); free(out); free(tok);
+    return rc;
+}
+
+int main(int argc, char **argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 200;
+    if (argc > 2) rng_state ^= strtoull(argv[2], nullptr, 10) * 0x9e3779b97f4a7c15ull;
+    long ok = 0, rejected = 0, differ = 0;
+    for (int r = 0; r < rounds; r++) {
+        const uint32_t size = 1 + rnd() % 65280u;
+        std::vector<uint8_t> data(size);
+        const uint32_t kind = rnd() % 4u;
+        for (uint32_t k = 0; k < size; k++)
+            data[k] = kind == 0 ? (uint8_t)rnd() : kind == 1 ? (uint8_t)("ACGTN!#I"[rnd() & 7u]) : kind == 2 ? (uint8_t)(rnd() % 3u ? 0 : rnd()) : (uint8_t)(k * 7u >> (rnd() & 3u));
+        const int level = (int)(rnd() % 10u), strategy = (rnd() & 7u) == 0 ? Z_FIXED : (rnd() & 7u) == 1 ? Z_HUFFMAN_ONLY : (rnd() & 7u) == 2 ? Z_RLE : Z_DEFAULT_STRATEGY;
+        const std::vector<uint8_t> comp = deflate_raw(data, level, strategy);
+        const int a = run(comp, rnd() & 3u, size, &data);
+        if (a != 0) {
+            fprintf(stderr, "round %d: valid stream (size %u level %d strategy %d) -> %d\n", r, size, level, strategy, a);
+            if (FILE *f = fopen("/tmp/covw_fuzz_fail.bin", "wb")) { fwrite(comp.data(), 1, comp.size(), f); fclose(f); }
+            return 1;
+        }
+        ok++;
+        for (int m = 0; m < 6; m++) {                                        // damaged copies: any status is fine, any bad access aborts
+            std::vector<uint8_t> bad = comp;
+            const uint32_t how = rnd() % 5u;
+            if (how == 0) bad[rnd() % bad.size()] ^= (uint8_t)(1u << (rnd() & 7u));
+            else if (how == 1) bad.resize(rnd() % bad.size());
+            else if (how == 2) for (int k = 0; k < 8; k++) bad[rnd() % bad.size()] = (uint8_t)rnd();
+            else if (how == 3) { const size_t at = rnd() % bad.size(); for (size_t k = at; k < bad.size(); k++) bad[k] = (uint8_t)rnd(); }
+            else bad[0] = (uint8_t)rnd();
+            const uint32_t isz = (rnd() & 3u) ? size : (rnd() % 65536u);
+            const int b = run(bad, rnd() & 3u, isz, nullptr);
+            if (b == -2) { fprintf(stderr, "round %d: status OK with a token outside the block\n", r); return 1; }
+            if (b != 0) rejected++; else differ++;
+        }
+    }
+    printf("%ld valid streams exact, %ld damaged rejected, %ld damaged decoded to something (the CRC pass judges those)\n", ok, rejected, differ);
+    return 0;
+}
