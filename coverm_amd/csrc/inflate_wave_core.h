@@ -14,8 +14,8 @@
 //           tables and is discarded;
 //   pass 3  output offsets = prefix sums of the counts; every lane decodes its units once more and writes: literals at their final
 //           positions, a match as a 3-byte token in place + its 16-bit position in the block's token list (k_lz_resolve's contract,
-//           unchanged).  No store touches a byte that another lane owns: pending literals and the token behind them leave as ONE store
-//           where the padding falls into the match's own bytes (which k_lz_resolve writes later), as exact 4/2/1-byte stores otherwise.
+//           unchanged).  No store touches a byte that another lane owns; within its own bytes a lane writes front to back and may run over
+//           what it (or k_lz_resolve) writes later: pending literals and the token behind them leave as one 8-byte store.
 // Header parsing and the per-length tables are serial (lane 0); the lookup tables are filled in parallel, one INDEX per lane step
 // (an index is decoded canonically like a long code), so no lane writes more entries than another.
 //
@@ -27,10 +27,14 @@
 //   COVW_PARFOR(lane)          `for`-like header: runs the following block for lane = 0 .. 63 (device: once, lane = the thread's lane)
 //   COVW_SYNC()                wave barrier + LDS fence (host: nothing)
 //   covw_brev32(x)             bit reversal of a 32-bit word
+//   COVW_NO_UNROLL             (optional) loop pragma that keeps the following loop rolled
 // Statements outside COVW_PARFOR regions are executed by all lanes with identical (wave-uniform) values.
 #pragma once
 #include <stdint.h>
 
+#ifndef COVW_NO_UNROLL
+#define COVW_NO_UNROLL
+#endif
 #ifndef COVW_TRACE_UNIT
 #define COVW_TRACE_UNIT(mode, flags) do { } while (0)      // tools/proto/wave_cost_model.cpp: lock-step cost model
 #endif
@@ -252,28 +256,26 @@ COVW_FN void store_bytes(u8 *d, u64 v, u32 n) {        // exactly n <= 8 bytes o
     if (n & 2u) { const u16 x = (u16)v; __builtin_memcpy(d, &x, 2); d += 2; v >>= 16; }
     if (n & 1u) *d = (u8)v;
 }
-// n <= 8 bytes of v (zero above them); up to `room` bytes behind them may be overwritten
-COVW_FN void store_padded(u8 *d, u64 v, u32 n, u32 room) {
-    if (n > 4u) { if (n + room >= 8u) store8(d, v); else store_bytes(d, v, n); }
-    else { if (n + room >= 4u) store4(d, (u32)v); else store_bytes(d, v, n); }
-}
-
 // Decodes one lane's units from `from` until the position reaches `until`.  MODE 0: positions only, and an invalid code is skipped over
 // bit by bit (the start is a guess); 1: also counts output bytes and matches; 2: writes them (out + opos = where the lane's first
-// byte goes, tok + tpos = its first token position; *err receives what went wrong).
+// byte goes, out + own_end = where its last byte ends, tok + tpos = its first token position; *err receives what went wrong).
+// Stores in MODE 2: a lane writes its bytes front to back, so a store may run over bytes of the lane's OWN range that come later (the
+// lane overwrites them, or they are a match's and k_lz_resolve does) — never past own_end, where the next lane's bytes begin.  Literals
+// wait in a 4-byte FIFO; a full FIFO leaves as one exact 4-byte store, a match takes the pending literals and its token along in ONE
+// 8-byte store, and only a lane's last few bytes need exact byte stores.  The paths are few on purpose: a wave pays every path that any
+// of its lanes takes, in every step.
 // Returns the end position; *flags: bit 0 end of block met, bit 1 invalid code / ran off the payload.
 template <int MODE>
-COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, u8 *out, u32 opos, u32 isize, u16 *tok, u32 tpos,
+COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, u8 *out, u32 opos, u32 own_end, u16 *tok, u32 tpos,
                       u32 *err) {
     Cursor c; c.init(s, from);
-    u32 f = 0, bytes = 0, toks = 0, on = 0, tn = 0;
-    u64 obuf = 0, tbuf = 0;        // pending literals (the `on` bytes in front of out + opos + bytes) and token positions (the last tn)
+    u32 f = 0, bytes = 0, toks = 0, osh = 0, obuf = 0;       // obuf: the osh / 8 pending literals in front of out + opos + bytes
     // (Bounds in MODE 2: pass 2 counted this lane's bytes and matches with the same decoder and inflate_block checked the block's totals
     // against isize and TOK_CAP before pass 3, so only a match's distance is left to check here.)
     while (c.pos < until) {
         const u32 unit_at = c.pos;
         u32 trace = 0;
-        (void)trace; (void)unit_at; (void)isize;
+        (void)trace; (void)unit_at; (void)own_end;
         c.refill();
         u32 x = c.low32();
         u32 e = T.lit[x & ((1u << LB) - 1u)];
@@ -292,8 +294,9 @@ COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *f
                 f |= 1u; break;
             }
             if (MODE == 2) {
-                obuf |= (u64)(e >> 4) << (8u * on);
-                if (++on == 8u) { store8(out + opos + bytes - 7u, obuf); obuf = 0; on = 0; }
+                obuf |= (e >> 4) << osh;
+                osh += 8u;
+                if (osh == 32u) { store4(out + opos + bytes - 3u, obuf); obuf = 0; osh = 0; }
             }
             bytes++;
             continue;
@@ -320,26 +323,19 @@ COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *f
             f |= 2u; break;
         }
         if (MODE == 2) {
-            const u32 p = opos + bytes;
+            const u32 p = opos + bytes, on = osh >> 3;
             if (dist > p) { *err = ERR_FORMAT; break; }
-            // k_lz_resolve's token sits in the first three bytes of the match's own destination; the match's other len - 3 bytes are
-            // written by k_lz_resolve later, so a store may run over them
-            const u32 t24 = (dist - 1u) | ((len - 3u) << 15), room = len - 3u;
+            // k_lz_resolve's token sits in the first three bytes of the match's own destination
+            const u64 v = (u64)obuf | ((u64)((dist - 1u) | ((len - 3u) << 15)) << osh);      // <= 3 literals + 3 token bytes
             u8 *d = out + p - on;
-            const u64 v = obuf | ((u64)t24 << (8u * on));                // on <= 7: at least one token byte fits
-            if (on <= 5u) store_padded(d, v, on + 3u, room);
-            else { store8(d, v); store_padded(d + 8, t24 >> (8u * (8u - on)), on - 5u, room); }
-            obuf = 0; on = 0;
-            tbuf |= (u64)p << (16u * tn);
-            if (++tn == 4u) { store8(reinterpret_cast<u8 *>(tok + tpos + toks - 3u), tbuf); tbuf = 0; tn = 0; }
+            if (p - on + 8u <= own_end) store8(d, v); else store_bytes(d, v, on + 3u);
+            obuf = 0; osh = 0;
+            tok[tpos + toks] = (u16)p;
         }
         bytes += len; toks++;
     }
     if (MODE != 0 && c.pos > s.total_bits) f |= 2u;      // only a lane's last unit can run off the payload: `until` lies inside it
-    if (MODE == 2) {
-        if (on) store_bytes(out + opos + bytes - on, obuf, on);
-        if (tn) store_bytes(reinterpret_cast<u8 *>(tok + tpos + toks - tn), tbuf, 2u * tn);
-    }
+    if (MODE == 2 && osh) store_bytes(out + opos + bytes - (osh >> 3), obuf, osh >> 3);
     *flags = f; *nb = bytes; *nt = toks;
     return c.pos;
 }
@@ -365,7 +361,10 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
             const u32 len = W.hdr[5], src_bit = W.hdr[4];
             if (opos + len > isize) { err = ERR_FORMAT; break; }
             const u8 *src = reinterpret_cast<const u8 *>(s.w) + (src_bit >> 3);
-            COVW_PARFOR(lane) { for (u32 k = lane; k < len; k += 64u) out[opos + k] = src[k]; }
+            COVW_PARFOR(lane) {
+                COVW_NO_UNROLL                 // (unrolled eight times this loop's address registers were the kernel's register peak)
+                for (u32 k = lane; k < len; k += 64u) out[opos + k] = src[k];
+            }
             opos += len; pos = src_bit + 8u * len;
             COVW_SYNC();
             continue;
@@ -466,7 +465,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                 const u32 from = lane ? W.end[lane - 1u] : B0;
                 const u32 ge = share_begin_of(B0, S, lane + 1u, s.total_bits);
                 u32 f, nb, nt, e2 = OK;
-                if (from < ge) (void)run_share<2>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], isize, tok, ntok + W.tbase[lane], &e2);
+                if (from < ge) (void)run_share<2>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], opos + W.obase[lane] + W.nbytes[lane], tok, ntok + W.tbase[lane], &e2);
                 if (e2 != OK) W.hdr[6] = e2;
             }
         }

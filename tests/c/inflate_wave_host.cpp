@@ -7,7 +7,11 @@
 #include <vector>
 
 #define COVW_FN inline
+#ifdef COVW_REVERSE      // the lanes of a region run concurrently on the device: no result may depend on their order here
+#define COVW_PARFOR(lane) for (unsigned lane##_r = 0, lane = 63u; lane##_r < 64u; lane##_r++, lane = 63u - lane##_r)
+#else
 #define COVW_PARFOR(lane) for (unsigned lane = 0; lane < 64u; lane++)
+#endif
 #define COVW_SYNC() do { } while (0)
 static inline unsigned covw_brev32(unsigned x) {
     x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
