@@ -256,26 +256,124 @@ COVW_FN void store_bytes(u8 *d, u64 v, u32 n) {        // exactly n <= 8 bytes o
     if (n & 2u) { const u16 x = (u16)v; __builtin_memcpy(d, &x, 2); d += 2; v >>= 16; }
     if (n & 1u) *d = (u8)v;
 }
+// ---- pass 3's output of one lane, in four versions (COVW_STORES; the kernel is bound by its scattered stores, and which shape of store the
+// memory path likes is a measurement: profiles/r03_wave_variants*.log).  A lane writes its bytes front to back, bytes [lo, own_end) of the
+// block; it may run over bytes of its OWN range that come later (it overwrites them, or they are a match's and k_lz_resolve does), never
+// past own_end, where the next lane's bytes begin.  literal(p, b): byte b belongs at p; match(p, len, t24, k): a match of len bytes begins
+// at p, its token t24 goes into its first three bytes and p into token slot k; finish(p): p = own_end, everything pending leaves.
+template <int ST> struct Sink;
+
+// 1: exact stores only.  Literals wait in an 8-byte FIFO; a match flushes them (4 + 2 + 1 bytes), then its token (4 bytes when the match is
+// longer than three, 2 + 1 otherwise), then its position.
+template <> struct Sink<1> {
+    u8 *out; u16 *tok; u64 obuf; u32 on;
+    COVW_FN void init(u8 *o, u16 *t, u32, u32) { out = o; tok = t; obuf = 0; on = 0; }
+    COVW_FN void literal(u32 p, u32 b) {
+        obuf |= (u64)b << (8u * on);
+        if (++on == 8u) { store8(out + p - 7u, obuf); obuf = 0; on = 0; }
+    }
+    COVW_FN void match(u32 p, u32 len, u32 t24, u32 k) {
+        if (on) { store_bytes(out + p - on, obuf, on); obuf = 0; on = 0; }
+        store_bytes(out + p, t24, len > 3u ? 4u : 3u);
+        tok[k] = (u16)p;
+    }
+    COVW_FN void finish(u32 p) { if (on) store_bytes(out + p - on, obuf, on); }
+};
+
+// 2: the pending literals and the token leave together, as one 4- or 8-byte store when the padding falls into the match's own bytes;
+// token positions leave four at a time.
+template <> struct Sink<2> {
+    u8 *out; u16 *tok; u64 obuf, tbuf; u32 on, tn, last_k;
+    COVW_FN void init(u8 *o, u16 *t, u32, u32) { out = o; tok = t; obuf = 0; tbuf = 0; on = 0; tn = 0; last_k = 0; }
+    COVW_FN void literal(u32 p, u32 b) {
+        obuf |= (u64)b << (8u * on);
+        if (++on == 8u) { store8(out + p - 7u, obuf); obuf = 0; on = 0; }
+    }
+    // n <= 8 bytes of v (zero above them); up to `room` bytes behind them may be overwritten
+    COVW_FN void store_padded(u8 *d, u64 v, u32 n, u32 room) {
+        if (n > 4u) { if (n + room >= 8u) store8(d, v); else store_bytes(d, v, n); }
+        else { if (n + room >= 4u) store4(d, (u32)v); else store_bytes(d, v, n); }
+    }
+    COVW_FN void match(u32 p, u32 len, u32 t24, u32 k) {
+        const u32 room = len - 3u;
+        u8 *d = out + p - on;
+        const u64 v = obuf | ((u64)t24 << (8u * on));                 // on <= 7: at least one token byte fits
+        if (on <= 5u) store_padded(d, v, on + 3u, room);
+        else { store8(d, v); store_padded(d + 8, t24 >> (8u * (8u - on)), on - 5u, room); }
+        obuf = 0; on = 0;
+        tbuf |= (u64)p << (16u * tn);
+        if (++tn == 4u) { store8(reinterpret_cast<u8 *>(tok + k - 3u), tbuf); tbuf = 0; tn = 0; }
+        last_k = k;
+    }
+    COVW_FN void finish(u32 p) {
+        if (on) store_bytes(out + p - on, obuf, on);
+        if (tn) store_bytes(reinterpret_cast<u8 *>(tok + last_k + 1u - tn), tbuf, 2u * tn);
+    }
+};
+
+// 3: three paths.  Literals wait in a 4-byte FIFO that leaves as one exact store when full; a match takes the pending literals and its
+// token along in one 8-byte store while that stays inside the lane's range.
+template <> struct Sink<3> {
+    u8 *out; u16 *tok; u32 own_end, obuf, osh;
+    COVW_FN void init(u8 *o, u16 *t, u32, u32 end) { out = o; tok = t; own_end = end; obuf = 0; osh = 0; }
+    COVW_FN void literal(u32 p, u32 b) {
+        obuf |= b << osh;
+        osh += 8u;
+        if (osh == 32u) { store4(out + p - 3u, obuf); obuf = 0; osh = 0; }
+    }
+    COVW_FN void match(u32 p, u32, u32 t24, u32 k) {
+        const u32 on = osh >> 3;
+        const u64 v = (u64)obuf | ((u64)t24 << osh);                   // <= 3 literals + 3 token bytes
+        if (p - on + 8u <= own_end) store8(out + p - on, v); else store_bytes(out + p - on, v, on + 3u);
+        obuf = 0; osh = 0;
+        tok[k] = (u16)p;
+    }
+    COVW_FN void finish(u32 p) { if (osh) store_bytes(out + p - (osh >> 3), obuf, osh >> 3); }
+};
+
+// 4: aligned words only.  The bytes collect in a FIFO that begins at a 4-byte boundary of the output and leave as aligned 4-byte stores;
+// behind a match's token the FIFO jumps to the word the match ends in (what it skips are the match's own bytes).  Byte stores only in the
+// lane's first and last word, which it may share with its neighbours.
+template <> struct Sink<4> {
+    u8 *out; u16 *tok; u64 acc; u32 lo, own_end, ab, nb;       // acc: bytes [ab, ab + nb) of the block, ab a multiple of four
+    COVW_FN void init(u8 *o, u16 *t, u32 first, u32 end) { out = o; tok = t; lo = first; own_end = end; ab = first & ~3u; nb = first & 3u; acc = 0; }
+    COVW_FN void word() {                                       // the low word of acc leaves
+        if (ab >= lo && ab + 4u <= own_end) store4(out + ab, (u32)acc);
+        else for (u32 k = 0; k < 4u; k++) if (ab + k >= lo && ab + k < own_end) out[ab + k] = (u8)(acc >> (8u * k));
+    }
+    COVW_FN void shift() { if (nb >= 4u) { word(); acc >>= 32; ab += 4u; nb -= 4u; } }
+    COVW_FN void literal(u32, u32 b) { acc |= (u64)b << (8u * nb); nb++; shift(); }
+    COVW_FN void match(u32 p, u32 len, u32 t24, u32 k) {
+        acc |= (u64)t24 << (8u * nb); nb += 3u; shift();           // nb <= 6 before, <= 2 after
+        const u32 q = p + len;
+        if ((q >> 2) != (ab >> 2)) { if (nb) word(); ab = q & ~3u; nb = q & 3u; acc = 0; }
+        else nb = q - ab;
+        tok[k] = (u16)p;
+    }
+    COVW_FN void finish(u32) { if (nb) word(); }
+};
+
+#ifndef COVW_STORES
+#define COVW_STORES 2      // the fastest measured so far (profiles/r03_wave_variants2.log)
+#endif
+
 // Decodes one lane's units from `from` until the position reaches `until`.  MODE 0: positions only, and an invalid code is skipped over
-// bit by bit (the start is a guess); 1: also counts output bytes and matches; 2: writes them (out + opos = where the lane's first
-// byte goes, out + own_end = where its last byte ends, tok + tpos = its first token position; *err receives what went wrong).
-// Stores in MODE 2: a lane writes its bytes front to back, so a store may run over bytes of the lane's OWN range that come later (the
-// lane overwrites them, or they are a match's and k_lz_resolve does) — never past own_end, where the next lane's bytes begin.  Literals
-// wait in a 4-byte FIFO; a full FIFO leaves as one exact 4-byte store, a match takes the pending literals and its token along in ONE
-// 8-byte store, and only a lane's last few bytes need exact byte stores.  The paths are few on purpose: a wave pays every path that any
-// of its lanes takes, in every step.
+// bit by bit (the start is a guess); 1: also counts output bytes and matches; 2: writes them through Sink<ST> (out + opos = where the
+// lane's first byte goes, out + own_end = where its last byte ends, tok + tpos = its first token position; *err receives what went wrong).
 // Returns the end position; *flags: bit 0 end of block met, bit 1 invalid code / ran off the payload.
-template <int MODE>
+template <int MODE, int ST>
 COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, u8 *out, u32 opos, u32 own_end, u16 *tok, u32 tpos,
                       u32 *err) {
     Cursor c; c.init(s, from);
-    u32 f = 0, bytes = 0, toks = 0, osh = 0, obuf = 0;       // obuf: the osh / 8 pending literals in front of out + opos + bytes
+    u32 f = 0, bytes = 0, toks = 0;
+    Sink<MODE == 2 ? ST : 1> sink;
+    if (MODE == 2) sink.init(out, tok, opos, own_end);
     // (Bounds in MODE 2: pass 2 counted this lane's bytes and matches with the same decoder and inflate_block checked the block's totals
     // against isize and TOK_CAP before pass 3, so only a match's distance is left to check here.)
     while (c.pos < until) {
         const u32 unit_at = c.pos;
         u32 trace = 0;
-        (void)trace; (void)unit_at; (void)own_end;
+        (void)trace; (void)unit_at;
         c.refill();
         u32 x = c.low32();
         u32 e = T.lit[x & ((1u << LB) - 1u)];
@@ -293,11 +391,7 @@ COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *f
                 if (MODE == 0) continue;           // (a guessed start may see an end-of-block that is none; a true one ends what anybody uses of this lane)
                 f |= 1u; break;
             }
-            if (MODE == 2) {
-                obuf |= (e >> 4) << osh;
-                osh += 8u;
-                if (osh == 32u) { store4(out + opos + bytes - 3u, obuf); obuf = 0; osh = 0; }
-            }
+            if (MODE == 2) sink.literal(opos + bytes, e >> 4);
             bytes++;
             continue;
         }
@@ -323,19 +417,14 @@ COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *f
             f |= 2u; break;
         }
         if (MODE == 2) {
-            const u32 p = opos + bytes, on = osh >> 3;
+            const u32 p = opos + bytes;
             if (dist > p) { *err = ERR_FORMAT; break; }
-            // k_lz_resolve's token sits in the first three bytes of the match's own destination
-            const u64 v = (u64)obuf | ((u64)((dist - 1u) | ((len - 3u) << 15)) << osh);      // <= 3 literals + 3 token bytes
-            u8 *d = out + p - on;
-            if (p - on + 8u <= own_end) store8(d, v); else store_bytes(d, v, on + 3u);
-            obuf = 0; osh = 0;
-            tok[tpos + toks] = (u16)p;
+            sink.match(p, len, (dist - 1u) | ((len - 3u) << 15), tpos + toks);      // k_lz_resolve's token
         }
         bytes += len; toks++;
     }
     if (MODE != 0 && c.pos > s.total_bits) f |= 2u;      // only a lane's last unit can run off the payload: `until` lies inside it
-    if (MODE == 2 && osh) store_bytes(out + opos + bytes - (osh >> 3), obuf, osh >> 3);
+    if (MODE == 2) sink.finish(opos + bytes);
     *flags = f; *nb = bytes; *nt = toks;
     return c.pos;
 }
@@ -348,6 +437,7 @@ COVW_FN u32 share_begin_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
 // One BGZF block.  comp_words: aligned words holding the raw DEFLATE payload from bit `bit0` on; out: the block's `isize` output
 // bytes; tok: its token-position list.  *status = OK / ERR_*, *n_tok = matches written (0 unless OK).
 // stop_after (measurements only, 0 in production): 1 = give up after the tables are built, 2 = after pass 1, 3 = after pass 2.
+template <int ST = COVW_STORES>
 COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0) {
     Src s; s.w = comp_words; s.total_bits = bit0 + payload_bits;
     u32 pos = bit0, opos = 0, ntok = 0, err = OK;
@@ -408,7 +498,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
             u32 f, nb, nt;
             const u32 g = share_begin_of(B0, S, lane, s.total_bits);
             if (lane) W.end[lane - 1u] = g >= s.total_bits ? s.total_bits
-                                                           : run_share<0>(W.T, s, g - B0 > OVERLAP_BITS ? g - OVERLAP_BITS : B0, g, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr);
+                                                           : run_share<0, ST>(W.T, s, g - B0 > OVERLAP_BITS ? g - OVERLAP_BITS : B0, g, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr);
             if (lane == 63u) W.end[63] = s.total_bits;
         }
         COVW_SYNC();
@@ -420,7 +510,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                 const u32 from = lane ? W.end[lane - 1u] : B0;
                 const u32 ge = share_begin_of(B0, S, lane + 1u, s.total_bits);
                 u32 f = 0, nb = 0, nt = 0, e = from;
-                if (from < ge) e = run_share<1>(W.T, s, from, ge, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr);
+                if (from < ge) e = run_share<1, ST>(W.T, s, from, ge, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr);
                 W.flags[lane] = f; W.nbytes[lane] = nb; W.ntok[lane] = nt; W.tmp[lane] = e;
             }
             COVW_SYNC();          // every lane has read its neighbour's old end
@@ -465,7 +555,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                 const u32 from = lane ? W.end[lane - 1u] : B0;
                 const u32 ge = share_begin_of(B0, S, lane + 1u, s.total_bits);
                 u32 f, nb, nt, e2 = OK;
-                if (from < ge) (void)run_share<2>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], opos + W.obase[lane] + W.nbytes[lane], tok, ntok + W.tbase[lane], &e2);
+                if (from < ge) (void)run_share<2, ST>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], opos + W.obase[lane] + W.nbytes[lane], tok, ntok + W.tbase[lane], &e2);
                 if (e2 != OK) W.hdr[6] = e2;
             }
         }

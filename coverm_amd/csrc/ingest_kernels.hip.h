@@ -709,16 +709,16 @@ __global__ __launch_bounds__(64) void k_inflate2(const uint8_t *__restrict__ com
 #define COVW_PARFOR(lane) for (unsigned lane = threadIdx.x & 63u, covw_once = 1u; covw_once; covw_once = 0u)
 #define COVW_SYNC() __syncthreads()
 #define covw_brev32(x) __brev(x)
-#define COVW_NO_UNROLL _Pragma("unroll 1")
+#define COVW_NO_UNROLL _Pragma("clang loop unroll(disable) vectorize(disable)")
 #include "inflate_wave_core.h"
 namespace covi {
 static_assert(covw::TOK_CAP == INF_TOK_CAP && covw::OK == INF_OK && covw::ERR_FORMAT == INF_ERR_FORMAT && covw::ERR_SIZE == INF_ERR_SIZE, "the core mirrors k_inflate's contract");
-// WPE: waves per SIMD the register allocation is held to (5: 96 VGPRs, 6: 80, 7: 72 — a handful of spilled dwords each; 0: what the
-// compiler takes, 98 = four waves).  Which one is fastest is a measurement (COVERM_INFLATE_WAVE_WPE).
-template <int WPE>
-__device__ __forceinline__ void inflate_wave_body(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks, uint8_t *__restrict__ out,
-                                                  tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed,
-                                                  u32 stop_after) {
+// ST: how pass 3 stores (covw::Sink<ST>; COVERM_INFLATE_WAVE_STORES) — which shape of scattered store the memory path likes is a measurement.
+// (Holding the register allocation to five waves per SIMD changed nothing, to six or seven cost 40 % in spills: profiles/r03_wave_variants2.log.)
+template <int ST>
+__global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
+                                                     uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
+                                                     u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
     __shared__ covw::Wave W;
     const u32 b = blockIdx.x;
     if (b >= n_blocks) return;
@@ -726,25 +726,14 @@ __device__ __forceinline__ void inflate_wave_body(const uint8_t *__restrict__ co
     u32 st = INF_OK, nt = 0;
     if (B.isize != 0u) {
         const u32 mis = (u32)((u64)(comp + B.in_off) & 3u);
-        covw::inflate_block(W, reinterpret_cast<const u32 *>(comp + B.in_off - mis), 8u * mis, 8u * B.in_len, out + B.out_off, B.isize,
-                            tok + (size_t)b * INF_TOK_CAP, &nt, &st, stop_after);
+        covw::inflate_block<ST>(W, reinterpret_cast<const u32 *>(comp + B.in_off - mis), 8u * mis, 8u * B.in_len, out + B.out_off, B.isize,
+                                tok + (size_t)b * INF_TOK_CAP, &nt, &st, stop_after);
     }
     if ((threadIdx.x & 63u) == 0u) {
         n_tok[b] = nt; status[b] = st;
         if (st != INF_OK) atomicAdd(n_failed, 1u);
     }
 }
-#define COV_INFLATE_WAVE_KERNEL(NAME, ATTR)                                                                                                              \
-    __global__ __launch_bounds__(64) ATTR void NAME(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,             \
-                                                    uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,                      \
-                                                    u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {                              \
-        inflate_wave_body<0>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);                                                     \
-    }
-COV_INFLATE_WAVE_KERNEL(k_inflate_wave, )
-COV_INFLATE_WAVE_KERNEL(k_inflate_wave5, __attribute__((amdgpu_waves_per_eu(5, 5))))
-COV_INFLATE_WAVE_KERNEL(k_inflate_wave6, __attribute__((amdgpu_waves_per_eu(6, 6))))
-COV_INFLATE_WAVE_KERNEL(k_inflate_wave7, __attribute__((amdgpu_waves_per_eu(7, 7))))
-#undef COV_INFLATE_WAVE_KERNEL
 
 // Inclusive wave64 prefix sum (DPP row shifts + row broadcasts; VALU latency only).
 __device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {

@@ -36,7 +36,7 @@ static std::vector<uint8_t> deflate_raw(const std::vector<uint8_t> &in, int leve
 }
 
 // -> status; `want` non-null: the resolved bytes must equal it when the status is OK
-static int run(const std::vector<uint8_t> &payload, uint32_t misalign, uint32_t isize, const std::vector<uint8_t> *want) {
+static int run(int stores, const std::vector<uint8_t> &payload, uint32_t misalign, uint32_t isize, const std::vector<uint8_t> *want) {
     const size_t nbytes = misalign + payload.size() + 16;                    // the contract: 16 readable bytes behind the payload
     uint32_t *words = static_cast<uint32_t *>(malloc((nbytes + 3) / 4 * 4));
     for (size_t k = 0; k < (nbytes + 3) / 4; k++) words[k] = rnd();
@@ -45,7 +45,11 @@ static int run(const std::vector<uint8_t> &payload, uint32_t misalign, uint32_t 
     uint16_t *tok = static_cast<uint16_t *>(malloc(covw::TOK_CAP * 2));
     static covw::Wave W;
     uint32_t nt = 0, st = 0;
-    covw::inflate_block(W, words, 8u * misalign, 8u * (uint32_t)payload.size(), out, isize, tok, &nt, &st);
+    const uint32_t b0 = 8u * misalign, nb = 8u * (uint32_t)payload.size();
+    if (stores == 1) covw::inflate_block<1>(W, words, b0, nb, out, isize, tok, &nt, &st);
+    else if (stores == 2) covw::inflate_block<2>(W, words, b0, nb, out, isize, tok, &nt, &st);
+    else if (stores == 3) covw::inflate_block<3>(W, words, b0, nb, out, isize, tok, &nt, &st);
+    else covw::inflate_block<4>(W, words, b0, nb, out, isize, tok, &nt, &st);
     int rc = (int)st;
     if (st == covw::OK) {
         for (uint32_t t = 0; t < nt; t++) {                                  // k_lz_resolve, serially
@@ -74,7 +78,8 @@ int main(int argc, char **argv) {
             data[k] = kind == 0 ? (uint8_t)rnd() : kind == 1 ? (uint8_t)("ACGTN!#I"[rnd() & 7u]) : kind == 2 ? (uint8_t)(rnd() % 3u ? 0 : rnd()) : (uint8_t)(k * 7u >> (rnd() & 3u));
         const int level = (int)(rnd() % 10u), strategy = (rnd() & 7u) == 0 ? Z_FIXED : (rnd() & 7u) == 1 ? Z_HUFFMAN_ONLY : (rnd() & 7u) == 2 ? Z_RLE : Z_DEFAULT_STRATEGY;
         const std::vector<uint8_t> comp = deflate_raw(data, level, strategy);
-        const int a = run(comp, rnd() & 3u, size, &data);
+        const int stores = 1 + r % 4;                                        // covw::Sink<1..4> in turn
+        const int a = run(stores, comp, rnd() & 3u, size, &data);
         if (a != 0) {
             fprintf(stderr, "round %d: valid stream (size %u level %d strategy %d) -> %d\n", r, size, level, strategy, a);
             if (FILE *f = fopen("/tmp/covw_fuzz_fail.bin", "wb")) { fwrite(comp.data(), 1, comp.size(), f); fclose(f); }
@@ -90,7 +95,7 @@ int main(int argc, char **argv) {
             else if (how == 3) { const size_t at = rnd() % bad.size(); for (size_t k = at; k < bad.size(); k++) bad[k] = (uint8_t)rnd(); }
             else bad[0] = (uint8_t)rnd();
             const uint32_t isz = (rnd() & 3u) ? size : (rnd() % 65536u);
-            const int b = run(bad, rnd() & 3u, isz, nullptr);
+            const int b = run(stores, bad, rnd() & 3u, isz, nullptr);
             if (b == -2) { fprintf(stderr, "round %d: status OK with a token outside the block\n", r); return 1; }
             if (b != 0) rejected++; else differ++;
         }

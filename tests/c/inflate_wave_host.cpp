@@ -35,7 +35,7 @@ int covw_host_inflate(const uint8_t *payload, uint32_t nbytes, uint32_t misalign
     static covw::Wave W;
     uint32_t status = 0;
     W.rounds = 0;
-    covw::inflate_block(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status);
+    covw::inflate_block<COVW_STORES>(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status);
     if (rounds) *rounds = W.rounds;
     for (int k = 0; k < 8; k++) if (out[k] != 0xC3 || out[8 + isize + k] != 0xC3) return -1;
     return (int)status;
