@@ -84,6 +84,7 @@ struct Wave {                             // wave-shared state (LDS on the devic
     u16 climit[16], coff[16];             // the code-length code ...
     u8 csorted[32], cl[32];
     u8 cltab[128];                        // ... and its lookup table: (symbol << 3) | code length by the next 7 bits, 0 = no code
+    u32 ring[4 * 64];                     // Sink<5>: every lane's current 16-byte output line, word k of lane l at [k * 64 + l]
 };
 
 struct Src { const u32 *w; u32 total_bits; };     // aligned words of the payload (readable 16 bytes past its end); bit 0 = bit 0 of w[0]
@@ -256,7 +257,7 @@ COVW_FN void store_bytes(u8 *d, u64 v, u32 n) {        // exactly n <= 8 bytes o
     if (n & 2u) { const u16 x = (u16)v; __builtin_memcpy(d, &x, 2); d += 2; v >>= 16; }
     if (n & 1u) *d = (u8)v;
 }
-// ---- pass 3's output of one lane, in four versions (COVW_STORES; the kernel is bound by its scattered stores, and which shape of store the
+// ---- pass 3's output of one lane, in five versions (COVW_STORES; the kernel is bound by its scattered stores, and which shape of store the
 // memory path likes is a measurement: profiles/r03_wave_variants*.log).  A lane writes its bytes front to back, bytes [lo, own_end) of the
 // block; it may run over bytes of its OWN range that come later (it overwrites them, or they are a match's and k_lz_resolve does), never
 // past own_end, where the next lane's bytes begin.  literal(p, b): byte b belongs at p; match(p, len, t24, k): a match of len bytes begins
@@ -267,7 +268,7 @@ template <int ST> struct Sink;
 // longer than three, 2 + 1 otherwise), then its position.
 template <> struct Sink<1> {
     u8 *out; u16 *tok; u64 obuf; u32 on;
-    COVW_FN void init(u8 *o, u16 *t, u32, u32) { out = o; tok = t; obuf = 0; on = 0; }
+    COVW_FN void init(u8 *o, u16 *t, u32, u32, u32 *) { out = o; tok = t; obuf = 0; on = 0; }
     COVW_FN void literal(u32 p, u32 b) {
         obuf |= (u64)b << (8u * on);
         if (++on == 8u) { store8(out + p - 7u, obuf); obuf = 0; on = 0; }
@@ -284,7 +285,7 @@ template <> struct Sink<1> {
 // token positions leave four at a time.
 template <> struct Sink<2> {
     u8 *out; u16 *tok; u64 obuf, tbuf; u32 on, tn, last_k;
-    COVW_FN void init(u8 *o, u16 *t, u32, u32) { out = o; tok = t; obuf = 0; tbuf = 0; on = 0; tn = 0; last_k = 0; }
+    COVW_FN void init(u8 *o, u16 *t, u32, u32, u32 *) { out = o; tok = t; obuf = 0; tbuf = 0; on = 0; tn = 0; last_k = 0; }
     COVW_FN void literal(u32 p, u32 b) {
         obuf |= (u64)b << (8u * on);
         if (++on == 8u) { store8(out + p - 7u, obuf); obuf = 0; on = 0; }
@@ -315,7 +316,7 @@ template <> struct Sink<2> {
 // token along in one 8-byte store while that stays inside the lane's range.
 template <> struct Sink<3> {
     u8 *out; u16 *tok; u32 own_end, obuf, osh;
-    COVW_FN void init(u8 *o, u16 *t, u32, u32 end) { out = o; tok = t; own_end = end; obuf = 0; osh = 0; }
+    COVW_FN void init(u8 *o, u16 *t, u32, u32 end, u32 *) { out = o; tok = t; own_end = end; obuf = 0; osh = 0; }
     COVW_FN void literal(u32 p, u32 b) {
         obuf |= b << osh;
         osh += 8u;
@@ -336,7 +337,7 @@ template <> struct Sink<3> {
 // lane's first and last word, which it may share with its neighbours.
 template <> struct Sink<4> {
     u8 *out; u16 *tok; u64 acc; u32 lo, own_end, ab, nb;       // acc: bytes [ab, ab + nb) of the block, ab a multiple of four
-    COVW_FN void init(u8 *o, u16 *t, u32 first, u32 end) { out = o; tok = t; lo = first; own_end = end; ab = first & ~3u; nb = first & 3u; acc = 0; }
+    COVW_FN void init(u8 *o, u16 *t, u32 first, u32 end, u32 *) { out = o; tok = t; lo = first; own_end = end; ab = first & ~3u; nb = first & 3u; acc = 0; }
     COVW_FN void word() {                                       // the low word of acc leaves
         if (ab >= lo && ab + 4u <= own_end) store4(out + ab, (u32)acc);
         else for (u32 k = 0; k < 4u; k++) if (ab + k >= lo && ab + k < own_end) out[ab + k] = (u8)(acc >> (8u * k));
@@ -353,6 +354,46 @@ template <> struct Sink<4> {
     COVW_FN void finish(u32) { if (nb) word(); }
 };
 
+// 5: aligned 16-byte lines.  As 4, but a word goes into the lane's line buffer in LDS (four words, ring[k * 64] = word k) and the line
+// leaves as ONE aligned 16-byte store when the lane moves out of it — a quarter of the store instructions of 4, each a full aligned
+// quarter cache line.  A line is stored once; what it holds beyond the lane's valid bytes are bytes of a match (stale words of the
+// line before: k_lz_resolve overwrites them) — or bytes outside the lane's range, and then the line leaves byte by byte instead.
+template <> struct Sink<5> {
+    u8 *out; u16 *tok; u32 *ring; u64 acc; u32 lo, own_end, ab, nb;
+    COVW_FN void init(u8 *o, u16 *t, u32 first, u32 end, u32 *r) { out = o; tok = t; ring = r; lo = first; own_end = end; ab = first & ~3u; nb = first & 3u; acc = 0; }
+    COVW_FN void line(u32 L) {                                  // bytes [L, L + 16) leave
+        const u32 w0 = ring[0], w1 = ring[64], w2 = ring[128], w3 = ring[192];
+        if (L >= lo && L + 16u <= own_end) { const u32 v[4] = {w0, w1, w2, w3}; __builtin_memcpy(out + L, v, 16); }
+        else {
+            const u64 a = (u64)w0 | ((u64)w1 << 32), b = (u64)w2 | ((u64)w3 << 32);
+            for (u32 k = 0; k < 16u; k++) if (L + k >= lo && L + k < own_end) out[L + k] = (u8)((k < 8u ? a : b) >> (8u * (k & 7u)));
+        }
+    }
+    COVW_FN void put() { ring[((ab >> 2) & 3u) * 64u] = (u32)acc; }      // the low word of acc into the line
+    COVW_FN void shift() {
+        if (nb >= 4u) {
+            put();
+            if ((ab & 12u) == 12u) line(ab & ~15u);
+            acc >>= 32; ab += 4u; nb -= 4u;
+        }
+    }
+    COVW_FN void literal(u32, u32 b) { acc |= (u64)b << (8u * nb); nb++; shift(); }
+    COVW_FN void match(u32 p, u32 len, u32 t24, u32 k) {
+        acc |= (u64)t24 << (8u * nb); nb += 3u; shift();
+        const u32 q = p + len;
+        if ((q >> 2) != (ab >> 2)) {
+            if (nb) put();
+            if ((q >> 4) != (ab >> 4) && (nb || (ab & 15u))) line(ab & ~15u);
+            ab = q & ~3u; nb = q & 3u; acc = 0;
+        } else nb = q - ab;
+        tok[k] = (u16)p;
+    }
+    COVW_FN void finish(u32) {
+        if (nb) put();
+        if (nb || (ab & 15u)) line(ab & ~15u);
+    }
+};
+
 #ifndef COVW_STORES
 #define COVW_STORES 2      // the fastest measured so far (profiles/r03_wave_variants2.log)
 #endif
@@ -363,11 +404,11 @@ template <> struct Sink<4> {
 // Returns the end position; *flags: bit 0 end of block met, bit 1 invalid code / ran off the payload.
 template <int MODE, int ST>
 COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, u8 *out, u32 opos, u32 own_end, u16 *tok, u32 tpos,
-                      u32 *err) {
+                      u32 *err, u32 *ring) {
     Cursor c; c.init(s, from);
     u32 f = 0, bytes = 0, toks = 0;
     Sink<MODE == 2 ? ST : 1> sink;
-    if (MODE == 2) sink.init(out, tok, opos, own_end);
+    if (MODE == 2) sink.init(out, tok, opos, own_end, ring);
     // (Bounds in MODE 2: pass 2 counted this lane's bytes and matches with the same decoder and inflate_block checked the block's totals
     // against isize and TOK_CAP before pass 3, so only a match's distance is left to check here.)
     while (c.pos < until) {
@@ -498,7 +539,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
             u32 f, nb, nt;
             const u32 g = share_begin_of(B0, S, lane, s.total_bits);
             if (lane) W.end[lane - 1u] = g >= s.total_bits ? s.total_bits
-                                                           : run_share<0, ST>(W.T, s, g - B0 > OVERLAP_BITS ? g - OVERLAP_BITS : B0, g, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr);
+                                                           : run_share<0, ST>(W.T, s, g - B0 > OVERLAP_BITS ? g - OVERLAP_BITS : B0, g, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
             if (lane == 63u) W.end[63] = s.total_bits;
         }
         COVW_SYNC();
@@ -510,7 +551,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                 const u32 from = lane ? W.end[lane - 1u] : B0;
                 const u32 ge = share_begin_of(B0, S, lane + 1u, s.total_bits);
                 u32 f = 0, nb = 0, nt = 0, e = from;
-                if (from < ge) e = run_share<1, ST>(W.T, s, from, ge, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr);
+                if (from < ge) e = run_share<1, ST>(W.T, s, from, ge, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
                 W.flags[lane] = f; W.nbytes[lane] = nb; W.ntok[lane] = nt; W.tmp[lane] = e;
             }
             COVW_SYNC();          // every lane has read its neighbour's old end
@@ -555,7 +596,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                 const u32 from = lane ? W.end[lane - 1u] : B0;
                 const u32 ge = share_begin_of(B0, S, lane + 1u, s.total_bits);
                 u32 f, nb, nt, e2 = OK;
-                if (from < ge) (void)run_share<2, ST>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], opos + W.obase[lane] + W.nbytes[lane], tok, ntok + W.tbase[lane], &e2);
+                if (from < ge) (void)run_share<2, ST>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], opos + W.obase[lane] + W.nbytes[lane], tok, ntok + W.tbase[lane], &e2, W.ring + lane);
                 if (e2 != OK) W.hdr[6] = e2;
             }
         }

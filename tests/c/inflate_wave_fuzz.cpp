@@ -49,7 +49,8 @@ static int run(int stores, const std::vector<uint8_t> &payload, uint32_t misalig
     if (stores == 1) covw::inflate_block<1>(W, words, b0, nb, out, isize, tok, &nt, &st);
     else if (stores == 2) covw::inflate_block<2>(W, words, b0, nb, out, isize, tok, &nt, &st);
     else if (stores == 3) covw::inflate_block<3>(W, words, b0, nb, out, isize, tok, &nt, &st);
-    else covw::inflate_block<4>(W, words, b0, nb, out, isize, tok, &nt, &st);
+    else if (stores == 4) covw::inflate_block<4>(W, words, b0, nb, out, isize, tok, &nt, &st);
+    else covw::inflate_block<5>(W, words, b0, nb, out, isize, tok, &nt, &st);
     int rc = (int)st;
     if (st == covw::OK) {
         for (uint32_t t = 0; t < nt; t++) {                                  // k_lz_resolve, serially
@@ -78,7 +79,7 @@ int main(int argc, char **argv) {
             data[k] = kind == 0 ? (uint8_t)rnd() : kind == 1 ? (uint8_t)("ACGTN!#I"[rnd() & 7u]) : kind == 2 ? (uint8_t)(rnd() % 3u ? 0 : rnd()) : (uint8_t)(k * 7u >> (rnd() & 3u));
         const int level = (int)(rnd() % 10u), strategy = (rnd() & 7u) == 0 ? Z_FIXED : (rnd() & 7u) == 1 ? Z_HUFFMAN_ONLY : (rnd() & 7u) == 2 ? Z_RLE : Z_DEFAULT_STRATEGY;
         const std::vector<uint8_t> comp = deflate_raw(data, level, strategy);
-        const int stores = 1 + r % 4;                                        // covw::Sink<1..4> in turn
+        const int stores = 1 + r % 5;                                        // covw::Sink<1..5> in turn
         const int a = run(stores, comp, rnd() & 3u, size, &data);
         if (a != 0) {
             fprintf(stderr, "round %d: valid stream (size %u level %d strategy %d) -> %d\n", r, size, level, strategy, a);
