@@ -28,10 +28,15 @@
 //   COVW_SYNC()                wave barrier + LDS fence (host: nothing)
 //   covw_brev32(x)             bit reversal of a 32-bit word
 //   COVW_NO_UNROLL             (optional) loop pragma that keeps the following loop rolled
+//   COVW_ATOMIC_ADD / _OR(p, v) (optional on the host) atomic update of a wave-shared word
 // Statements outside COVW_PARFOR regions are executed by all lanes with identical (wave-uniform) values.
 #pragma once
 #include <stdint.h>
 
+#ifndef COVW_ATOMIC_ADD      // wave-shared counters and bit sets touched by several lanes of one region (host: the lanes run one after the other)
+#define COVW_ATOMIC_ADD(p, v) (*(p) += (v))
+#define COVW_ATOMIC_OR(p, v) (*(p) |= (v))
+#endif
 #ifndef COVW_NO_UNROLL
 #define COVW_NO_UNROLL
 #endif
@@ -60,15 +65,20 @@ constexpr u32 MIN_SHARE_BITS = 512, OVERLAP_BITS = 768;
 constexpr u32 DIST_INVALID = 0x80000000u;
 
 struct Tables {
-    u16 lit[1u << LB];                    // bits 0-3 code length (0: not decidable from LB bits); literal / end of block: bit 15 = 0, bits 4-12 symbol;
+    union {
+        u16 lit[1u << LB];                // bits 0-3 code length (0: not decidable from LB bits); literal / end of block: bit 15 = 0, bits 4-12 symbol;
                                           // length symbol: bit 15 = 1, bits 4-11 base - 3, bits 12-14 extra bits; 0xfff0 | length: symbols 286 / 287
+        u32 mask[16 * 9 + 16];            // while the code is built: the set of symbols of every code length (nine words per literal/length
+    };                                    // length, one per distance length) — a symbol's rank among its length = population count below it
     u32 dist[1u << DB];                   // bits 0-3 code length, bits 4-7 extra bits, bits 8-22 base; bit 31: symbols 30 / 31
     u16 lit_limit[16], dist_limit[16];    // limit[l] = (first code of length l + count[l]) << (15 - l)
     u16 lit_off[16], dist_off[16];        // (index of the first symbol of length l in sorted[]) - (first code of length l)  (mod 2^16)
-    u16 lit_sorted[288];                  // the symbols sorted by (code length, value) — as table entries without the length once the tables are built
+    u16 lit_sorted[288];                  // the symbols sorted by (code length, value), as table entries without the length
     u8 dist_sorted[32];
     u8 lens[320];                         // code lengths: [0, 288) literal/length, [288, 320) distance
 };
+
+static_assert(sizeof(u16) << LB >= sizeof(u32) * (16 * 9 + 16), "the symbol sets of the code lengths live where the literal/length table goes");
 
 struct Wave {                             // wave-shared state (LDS on the device)
     Tables T;
@@ -80,7 +90,7 @@ struct Wave {                             // wave-shared state (LDS on the devic
     u32 hdr[8];                           // [0] type, [1] last, [2] hlit, [3] hdist, [4] first unit bit (stored: first data bit), [5] stored length / tokens,
                                           // [6] error, [7] bytes
     u32 changed, n_valid, eob_at, rounds; // rounds: pass-2 rounds of the last Huffman block (statistics)
-    u32 cnt[16], start[16];               // build_lengths' scratch (indexed dynamically: in LDS, not in private memory)
+    u32 cnt[32], start[32];               // symbols per code length and where each length begins in sorted[]: [0, 16) literal/length, [16, 32) distance
     u16 climit[16], coff[16];             // the code-length code ...
     u8 csorted[32], cl[32];
     u8 cltab[128];                        // ... and its lookup table: (symbol << 3) | code length by the next 7 bits, 0 = no code
@@ -130,6 +140,23 @@ COVW_FN bool build_lengths(Wave &W, const u8 *lens, u32 n, u16 *limit, u16 *off,
         if (!l) continue;
         if (sorted16) sorted16[start[l]] = (u16)s; else sorted8[start[l]] = (u8)s;
         start[l]++;
+    }
+    return true;
+}
+
+// Per-length limits / offsets of a canonical code from its per-length counts; start[l] = index of length l's first symbol in sorted[].
+// False when the set is over-subscribed.
+COVW_FN bool code_offsets(const u32 *cnt, u32 *start, u16 *limit, u16 *off) {
+    u32 left = 1, run = 0, first = 0;
+    limit[0] = 0; off[0] = 0; start[0] = 0;
+    for (u32 l = 1; l < 16; l++) {
+        left <<= 1;
+        if (cnt[l] > left) return false;
+        left -= cnt[l];
+        start[l] = run;
+        limit[l] = (u16)((first + cnt[l]) << (15u - l));
+        off[l] = (u16)((run - first) & 0xffffu);
+        run += cnt[l]; first = (first + cnt[l]) << 1;
     }
     return true;
 }
@@ -513,18 +540,48 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
             COVW_SYNC();
             if (W.hdr[6] != OK) { err = W.hdr[6]; break; }
         }
+        // ---- both codes from their lengths, with the whole wave: count and mark every symbol under its length, offsets per length (serial,
+        // 2 x 15 steps), then every symbol finds its place among the symbols of its length by counting the marks below it
+        COVW_PARFOR(lane) {
+            for (u32 i = lane; i < 16u * 9u + 16u; i += 64u) W.T.mask[i] = 0;
+            if (lane < 32u) W.cnt[lane] = 0;
+        }
+        COVW_SYNC();
+        COVW_PARFOR(lane) {
+            for (u32 sy = lane; sy < 320u; sy += 64u) {
+                const u32 l = W.T.lens[sy] & 15u;
+                if (!l) continue;
+                if (sy < 288u) { COVW_ATOMIC_ADD(&W.cnt[l], 1u); COVW_ATOMIC_OR(&W.T.mask[l * 9u + (sy >> 5)], 1u << (sy & 31u)); }
+                else { COVW_ATOMIC_ADD(&W.cnt[16u + l], 1u); COVW_ATOMIC_OR(&W.T.mask[144u + l], 1u << (sy - 288u)); }
+            }
+        }
+        COVW_SYNC();
         COVW_PARFOR(lane) {
             if (lane == 0u) {
-                Tables &T = W.T;
-                const bool a = build_lengths(W, T.lens, W.hdr[2], T.lit_limit, T.lit_off, T.lit_sorted, nullptr);
-                const bool b = a && build_lengths(W, T.lens + 288, W.hdr[3], T.dist_limit, T.dist_off, nullptr, T.dist_sorted);
+                W.cnt[0] = 0; W.cnt[16] = 0;
+                const bool a = code_offsets(W.cnt, W.start, W.T.lit_limit, W.T.lit_off);
+                const bool b = a && code_offsets(W.cnt + 16, W.start + 16, W.T.dist_limit, W.T.dist_off);
                 if (!b) W.hdr[6] = ERR_FORMAT;
             }
         }
         COVW_SYNC();
         if (W.hdr[6] != OK) { err = W.hdr[6]; break; }
-        COVW_PARFOR(lane) { for (u32 i = lane; i < 288u; i += 64u) W.T.lit_sorted[i] = (u16)lit_entry(W.T.lit_sorted[i]); }      // symbols -> entries
-        COVW_SYNC();
+        COVW_PARFOR(lane) {
+            for (u32 sy = lane; sy < 320u; sy += 64u) {
+                const u32 l = W.T.lens[sy] & 15u;
+                if (!l) continue;
+                if (sy < 288u) {
+                    const u32 *m = W.T.mask + l * 9u, w = sy >> 5;
+                    u32 rank = (u32)__builtin_popcount(m[w] & ((1u << (sy & 31u)) - 1u));
+                    for (u32 j = 0; j < w; j++) rank += (u32)__builtin_popcount(m[j]);
+                    W.T.lit_sorted[W.start[l] + rank] = (u16)lit_entry(sy);          // entries, not symbols: what the decoder wants
+                } else {
+                    const u32 d = sy - 288u;
+                    W.T.dist_sorted[W.start[16u + l] + (u32)__builtin_popcount(W.T.mask[144u + l] & ((1u << d) - 1u))] = (u8)d;
+                }
+            }
+        }
+        COVW_SYNC();          // (the masks share their memory with the lookup table that is filled next)
         COVW_PARFOR(lane) {
             for (u32 i = lane; i < (1u << LB); i += 64u) fill_lit_index(W.T, i);
             for (u32 i = lane; i < (1u << DB); i += 64u) fill_dist_index(W.T, i);

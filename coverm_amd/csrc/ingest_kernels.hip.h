@@ -710,6 +710,8 @@ __global__ __launch_bounds__(64) void k_inflate2(const uint8_t *__restrict__ com
 #define COVW_SYNC() __syncthreads()
 #define covw_brev32(x) __brev(x)
 #define COVW_NO_UNROLL _Pragma("clang loop unroll(disable) vectorize(disable)")
+#define COVW_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define COVW_ATOMIC_OR(p, v) atomicOr((p), (v))
 #include "inflate_wave_core.h"
 namespace covi {
 static_assert(covw::TOK_CAP == INF_TOK_CAP && covw::OK == INF_OK && covw::ERR_FORMAT == INF_ERR_FORMAT && covw::ERR_SIZE == INF_ERR_SIZE, "the core mirrors k_inflate's contract");

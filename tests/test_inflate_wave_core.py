@@ -99,8 +99,8 @@ def bam_like(rng, n):
     return b"".join(parts)[:n]
 
 
-def test_state_fits_twenty_two_waves_per_cu(host):
-    assert host.covw_host_wave_bytes() <= 7424      # 160 KiB of LDS per CU / 7.25 KiB: 22 waves; the lookup tables are 3 KiB of it, Sink<5>'s line buffers 1 KiB
+def test_state_fits_twenty_one_waves_per_cu(host):
+    assert host.covw_host_wave_bytes() <= 7552      # 160 KiB of LDS per CU / 7.4 KiB: 21 waves; the lookup tables are 3 KiB of it, Sink<5>'s line buffers 1 KiB
 
 
 @pytest.mark.parametrize("level", [1, 6, 9])
