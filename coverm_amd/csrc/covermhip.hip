@@ -1242,7 +1242,12 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
             // every block after the tables / pass 1 / pass 2 (the file then falls back to the host reader)
             static const u32 pad = (u32)(getenv("COVERM_INFLATE_WAVE_PAD_KB") ? atoi(getenv("COVERM_INFLATE_WAVE_PAD_KB")) : 0) << 10;
             static const int st = getenv("COVERM_INFLATE_WAVE_STORES") ? atoi(getenv("COVERM_INFLATE_WAVE_STORES")) : COVW_STORES;
-            auto kern = st == 1 ? covi::k_inflate_wave<1> : st == 3 ? covi::k_inflate_wave<3> : st == 4 ? covi::k_inflate_wave<4> : st == 5 ? covi::k_inflate_wave<5> : covi::k_inflate_wave<2>;
+            static const int cur = getenv("COVERM_INFLATE_WAVE_CURSOR") ? atoi(getenv("COVERM_INFLATE_WAVE_CURSOR")) : COVW_CURSOR;
+            auto kern = covi::k_inflate_wave<COVW_STORES, COVW_CURSOR>;
+#define COV_WAVE_PICK(ST, CUR) if (st == ST && cur == CUR) kern = covi::k_inflate_wave<ST, CUR>;
+            COV_WAVE_PICK(1, 1) COV_WAVE_PICK(2, 1) COV_WAVE_PICK(3, 1) COV_WAVE_PICK(4, 1) COV_WAVE_PICK(5, 1)
+            COV_WAVE_PICK(1, 2) COV_WAVE_PICK(2, 2) COV_WAVE_PICK(3, 2) COV_WAVE_PICK(4, 2) COV_WAVE_PICK(5, 2)
+#undef COV_WAVE_PICK
             hipLaunchKernelGGL(kern, dim3(n), dim3(64), pad, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, tokb.p, ntokb.p,
                                s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
         }

@@ -97,7 +97,7 @@ struct Wave {                             // wave-shared state (LDS on the devic
     u32 ring[4 * 64];                     // Sink<5>: every lane's current 16-byte output line, word k of lane l at [k * 64 + l]
 };
 
-struct Src { const u32 *w; u32 total_bits; };     // aligned words of the payload (readable 16 bytes past its end); bit 0 = bit 0 of w[0]
+struct Src { const u32 *w; u32 total_bits; };     // aligned words of the payload (readable 64 bytes past its end); bit 0 = bit 0 of w[0]
 
 COVW_FN u32 bits_at(u32 x, u32 off, u32 n) { return (x >> off) & ((1u << n) - 1u); }      // off + n <= 31
 
@@ -116,6 +116,37 @@ struct Cursor {
     COVW_FN u32 low32() const { return (u32)buf; }
     COVW_FN void drop(u32 n) { buf >>= n; cnt -= n; pos += n; }
 };
+// The same with the stream requested four to eight words ahead, 16 bytes per load (COVW_CURSOR 2): the compressed bytes of the blocks
+// in flight on a CU do not fit its caches, a lane's next word is a miss once per cache line, and a wave waits for the slowest of 64.
+struct Words4 { u32 a, b, c, d; };
+struct CursorAhead {
+    const u32 *w; u64 buf; u32 cnt, wi, qn, pos;
+    u32 q0, q1, q2, q3;                   // the qn words that enter buf next, q0 first
+    Words4 nx;                            // the four words behind them (w[wi ..]), requested
+    COVW_FN Words4 load4(u32 i) const { Words4 x; __builtin_memcpy(&x, w + i, 16); return x; }
+    COVW_FN void init(const Src &s, u32 p) {
+        w = s.w; pos = p;
+        const u32 i = p >> 5, d = p & 31u;
+        buf = ((u64)w[i] | ((u64)w[i + 1u] << 32)) >> d; cnt = 64u - d;
+        const Words4 x = load4(i + 2u);
+        q0 = x.a; q1 = x.b; q2 = x.c; q3 = x.d; qn = 4u;
+        wi = i + 6u; nx = load4(wi);
+    }
+    COVW_FN void refill() {               // afterwards cnt >= 33
+        if (cnt <= 32u) {
+            buf |= (u64)q0 << cnt; cnt += 32u;
+            q0 = q1; q1 = q2; q2 = q3;
+            if (--qn == 0u) { q0 = nx.a; q1 = nx.b; q2 = nx.c; q3 = nx.d; qn = 4u; wi += 4u; nx = load4(wi); }
+        }
+    }
+    COVW_FN u32 low32() const { return (u32)buf; }
+    COVW_FN void drop(u32 n) { buf >>= n; cnt -= n; pos += n; }
+};
+template <int CUR> struct CursorOf { typedef Cursor type; };
+template <> struct CursorOf<2> { typedef CursorAhead type; };
+#ifndef COVW_CURSOR
+#define COVW_CURSOR 1
+#endif
 
 // ---- canonical code of `n` symbols with code lengths lens[0 .. n): per-length limits / offsets and the symbols sorted by (length, value).
 // Serial; false when the set is over-subscribed.
@@ -429,10 +460,10 @@ template <> struct Sink<5> {
 // bit by bit (the start is a guess); 1: also counts output bytes and matches; 2: writes them through Sink<ST> (out + opos = where the
 // lane's first byte goes, out + own_end = where its last byte ends, tok + tpos = its first token position; *err receives what went wrong).
 // Returns the end position; *flags: bit 0 end of block met, bit 1 invalid code / ran off the payload.
-template <int MODE, int ST>
+template <int MODE, int ST, int CUR>
 COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, u8 *out, u32 opos, u32 own_end, u16 *tok, u32 tpos,
                       u32 *err, u32 *ring) {
-    Cursor c; c.init(s, from);
+    typename CursorOf<CUR>::type c; c.init(s, from);
     u32 f = 0, bytes = 0, toks = 0;
     Sink<MODE == 2 ? ST : 1> sink;
     if (MODE == 2) sink.init(out, tok, opos, own_end, ring);
@@ -505,7 +536,7 @@ COVW_FN u32 share_begin_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
 // One BGZF block.  comp_words: aligned words holding the raw DEFLATE payload from bit `bit0` on; out: the block's `isize` output
 // bytes; tok: its token-position list.  *status = OK / ERR_*, *n_tok = matches written (0 unless OK).
 // stop_after (measurements only, 0 in production): 1 = give up after the tables are built, 2 = after pass 1, 3 = after pass 2.
-template <int ST = COVW_STORES>
+template <int ST = COVW_STORES, int CUR = COVW_CURSOR>
 COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0) {
     Src s; s.w = comp_words; s.total_bits = bit0 + payload_bits;
     u32 pos = bit0, opos = 0, ntok = 0, err = OK;
@@ -596,7 +627,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
             u32 f, nb, nt;
             const u32 g = share_begin_of(B0, S, lane, s.total_bits);
             if (lane) W.end[lane - 1u] = g >= s.total_bits ? s.total_bits
-                                                           : run_share<0, ST>(W.T, s, g - B0 > OVERLAP_BITS ? g - OVERLAP_BITS : B0, g, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
+                                                           : run_share<0, ST, CUR>(W.T, s, g - B0 > OVERLAP_BITS ? g - OVERLAP_BITS : B0, g, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
             if (lane == 63u) W.end[63] = s.total_bits;
         }
         COVW_SYNC();
@@ -608,7 +639,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                 const u32 from = lane ? W.end[lane - 1u] : B0;
                 const u32 ge = share_begin_of(B0, S, lane + 1u, s.total_bits);
                 u32 f = 0, nb = 0, nt = 0, e = from;
-                if (from < ge) e = run_share<1, ST>(W.T, s, from, ge, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
+                if (from < ge) e = run_share<1, ST, CUR>(W.T, s, from, ge, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
                 W.flags[lane] = f; W.nbytes[lane] = nb; W.ntok[lane] = nt; W.tmp[lane] = e;
             }
             COVW_SYNC();          // every lane has read its neighbour's old end
@@ -653,7 +684,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                 const u32 from = lane ? W.end[lane - 1u] : B0;
                 const u32 ge = share_begin_of(B0, S, lane + 1u, s.total_bits);
                 u32 f, nb, nt, e2 = OK;
-                if (from < ge) (void)run_share<2, ST>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], opos + W.obase[lane] + W.nbytes[lane], tok, ntok + W.tbase[lane], &e2, W.ring + lane);
+                if (from < ge) (void)run_share<2, ST, CUR>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], opos + W.obase[lane] + W.nbytes[lane], tok, ntok + W.tbase[lane], &e2, W.ring + lane);
                 if (e2 != OK) W.hdr[6] = e2;
             }
         }

@@ -716,8 +716,9 @@ __global__ __launch_bounds__(64) void k_inflate2(const uint8_t *__restrict__ com
 namespace covi {
 static_assert(covw::TOK_CAP == INF_TOK_CAP && covw::OK == INF_OK && covw::ERR_FORMAT == INF_ERR_FORMAT && covw::ERR_SIZE == INF_ERR_SIZE, "the core mirrors k_inflate's contract");
 // ST: how pass 3 stores (covw::Sink<ST>; COVERM_INFLATE_WAVE_STORES) — which shape of scattered store the memory path likes is a measurement.
+// CUR: how far ahead a lane requests its compressed words (1: one word, 2: four to eight, 16 bytes per load; COVERM_INFLATE_WAVE_CURSOR).
 // (Holding the register allocation to five waves per SIMD changed nothing, to six or seven cost 40 % in spills: profiles/r03_wave_variants2.log.)
-template <int ST>
+template <int ST, int CUR>
 __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                      uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
                                                      u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__
     u32 st = INF_OK, nt = 0;
     if (B.isize != 0u) {
         const u32 mis = (u32)((u64)(comp + B.in_off) & 3u);
-        covw::inflate_block<ST>(W, reinterpret_cast<const u32 *>(comp + B.in_off - mis), 8u * mis, 8u * B.in_len, out + B.out_off, B.isize,
+        covw::inflate_block<ST, CUR>(W, reinterpret_cast<const u32 *>(comp + B.in_off - mis), 8u * mis, 8u * B.in_len, out + B.out_off, B.isize,
                                 tok + (size_t)b * INF_TOK_CAP, &nt, &st, stop_after);
     }
     if ((threadIdx.x & 63u) == 0u) {

@@ -1,5 +1,5 @@
 // AddressSanitizer + UBSan run of csrc/inflate_wave_core.h over valid and damaged DEFLATE streams: the buffers are exactly as large as the
-// kernel's contract says (payload + 16 readable bytes, isize output bytes, TOK_CAP token positions), so any access outside them aborts.
+// kernel's contract says (payload + 64 readable bytes, isize output bytes, TOK_CAP token positions), so any access outside them aborts.
 //   g++ -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -o fuzz tests/c/inflate_wave_fuzz.cpp -lz && ./fuzz [rounds] [seed]
 #include <stdint.h>
 #include <stdio.h>
@@ -36,8 +36,8 @@ static std::vector<uint8_t> deflate_raw(const std::vector<uint8_t> &in, int leve
 }
 
 // -> status; `want` non-null: the resolved bytes must equal it when the status is OK
-static int run(int stores, const std::vector<uint8_t> &payload, uint32_t misalign, uint32_t isize, const std::vector<uint8_t> *want) {
-    const size_t nbytes = misalign + payload.size() + 16;                    // the contract: 16 readable bytes behind the payload
+static int run(int stores, int cursor, const std::vector<uint8_t> &payload, uint32_t misalign, uint32_t isize, const std::vector<uint8_t> *want) {
+    const size_t nbytes = misalign + payload.size() + 64;                    // the contract: 64 readable bytes behind the payload
     uint32_t *words = static_cast<uint32_t *>(malloc((nbytes + 3) / 4 * 4));
     for (size_t k = 0; k < (nbytes + 3) / 4; k++) words[k] = rnd();
     memcpy(reinterpret_cast<uint8_t *>(words) + misalign, payload.data(), payload.size());
@@ -46,11 +46,11 @@ static int run(int stores, const std::vector<uint8_t> &payload, uint32_t misalig
     static covw::Wave W;
     uint32_t nt = 0, st = 0;
     const uint32_t b0 = 8u * misalign, nb = 8u * (uint32_t)payload.size();
-    if (stores == 1) covw::inflate_block<1>(W, words, b0, nb, out, isize, tok, &nt, &st);
-    else if (stores == 2) covw::inflate_block<2>(W, words, b0, nb, out, isize, tok, &nt, &st);
-    else if (stores == 3) covw::inflate_block<3>(W, words, b0, nb, out, isize, tok, &nt, &st);
-    else if (stores == 4) covw::inflate_block<4>(W, words, b0, nb, out, isize, tok, &nt, &st);
-    else covw::inflate_block<5>(W, words, b0, nb, out, isize, tok, &nt, &st);
+    if (stores == 1) (cursor == 2 ? covw::inflate_block<1, 2> : covw::inflate_block<1, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0);
+    else if (stores == 2) (cursor == 2 ? covw::inflate_block<2, 2> : covw::inflate_block<2, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0);
+    else if (stores == 3) (cursor == 2 ? covw::inflate_block<3, 2> : covw::inflate_block<3, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0);
+    else if (stores == 4) (cursor == 2 ? covw::inflate_block<4, 2> : covw::inflate_block<4, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0);
+    else (cursor == 2 ? covw::inflate_block<5, 2> : covw::inflate_block<5, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0);
     int rc = (int)st;
     if (st == covw::OK) {
         for (uint32_t t = 0; t < nt; t++) {                                  // k_lz_resolve, serially
@@ -80,7 +80,8 @@ int main(int argc, char **argv) {
         const int level = (int)(rnd() % 10u), strategy = (rnd() & 7u) == 0 ? Z_FIXED : (rnd() & 7u) == 1 ? Z_HUFFMAN_ONLY : (rnd() & 7u) == 2 ? Z_RLE : Z_DEFAULT_STRATEGY;
         const std::vector<uint8_t> comp = deflate_raw(data, level, strategy);
         const int stores = 1 + r % 5;                                        // covw::Sink<1..5> in turn
-        const int a = run(stores, comp, rnd() & 3u, size, &data);
+        const int cursor = 1 + (r / 5) % 2;
+        const int a = run(stores, cursor, comp, rnd() & 3u, size, &data);
         if (a != 0) {
             fprintf(stderr, "round %d: valid stream (size %u level %d strategy %d) -> %d\n", r, size, level, strategy, a);
             if (FILE *f = fopen("/tmp/covw_fuzz_fail.bin", "wb")) { fwrite(comp.data(), 1, comp.size(), f); fclose(f); }
@@ -96,7 +97,7 @@ int main(int argc, char **argv) {
             else if (how == 3) { const size_t at = rnd() % bad.size(); for (size_t k = at; k < bad.size(); k++) bad[k] = (uint8_t)rnd(); }
             else bad[0] = (uint8_t)rnd();
             const uint32_t isz = (rnd() & 3u) ? size : (rnd() % 65536u);
-            const int b = run(stores, bad, rnd() & 3u, isz, nullptr);
+            const int b = run(stores, cursor, bad, rnd() & 3u, isz, nullptr);
             if (b == -2) { fprintf(stderr, "round %d: status OK with a token outside the block\n", r); return 1; }
             if (b != 0) rejected++; else differ++;
         }

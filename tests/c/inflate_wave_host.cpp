@@ -28,14 +28,14 @@ extern "C" {
 // canaries this function checks.  Returns the status (covw::OK ...), -1 when a canary was overwritten.
 int covw_host_inflate(const uint8_t *payload, uint32_t nbytes, uint32_t misalign, uint32_t slack_fill, uint8_t *out, uint32_t isize, uint16_t *tok, uint32_t *n_tok,
                       uint32_t *rounds) {
-    std::vector<uint32_t> words((nbytes + misalign + 3) / 4 + 8);
+    std::vector<uint32_t> words((nbytes + misalign + 3) / 4 + 20);
     memset(words.data(), (int)slack_fill, words.size() * 4);
     memcpy(reinterpret_cast<uint8_t *>(words.data()) + misalign, payload, nbytes);
     memset(out, 0xC3, 8); memset(out + 8 + isize, 0xC3, 8);
     static covw::Wave W;
     uint32_t status = 0;
     W.rounds = 0;
-    covw::inflate_block<COVW_STORES>(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status);
+    covw::inflate_block<COVW_STORES, COVW_CURSOR>(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status);
     if (rounds) *rounds = W.rounds;
     for (int k = 0; k < 8; k++) if (out[k] != 0xC3 || out[8 + isize + k] != 0xC3) return -1;
     return (int)status;
