@@ -90,6 +90,7 @@ struct Wave {                             // wave-shared state (LDS on the devic
     u32 hdr[8];                           // [0] type, [1] last, [2] hlit, [3] hdist, [4] first unit bit (stored: first data bit), [5] stored length / tokens,
                                           // [6] error, [7] bytes
     u32 changed, n_valid, eob_at, rounds; // rounds: pass-2 rounds of the last Huffman block (statistics)
+    u32 n_deflate_blocks, pad_[3];        // DEFLATE blocks in the payload (statistics)
     u32 cnt[32], start[32];               // symbols per code length and where each length begins in sorted[]: [0, 16) literal/length, [16, 32) distance
     u16 climit[16], coff[16];             // the code-length code ...
     u8 csorted[32], cl[32];
@@ -539,10 +540,11 @@ COVW_FN u32 share_begin_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
 template <int ST = COVW_STORES, int CUR = COVW_CURSOR>
 COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0) {
     Src s; s.w = comp_words; s.total_bits = bit0 + payload_bits;
-    u32 pos = bit0, opos = 0, ntok = 0, err = OK;
+    u32 pos = bit0, opos = 0, ntok = 0, err = OK, nblk = 0;
     bool last = false;
     while (!last && err == OK) {
-        COVW_PARFOR(lane) { if (lane == 0u) parse_header(W, s, pos); }
+        nblk++;
+        COVW_PARFOR(lane) { if (lane == 0u) { parse_header(W, s, pos); W.n_deflate_blocks = nblk; } }
         COVW_SYNC();
         if (W.hdr[6] != OK) { err = W.hdr[6]; break; }
         last = W.hdr[1] != 0u;

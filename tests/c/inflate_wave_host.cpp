@@ -21,6 +21,8 @@ static inline unsigned covw_brev32(unsigned x) {
 }
 #include "../../coverm_amd/csrc/inflate_wave_core.h"
 
+static covw::Wave g_wave;
+
 extern "C" {
 
 // payload: raw DEFLATE stream of one BGZF block; misalign 0..3 = where its first byte sits in the aligned word buffer (the device reads
@@ -32,7 +34,7 @@ int covw_host_inflate(const uint8_t *payload, uint32_t nbytes, uint32_t misalign
     memset(words.data(), (int)slack_fill, words.size() * 4);
     memcpy(reinterpret_cast<uint8_t *>(words.data()) + misalign, payload, nbytes);
     memset(out, 0xC3, 8); memset(out + 8 + isize, 0xC3, 8);
-    static covw::Wave W;
+    covw::Wave &W = g_wave;
     uint32_t status = 0;
     W.rounds = 0;
     covw::inflate_block<COVW_STORES, COVW_CURSOR>(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status);
@@ -55,4 +57,5 @@ int covw_host_resolve(uint8_t *out, uint32_t isize, const uint16_t *tok, uint32_
 }
 
 uint32_t covw_host_wave_bytes(void) { return (uint32_t)sizeof(covw::Wave); }
+uint32_t covw_host_last_deflate_blocks(void) { return g_wave.n_deflate_blocks; }
 }
