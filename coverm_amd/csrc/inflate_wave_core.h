@@ -90,7 +90,7 @@ struct Wave {                             // wave-shared state (LDS on the devic
     u32 hdr[8];                           // [0] type, [1] last, [2] hlit, [3] hdist, [4] first unit bit (stored: first data bit), [5] stored length / tokens,
                                           // [6] error, [7] bytes
     u32 changed, n_valid, eob_at, rounds; // rounds: pass-2 rounds of the last Huffman block (statistics)
-    u32 n_deflate_blocks, pad_[3];        // DEFLATE blocks in the payload (statistics)
+    u32 n_deflate_blocks, n_chunks, pad_[2];   // DEFLATE blocks in the payload, chunks they were decoded in (statistics)
     u32 cnt[32], start[32];               // symbols per code length and where each length begins in sorted[]: [0, 16) literal/length, [16, 32) distance
     u16 climit[16], coff[16];             // the code-length code ...
     u8 csorted[32], cl[32];
@@ -540,11 +540,11 @@ COVW_FN u32 share_begin_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
 template <int ST = COVW_STORES, int CUR = COVW_CURSOR>
 COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0) {
     Src s; s.w = comp_words; s.total_bits = bit0 + payload_bits;
-    u32 pos = bit0, opos = 0, ntok = 0, err = OK, nblk = 0;
+    u32 pos = bit0, opos = 0, ntok = 0, err = OK, nblk = 0, chunk_bits = 0;
     bool last = false;
     while (!last && err == OK) {
         nblk++;
-        COVW_PARFOR(lane) { if (lane == 0u) { parse_header(W, s, pos); W.n_deflate_blocks = nblk; } }
+        COVW_PARFOR(lane) { if (lane == 0u) { parse_header(W, s, pos); W.n_deflate_blocks = nblk; if (nblk == 1u) W.n_chunks = 0; } }
         COVW_SYNC();
         if (W.hdr[6] != OK) { err = W.hdr[6]; break; }
         last = W.hdr[1] != 0u;
@@ -621,78 +621,93 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
         }
         COVW_SYNC();
         if (stop_after == 1u) { err = ERR_FORMAT; break; }
+        // ---- the block's units, CHUNK by chunk: 64 shares of the bits [cur, span_end), three passes, and on behind the chunk's last unit
+        // with the same tables until a lane meets end-of-block.  The first DEFLATE block of a payload takes the whole payload as its
+        // one chunk (zlib and this repository's writer emit one block per BGZF block); if it ends early, the blocks behind it are
+        // taken in chunks of about its length, so that the lanes are not spent on bits that belong to later blocks (other tables).
         const u32 B0 = W.hdr[4];
-        const u32 span = s.total_bits > B0 ? s.total_bits - B0 : 0u;
-        const u32 S = span > 64u * MIN_SHARE_BITS ? (span + 63u) / 64u : MIN_SHARE_BITS;
-        // ---- pass 1: where lane i's units begin = end[i - 1]
-        COVW_PARFOR(lane) {
-            u32 f, nb, nt;
-            const u32 g = share_begin_of(B0, S, lane, s.total_bits);
-            if (lane) W.end[lane - 1u] = g >= s.total_bits ? s.total_bits
-                                                           : run_share<0, ST, CUR>(W.T, s, g - B0 > OVERLAP_BITS ? g - OVERLAP_BITS : B0, g, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
-            if (lane == 63u) W.end[63] = s.total_bits;
-        }
-        COVW_SYNC();
-        if (stop_after == 2u) { err = ERR_FORMAT; break; }
-        // ---- pass 2: from the left neighbour's end, until no end moves
-        for (u32 round = 0;; round++) {
+        u32 cur = B0;
+        for (bool eob = false; !eob && err == OK;) {
+            if (cur >= s.total_bits) { err = ERR_FORMAT; break; }            // no end-of-block inside the payload
+            const u32 span_end = chunk_bits && s.total_bits - cur > chunk_bits ? cur + chunk_bits : s.total_bits;
+            const u32 span = span_end - cur;
+            const u32 S = span > 64u * MIN_SHARE_BITS ? (span + 63u) / 64u : MIN_SHARE_BITS;
+            // ---- pass 1: where lane i's units begin = end[i - 1]
             COVW_PARFOR(lane) {
-                if (lane == 0u) W.rounds = round + 1u;
-                const u32 from = lane ? W.end[lane - 1u] : B0;
-                const u32 ge = share_begin_of(B0, S, lane + 1u, s.total_bits);
-                u32 f = 0, nb = 0, nt = 0, e = from;
-                if (from < ge) e = run_share<1, ST, CUR>(W.T, s, from, ge, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
-                W.flags[lane] = f; W.nbytes[lane] = nb; W.ntok[lane] = nt; W.tmp[lane] = e;
+                u32 f, nb, nt;
+                const u32 g = share_begin_of(cur, S, lane, span_end);
+                if (lane) W.end[lane - 1u] = g >= span_end ? span_end
+                                                           : run_share<0, ST, CUR>(W.T, s, g - cur > OVERLAP_BITS ? g - OVERLAP_BITS : cur, g, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
+                if (lane == 63u) W.end[63] = span_end;
             }
-            COVW_SYNC();          // every lane has read its neighbour's old end
-            // The lanes in front of F (F = the first lane that stopped at end-of-block or an invalid code) decide: when none of their ends
-            // moved, they are a fixed point of the chain that starts at the exact B0, i.e. exact — and with them lane F's start.  What
-            // the lanes behind F decode belongs to the next DEFLATE block (other tables): it never settles and nobody uses it.
+            COVW_SYNC();
+            if (stop_after == 2u) { err = ERR_FORMAT; break; }
+            // ---- pass 2: from the left neighbour's end, until no end moves
+            for (u32 round = 0;; round++) {
+                COVW_PARFOR(lane) {
+                    if (lane == 0u) { W.rounds = round + 1u; if (round == 0u) W.n_chunks++; }
+                    const u32 from = lane ? W.end[lane - 1u] : cur;
+                    const u32 ge = share_begin_of(cur, S, lane + 1u, span_end);
+                    u32 f = 0, nb = 0, nt = 0, e = from;
+                    if (from < ge) e = run_share<1, ST, CUR>(W.T, s, from, ge, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
+                    W.flags[lane] = f; W.nbytes[lane] = nb; W.ntok[lane] = nt; W.tmp[lane] = e;
+                }
+                COVW_SYNC();          // every lane has read its neighbour's old end
+                // The lanes in front of F (F = the first lane that stopped at end-of-block or an invalid code) decide: when none of their
+                // ends moved, they are a fixed point of the chain that starts at the exact `cur`, i.e. exact — and with them lane F's
+                // start.  What the lanes behind F decode belongs to the next DEFLATE block: it never settles and nobody uses it.
+                COVW_PARFOR(lane) {
+                    if (lane == 0u) {
+                        u32 ch = 0;
+                        for (u32 i = 0; i < 63u && !W.flags[i]; i++) ch |= W.tmp[i] != W.end[i] ? 1u : 0u;
+                        W.changed = ch;
+                    }
+                }
+                COVW_SYNC();
+                COVW_PARFOR(lane) { W.end[lane] = W.tmp[lane]; }
+                COVW_SYNC();
+                if (!W.changed) break;
+                if (round >= 65u) { err = ERR_FORMAT; break; }
+            }
+            if (err != OK) break;
+            if (stop_after == 3u) { err = ERR_FORMAT; break; }
+            // ---- the lanes up to the first one that met end-of-block are what is left of the block (all 64 when none did); prefix sums
             COVW_PARFOR(lane) {
                 if (lane == 0u) {
-                    u32 ch = 0;
-                    for (u32 i = 0; i < 63u && !W.flags[i]; i++) ch |= W.tmp[i] != W.end[i] ? 1u : 0u;
-                    W.changed = ch;
+                    u32 nv = 64, eob_at = NO_EOB, ob = 0, tb = 0, bad = 0;
+                    for (u32 i = 0; i < 64u; i++) {
+                        W.obase[i] = ob; W.tbase[i] = tb;
+                        ob += W.nbytes[i]; tb += W.ntok[i];
+                        if (W.flags[i]) { nv = i + 1u; if (W.flags[i] == 1u) eob_at = W.end[i]; else bad = 1; break; }
+                    }
+                    W.n_valid = nv; W.eob_at = eob_at;
+                    W.hdr[7] = ob; W.hdr[5] = tb;
+                    if (bad) W.hdr[6] = ERR_FORMAT;                          // an invalid code, or a unit that runs off the payload
                 }
             }
             COVW_SYNC();
-            COVW_PARFOR(lane) { W.end[lane] = W.tmp[lane]; }
+            if (W.hdr[6] != OK) { err = W.hdr[6]; break; }
+            if (opos + W.hdr[7] > isize) { err = ERR_SIZE; break; }
+            if (ntok + W.hdr[5] > TOK_CAP) { err = ERR_FORMAT; break; }
+            // ---- pass 3: write
+            COVW_PARFOR(lane) {
+                if (lane < W.n_valid) {
+                    const u32 from = lane ? W.end[lane - 1u] : cur;
+                    const u32 ge = share_begin_of(cur, S, lane + 1u, span_end);
+                    u32 f, nb, nt, e2 = OK;
+                    if (from < ge) (void)run_share<2, ST, CUR>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], opos + W.obase[lane] + W.nbytes[lane], tok, ntok + W.tbase[lane], &e2, W.ring + lane);
+                    if (e2 != OK) W.hdr[6] = e2;
+                }
+            }
             COVW_SYNC();
-            if (!W.changed) break;
-            if (round >= 65u) { err = ERR_FORMAT; break; }
+            if (W.hdr[6] != OK) { err = W.hdr[6]; break; }
+            opos += W.hdr[7]; ntok += W.hdr[5];
+            if (W.eob_at != NO_EOB) { eob = true; pos = W.eob_at; }
+            else cur = W.end[63];                                            // exact: the chunk's last unit ends here
         }
         if (err != OK) break;
-        if (stop_after == 3u) { err = ERR_FORMAT; break; }
-        // ---- the Huffman block = the lanes up to the first one that met end-of-block (or an invalid code); prefix sums
-        COVW_PARFOR(lane) {
-            if (lane == 0u) {
-                u32 nv = 64, eob_at = NO_EOB, ob = 0, tb = 0;
-                for (u32 i = 0; i < 64u; i++) {
-                    W.obase[i] = ob; W.tbase[i] = tb;
-                    ob += W.nbytes[i]; tb += W.ntok[i];
-                    if (W.flags[i]) { nv = i + 1u; if (W.flags[i] == 1u) eob_at = W.end[i]; break; }
-                }
-                W.n_valid = nv; W.eob_at = eob_at;
-                W.hdr[7] = ob; W.hdr[5] = tb;
-            }
-        }
-        COVW_SYNC();
-        if (W.eob_at == NO_EOB) { err = ERR_FORMAT; break; }               // no end-of-block inside the payload, or an invalid code in front of it
-        if (opos + W.hdr[7] > isize) { err = ERR_SIZE; break; }
-        if (ntok + W.hdr[5] > TOK_CAP) { err = ERR_FORMAT; break; }
-        // ---- pass 3: write
-        COVW_PARFOR(lane) {
-            if (lane < W.n_valid) {
-                const u32 from = lane ? W.end[lane - 1u] : B0;
-                const u32 ge = share_begin_of(B0, S, lane + 1u, s.total_bits);
-                u32 f, nb, nt, e2 = OK;
-                if (from < ge) (void)run_share<2, ST, CUR>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], opos + W.obase[lane] + W.nbytes[lane], tok, ntok + W.tbase[lane], &e2, W.ring + lane);
-                if (e2 != OK) W.hdr[6] = e2;
-            }
-        }
-        COVW_SYNC();
-        if (W.hdr[6] != OK) { err = W.hdr[6]; break; }
-        opos += W.hdr[7]; ntok += W.hdr[5]; pos = W.eob_at;
+        // the blocks behind an early end are taken in chunks of about this block's length (+ 1/8), at least the smallest full set of shares
+        { const u32 body = pos - B0; chunk_bits = body + (body >> 3); if (chunk_bits < 64u * MIN_SHARE_BITS) chunk_bits = 64u * MIN_SHARE_BITS; }
     }
     if (err == OK && opos != isize) err = ERR_SIZE;
     *n_tok = err == OK ? ntok : 0u;

@@ -58,4 +58,5 @@ int covw_host_resolve(uint8_t *out, uint32_t isize, const uint16_t *tok, uint32_
 
 uint32_t covw_host_wave_bytes(void) { return (uint32_t)sizeof(covw::Wave); }
 uint32_t covw_host_last_deflate_blocks(void) { return g_wave.n_deflate_blocks; }
+uint32_t covw_host_last_chunks(void) { return g_wave.n_chunks; }
 }

@@ -32,6 +32,8 @@ def host(request, tmp_path_factory):
     L.covw_host_resolve.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     L.covw_host_resolve.restype = C.c_int
     L.covw_host_wave_bytes.restype = C.c_uint32
+    L.covw_host_last_deflate_blocks.restype = C.c_uint32
+    L.covw_host_last_chunks.restype = C.c_uint32
     return L
 
 
@@ -128,6 +130,27 @@ def test_fixed_huffman_stored_and_multi_block_payloads(host):
         for fill in (0x00, 0xff, 0xA5):
             st, got, nt, rounds = inflate(host, comp, len(want), 2, fill)
             assert st == 0 and got == want
+
+
+def test_blocks_behind_an_early_end_are_taken_in_chunks(host):
+    # libdeflate splits a BGZF block into several DEFLATE blocks; what follows a short first block is decoded in chunks of about its length,
+    # continuing with the same tables until the end-of-block symbol turns up
+    rng = np.random.default_rng(23)
+    data = bam_like(rng, 60000)
+    for cuts in ([3000], [3000, 6000, 40000], [500, 1000, 1500], [30000], [59990]):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        parts, at = [], 0
+        for c in cuts + [len(data)]:
+            parts.append(co.compress(data[at:c]))
+            parts.append(co.flush(zlib.Z_FULL_FLUSH) if c < len(data) else co.flush())
+            at = c
+        comp = b"".join(parts)
+        st, got, nt, rounds = inflate(host, comp, len(data), 1)
+        assert st == 0 and got == data, cuts
+        n_blocks, n_chunks = host.covw_host_last_deflate_blocks(), host.covw_host_last_chunks()
+        assert n_blocks >= len(cuts) + 1
+        if cuts[0] <= 3000:
+            assert n_chunks > n_blocks - len(cuts), (cuts, n_blocks, n_chunks)      # some block took more than one chunk
 
 
 def test_long_codes_behind_the_primary_tables(host):
