@@ -23,13 +23,21 @@ static inline unsigned covw_brev32(unsigned x) {
 static uint64_t rng_state = 88172645463325252ull;
 static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
 
-static std::vector<uint8_t> deflate_raw(const std::vector<uint8_t> &in, int level, int strategy) {
+// pieces > 1: the input goes in that many pieces with a flush between them, i.e. several DEFLATE blocks (and empty stored blocks) per stream
+static std::vector<uint8_t> deflate_raw(const std::vector<uint8_t> &in, int level, int strategy, int pieces) {
     z_stream z; memset(&z, 0, sizeof z);
     deflateInit2(&z, level, Z_DEFLATED, -15, 8, strategy);
-    std::vector<uint8_t> out(in.size() * 2 + 4096);      // (deflateBound does not cover Z_FIXED on incompressible input)
-    z.next_in = const_cast<uint8_t *>(in.data()); z.avail_in = (uInt)in.size();
+    std::vector<uint8_t> out(in.size() * 2 + 4096 + 64 * (size_t)pieces);      // (deflateBound does not cover Z_FIXED on incompressible input)
     z.next_out = out.data(); z.avail_out = (uInt)out.size();
-    if (deflate(&z, Z_FINISH) != Z_STREAM_END) { fprintf(stderr, "deflate did not finish\n"); exit(2); }
+    size_t at = 0;
+    for (int k = 0; k < pieces; k++) {
+        const size_t end = k + 1 == pieces ? in.size() : at + rnd() % (in.size() - at + 1);
+        z.next_in = const_cast<uint8_t *>(in.data()) + at; z.avail_in = (uInt)(end - at);
+        const int flush = k + 1 == pieces ? Z_FINISH : (rnd() & 1u) ? Z_FULL_FLUSH : Z_BLOCK;
+        const int rc = deflate(&z, flush);
+        if (k + 1 == pieces ? rc != Z_STREAM_END : (rc != Z_OK && rc != Z_BUF_ERROR)) { fprintf(stderr, "deflate did not finish\n"); exit(2); }
+        at = end;
+    }
     out.resize(z.total_out);
     deflateEnd(&z);
     return out;
@@ -78,7 +86,7 @@ int main(int argc, char **argv) {
         for (uint32_t k = 0; k < size; k++)
             data[k] = kind == 0 ? (uint8_t)rnd() : kind == 1 ? (uint8_t)("ACGTN!#I"[rnd() & 7u]) : kind == 2 ? (uint8_t)(rnd() % 3u ? 0 : rnd()) : (uint8_t)(k * 7u >> (rnd() & 3u));
         const int level = (int)(rnd() % 10u), strategy = (rnd() & 7u) == 0 ? Z_FIXED : (rnd() & 7u) == 1 ? Z_HUFFMAN_ONLY : (rnd() & 7u) == 2 ? Z_RLE : Z_DEFAULT_STRATEGY;
-        const std::vector<uint8_t> comp = deflate_raw(data, level, strategy);
+        const std::vector<uint8_t> comp = deflate_raw(data, level, strategy, (rnd() & 3u) ? 1 : 2 + (int)(rnd() % 6u));
         const int stores = 1 + r % 5;                                        // covw::Sink<1..5> in turn
         const int cursor = 1 + (r / 5) % 2;
         const int a = run(stores, cursor, comp, rnd() & 3u, size, &data);
