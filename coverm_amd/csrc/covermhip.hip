@@ -302,9 +302,9 @@ void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
 }
 
 // k_pileup_fast over every tile (it skips the ones k_ranges flagged TILE_F_SLOW)
-template <bool H>
-void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    const size_t smem = pileup_fast_smem_bytes(H);
+template <bool H, int R>
+void launch_fast_r(cov_session *s, const PileupArgs &a, u32 n_tiles) {
+    const size_t smem = pileup_fast_smem_bytes(H, R);
     // the dynamic-LDS limit and the occupancy are per-device facts, and span mode launches from one thread per device: cached per
     // device id, in atomics (two threads racing for the same device compute the same value)
     static std::atomic<int> occ_dev[64];
@@ -313,9 +313,9 @@ void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
     const u32 chunk = (u32)s->chunk_tiles;
     const u32 n_chunks = (n_tiles + chunk - 1) / chunk;
     if (!occ) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_fast<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_fast<H, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_pileup_fast<H>), 256, smem) != hipSuccess || nb < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_pileup_fast<H, R>), 256, smem) != hipSuccess || nb < 1) {
             (void)hipGetLastError();
             nb = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
         }
@@ -324,7 +324,17 @@ void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
     const char *wg_env = getenv("COVERM_WG_PER_CU");
     const u32 wg_per_cu = wg_env && atoi(wg_env) > 0 ? (u32)atoi(wg_env) : 8u * (u32)occ;
     const u32 grid = std::max(1u, std::min((n_chunks + 3) / 4, (u32)s->n_cus * wg_per_cu));
-    hipLaunchKernelGGL((k_pileup_fast<H>), dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
+    hipLaunchKernelGGL((k_pileup_fast<H, R>), dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
+}
+
+// COVERM_PILEUP_HREP = 2 | 4: that many copies of every histogram bin in LDS (fewer lanes adding to one address, fewer resident waves):
+// opt-in until it is measured
+template <bool H>
+void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
+    static const int hrep = getenv("COVERM_PILEUP_HREP") ? atoi(getenv("COVERM_PILEUP_HREP")) : 1;
+    if (H && hrep == 2) launch_fast_r<H, 2>(s, a, n_tiles);
+    else if (H && hrep == 4) launch_fast_r<H, 4>(s, a, n_tiles);
+    else launch_fast_r<H, 1>(s, a, n_tiles);
 }
 
 template <bool H, bool W>

@@ -7,4 +7,9 @@ timeout 60 tools/ubench/store_probe > $OUT/store_probe.log 2>&1
 timeout 120 tools/r03/wave_variants.sh r04_call1 20000000 "v1:X=0 v3_st1:COVERM_INFLATE_V=3,COVERM_INFLATE_WAVE_STORES=1 v3_st2:COVERM_INFLATE_V=3,COVERM_INFLATE_WAVE_STORES=2 v3_st3:COVERM_INFLATE_V=3,COVERM_INFLATE_WAVE_STORES=3 v3_st4:COVERM_INFLATE_V=3,COVERM_INFLATE_WAVE_STORES=4 v3_st5:COVERM_INFLATE_V=3,COVERM_INFLATE_WAVE_STORES=5 v3_st2_cur2:COVERM_INFLATE_V=3,COVERM_INFLATE_WAVE_STORES=2,COVERM_INFLATE_WAVE_CURSOR=2 v3_st5_cur2:COVERM_INFLATE_V=3,COVERM_INFLATE_WAVE_STORES=5,COVERM_INFLATE_WAVE_CURSOR=2 v3_st5_pass2:COVERM_INFLATE_V=3,COVERM_INFLATE_WAVE_STORES=5,COVERM_INFLATE_ABLATE=3 v3_st5_cur2_pass2:COVERM_INFLATE_V=3,COVERM_INFLATE_WAVE_STORES=5,COVERM_INFLATE_WAVE_CURSOR=2,COVERM_INFLATE_ABLATE=3" > /dev/null 2>&1
 cd $R
 ( COVERM_INFLATE_V=3 timeout 240 python -m pytest tests/test_gpu_ingest.py -m gpu -x -q --timeout 120 2>&1 | tail -5 ) > $OUT/pytest_v3.log 2>&1
-cat $OUT/store_probe.log $OUT/variants.log $OUT/pytest_v3.log
+# replicated histogram bins in k_pileup_fast: parity (the coverage parity tests) and time
+for r in 2 4; do
+  ( COVERM_PILEUP_HREP=$r timeout 200 python -m pytest tests/test_gpu_abi_parity.py -m gpu -x -q --timeout 120 2>&1 | tail -3 ) > $OUT/pytest_hrep$r.log 2>&1
+  ( COVERM_PILEUP_HREP=$r timeout 120 python bench.py --no-cpu-baseline --no-e2e --steps 10 --warmup 2 2>&1 | tail -2 ) > $OUT/bench_hrep$r.log 2>&1
+done
+cat $OUT/store_probe.log $OUT/variants.log $OUT/pytest_v3.log $OUT/pytest_hrep*.log $OUT/bench_hrep*.log
