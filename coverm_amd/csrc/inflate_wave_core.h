@@ -66,8 +66,9 @@ constexpr u32 DIST_INVALID = 0x80000000u;
 
 struct Tables {
     union {
-        u16 lit[1u << LB];                // bits 0-3 code length (0: not decidable from LB bits); literal / end of block: bit 15 = 0, bits 4-12 symbol;
-                                          // length symbol: bit 15 = 1, bits 4-11 base - 3, bits 12-14 extra bits; 0xfff0 | length: symbols 286 / 287
+        u16 lit[1u << LB];                // bits 0-3 code length (0: not decidable from LB bits); literal: bit 15 = 0, bits 4-11 the byte;
+                                          // length symbol: bit 15 = 1, bits 4-11 base - 3, bits 12-14 extra bits (<= 5); extra bits = 7 marks the
+                                          // two entries that are neither: 0xf000 end of block, 0xfff0 no symbol (286 / 287, or no code at all)
         u32 mask[16 * 9 + 16];            // while the code is built: the set of symbols of every code length (nine words per literal/length
     };                                    // length, one per distance length) — a symbol's rank among its length = population count below it
     u32 dist[1u << DB];                   // bits 0-3 code length, bits 4-7 extra bits, bits 8-22 base; bit 31: symbols 30 / 31
@@ -205,7 +206,8 @@ COVW_FN u32 canonical(const u16 *limit, const u16 *off, u32 v, u32 &idx) {
 }
 
 COVW_FN u32 lit_entry(u32 sym) {                   // table entry of a literal/length symbol, without the code length
-    if (sym <= 256u) return sym << 4;
+    if (sym < 256u) return sym << 4;
+    if (sym == 256u) return 0xf000u;
     if (sym > 285u) return 0xfff0u;
     const u32 li = sym - 257u;                     // RFC 1951 3.2.5: 257-264 are lengths 3-10, then groups of four share e extra bits, 285 = 258
     const u32 le = li < 8u ? 0u : (li == 28u ? 0u : (li - 4u) >> 2);
@@ -484,16 +486,22 @@ COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *f
             e = l ? ((u32)T.lit_sorted[idx < 288u ? idx : 287u] | l) : 0xfff0u;
         }
         const u32 n = e & 15u;
-        if (!(e & 0x8000u)) {
+        if (!(e & 0x8000u)) {                       // a literal
             COVW_TRACE_UNIT(MODE, trace);
             c.drop(n);
-            if (e == ((256u << 4) | n)) {
-                if (MODE == 0) continue;           // (a guessed start may see an end-of-block that is none; a true one ends what anybody uses of this lane)
-                f |= 1u; break;
-            }
             if (MODE == 2) sink.literal(opos + bytes, e >> 4);
             bytes++;
             continue;
+        }
+        if ((e & 0x7000u) == 0x7000u) {             // neither literal nor length
+            if ((e & 0x0ff0u) == 0u) {              // end of block
+                COVW_TRACE_UNIT(MODE, trace);
+                c.drop(n);
+                if (MODE == 0) continue;           // (a guessed start may see an end-of-block that is none; a true one ends what anybody uses of this lane)
+                f |= 1u; break;
+            }
+            if (MODE == 0 && unit_at + 1u < until) { c.init(s, unit_at + 1u); continue; }
+            f |= 2u; break;
         }
         const u32 le = (e >> 12) & 7u;
         const u32 len = 3u + ((e >> 4) & 0xffu) + bits_at(x, n, le);      // n + le <= 22 of the >= 33 bits
@@ -512,7 +520,7 @@ COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *f
         const u32 dl = ed & 15u, de = (ed >> 4) & 15u;
         const u32 dist = ((ed >> 8) & 0x7fffu) + bits_at(x, dl, de);      // dl + de <= 28
         c.drop(dl + de);
-        if ((e & 0xfff0u) == 0xfff0u || (ed & DIST_INVALID) != 0u) {      // no code of the set / symbols 286, 287, 30, 31
+        if ((ed & DIST_INVALID) != 0u) {            // no code of the set / symbols 30, 31
             if (MODE == 0 && unit_at + 1u < until) { c.init(s, unit_at + 1u); continue; }
             f |= 2u; break;
         }

@@ -717,6 +717,8 @@ namespace covi {
 static_assert(covw::TOK_CAP == INF_TOK_CAP && covw::OK == INF_OK && covw::ERR_FORMAT == INF_ERR_FORMAT && covw::ERR_SIZE == INF_ERR_SIZE, "the core mirrors k_inflate's contract");
 // ST: how pass 3 stores (covw::Sink<ST>; COVERM_INFLATE_WAVE_STORES) — which shape of scattered store the memory path likes is a measurement.
 // CUR: how far ahead a lane requests its compressed words (1: one word, 2: four to eight, 16 bytes per load; COVERM_INFLATE_WAVE_CURSOR).
+// (A cursor of two words and a funnel shift instead of the 64-bit buffer was tried: no fewer instructions per unit — each of the three
+// places that consume bits then carries the word roll.)
 // (Holding the register allocation to five waves per SIMD changed nothing, to six or seven cost 40 % in spills: profiles/r03_wave_variants2.log.)
 template <int ST, int CUR>
 __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,

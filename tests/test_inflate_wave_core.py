@@ -25,7 +25,7 @@ def host(request, tmp_path_factory):
     # exists with five store policies (covw::Sink<1..5>), each a kernel of its own on the device
     so = str(tmp_path_factory.mktemp("covw") / "covw_host.so")
     subprocess.check_call(["g++", "-O2", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "c", "inflate_wave_host.cpp"),
-                           "-DCOVW_STORES=" + request.param[7]] + (["-DCOVW_REVERSE"] if "63..0" in request.param else []) + (["-DCOVW_CURSOR=2"] if "cursor 2" in request.param else []))
+                           "-DCOVW_STORES=" + request.param[7]] + (["-DCOVW_REVERSE"] if "63..0" in request.param else []) + (["-DCOVW_CURSOR=" + request.param[-1]] if "cursor" in request.param else []))
     L = C.CDLL(so)
     L.covw_host_inflate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.covw_host_inflate.restype = C.c_int
