@@ -1278,8 +1278,12 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
         HIPCHK(hipEventRecord(s->ing_inf_done[bb], s->stream));
         HIPCHK(hipEventRecord(s->ing_cdone[w % 3u], s->stream));      // this round's compressed buffer may be overwritten (three rounds on)
         HIPCHK(hipStreamWaitEvent(s->ing_aux, s->ing_inf_done[bb], 0));
-        hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
-                           (const covi::tokpos_t *)tokb.p, (const u32 *)ntokb.p);
+        {
+            static const int lzu = getenv("COVERM_LZ_UNROLL") ? atoi(getenv("COVERM_LZ_UNROLL")) : 1;
+            auto lz = lzu == 2 ? covi::k_lz_resolve_u<2> : lzu == 4 ? covi::k_lz_resolve_u<4> : lzu == 8 ? covi::k_lz_resolve_u<8> : covi::k_lz_resolve;
+            hipLaunchKernelGGL(lz, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
+                               (const covi::tokpos_t *)tokb.p, (const u32 *)ntokb.p);
+        }
         // the window's bytes are final once the matches are resolved: the boundary search (parse stream) starts here, beside the
         // CRC-32 pass, whose verdict is only looked at in cov_ingest_end (the aux stream is in order, so CRC(w) is done before LZ(w + 1)
         // and with it before anything may overwrite window w)

@@ -821,6 +821,82 @@ __global__ __launch_bounds__(256) void k_lz_resolve(const BgzfBlock *__restrict_
     }
 }
 
+// The same with the copy loop taking U groups of 64 bytes per trip (COVERM_LZ_UNROLL = 2 | 4 | 8; opt-in until measured): in k_lz_resolve every
+// 64 bytes cost a full load-to-store round trip, because a later load may not pass an earlier store to what could be the same address.
+template <int U>
+__global__ __launch_bounds__(256) void k_lz_resolve_u(const BgzfBlock *__restrict__ blocks, u32 n_blocks, uint8_t *__restrict__ out,
+                                                    const tokpos_t *__restrict__ tok, const u32 *__restrict__ n_tok) {
+    const int lane = threadIdx.x & 63;
+    const u32 b = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (b >= n_blocks) return;
+    const u32 nt = n_tok[b];
+    if (nt == 0u) return;
+    uint8_t *dst = out + blocks[b].out_off;
+    const tokpos_t *my = tok + (size_t)b * INF_TOK_CAP;
+    for (u32 t0 = 0; t0 < nt; t0 += 64u) {
+        const u32 t = t0 + (u32)lane;
+        const bool have = t < nt;
+        const u32 pos = have ? (u32)my[t] : 0xffffffffu;
+        u32 t24 = 0;
+        if (have) { const uint8_t *tp = dst + pos; t24 = (u32)tp[0] | ((u32)tp[1] << 8) | ((u32)tp[2] << 16); }    // written by k_inflate (the kernel before this one)
+        const u32 len = have ? ((t24 >> 15) & 0xffu) + 3u : 0u, dist = have ? (t24 & 0x7fffu) + 1u : 0u;
+        const u32 src_lo = pos - dist, src_end = pos - dist + min(len, dist), dst_end = pos + len;
+        // Output ranges of the window's tokens are disjoint and increasing with the lane, so the tokens whose output overlaps
+        // this lane's source range form a contiguous lane interval [dep_lo, dep_hi): dep_hi = lanes with pos < src_end,
+        // dep_lo = lanes with dst_end <= src_lo.  Two binary searches over the lanes (6 shuffles each), once per window.
+        u32 dep_hi = 0, dep_lo = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            const u32 p_hi = (u32)__shfl((int)pos, (int)(dep_hi + step - 1)), e_lo = (u32)__shfl((int)dst_end, (int)(dep_lo + step - 1));
+            const bool v_hi = dep_hi + step <= 64u, v_lo = dep_lo + step <= 64u;
+            if (v_hi && p_hi < src_end) dep_hi += step;
+            const bool lo_have = (u32)__shfl((int)(have ? 1 : 0), (int)(dep_lo + step - 1)) != 0u;
+            if (v_lo && lo_have && e_lo <= src_lo) dep_lo += step;
+        }
+        dep_hi = min(dep_hi, (u32)lane);            // only earlier tokens matter
+        const u64 dep_mask = dep_hi > dep_lo ? ((dep_hi - dep_lo >= 64u ? ~0ull : ((1ull << (dep_hi - dep_lo)) - 1ull)) << dep_lo) : 0ull;
+        u64 todo = __ballot(have);
+        while (todo) {
+            const bool go = have && ((todo >> lane) & 1ull) && (todo & dep_mask) == 0ull;
+            // The bytes of all ready matches of this round, concatenated, are copied 64 at a time, one byte per lane: a match of
+            // 200 bytes costs four wave steps, not 200 dependent round trips of its one lane.  Owner of byte x = the lane whose
+            // running length first exceeds x (binary search over the lanes' inclusive prefix sums, 6 shuffles).
+            const u32 glen = go ? len : 0u;
+            const u32 incl = wave_incl_scan_u32(glen), excl = incl - glen;
+            const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            // U groups of 64 bytes at a time: the sources of a round's matches are final and none of its stores touches them (a match
+            // whose source another match of the window writes is not ready), so the U loads are issued back to back and waited for once
+            for (u32 base = 0; base < total; base += 64u * (u32)U) {
+                u32 val[U], at[U]; bool ok[U];
+#pragma unroll
+                for (int g = 0; g < U; g++) {
+                    const u32 x = base + 64u * (u32)g + (u32)lane;
+                    u32 o = 0;
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1) {
+                        const u32 v = (u32)__shfl((int)incl, (int)(o + step - 1));
+                        if (v <= x) o += step;
+                    }
+                    const u32 oc = min(o, 63u);
+                    const u32 po = (u32)__shfl((int)pos, (int)oc), dd = (u32)__shfl((int)dist, (int)oc), ex = (u32)__shfl((int)excl, (int)oc),
+                              ln = (u32)__shfl((int)len, (int)oc);
+                    ok[g] = x < total;
+                    const u32 k = x - ex;
+                    const u32 sk = dd >= ln ? k : k % max(dd, 1u);
+                    // every lane loads (the lanes behind the round's last byte from the block's first byte): no branch around the load, so
+                    // nothing needs its value before the stores below
+                    val[g] = (u32)__hip_atomic_load(dst + (ok[g] ? po - dd + sk : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    at[g] = po + k;
+                }
+#pragma unroll
+                for (int g = 0; g < U; g++) if (ok[g]) dst[at[g]] = (uint8_t)val[g];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            todo &= ~__ballot(go);
+        }
+    }
+}
+
 // CRC-32 of every inflated block against its BGZF trailer (htslib checks it in bgzf.c:inflate_block): one lane per block,
 // slicing-by-4 tables in LDS (4 bytes per dependent step).  Only 4 KiB of LDS per workgroup, so the CU is full of waves and the
 // per-step LDS latency overlaps.
