@@ -2,7 +2,8 @@
 //
 // Lane-per-block inflate (k_inflate) keeps a private Huffman table per lane in LDS, which bounds the resident lanes, and decodes a
 // block serially, which sets the latency of a round.  Here the 64 lanes of a wave share ONE set of tables and each decodes 1/64 of
-// the block's bit stream (share i = bits [B0 + i * S, B0 + (i + 1) * S) behind the block header):
+// a CHUNK of the block's bit stream (share i = bits [cur + i * S, cur + (i + 1) * S); the first DEFLATE block of a payload is one
+// chunk, see inflate_block):
 //   pass 1  where does the first unit (literal | length + extra + distance + extra | end of block) of share i begin?  Lane i starts
 //           OVERLAP bits in front of its share as if a unit began there and decodes up to the share: Huffman streams self-synchronise
 //           — on BAM blocks a decoder started at an arbitrary bit is in step with the true sequence after a median of 6 units, 70 at most
@@ -10,14 +11,14 @@
 //   pass 2  lane i decodes exactly the units that begin in its share, from where pass 1 says they begin, and counts output bytes and
 //           matches.  Where it ends must be where lane i + 1 began: if not, lane i + 1 takes the end as its beginning and the pass is
 //           repeated (lane k is exact after round k whatever pass 1 guessed; normally there is one round).  The lanes up to the first
-//           end-of-block symbol are the Huffman block; the rest of the wave decoded what belongs to the next DEFLATE block with the wrong
-//           tables and is discarded;
+//           end-of-block symbol are what is left of the block; the rest of the wave decoded what belongs to the next DEFLATE block with
+//           the wrong tables and is discarded;
 //   pass 3  output offsets = prefix sums of the counts; every lane decodes its units once more and writes: literals at their final
 //           positions, a match as a 3-byte token in place + its 16-bit position in the block's token list (k_lz_resolve's contract,
-//           unchanged).  No store touches a byte that another lane owns; within its own bytes a lane writes front to back and may run over
-//           what it (or k_lz_resolve) writes later: pending literals and the token behind them leave as one 8-byte store.
-// Header parsing and the per-length tables are serial (lane 0); the lookup tables are filled in parallel, one INDEX per lane step
-// (an index is decoded canonically like a long code), so no lane writes more entries than another.
+//           unchanged).  No store touches a byte that another lane owns; how the bytes leave is a policy (Sink<1..5>).
+// The block header and the code lengths are parsed by lane 0 (a Huffman-coded list is serial); both codes are then built by the whole
+// wave — symbols counted and marked per length with LDS atomics, ranked by population count — and the lookup tables filled one INDEX
+// per lane step (an index is decoded canonically like a long code), so no lane writes more entries than another.
 //
 // This file contains no HIP: it is a sequence of `COVW_PARFOR(lane) { ... }` regions over wave-shared state, separated by wave
 // barriers.  csrc/ingest_kernels.hip.h instantiates it with lane = the thread and LDS-resident state; tests/c/inflate_wave_host.cpp
@@ -53,7 +54,7 @@ typedef unsigned char u8;
 
 #ifndef COVW_LB
 #define COVW_LB 10      // 2 KiB + 1 KiB of lookup tables: some lane of 64 meets a longer literal code in 67 % of the steps (62 % at 11 bits), a longer
-#define COVW_DB 8       // distance code in 6 % (1 % at 9 bits) — tools/proto/wave_cost_model.cpp — and the wave state stays at 6.2 KiB: 25 waves per CU
+#define COVW_DB 8       // distance code in 6 % (1 % at 9 bits) — profiles/r03_wave_cost_model.log — and the wave state stays at 7.3 KiB: 21 waves per CU
 #endif
 constexpr u32 LB = COVW_LB, DB = COVW_DB;  // index bits of the lookup tables of the literal/length and the distance alphabet
 constexpr u32 TOK_CAP = 21888;            // = covi::INF_TOK_CAP
