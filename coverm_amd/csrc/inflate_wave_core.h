@@ -398,17 +398,22 @@ template <> struct Sink<3> {
 // behind a match's token the FIFO jumps to the word the match ends in (what it skips are the match's own bytes).  Byte stores only in the
 // lane's first and last word, which it may share with its neighbours.
 template <> struct Sink<4> {
-    u8 *out; u16 *tok; u64 acc; u32 lo, own_end, ab, nb;       // acc: bytes [ab, ab + nb) of the block, ab a multiple of four
-    COVW_FN void init(u8 *o, u16 *t, u32 first, u32 end, u32 *) { out = o; tok = t; lo = first; own_end = end; ab = first & ~3u; nb = first & 3u; acc = 0; }
+    // positions inside the sink are relative to `base` = the block's output pointer rounded down to 16 bytes, so that "aligned" means the
+    // address, not the offset inside the block (a block begins wherever the one before it ended)
+    u8 *base; u16 *tok; u64 acc; u32 bias, lo, own_end, ab, nb;       // acc: bytes [ab, ab + nb), ab a multiple of four
+    COVW_FN void init(u8 *o, u16 *t, u32 first, u32 end, u32 *) {
+        bias = (u32)((uintptr_t)o & 15u); base = o - bias; tok = t;
+        lo = first + bias; own_end = end + bias; ab = lo & ~3u; nb = lo & 3u; acc = 0;
+    }
     COVW_FN void word() {                                       // the low word of acc leaves
-        if (ab >= lo && ab + 4u <= own_end) store4(out + ab, (u32)acc);
-        else for (u32 k = 0; k < 4u; k++) if (ab + k >= lo && ab + k < own_end) out[ab + k] = (u8)(acc >> (8u * k));
+        if (ab >= lo && ab + 4u <= own_end) store4(base + ab, (u32)acc);
+        else for (u32 k = 0; k < 4u; k++) if (ab + k >= lo && ab + k < own_end) base[ab + k] = (u8)(acc >> (8u * k));
     }
     COVW_FN void shift() { if (nb >= 4u) { word(); acc >>= 32; ab += 4u; nb -= 4u; } }
     COVW_FN void literal(u32, u32 b) { acc |= (u64)b << (8u * nb); nb++; shift(); }
     COVW_FN void match(u32 p, u32 len, u32 t24, u32 k) {
         acc |= (u64)t24 << (8u * nb); nb += 3u; shift();           // nb <= 6 before, <= 2 after
-        const u32 q = p + len;
+        const u32 q = p + bias + len;
         if ((q >> 2) != (ab >> 2)) { if (nb) word(); ab = q & ~3u; nb = q & 3u; acc = 0; }
         else nb = q - ab;
         tok[k] = (u16)p;
@@ -421,14 +426,17 @@ template <> struct Sink<4> {
 // quarter cache line.  A line is stored once; what it holds beyond the lane's valid bytes are bytes of a match (stale words of the
 // line before: k_lz_resolve overwrites them) — or bytes outside the lane's range, and then the line leaves byte by byte instead.
 template <> struct Sink<5> {
-    u8 *out; u16 *tok; u32 *ring; u64 acc; u32 lo, own_end, ab, nb;
-    COVW_FN void init(u8 *o, u16 *t, u32 first, u32 end, u32 *r) { out = o; tok = t; ring = r; lo = first; own_end = end; ab = first & ~3u; nb = first & 3u; acc = 0; }
+    u8 *base; u16 *tok; u32 *ring; u64 acc; u32 bias, lo, own_end, ab, nb;      // positions relative to the 16-byte-aligned `base`, as in 4
+    COVW_FN void init(u8 *o, u16 *t, u32 first, u32 end, u32 *r) {
+        bias = (u32)((uintptr_t)o & 15u); base = o - bias; tok = t; ring = r;
+        lo = first + bias; own_end = end + bias; ab = lo & ~3u; nb = lo & 3u; acc = 0;
+    }
     COVW_FN void line(u32 L) {                                  // bytes [L, L + 16) leave
         const u32 w0 = ring[0], w1 = ring[64], w2 = ring[128], w3 = ring[192];
-        if (L >= lo && L + 16u <= own_end) { const u32 v[4] = {w0, w1, w2, w3}; __builtin_memcpy(out + L, v, 16); }
+        if (L >= lo && L + 16u <= own_end) { const u32 v[4] = {w0, w1, w2, w3}; __builtin_memcpy(__builtin_assume_aligned(base + L, 16), v, 16); }
         else {
             const u64 a = (u64)w0 | ((u64)w1 << 32), b = (u64)w2 | ((u64)w3 << 32);
-            for (u32 k = 0; k < 16u; k++) if (L + k >= lo && L + k < own_end) out[L + k] = (u8)((k < 8u ? a : b) >> (8u * (k & 7u)));
+            for (u32 k = 0; k < 16u; k++) if (L + k >= lo && L + k < own_end) base[L + k] = (u8)((k < 8u ? a : b) >> (8u * (k & 7u)));
         }
     }
     COVW_FN void put() { ring[((ab >> 2) & 3u) * 64u] = (u32)acc; }      // the low word of acc into the line
@@ -442,7 +450,7 @@ template <> struct Sink<5> {
     COVW_FN void literal(u32, u32 b) { acc |= (u64)b << (8u * nb); nb++; shift(); }
     COVW_FN void match(u32 p, u32 len, u32 t24, u32 k) {
         acc |= (u64)t24 << (8u * nb); nb += 3u; shift();
-        const u32 q = p + len;
+        const u32 q = p + bias + len;
         if ((q >> 2) != (ab >> 2)) {
             if (nb) put();
             if ((q >> 4) != (ab >> 4) && (nb || (ab & 15u))) line(ab & ~15u);

@@ -49,7 +49,10 @@ static int run(int stores, int cursor, const std::vector<uint8_t> &payload, uint
     uint32_t *words = static_cast<uint32_t *>(malloc((nbytes + 3) / 4 * 4));
     for (size_t k = 0; k < (nbytes + 3) / 4; k++) words[k] = rnd();
     memcpy(reinterpret_cast<uint8_t *>(words) + misalign, payload.data(), payload.size());
-    uint8_t *out = static_cast<uint8_t *>(malloc(isize ? isize : 1));
+    const uint32_t off = rnd() & 15u;                                        // a block's output begins at any address
+    uint8_t *out_alloc = static_cast<uint8_t *>(malloc(isize + off + (isize + off ? 0 : 1)));
+    memset(out_alloc, 0x5A, off);
+    uint8_t *out = out_alloc + off;
     uint16_t *tok = static_cast<uint16_t *>(malloc(covw::TOK_CAP * 2));
     static covw::Wave W;
     uint32_t nt = 0, st = 0;
@@ -71,7 +74,8 @@ static int run(int stores, int cursor, const std::vector<uint8_t> &payload, uint
         }
         if (rc == 0 && want && (want->size() != isize || memcmp(want->data(), out, isize) != 0)) rc = -3;
     }
-    free(words); free(out); free(tok);
+    for (uint32_t k = 0; k < off; k++) if (out_alloc[k] != 0x5A) rc = -4;    // wrote in front of the block
+    free(words); free(out_alloc); free(tok);
     return rc;
 }
 
@@ -106,7 +110,7 @@ int main(int argc, char **argv) {
             else bad[0] = (uint8_t)rnd();
             const uint32_t isz = (rnd() & 3u) ? size : (rnd() % 65536u);
             const int b = run(stores, cursor, bad, rnd() & 3u, isz, nullptr);
-            if (b == -2) { fprintf(stderr, "round %d: status OK with a token outside the block\n", r); return 1; }
+            if (b == -2 || b == -4) { fprintf(stderr, "round %d: status OK with a token outside the block, or bytes written in front of it (%d)\n", r, b); return 1; }
             if (b != 0) rejected++; else differ++;
         }
     }
