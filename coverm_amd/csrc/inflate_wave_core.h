@@ -15,7 +15,7 @@
 //           the wrong tables and is discarded;
 //   pass 3  output offsets = prefix sums of the counts; every lane decodes its units once more and writes: literals at their final
 //           positions, a match as a 3-byte token in place + its 16-bit position in the block's token list (k_lz_resolve's contract,
-//           unchanged).  No store touches a byte that another lane owns; how the bytes leave is a policy (Sink<1..5>).
+//           unchanged).  No store touches a byte that another lane owns; how the bytes leave is a policy (Sink<1..6>).
 // The block header and the code lengths are parsed by lane 0 (a Huffman-coded list is serial); both codes are then built by the whole
 // wave — symbols counted and marked per length with LDS atomics, ranked by population count — and the lookup tables filled one INDEX
 // per lane step (an index is decoded canonically like a long code), so no lane writes more entries than another.
@@ -97,7 +97,6 @@ struct Wave {                             // wave-shared state (LDS on the devic
     u16 climit[16], coff[16];             // the code-length code ...
     u8 csorted[32], cl[32];
     u8 cltab[128];                        // ... and its lookup table: (symbol << 3) | code length by the next 7 bits, 0 = no code
-    u32 ring[4 * 64];                     // Sink<5>: every lane's current 16-byte output line, word k of lane l at [k * 64 + l]
 };
 
 struct Src { const u32 *w; u32 total_bits; };     // aligned words of the payload (readable 64 bytes past its end); bit 0 = bit 0 of w[0]
@@ -319,7 +318,7 @@ COVW_FN void store_bytes(u8 *d, u64 v, u32 n) {        // exactly n <= 8 bytes o
     if (n & 2u) { const u16 x = (u16)v; __builtin_memcpy(d, &x, 2); d += 2; v >>= 16; }
     if (n & 1u) *d = (u8)v;
 }
-// ---- pass 3's output of one lane, in five versions (COVW_STORES; the kernel is bound by its scattered stores, and which shape of store the
+// ---- pass 3's output of one lane, in six versions (COVW_STORES; the kernel is bound by its scattered stores, and which shape of store the
 // memory path likes is a measurement: profiles/r03_wave_variants*.log).  A lane writes its bytes front to back, bytes [lo, own_end) of the
 // block; it may run over bytes of its OWN range that come later (it overwrites them, or they are a match's and k_lz_resolve does), never
 // past own_end, where the next lane's bytes begin.  literal(p, b): byte b belongs at p; match(p, len, t24, k): a match of len bytes begins
@@ -425,25 +424,31 @@ template <> struct Sink<4> {
 // leaves as ONE aligned 16-byte store when the lane moves out of it — a quarter of the store instructions of 4, each a full aligned
 // quarter cache line.  A line is stored once; what it holds beyond the lane's valid bytes are bytes of a match (stale words of the
 // line before: k_lz_resolve overwrites them) — or bytes outside the lane's range, and then the line leaves byte by byte instead.
-template <> struct Sink<5> {
-    u8 *base; u16 *tok; u32 *ring; u64 acc; u32 bias, lo, own_end, ab, nb;      // positions relative to the 16-byte-aligned `base`, as in 4
+template <u32 LW> struct LineSink {       // LW words per line: 4 (16 bytes, one store) or 16 (64 bytes = one memory request, four stores back to back)
+    static constexpr u32 LBYTES = 4u * LW;
+    u8 *base; u16 *tok; u32 *ring; u64 acc; u32 bias, lo, own_end, ab, nb;      // positions relative to the 64-byte-aligned `base`, as in 4
     COVW_FN void init(u8 *o, u16 *t, u32 first, u32 end, u32 *r) {
-        bias = (u32)((uintptr_t)o & 15u); base = o - bias; tok = t; ring = r;
+        bias = (u32)((uintptr_t)o & 63u); base = o - bias; tok = t; ring = r;
         lo = first + bias; own_end = end + bias; ab = lo & ~3u; nb = lo & 3u; acc = 0;
     }
-    COVW_FN void line(u32 L) {                                  // bytes [L, L + 16) leave
-        const u32 w0 = ring[0], w1 = ring[64], w2 = ring[128], w3 = ring[192];
-        if (L >= lo && L + 16u <= own_end) { const u32 v[4] = {w0, w1, w2, w3}; __builtin_memcpy(__builtin_assume_aligned(base + L, 16), v, 16); }
-        else {
-            const u64 a = (u64)w0 | ((u64)w1 << 32), b = (u64)w2 | ((u64)w3 << 32);
-            for (u32 k = 0; k < 16u; k++) if (L + k >= lo && L + k < own_end) base[L + k] = (u8)((k < 8u ? a : b) >> (8u * (k & 7u)));
+    COVW_FN void line(u32 L) {                                  // bytes [L, L + LBYTES) leave
+        if (L >= lo && L + LBYTES <= own_end) {
+            COVW_NO_UNROLL               // (sixteen words in flight at once were 32 more registers for the whole kernel)
+            for (u32 k = 0; k < LW; k += 4u) {
+                const u32 v[4] = {ring[k * 64u], ring[(k + 1u) * 64u], ring[(k + 2u) * 64u], ring[(k + 3u) * 64u]};
+                __builtin_memcpy(__builtin_assume_aligned(base + L + 4u * k, 16), v, 16);
+            }
+        } else {
+            COVW_NO_UNROLL
+            for (u32 k = 0; k < LBYTES; k++)
+                if (L + k >= lo && L + k < own_end) base[L + k] = (u8)(ring[(k >> 2) * 64u] >> (8u * (k & 3u)));
         }
     }
-    COVW_FN void put() { ring[((ab >> 2) & 3u) * 64u] = (u32)acc; }      // the low word of acc into the line
+    COVW_FN void put() { ring[((ab >> 2) & (LW - 1u)) * 64u] = (u32)acc; }      // the low word of acc into the line
     COVW_FN void shift() {
         if (nb >= 4u) {
             put();
-            if ((ab & 12u) == 12u) line(ab & ~15u);
+            if ((ab & (LBYTES - 4u)) == LBYTES - 4u) line(ab & ~(LBYTES - 1u));
             acc >>= 32; ab += 4u; nb -= 4u;
         }
     }
@@ -453,16 +458,21 @@ template <> struct Sink<5> {
         const u32 q = p + bias + len;
         if ((q >> 2) != (ab >> 2)) {
             if (nb) put();
-            if ((q >> 4) != (ab >> 4) && (nb || (ab & 15u))) line(ab & ~15u);
+            if ((q / LBYTES) != (ab / LBYTES) && (nb || (ab & (LBYTES - 1u)))) line(ab & ~(LBYTES - 1u));
             ab = q & ~3u; nb = q & 3u; acc = 0;
         } else nb = q - ab;
         tok[k] = (u16)p;
     }
     COVW_FN void finish(u32) {
         if (nb) put();
-        if (nb || (ab & 15u)) line(ab & ~15u);
+        if (nb || (ab & (LBYTES - 1u))) line(ab & ~(LBYTES - 1u));
     }
 };
+template <> struct Sink<5> : LineSink<4> {};
+// 6: aligned 64-byte lines — what the memory side moves in one request.  A partly written cache line that is evicted before the lane
+// gets to its end costs a masked write or a read-modify-write further out, and with 64 lanes x 16 waves x 32 CUs writing front to back
+// through their own KiB there are as many lines open per L2 as it holds.
+template <> struct Sink<6> : LineSink<16> {};
 
 #ifndef COVW_STORES
 #define COVW_STORES 2      // the fastest measured so far (profiles/r03_wave_variants2.log)
@@ -554,8 +564,10 @@ COVW_FN u32 share_begin_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
 // One BGZF block.  comp_words: aligned words holding the raw DEFLATE payload from bit `bit0` on; out: the block's `isize` output
 // bytes; tok: its token-position list.  *status = OK / ERR_*, *n_tok = matches written (0 unless OK).
 // stop_after (measurements only, 0 in production): 1 = give up after the tables are built, 2 = after pass 1, 3 = after pass 2.
+// ring: wave-shared line buffers of Sink<5> (4 x 64 words) / Sink<6> (16 x 64 words): word k of lane l at [k * 64 + l]; unused otherwise.
 template <int ST = COVW_STORES, int CUR = COVW_CURSOR>
-COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0) {
+COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0,
+                           u32 *ring = nullptr) {
     Src s; s.w = comp_words; s.total_bits = bit0 + payload_bits;
     u32 pos = bit0, opos = 0, ntok = 0, err = OK, nblk = 0, chunk_bits = 0;
     bool last = false;
@@ -712,7 +724,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                     const u32 from = lane ? W.end[lane - 1u] : cur;
                     const u32 ge = share_begin_of(cur, S, lane + 1u, span_end);
                     u32 f, nb, nt, e2 = OK;
-                    if (from < ge) (void)run_share<2, ST, CUR>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], opos + W.obase[lane] + W.nbytes[lane], tok, ntok + W.tbase[lane], &e2, W.ring + lane);
+                    if (from < ge) (void)run_share<2, ST, CUR>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], opos + W.obase[lane] + W.nbytes[lane], tok, ntok + W.tbase[lane], &e2, ring + lane);
                     if (e2 != OK) W.hdr[6] = e2;
                 }
             }

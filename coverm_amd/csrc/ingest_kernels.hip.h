@@ -720,11 +720,13 @@ static_assert(covw::TOK_CAP == INF_TOK_CAP && covw::OK == INF_OK && covw::ERR_FO
 // (A cursor of two words and a funnel shift instead of the 64-bit buffer was tried: no fewer instructions per unit — each of the three
 // places that consume bits then carries the word roll.)
 // (Holding the register allocation to five waves per SIMD changed nothing, to six or seven cost 40 % in spills: profiles/r03_wave_variants2.log.)
+// (Four waves per SIMD = 128 registers: what most variants take by themselves, two or four more than that in the others.)
 template <int ST, int CUR>
-__global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_inflate_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                      uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
                                                      u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
     __shared__ covw::Wave W;
+    __shared__ u32 ring[ST == 6 ? 16 * 64 : ST == 5 ? 4 * 64 : 1];      // the line buffers of Sink<5> / Sink<6>
     const u32 b = blockIdx.x;
     if (b >= n_blocks) return;
     const BgzfBlock B = blocks[b];
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__
     if (B.isize != 0u) {
         const u32 mis = (u32)((u64)(comp + B.in_off) & 3u);
         covw::inflate_block<ST, CUR>(W, reinterpret_cast<const u32 *>(comp + B.in_off - mis), 8u * mis, 8u * B.in_len, out + B.out_off, B.isize,
-                                tok + (size_t)b * INF_TOK_CAP, &nt, &st, stop_after);
+                                tok + (size_t)b * INF_TOK_CAP, &nt, &st, stop_after, ring);
     }
     if ((threadIdx.x & 63u) == 0u) {
         n_tok[b] = nt; status[b] = st;

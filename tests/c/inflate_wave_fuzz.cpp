@@ -20,6 +20,7 @@ static inline unsigned covw_brev32(unsigned x) {
 }
 #include "../../coverm_amd/csrc/inflate_wave_core.h"
 
+static uint32_t g_ring[16 * 64];
 static uint64_t rng_state = 88172645463325252ull;
 static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
 
@@ -49,7 +50,7 @@ static int run(int stores, int cursor, const std::vector<uint8_t> &payload, uint
     uint32_t *words = static_cast<uint32_t *>(malloc((nbytes + 3) / 4 * 4));
     for (size_t k = 0; k < (nbytes + 3) / 4; k++) words[k] = rnd();
     memcpy(reinterpret_cast<uint8_t *>(words) + misalign, payload.data(), payload.size());
-    const uint32_t off = rnd() & 15u;                                        // a block's output begins at any address
+    const uint32_t off = rnd() & 63u;                                        // a block's output begins at any address
     uint8_t *out_alloc = static_cast<uint8_t *>(malloc(isize + off + (isize + off ? 0 : 1)));
     memset(out_alloc, 0x5A, off);
     uint8_t *out = out_alloc + off;
@@ -57,11 +58,12 @@ static int run(int stores, int cursor, const std::vector<uint8_t> &payload, uint
     static covw::Wave W;
     uint32_t nt = 0, st = 0;
     const uint32_t b0 = 8u * misalign, nb = 8u * (uint32_t)payload.size();
-    if (stores == 1) (cursor == 2 ? covw::inflate_block<1, 2> : covw::inflate_block<1, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0);
-    else if (stores == 2) (cursor == 2 ? covw::inflate_block<2, 2> : covw::inflate_block<2, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0);
-    else if (stores == 3) (cursor == 2 ? covw::inflate_block<3, 2> : covw::inflate_block<3, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0);
-    else if (stores == 4) (cursor == 2 ? covw::inflate_block<4, 2> : covw::inflate_block<4, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0);
-    else (cursor == 2 ? covw::inflate_block<5, 2> : covw::inflate_block<5, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0);
+    if (stores == 1) (cursor == 2 ? covw::inflate_block<1, 2> : covw::inflate_block<1, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
+    else if (stores == 2) (cursor == 2 ? covw::inflate_block<2, 2> : covw::inflate_block<2, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
+    else if (stores == 3) (cursor == 2 ? covw::inflate_block<3, 2> : covw::inflate_block<3, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
+    else if (stores == 4) (cursor == 2 ? covw::inflate_block<4, 2> : covw::inflate_block<4, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
+    else if (stores == 5) (cursor == 2 ? covw::inflate_block<5, 2> : covw::inflate_block<5, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
+    else (cursor == 2 ? covw::inflate_block<6, 2> : covw::inflate_block<6, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
     int rc = (int)st;
     if (st == covw::OK) {
         for (uint32_t t = 0; t < nt; t++) {                                  // k_lz_resolve, serially
@@ -91,8 +93,8 @@ int main(int argc, char **argv) {
             data[k] = kind == 0 ? (uint8_t)rnd() : kind == 1 ? (uint8_t)("ACGTN!#I"[rnd() & 7u]) : kind == 2 ? (uint8_t)(rnd() % 3u ? 0 : rnd()) : (uint8_t)(k * 7u >> (rnd() & 3u));
         const int level = (int)(rnd() % 10u), strategy = (rnd() & 7u) == 0 ? Z_FIXED : (rnd() & 7u) == 1 ? Z_HUFFMAN_ONLY : (rnd() & 7u) == 2 ? Z_RLE : Z_DEFAULT_STRATEGY;
         const std::vector<uint8_t> comp = deflate_raw(data, level, strategy, (rnd() & 3u) ? 1 : 2 + (int)(rnd() % 6u));
-        const int stores = 1 + r % 5;                                        // covw::Sink<1..5> in turn
-        const int cursor = 1 + (r / 5) % 2;
+        const int stores = 1 + r % 6;                                        // covw::Sink<1..6> in turn
+        const int cursor = 1 + (r / 6) % 2;
         const int a = run(stores, cursor, comp, rnd() & 3u, size, &data);
         if (a != 0) {
             fprintf(stderr, "round %d: valid stream (size %u level %d strategy %d) -> %d\n", r, size, level, strategy, a);

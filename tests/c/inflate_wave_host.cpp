@@ -22,6 +22,7 @@ static inline unsigned covw_brev32(unsigned x) {
 #include "../../coverm_amd/csrc/inflate_wave_core.h"
 
 static covw::Wave g_wave;
+static uint32_t g_ring[16 * 64];
 
 extern "C" {
 
@@ -37,7 +38,7 @@ int covw_host_inflate(const uint8_t *payload, uint32_t nbytes, uint32_t misalign
     covw::Wave &W = g_wave;
     uint32_t status = 0;
     W.rounds = 0;
-    covw::inflate_block<COVW_STORES, COVW_CURSOR>(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status);
+    covw::inflate_block<COVW_STORES, COVW_CURSOR>(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status, 0, g_ring);
     if (rounds) *rounds = W.rounds;
     for (int k = 0; k < 8; k++) if (out[k] != 0xC3 || out[8 + isize + k] != 0xC3) return -1;
     return (int)status;

@@ -52,7 +52,8 @@ int main(int argc, char **argv) {
         memcpy(words.data(), pay, plen);
         for (int m = 0; m < 3; m++) for (int l = 0; l < 64; l++) g_trace[m][l].clear();
         uint32_t nt = 0, st = 0;
-        covw::inflate_block(W, words.data(), 0, 8u * plen, out.data(), isize, tok.data(), &nt, &st);
+        static uint32_t ring[16 * 64];
+        covw::inflate_block(W, words.data(), 0, 8u * plen, out.data(), isize, tok.data(), &nt, &st, 0, ring);
         if (st != 0) { fprintf(stderr, "block %ld: status %u\n", nb, st); return 1; }
         rounds += W.rounds;
         for (int m = 0; m < 3; m++) {
