@@ -1255,8 +1255,8 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
             static const int cur = getenv("COVERM_INFLATE_WAVE_CURSOR") ? atoi(getenv("COVERM_INFLATE_WAVE_CURSOR")) : COVW_CURSOR;
             auto kern = covi::k_inflate_wave<COVW_STORES, COVW_CURSOR>;
 #define COV_WAVE_PICK(ST, CUR) if (st == ST && cur == CUR) kern = covi::k_inflate_wave<ST, CUR>;
-            COV_WAVE_PICK(1, 1) COV_WAVE_PICK(2, 1) COV_WAVE_PICK(3, 1) COV_WAVE_PICK(4, 1) COV_WAVE_PICK(5, 1) COV_WAVE_PICK(6, 1)
-            COV_WAVE_PICK(1, 2) COV_WAVE_PICK(2, 2) COV_WAVE_PICK(3, 2) COV_WAVE_PICK(4, 2) COV_WAVE_PICK(5, 2) COV_WAVE_PICK(6, 2)
+            COV_WAVE_PICK(1, 1) COV_WAVE_PICK(2, 1) COV_WAVE_PICK(3, 1) COV_WAVE_PICK(4, 1) COV_WAVE_PICK(5, 1) COV_WAVE_PICK(6, 1) COV_WAVE_PICK(7, 1)
+            COV_WAVE_PICK(1, 2) COV_WAVE_PICK(2, 2) COV_WAVE_PICK(3, 2) COV_WAVE_PICK(4, 2) COV_WAVE_PICK(5, 2) COV_WAVE_PICK(6, 2) COV_WAVE_PICK(7, 2)
 #undef COV_WAVE_PICK
             hipLaunchKernelGGL(kern, dim3(n), dim3(64), pad, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, tokb.p, ntokb.p,
                                s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);

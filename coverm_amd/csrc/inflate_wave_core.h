@@ -15,7 +15,7 @@
 //           the wrong tables and is discarded;
 //   pass 3  output offsets = prefix sums of the counts; every lane decodes its units once more and writes: literals at their final
 //           positions, a match as a 3-byte token in place + its 16-bit position in the block's token list (k_lz_resolve's contract,
-//           unchanged).  No store touches a byte that another lane owns; how the bytes leave is a policy (Sink<1..6>).
+//           unchanged).  No store touches a byte that another lane owns; how the bytes leave is a policy (Sink<1..7>).
 // The block header and the code lengths are parsed by lane 0 (a Huffman-coded list is serial); both codes are then built by the whole
 // wave — symbols counted and marked per length with LDS atomics, ranked by population count — and the lookup tables filled one INDEX
 // per lane step (an index is decoded canonically like a long code), so no lane writes more entries than another.
@@ -40,6 +40,9 @@
 #endif
 #ifndef COVW_NO_UNROLL
 #define COVW_NO_UNROLL
+#endif
+#ifndef COVW_TRACE_STORE
+#define COVW_TRACE_STORE(ptr, width) do { } while (0)       // tools/proto/wave_cost_model.cpp: store shapes per block
 #endif
 #ifndef COVW_TRACE_UNIT
 #define COVW_TRACE_UNIT(mode, flags) do { } while (0)      // tools/proto/wave_cost_model.cpp: lock-step cost model
@@ -310,15 +313,15 @@ COVW_FN void parse_code_lengths(Wave &W, const Src &s) {
     h[4] = c.pos;
 }
 
-COVW_FN void store8(u8 *d, u64 v) { __builtin_memcpy(d, &v, 8); }
-COVW_FN void store4(u8 *d, u32 v) { __builtin_memcpy(d, &v, 4); }
+COVW_FN void store8(u8 *d, u64 v) { COVW_TRACE_STORE(d, 8); __builtin_memcpy(d, &v, 8); }
+COVW_FN void store4(u8 *d, u32 v) { COVW_TRACE_STORE(d, 4); __builtin_memcpy(d, &v, 4); }
 COVW_FN void store_bytes(u8 *d, u64 v, u32 n) {        // exactly n <= 8 bytes of v
     if (n == 8u) { store8(d, v); return; }
     if (n & 4u) { store4(d, (u32)v); d += 4; v >>= 32; }
-    if (n & 2u) { const u16 x = (u16)v; __builtin_memcpy(d, &x, 2); d += 2; v >>= 16; }
-    if (n & 1u) *d = (u8)v;
+    if (n & 2u) { const u16 x = (u16)v; COVW_TRACE_STORE(d, 2); __builtin_memcpy(d, &x, 2); d += 2; v >>= 16; }
+    if (n & 1u) { COVW_TRACE_STORE(d, 1); *d = (u8)v; }
 }
-// ---- pass 3's output of one lane, in six versions (COVW_STORES; the kernel is bound by its scattered stores, and which shape of store the
+// ---- pass 3's output of one lane, in seven versions (COVW_STORES; the kernel is bound by its scattered stores, and which shape of store the
 // memory path likes is a measurement: profiles/r03_wave_variants*.log).  A lane writes its bytes front to back, bytes [lo, own_end) of the
 // block; it may run over bytes of its OWN range that come later (it overwrites them, or they are a match's and k_lz_resolve does), never
 // past own_end, where the next lane's bytes begin.  literal(p, b): byte b belongs at p; match(p, len, t24, k): a match of len bytes begins
@@ -337,7 +340,7 @@ template <> struct Sink<1> {
     COVW_FN void match(u32 p, u32 len, u32 t24, u32 k) {
         if (on) { store_bytes(out + p - on, obuf, on); obuf = 0; on = 0; }
         store_bytes(out + p, t24, len > 3u ? 4u : 3u);
-        tok[k] = (u16)p;
+        COVW_TRACE_STORE(tok + k, 2); tok[k] = (u16)p;
     }
     COVW_FN void finish(u32 p) { if (on) store_bytes(out + p - on, obuf, on); }
 };
@@ -388,7 +391,7 @@ template <> struct Sink<3> {
         const u64 v = (u64)obuf | ((u64)t24 << osh);                   // <= 3 literals + 3 token bytes
         if (p - on + 8u <= own_end) store8(out + p - on, v); else store_bytes(out + p - on, v, on + 3u);
         obuf = 0; osh = 0;
-        tok[k] = (u16)p;
+        COVW_TRACE_STORE(tok + k, 2); tok[k] = (u16)p;
     }
     COVW_FN void finish(u32 p) { if (osh) store_bytes(out + p - (osh >> 3), obuf, osh >> 3); }
 };
@@ -406,7 +409,7 @@ template <> struct Sink<4> {
     }
     COVW_FN void word() {                                       // the low word of acc leaves
         if (ab >= lo && ab + 4u <= own_end) store4(base + ab, (u32)acc);
-        else for (u32 k = 0; k < 4u; k++) if (ab + k >= lo && ab + k < own_end) base[ab + k] = (u8)(acc >> (8u * k));
+        else for (u32 k = 0; k < 4u; k++) if (ab + k >= lo && ab + k < own_end) { COVW_TRACE_STORE(base + ab + k, 1); base[ab + k] = (u8)(acc >> (8u * k)); }
     }
     COVW_FN void shift() { if (nb >= 4u) { word(); acc >>= 32; ab += 4u; nb -= 4u; } }
     COVW_FN void literal(u32, u32 b) { acc |= (u64)b << (8u * nb); nb++; shift(); }
@@ -415,7 +418,7 @@ template <> struct Sink<4> {
         const u32 q = p + bias + len;
         if ((q >> 2) != (ab >> 2)) { if (nb) word(); ab = q & ~3u; nb = q & 3u; acc = 0; }
         else nb = q - ab;
-        tok[k] = (u16)p;
+        COVW_TRACE_STORE(tok + k, 2); tok[k] = (u16)p;
     }
     COVW_FN void finish(u32) { if (nb) word(); }
 };
@@ -424,24 +427,48 @@ template <> struct Sink<4> {
 // leaves as ONE aligned 16-byte store when the lane moves out of it — a quarter of the store instructions of 4, each a full aligned
 // quarter cache line.  A line is stored once; what it holds beyond the lane's valid bytes are bytes of a match (stale words of the
 // line before: k_lz_resolve overwrites them) — or bytes outside the lane's range, and then the line leaves byte by byte instead.
-template <u32 LW> struct LineSink {       // LW words per line: 4 (16 bytes, one store) or 16 (64 bytes = one memory request, four stores back to back)
+// Token positions four at a time as aligned 8-byte stores (a lane's positions are consecutive slots of the block's list); the slots of
+// the lane's first and last group that are not its own leave as single 2-byte stores.
+struct TokFifo {
+    u16 *tok; u64 acc; u32 first, n;          // acc holds slots [first, first + n) of the list, first + n never crosses a group of four (by address)
+    COVW_FN void init(u16 *t) { tok = t; acc = 0; first = 0; n = 0; }
+    COVW_FN u32 slot_in_group(u32 k) const { return (u32)(((uintptr_t)(tok + k) >> 1) & 3u); }
+    COVW_FN void flush() {
+        if (n == 4u) { COVW_TRACE_STORE(tok + first, 8); __builtin_memcpy(__builtin_assume_aligned(tok + first, 8), &acc, 8); }
+        else for (u32 j = 0; j < n; j++) { COVW_TRACE_STORE(tok + first + j, 2); tok[first + j] = (u16)(acc >> (16u * j)); }
+        acc = 0; n = 0;
+    }
+    COVW_FN void push(u32 k, u32 p) {
+        if (n == 0u) first = k;
+        acc |= (u64)p << (16u * n); n++;
+        if (slot_in_group(k) == 3u) flush();       // the group's last slot: a full group iff the lane owns all four
+    }
+};
+
+template <u32 LW, bool TOKB> struct LineSink {       // LW words per line: 4 (16 bytes, one store) or 16 (64 bytes = one memory request, four stores back to back)
     static constexpr u32 LBYTES = 4u * LW;
+    TokFifo tf;
     u8 *base; u16 *tok; u32 *ring; u64 acc; u32 bias, lo, own_end, ab, nb;      // positions relative to the 64-byte-aligned `base`, as in 4
     COVW_FN void init(u8 *o, u16 *t, u32 first, u32 end, u32 *r) {
         bias = (u32)((uintptr_t)o & 63u); base = o - bias; tok = t; ring = r;
         lo = first + bias; own_end = end + bias; ab = lo & ~3u; nb = lo & 3u; acc = 0;
+        if (TOKB) tf.init(t);
     }
     COVW_FN void line(u32 L) {                                  // bytes [L, L + LBYTES) leave
         if (L >= lo && L + LBYTES <= own_end) {
             COVW_NO_UNROLL               // (sixteen words in flight at once were 32 more registers for the whole kernel)
             for (u32 k = 0; k < LW; k += 4u) {
                 const u32 v[4] = {ring[k * 64u], ring[(k + 1u) * 64u], ring[(k + 2u) * 64u], ring[(k + 3u) * 64u]};
+                COVW_TRACE_STORE(base + L + 4u * k, 16);
                 __builtin_memcpy(__builtin_assume_aligned(base + L + 4u * k, 16), v, 16);
             }
-        } else {
+        } else {                                                // the lane's first or last line: whole words where they are the lane's, bytes at the two ends
             COVW_NO_UNROLL
-            for (u32 k = 0; k < LBYTES; k++)
-                if (L + k >= lo && L + k < own_end) base[L + k] = (u8)(ring[(k >> 2) * 64u] >> (8u * (k & 3u)));
+            for (u32 k = 0; k < LW; k++) {
+                const u32 a = L + 4u * k, w = ring[k * 64u];
+                if (a >= lo && a + 4u <= own_end) store4(base + a, w);
+                else for (u32 j = 0; j < 4u; j++) if (a + j >= lo && a + j < own_end) { COVW_TRACE_STORE(base + a + j, 1); base[a + j] = (u8)(w >> (8u * j)); }
+            }
         }
     }
     COVW_FN void put() { ring[((ab >> 2) & (LW - 1u)) * 64u] = (u32)acc; }      // the low word of acc into the line
@@ -461,18 +488,21 @@ template <u32 LW> struct LineSink {       // LW words per line: 4 (16 bytes, one
             if ((q / LBYTES) != (ab / LBYTES) && (nb || (ab & (LBYTES - 1u)))) line(ab & ~(LBYTES - 1u));
             ab = q & ~3u; nb = q & 3u; acc = 0;
         } else nb = q - ab;
-        tok[k] = (u16)p;
+        if (TOKB) tf.push(k, p); else { COVW_TRACE_STORE(tok + k, 2); tok[k] = (u16)p; }
     }
     COVW_FN void finish(u32) {
         if (nb) put();
         if (nb || (ab & (LBYTES - 1u))) line(ab & ~(LBYTES - 1u));
+        if (TOKB && tf.n) tf.flush();
     }
 };
-template <> struct Sink<5> : LineSink<4> {};
+template <> struct Sink<5> : LineSink<4, false> {};
 // 6: aligned 64-byte lines — what the memory side moves in one request.  A partly written cache line that is evicted before the lane
 // gets to its end costs a masked write or a read-modify-write further out, and with 64 lanes x 16 waves x 32 CUs writing front to back
 // through their own KiB there are as many lines open per L2 as it holds.
-template <> struct Sink<6> : LineSink<16> {};
+template <> struct Sink<6> : LineSink<16, false> {};
+// 7: 6 with the token positions leaving four at a time, as aligned 8-byte stores — in 4 to 6 they are more than half of the store instructions
+template <> struct Sink<7> : LineSink<16, true> {};
 
 #ifndef COVW_STORES
 #define COVW_STORES 2      // the fastest measured so far (profiles/r03_wave_variants2.log)

@@ -726,7 +726,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                                                      uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
                                                      u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
     __shared__ covw::Wave W;
-    __shared__ u32 ring[ST == 6 ? 16 * 64 : ST == 5 ? 4 * 64 : 1];      // the line buffers of Sink<5> / Sink<6>
+    __shared__ u32 ring[ST >= 6 ? 16 * 64 : ST == 5 ? 4 * 64 : 1];      // the line buffers of Sink<5> / Sink<6> / Sink<7>
     const u32 b = blockIdx.x;
     if (b >= n_blocks) return;
     const BgzfBlock B = blocks[b];

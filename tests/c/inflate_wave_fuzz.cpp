@@ -54,7 +54,9 @@ static int run(int stores, int cursor, const std::vector<uint8_t> &payload, uint
     uint8_t *out_alloc = static_cast<uint8_t *>(malloc(isize + off + (isize + off ? 0 : 1)));
     memset(out_alloc, 0x5A, off);
     uint8_t *out = out_alloc + off;
-    uint16_t *tok = static_cast<uint16_t *>(malloc(covw::TOK_CAP * 2));
+    const uint32_t toff = rnd() & 3u;                                        // the list begins at any 2-byte address
+    uint16_t *tok_alloc = static_cast<uint16_t *>(malloc((covw::TOK_CAP + toff) * 2));
+    uint16_t *tok = tok_alloc + toff;
     static covw::Wave W;
     uint32_t nt = 0, st = 0;
     const uint32_t b0 = 8u * misalign, nb = 8u * (uint32_t)payload.size();
@@ -63,7 +65,8 @@ static int run(int stores, int cursor, const std::vector<uint8_t> &payload, uint
     else if (stores == 3) (cursor == 2 ? covw::inflate_block<3, 2> : covw::inflate_block<3, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
     else if (stores == 4) (cursor == 2 ? covw::inflate_block<4, 2> : covw::inflate_block<4, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
     else if (stores == 5) (cursor == 2 ? covw::inflate_block<5, 2> : covw::inflate_block<5, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
-    else (cursor == 2 ? covw::inflate_block<6, 2> : covw::inflate_block<6, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
+    else if (stores == 6) (cursor == 2 ? covw::inflate_block<6, 2> : covw::inflate_block<6, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
+    else (cursor == 2 ? covw::inflate_block<7, 2> : covw::inflate_block<7, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
     int rc = (int)st;
     if (st == covw::OK) {
         for (uint32_t t = 0; t < nt; t++) {                                  // k_lz_resolve, serially
@@ -77,7 +80,7 @@ static int run(int stores, int cursor, const std::vector<uint8_t> &payload, uint
         if (rc == 0 && want && (want->size() != isize || memcmp(want->data(), out, isize) != 0)) rc = -3;
     }
     for (uint32_t k = 0; k < off; k++) if (out_alloc[k] != 0x5A) rc = -4;    // wrote in front of the block
-    free(words); free(out_alloc); free(tok);
+    free(words); free(out_alloc); free(tok_alloc);
     return rc;
 }
 
@@ -93,8 +96,8 @@ int main(int argc, char **argv) {
             data[k] = kind == 0 ? (uint8_t)rnd() : kind == 1 ? (uint8_t)("ACGTN!#I"[rnd() & 7u]) : kind == 2 ? (uint8_t)(rnd() % 3u ? 0 : rnd()) : (uint8_t)(k * 7u >> (rnd() & 3u));
         const int level = (int)(rnd() % 10u), strategy = (rnd() & 7u) == 0 ? Z_FIXED : (rnd() & 7u) == 1 ? Z_HUFFMAN_ONLY : (rnd() & 7u) == 2 ? Z_RLE : Z_DEFAULT_STRATEGY;
         const std::vector<uint8_t> comp = deflate_raw(data, level, strategy, (rnd() & 3u) ? 1 : 2 + (int)(rnd() % 6u));
-        const int stores = 1 + r % 6;                                        // covw::Sink<1..6> in turn
-        const int cursor = 1 + (r / 6) % 2;
+        const int stores = 1 + r % 7;                                        // covw::Sink<1..7> in turn
+        const int cursor = 1 + (r / 7) % 2;
         const int a = run(stores, cursor, comp, rnd() & 3u, size, &data);
         if (a != 0) {
             fprintf(stderr, "round %d: valid stream (size %u level %d strategy %d) -> %d\n", r, size, level, strategy, a);

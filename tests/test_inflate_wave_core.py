@@ -19,10 +19,10 @@ ROOT = os.path.dirname(HERE)
 
 
 @pytest.fixture(scope="module", params=["stores 2, lanes 0..63", "stores 2, lanes 63..0", "stores 1, lanes 63..0", "stores 3, lanes 63..0", "stores 4, lanes 63..0",
-                                        "stores 4, lanes 0..63", "stores 5, lanes 63..0", "stores 5, lanes 0..63", "stores 2, lanes 63..0, cursor 2", "stores 5, lanes 0..63, cursor 2", "stores 6, lanes 63..0", "stores 6, lanes 0..63, cursor 2"])
+                                        "stores 4, lanes 0..63", "stores 5, lanes 63..0", "stores 5, lanes 0..63", "stores 2, lanes 63..0, cursor 2", "stores 5, lanes 0..63, cursor 2", "stores 6, lanes 63..0", "stores 6, lanes 0..63, cursor 2", "stores 7, lanes 63..0", "stores 7, lanes 0..63, cursor 2"])
 def host(request, tmp_path_factory):
     # the lanes of a COVW_PARFOR region run concurrently on the device; here they run one after the other, in both orders; and pass 3
-    # exists with six store policies (covw::Sink<1..6>), each a kernel of its own on the device
+    # exists with seven store policies (covw::Sink<1..7>), each a kernel of its own on the device
     so = str(tmp_path_factory.mktemp("covw") / "covw_host.so")
     subprocess.check_call(["g++", "-O2", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "c", "inflate_wave_host.cpp"),
                            "-DCOVW_STORES=" + request.param[7]] + (["-DCOVW_REVERSE"] if "63..0" in request.param else []) + (["-DCOVW_CURSOR=" + request.param[-1]] if "cursor" in request.param else []))

@@ -16,6 +16,13 @@ static std::vector<uint8_t> g_trace[3][64];
 #define COVW_PARFOR(lane) for (unsigned lane = 0; lane < 64u && ((g_lane = lane), true); lane++)
 #define COVW_SYNC() do { } while (0)
 #define COVW_TRACE_UNIT(mode, flags) g_trace[mode][g_lane].push_back((uint8_t)(flags))
+// store shapes: [width 1 2 4 8 16][aligned to its width?] lane-stores, and bytes written
+static double g_stores[5][2], g_store_bytes[2];
+static inline void trace_store(const void *p, unsigned w) {
+    const int wi = w == 1 ? 0 : w == 2 ? 1 : w == 4 ? 2 : w == 8 ? 3 : 4, al = ((uintptr_t)p & (w - 1)) == 0;
+    g_stores[wi][al]++; g_store_bytes[al] += w;
+}
+#define COVW_TRACE_STORE(ptr, width) trace_store((ptr), (width))
 static inline unsigned covw_brev32(unsigned x) {
     x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
     x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
@@ -36,7 +43,8 @@ int main(int argc, char **argv) {
     fclose(f);
     const long max_blocks = argc > 2 ? atol(argv[2]) : 400;
     static covw::Wave W;
-    std::vector<uint8_t> out(65536 + 16);
+    std::vector<uint8_t> out_v(65536 + 64 + 64);
+    uint8_t *const out_al = out_v.data() + (64 - ((uintptr_t)out_v.data() & 63));      // 64-byte aligned; the blocks' output begins at varying offsets behind it
     std::vector<uint16_t> tok(covw::TOK_CAP);
     Acc A[3];
     long p = 0, nb = 0, rounds = 0;
@@ -48,12 +56,12 @@ int main(int argc, char **argv) {
         const uint32_t plen = bsize - 12 - xlen - 8;
         p += bsize;
         if (isize < 30000) continue;
-        std::vector<uint32_t> words(plen / 4 + 8, 0);
+        std::vector<uint32_t> words(plen / 4 + 20, 0);
         memcpy(words.data(), pay, plen);
         for (int m = 0; m < 3; m++) for (int l = 0; l < 64; l++) g_trace[m][l].clear();
         uint32_t nt = 0, st = 0;
         static uint32_t ring[16 * 64];
-        covw::inflate_block(W, words.data(), 0, 8u * plen, out.data(), isize, tok.data(), &nt, &st, 0, ring);
+        covw::inflate_block(W, words.data(), 0, 8u * plen, out_al + (nb * 13) % 64, isize, tok.data(), &nt, &st, 0, ring);
         if (st != 0) { fprintf(stderr, "block %ld: status %u\n", nb, st); return 1; }
         rounds += W.rounds;
         for (int m = 0; m < 3; m++) {
@@ -85,7 +93,12 @@ int main(int argc, char **argv) {
         }
         nb++;
     }
-    printf("LB %u DB %u: %ld blocks, pass-2 rounds per block %.3f\n", covw::LB, covw::DB, nb, (double)rounds / nb);
+    printf("LB %u DB %u, stores %d: %ld blocks, pass-2 rounds per block %.3f\n", covw::LB, covw::DB, COVW_STORES, nb, (double)rounds / nb);
+    printf("lane-stores per block (width: unaligned + aligned):");
+    const int widths[5] = {1, 2, 4, 8, 16};
+    double tot = 0;
+    for (int w = 0; w < 5; w++) { if (g_stores[w][0] + g_stores[w][1] > 0) printf("  %dB: %.0f + %.0f", widths[w], g_stores[w][0] / nb, g_stores[w][1] / nb); tot += g_stores[w][0] + g_stores[w][1]; }
+    printf("  = %.0f stores, %.0f bytes through unaligned and %.0f through aligned ones\n", tot / nb, g_store_bytes[0] / nb, g_store_bytes[1] / nb);
     const char *names[3] = {"pass 1 (positions)", "pass 2 (count)    ", "pass 3 (write)    "};
     for (int m = 0; m < 3; m++) {
         const Acc &a = A[m];
