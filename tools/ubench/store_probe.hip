@@ -25,6 +25,22 @@ __global__ __launch_bounds__(64) void k_store(uint8_t *__restrict__ out, uint32_
     }
 }
 
+// the same address pattern read instead of written (k_bam_extract and k_lz_resolve read records and matches at any byte offset)
+template <int WIDTH>
+__global__ __launch_bounds__(64) void k_load(const uint8_t *__restrict__ in, uint32_t mis, uint32_t advance, uint32_t n_loads, uint64_t *__restrict__ sink) {
+    const uint8_t *p = in + (size_t)blockIdx.x * 65536u + (threadIdx.x & 63u) * 1024u + mis;
+    uint64_t acc = 0;
+    for (uint32_t k = 0; k < n_loads; k++) {
+        if (WIDTH == 1) acc += *p;
+        else if (WIDTH == 2) { uint16_t x; __builtin_memcpy(&x, p, 2); acc += x; }
+        else if (WIDTH == 4) { uint32_t x; __builtin_memcpy(&x, p, 4); acc += x; }
+        else if (WIDTH == 8) { uint64_t x; __builtin_memcpy(&x, p, 8); acc += x; }
+        else { uint64_t x[2]; __builtin_memcpy(x, p, 16); acc += x[0] ^ x[1]; }
+        p += advance;
+    }
+    if (acc == 0x123456789abcdefull) sink[0] = acc;      // never true for this data: keeps the loads alive
+}
+
 int main() {
     const uint32_t blocks = 81920;                                   // one round of the ingest
     uint8_t *out;
@@ -60,6 +76,33 @@ int main() {
         printf("width %2d  misaligned by %u  advance %2u: %8.3f ms  %7.1f ns per wave-store per CU  %7.1f GB/s payload  (%u stores per lane)\n", c.width, c.mis, c.advance,
                best, best * 1e6 / (wave_stores / cus), (double)blocks * 64 * n * c.advance / best / 1e6, n);
     }
+    uint64_t *sink;
+    CHK(hipMalloc(&sink, 8));
+    printf("loads, same address pattern:\n");
+    const Case lcases[] = {{1, 0, 1}, {2, 0, 2}, {2, 1, 2}, {4, 0, 4}, {4, 1, 4}, {4, 2, 4}, {8, 0, 8}, {8, 4, 8}, {8, 1, 8}, {16, 0, 16}, {16, 4, 16}, {16, 1, 16}};
+    for (const Case &c : lcases) {
+        const uint32_t n = 960u / c.advance;
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; rep++) {
+            CHK(hipEventRecord(e0, 0));
+            switch (c.width) {
+                case 1: hipLaunchKernelGGL(k_load<1>, dim3(blocks), dim3(64), 0, 0, out, c.mis, c.advance, n, sink); break;
+                case 2: hipLaunchKernelGGL(k_load<2>, dim3(blocks), dim3(64), 0, 0, out, c.mis, c.advance, n, sink); break;
+                case 4: hipLaunchKernelGGL(k_load<4>, dim3(blocks), dim3(64), 0, 0, out, c.mis, c.advance, n, sink); break;
+                case 8: hipLaunchKernelGGL(k_load<8>, dim3(blocks), dim3(64), 0, 0, out, c.mis, c.advance, n, sink); break;
+                default: hipLaunchKernelGGL(k_load<16>, dim3(blocks), dim3(64), 0, 0, out, c.mis, c.advance, n, sink); break;
+            }
+            CHK(hipEventRecord(e1, 0));
+            CHK(hipEventSynchronize(e1));
+            float ms = 0;
+            CHK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        const double wave_loads = (double)blocks * n;
+        printf("width %2d  misaligned by %u  advance %2u: %8.3f ms  %7.1f ns per wave-load per CU  %7.1f GB/s  (%u loads per lane)\n", c.width, c.mis, c.advance, best,
+               best * 1e6 / (wave_loads / cus), (double)blocks * 64 * n * c.advance / best / 1e6, n);
+    }
+    CHK(hipFree(sink));
     CHK(hipFree(out));
     return 0;
 }
