@@ -74,6 +74,13 @@ std::string g_create_error;
 
 }  // namespace
 
+// Which inflate kernel runs, how many blocks make one round (= one launch = one window of the inflated stream) and the size of the carry area.
+//   version 3 (default): k_inflate_wave, one wave per BGZF block; a round is as long as the parse wants it (windows bound the memory and set
+//                        the fill and drain of the pipeline);
+//   version 1 (COVERM_INFLATE_V=1): k_inflate, one LANE per block, private Huffman tables per lane in LDS — the second implementation the
+//                        tests compare with; a launch is cut to exactly the blocks resident at once (a lane decodes a block serially).
+struct InflateKernel { int version = 3; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ablate = 0; };
+
 struct cov_session {
     cov_config cfg{};
     hipStream_t stream = nullptr;
@@ -178,6 +185,7 @@ struct cov_session {
     covi::BgzfBlock *h_blocks = nullptr; size_t h_blocks_cap = 0;   // page-locked mirror of the block table (async uploads read from it)
     uint64_t ing_comp = 0, ing_infl = 0, ing_blocks = 0;
     bool ing_active = false;
+    InflateKernel ing_K;
     hipStream_t ing_copy = nullptr;
     // second upload queue: the halves of a large piece go to HBM through two DMA engines at once (one queue moved ~42 GB/s of
     // 32 MiB pieces between table uploads; the link does 57); joined into ing_copy before anything is recorded there
@@ -302,9 +310,9 @@ void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
 }
 
 // k_pileup_fast over every tile (it skips the ones k_ranges flagged TILE_F_SLOW)
-template <bool H, int R>
-void launch_fast_r(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    const size_t smem = pileup_fast_smem_bytes(H, R);
+template <bool H>
+void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
+    const size_t smem = pileup_fast_smem_bytes(H);
     // the dynamic-LDS limit and the occupancy are per-device facts, and span mode launches from one thread per device: cached per
     // device id, in atomics (two threads racing for the same device compute the same value)
     static std::atomic<int> occ_dev[64];
@@ -313,9 +321,9 @@ void launch_fast_r(cov_session *s, const PileupArgs &a, u32 n_tiles) {
     const u32 chunk = (u32)s->chunk_tiles;
     const u32 n_chunks = (n_tiles + chunk - 1) / chunk;
     if (!occ) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_fast<H, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_fast<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_pileup_fast<H, R>), 256, smem) != hipSuccess || nb < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_pileup_fast<H>), 256, smem) != hipSuccess || nb < 1) {
             (void)hipGetLastError();
             nb = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
         }
@@ -324,17 +332,7 @@ void launch_fast_r(cov_session *s, const PileupArgs &a, u32 n_tiles) {
     const char *wg_env = getenv("COVERM_WG_PER_CU");
     const u32 wg_per_cu = wg_env && atoi(wg_env) > 0 ? (u32)atoi(wg_env) : 8u * (u32)occ;
     const u32 grid = std::max(1u, std::min((n_chunks + 3) / 4, (u32)s->n_cus * wg_per_cu));
-    hipLaunchKernelGGL((k_pileup_fast<H, R>), dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
-}
-
-// COVERM_PILEUP_HREP = 2 | 4: that many copies of every histogram bin in LDS (fewer lanes adding to one address, fewer resident waves):
-// opt-in until it is measured
-template <bool H>
-void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    static const int hrep = getenv("COVERM_PILEUP_HREP") ? atoi(getenv("COVERM_PILEUP_HREP")) : 1;
-    if (H && hrep == 2) launch_fast_r<H, 2>(s, a, n_tiles);
-    else if (H && hrep == 4) launch_fast_r<H, 4>(s, a, n_tiles);
-    else launch_fast_r<H, 1>(s, a, n_tiles);
+    hipLaunchKernelGGL((k_pileup_fast<H>), dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
 }
 
 template <bool H, bool W>
@@ -1009,84 +1007,33 @@ cov_status cov_gathered(cov_session *root, uint32_t rank, cov_contig_stats *stat
 static_assert(sizeof(cov_bgzf_block) == sizeof(covi::BgzfBlock) && offsetof(cov_bgzf_block, in_len) == offsetof(covi::BgzfBlock, in_len) &&
               offsetof(cov_bgzf_block, out_off) == offsetof(covi::BgzfBlock, out_off), "cov_bgzf_block mirrors the device struct");
 
-// Which k_inflate instantiation runs (COVERM_INFLATE_BITS / COVERM_INFLATE_DIST_BITS: primary table sizes), how many of its
-// one-wave workgroups the device holds at once (= blocks per round = blocks per window), and the size of the carry area.
-struct InflateKernel { int version = 1; int lit_bits = 8, dist_bits = 6; bool sort8 = false; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; };
-// k_inflate2 instantiations (COVERM_INFLATE_V=2; the default is k_inflate)
-#define COV_INFLATE2_VARIANTS(X) X(8, 6, false) X(8, 5, false) X(7, 6, false) X(7, 5, false) X(6, 5, false) X(7, 6, true) X(7, 5, true) X(6, 5, true)
-#define COV_INFLATE_VARIANTS(X) X(9, 6, false) X(8, 6, false) X(7, 6, false) X(7, 5, false) X(6, 5, false) X(7, 6, true) X(6, 5, true) X(5, 5, true)
-static const InflateKernel &inflate_kernel(cov_session *s) {
-    static InflateKernel K;
-    static std::once_flag once;
-    std::call_once(once, [&]() {
-        const char *e = getenv("COVERM_INFLATE_BITS"), *d = getenv("COVERM_INFLATE_DIST_BITS");
-        const bool s8 = getenv("COVERM_INFLATE_SORT8") && atoi(getenv("COVERM_INFLATE_SORT8"));
-        const char *ve = getenv("COVERM_INFLATE_V");
-        K.version = ve && atoi(ve) == 2 ? 2 : (ve && atoi(ve) == 3 ? 3 : 1);      // k_inflate2 is correct but not faster (profiles/r03_inflate2_variants.log), k_inflate_wave is not measured yet: opt-in
-        const bool wave = K.version == 3;     // k_inflate_wave has no table-size variants; its rounds (= windows) are those of the default k_inflate
-        if (wave) K.version = 1;
-        const int lb = e && !wave ? atoi(e) : 7, db = d && !wave ? atoi(d) : (K.version == 2 ? 5 : (lb <= 6 ? 5 : 6));     // k_inflate: 7 + 6 bits, five waves per CU, the fastest measured (200 M reads: 0.71 s against 0.87 s at 8 + 6, 0.84 s at 6 + 5); k_inflate2: 7 + 5 = 32 KiB, five waves per CU
+constexpr int INF1_LB = 7, INF1_DB = 6;       // k_inflate's primary tables: 7 + 6 bits = 28 KiB per wave, five waves per CU (the fastest measured)
+constexpr u32 WAVE_ROUND_BLOCKS = 81920;
+// Decided once per ingest (cov_ingest_begin) and kept in the session: the switches are read there, never in a launch path.
+static InflateKernel choose_inflate_kernel(cov_session *s) {
+    InflateKernel K;
+    const char *ve = getenv("COVERM_INFLATE_V");
+    K.version = ve && atoi(ve) == 1 ? 1 : (ve && atoi(ve) == 4 ? 4 : 3);
+    if (K.version == 4) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)covi::inflate_lds_smem_bytes());
+    if (K.version == 1) {
         int per_cu = 0;
-        bool found = false;
-#define COV_INF2_SETUP(LB, DB, S8)                                                                                                             \
-        if (K.version == 2 && lb == LB && db == DB && s8 == S8) {                                                                              \
-            found = true; K.lit_bits = LB; K.dist_bits = DB; K.sort8 = S8;                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate2<LB, DB, S8>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)covi::inflate2_smem_bytes(LB, DB, S8));                                                             \
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate2<LB, DB, S8>, 64, covi::inflate2_smem_bytes(LB, DB, S8)); \
-        }
-        COV_INFLATE2_VARIANTS(COV_INF2_SETUP)
-#undef COV_INF2_SETUP
-        if (K.version == 2 && !found) {
-            found = true; K.lit_bits = 7; K.dist_bits = 5;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate2<7, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)covi::inflate2_smem_bytes(7, 5));
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate2<7, 5, false>, 64, covi::inflate2_smem_bytes(7, 5));
-        }
-#define COV_INF_SETUP(LB, DB, S8)                                                                                                              \
-        if (K.version == 1 && lb == LB && db == DB && s8 == S8) {                                                                                                \
-            found = true; K.lit_bits = LB; K.dist_bits = DB; K.sort8 = S8;                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, DB, S8>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)covi::inflate_smem_bytes(LB, DB, S8));                                                              \
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate<LB, DB, S8>, 64, covi::inflate_smem_bytes(LB, DB, S8)); \
-        }
-        COV_INFLATE_VARIANTS(COV_INF_SETUP)
-#undef COV_INF_SETUP
-        if (!found) {
-            K.lit_bits = 7; K.dist_bits = 6; K.sort8 = false;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<7, 6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)covi::inflate_smem_bytes(7, 6));
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate<7, 6, false>, 64, covi::inflate_smem_bytes(7, 6));
-        }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<INF1_LB, INF1_DB, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)covi::inflate_smem_bytes(INF1_LB, INF1_DB));
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, covi::k_inflate<INF1_LB, INF1_DB, false>, 64, covi::inflate_smem_bytes(INF1_LB, INF1_DB));
         if (per_cu <= 0) per_cu = 2;
-        if (wave) K.version = 3;
         K.round_blocks = (u32)s->n_cus * (u32)per_cu * 64u;
-        if (const char *w = getenv("COVERM_INGEST_ROUND_BLOCKS")) { const long v = atol(w); if (v >= 64) K.round_blocks = (u32)v / 64u * 64u; }   // tests: many small windows
-        if (const char *c = getenv("COVERM_INGEST_CARRY_KB")) { const long v = atol(c); if (v >= 1) K.carry = (u64)v << 10; }
-        K.carry = (K.carry + 63u) & ~63ull;
-        // compressed bytes one round may span: 32 KiB per block on average (BGZF blocks of BAM files compress to 15-25 KiB); a round of
-        // less compressible blocks simply closes earlier
-        K.cwin = std::max<u64>((u64)K.round_blocks * 32768u, 1ull << 20);
-        if (const char *c = getenv("COVERM_INGEST_CWIN_KB")) { const long v = atol(c); if (v >= 256) K.cwin = (u64)v << 10; }
-    });
+    } else K.round_blocks = WAVE_ROUND_BLOCKS;
+    if (const char *w = getenv("COVERM_INGEST_ROUND_BLOCKS")) { const long v = atol(w); if (v >= 64) K.round_blocks = (u32)v / 64u * 64u; }   // tests: many small windows
+    if (const char *c = getenv("COVERM_INGEST_CARRY_KB")) { const long v = atol(c); if (v >= 1) K.carry = (u64)v << 10; }
+    K.carry = (K.carry + 63u) & ~63ull;
+    // compressed bytes one round may span: 32 KiB per block on average (BGZF blocks of BAM files compress to 15-25 KiB); a round of
+    // less compressible blocks simply closes earlier
+    K.cwin = std::max<u64>((u64)K.round_blocks * 32768u, 1ull << 20);
+    if (const char *c = getenv("COVERM_INGEST_CWIN_KB")) { const long v = atol(c); if (v >= 256) K.cwin = (u64)v << 10; }
+    K.ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);      // measurements: stop every block after the tables / pass 1 / pass 2
     return K;
 }
-
-// The dynamic-LDS limit of a kernel is a per-device attribute: every session's device gets it (inflate_kernel's own call only
-// reaches the device of the first session of the process).
-static void inflate_prepare_device(const InflateKernel &K) {
-#define COV_INF2_ATTR(LB, DB, S8)                                                                                                               \
-    if (K.version == 2 && K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                               \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate2<LB, DB, S8>), hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                  (int)covi::inflate2_smem_bytes(LB, DB, S8));
-    COV_INFLATE2_VARIANTS(COV_INF2_ATTR)
-#undef COV_INF2_ATTR
-    if (K.version != 1) return;
-#define COV_INF_ATTR(LB, DB, S8)                                                                                                                \
-    if (K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                                                 \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<LB, DB, S8>), hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                  (int)covi::inflate_smem_bytes(LB, DB, S8));
-    COV_INFLATE_VARIANTS(COV_INF_ATTR)
-#undef COV_INF_ATTR
-}
+static inline const InflateKernel &inflate_kernel(cov_session *s) { return s->ing_K; }
 
 cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t first_record_offset, int check_crc) {
     if (!s) return COV_ERR_INVALID_ARG;
@@ -1118,7 +1065,7 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     }
     HIPCHK(hipStreamSynchronize(s->stream));     // the record store is about to be written from the parse stream
     s->ing_batch = 0; s->ing_extracted = 0; s->ing_rec_total = s->ing_cig_total = 0; s->ing_fail = 0;
-    inflate_prepare_device(inflate_kernel(s));
+    s->ing_K = choose_inflate_kernel(s);      // (also sets the kernel's dynamic-LDS limit on this session's device)
     s->ing_first_record = first_record_offset;
     s->ing_check_crc = (check_crc && !getenv("COVERM_NO_CRC")) ? 1 : 0;
     HIPCHK(s->g_result.reserve(8 + 4 * 8, s->stream));
@@ -1246,44 +1193,23 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
         if (w >= 3) HIPCHK(hipStreamWaitEvent(s->stream, s->ing_ext_done[w % 3u], 0));
         const u32 grid = (n + 63u) / 64u;
         const uint8_t *comp_bias = s->g_cwin[w % 3u].p - s->ing_round_start;     // blocks carry absolute file offsets
-        static const u32 ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);
-        if (K.version == 3) {
-            // measurements: COVERM_INFLATE_WAVE_PAD_KB of unused dynamic LDS lowers the resident waves per CU, COVERM_INFLATE_ABLATE = 1..3 stops
-            // every block after the tables / pass 1 / pass 2 (the file then falls back to the host reader)
-            static const u32 pad = (u32)(getenv("COVERM_INFLATE_WAVE_PAD_KB") ? atoi(getenv("COVERM_INFLATE_WAVE_PAD_KB")) : 0) << 10;
-            static const int st = getenv("COVERM_INFLATE_WAVE_STORES") ? atoi(getenv("COVERM_INFLATE_WAVE_STORES")) : COVW_STORES;
-            static const int cur = getenv("COVERM_INFLATE_WAVE_CURSOR") ? atoi(getenv("COVERM_INFLATE_WAVE_CURSOR")) : COVW_CURSOR;
-            auto kern = covi::k_inflate_wave<COVW_STORES, COVW_CURSOR>;
-#define COV_WAVE_PICK(ST, CUR) if (st == ST && cur == CUR) kern = covi::k_inflate_wave<ST, CUR>;
-            COV_WAVE_PICK(1, 1) COV_WAVE_PICK(2, 1) COV_WAVE_PICK(3, 1) COV_WAVE_PICK(4, 1) COV_WAVE_PICK(5, 1) COV_WAVE_PICK(6, 1) COV_WAVE_PICK(7, 1)
-            COV_WAVE_PICK(1, 2) COV_WAVE_PICK(2, 2) COV_WAVE_PICK(3, 2) COV_WAVE_PICK(4, 2) COV_WAVE_PICK(5, 2) COV_WAVE_PICK(6, 2) COV_WAVE_PICK(7, 2)
-#undef COV_WAVE_PICK
-            hipLaunchKernelGGL(kern, dim3(n), dim3(64), pad, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, tokb.p, ntokb.p,
+        const u32 ablate = K.ablate;
+        if (K.version == 4)
+            hipLaunchKernelGGL(covi::k_inflate_lds, dim3(n), dim3(256), covi::inflate_lds_smem_bytes(), s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, ntokb.p,
                                s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
-        }
-#define COV_LAUNCH_INFLATE2(LB, DB, S8)                                                                                                         \
-        if (K.version == 2 && K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                               \
-            hipLaunchKernelGGL((covi::k_inflate2<LB, DB, S8>), dim3(grid), dim3(64), covi::inflate2_smem_bytes(LB, DB, S8), s->stream, comp_bias,   \
-                               (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, s->g_scratch.p, tokb.p, ntokb.p,                         \
-                               s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
-        COV_INFLATE2_VARIANTS(COV_LAUNCH_INFLATE2)
-#undef COV_LAUNCH_INFLATE2
-#define COV_LAUNCH_INFLATE(LB, DB, S8)                                                                                                          \
-        if (K.version == 1 && K.lit_bits == LB && K.dist_bits == DB && K.sort8 == S8)                                                                                 \
-            hipLaunchKernelGGL((covi::k_inflate<LB, DB, S8>), dim3(grid), dim3(64), covi::inflate_smem_bytes(LB, DB, S8), s->stream, comp_bias, \
-                               (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, s->g_scratch.p, tokb.p, ntokb.p,                             \
+        else if (K.version == 3)
+            hipLaunchKernelGGL(covi::k_inflate_wave, dim3(n), dim3(64), 0, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, tokb.p, ntokb.p,
                                s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
-        COV_INFLATE_VARIANTS(COV_LAUNCH_INFLATE)
-#undef COV_LAUNCH_INFLATE
+        else
+            hipLaunchKernelGGL((covi::k_inflate<INF1_LB, INF1_DB, false>), dim3(grid), dim3(64), covi::inflate_smem_bytes(INF1_LB, INF1_DB), s->stream, comp_bias,
+                               (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, s->g_scratch.p, tokb.p, ntokb.p,
+                               s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
         HIPCHK(hipEventRecord(s->ing_inf_done[bb], s->stream));
         HIPCHK(hipEventRecord(s->ing_cdone[w % 3u], s->stream));      // this round's compressed buffer may be overwritten (three rounds on)
         HIPCHK(hipStreamWaitEvent(s->ing_aux, s->ing_inf_done[bb], 0));
-        {
-            static const int lzu = getenv("COVERM_LZ_UNROLL") ? atoi(getenv("COVERM_LZ_UNROLL")) : 1;
-            auto lz = lzu == 2 ? covi::k_lz_resolve_u<2> : lzu == 4 ? covi::k_lz_resolve_u<4> : lzu == 8 ? covi::k_lz_resolve_u<8> : covi::k_lz_resolve;
-            hipLaunchKernelGGL(lz, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
-                               (const covi::tokpos_t *)tokb.p, (const u32 *)ntokb.p);
-        }
+        if (K.version != 4)      // (k_inflate_lds resolves its matches itself)
+            hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
+                           (const covi::tokpos_t *)tokb.p, (const u32 *)ntokb.p);
         // the window's bytes are final once the matches are resolved: the boundary search (parse stream) starts here, beside the
         // CRC-32 pass, whose verdict is only looked at in cov_ingest_end (the aux stream is in order, so CRC(w) is done before LZ(w + 1)
         // and with it before anything may overwrite window w)

@@ -121,41 +121,10 @@ struct Cursor {
     COVW_FN u32 low32() const { return (u32)buf; }
     COVW_FN void drop(u32 n) { buf >>= n; cnt -= n; pos += n; }
 };
-// The same with the stream requested four to eight words ahead, 16 bytes per load (COVW_CURSOR 2): the compressed bytes of the blocks
-// in flight on a CU do not fit its caches, a lane's next word is a miss once per cache line, and a wave waits for the slowest of 64.
-struct Words4 { u32 a, b, c, d; };
-struct CursorAhead {
-    const u32 *w; u64 buf; u32 cnt, wi, qn, pos;
-    u32 q0, q1, q2, q3;                   // the qn words that enter buf next, q0 first
-    Words4 nx;                            // the four words behind them (w[wi ..]), requested
-    COVW_FN Words4 load4(u32 i) const { Words4 x; __builtin_memcpy(&x, w + i, 16); return x; }
-    COVW_FN void init(const Src &s, u32 p) {
-        w = s.w; pos = p;
-        const u32 i = p >> 5, d = p & 31u;
-        buf = ((u64)w[i] | ((u64)w[i + 1u] << 32)) >> d; cnt = 64u - d;
-        const Words4 x = load4(i + 2u);
-        q0 = x.a; q1 = x.b; q2 = x.c; q3 = x.d; qn = 4u;
-        wi = i + 6u; nx = load4(wi);
-    }
-    COVW_FN void refill() {               // afterwards cnt >= 33
-        if (cnt <= 32u) {
-            buf |= (u64)q0 << cnt; cnt += 32u;
-            q0 = q1; q1 = q2; q2 = q3;
-            if (--qn == 0u) { q0 = nx.a; q1 = nx.b; q2 = nx.c; q3 = nx.d; qn = 4u; wi += 4u; nx = load4(wi); }
-        }
-    }
-    COVW_FN u32 low32() const { return (u32)buf; }
-    COVW_FN void drop(u32 n) { buf >>= n; cnt -= n; pos += n; }
-};
-template <int CUR> struct CursorOf { typedef Cursor type; };
-template <> struct CursorOf<2> { typedef CursorAhead type; };
-#ifndef COVW_CURSOR
-#define COVW_CURSOR 1
-#endif
-
 // ---- canonical code of `n` symbols with code lengths lens[0 .. n): per-length limits / offsets and the symbols sorted by (length, value).
 // Serial; false when the set is over-subscribed.
-COVW_FN bool build_lengths(Wave &W, const u8 *lens, u32 n, u16 *limit, u16 *off, u16 *sorted16, u8 *sorted8) {
+template <class WS>
+COVW_FN bool build_lengths(WS &W, const u8 *lens, u32 n, u16 *limit, u16 *off, u16 *sorted16, u8 *sorted8) {
     u32 *cnt = W.cnt, *start = W.start;
     for (u32 l = 0; l < 16; l++) cnt[l] = 0;
     for (u32 s = 0; s < n; s++) cnt[lens[s] & 15u]++;
@@ -238,7 +207,8 @@ COVW_FN void fill_dist_index(Tables &T, u32 i) {
 
 // ---- header of the DEFLATE block at `pos` (serial): fills W.hdr; fixed codes: W.T.lens; dynamic codes: the code-length code (W.cl and its
 // canonical tables), hdr[4] = where the code lengths begin.
-COVW_FN void parse_header(Wave &W, const Src &s, u32 pos) {
+template <class WS>
+COVW_FN void parse_header(WS &W, const Src &s, u32 pos) {
     u32 *h = W.hdr;
     h[6] = OK;
     if (pos + 3u > s.total_bits) { h[6] = ERR_FORMAT; return; }
@@ -286,7 +256,8 @@ COVW_FN void parse_header(Wave &W, const Src &s, u32 pos) {
 }
 
 // ---- the code lengths of a dynamic block (serial, through W.cltab): fills W.T.lens, hdr[4] = first unit bit
-COVW_FN void parse_code_lengths(Wave &W, const Src &s) {
+template <class WS>
+COVW_FN void parse_code_lengths(WS &W, const Src &s) {
     u32 *h = W.hdr;
     u8 *lens = W.T.lens;
     const u32 hlit = h[2], hdist = h[3], want = hlit + hdist;
@@ -321,35 +292,17 @@ COVW_FN void store_bytes(u8 *d, u64 v, u32 n) {        // exactly n <= 8 bytes o
     if (n & 2u) { const u16 x = (u16)v; COVW_TRACE_STORE(d, 2); __builtin_memcpy(d, &x, 2); d += 2; v >>= 16; }
     if (n & 1u) { COVW_TRACE_STORE(d, 1); *d = (u8)v; }
 }
-// ---- pass 3's output of one lane, in seven versions (COVW_STORES; the kernel is bound by its scattered stores, and which shape of store the
-// memory path likes is a measurement: profiles/r03_wave_variants*.log).  A lane writes its bytes front to back, bytes [lo, own_end) of the
-// block; it may run over bytes of its OWN range that come later (it overwrites them, or they are a match's and k_lz_resolve does), never
-// past own_end, where the next lane's bytes begin.  literal(p, b): byte b belongs at p; match(p, len, t24, k): a match of len bytes begins
-// at p, its token t24 goes into its first three bytes and p into token slot k; finish(p): p = own_end, everything pending leaves.
-template <int ST> struct Sink;
-
-// 1: exact stores only.  Literals wait in an 8-byte FIFO; a match flushes them (4 + 2 + 1 bytes), then its token (4 bytes when the match is
-// longer than three, 2 + 1 otherwise), then its position.
-template <> struct Sink<1> {
-    u8 *out; u16 *tok; u64 obuf; u32 on;
-    COVW_FN void init(u8 *o, u16 *t, u32, u32, u32 *) { out = o; tok = t; obuf = 0; on = 0; }
-    COVW_FN void literal(u32 p, u32 b) {
-        obuf |= (u64)b << (8u * on);
-        if (++on == 8u) { store8(out + p - 7u, obuf); obuf = 0; on = 0; }
-    }
-    COVW_FN void match(u32 p, u32 len, u32 t24, u32 k) {
-        if (on) { store_bytes(out + p - on, obuf, on); obuf = 0; on = 0; }
-        store_bytes(out + p, t24, len > 3u ? 4u : 3u);
-        COVW_TRACE_STORE(tok + k, 2); tok[k] = (u16)p;
-    }
-    COVW_FN void finish(u32 p) { if (on) store_bytes(out + p - on, obuf, on); }
-};
-
-// 2: the pending literals and the token leave together, as one 4- or 8-byte store when the padding falls into the match's own bytes;
-// token positions leave four at a time.
-template <> struct Sink<2> {
+// ---- pass 3's output of one lane.  A lane writes its bytes front to back, bytes [lo, own_end) of the block; it may run over bytes of its
+// OWN range that come later (it overwrites them, or they are a match's and k_lz_resolve does), never past own_end, where the next lane's
+// bytes begin.  literal(p, b): byte b belongs at p; match(p, len, t24, k): a match of len bytes begins at p, its token t24 goes into its
+// first three bytes and p into token slot k; finish(p): p = own_end, everything pending leaves.
+// The pending literals and the token leave together, as one 4- or 8-byte store when the padding falls into the match's own bytes; token
+// positions leave four at a time.  (Seven store policies were measured — exact stores only, aligned words only, aligned 16- and 64-byte lines
+// through per-lane line buffers in LDS, ...: profiles/r04_wave_variants.log.  A scattered store instruction of a wave costs ~70 ns of a CU's
+// memory pipeline whatever its width (profiles/r04_store_probe.log), so the policy with the fewest store INSTRUCTIONS per lock-step wins.)
+struct Sink {
     u8 *out; u16 *tok; u64 obuf, tbuf; u32 on, tn, last_k;
-    COVW_FN void init(u8 *o, u16 *t, u32, u32, u32 *) { out = o; tok = t; obuf = 0; tbuf = 0; on = 0; tn = 0; last_k = 0; }
+    COVW_FN void init(u8 *o, u16 *t) { out = o; tok = t; obuf = 0; tbuf = 0; on = 0; tn = 0; last_k = 0; }
     COVW_FN void literal(u32 p, u32 b) {
         obuf |= (u64)b << (8u * on);
         if (++on == 8u) { store8(out + p - 7u, obuf); obuf = 0; on = 0; }
@@ -376,149 +329,21 @@ template <> struct Sink<2> {
     }
 };
 
-// 3: three paths.  Literals wait in a 4-byte FIFO that leaves as one exact store when full; a match takes the pending literals and its
-// token along in one 8-byte store while that stays inside the lane's range.
-template <> struct Sink<3> {
-    u8 *out; u16 *tok; u32 own_end, obuf, osh;
-    COVW_FN void init(u8 *o, u16 *t, u32, u32 end, u32 *) { out = o; tok = t; own_end = end; obuf = 0; osh = 0; }
-    COVW_FN void literal(u32 p, u32 b) {
-        obuf |= b << osh;
-        osh += 8u;
-        if (osh == 32u) { store4(out + p - 3u, obuf); obuf = 0; osh = 0; }
-    }
-    COVW_FN void match(u32 p, u32, u32 t24, u32 k) {
-        const u32 on = osh >> 3;
-        const u64 v = (u64)obuf | ((u64)t24 << osh);                   // <= 3 literals + 3 token bytes
-        if (p - on + 8u <= own_end) store8(out + p - on, v); else store_bytes(out + p - on, v, on + 3u);
-        obuf = 0; osh = 0;
-        COVW_TRACE_STORE(tok + k, 2); tok[k] = (u16)p;
-    }
-    COVW_FN void finish(u32 p) { if (osh) store_bytes(out + p - (osh >> 3), obuf, osh >> 3); }
-};
-
-// 4: aligned words only.  The bytes collect in a FIFO that begins at a 4-byte boundary of the output and leave as aligned 4-byte stores;
-// behind a match's token the FIFO jumps to the word the match ends in (what it skips are the match's own bytes).  Byte stores only in the
-// lane's first and last word, which it may share with its neighbours.
-template <> struct Sink<4> {
-    // positions inside the sink are relative to `base` = the block's output pointer rounded down to 16 bytes, so that "aligned" means the
-    // address, not the offset inside the block (a block begins wherever the one before it ended)
-    u8 *base; u16 *tok; u64 acc; u32 bias, lo, own_end, ab, nb;       // acc: bytes [ab, ab + nb), ab a multiple of four
-    COVW_FN void init(u8 *o, u16 *t, u32 first, u32 end, u32 *) {
-        bias = (u32)((uintptr_t)o & 15u); base = o - bias; tok = t;
-        lo = first + bias; own_end = end + bias; ab = lo & ~3u; nb = lo & 3u; acc = 0;
-    }
-    COVW_FN void word() {                                       // the low word of acc leaves
-        if (ab >= lo && ab + 4u <= own_end) store4(base + ab, (u32)acc);
-        else for (u32 k = 0; k < 4u; k++) if (ab + k >= lo && ab + k < own_end) { COVW_TRACE_STORE(base + ab + k, 1); base[ab + k] = (u8)(acc >> (8u * k)); }
-    }
-    COVW_FN void shift() { if (nb >= 4u) { word(); acc >>= 32; ab += 4u; nb -= 4u; } }
-    COVW_FN void literal(u32, u32 b) { acc |= (u64)b << (8u * nb); nb++; shift(); }
-    COVW_FN void match(u32 p, u32 len, u32 t24, u32 k) {
-        acc |= (u64)t24 << (8u * nb); nb += 3u; shift();           // nb <= 6 before, <= 2 after
-        const u32 q = p + bias + len;
-        if ((q >> 2) != (ab >> 2)) { if (nb) word(); ab = q & ~3u; nb = q & 3u; acc = 0; }
-        else nb = q - ab;
-        COVW_TRACE_STORE(tok + k, 2); tok[k] = (u16)p;
-    }
-    COVW_FN void finish(u32) { if (nb) word(); }
-};
-
-// 5: aligned 16-byte lines.  As 4, but a word goes into the lane's line buffer in LDS (four words, ring[k * 64] = word k) and the line
-// leaves as ONE aligned 16-byte store when the lane moves out of it — a quarter of the store instructions of 4, each a full aligned
-// quarter cache line.  A line is stored once; what it holds beyond the lane's valid bytes are bytes of a match (stale words of the
-// line before: k_lz_resolve overwrites them) — or bytes outside the lane's range, and then the line leaves byte by byte instead.
-// Token positions four at a time as aligned 8-byte stores (a lane's positions are consecutive slots of the block's list); the slots of
-// the lane's first and last group that are not its own leave as single 2-byte stores.
-struct TokFifo {
-    u16 *tok; u64 acc; u32 first, n;          // acc holds slots [first, first + n) of the list, first + n never crosses a group of four (by address)
-    COVW_FN void init(u16 *t) { tok = t; acc = 0; first = 0; n = 0; }
-    COVW_FN u32 slot_in_group(u32 k) const { return (u32)(((uintptr_t)(tok + k) >> 1) & 3u); }
-    COVW_FN void flush() {
-        if (n == 4u) { COVW_TRACE_STORE(tok + first, 8); __builtin_memcpy(__builtin_assume_aligned(tok + first, 8), &acc, 8); }
-        else for (u32 j = 0; j < n; j++) { COVW_TRACE_STORE(tok + first + j, 2); tok[first + j] = (u16)(acc >> (16u * j)); }
-        acc = 0; n = 0;
-    }
-    COVW_FN void push(u32 k, u32 p) {
-        if (n == 0u) first = k;
-        acc |= (u64)p << (16u * n); n++;
-        if (slot_in_group(k) == 3u) flush();       // the group's last slot: a full group iff the lane owns all four
-    }
-};
-
-template <u32 LW, bool TOKB> struct LineSink {       // LW words per line: 4 (16 bytes, one store) or 16 (64 bytes = one memory request, four stores back to back)
-    static constexpr u32 LBYTES = 4u * LW;
-    TokFifo tf;
-    u8 *base; u16 *tok; u32 *ring; u64 acc; u32 bias, lo, own_end, ab, nb;      // positions relative to the 64-byte-aligned `base`, as in 4
-    COVW_FN void init(u8 *o, u16 *t, u32 first, u32 end, u32 *r) {
-        bias = (u32)((uintptr_t)o & 63u); base = o - bias; tok = t; ring = r;
-        lo = first + bias; own_end = end + bias; ab = lo & ~3u; nb = lo & 3u; acc = 0;
-        if (TOKB) tf.init(t);
-    }
-    COVW_FN void line(u32 L) {                                  // bytes [L, L + LBYTES) leave
-        if (L >= lo && L + LBYTES <= own_end) {
-            COVW_NO_UNROLL               // (sixteen words in flight at once were 32 more registers for the whole kernel)
-            for (u32 k = 0; k < LW; k += 4u) {
-                const u32 v[4] = {ring[k * 64u], ring[(k + 1u) * 64u], ring[(k + 2u) * 64u], ring[(k + 3u) * 64u]};
-                COVW_TRACE_STORE(base + L + 4u * k, 16);
-                __builtin_memcpy(__builtin_assume_aligned(base + L + 4u * k, 16), v, 16);
-            }
-        } else {                                                // the lane's first or last line: whole words where they are the lane's, bytes at the two ends
-            COVW_NO_UNROLL
-            for (u32 k = 0; k < LW; k++) {
-                const u32 a = L + 4u * k, w = ring[k * 64u];
-                if (a >= lo && a + 4u <= own_end) store4(base + a, w);
-                else for (u32 j = 0; j < 4u; j++) if (a + j >= lo && a + j < own_end) { COVW_TRACE_STORE(base + a + j, 1); base[a + j] = (u8)(w >> (8u * j)); }
-            }
-        }
-    }
-    COVW_FN void put() { ring[((ab >> 2) & (LW - 1u)) * 64u] = (u32)acc; }      // the low word of acc into the line
-    COVW_FN void shift() {
-        if (nb >= 4u) {
-            put();
-            if ((ab & (LBYTES - 4u)) == LBYTES - 4u) line(ab & ~(LBYTES - 1u));
-            acc >>= 32; ab += 4u; nb -= 4u;
-        }
-    }
-    COVW_FN void literal(u32, u32 b) { acc |= (u64)b << (8u * nb); nb++; shift(); }
-    COVW_FN void match(u32 p, u32 len, u32 t24, u32 k) {
-        acc |= (u64)t24 << (8u * nb); nb += 3u; shift();
-        const u32 q = p + bias + len;
-        if ((q >> 2) != (ab >> 2)) {
-            if (nb) put();
-            if ((q / LBYTES) != (ab / LBYTES) && (nb || (ab & (LBYTES - 1u)))) line(ab & ~(LBYTES - 1u));
-            ab = q & ~3u; nb = q & 3u; acc = 0;
-        } else nb = q - ab;
-        if (TOKB) tf.push(k, p); else { COVW_TRACE_STORE(tok + k, 2); tok[k] = (u16)p; }
-    }
-    COVW_FN void finish(u32) {
-        if (nb) put();
-        if (nb || (ab & (LBYTES - 1u))) line(ab & ~(LBYTES - 1u));
-        if (TOKB && tf.n) tf.flush();
-    }
-};
-template <> struct Sink<5> : LineSink<4, false> {};
-// 6: aligned 64-byte lines — what the memory side moves in one request.  A partly written cache line that is evicted before the lane
-// gets to its end costs a masked write or a read-modify-write further out, and with 64 lanes x 16 waves x 32 CUs writing front to back
-// through their own KiB there are as many lines open per L2 as it holds.
-template <> struct Sink<6> : LineSink<16, false> {};
-// 7: 6 with the token positions leaving four at a time, as aligned 8-byte stores — in 4 to 6 they are more than half of the store instructions
-template <> struct Sink<7> : LineSink<16, true> {};
-
-#ifndef COVW_STORES
-#define COVW_STORES 2      // the fastest measured so far (profiles/r03_wave_variants2.log)
-#endif
-
 // Decodes one lane's units from `from` until the position reaches `until`.  MODE 0: positions only, and an invalid code is skipped over
-// bit by bit (the start is a guess); 1: also counts output bytes and matches; 2: writes them through Sink<ST> (out + opos = where the
-// lane's first byte goes, out + own_end = where its last byte ends, tok + tpos = its first token position; *err receives what went wrong).
+// bit by bit (the start is a guess); 1: also counts output bytes and matches; 2: writes them through Sink (out + opos = where the
+// lane's first byte goes, tok + tpos = its first token position; *err receives what went wrong).
 // Returns the end position; *flags: bit 0 end of block met, bit 1 invalid code / ran off the payload.
-template <int MODE, int ST, int CUR>
-COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, u8 *out, u32 opos, u32 own_end, u16 *tok, u32 tpos,
-                      u32 *err, u32 *ring) {
-    typename CursorOf<CUR>::type c; c.init(s, from);
+struct NoSink {      // passes 1 and 2 write nothing
+    COVW_FN void literal(u32, u32) {}
+    COVW_FN void match(u32, u32, u32, u32) {}
+    COVW_FN void finish(u32) {}
+};
+// (SinkT: where pass 3's bytes go — Sink: the block's place in global memory; covl::SinkLds: the block's image in LDS.  opos: position of the
+// lane's first byte in the sink's coordinates, pmin: position of the block's first byte — a match may not reach in front of it.)
+template <int MODE, class SinkT>
+COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, SinkT &sink, u32 opos, u32 pmin, u32 tpos, u32 *err) {
+    Cursor c; c.init(s, from);
     u32 f = 0, bytes = 0, toks = 0;
-    Sink<MODE == 2 ? ST : 1> sink;
-    if (MODE == 2) sink.init(out, tok, opos, own_end, ring);
     // (Bounds in MODE 2: pass 2 counted this lane's bytes and matches with the same decoder and inflate_block checked the block's totals
     // against isize and TOK_CAP before pass 3, so only a match's distance is left to check here.)
     while (c.pos < until) {
@@ -575,7 +400,7 @@ COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *f
         }
         if (MODE == 2) {
             const u32 p = opos + bytes;
-            if (dist > p) { *err = ERR_FORMAT; break; }
+            if (dist > p - pmin) { *err = ERR_FORMAT; break; }
             sink.match(p, len, (dist - 1u) | ((len - 3u) << 15), tpos + toks);      // k_lz_resolve's token
         }
         bytes += len; toks++;
@@ -594,10 +419,7 @@ COVW_FN u32 share_begin_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
 // One BGZF block.  comp_words: aligned words holding the raw DEFLATE payload from bit `bit0` on; out: the block's `isize` output
 // bytes; tok: its token-position list.  *status = OK / ERR_*, *n_tok = matches written (0 unless OK).
 // stop_after (measurements only, 0 in production): 1 = give up after the tables are built, 2 = after pass 1, 3 = after pass 2.
-// ring: wave-shared line buffers of Sink<5> (4 x 64 words) / Sink<6> (16 x 64 words): word k of lane l at [k * 64 + l]; unused otherwise.
-template <int ST = COVW_STORES, int CUR = COVW_CURSOR>
-COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0,
-                           u32 *ring = nullptr) {
+COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0) {
     Src s; s.w = comp_words; s.total_bits = bit0 + payload_bits;
     u32 pos = bit0, opos = 0, ntok = 0, err = OK, nblk = 0, chunk_bits = 0;
     bool last = false;
@@ -694,9 +516,10 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
             // ---- pass 1: where lane i's units begin = end[i - 1]
             COVW_PARFOR(lane) {
                 u32 f, nb, nt;
+                NoSink ns;
                 const u32 g = share_begin_of(cur, S, lane, span_end);
                 if (lane) W.end[lane - 1u] = g >= span_end ? span_end
-                                                           : run_share<0, ST, CUR>(W.T, s, g - cur > OVERLAP_BITS ? g - OVERLAP_BITS : cur, g, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
+                                                           : run_share<0>(W.T, s, g - cur > OVERLAP_BITS ? g - OVERLAP_BITS : cur, g, &f, &nb, &nt, ns, 0, 0, 0, nullptr);
                 if (lane == 63u) W.end[63] = span_end;
             }
             COVW_SYNC();
@@ -708,7 +531,8 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                     const u32 from = lane ? W.end[lane - 1u] : cur;
                     const u32 ge = share_begin_of(cur, S, lane + 1u, span_end);
                     u32 f = 0, nb = 0, nt = 0, e = from;
-                    if (from < ge) e = run_share<1, ST, CUR>(W.T, s, from, ge, &f, &nb, &nt, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
+                    NoSink ns;
+                    if (from < ge) e = run_share<1>(W.T, s, from, ge, &f, &nb, &nt, ns, 0, 0, 0, nullptr);
                     W.flags[lane] = f; W.nbytes[lane] = nb; W.ntok[lane] = nt; W.tmp[lane] = e;
                 }
                 COVW_SYNC();          // every lane has read its neighbour's old end
@@ -754,7 +578,8 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                     const u32 from = lane ? W.end[lane - 1u] : cur;
                     const u32 ge = share_begin_of(cur, S, lane + 1u, span_end);
                     u32 f, nb, nt, e2 = OK;
-                    if (from < ge) (void)run_share<2, ST, CUR>(W.T, s, from, ge, &f, &nb, &nt, out, opos + W.obase[lane], opos + W.obase[lane] + W.nbytes[lane], tok, ntok + W.tbase[lane], &e2, ring + lane);
+                    Sink sink; sink.init(out, tok);
+                    if (from < ge) (void)run_share<2>(W.T, s, from, ge, &f, &nb, &nt, sink, opos + W.obase[lane], 0, ntok + W.tbase[lane], &e2);
                     if (e2 != OK) W.hdr[6] = e2;
                 }
             }

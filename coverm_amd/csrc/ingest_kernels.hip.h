@@ -427,283 +427,12 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     if (err != INF_OK) atomicAdd(n_failed, 1u);
 }
 
-// ---------------------------------------------------------------------------------------------- k_inflate2
-// Same contract as k_inflate (one lane per BGZF block, literals in place, matches as in-place tokens), with the symbol loop
-// rebuilt around what the counters of round 2 showed (192 VALU instructions and one exposed global load per symbol step, 53 % of
-// wave time in s_waitcnt, 1.2 waves per SIMD):
-//   * bit reader in 32-bit arithmetic: the lane keeps a bit POSITION; the 32-bit window at that position is one v_alignbit over
-//     two words read from the LDS reservoir (three are read per step, so the distance code needs no second round trip).  No
-//     64-bit shifts, no conditional refill;
-//   * the reservoir holds 16 words per lane and is refilled for all lanes when any lane is within two words of its end — one
-//     exposed global round trip per ~10 steps instead of ~4;
-//   * per-length limits of the canonical search live unpacked in registers (occupancy is bound by LDS, not by VGPRs: the
-//     kernel may use 256), per-length offsets in LDS;
-//   * a long-code LITERAL does not wait for its symbol: which length the code has, and that it is a literal (its rank within the
-//     length lies below the first length/EOB symbol of that length), follow from registers; the byte itself is loaded from the
-//     lane's sorted-symbol scratch and joins the output one step later, while the next symbol is already being decoded;
-//   * primary-table entries of length symbols carry base and extra-bit count, so a match costs no arithmetic on the symbol.
-// LDS per wave: 64 x (2^LB + 2^DB) x 2 (primary tables) + 2 KiB (distance symbols, bytes) + 4 KiB (literal/length per-length
-// offset | first non-literal rank) + 2 KiB (distance per-length offsets) + 4 KiB (reservoir): 36 KiB at 7 + 6, 32 KiB at 7 + 5.
-constexpr u32 INF2_RES = 16;
-constexpr size_t inflate2_smem_bytes(int lit_bits, int dist_bits, bool s8l = false) {
-    return (size_t)64 * ((1u << lit_bits) + (1u << dist_bits)) * 2 + (size_t)64 * 32 + (size_t)64 * 16 * 4 + (size_t)64 * 16 * 2 + (size_t)64 * INF2_RES * 4 + (s8l ? (size_t)64 * 288 : 0);
-}
-// Per-lane global scratch of k_inflate2: u8 lit_sorted8[288] (low byte of the symbols sorted by (length, value)), u8 pad[32], u8 lens[320]
-constexpr u32 INF2_SCRATCH_BYTES = 320 + 320;
-
-// primary entry of the literal/length table: bits 0-3 code length (0: longer than the table), then
-//   literal / end of block:  bit 15 = 0, bits 4-12 = symbol (0 .. 256)
-//   length symbol:           bit 15 = 1, bits 4-11 = base length - 3, bits 12-14 = extra bits
-__device__ __forceinline__ u32 len_entry(u32 sym) {      // sym in 257 .. 285  (RFC 1951 3.2.5)
-    const u32 li = sym - 257u;
-    const u32 le = li < 8u ? 0u : (li == 28u ? 0u : (li - 4u) >> 2);
-    const u32 lb = li < 8u ? 3u + li : (li == 28u ? 258u : 3u + ((4u + (li & 3u)) << le));
-    return 0x8000u | (le << 12) | ((lb - 3u) << 4);
-}
-
-template <int LB, int DB, bool S8L>
-__global__ __launch_bounds__(64) void k_inflate2(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
-                                                 uint8_t *__restrict__ out, uint8_t *__restrict__ scratch, tokpos_t *__restrict__ tok,
-                                                 u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
-    constexpr u32 NL = 1u << LB, ND = 1u << DB;
-    const int lane = threadIdx.x & 63;
-    unsigned short *tabL = lds, *tabD = lds + 64 * NL;
-    uint8_t *dsort = reinterpret_cast<uint8_t *>(tabD + 64 * ND);                       // 32 x 64 bytes
-    u32 *lit_ot = reinterpret_cast<u32 *>(dsort + 64 * 32);                             // 16 x 64 words: off | thr << 16
-    unsigned short *dist_off = reinterpret_cast<unsigned short *>(lit_ot + 64 * 16);    // 16 x 64
-    u32 *res = reinterpret_cast<u32 *>(dist_off + 64 * 16) + lane;                      // INF2_RES x 64 words
-    uint8_t *lsort = reinterpret_cast<uint8_t *>(res - lane + 64 * INF2_RES);            // S8L: 288 x 64 bytes, the literal/length symbols' low bytes
-    const u32 b = blockIdx.x * 64u + (u32)lane;
-    if (b >= n_blocks) return;
-    const BgzfBlock B = blocks[b];
-    uint8_t *sc = scratch + (size_t)b * INF2_SCRATCH_BYTES;
-    uint8_t *lens = sc + 320;
-    Huff HL, HD;
-    HL.tab = tabL; HD.tab = tabD;
-    HL.sorted = nullptr; HL.sstride = 0; HL.sorted8 = S8L ? lsort + lane : sc; HL.s8stride = S8L ? 64 : 1;
-    HD.sorted = nullptr; HD.sstride = 0; HD.sorted8 = dsort + lane; HD.s8stride = 64;
-    uint8_t *dst = out + B.out_off;
-    tokpos_t *my_tok = tok + (size_t)b * INF_TOK_CAP;
-    u32 pos = 0, err = INF_OK, nt = 0;
-    u64 tbuf = 0;
-    if (B.isize != 0u) {
-        const u32 mis = (u32)((u64)(comp + B.in_off) & 3u);
-        BitReader br;
-        br.init(comp, B.in_off, B.in_len, res);
-        const u32 total_bits = B.in_len * 8u;
-        bool last = false;
-        while (!last && err == INF_OK) {
-            if (br.consumed > total_bits) { err = INF_ERR_FORMAT; break; }
-            br.refill();
-            last = br.take(1) != 0u;
-            const u32 type = br.take(2);
-            if (type == 0u) {                    // stored
-                br.drop((8u - (br.consumed & 7u)) & 7u);
-                br.refill();
-                const u32 len = br.take(16);
-                br.refill();
-                const u32 nlen = br.take(16);
-                if ((len ^ nlen) != 0xffffu || pos + len > B.isize) { err = INF_ERR_FORMAT; break; }
-                for (u32 k = 0; k < len; k++) { br.refill(); dst[pos++] = (uint8_t)br.take(8); }
-                continue;
-            }
-            if (type == 3u) { err = INF_ERR_FORMAT; break; }
-            u32 hlit, hdist;
-            if (type == 1u) {                    // fixed codes
-                for (u32 s = 0; s < 144; s++) lens[s] = 8;
-                for (u32 s = 144; s < 256; s++) lens[s] = 9;
-                for (u32 s = 256; s < 280; s++) lens[s] = 7;
-                for (u32 s = 280; s < 288; s++) lens[s] = 8;
-                for (u32 s = 0; s < 30; s++) lens[288 + s] = 5;
-                hlit = 288; hdist = 30;
-            } else {                             // dynamic codes: the code-length code as in k_inflate
-                br.refill();
-                hlit = br.take(5) + 257u; hdist = br.take(5) + 1u;
-                const u32 hclen = br.take(4) + 4u;
-                if (hlit > 286u || hdist > 30u) { err = INF_ERR_FORMAT; break; }
-                u64 cl = 0;
-                for (u32 i = 0; i < hclen; i++) { br.refill(); cl |= (u64)br.take(3) << (3u * c_clen_order[i]); }
-                u64 ccnt5 = 0;
-                for (u32 sy = 0; sy < 19; sy++) { const u32 l = (u32)(cl >> (3u * sy)) & 7u; if (l) ccnt5 += 1ull << (5u * l); }
-                { u32 left = 1; bool bad = false; for (u32 l = 1; l < 8; l++) { left <<= 1; const u32 c = (u32)(ccnt5 >> (5u * l)) & 31u; if (c > left) { bad = true; break; } left -= c; } if (bad) { err = INF_ERR_FORMAT; break; } }
-                u32 n = 0;
-                const u32 want = hlit + hdist;
-                while (n < want && err == INF_OK) {
-                    br.refill();
-                    u32 code = 0, first = 0; int sym = -1;
-                    u64 bits = br.buf;
-                    for (u32 l = 1; l <= 7; l++) {
-                        code |= (u32)(bits & 1u); bits >>= 1;
-                        const u32 c = (u32)(ccnt5 >> (5u * l)) & 31u;
-                        if (code < first + c) {
-                            u32 r = code - first;
-                            for (u32 sy = 0; sy < 19; sy++) if (((u32)(cl >> (3u * sy)) & 7u) == l) { if (r == 0) { sym = (int)sy; break; } r--; }
-                            br.drop(l);
-                            break;
-                        }
-                        first += c; first <<= 1; code <<= 1;
-                    }
-                    if (sym < 0) { err = INF_ERR_FORMAT; break; }
-                    if (sym < 16) lens[n++] = (uint8_t)sym;
-                    else {
-                        u32 rep, val = 0;
-                        if (sym == 16) { if (n == 0) { err = INF_ERR_FORMAT; break; } val = lens[n - 1]; rep = 3u + br.take(2); }
-                        else if (sym == 17) rep = 3u + br.take(3);
-                        else rep = 11u + br.take(7);
-                        if (n + rep > want) { err = INF_ERR_FORMAT; break; }
-                        for (u32 k = 0; k < rep; k++) lens[n++] = (uint8_t)val;
-                    }
-                }
-                if (err != INF_OK) break;
-                if (lens[256] == 0) { err = INF_ERR_FORMAT; break; }
-                for (u32 s = hdist; s-- > 0;) lens[288 + s] = lens[hlit + s];
-                for (u32 s = hlit; s < 288; s++) lens[s] = 0;
-            }
-            if (!build_table<true>(lens, hlit, LB, lane, HL)) { err = INF_ERR_FORMAT; break; }
-            if (!build_table<true>(lens + 288, hdist, DB, lane, HD)) { err = INF_ERR_FORMAT; break; }
-            // primary entries of length symbols carry base and extra-bit count; symbols 286 / 287 (fixed code only) stay invalid
-            for (u32 i = 0; i < NL; i++) {
-                const u32 e = tabL[i * 64 + lane];
-                const u32 sym = e >> 4;
-                if ((e & 15u) && sym > 256u) tabL[i * 64 + lane] = (unsigned short)(sym <= 285u ? (len_entry(sym) | (e & 15u)) : 0xfff0u | (e & 15u));
-            }
-            // per-length constants of the canonical search: limits into registers, offsets into LDS
-            u32 limL[16], limD[16];
-#pragma unroll
-            for (u32 l = 1; l < 16; l++) { limL[l] = HL.limit.get(l); limD[l] = HD.limit.get(l); }
-#pragma unroll
-            for (u32 l = 1; l < 16; l++) { lit_ot[l * 64 + lane] = HL.off.get(l) | (HL.thr.get(l) << 16); dist_off[l * 64 + lane] = (unsigned short)HD.off.get(l); }
-            // ---- symbols of this block
-            u32 bitpos = br.consumed + 8u * mis;
-            u32 rbase = 0xffff0000u;                       // forces the first fill
-            u32 olo = 0, ohi = 0, on = 0;                  // pending output bytes: the top `on` bytes of ohi:olo, oldest lowest
-            u32 pend = 0, pend_direct = 0; uint8_t pend_loaded = 0;      // pend: 0 none, 1 byte in pend_direct, 2 byte arriving in pend_loaded
-            auto append = [&](u32 byte) {                 // the byte belongs at output position pos_w; flush every eighth
-                olo = __builtin_amdgcn_alignbit(ohi, olo, 8);
-                ohi = (ohi >> 8) | (byte << 24);
-                on++;
-            };
-            u32 wpos = pos;                                // output position of the next byte to enter ohi:olo (pos minus a pending literal)
-            auto flush8 = [&]() { const u64 v = ((u64)ohi << 32) | olo; __builtin_memcpy(dst + wpos - 8u, &v, 8); on = 0; };
-            auto flush_part = [&]() {                     // the `on` pending bytes end at dst + wpos
-                if (on) {
-                    const u64 v = (((u64)ohi << 32) | olo) >> (8u * (8u - on));
-                    uint8_t *d = dst + wpos - on;
-                    if (wpos - on + 8u <= B.isize) __builtin_memcpy(d, &v, 8);
-                    else for (u32 k = 0; k < on; k++) d[k] = (uint8_t)(v >> (8u * k));
-                    on = 0; olo = 0; ohi = 0;
-                }
-            };
-            auto settle = [&]() {                          // a pending literal joins the output
-                if (pend) { append(pend == 2u ? (u32)pend_loaded : pend_direct); wpos++; pend = 0; if (on == 8u) flush8(); }
-            };
-            for (;;) {
-                const u32 cur = bitpos >> 5;
-                if (__any(cur - rbase >= INF2_RES - 2u)) {           // (also true for the initial rbase)
-                    const u32 *w = br.words + cur;
-                    const Words4 x0 = *reinterpret_cast<const Words4 *>(w), x1 = *reinterpret_cast<const Words4 *>(w + 4),
-                                 x2 = *reinterpret_cast<const Words4 *>(w + 8), x3 = *reinterpret_cast<const Words4 *>(w + 12);
-                    res[0 * 64] = x0.a; res[1 * 64] = x0.b; res[2 * 64] = x0.c; res[3 * 64] = x0.d;
-                    res[4 * 64] = x1.a; res[5 * 64] = x1.b; res[6 * 64] = x1.c; res[7 * 64] = x1.d;
-                    res[8 * 64] = x2.a; res[9 * 64] = x2.b; res[10 * 64] = x2.c; res[11 * 64] = x2.d;
-                    res[12 * 64] = x3.a; res[13 * 64] = x3.b; res[14 * 64] = x3.c; res[15 * 64] = x3.d;
-                    rbase = cur;
-                }
-                const u32 j = cur - rbase;
-                const u32 w0 = res[j * 64u], w1 = res[(j + 1u) * 64u], w2 = res[(j + 2u) * 64u];
-                const u32 sh = bitpos & 31u;
-                const u32 win = __builtin_amdgcn_alignbit(w1, w0, sh);
-                u32 e = tabL[(win & (NL - 1u)) * 64u + (u32)lane];
-                u32 clen = e & 15u;
-                u32 load_idx = 0xffffffffu;                 // long-code literal: rank of its symbol in the sorted list
-                if (clen == 0u) {                           // longer than the primary table: parallel search over the per-length limits
-                    const u32 v = __brev(win) >> 17;
-                    u32 l = LB + 1;
-#pragma unroll
-                    for (u32 k = LB + 1; k < 15; k++) l += v >= limL[k] ? 1u : 0u;
-                    if (v >= limL[15]) { err = INF_ERR_FORMAT; break; }
-                    const u32 ot = lit_ot[l * 64u + (u32)lane];
-                    const u32 idx = ((ot & 0xffffu) + (v >> (15u - l))) & 0xffffu;
-                    clen = l;
-                    if (idx < (ot >> 16)) { load_idx = idx; e = 0; }                     // a literal: its byte follows
-                    else {                                                               // length symbol or end of block: needed now
-                        const u32 sym = 256u + (u32)HL.sorted8[min(idx, 287u) * HL.s8stride];
-                        e = sym == 256u ? (256u << 4) : (sym <= 285u ? len_entry(sym) : 0xfff0u);
-                    }
-                }
-                bitpos += clen;
-                if (!(e & 0x8000u)) {
-                    const u32 sym = (e >> 4) & 0x1ffu;
-                    if (load_idx == 0xffffffffu && sym == 256u) { settle(); break; }     // end of block
-                    if (pos >= B.isize) { err = INF_ERR_SIZE; break; }
-                    settle();                                                            // the previous literal first (its load has had a step to arrive)
-                    if (load_idx != 0xffffffffu) { pend_loaded = HL.sorted8[load_idx * HL.s8stride]; pend = 2u; }
-                    else { pend_direct = sym; pend = 1u; }
-                    pos++;
-                    continue;
-                }
-                // ---- a match: everything pending goes out first
-                settle();
-                flush_part();
-                if ((e & 0xfff0u) == 0xfff0u) { err = INF_ERR_FORMAT; break; }           // symbols 286 / 287
-                const u32 le = (e >> 12) & 7u;
-                // window at the new position from the three words already here
-                const u32 sh1 = sh + clen;
-                const u32 winl = sh1 >= 32u ? __builtin_amdgcn_alignbit(w2, w1, sh1 & 31u) : __builtin_amdgcn_alignbit(w1, w0, sh1);
-                const u32 len = 3u + ((e >> 4) & 0xffu) + (winl & ((1u << le) - 1u));
-                bitpos += le;
-                // distance code: the words may have moved on by one
-                const u32 cur2 = bitpos >> 5;
-                const u32 j2 = cur2 - rbase;
-                const u32 d0 = res[j2 * 64u], d1 = res[(j2 + 1u) * 64u];
-                const u32 wind = __builtin_amdgcn_alignbit(d1, d0, bitpos & 31u);
-                const u32 ed = tabD[(wind & (ND - 1u)) * 64u + (u32)lane];
-                u32 dl = ed & 15u, ds = ed >> 4;
-                if (dl == 0u) {
-                    const u32 v = __brev(wind) >> 17;
-                    u32 l = DB + 1;
-#pragma unroll
-                    for (u32 k = DB + 1; k < 15; k++) l += v >= limD[k] ? 1u : 0u;
-                    if (v >= limD[15]) { err = INF_ERR_FORMAT; break; }
-                    const u32 idx = ((u32)dist_off[l * 64u + (u32)lane] + (v >> (15u - l))) & 0xffffu;
-                    ds = (u32)dsort[min(idx, 31u) * 64u + (u32)lane];
-                    dl = l;
-                }
-                if (ds >= 30u) { err = INF_ERR_FORMAT; break; }
-                const u32 de = ds < 4u ? 0u : (ds - 2u) >> 1;
-                const u32 dx = (wind >> dl) & ((1u << de) - 1u);                         // dl + de <= 15 + 13 = 28 bits of the window
-                const u32 dist = (ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << de)) + dx;
-                bitpos += dl + de;
-                if (dist > pos || pos + len > B.isize || nt >= INF_TOK_CAP) { err = INF_ERR_FORMAT; break; }
-                tbuf |= (u64)pos << (16u * (nt & 3u));
-                if ((nt & 3u) == 3u) { __builtin_memcpy(my_tok + (nt - 3u), &tbuf, 8); tbuf = 0; }
-                const u32 t24 = (dist - 1u) | ((len - 3u) << 15);
-                uint8_t *d = dst + pos;
-                if (pos + 4u <= B.isize) __builtin_memcpy(d, &t24, 4);
-                else { d[0] = (uint8_t)t24; d[1] = (uint8_t)(t24 >> 8); d[2] = (uint8_t)(t24 >> 16); }
-                nt++;
-                pos += len; wpos = pos;
-            }
-            if (err != INF_OK) break;
-            flush_part();
-            if (bitpos - 8u * mis > total_bits) { err = INF_ERR_FORMAT; break; }
-            br.seek(bitpos, mis);
-        }
-        if (err == INF_OK && pos != B.isize) err = INF_ERR_SIZE;
-    }
-    if (nt & 3u) __builtin_memcpy(my_tok + (nt & ~3u), &tbuf, 8);
-    n_tok[b] = err == INF_OK ? nt : 0u;
-    status[b] = err;
-    if (err != INF_OK) atomicAdd(n_failed, 1u);
-}
-
 // ---------------------------------------------------------------------------------------------- k_inflate_wave
-// One WAVE per BGZF block (COVERM_INFLATE_V=3, opt-in until it is measured on the device): the 64 lanes share one set of Huffman
-// tables in LDS (8.2 KiB per wave against 28 KiB of per-lane tables: 16+ waves per CU instead of five) and each decodes 1/64 of the
-// block's bit stream — three passes, described with the code in csrc/inflate_wave_core.h, which is plain C++ and runs lane by lane on
-// the CPU in tests/test_inflate_wave_core.py.  Same contract as k_inflate: literals in place, matches as in-place tokens for
-// k_lz_resolve, n_tok / status per block.
+// One WAVE per BGZF block (the default): the 64 lanes share one set of Huffman tables in LDS (7.3 KiB per wave against 28 KiB of
+// per-lane tables in k_inflate: 16 waves per CU instead of five) and each decodes 1/64 of the block's bit stream — three passes, described
+// with the code in csrc/inflate_wave_core.h, which is plain C++ and runs lane by lane on the CPU in tests/test_inflate_wave_core.py.
+// Same contract as k_inflate: literals in place, matches as in-place tokens for k_lz_resolve, n_tok / status per block.
+// Measured (profiles/r04_wave_variants.log): 20.3 ms per 81 920 blocks against k_inflate's 27.6, 6.4 ms against 26.4 for 12 k blocks.
 }  // namespace covi
 #define COVW_FN __device__ __forceinline__
 #define COVW_PARFOR(lane) for (unsigned lane = threadIdx.x & 63u, covw_once = 1u; covw_once; covw_once = 0u)
@@ -712,32 +441,79 @@ __global__ __launch_bounds__(64) void k_inflate2(const uint8_t *__restrict__ com
 #define COVW_NO_UNROLL _Pragma("clang loop unroll(disable) vectorize(disable)")
 #define COVW_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define COVW_ATOMIC_OR(p, v) atomicOr((p), (v))
+#define COVW_ATOMIC_MIN(p, v) atomicMin((p), (v))
+#define COVW_ATOMIC_AND(p, v) atomicAnd((p), (v))
+#define COVL_PARFOR(lane) for (unsigned lane = threadIdx.x, covl_once = 1u; covl_once; covl_once = 0u)
+#define COVL_SYNC() __syncthreads()
+#define COVL_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define COVL_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#define COVL_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
+#define COVL_RELAX() do { } while (0)
+#define COVL_SPIN_LIMIT 0xffffffffu
 #include "inflate_wave_core.h"
+#include "inflate_lds_core.h"
 namespace covi {
 static_assert(covw::TOK_CAP == INF_TOK_CAP && covw::OK == INF_OK && covw::ERR_FORMAT == INF_ERR_FORMAT && covw::ERR_SIZE == INF_ERR_SIZE, "the core mirrors k_inflate's contract");
-// ST: how pass 3 stores (covw::Sink<ST>; COVERM_INFLATE_WAVE_STORES) — which shape of scattered store the memory path likes is a measurement.
-// CUR: how far ahead a lane requests its compressed words (1: one word, 2: four to eight, 16 bytes per load; COVERM_INFLATE_WAVE_CURSOR).
-// (A cursor of two words and a funnel shift instead of the 64-bit buffer was tried: no fewer instructions per unit — each of the three
-// places that consume bits then carries the word roll.)
-// (Holding the register allocation to five waves per SIMD changed nothing, to six or seven cost 40 % in spills: profiles/r03_wave_variants2.log.)
-// (Four waves per SIMD = 128 registers: what most variants take by themselves, two or four more than that in the others.)
-template <int ST, int CUR>
+// (A cursor of two words and a funnel shift instead of the 64-bit buffer was tried: no fewer instructions per unit; a look-ahead cursor with
+// 16-byte loads was slower; holding the register allocation to five waves per SIMD changed nothing, to six or seven cost 40 % in spills.)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_inflate_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                      uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
                                                      u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
     __shared__ covw::Wave W;
-    __shared__ u32 ring[ST >= 6 ? 16 * 64 : ST == 5 ? 4 * 64 : 1];      // the line buffers of Sink<5> / Sink<6> / Sink<7>
     const u32 b = blockIdx.x;
     if (b >= n_blocks) return;
     const BgzfBlock B = blocks[b];
     u32 st = INF_OK, nt = 0;
     if (B.isize != 0u) {
         const u32 mis = (u32)((u64)(comp + B.in_off) & 3u);
-        covw::inflate_block<ST, CUR>(W, reinterpret_cast<const u32 *>(comp + B.in_off - mis), 8u * mis, 8u * B.in_len, out + B.out_off, B.isize,
-                                tok + (size_t)b * INF_TOK_CAP, &nt, &st, stop_after, ring);
+        covw::inflate_block(W, reinterpret_cast<const u32 *>(comp + B.in_off - mis), 8u * mis, 8u * B.in_len, out + B.out_off, B.isize,
+                            tok + (size_t)b * INF_TOK_CAP, &nt, &st, stop_after);
     }
     if ((threadIdx.x & 63u) == 0u) {
         n_tok[b] = nt; status[b] = st;
+        if (st != INF_OK) atomicAdd(n_failed, 1u);
+    }
+}
+
+// One WORKGROUP (256 lanes) per BGZF block, the block assembled in LDS (csrc/inflate_lds_core.h): stage the payload, decode in three passes,
+// resolve the matches in LDS, write the finished 64 KiB once with aligned 16-byte stores.  No tokens leave the kernel: n_tok[b] = 0 and
+// k_lz_resolve is not launched.  Dynamic LDS: sizeof(covl::Block) = 79.2 KiB, two workgroups per CU.
+constexpr size_t inflate_lds_smem_bytes() { return sizeof(covl::Block); }
+static_assert(sizeof(covl::Block) <= 80u * 1024u, "two blocks per CU");
+__global__ __launch_bounds__(256) void k_inflate_lds(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
+                                                     uint8_t *__restrict__ out, u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char covl_lds[];
+    covl::Block &W = *reinterpret_cast<covl::Block *>(covl_lds);
+    const u32 b = blockIdx.x, tid = threadIdx.x;
+    if (b >= n_blocks) return;
+    const BgzfBlock B = blocks[b];
+    u32 st = INF_OK;
+    if (B.isize != 0u) {
+        for (u32 i = tid; i < covl::PEND_WORDS; i += 256u) W.pend[i] = 0u;
+        const uint8_t *src = comp + B.in_off;
+        const u32 mis = (u32)((u64)src & 15u);
+        const u32 nbytes = mis + B.in_len + 48u;             // (the compressed buffer is readable 64 bytes past a payload: 48 + up to 15 of rounding)
+        const bool staged = nbytes <= covl::IMG_BYTES;
+        if (staged) {
+            const uint4 *s16 = reinterpret_cast<const uint4 *>(src - mis);
+            uint4 *d16 = reinterpret_cast<uint4 *>(W.cin);
+            for (u32 i = tid; i < (nbytes + 15u) / 16u; i += 256u) d16[i] = s16[i];
+        }
+        __syncthreads();
+        uint8_t *dst = out + B.out_off;
+        const u32 bias = (u32)((u64)dst & 15u);
+        covl::inflate_block_lds(W, reinterpret_cast<const u32 *>(src - mis), 8u * mis, 8u * B.in_len, staged, bias, B.isize, &st, stop_after);
+        __syncthreads();
+        if (st == INF_OK) {      // image position a <-> dst - bias + a: the same alignment on both sides
+            const u32 total = bias + B.isize;
+            for (u32 a = 16u * tid; a < total; a += 16u * 256u) {
+                if (a >= bias && a + 16u <= total) *reinterpret_cast<uint4 *>(dst - bias + a) = *reinterpret_cast<const uint4 *>(W.img + a);
+                else for (u32 k = max(a, bias); k < min(a + 16u, total); k++) dst[k - bias] = W.img[k];
+            }
+        }
+    }
+    if (tid == 0u) {
+        n_tok[b] = 0u; status[b] = st;
         if (st != INF_OK) atomicAdd(n_failed, 1u);
     }
 }
@@ -816,82 +592,6 @@ __global__ __launch_bounds__(256) void k_lz_resolve(const BgzfBlock *__restrict_
                     const u32 sk = dd >= ln ? k : k % dd;      // overlapping match: its first `dist` bytes are final, the rest repeats them
                     dst[po + k] = __hip_atomic_load(dst + po - dd + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            todo &= ~__ballot(go);
-        }
-    }
-}
-
-// The same with the copy loop taking U groups of 64 bytes per trip (COVERM_LZ_UNROLL = 2 | 4 | 8; opt-in until measured): in k_lz_resolve every
-// 64 bytes cost a full load-to-store round trip, because a later load may not pass an earlier store to what could be the same address.
-template <int U>
-__global__ __launch_bounds__(256) void k_lz_resolve_u(const BgzfBlock *__restrict__ blocks, u32 n_blocks, uint8_t *__restrict__ out,
-                                                    const tokpos_t *__restrict__ tok, const u32 *__restrict__ n_tok) {
-    const int lane = threadIdx.x & 63;
-    const u32 b = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (b >= n_blocks) return;
-    const u32 nt = n_tok[b];
-    if (nt == 0u) return;
-    uint8_t *dst = out + blocks[b].out_off;
-    const tokpos_t *my = tok + (size_t)b * INF_TOK_CAP;
-    for (u32 t0 = 0; t0 < nt; t0 += 64u) {
-        const u32 t = t0 + (u32)lane;
-        const bool have = t < nt;
-        const u32 pos = have ? (u32)my[t] : 0xffffffffu;
-        u32 t24 = 0;
-        if (have) { const uint8_t *tp = dst + pos; t24 = (u32)tp[0] | ((u32)tp[1] << 8) | ((u32)tp[2] << 16); }    // written by k_inflate (the kernel before this one)
-        const u32 len = have ? ((t24 >> 15) & 0xffu) + 3u : 0u, dist = have ? (t24 & 0x7fffu) + 1u : 0u;
-        const u32 src_lo = pos - dist, src_end = pos - dist + min(len, dist), dst_end = pos + len;
-        // Output ranges of the window's tokens are disjoint and increasing with the lane, so the tokens whose output overlaps
-        // this lane's source range form a contiguous lane interval [dep_lo, dep_hi): dep_hi = lanes with pos < src_end,
-        // dep_lo = lanes with dst_end <= src_lo.  Two binary searches over the lanes (6 shuffles each), once per window.
-        u32 dep_hi = 0, dep_lo = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1) {
-            const u32 p_hi = (u32)__shfl((int)pos, (int)(dep_hi + step - 1)), e_lo = (u32)__shfl((int)dst_end, (int)(dep_lo + step - 1));
-            const bool v_hi = dep_hi + step <= 64u, v_lo = dep_lo + step <= 64u;
-            if (v_hi && p_hi < src_end) dep_hi += step;
-            const bool lo_have = (u32)__shfl((int)(have ? 1 : 0), (int)(dep_lo + step - 1)) != 0u;
-            if (v_lo && lo_have && e_lo <= src_lo) dep_lo += step;
-        }
-        dep_hi = min(dep_hi, (u32)lane);            // only earlier tokens matter
-        const u64 dep_mask = dep_hi > dep_lo ? ((dep_hi - dep_lo >= 64u ? ~0ull : ((1ull << (dep_hi - dep_lo)) - 1ull)) << dep_lo) : 0ull;
-        u64 todo = __ballot(have);
-        while (todo) {
-            const bool go = have && ((todo >> lane) & 1ull) && (todo & dep_mask) == 0ull;
-            // The bytes of all ready matches of this round, concatenated, are copied 64 at a time, one byte per lane: a match of
-            // 200 bytes costs four wave steps, not 200 dependent round trips of its one lane.  Owner of byte x = the lane whose
-            // running length first exceeds x (binary search over the lanes' inclusive prefix sums, 6 shuffles).
-            const u32 glen = go ? len : 0u;
-            const u32 incl = wave_incl_scan_u32(glen), excl = incl - glen;
-            const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-            // U groups of 64 bytes at a time: the sources of a round's matches are final and none of its stores touches them (a match
-            // whose source another match of the window writes is not ready), so the U loads are issued back to back and waited for once
-            for (u32 base = 0; base < total; base += 64u * (u32)U) {
-                u32 val[U], at[U]; bool ok[U];
-#pragma unroll
-                for (int g = 0; g < U; g++) {
-                    const u32 x = base + 64u * (u32)g + (u32)lane;
-                    u32 o = 0;
-#pragma unroll
-                    for (int step = 32; step > 0; step >>= 1) {
-                        const u32 v = (u32)__shfl((int)incl, (int)(o + step - 1));
-                        if (v <= x) o += step;
-                    }
-                    const u32 oc = min(o, 63u);
-                    const u32 po = (u32)__shfl((int)pos, (int)oc), dd = (u32)__shfl((int)dist, (int)oc), ex = (u32)__shfl((int)excl, (int)oc),
-                              ln = (u32)__shfl((int)len, (int)oc);
-                    ok[g] = x < total;
-                    const u32 k = x - ex;
-                    const u32 sk = dd >= ln ? k : k % max(dd, 1u);
-                    // every lane loads (the lanes behind the round's last byte from the block's first byte): no branch around the load, so
-                    // nothing needs its value before the stores below
-                    val[g] = (u32)__hip_atomic_load(dst + (ok[g] ? po - dd + sk : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    at[g] = po + k;
-                }
-#pragma unroll
-                for (int g = 0; g < U; g++) if (ok[g]) dst[at[g]] = (uint8_t)val[g];
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             todo &= ~__ballot(go);

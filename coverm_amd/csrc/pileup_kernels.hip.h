@@ -1741,20 +1741,17 @@ constexpr size_t pileup_stream_smem_bytes() { return (size_t)4 * ((size_t)STREAM
 //     32-bit per-tile partial sums and no bounds tests; everything else takes the general loop (window / contig-end
 //     masks, 64-bit sums, histogram overflow to the arena).
 //   * histogram: one LDS atomic per constant-depth segment of a lane's 16 positions (depth changes only where a delta
-//     is non-zero).  HREP (COVERM_PILEUP_HREP, 1 | 2 | 4; default 1) keeps that many copies of every bin in adjacent words, lane l
-//     adds to copy l mod HREP: the lanes of a wave mostly add to the same few bins (depth varies little inside a tile), and adds of
-//     several lanes to one address are served one after the other — 44 % of the LDS pipe's busy cycles were such conflicts
-//     (profiles/pmc_pipes.json).  The copies are summed when a contig's histogram leaves for the arena.
+//     is non-zero).  (Copies of every bin in adjacent words, lane l adding to copy l mod 2 | 4, were measured: 0.62 -> 0.72 / 0.85 ms,
+//     profiles/r04_pileup_hrep.log — what the conflicts cost is less than what the lost occupancy does.)
 constexpr int FAST_TW = 1024, FAST_HB = 512;
-constexpr size_t pileup_fast_smem_bytes(bool hist, int hrep = 1) { return (size_t)4 * ((size_t)FAST_TW * 4 + (hist ? (size_t)FAST_HB * 4 * (size_t)hrep : 0)); }
+constexpr size_t pileup_fast_smem_bytes(bool hist) { return (size_t)4 * ((size_t)FAST_TW * 4 + (hist ? (size_t)FAST_HB * 4 : 0)); }
 
 typedef short v2i16 __attribute__((ext_vector_type(2)));
 
-template <bool WANT_HIST, int HREP = 1>
+template <bool WANT_HIST>
 __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
     constexpr int TW = FAST_TW, HBW = FAST_HB;
-    constexpr size_t WB = (size_t)TW * 4 + (WANT_HIST ? (size_t)HBW * 4 * HREP : 0);
-    static_assert(HREP == 1 || HREP == 2 || HREP == 4, "copies of a histogram bin");
+    constexpr size_t WB = (size_t)TW * 4 + (WANT_HIST ? (size_t)HBW * 4 : 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     u32 *S = reinterpret_cast<u32 *>(smem + (size_t)w * WB);   // 512 dwords = 1024 u16
@@ -1764,17 +1761,16 @@ __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, 
     const u32 wave_id = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (u32)w)), n_waves = gridDim.x * 4u;
     if (WANT_HIST) {
 #pragma unroll
-        for (int b = lane; b < HBW * HREP; b += 64) lhist[b] = 0u;
+        for (int b = lane; b < HBW; b += 64) lhist[b] = 0u;
     }
     u64 sum_d = 0, sum_d2 = 0, proc_win = 0;
     u32 cov_w = 0, cov_f = 0, mn = 0xffffffffu, mx = 0;
     int cur_c = -1;
     u64 hoff = 0; u32 hcap = 0;
     const u64 excl = a.excl;
-    const u32 hcopy = (u32)lane & (u32)(HREP - 1);       // this lane's copy of every bin
 
     auto hist_add = [&](u32 d, u32 x) {
-        if (__builtin_expect(d < (u32)HBW, 1)) atomicAdd(&lhist[d * (u32)HREP + hcopy], x);
+        if (__builtin_expect(d < (u32)HBW, 1)) atomicAdd(&lhist[d], x);
         else hist_add_overflow(a.hist_arena, hoff, hcap, a.g, d, x);
     };
     auto flush = [&]() {
@@ -1798,15 +1794,8 @@ __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, 
                 lds_fence();
                 const u32 hi_b = min(m2, (u32)HBW - 1u);
                 for (u32 b = m1 + (u32)lane; b <= hi_b; b += 64) {
-                    if (HREP == 1) {
-                        const u32 x = lhist[b];
-                        if (x) { atomicAdd(&a.hist_arena[hoff + b], x); lhist[b] = 0u; }
-                    } else {
-                        u32 x = 0;
-#pragma unroll
-                        for (int r = 0; r < HREP; r++) { x += lhist[b * (u32)HREP + (u32)r]; lhist[b * (u32)HREP + (u32)r] = 0u; }
-                        if (x) atomicAdd(&a.hist_arena[hoff + b], x);
-                    }
+                    const u32 x = lhist[b];
+                    if (x) { atomicAdd(&a.hist_arena[hoff + b], x); lhist[b] = 0u; }
                 }
                 lds_fence();
             }
@@ -1925,7 +1914,7 @@ __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, 
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     const int dj = (j & 1) ? (int)dl[j >> 1].y : (int)dl[j >> 1].x;
-                    if (WANT_HIST && j > 0 && dj != 0) { atomicAdd(&lhist[(u32)d * (u32)HREP + hcopy], (u32)j - seg0); seg0 = (u32)j; }
+                    if (WANT_HIST && j > 0 && dj != 0) { atomicAdd(&lhist[(u32)d], (u32)j - seg0); seg0 = (u32)j; }
                     d += dj;
                     const u32 du = (u32)d;
                     s1t += du;
@@ -1933,7 +1922,7 @@ __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, 
                     cv += du != 0u ? 1u : 0u;
                     mn = min(mn, du); mx = max(mx, du);
                 }
-                if (WANT_HIST) atomicAdd(&lhist[(u32)d * (u32)HREP + hcopy], 16u - seg0);
+                if (WANT_HIST) atomicAdd(&lhist[(u32)d], 16u - seg0);
                 sum_d += s1t; sum_d2 += s2t; cov_w += cv; cov_f += cv;
             } else {
                 // ---- general loop: window and contig-end tests per position, 64-bit sums, histogram overflow

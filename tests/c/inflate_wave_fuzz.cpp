@@ -18,9 +18,19 @@ static inline unsigned covw_brev32(unsigned x) {
     x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
     return __builtin_bswap32(x);
 }
+#ifdef COVL          // the workgroup-per-block decoder (csrc/inflate_lds_core.h): 256 lanes, the block assembled in (what is on the device) LDS
+#define COVL_PARFOR(lane) for (unsigned lane = 0; lane < 256u; lane++)
+#define COVL_SYNC() do { } while (0)
+#define COVL_LD(p) (*(p))
+#define COVL_RELEASE() do { } while (0)
+#define COVL_ACQUIRE() do { } while (0)
+#define COVL_RELAX() do { } while (0)
+#define COVL_SPIN_LIMIT 1u
+#include "../../coverm_amd/csrc/inflate_lds_core.h"
+#else
 #include "../../coverm_amd/csrc/inflate_wave_core.h"
+#endif
 
-static uint32_t g_ring[16 * 64];
 static uint64_t rng_state = 88172645463325252ull;
 static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
 
@@ -45,7 +55,7 @@ static std::vector<uint8_t> deflate_raw(const std::vector<uint8_t> &in, int leve
 }
 
 // -> status; `want` non-null: the resolved bytes must equal it when the status is OK
-static int run(int stores, int cursor, const std::vector<uint8_t> &payload, uint32_t misalign, uint32_t isize, const std::vector<uint8_t> *want) {
+static int run(const std::vector<uint8_t> &payload, uint32_t misalign, uint32_t isize, const std::vector<uint8_t> *want) {
     const size_t nbytes = misalign + payload.size() + 64;                    // the contract: 64 readable bytes behind the payload
     uint32_t *words = static_cast<uint32_t *>(malloc((nbytes + 3) / 4 * 4));
     for (size_t k = 0; k < (nbytes + 3) / 4; k++) words[k] = rnd();
@@ -57,18 +67,30 @@ static int run(int stores, int cursor, const std::vector<uint8_t> &payload, uint
     const uint32_t toff = rnd() & 3u;                                        // the list begins at any 2-byte address
     uint16_t *tok_alloc = static_cast<uint16_t *>(malloc((covw::TOK_CAP + toff) * 2));
     uint16_t *tok = tok_alloc + toff;
-    static covw::Wave W;
     uint32_t nt = 0, st = 0;
     const uint32_t b0 = 8u * misalign, nb = 8u * (uint32_t)payload.size();
-    if (stores == 1) (cursor == 2 ? covw::inflate_block<1, 2> : covw::inflate_block<1, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
-    else if (stores == 2) (cursor == 2 ? covw::inflate_block<2, 2> : covw::inflate_block<2, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
-    else if (stores == 3) (cursor == 2 ? covw::inflate_block<3, 2> : covw::inflate_block<3, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
-    else if (stores == 4) (cursor == 2 ? covw::inflate_block<4, 2> : covw::inflate_block<4, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
-    else if (stores == 5) (cursor == 2 ? covw::inflate_block<5, 2> : covw::inflate_block<5, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
-    else if (stores == 6) (cursor == 2 ? covw::inflate_block<6, 2> : covw::inflate_block<6, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
-    else (cursor == 2 ? covw::inflate_block<7, 2> : covw::inflate_block<7, 1>)(W, words, b0, nb, out, isize, tok, &nt, &st, 0, g_ring);
+#ifdef COVL
+    // what k_inflate_lds does around the core: the bitmap zeroed, the payload staged into the image when it fits, the image copied out
+    static covl::Block *W = static_cast<covl::Block *>(malloc(sizeof(covl::Block)));      // exactly the LDS allocation: the sanitizer sees every access outside it
+    memset(W->pend, 0, sizeof W->pend);
+    memset(W->img, 0xEE, sizeof W->img);
+    const bool staged = misalign + payload.size() + 48 <= covl::IMG_BYTES && (rnd() & 7u) != 0;
+    if (staged) memcpy(W->cin, words, (misalign + payload.size() + 48 + 3) / 4 * 4);
+    const uint32_t bias = off & 15u;
+    covl::inflate_block_lds(*W, words, b0, nb, staged, bias, isize, &st, 0);
+    if (st == covw::OK) {
+        memcpy(out, W->img + bias, isize);
+        for (uint32_t k = 0; k < covl::PEND_WORDS; k++) if (W->pend[k]) st = 99;      // every match resolved: the bitmap is all zero again
+    }
+    int rc = (int)st;
+    if (st == covw::OK) { if (want && (want->size() != isize || memcmp(want->data(), out, isize) != 0)) rc = -3; }
+    if (false) {
+#else
+    static covw::Wave W;
+    covw::inflate_block(W, words, b0, nb, out, isize, tok, &nt, &st, 0);
     int rc = (int)st;
     if (st == covw::OK) {
+#endif
         for (uint32_t t = 0; t < nt; t++) {                                  // k_lz_resolve, serially
             const uint32_t p = tok[t];
             if (p + 3 > isize) { rc = -2; break; }
@@ -96,9 +118,7 @@ int main(int argc, char **argv) {
             data[k] = kind == 0 ? (uint8_t)rnd() : kind == 1 ? (uint8_t)("ACGTN!#I"[rnd() & 7u]) : kind == 2 ? (uint8_t)(rnd() % 3u ? 0 : rnd()) : (uint8_t)(k * 7u >> (rnd() & 3u));
         const int level = (int)(rnd() % 10u), strategy = (rnd() & 7u) == 0 ? Z_FIXED : (rnd() & 7u) == 1 ? Z_HUFFMAN_ONLY : (rnd() & 7u) == 2 ? Z_RLE : Z_DEFAULT_STRATEGY;
         const std::vector<uint8_t> comp = deflate_raw(data, level, strategy, (rnd() & 3u) ? 1 : 2 + (int)(rnd() % 6u));
-        const int stores = 1 + r % 7;                                        // covw::Sink<1..7> in turn
-        const int cursor = 1 + (r / 7) % 2;
-        const int a = run(stores, cursor, comp, rnd() & 3u, size, &data);
+        const int a = run(comp, rnd() & 3u, size, &data);
         if (a != 0) {
             fprintf(stderr, "round %d: valid stream (size %u level %d strategy %d) -> %d\n", r, size, level, strategy, a);
             if (FILE *f = fopen("/tmp/covw_fuzz_fail.bin", "wb")) { fwrite(comp.data(), 1, comp.size(), f); fclose(f); }
@@ -114,7 +134,7 @@ int main(int argc, char **argv) {
             else if (how == 3) { const size_t at = rnd() % bad.size(); for (size_t k = at; k < bad.size(); k++) bad[k] = (uint8_t)rnd(); }
             else bad[0] = (uint8_t)rnd();
             const uint32_t isz = (rnd() & 3u) ? size : (rnd() % 65536u);
-            const int b = run(stores, cursor, bad, rnd() & 3u, isz, nullptr);
+            const int b = run(bad, rnd() & 3u, isz, nullptr);
             if (b == -2 || b == -4) { fprintf(stderr, "round %d: status OK with a token outside the block, or bytes written in front of it (%d)\n", r, b); return 1; }
             if (b != 0) rejected++; else differ++;
         }

@@ -18,14 +18,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-@pytest.fixture(scope="module", params=["stores 2, lanes 0..63", "stores 2, lanes 63..0", "stores 1, lanes 63..0", "stores 3, lanes 63..0", "stores 4, lanes 63..0",
-                                        "stores 4, lanes 0..63", "stores 5, lanes 63..0", "stores 5, lanes 0..63", "stores 2, lanes 63..0, cursor 2", "stores 5, lanes 0..63, cursor 2", "stores 6, lanes 63..0", "stores 6, lanes 0..63, cursor 2", "stores 7, lanes 63..0", "stores 7, lanes 0..63, cursor 2"])
+@pytest.fixture(scope="module", params=["wave, lanes 0..63", "wave, lanes 63..0", "lds, lanes 0..255", "lds, lanes 255..0"])
 def host(request, tmp_path_factory):
-    # the lanes of a COVW_PARFOR region run concurrently on the device; here they run one after the other, in both orders; and pass 3
-    # exists with seven store policies (covw::Sink<1..7>), each a kernel of its own on the device
+    # the lanes of a COVW_PARFOR region run concurrently on the device; here they run one after the other, in both orders
     so = str(tmp_path_factory.mktemp("covw") / "covw_host.so")
-    subprocess.check_call(["g++", "-O2", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "c", "inflate_wave_host.cpp"),
-                           "-DCOVW_STORES=" + request.param[7]] + (["-DCOVW_REVERSE"] if "63..0" in request.param else []) + (["-DCOVW_CURSOR=" + request.param[-1]] if "cursor" in request.param else []))
+    subprocess.check_call(["g++", "-O2", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "c", "inflate_wave_host.cpp")]
+                          + (["-DCOVW_REVERSE"] if "..0" in request.param else []) + (["-DCOVL"] if "lds" in request.param else []))
     L = C.CDLL(so)
     L.covw_host_inflate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.covw_host_inflate.restype = C.c_int
@@ -34,6 +32,7 @@ def host(request, tmp_path_factory):
     L.covw_host_wave_bytes.restype = C.c_uint32
     L.covw_host_last_deflate_blocks.restype = C.c_uint32
     L.covw_host_last_chunks.restype = C.c_uint32
+    L.kind = request.param.split(",")[0]
     return L
 
 
@@ -101,8 +100,11 @@ def bam_like(rng, n):
     return b"".join(parts)[:n]
 
 
-def test_state_fits_twenty_five_waves_per_cu(host):
-    assert host.covw_host_wave_bytes() <= 6528      # 160 KiB of LDS per CU / 6.4 KiB: 25 waves (the registers allow 16); the line buffers of Sink<5> / <6> are 1 / 4 KiB more
+def test_state_fits_the_lds_of_a_cu(host):
+    if host.kind == "lds":
+        assert host.covw_host_wave_bytes() <= 80 * 1024      # two workgroups (blocks) per CU of 160 KiB
+    else:
+        assert host.covw_host_wave_bytes() <= 6528      # 160 KiB of LDS per CU / 6.4 KiB: 25 waves (the registers allow 16)
 
 
 @pytest.mark.parametrize("level", [1, 6, 9])
@@ -230,11 +232,14 @@ def test_blocks_written_by_the_product_writer(host, tmp_path):
     assert np.mean(rounds_seen) < 1.5, np.bincount(rounds_seen)     # pass 2 runs once on nearly every block
 
 
-def test_sanitizer_run_over_valid_and_damaged_streams(tmp_path):
-    """tests/c/inflate_wave_fuzz.cpp: exact-size buffers under AddressSanitizer + UBSan — the 16 readable bytes behind the payload, the isize
-    output bytes and the TOK_CAP token positions are all the core may touch, whatever the stream holds."""
+@pytest.mark.parametrize("core", ["wave", "lds"])
+def test_sanitizer_run_over_valid_and_damaged_streams(tmp_path, core):
+    """tests/c/inflate_wave_fuzz.cpp: exact-size buffers under AddressSanitizer + UBSan — the 64 readable bytes behind the payload, the isize
+    output bytes and the TOK_CAP token positions (wave core), the LDS allocation of one block (lds core: the state is malloc'ed at exactly
+    sizeof(covl::Block)) are all a core may touch, whatever the stream holds."""
     exe = str(tmp_path / "covw_fuzz")
-    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe, os.path.join(HERE, "c", "inflate_wave_fuzz.cpp"), "-lz"],
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe, os.path.join(HERE, "c", "inflate_wave_fuzz.cpp"), "-lz"]
+                       + (["-DCOVL"] if core == "lds" else []),
                        capture_output=True, text=True)
     if r.returncode != 0:
         pytest.skip("no sanitizer runtime / zlib headers here: " + r.stderr[-200:])

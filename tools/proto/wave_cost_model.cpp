@@ -60,8 +60,7 @@ int main(int argc, char **argv) {
         memcpy(words.data(), pay, plen);
         for (int m = 0; m < 3; m++) for (int l = 0; l < 64; l++) g_trace[m][l].clear();
         uint32_t nt = 0, st = 0;
-        static uint32_t ring[16 * 64];
-        covw::inflate_block(W, words.data(), 0, 8u * plen, out_al + (nb * 13) % 64, isize, tok.data(), &nt, &st, 0, ring);
+        covw::inflate_block(W, words.data(), 0, 8u * plen, out_al + (nb * 13) % 64, isize, tok.data(), &nt, &st, 0);
         if (st != 0) { fprintf(stderr, "block %ld: status %u\n", nb, st); return 1; }
         rounds += W.rounds;
         for (int m = 0; m < 3; m++) {
@@ -93,7 +92,7 @@ int main(int argc, char **argv) {
         }
         nb++;
     }
-    printf("LB %u DB %u, stores %d: %ld blocks, pass-2 rounds per block %.3f\n", covw::LB, covw::DB, COVW_STORES, nb, (double)rounds / nb);
+    printf("LB %u DB %u: %ld blocks, pass-2 rounds per block %.3f\n", covw::LB, covw::DB, nb, (double)rounds / nb);
     printf("lane-stores per block (width: unaligned + aligned):");
     const int widths[5] = {1, 2, 4, 8, 16};
     double tot = 0;

@@ -21,10 +21,13 @@ print("write %.1fs %.2f GB" % (time.time() - t, os.path.getsize(p) / 1e9), flush
 BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "coverm_amd", "coverm-amd")
 cmd = [BIN, "contig", "-b", p, "-m", "mean", "trimmed_mean", "covered_fraction", "variance", "count", "--min-read-percent-identity", "95", "--min-read-aligned-length", "50",
        "--proper-pairs-only", "-t", str(threads)]
-stores = os.environ.get("SWEEP_STORES", "2")
-configs = [("k_inflate, 81920-block windows", {})]
-for rb in (81920, 40960, 20480, 10240):
-    configs.append(("k_inflate_wave, %d-block windows" % rb, {"COVERM_INFLATE_V": "3", "COVERM_INFLATE_WAVE_STORES": stores, "COVERM_INGEST_ROUND_BLOCKS": str(rb)}))
+configs = [("k_inflate (lane per block), 81920-block windows", {"COVERM_INFLATE_V": "1"})]
+for rb in (81920, 40960, 20480, 10240, 5120):
+    configs.append(("k_inflate_wave, %d-block windows" % rb, {"COVERM_INGEST_ROUND_BLOCKS": str(rb)}))
+if os.environ.get("SWEEP_ONLY_LDS"):
+    configs = [("k_inflate_wave, 81920-block windows", {}), ("k_inflate_lds, 81920-block windows", {"COVERM_INFLATE_V": "4"}),
+               ("k_inflate_lds, 40960-block windows", {"COVERM_INFLATE_V": "4", "COVERM_INGEST_ROUND_BLOCKS": "40960"}),
+               ("k_inflate_lds, 20480-block windows", {"COVERM_INFLATE_V": "4", "COVERM_INGEST_ROUND_BLOCKS": "20480"})]
 tables = {}
 for name, env in configs:
     walls = []
@@ -41,7 +44,7 @@ for name, env in configs:
         if rep == 0:
             tables[name] = open(out).read() if r.returncode == 0 else None
             for l in r.stderr.splitlines():
-                if "device ingest: buffers" in l or "windows of" in l or "VmHWM" in l or "fallback" in l.lower():
+                if "device ingest" in l or "windows of" in l or "VmHWM" in l or "fallback" in l.lower() or "[cli]" in l or "exit" in l:
                     print("    " + l.strip())
     if walls:
         print("%s: wall %s s, median %.3f s (rc %d)" % (name, " ".join("%.3f" % w for w in walls), sorted(walls)[len(walls) // 2], r.returncode), flush=True)
