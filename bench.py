@@ -324,9 +324,9 @@ def end_to_end(a, threads):
             size6 = os.path.getsize(p6)
             g6, reps6, err6, rss6 = run_binary(cmd, 3)
             same6 = open(out_tsv).read() == want_text
-            d6, d6_all, _ = cpu_decode(p6, threads, 1)
+            d6, d6_all, _ = cpu_decode(p6, threads, 3)
             res["level6"] = dict(bam_bytes=size6, bam_bytes_per_read=size6 / reads, bam_write_s=w6, gpu_seconds=g6, seconds_is="median of three runs", rep_seconds=reps6,
-                                 reads_per_s=reads / g6, max_rss_bytes=rss6, stderr_timing=timing_lines(err6), cpu_decode_s=d6, cpu_scan_s=scan_s,
+                                 reads_per_s=reads / g6, max_rss_bytes=rss6, stderr_timing=timing_lines(err6), cpu_decode_s=d6, cpu_decode_runs=d6_all, cpu_scan_s=scan_s,
                                  speedup_vs_cpu_overlapped=(reads / g6) / (reads / max(d6, scan_s)), speedup_vs_cpu_serial=(reads / g6) / (reads / (d6 + scan_s)),
                                  tables_equal=same6)
             res["tables_equal"] = res["tables_equal"] and same6
@@ -661,6 +661,25 @@ def main():
                     exit_code = 3
             except Exception as ex:
                 out["multi_device_end_to_end"] = {"error": repr(ex)[:1000]}
+        # The scalars a reader of the record needs, as the LAST keys of the line (a log that keeps only the tail of the line keeps these):
+        # end to end (BAM file -> TSV, config-5 size and flags) at BGZF level 1 and 6 — GPU median of three, CPU best of three, x = GPU rate
+        # over the CPU's decode and scan perfectly overlapped —, configs 2 and 3 through the binary, and whether every table compared equal.
+        e2e = (out.get("bases") or {}).get("end_to_end") or {}
+        l6 = e2e.get("level6") or {}
+        bc = out.get("binary_configs") or {}
+        r3 = lambda x: None if x is None else round(float(x), 3)
+        out.update({
+            "e2e_reads": e2e.get("reads"),
+            "e2e_l1_s": r3((e2e.get("gpu") or {}).get("seconds")), "e2e_l1_x_overlapped": r3(e2e.get("speedup_vs_cpu_overlapped")),
+            "e2e_l1_x_serial": r3(e2e.get("speedup_vs_cpu_serial")),
+            "e2e_l6_s": r3(l6.get("gpu_seconds")), "e2e_l6_x_overlapped": r3(l6.get("speedup_vs_cpu_overlapped")), "e2e_l6_x_serial": r3(l6.get("speedup_vs_cpu_serial")),
+            "cpu_decode_s": r3((e2e.get("cpu") or {}).get("decode_s")), "cpu_decode_l6_s": r3(l6.get("cpu_decode_s")), "cpu_scan_s": r3((e2e.get("cpu") or {}).get("scan_s")),
+            "cpu_threads": e2e.get("threads"),
+            "cfg2_binary_s": r3((bc.get("config2_contig") or {}).get("seconds")), "cfg3_binary_s": r3((bc.get("config3_genome") or {}).get("seconds")),
+            "parity_equal": (out.get("parity_checked") or {}).get("equal"),
+            "tables_equal": (bool(e2e.get("tables_equal")) and bool(bc.get("tables_equal"))) if (e2e and bc and "error" not in e2e and "error" not in bc) else None,
+            "device_resident_ms": r3(out["ms_per_step"]), "pileup_kernel_ms": r3(roof.get("kernel_ms")), "roofline_frac": round(float(roof.get("frac") or 0.0), 4),
+        })
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

@@ -79,7 +79,7 @@ std::string g_create_error;
 //                        the fill and drain of the pipeline);
 //   version 1 (COVERM_INFLATE_V=1): k_inflate, one LANE per block, private Huffman tables per lane in LDS — the second implementation the
 //                        tests compare with; a launch is cut to exactly the blocks resident at once (a lane decodes a block serially).
-struct InflateKernel { int version = 3; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ablate = 0; };
+struct InflateKernel { int version = 3; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ablate = 0; u32 pad_lds = 0; };
 
 struct cov_session {
     cov_config cfg{};
@@ -1013,8 +1013,7 @@ constexpr u32 WAVE_ROUND_BLOCKS = 81920;
 static InflateKernel choose_inflate_kernel(cov_session *s) {
     InflateKernel K;
     const char *ve = getenv("COVERM_INFLATE_V");
-    K.version = ve && atoi(ve) == 1 ? 1 : (ve && atoi(ve) == 4 ? 4 : 3);
-    if (K.version == 4) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)covi::inflate_lds_smem_bytes());
+    K.version = ve && atoi(ve) == 1 ? 1 : 3;
     if (K.version == 1) {
         int per_cu = 0;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<INF1_LB, INF1_DB, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1030,6 +1029,7 @@ static InflateKernel choose_inflate_kernel(cov_session *s) {
     // less compressible blocks simply closes earlier
     K.cwin = std::max<u64>((u64)K.round_blocks * 32768u, 1ull << 20);
     if (const char *c = getenv("COVERM_INGEST_CWIN_KB")) { const long v = atol(c); if (v >= 256) K.cwin = (u64)v << 10; }
+    K.pad_lds = (u32)(getenv("COVERM_INFLATE_WAVE_PAD_KB") ? atoi(getenv("COVERM_INFLATE_WAVE_PAD_KB")) : 0) << 10;      // measurements: unused LDS lowers k_inflate_wave's resident waves per CU
     K.ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);      // measurements: stop every block after the tables / pass 1 / pass 2
     return K;
 }
@@ -1194,11 +1194,8 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
         const u32 grid = (n + 63u) / 64u;
         const uint8_t *comp_bias = s->g_cwin[w % 3u].p - s->ing_round_start;     // blocks carry absolute file offsets
         const u32 ablate = K.ablate;
-        if (K.version == 4)
-            hipLaunchKernelGGL(covi::k_inflate_lds, dim3(n), dim3(256), covi::inflate_lds_smem_bytes(), s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, ntokb.p,
-                               s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
-        else if (K.version == 3)
-            hipLaunchKernelGGL(covi::k_inflate_wave, dim3(n), dim3(64), 0, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, tokb.p, ntokb.p,
+        if (K.version == 3)
+            hipLaunchKernelGGL(covi::k_inflate_wave, dim3(n), dim3(64), K.pad_lds, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, tokb.p, ntokb.p,
                                s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
         else
             hipLaunchKernelGGL((covi::k_inflate<INF1_LB, INF1_DB, false>), dim3(grid), dim3(64), covi::inflate_smem_bytes(INF1_LB, INF1_DB), s->stream, comp_bias,
@@ -1207,8 +1204,7 @@ static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
         HIPCHK(hipEventRecord(s->ing_inf_done[bb], s->stream));
         HIPCHK(hipEventRecord(s->ing_cdone[w % 3u], s->stream));      // this round's compressed buffer may be overwritten (three rounds on)
         HIPCHK(hipStreamWaitEvent(s->ing_aux, s->ing_inf_done[bb], 0));
-        if (K.version != 4)      // (k_inflate_lds resolves its matches itself)
-            hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
+        hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
                            (const covi::tokpos_t *)tokb.p, (const u32 *)ntokb.p);
         // the window's bytes are final once the matches are resolved: the boundary search (parse stream) starts here, beside the
         // CRC-32 pass, whose verdict is only looked at in cov_ingest_end (the aux stream is in order, so CRC(w) is done before LZ(w + 1)

@@ -338,7 +338,7 @@ struct NoSink {      // passes 1 and 2 write nothing
     COVW_FN void match(u32, u32, u32, u32) {}
     COVW_FN void finish(u32) {}
 };
-// (SinkT: where pass 3's bytes go — Sink: the block's place in global memory; covl::SinkLds: the block's image in LDS.  opos: position of the
+// (SinkT: where pass 3's bytes go — Sink: the block's place in global memory.  opos: position of the
 // lane's first byte in the sink's coordinates, pmin: position of the block's first byte — a match may not reach in front of it.)
 template <int MODE, class SinkT>
 COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, SinkT &sink, u32 opos, u32 pmin, u32 tpos, u32 *err) {

@@ -441,17 +441,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
 #define COVW_NO_UNROLL _Pragma("clang loop unroll(disable) vectorize(disable)")
 #define COVW_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define COVW_ATOMIC_OR(p, v) atomicOr((p), (v))
-#define COVW_ATOMIC_MIN(p, v) atomicMin((p), (v))
-#define COVW_ATOMIC_AND(p, v) atomicAnd((p), (v))
-#define COVL_PARFOR(lane) for (unsigned lane = threadIdx.x, covl_once = 1u; covl_once; covl_once = 0u)
-#define COVL_SYNC() __syncthreads()
-#define COVL_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define COVL_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
-#define COVL_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
-#define COVL_RELAX() do { } while (0)
-#define COVL_SPIN_LIMIT 0xffffffffu
 #include "inflate_wave_core.h"
-#include "inflate_lds_core.h"
 namespace covi {
 static_assert(covw::TOK_CAP == INF_TOK_CAP && covw::OK == INF_OK && covw::ERR_FORMAT == INF_ERR_FORMAT && covw::ERR_SIZE == INF_ERR_SIZE, "the core mirrors k_inflate's contract");
 // (A cursor of two words and a funnel shift instead of the 64-bit buffer was tried: no fewer instructions per unit; a look-ahead cursor with
@@ -471,49 +461,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     }
     if ((threadIdx.x & 63u) == 0u) {
         n_tok[b] = nt; status[b] = st;
-        if (st != INF_OK) atomicAdd(n_failed, 1u);
-    }
-}
-
-// One WORKGROUP (256 lanes) per BGZF block, the block assembled in LDS (csrc/inflate_lds_core.h): stage the payload, decode in three passes,
-// resolve the matches in LDS, write the finished 64 KiB once with aligned 16-byte stores.  No tokens leave the kernel: n_tok[b] = 0 and
-// k_lz_resolve is not launched.  Dynamic LDS: sizeof(covl::Block) = 79.2 KiB, two workgroups per CU.
-constexpr size_t inflate_lds_smem_bytes() { return sizeof(covl::Block); }
-static_assert(sizeof(covl::Block) <= 80u * 1024u, "two blocks per CU");
-__global__ __launch_bounds__(256) void k_inflate_lds(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
-                                                     uint8_t *__restrict__ out, u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char covl_lds[];
-    covl::Block &W = *reinterpret_cast<covl::Block *>(covl_lds);
-    const u32 b = blockIdx.x, tid = threadIdx.x;
-    if (b >= n_blocks) return;
-    const BgzfBlock B = blocks[b];
-    u32 st = INF_OK;
-    if (B.isize != 0u) {
-        for (u32 i = tid; i < covl::PEND_WORDS; i += 256u) W.pend[i] = 0u;
-        const uint8_t *src = comp + B.in_off;
-        const u32 mis = (u32)((u64)src & 15u);
-        const u32 nbytes = mis + B.in_len + 48u;             // (the compressed buffer is readable 64 bytes past a payload: 48 + up to 15 of rounding)
-        const bool staged = nbytes <= covl::IMG_BYTES;
-        if (staged) {
-            const uint4 *s16 = reinterpret_cast<const uint4 *>(src - mis);
-            uint4 *d16 = reinterpret_cast<uint4 *>(W.cin);
-            for (u32 i = tid; i < (nbytes + 15u) / 16u; i += 256u) d16[i] = s16[i];
-        }
-        __syncthreads();
-        uint8_t *dst = out + B.out_off;
-        const u32 bias = (u32)((u64)dst & 15u);
-        covl::inflate_block_lds(W, reinterpret_cast<const u32 *>(src - mis), 8u * mis, 8u * B.in_len, staged, bias, B.isize, &st, stop_after);
-        __syncthreads();
-        if (st == INF_OK) {      // image position a <-> dst - bias + a: the same alignment on both sides
-            const u32 total = bias + B.isize;
-            for (u32 a = 16u * tid; a < total; a += 16u * 256u) {
-                if (a >= bias && a + 16u <= total) *reinterpret_cast<uint4 *>(dst - bias + a) = *reinterpret_cast<const uint4 *>(W.img + a);
-                else for (u32 k = max(a, bias); k < min(a + 16u, total); k++) dst[k - bias] = W.img[k];
-            }
-        }
-    }
-    if (tid == 0u) {
-        n_tok[b] = 0u; status[b] = st;
         if (st != INF_OK) atomicAdd(n_failed, 1u);
     }
 }

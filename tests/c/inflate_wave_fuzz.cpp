@@ -18,18 +18,7 @@ static inline unsigned covw_brev32(unsigned x) {
     x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
     return __builtin_bswap32(x);
 }
-#ifdef COVL          // the workgroup-per-block decoder (csrc/inflate_lds_core.h): 256 lanes, the block assembled in (what is on the device) LDS
-#define COVL_PARFOR(lane) for (unsigned lane = 0; lane < 256u; lane++)
-#define COVL_SYNC() do { } while (0)
-#define COVL_LD(p) (*(p))
-#define COVL_RELEASE() do { } while (0)
-#define COVL_ACQUIRE() do { } while (0)
-#define COVL_RELAX() do { } while (0)
-#define COVL_SPIN_LIMIT 1u
-#include "../../coverm_amd/csrc/inflate_lds_core.h"
-#else
 #include "../../coverm_amd/csrc/inflate_wave_core.h"
-#endif
 
 static uint64_t rng_state = 88172645463325252ull;
 static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
@@ -69,28 +58,11 @@ static int run(const std::vector<uint8_t> &payload, uint32_t misalign, uint32_t 
     uint16_t *tok = tok_alloc + toff;
     uint32_t nt = 0, st = 0;
     const uint32_t b0 = 8u * misalign, nb = 8u * (uint32_t)payload.size();
-#ifdef COVL
-    // what k_inflate_lds does around the core: the bitmap zeroed, the payload staged into the image when it fits, the image copied out
-    static covl::Block *W = static_cast<covl::Block *>(malloc(sizeof(covl::Block)));      // exactly the LDS allocation: the sanitizer sees every access outside it
-    memset(W->pend, 0, sizeof W->pend);
-    memset(W->img, 0xEE, sizeof W->img);
-    const bool staged = misalign + payload.size() + 48 <= covl::IMG_BYTES && (rnd() & 7u) != 0;
-    if (staged) memcpy(W->cin, words, (misalign + payload.size() + 48 + 3) / 4 * 4);
-    const uint32_t bias = off & 15u;
-    covl::inflate_block_lds(*W, words, b0, nb, staged, bias, isize, &st, 0);
-    if (st == covw::OK) {
-        memcpy(out, W->img + bias, isize);
-        for (uint32_t k = 0; k < covl::PEND_WORDS; k++) if (W->pend[k]) st = 99;      // every match resolved: the bitmap is all zero again
-    }
-    int rc = (int)st;
-    if (st == covw::OK) { if (want && (want->size() != isize || memcmp(want->data(), out, isize) != 0)) rc = -3; }
-    if (false) {
-#else
     static covw::Wave W;
     covw::inflate_block(W, words, b0, nb, out, isize, tok, &nt, &st, 0);
     int rc = (int)st;
     if (st == covw::OK) {
-#endif
+
         for (uint32_t t = 0; t < nt; t++) {                                  // k_lz_resolve, serially
             const uint32_t p = tok[t];
             if (p + 3 > isize) { rc = -2; break; }

@@ -19,25 +19,9 @@ static inline unsigned covw_brev32(unsigned x) {
     x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
     return __builtin_bswap32(x);
 }
-#ifdef COVL          // the workgroup-per-block decoder (csrc/inflate_lds_core.h): 256 lanes, the block assembled in (what is on the device) LDS
-#ifdef COVW_REVERSE
-#define COVL_PARFOR(lane) for (unsigned lane##_r = 0, lane = 255u; lane##_r < 256u; lane##_r++, lane = 255u - lane##_r)
-#else
-#define COVL_PARFOR(lane) for (unsigned lane = 0; lane < 256u; lane++)
-#endif
-#define COVL_SYNC() do { } while (0)
-#define COVL_LD(p) (*(p))
-#define COVL_RELEASE() do { } while (0)
-#define COVL_ACQUIRE() do { } while (0)
-#define COVL_RELAX() do { } while (0)
-#define COVL_SPIN_LIMIT 1u
-#include "../../coverm_amd/csrc/inflate_lds_core.h"
-static covl::Block g_wave;
-#else
 #include "../../coverm_amd/csrc/inflate_wave_core.h"
 
 static covw::Wave g_wave;
-#endif
 
 extern "C" {
 
@@ -51,22 +35,9 @@ int covw_host_inflate(const uint8_t *payload, uint32_t nbytes, uint32_t misalign
     memcpy(reinterpret_cast<uint8_t *>(words.data()) + misalign, payload, nbytes);
     memset(out, 0xC3, 8); memset(out + 8 + isize, 0xC3, 8);
     uint32_t status = 0;
-#ifdef COVL
-    // what k_inflate_lds does around the core: the bitmap zeroed, the payload staged into the image when it fits, the image copied out
-    covl::Block &W = g_wave;
-    W.rounds = 0;
-    memset(W.pend, 0, sizeof W.pend);
-    const bool staged = misalign + nbytes + 48 <= covl::IMG_BYTES && (slack_fill & 1u);
-    if (staged) memcpy(W.cin, words.data(), (misalign + nbytes + 48 + 3) / 4 * 4);
-    const uint32_t bias = (misalign * 5u + 3u) & 15u;
-    covl::inflate_block_lds(W, words.data(), 8u * misalign, 8u * nbytes, staged, bias, isize, &status, 0);
-    if (status == covw::OK) memcpy(out + 8, W.img + bias, isize);
-    *n_tok = 0; (void)tok;
-#else
     covw::Wave &W = g_wave;
     W.rounds = 0;
     covw::inflate_block(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status, 0);
-#endif
     if (rounds) *rounds = W.rounds;
     for (int k = 0; k < 8; k++) if (out[k] != 0xC3 || out[8 + isize + k] != 0xC3) return -1;
     return (int)status;

@@ -18,14 +18,14 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar")
 
 
-@pytest.fixture(autouse=True, params=["default", "lane-per-block", "workgroup-per-block"])
+@pytest.fixture(autouse=True, params=["default", "lane-per-block"])
 def inflate_version(request, monkeypatch):
     """Every test of this file runs with the inflate kernel that ships (k_inflate_wave: one wave per BGZF block) and with the second
     implementation (k_inflate: one lane per block).  cov_ingest_begin reads the switch, so sessions of one process may differ."""
     if request.param == "default":
         monkeypatch.delenv("COVERM_INFLATE_V", raising=False)
     else:
-        monkeypatch.setenv("COVERM_INFLATE_V", "1" if request.param == "lane-per-block" else "4")
+        monkeypatch.setenv("COVERM_INFLATE_V", "1")
     return request.param
 
 

@@ -18,12 +18,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-@pytest.fixture(scope="module", params=["wave, lanes 0..63", "wave, lanes 63..0", "lds, lanes 0..255", "lds, lanes 255..0"])
+@pytest.fixture(scope="module", params=["lanes 0..63", "lanes 63..0"])
 def host(request, tmp_path_factory):
     # the lanes of a COVW_PARFOR region run concurrently on the device; here they run one after the other, in both orders
     so = str(tmp_path_factory.mktemp("covw") / "covw_host.so")
     subprocess.check_call(["g++", "-O2", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "c", "inflate_wave_host.cpp")]
-                          + (["-DCOVW_REVERSE"] if "..0" in request.param else []) + (["-DCOVL"] if "lds" in request.param else []))
+                          + (["-DCOVW_REVERSE"] if "..0" in request.param else []))
     L = C.CDLL(so)
     L.covw_host_inflate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.covw_host_inflate.restype = C.c_int
@@ -32,7 +32,6 @@ def host(request, tmp_path_factory):
     L.covw_host_wave_bytes.restype = C.c_uint32
     L.covw_host_last_deflate_blocks.restype = C.c_uint32
     L.covw_host_last_chunks.restype = C.c_uint32
-    L.kind = request.param.split(",")[0]
     return L
 
 
@@ -100,11 +99,8 @@ def bam_like(rng, n):
     return b"".join(parts)[:n]
 
 
-def test_state_fits_the_lds_of_a_cu(host):
-    if host.kind == "lds":
-        assert host.covw_host_wave_bytes() <= 80 * 1024      # two workgroups (blocks) per CU of 160 KiB
-    else:
-        assert host.covw_host_wave_bytes() <= 6528      # 160 KiB of LDS per CU / 6.4 KiB: 25 waves (the registers allow 16)
+def test_state_fits_twenty_five_waves_per_cu(host):
+    assert host.covw_host_wave_bytes() <= 6528      # 160 KiB of LDS per CU / 6.4 KiB: 25 waves (the registers allow 16)
 
 
 @pytest.mark.parametrize("level", [1, 6, 9])
@@ -232,14 +228,11 @@ def test_blocks_written_by_the_product_writer(host, tmp_path):
     assert np.mean(rounds_seen) < 1.5, np.bincount(rounds_seen)     # pass 2 runs once on nearly every block
 
 
-@pytest.mark.parametrize("core", ["wave", "lds"])
-def test_sanitizer_run_over_valid_and_damaged_streams(tmp_path, core):
+def test_sanitizer_run_over_valid_and_damaged_streams(tmp_path):
     """tests/c/inflate_wave_fuzz.cpp: exact-size buffers under AddressSanitizer + UBSan — the 64 readable bytes behind the payload, the isize
-    output bytes and the TOK_CAP token positions (wave core), the LDS allocation of one block (lds core: the state is malloc'ed at exactly
-    sizeof(covl::Block)) are all a core may touch, whatever the stream holds."""
+    output bytes and the TOK_CAP token positions are all the core may touch, whatever the stream holds."""
     exe = str(tmp_path / "covw_fuzz")
-    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe, os.path.join(HERE, "c", "inflate_wave_fuzz.cpp"), "-lz"]
-                       + (["-DCOVL"] if core == "lds" else []),
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe, os.path.join(HERE, "c", "inflate_wave_fuzz.cpp"), "-lz"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         pytest.skip("no sanitizer runtime / zlib headers here: " + r.stderr[-200:])
@@ -247,3 +240,4 @@ def test_sanitizer_run_over_valid_and_damaged_streams(tmp_path, core):
         r = subprocess.run([exe, "120", seed], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         assert "120 valid streams exact" in r.stdout
+
