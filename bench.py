@@ -388,28 +388,30 @@ def multi_device_legs(a, threads, world, devs=None):
     res["devices_arg"] = devs
     try:
         ref = synth.make_reference(a.contigs, a.bp, seed=1)
-        # ---- config 4: N samples (the same 50 M reads under N names: hard links), one per device
-        batch = synth.make_reads(ref, a.reads, seed=2)
-        first = os.path.join(tmpdir, "sample0.bam")
-        cbam.write_bam(first, ref.names, ref.lengths, batch, with_seq=2, level=1, threads=threads)
-        paths = [first]
-        for k in range(1, world):
+        # ---- config 4: N DISTINCT samples (seeds 10 .. 10 + N - 1), one per device: N readers pull N different files through
+        # the host's memory system at once — what N devices really contend for (N names for one file would share one page-cache copy)
+        paths, nrec, nbytes = [], 0, 0
+        t0 = time.time()
+        for k in range(world):
+            batch = synth.make_reads(ref, a.reads, seed=10 + k)
             paths.append(os.path.join(tmpdir, "sample%d.bam" % k))
-            os.link(first, paths[-1])
+            cbam.write_bam(paths[-1], ref.names, ref.lengths, batch, with_seq=2, level=1, threads=threads)
+            nrec += batch.n_records
+            nbytes += os.path.getsize(paths[-1])
+            del batch
+        gen4 = time.time() - t0
         out = os.path.join(tmpdir, "out.tsv")
-        cmd1 = [BIN, "contig", "-b", first, "-m"] + METHODS + ["-t", str(threads), "-o", out]
-        s1, _, _, _ = run_binary(cmd1, 1)
-        one = [l.split("\t") for l in open(out).read().splitlines()]
-        cmdn = [BIN, "contig", "-b"] + paths + ["-m"] + METHODS + ["-t", str(threads), "--devices", devs, "-o", out]
-        sn, repsn, errn, rssn = run_binary(cmdn, 3)
-        many = [l.split("\t") for l in open(out).read().splitlines()]
-        nm = len(METHODS)
-        same4 = len(one) == len(many) and all(r[0] == q[0] and all(r[1 + k * nm:1 + (k + 1) * nm] == q[1:1 + nm] for k in range(world)) for r, q in zip(many[1:], one[1:]))
-        res["config4_samples"] = dict(bams=world, reads_per_bam=batch.n_records, seconds=sn, seconds_is="median of three runs", rep_seconds=repsn,
-                                      reads_per_s=world * batch.n_records / sn, single_device_one_bam_seconds=s1, max_rss_bytes=rssn,
-                                      tables_equal=bool(same4), stderr_timing=[l for l in errn.splitlines() if "device ingest:" in l][:world],
-                                      note="the N files are hard links of one BAM (same bytes, N sample names): what is measured is N readers + N devices sharing the host")
-        del batch
+        cmd1 = [BIN, "contig", "-b"] + paths + ["-m"] + METHODS + ["-t", str(threads), "-o", out]
+        s1, _, _, _ = run_binary(cmd1 + ["--devices", devs.split(",")[0].split("-")[0]], 1)      # the same files, one device, one after the other
+        text1 = open(out).read()
+        sn, repsn, errn, rssn = run_binary(cmd1 + ["--devices", devs], 3)
+        same4 = open(out).read() == text1
+        res["config4_samples"] = dict(bams=world, reads=nrec, bam_bytes=nbytes, generation_and_write_s=gen4, seconds=sn, seconds_is="median of three runs", rep_seconds=repsn,
+                                      reads_per_s=nrec / sn, host_read_GBps=nbytes / sn / 1e9, single_device_all_bams_seconds=s1, speedup_vs_single_device=s1 / sn,
+                                      max_rss_bytes=rssn, tables_equal=bool(same4),
+                                      stderr_timing=[l for l in errn.splitlines() if "device ingest:" in l or "[covermhip] ingest" in l][:2 * world],
+                                      note="N distinct BAMs (seeds 10 ..); per device: file read = time its reader threads spent in pread, staging waits = time they "
+                                           "waited for the device to take a slot (reader-bound when the first dominates, link- or device-bound when the second does)")
         for q in paths:
             os.remove(q)
         # ---- config 5: one big BAM, N tid spans
@@ -424,7 +426,8 @@ def multi_device_legs(a, threads, world, devs=None):
         sn, repsn, errn, rssn = run_binary(cmd1 + ["--devices", devs], 3)
         res["config5_spans"] = dict(reads=nbig, bam_bytes=os.path.getsize(path), seconds=sn, seconds_is="median of three runs", rep_seconds=repsn, reads_per_s=nbig / sn,
                                     single_device_seconds=s1, single_device_rep_seconds=reps1, speedup_vs_single_device=s1 / sn, max_rss_bytes=rssn,
-                                    tables_equal=open(out).read() == text1, stderr_timing=[l for l in errn.splitlines() if "device ingest:" in l][:world])
+                                    host_read_GBps=os.path.getsize(path) / sn / 1e9, tables_equal=open(out).read() == text1,
+                                    stderr_timing=[l for l in errn.splitlines() if "device ingest:" in l or "[covermhip] ingest" in l][:2 * world])
         res["tables_equal"] = bool(same4 and res["config5_spans"]["tables_equal"])
     finally:
         shutil.rmtree(tmpdir, ignore_errors=True)
@@ -550,7 +553,7 @@ def main():
         # algorithmic HBM bytes per launch (DESIGN.md "Algorithmic bytes")
         kbytes = {"k_prep": R * 24 + ncig * 4 + R * 8,                    # SoA + CIGAR read once, run words written
                   "k_pileup": R * 8 + n_tiles * 32 + len(ref.lengths) * 160,  # run words + tile descriptors + results
-                  "k_ranges": n_tiles * 40, "k_identity": R * 32, "k_hist": 0}
+                  "k_ranges": n_tiles * 40, "k_identity": R * 32, "k_hist": 0, "k_hist_compact": 0}
         dom = max(kms, key=kms.get)
         pipe_ms = sum(kms.values())
         aligned_bp = synth.aligned_bases(batch) * (considered / max(1, R))

@@ -143,7 +143,7 @@ struct cov_session {
     hipEvent_t ev_prep_done = nullptr, ev_side_done = nullptr;
     DevBuf<u32> d_arena;
     DevBuf<u64> d_chist;
-    u64 *h_chist = nullptr; u64 h_chist_cap = 0, hist_prefetched = 0, last_chist_total = 0; bool hist_compacted = false;
+    u64 *h_chist = nullptr; u64 h_chist_cap = 0, hist_prefetched = 0, last_chist_total = 0; bool hist_compacted = false, hist_fetch_seen = false;
     DevBuf<int32_t> d_depth;
 
     // device ingest (cov_ingest_*): compressed file and inflated stream in HBM, BGZF block table, record-boundary scratch
@@ -192,6 +192,7 @@ struct cov_session {
     hipStream_t ing_copy2 = nullptr; hipEvent_t ing_c2_done = nullptr; bool ing_c2_dirty = false; int64_t ing_copy2_cleared = -1;
     hipEvent_t ing_ev[COV_INGEST_SLOTS] = {}, ing_fed = nullptr;
     double ing_s_alloc = 0;     // host seconds inside device allocations of the ingest
+    double ing_s_part[4] = {0, 0, 0, 0};     // ... inside ingest_drain / launch_round / the upload calls / event waits (COVERM_CLI_TIMING)
 
     // results of the last finish
     bool finished = false;
@@ -835,10 +836,14 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
             // bound), and as many of its bins as the previous finish had already on their way to page-locked memory, so that
             // cov_fetch_hist is no second launch + round trip (0.08 ms of a 1.9 ms step at BASELINE config 2)
             HIPCHK(s->d_chist.reserve((size_t)R + nT + 1, st));
+            time_begin(s, COV_K_HIST_COMPACT);
             hipLaunchKernelGGL(k_hist_compact, dim3(nT), dim3(256), 0, st, s->d_ctg.p, nT, s->d_tlen.p, (u64)s->cfg.contig_end_exclusion, s->d_arena.p, s->d_chist.p);
+            time_end(s, COV_K_HIST_COMPACT);
             HIPCHK(hipGetLastError());
             s->hist_prefetched = 0;
-            const u64 guess = std::min<u64>({s->last_chist_total + s->last_chist_total / 16, (u64)R + nT + 1, (u64)(64u << 20) / 8});
+            // (only for a caller that fetched the histogram after the finish before this one: a caller that never does pays no copy)
+            const u64 guess = s->hist_fetch_seen ? std::min<u64>({s->last_chist_total + s->last_chist_total / 16, (u64)R + nT + 1, (u64)(64u << 20) / 8}) : 0;
+            s->hist_fetch_seen = false;
             if (guess) {
                 if (guess > s->h_chist_cap) {
                     if (s->h_chist) (void)hipHostFree(s->h_chist);
@@ -1085,7 +1090,7 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     s->ing_key_lo = 0; s->ing_key_hi = 0x80000000ll; s->ing_search_first = false; s->ing_open_end = false; s->ing_fed_any = false;
     s->ing_span_lo = 0; s->ing_span_hi = compressed_bytes; s->ing_tail_key = ~0ull;
     s->ing_ccap = std::min<u64>(inflate_kernel(s).cwin, compressed_bytes + 65536u + 128u);     // a small file is one buffer: the byte rule never fires
-    s->ing_s_alloc = 0;
+    s->ing_s_alloc = 0; for (double &x : s->ing_s_part) x = 0;
     return COV_OK;
 }
 
@@ -1098,12 +1103,15 @@ cov_status cov_ingest_span(cov_session *s, int64_t key_lo, int64_t key_hi, int s
 
 // Records of the windows whose boundaries are verified go into the store: all windows up to `must_upto` (waiting for their
 // k_bam_verify if need be), later ones only if their result is already here.
-static cov_status ingest_drain(cov_session *s, int64_t must_upto) {
+static cov_status ingest_drain_(cov_session *s, int64_t must_upto);
+struct PartTimer { double &acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); ~PartTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } };
+static cov_status ingest_drain(cov_session *s, int64_t must_upto) { PartTimer t{s->ing_s_part[0]}; return ingest_drain_(s, must_upto); }
+static cov_status ingest_drain_(cov_session *s, int64_t must_upto) {
     hipStream_t ps = s->ing_ext;     // the host has seen the window's verification finish: nothing on the device to wait for
     while (s->ing_extracted < s->ing_batch) {
         const u32 w = s->ing_extracted, q = w & 3u;
         if ((int64_t)w > must_upto) { if (hipEventQuery(s->ing_ver_done[q]) != hipSuccess) { (void)hipGetLastError(); break; } }   // not ready is not an error
-        else HIPCHK(hipEventSynchronize(s->ing_ver_done[q]));
+        else { PartTimer pt{s->ing_s_part[3]}; HIPCHK(hipEventSynchronize(s->ing_ver_done[q])); }
         const u64 *res = s->h_winres + 8 * q;
         const u64 nrec = res[0], ncig = res[1];
         u32 st = (u32)res[2];
@@ -1115,7 +1123,11 @@ static cov_status ingest_drain(cov_session *s, int64_t must_upto) {
         if (!s->ing_fail && (R + nrec >= 0xfffffff0ull || Cg + ncig >= 0xfffffff0ull)) s->ing_fail = 16u;
         if (!s->ing_fail && nrec) {
             u64 Nn = R + nrec, Cn = Cg + ncig + 1;
-            if (w == 0 && s->ing_batch > 1 && s->ing_win[0].comp_end) {    // first of several windows: size the store for the whole file at once
+            // first of several windows (it ends in front of the span's end): size the store for the whole file at once.  (Not "several
+            // windows launched so far": with a fast inflate kernel window 0 is verified before window 1 is launched, the store was then
+            // sized for one window, and every later window grew it — allocate, copy, drain the device, free: 0.8 s of stalls at 100 M reads,
+            // profiles/r04_timeline_store_regrowth.txt.)
+            if (w == 0 && s->ing_win[0].comp_end && s->ing_win[0].comp_end + 65536u < s->ing_span_hi) {
                 const double scale = (double)(s->ing_span_hi - s->ing_span_lo) / (double)std::max<u64>(1, s->ing_win[0].comp_end - std::min<u64>(s->ing_win[0].comp_end, s->ing_span_lo)) * 1.1;
                 Nn = std::max<u64>(Nn, R + (u64)((double)nrec * scale) + 1024); Cn = std::max<u64>(Cn, Cg + (u64)((double)ncig * scale) + 1024);
                 Nn = std::min<u64>(Nn, 0xfffffff0ull); Cn = std::min<u64>(Cn, 0xfffffff0ull);
@@ -1151,7 +1163,9 @@ static cov_status ingest_drain(cov_session *s, int64_t must_upto) {
 // of resident waves: launches are cut to exactly the number of blocks the device holds at once (a launch of 1.05 rounds
 // costs 2 T — measured: 46 ms per launch of ~51 k blocks against 23.5 ms per round of 49 152).
 // Windows bound the memory: the inflated stream of a 200 M-read BAM is 62 GB, and device allocations cost ~30 ms per GB.
-static cov_status launch_round(cov_session *s, uint64_t n64, bool final) {
+static cov_status launch_round_(cov_session *s, uint64_t n64, bool final);
+static cov_status launch_round(cov_session *s, uint64_t n64, bool final) { PartTimer t{s->ing_s_part[1]}; return launch_round_(s, n64, final); }
+static cov_status launch_round_(cov_session *s, uint64_t n64, bool final) {
     const uint64_t b0 = s->ing_launched;
     n64 = std::min<uint64_t>(n64, s->ing_blocks - b0);
     const InflateKernel &K = inflate_kernel(s);
@@ -1249,6 +1263,7 @@ cov_status cov_ingest_slot_wait(cov_session *s, int slot) {
 // round r, whose first byte is file offset `origin`.
 static cov_status ingest_copy_range(cov_session *s, u32 r, u64 origin, u64 a, u64 b, const uint8_t *piece, u64 piece_off) {
     if (b <= a) return COV_OK;
+    PartTimer pt{s->ing_s_part[2]};
     DevBuf<uint8_t> &cw = s->g_cwin[r % 3u];
     const size_t need = (size_t)s->ing_ccap + 2 * 65536u + 256u;
     if (cw.cap < need) {
@@ -1374,8 +1389,8 @@ cov_status cov_ingest_end(cov_session *s, uint64_t *n_records_out) {
     HIPCHK(hipStreamSynchronize(s->ing_parse));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (getenv("COVERM_CLI_TIMING"))
-        fprintf(stderr, "[covermhip] ingest: %llu blocks in %u windows of %u, device allocations %.3fs\n", (unsigned long long)s->ing_blocks, s->ing_batch,
-                K.round_blocks, s->ing_s_alloc);
+        fprintf(stderr, "[covermhip] ingest: %llu blocks in %u windows of %u, device allocations %.3fs; host time in drain %.3fs (waiting for a verification %.3fs), in launches %.3fs (drains inside included), in upload calls %.3fs\n",
+                (unsigned long long)s->ing_blocks, s->ing_batch, K.round_blocks, s->ing_s_alloc, s->ing_s_part[0], s->ing_s_part[3], s->ing_s_part[1], s->ing_s_part[2]);
     const u32 inflate_fail = (u32)(glob[3] & 0xffffffffu);
     if (inflate_fail) { s->err = "device ingest: " + std::to_string(inflate_fail) + " BGZF blocks failed to inflate or their CRC-32 (handing the file to the CPU reader)"; return COV_ERR_INGEST_FALLBACK; }
     if (s->ing_fail) {
@@ -1456,7 +1471,8 @@ cov_status cov_pair_filter_apply(cov_session *s, const cov_pair_filter *f, uint6
     DevBuf<covp::PairEntry> d_tab;
     struct Rel { DevBuf<u32> &a, &b, &c, &d, &e; DevBuf<u64> &w; DevBuf<covp::PairEntry> &t; ~Rel() { a.release(); b.release(); c.release(); d.release(); e.release(); w.release(); t.release(); } }
         rel{d_cuts, d_partner, d_bsum, d_order, d_cnt, d_w, d_tab};
-    HIPCHK(d_cuts.reserve((size_t)n_chunks + 1, st)); HIPCHK(d_partner.reserve(R, st)); HIPCHK(d_w.reserve(4, st)); HIPCHK(d_cnt.reserve((size_t)n_chunks + 2, st));
+    HIPCHK(d_cuts.reserve((size_t)n_chunks + 1, st)); HIPCHK(d_w.reserve(4, st)); HIPCHK(d_cnt.reserve((size_t)n_chunks + 2, st));
+    if (d_partner.reserve(R, st) != hipSuccess) { (void)hipGetLastError(); s->err = "device pair filter: no device memory for the partner column (handing the file to the CPU reader)"; return COV_ERR_INGEST_FALLBACK; }
     const u64 w_init[4] = {0ull, ~0ull, 0ull, 0ull};
     HIPCHK(hipMemcpyAsync(d_w.p, w_init, sizeof w_init, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(d_cnt.p, 0, ((size_t)n_chunks + 2) * sizeof(u32), st));
@@ -1471,8 +1487,15 @@ cov_status cov_pair_filter_apply(cov_session *s, const cov_pair_filter *f, uint6
     for (u32 c = 0; c < n_chunks; c++) biggest = std::max(biggest, cuts[c + 1] > cuts[c] ? cuts[c + 1] - cuts[c] : 0u);
     u64 cap = 1024;
     while (cap < 2ull * biggest) cap <<= 1;
-    if (cap > (1ull << 32)) { s->err = "cov_pair_filter_apply: more than 2^31 records of one reference"; return COV_ERR_INVALID_ARG; }
-    HIPCHK(d_tab.reserve((size_t)cap, st));
+    // (the kernels carry the table size as 32 bits: a table of 2^32 entries would read as 0.)  A reference with that many records, or a
+    // table that does not fit the device beside the store, goes to the host's pair filter: the store is still untouched here.
+    auto too_big = [&](const char *what) {
+        (void)hipGetLastError();
+        s->err = std::string("device pair filter: ") + what + " (handing the file to the CPU reader)";
+        return COV_ERR_INGEST_FALLBACK;
+    };
+    if (cap > (1ull << 31)) return too_big("more than 2^30 records of one reference");
+    if (d_tab.reserve((size_t)cap, st) != hipSuccess) return too_big("the join table of the largest reference does not fit the device's memory");
     auto chunk_table = [&](u32 r0, u32 r1) -> u64 {        // this chunk's table (a prefix of the buffer) built: its size
         u64 cc = 1024;
         while (cc < 2ull * (r1 - r0)) cc <<= 1;
@@ -1569,6 +1592,9 @@ cov_status cov_pair_filter_apply(cov_session *s, const cov_pair_filter *f, uint6
     HIPCHK(hipMemcpyAsync(&n_cig_sel, d_w.p + 3, sizeof n_cig_sel, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     DevBuf<int32_t> n_tid, n_pos; DevBuf<uint16_t> n_flag; DevBuf<uint8_t> n_mapq, n_nmk; DevBuf<u32> n_nm, n_lseq, n_coff, n_cig;
+    struct Rel3 { DevBuf<int32_t> &a, &b; DevBuf<uint16_t> &c; DevBuf<uint8_t> &d, &e; DevBuf<u32> &f, &g, &h, &i;
+                  ~Rel3() { a.release(); b.release(); c.release(); d.release(); e.release(); f.release(); g.release(); h.release(); i.release(); } }
+        rel3{n_tid, n_pos, n_flag, n_mapq, n_nmk, n_nm, n_lseq, n_coff, n_cig};      // (after the swap below: the old store)
     HIPCHK(n_tid.reserve(S, st)); HIPCHK(n_pos.reserve(S, st)); HIPCHK(n_flag.reserve(S, st)); HIPCHK(n_mapq.reserve(S, st)); HIPCHK(n_nmk.reserve(S, st));
     HIPCHK(n_nm.reserve(S, st)); HIPCHK(n_lseq.reserve(S, st)); HIPCHK(n_coff.reserve((size_t)S + 1, st)); HIPCHK(n_cig.reserve((size_t)n_cig_sel + 1, st));
     covp::SelGather G{};
@@ -1582,7 +1608,6 @@ cov_status cov_pair_filter_apply(cov_session *s, const cov_pair_filter *f, uint6
     HIPCHK(hipStreamSynchronize(st));
     std::swap(s->s_tid, n_tid); std::swap(s->s_pos, n_pos); std::swap(s->s_flag, n_flag); std::swap(s->s_mapq, n_mapq); std::swap(s->s_nmk, n_nmk);
     std::swap(s->s_nm, n_nm); std::swap(s->s_lseq, n_lseq); std::swap(s->s_coff, n_coff); std::swap(s->s_cig, n_cig);
-    n_tid.release(); n_pos.release(); n_flag.release(); n_mapq.release(); n_nmk.release(); n_nm.release(); n_lseq.release(); n_coff.release(); n_cig.release();
     s->n_records = S; s->n_cigar = n_cig_sel; s->mates_valid = 0;      // the mate columns still describe the unselected store: spent
     return COV_OK;
 }
@@ -1638,6 +1663,7 @@ cov_status cov_fetch_hist(cov_session *s, uint64_t *hist) {
     if (!s || !s->finished || !(s->cfg.want & COV_WANT_HIST)) return COV_ERR_STATE;
     HIPCHK(hipSetDevice(s->cfg.device));
     const uint64_t total = s->h_glob.chist_total;
+    s->hist_fetch_seen = true;
     if (total == 0) return COV_OK;
     if (!hist) return COV_ERR_INVALID_ARG;
     if (!s->hist_compacted) {      // (a finish that had nothing to launch)

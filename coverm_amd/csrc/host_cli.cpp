@@ -599,7 +599,10 @@ int run_cli(int argc, char **argv) {
     if (!span_mode) {
         // samples dealt to devices; host threads shared between the concurrently decoded files
         const size_t lanes = std::min(nd, nb);
-        const int thr = std::max(1, a.threads / (int)lanes);
+        // every device's reader gets at least six threads (four of them read): with -t divided evenly, eight devices under a 16-CPU
+        // quota had two threads each and a reader that cannot fill its link; the readers block in pread and in slot waits most of
+        // the time, so oversubscribing the CPUs costs less than starving a device
+        const int thr = std::min(std::max(1, a.threads), std::max(6, a.threads / (int)lanes));
         std::atomic<size_t> next{0};
         std::vector<std::thread> th;
         for (size_t d = 0; d < lanes; d++)
@@ -621,7 +624,7 @@ int run_cli(int argc, char **argv) {
         }
     } else {
         // every BAM cut into nd tid spans; the per-contig result blocks meet on device 0 through one RCCL gather
-        const int thr = std::max(1, a.threads / (int)nd);
+        const int thr = std::min(std::max(1, a.threads), std::max(6, a.threads / (int)nd));      // (as above)
         for (size_t bi = 0; bi < nb; bi++) {
             std::vector<Sample> part(nd);
             std::vector<std::thread> th;

@@ -20,7 +20,7 @@
 //   k_bam_extract   per segment: second hop, one record at a time per lane, fields written straight into the session's
 //                   record store (tid, pos, flag, mapq, l_seq, NM + its type, CIGAR words)
 //
-// Anything irregular (malformed stream, CRC mismatch, speculation that does not verify, a CG:B,I long-CIGAR record) raises
+// Anything irregular (malformed stream, CRC mismatch, speculation that does not verify) raises
 // a flag and the host decodes that file with the CPU reader instead: the device path is an accelerator, never a different
 // semantics.
 #pragma once
@@ -546,6 +546,10 @@ __global__ __launch_bounds__(256) void k_lz_resolve(const BgzfBlock *__restrict_
     }
 }
 
+// (A SLIDING window of 64 consecutive tokens — token k held by lane k mod 64, the window following the block's lowest unfinished token —
+// cuts the rounds from ~940 to ~660 per block and was slower on the device, 25.2 ms per round against 19.4: the dependency search then
+// runs every round instead of once per batch, and about half of this kernel's time is instruction issue, not latency.
+// profiles/r04_lz_slide.log.)
 // CRC-32 of every inflated block against its BGZF trailer (htslib checks it in bgzf.c:inflate_block): one lane per block,
 // slicing-by-4 tables in LDS (4 bytes per dependent step).  Only 4 KiB of LDS per workgroup, so the CU is full of waves and the
 // per-step LDS latency overlaps.
@@ -580,6 +584,10 @@ __global__ __launch_bounds__(256) void k_crc32(const BgzfBlock *__restrict__ blo
     if ((crc ^ 0xffffffffu) != B.crc) { status[b] = INF_ERR_CRC; atomicAdd(n_failed, 1u); }
 }
 
+// (One WAVE per block — every lane 1 KiB, the 64 pieces combined through the CRC's linearity, crc(A || B) = crc(A) * x^(8 |B|) mod P xor
+// crc(B) with the 64 powers as compile-time constants — was built and measured: 5.6 ms per full round against 2.8 (0.8 against 1.9 for a
+// 12 k-block round).  Either way a wave's load touches 64 different cache lines, and that, not the length of a lane's chain, is what the
+// kernel's time is made of.  profiles/r04_crc_wave.log.)
 // ------------------------------------------------------------------------------------ BAM record parsing on the device
 // The inflated stream is parsed window by window (one window = the blocks of one k_inflate round, in its own buffer): the bytes
 // of a record cut by the window's end (the "tail") are carried in front of the next window's bytes, so a window always starts
@@ -653,13 +661,55 @@ struct SegInfo {
     u64 start;     // first record start found in the segment (~0 = none)
     u64 landed;    // where the hop from `start` ended (first record start at or beyond the segment end, or N)
     u32 n_rec, n_cig;
-    u32 flags;     // bit 0: a record that needs the CPU reader (CG:B,I long CIGAR candidate); bit 1: keys decrease inside the hop
+    u32 flags;     // bit 1: keys decrease inside the hop (bit 0 was: a CG:B,I record, now resolved by the extraction)
     u32 first_key, last_key;     // keys of the first / last record hopped over (any record, not only the span's); valid when n_hop != 0
     u32 n_hop;                   // records hopped over
 };
 
 // One wave per segment: lanes test consecutive offsets for an 8-record plausible chain; the lowest hit wins.  The segment that
 // holds *p0 starts there by definition; segments below it are dead.
+// A record whose CIGAR has more than 65535 operations stores `<l_seq>S<ref_len>N` in the CIGAR field and the real one in CG:B,I; htslib
+// swaps it back in while reading (bam_tag2cigar, sam.c), so record.cigar() at contig.rs:168 sees the real CIGAR.  The conditions of
+// csrc/host_bam.cpp real_cigar_from_cg: exactly two operations, mapped, the first one `<l_seq>S`, the first CG tag of type B,I / B,i
+// with at least as many words as the placeholder.  Returns the words and their count, or nullptr.
+__device__ __forceinline__ const uint8_t *cg_cigar(const uint8_t *r, const uint8_t *end, u32 &cnt) {
+    const u32 n_cig = ld16(r + 16), l_read_name = r[12], l_seq = ld32(r + 20);
+    if (n_cig != 2u || (int)ld32(r + 4) < 0 || (int)ld32(r + 8) < 0) return nullptr;
+    const uint8_t *c = r + 36 + l_read_name;
+    if (c + 8 > end) return nullptr;
+    const u32 c0 = ld32(c);
+    if ((c0 & 15u) != 4u || (c0 >> 4) != l_seq) return nullptr;
+    const uint8_t *p = c + 8 + ((u64)l_seq + 1ull) / 2 + l_seq;
+    if (p > end) return nullptr;
+    while (p + 3 <= end) {
+        const bool is_cg = p[0] == 'C' && p[1] == 'G';
+        const uint8_t t = p[2];
+        p += 3;
+        u32 sz;
+        if (t == 'A' || t == 'c' || t == 'C') sz = 1;
+        else if (t == 's' || t == 'S') sz = 2;
+        else if (t == 'i' || t == 'I' || t == 'f') sz = 4;
+        else if (t == 'Z' || t == 'H') {
+            while (p < end && *p) p++;
+            if (p >= end) return nullptr;
+            p++;
+            continue;
+        } else if (t == 'B') {
+            if (p + 5 > end) return nullptr;
+            const uint8_t st = p[0];
+            const u32 n = ld32(p + 1);
+            const u32 es = (st == 'c' || st == 'C') ? 1u : (st == 's' || st == 'S') ? 2u : 4u;
+            if ((u64)(end - p - 5) / es < n) return nullptr;
+            if (is_cg && (st == 'I' || st == 'i')) { cnt = n; return (n >= n_cig && n < (1u << 29)) ? p + 5 : nullptr; }
+            p += 5 + (u64)n * es;
+            continue;
+        } else return nullptr;
+        if (p + sz > end) return nullptr;
+        p += sz;
+    }
+    return nullptr;
+}
+
 __global__ __launch_bounds__(256) void k_bam_find(BamScan S, SegInfo *__restrict__ seg) {
     const int lane = threadIdx.x & 63;
     const u32 k = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -705,11 +755,12 @@ __global__ __launch_bounds__(64) void k_bam_hop(BamScan S, SegInfo *__restrict__
         if (nh == 0u) k_first = (u32)key; else if ((u32)key < k_last) fl |= 2u;
         k_last = (u32)key; nh++;
         if (key >= S.key_lo && key < S.key_hi) {
-            if (ncig == 2u) {    // `<l_seq>S <n>N` is the placeholder of a CIGAR stored in CG:B,I (SAM spec 4.2.2): leave the file to the CPU reader
-                const u32 c0 = ld32(r + 36 + r[12]);
-                if ((c0 & 15u) == 4u && (c0 >> 4) == ld32(r + 20)) fl |= 1u;
+            u32 words = ncig;
+            if (ncig == 2u) {    // `<l_seq>S <n>N` may be the placeholder of a CIGAR stored in CG:B,I (SAM spec 4.2.2): the store takes the real one
+                u32 cnt = 0;
+                if (cg_cigar(r, r + 4 + bs, cnt) != nullptr) words = cnt;
             }
-            nr++; nc += ncig;
+            nr++; nc += words;
         }
         q += 4 + (u64)bs;
     }
@@ -752,7 +803,6 @@ __global__ __launch_bounds__(1024) void k_bam_verify(BamScan S, SegInfo *__restr
             s_tail = s.landed;                                  // exactly one segment is the last live one
             if (S.final && s.landed != S.N) { bad |= 2u; atomicMin(&s_badk, (u64)k); }
         } else if (s.landed != want) { bad |= 1u; atomicMin(&s_badk, (u64)k); }
-        if (s.flags & 1u) bad |= 4u;
         nr += s.n_rec; nc += s.n_cig;
     }
     if (bad) atomicOr(&s_bad, bad);
@@ -876,12 +926,18 @@ __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__
         }
         const uint8_t *c = r + 36 + l_read_name;
         const uint8_t *aux = c + 4ull * n_cig + ((u64)l_seq + 1ull) / 2 + l_seq;
+        u32 words = n_cig;
         if (aux > end) { atomicAdd(n_bad, 1u); aux = end; }
-        else for (u32 x = 0; x < n_cig; x++) R.cigar[ci + x] = ld32(c + 4u * x);
+        else {
+            u32 cnt = 0;
+            const uint8_t *cg = n_cig == 2u ? cg_cigar(r, end, cnt) : nullptr;      // (the same test k_bam_hop counted the words with)
+            if (cg) { words = cnt; c = cg; }
+            for (u32 x = 0; x < words; x++) R.cigar[ci + x] = ld32(c + 4ull * x);
+        }
         u32 nm = 0;
         R.nm_kind[ri] = (uint8_t)scan_nm(aux, end, nm);
         R.nm[ri] = nm;
-        ri++; ci += n_cig;
+        ri++; ci += words;
         q += 4 + (u64)bs;
     }
 }

@@ -1743,6 +1743,10 @@ constexpr size_t pileup_stream_smem_bytes() { return (size_t)4 * ((size_t)STREAM
 //   * histogram: one LDS atomic per constant-depth segment of a lane's 16 positions (depth changes only where a delta
 //     is non-zero).  (Copies of every bin in adjacent words, lane l adding to copy l mod 2 | 4, were measured: 0.62 -> 0.72 / 0.85 ms,
 //     profiles/r04_pileup_hrep.log — what the conflicts cost is less than what the lost occupancy does.)
+//   * (Packed 16-bit arithmetic — a lane's dword k holding positions k and k + 8, v_pk_add / v_dot2_u32_u16 / v_pk_min / v_pk_max walking both
+//     halves at once, 16 + 8 + 8 + 32 instructions instead of ~130 — was built and measured: 0.683 ms against 0.623.  A VOP3P instruction
+//     issues in 4.2 cycles per wave where the plain two-operand forms it replaces take 2.4 (profiles/r03_valu_rate.json), so two values per
+//     instruction buy nothing here, and the permuted table layout costs two more address operations per event.  profiles/r04_pileup_packed.log.)
 constexpr int FAST_TW = 1024, FAST_HB = 512;
 constexpr size_t pileup_fast_smem_bytes(bool hist) { return (size_t)4 * ((size_t)FAST_TW * 4 + (hist ? (size_t)FAST_HB * 4 : 0)); }
 

@@ -16,9 +16,9 @@ ERR_UNSORTED, ERR_NM_MISSING, ERR_NM_BADTYPE, ERR_POS_OOB, ERR_BAD_CIGAR, ERR_BA
 ERR_INVALID_ARG, ERR_HIP, ERR_STATE = 16, 17, 18
 WANT_HIST, WANT_IDENTITY = 1, 2
 WANT_IDENTITY_PRIMARY_ONLY, WANT_IDENTITY_NONSUPP_ONLY = 4, 8
-K_PREP, K_RANGES, K_PILEUP, K_IDENTITY, K_HIST, K_COUNT = 0, 1, 2, 3, 4, 5
+K_PREP, K_RANGES, K_PILEUP, K_IDENTITY, K_HIST, K_HIST_COMPACT, K_COUNT = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = {K_PREP: "k_prep", K_RANGES: "k_ranges", K_PILEUP: "k_pileup", K_IDENTITY: "k_identity",
-                K_HIST: "k_hist"}
+                K_HIST: "k_hist", K_HIST_COMPACT: "k_hist_compact"}
 
 
 class CovConfig(C.Structure):

@@ -143,8 +143,9 @@ typedef enum {
     COV_K_RANGES = 1,   /* tile -> candidate record range */
     COV_K_PILEUP = 2,   /* LDS-tiled events + scan + statistics (the dominant kernel) */
     COV_K_IDENTITY = 3, /* ordered f64 identity sums */
-    COV_K_HIST = 4,     /* histogram layout / zero / compaction */
-    COV_K_COUNT = 5
+    COV_K_HIST = 4,     /* histogram arena layout + zero fill (before the pileup) */
+    COV_K_HIST_COMPACT = 5, /* compact histogram (behind the pileup) */
+    COV_K_COUNT = 6
 } cov_kernel_id;
 
 /* --- lifecycle ------------------------------------------------------------------------------- */

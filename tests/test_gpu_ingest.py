@@ -29,6 +29,15 @@ def inflate_version(request, monkeypatch):
     return request.param
 
 
+def binary_stderr(mode, paths, **kw):
+    """stderr of a coverm-amd run with its timing lines on (they say which ingest path a file took)"""
+    import subprocess
+    from tests import binary
+    r = subprocess.run(binary.argv(mode, paths, **kw), capture_output=True, text=True, timeout=300, env=dict(os.environ, COVERM_CLI_TIMING="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stderr
+
+
 def _check(path, threads=4, **kw):
     whole = cbam.read_alignment_file(path, threads=2, want_names=False)
     with Session(0, FilterConfig(), 75, want_hist=True, want_identity=True) as s:
@@ -98,7 +107,8 @@ def test_device_ingest_inflated_stream_is_bit_exact(tmp_path):
 
 def test_device_ingest_hands_irregular_files_back(tmp_path):
     """A BGZF block whose CRC-32 does not match (beyond the part the host inflates for the header): IngestFallback and nothing
-    appended; with the check switched off the (intact) payload goes through.  A CG:B,I long-CIGAR placeholder: handed back too."""
+    appended; with the check switched off the (intact) payload goes through.  A CG:B,I long-CIGAR placeholder is NOT irregular: the
+    device ingest resolves it like htslib does, and the binary's table over such a file equals the oracle's."""
     ref = synth.make_reference(12, 900_000, seed=41, min_len=1500, max_len=200_000)
     b = synth.make_reads(ref, 60_000, seed=43)
     good = str(tmp_path / "good.bam")
@@ -142,10 +152,19 @@ def test_device_ingest_hands_irregular_files_back(tmp_path):
     out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
     p = str(tmp_path / "cg.bam")
     open(p, "wb").write(out)
-    with Session(0, FilterConfig(), 75) as s:
-        with pytest.raises(cbam.IngestFallback) as ei:
-            cbam.gpu_ingest(s, p, threads=2)
-        assert "CG:B,I" in str(ei.value)
+    # ... and so does the device ingest: k_bam_hop counts the CG words, k_bam_extract copies them (contig.rs:166-168 sees htslib's swap)
+    w = _check(p, threads=2)
+    assert w.records.n_records == 2 and int(w.records.cigar_off[1]) == n_ops
+    from oracle import oracle as O
+    from tests import binary
+    args = dict(methods=["mean", "covered_bases", "variance", "count"], contig_end_exclusion=0)
+    ob = bamio.read_alignment_file(p)       # the oracle's reader keeps the placeholder: give it the CIGAR htslib would hand the reference
+    placeholder = int(ob.cigar_off[1])
+    ob.cigar = np.concatenate([ops, ob.cigar[placeholder:]]).astype(np.uint32)
+    ob.cigar_off = np.concatenate([[0], ob.cigar_off[1:].astype(np.int64) - placeholder + n_ops]).astype(np.uint32)
+    want = O.run_cli("contig", [p], bams=[ob], **args)
+    assert binary.run("contig", [p], **args) == want
+    assert "device ingest" in binary_stderr("contig", [p], **args)
 
 
 @pytest.mark.parametrize("mode,round_blocks,carry_kb,cwin_kb,piece_kb", [("short", 64, 64, 0, 0), ("long", 64, 1024, 0, 0), ("short", 128, 4, 0, 0),

@@ -16,7 +16,7 @@ for v in $VARS; do
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
-    if "k_inflate" in n or "k_lz_resolve" in n:
+    if "k_inflate" in n or "k_lz_resolve" in n or "k_crc32" in n or "k_bam" in n:
         print("   %-34s calls %s  avg %.2f ms  min %.2f max %.2f  total %.1f ms" % (n.split("(")[0].replace("void ", "")[:34], r["Calls"], float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6, float(r["TotalDurationNs"]) / 1e6))
 PY
 done
