@@ -285,6 +285,27 @@ def test_spans_of_a_file_that_is_not_sorted_by_reference_are_refused(tmp_path):
     assert seen_dev >= 1 and seen_cpu >= 1
 
 
+def test_spans_leave_a_file_only_the_reference_would_accept_to_one_device(tmp_path):
+    """contig.rs:118-132 compares the tids of MAPPED records that passed the flag filters only: an unmapped record that carries a
+    lower tid than its predecessor does not make the file unsorted for the reference.  The span readers refuse any decrease (above), so
+    `--devices` with fewer files than devices sends such a file through one device whole: same table as one device, as the oracle."""
+    from oracle import oracle as O
+    from tests import binary
+    ref = synth.make_reference(30, 3_000_000, seed=21, min_len=5000, max_len=400_000)
+    b = synth.make_reads(ref, 90_000, seed=22)
+    k = int(np.searchsorted(b.tid, 15)) + 5
+    assert 0 < k < b.n_records - 1 and b.tid[k] >= 15
+    b.tid[k] = 2                                   # one record of an early contig in the middle of the file ...
+    b.pos[k] = 10
+    b.flag[k] = np.uint16(int(b.flag[k]) | 4)      # ... unmapped: skipped before the order check
+    p = str(tmp_path / "stray_unmapped.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=2, threads=4)
+    args = dict(methods=["mean", "variance", "count"])
+    want = O.run_cli("contig", [p], bams=[bamio.read_alignment_file(p)], **args)
+    assert binary.run("contig", [p], **args) == want
+    assert binary.run("contig", [p], devices="0,0", **args) == want
+
+
 RAW = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raw")
 
 
