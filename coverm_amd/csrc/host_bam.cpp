@@ -90,6 +90,8 @@ struct Bam {
     std::string qnames;
     int threads = 1;
     bool want_names = false;
+    bool keep_offsets = false;                 // `coverm filter`: where every record begins in the inflated stream, and where the first one does
+    std::vector<size_t> rec_off; size_t first_record = 0;
 };
 
 inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
@@ -642,6 +644,7 @@ bool parse_bam(Bam &b, const Buf &u) {
         b.err = "truncated BAM record"; return false;
     }
     const size_t R = rec.size();
+    if (b.keep_offsets) { b.first_record = p; b.rec_off.resize(R); for (size_t i = 0; i < R; i++) b.rec_off[i] = rec[i]; }
     b.cigar_off.resize(R + 1);
     if (b.want_names) b.qname_off.resize(R + 1);
     auto ensure = [&](uint64_t ncig, uint64_t nq) { b.cigar.resize(ncig); if (b.want_names) b.qnames.resize(nq); return true; };
@@ -1767,6 +1770,90 @@ int covh_bam_write(const char *path, uint32_t n_targets, const char *const *name
     fwrite(eof, 1, 28, f);
     const bool werr = ferror(f) != 0;
     if (fclose(f) != 0 || werr) return 3;
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+// `n` bytes as BGZF blocks of 0xff00 bytes (what htslib writes) + the EOF marker, compressed by `threads` threads.
+bool bgzf_write_all(FILE *f, const uint8_t *data, size_t n, int level, int threads) {
+    const size_t BLK = 0xff00, nblk = (n + BLK - 1) / BLK;
+    const size_t WAVE = 4096;                       // blocks compressed before they are written: bounds the memory
+    std::vector<std::vector<uint8_t>> comp(std::min(nblk, WAVE));
+    std::atomic<bool> ok{true};
+    for (size_t b0 = 0; b0 < nblk; b0 += WAVE) {
+        const size_t nb = std::min(WAVE, nblk - b0);
+        parallel_for(nb, threads, [&](size_t k) {
+            const size_t s0 = (b0 + k) * BLK, len = std::min(BLK, n - s0);
+            std::vector<uint8_t> &o = comp[k];
+            o.resize(len + len / 8 + 256);
+            z_stream zs; memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok = false; return; }
+            zs.next_in = const_cast<uint8_t *>(data + s0); zs.avail_in = (uInt)len; zs.next_out = o.data() + 18; zs.avail_out = (uInt)(o.size() - 26);
+            if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { ok = false; deflateEnd(&zs); return; }
+            const size_t clen = zs.total_out;
+            deflateEnd(&zs);
+            static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+            memcpy(o.data(), hdr, 16);
+            const uint16_t bsz = (uint16_t)(clen + 25);
+            memcpy(o.data() + 16, &bsz, 2);
+            const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + s0, (uInt)len), isz = (uint32_t)len;
+            memcpy(o.data() + 18 + clen, &crc, 4); memcpy(o.data() + 22 + clen, &isz, 4);
+            o.resize(clen + 26);
+        });
+        if (!ok) return false;
+        for (size_t k = 0; k < nb; k++) if (fwrite(comp[k].data(), 1, comp[k].size(), f) != comp[k].size()) return false;
+    }
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return fwrite(eof, 1, 28, f) == 28;
+}
+
+}  // namespace
+
+extern "C" {
+
+// `coverm filter` (bin/coverm.rs:408-472): bam::Reader -> ReferenceSortedBamFilter -> bam::Writer under the reader's header.  Here: the
+// file inflated on `threads` threads, its records located and their filter fields extracted (the whole-file reader's own passes), the
+// reader filter's selection (covh_reader_filter_order), and the selected records copied byte for byte behind the input's header bytes.
+int covh_bam_filter_file(const char *in_path, const char *out_path, const covh_pair_filter *f, int filter_pairs, int include_supplementary,
+                         int include_secondary, int filter_out, int level, int threads, uint64_t *n_in, uint64_t *n_out, char *err, size_t errcap) {
+    auto fail = [&](const std::string &e) { if (err && errcap) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; } return -1; };
+    if (!in_path || !out_path || !f) return fail("covh_bam_filter_file: invalid argument");
+    if (n_in) *n_in = 0;
+    if (n_out) *n_out = 0;
+    Bam b; b.path = in_path; b.threads = std::max(1, threads); b.want_names = true; b.keep_offsets = true;
+    Buf raw, u;
+    if (!read_file(in_path, raw, b.err)) return fail(std::string("Unable to find BAM file ") + in_path);
+    if (raw.size() < 2 || raw[0] != 0x1f || raw[1] != 0x8b) return fail(std::string(in_path) + ": `filter` reads BAM files");
+    if (!bgzf_inflate_all(raw, u, b.threads, b.err)) return fail(b.err);
+    raw.alloc(0);
+    if (!parse_bam(b, u)) return fail(b.err);
+    const uint64_t R = b.tid.size();
+    cov_batch cb; memset(&cb, 0, sizeof cb);
+    cb.tid = b.tid.data(); cb.pos = b.pos.data(); cb.flag = b.flag.data(); cb.mapq = b.mapq.data(); cb.nm = b.nm.data(); cb.nm_kind = b.nm_kind.data();
+    cb.l_seq = b.l_seq.data(); cb.cigar_off = b.cigar_off.data(); cb.cigar = b.cigar.data(); cb.n_records = R;
+    uint64_t *order = nullptr, n_sel = 0;
+    const int rc = covh_reader_filter_order(&cb, b.mtid.data(), b.qname_off.data(), b.qnames.data(), f, filter_pairs, include_supplementary, include_secondary,
+                                            filter_out, &order, &n_sel);
+    if (rc == COV_ERR_NM_MISSING) return fail("Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM format");
+    if (rc == COV_ERR_NM_BADTYPE) return fail("Unexpected data type of NM aux tag");
+    if (rc != COV_OK) return fail("covh_reader_filter_order failed");
+    struct FreeOrd { uint64_t *p; ~FreeOrd() { free(p); } } free_ord{order};
+    // header bytes as they are, then the selected records as they are
+    std::vector<size_t> at(n_sel + 1, 0);
+    for (uint64_t j = 0; j < n_sel; j++) at[j + 1] = at[j] + 4 + (size_t)rd32(u.data() + b.rec_off[order[j]]);
+    Buf outb; outb.alloc(b.first_record + at[n_sel]);
+    memcpy(outb.p, u.data(), b.first_record);
+    parallel_for((size_t)n_sel, b.threads, [&](size_t j) { memcpy(outb.p + b.first_record + at[j], u.data() + b.rec_off[order[j]], at[j + 1] - at[j]); });
+    FILE *fo = fopen(out_path, "wb");
+    if (!fo) return fail(std::string("Failed to write BAM file ") + out_path);
+    const bool ok = bgzf_write_all(fo, outb.p, outb.size(), level, b.threads);
+    const bool werr = ferror(fo) != 0;
+    if (fclose(fo) != 0 || werr || !ok) return fail(std::string("Failed to write BAM file ") + out_path);
+    if (n_in) *n_in = R;
+    if (n_out) *n_out = n_sel;
     return 0;
 }
 

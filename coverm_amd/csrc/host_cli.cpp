@@ -363,13 +363,66 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
     S.t_finish = now() - t0 - S.t_ingest;
 }
 
+// `coverm filter` (bin/coverm.rs:408-472): every input BAM through ReferenceSortedBamFilter into its output BAM.  Host code in the
+// reference and here: the work is rewriting a BAM (inflate, select, deflate), which no pass over coverage touches.  The thresholds
+// are FilterParameters::generate_from_clap's (coverm.rs:1659-1678); filter_out = !--inverse.
+int run_filter(int argc, char **argv) {
+    std::vector<std::string> in, out;
+    Filter f;
+    bool inverse = false, proper_pairs_only = false, exclude_supplementary = false, include_secondary = false;
+    const char *pid = nullptr, *pct = nullptr, *pid_pair = nullptr, *pct_pair = nullptr;
+    int threads = 1;
+    auto collect = [&](int &i, std::vector<std::string> &dst) { while (i + 1 < argc && argv[i + 1][0] != '-') dst.push_back(argv[++i]); };
+    for (int i = 2; i < argc; i++) {
+        const std::string k = argv[i];
+        auto val = [&]() -> const char * { if (i + 1 >= argc) die("missing value for " + k); return argv[++i]; };
+        if (k == "-b" || k == "--bam-files") collect(i, in);
+        else if (k == "-o" || k == "--output-bam-files") collect(i, out);
+        else if (k == "--inverse") inverse = true;
+        else if (k == "--proper-pairs-only") proper_pairs_only = true;
+        else if (k == "--exclude-supplementary") exclude_supplementary = true;
+        else if (k == "--include-secondary") include_secondary = true;
+        else if (k == "--min-read-aligned-length") f.len_single = (uint32_t)strtoul(val(), nullptr, 10);
+        else if (k == "--min-read-percent-identity") pid = val();
+        else if (k == "--min-read-aligned-percent") pct = val();
+        else if (k == "--min-read-aligned-length-pair") f.len_pair = (uint32_t)strtoul(val(), nullptr, 10);
+        else if (k == "--min-read-percent-identity-pair") pid_pair = val();
+        else if (k == "--min-read-aligned-percent-pair") pct_pair = val();
+        else if (k == "--min-mapq") f.mapq = atoi(val());
+        else if (k == "-t" || k == "--threads") threads = atoi(val());
+        else if (k == "-v" || k == "--verbose" || k == "-q" || k == "--quiet") {}
+        else die("unknown argument " + k);
+    }
+    if (in.empty()) die("--bam-files is required");
+    if (in.size() != out.size()) die("The number of input BAM files must be the same as the number output");     // coverm.rs:422-425
+    f.improper = !proper_pairs_only; f.supp = !exclude_supplementary; f.sec = include_secondary;
+    f.pid_single = parse_percentage(pid); f.pct_single = parse_percentage(pct); f.pid_pair = parse_percentage(pid_pair); f.pct_pair = parse_percentage(pct_pair);
+    bool fs = false, fp = false;
+    f.mode(fs, fp);
+    covh_pair_filter pf; memset(&pf, 0, sizeof pf);
+    pf.filter_single = fs; pf.min_mapq = (uint8_t)f.mapq; pf.min_aligned_length_single = f.len_single; pf.min_percent_identity_single = f.pid_single;
+    pf.min_aligned_percent_single = f.pct_single; pf.min_aligned_length_pair = f.len_pair; pf.min_percent_identity_pair = f.pid_pair;
+    pf.min_aligned_percent_pair = f.pct_pair;
+    for (size_t k = 0; k < in.size(); k++) {
+        char err[512] = {0};
+        uint64_t n_in = 0, n_out = 0;
+        if (covh_bam_filter_file(in[k].c_str(), out[k].c_str(), &pf, fp ? 1 : 0, f.supp ? 1 : 0, f.sec ? 1 : 0, inverse ? 0 : 1, 6, std::max(1, threads), &n_in, &n_out, err,
+                                 sizeof err) != 0)
+            die(err);
+        if (timing_on()) fprintf(stderr, "[coverm-amd] filter %s -> %s: %llu of %llu records\n", in[k].c_str(), out[k].c_str(), (unsigned long long)n_out, (unsigned long long)n_in);
+    }
+    return 0;
+}
+
 int run_cli(int argc, char **argv) {
     const double t_main0 = now();
     Run R;
     Args &a = R.a;
+    if (argc >= 2 && !strcmp(argv[1], "filter")) return run_filter(argc, argv);
     if (argc < 2 || (strcmp(argv[1], "contig") && strcmp(argv[1], "genome"))) {
         fprintf(stderr, "usage: coverm-amd contig|genome -b <bam>... [-m <methods>...] [options]   (see src/cli.rs of CoverM for the flags; "
-                        "engine flags: --device N | --devices a,b,..., --no-stream)\n");
+                        "engine flags: --device N | --devices a,b,..., --no-stream)\n"
+                        "       coverm-amd filter -b <bam>... -o <bam>... [thresholds] [--inverse]\n");
         return 2;
     }
     a.mode = argv[1];

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/coverm_host.h"
@@ -165,6 +166,60 @@ int covh_pair_mode_order(const cov_batch *b, const int32_t *mtid, const uint32_t
     uint64_t w = 0;
     for (auto &o : outs) { if (!o.empty()) memcpy(ord + w, o.data(), o.size() * sizeof(uint64_t)); w += o.size(); }
     *order_out = ord; *n_out = tot;
+    return COV_OK;
+}
+
+// ReferenceSortedBamFilter::read as a whole (src/filter.rs:84-228): both branches, filter_out = true (what the coverage commands and
+// `coverm filter` use) or false (`coverm filter --inverse`).  Serial, in file order, names compared in full: this is the `filter`
+// subcommand's selection (bin/coverm.rs:408-472), whose cost is the BAM rewrite around it; the coverage path has its own fast
+// implementations (the device's k_prep / cov_pair_filter_apply, covh_pair_mode_order above).
+//   single branch (filter_single && !filter_pairs, :88-116): an unmapped record is returned when !filter_out; a record that passes
+//     the flag test (:100-102) is returned iff single_read_passes_filter == filter_out; every other record is dropped;
+//   pair branch (:117-228): an unmapped record is returned when !filter_out; secondary / supplementary records are dropped; a record
+//     that is not a proper pair is dropped (filter_out) or returned (!filter_out); proper pairs are matched by name within one
+//     reference and the pair is returned, first mate then second, iff (its judgement == filter_out).
+int covh_reader_filter_order(const cov_batch *b, const int32_t *mtid, const uint32_t *qname_off, const char *qnames, const covh_pair_filter *f,
+                             int filter_pairs, int include_supplementary, int include_secondary, int filter_out, uint64_t **order_out, uint64_t *n_out) {
+    if (!b || !f || !order_out || !n_out || (b->n_records && (!mtid || !qname_off || !qnames))) return COV_ERR_INVALID_ARG;
+    *order_out = nullptr; *n_out = 0;
+    const uint64_t R = b->n_records;
+    const bool out = filter_out != 0;
+    Judge J{*b, *f};
+    std::vector<uint64_t> ord;
+    if (f->filter_single && !filter_pairs) {
+        for (uint64_t i = 0; i < R; i++) {
+            const uint16_t flag = b->flag[i];
+            const bool unmapped = flag & 0x4, supp = flag & 0x800, sec = flag & 0x100;
+            if (unmapped && !out) { ord.push_back(i); continue; }
+            const bool p1 = !unmapped && (include_supplementary || !supp) && (include_secondary || !sec);
+            if (p1 && J.single_ok(i) == out) ord.push_back(i);
+            if (J.err) return J.err;
+        }
+    } else {
+        int32_t cur = -1;            // current_reference starts at -1 (filter.rs:76)
+        std::unordered_map<std::string, uint64_t> first;      // first_set: the parked records of the current reference by name
+        for (uint64_t i = 0; i < R; i++) {
+            const uint16_t flag = b->flag[i];
+            if ((flag & 0x4) && !out) { ord.push_back(i); continue; }
+            if (flag & 0x900) continue;
+            if (!(flag & 0x2)) { if (!out) ord.push_back(i); continue; }
+            if (b->tid[i] != cur) { cur = b->tid[i]; first.clear(); }
+            const std::string q(qnames + qname_off[i], qname_off[i + 1] - qname_off[i]);
+            auto it = first.find(q);
+            if (it == first.end()) { if (mtid[i] == cur) first.emplace(q, i); }
+            else {
+                const uint64_t i1 = it->second;
+                first.erase(it);
+                const bool pass = (!f->filter_single || (J.single_ok(i1) && J.single_ok(i))) && J.pair_ok(i, i1);
+                if (J.err) return J.err;
+                if (pass == out) { ord.push_back(i1); ord.push_back(i); }
+            }
+        }
+    }
+    uint64_t *o = (uint64_t *)malloc(std::max<size_t>(1, ord.size()) * sizeof(uint64_t));
+    if (!o) return COV_ERR_INVALID_ARG;
+    if (!ord.empty()) memcpy(o, ord.data(), ord.size() * sizeof(uint64_t));
+    *order_out = o; *n_out = ord.size();
     return COV_OK;
 }
 

@@ -221,6 +221,16 @@ typedef struct {
  * COV_ERR_NM_MISSING / COV_ERR_NM_BADTYPE where the reference's nm() would have panicked. */
 int covh_pair_mode_order(const cov_batch *b, const int32_t *mtid, const uint32_t *qname_off, const char *qnames,
                          const covh_pair_filter *f, int threads, uint64_t **order_out, uint64_t *n_out);
+/* ReferenceSortedBamFilter::read as a whole (filter.rs:84-228), serial: the single-read branch when f->filter_single && !filter_pairs,
+ * the pair branch otherwise; filter_out = 0 is `coverm filter --inverse` (unmapped records and — in the pair branch — improper pairs are
+ * returned, and a record / pair is returned iff it FAILS its judgement).  The selection of the `filter` subcommand. */
+int covh_reader_filter_order(const cov_batch *b, const int32_t *mtid, const uint32_t *qname_off, const char *qnames, const covh_pair_filter *f,
+                             int filter_pairs, int include_supplementary, int include_secondary, int filter_out, uint64_t **order_out, uint64_t *n_out);
+/* `coverm filter` (bin/coverm.rs:408-472): the records of the BAM file `in_path` that the reader filter returns, byte for byte (names,
+ * bases, qualities, tags) and in its order, under the input's header, as a new BGZF-compressed BAM.  Host code, like the reference's.
+ * Returns 0, or -1 with a message. */
+int covh_bam_filter_file(const char *in_path, const char *out_path, const covh_pair_filter *f, int filter_pairs, int include_supplementary,
+                         int include_secondary, int filter_out, int level, int threads, uint64_t *n_in, uint64_t *n_out, char *err, size_t errcap);
 void covh_free(void *p);
 /* Gathers records order[0..n) of src into a new batch (page-locked memory when a device is usable). */
 int covh_batch_select(const cov_batch *src, const uint64_t *order, uint64_t n, int threads, cov_batch *out);

@@ -632,6 +632,53 @@ def reader_stage(b: BamData, fp: Optional[FilterParameters]):
     return np.asarray(order, dtype=np.uint64), prim
 
 
+def reader_filter(b: BamData, fp: FilterParameters, filter_out: bool = True):
+    """ReferenceSortedBamFilter::read as a whole (filter.rs:84-228), record by record, for both values of filter_out: the
+    selection of `coverm filter` (bin/coverm.rs:408-472; filter_out = not --inverse).  Always constructed there, whether or
+    not any threshold is set (with none, filter.rs:48-61 selects the pair branch).  Returns the indices in return order."""
+    fs, fpairs = filter_mode(fp)
+    ff = fp.flag_filters
+    order = []
+    if fs and not fpairs:                                   # :88-116
+        for i in range(b.n_records):
+            flag = int(b.flag[i])
+            unmapped, supp, sec = bool(flag & 0x4), bool(flag & 0x800), bool(flag & 0x100)
+            if unmapped and not filter_out:                  # :97-99
+                order.append(i)
+                continue
+            passes1 = (not unmapped) and (ff.include_supplementary or not supp) and (ff.include_secondary or not sec)
+            if passes1 and _single_passes(b, i, fp) == filter_out:      # :103-113
+                order.append(i)
+        return np.asarray(order, dtype=np.uint64)
+    first_set = {}
+    current_reference = -1                                  # :76
+    for i in range(b.n_records):
+        flag = int(b.flag[i])
+        if flag & 0x4 and not filter_out:                    # :133-135
+            order.append(i)
+            continue
+        if flag & 0x100 or flag & 0x800:                     # :138-140
+            continue
+        if not flag & 0x2:                                   # :141-147
+            if not filter_out:
+                order.append(i)
+            continue
+        if b.tid[i] != current_reference:                    # :150-162
+            current_reference = int(b.tid[i])
+            first_set = {}
+        q = b.qname[i]
+        if q not in first_set:                               # :168-184
+            if b.mtid[i] == current_reference:
+                first_set[q] = i
+        else:
+            i1 = first_set.pop(q)
+            ok = ((not fs) or (_single_passes(b, i1, fp) and _single_passes(b, i, fp))) and _pair_passes(b, i, i1, fp)
+            if ok == filter_out:                             # :212-220
+                order.append(i1)
+                order.append(i)
+    return np.asarray(order, dtype=np.uint64)
+
+
 # ------------------------------------------------------------------ scan entry points
 def contig_coverage(bams: Sequence[BamData], stoit_names: Sequence[str], taker, estimators: Sequence[EstParam],
                     print_zero_coverage_contigs: bool, flag_filters: FlagFilter,

@@ -58,5 +58,6 @@ int covw_host_resolve(uint8_t *out, uint32_t isize, const uint16_t *tok, uint32_
 
 uint32_t covw_host_wave_bytes(void) { return (uint32_t)sizeof(g_wave); }
 uint32_t covw_host_last_deflate_blocks(void) { return g_wave.n_deflate_blocks; }
+void covw_host_last_share_bytes(uint32_t *nbytes64, uint32_t *ntok64) { for (int i = 0; i < 64; i++) { nbytes64[i] = i < (int)g_wave.n_valid ? g_wave.nbytes[i] : 0; ntok64[i] = i < (int)g_wave.n_valid ? g_wave.ntok[i] : 0; } }
 uint32_t covw_host_last_chunks(void) { return g_wave.n_chunks; }
 }

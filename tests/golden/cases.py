@@ -258,6 +258,21 @@ FILTER_CASES = [
          single=(0, 0.0, 0.0), mapq=51, pair=(1, 0.0, 0.0), mode=(False, True), qnames="2 2".split(),
          exhaustive=False),
 ]
+# the same constructor with filter_out = false (`coverm filter --inverse`): expected qname order
+FILTER_INVERSE_CASES = [
+    dict(id="filter_hello_world_inverse", cite="src/filter.rs:375-404", bam=S7 + ".bam", ff=(False, False, False),
+         single=(0, 0.0, 0.0), mapq=0, pair=(90, 0.99, 0.0), qnames=[], exhaustive=True),
+    dict(id="filter_one_bad_read_inverse_a", cite="src/filter.rs:505-529", bam="2seqs.bad_read.1.bam", ff=(False, False, False),
+         single=(0, 0.0, 0.0), mapq=0, pair=(250, 0.99, 0.0), qnames="1 1".split(), exhaustive=False),
+    dict(id="filter_one_bad_read_inverse_b", cite="src/filter.rs:531-553", bam="2seqs.bad_read.1.bam", ff=(False, False, False),
+         single=(0, 0.0, 0.0), mapq=0, pair=(300, 0.98, 0.0), qnames="1 1".split(), exhaustive=False),
+    dict(id="filter_one_bad_read_inverse_c", cite="src/filter.rs:555-577", bam="2seqs.bad_read.1.with_extra.bam", ff=(False, False, False),
+         single=(0, 0.0, 0.0), mapq=0, pair=(0, 0.98, 0.94), qnames="1 1".split(), exhaustive=False),
+    dict(id="filter_single_reads_inverse", cite="src/filter.rs:635-662", bam="2seqs.bad_read.1.bam", ff=(True, False, False),
+         single=(0, 0.99, 0.0), mapq=0, pair=(0, 0.0, 0.0), qnames="1".split(), exhaustive=False),
+    dict(id="filter_single_and_paired_inverse", cite="src/filter.rs:695-722", bam="2seqs.bad_read.1.bam", ff=(False, False, False),
+         single=(0, 0.95, 0.0), mapq=0, pair=(300, 0.0, 0.0), qnames="1 1".split(), exhaustive=False),
+]
 # NB: filter.rs passes min_mapq_single=0 in most cases above; 0 != 255 so MAPQ "filtering" is on with
 # threshold 0 (everything >= 0 passes unless mapq == 255) and it participates in mode selection (:48-61).
 

@@ -1,0 +1,124 @@
+"""`coverm-amd filter` (csrc/host_cli.cpp run_filter -> covh_bam_filter_file) against the oracle's restatement of
+ReferenceSortedBamFilter::read (oracle.reader_filter, pinned on filter.rs's own tests in tests/test_oracle_golden.py) on the reference's
+fixture BAMs: the output must hold exactly the records the filter returns, in its order, byte for byte, under the input's header —
+what `coverm filter` does with a bam::Writer (bin/coverm.rs:408-472).  Host code only: runs without a GPU."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import bamio, oracle as O
+from tests.golden import cases
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+RAW = os.path.join(HERE, "golden", "raw")
+BIN = os.path.join(os.path.dirname(HERE), "coverm_amd", "coverm-amd")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(BIN), reason="coverm-amd not built")
+
+
+def inflate_bam(path):
+    """-> (header bytes, [record bytes]) of a BAM file, every BGZF block's CRC-32 checked"""
+    buf = open(path, "rb").read()
+    out, p = [], 0
+    while p < len(buf):
+        assert buf[p:p + 4] == b"\x1f\x8b\x08\x04"
+        bsize = struct.unpack_from("<H", buf, p + 16)[0] + 1
+        data = zlib.decompress(buf[p + 18:p + bsize - 8], -15)
+        crc, isize = struct.unpack_from("<II", buf, p + bsize - 8)
+        assert zlib.crc32(data) == crc and len(data) == isize
+        out.append(data)
+        p += bsize
+    assert buf[-28:] == bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])     # the EOF marker
+    u = b"".join(out)
+    assert u[:4] == b"BAM\x01"
+    l_text = struct.unpack_from("<i", u, 4)[0]
+    q = 8 + l_text
+    n_ref = struct.unpack_from("<i", u, q)[0]
+    q += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", u, q)[0]
+        q += 4 + l_name + 4
+    header, recs = u[:q], []
+    while q < len(u):
+        bs = struct.unpack_from("<i", u, q)[0]
+        recs.append(u[q:q + 4 + bs])
+        q += 4 + bs
+    assert q == len(u)
+    return header, recs
+
+
+def flags_of(case, inverse):
+    v = []
+    imp, supp, sec = case["ff"]
+    if not imp:
+        v.append("--proper-pairs-only")
+    if not supp:
+        v.append("--exclude-supplementary")
+    if sec:
+        v.append("--include-secondary")
+    ls, ps, cs = case["single"]
+    lp, pp, cp = case["pair"]
+    v += ["--min-read-aligned-length", str(ls), "--min-read-percent-identity", repr(ps), "--min-read-aligned-percent", repr(cs),
+          "--min-read-aligned-length-pair", str(lp), "--min-read-percent-identity-pair", repr(pp), "--min-read-aligned-percent-pair", repr(cp),
+          "--min-mapq", str(case["mapq"])]
+    if inverse:
+        v.append("--inverse")
+    return v
+
+
+ALL = [(c, False) for c in cases.FILTER_CASES if c["bam"].endswith(".bam")] + [(c, True) for c in cases.FILTER_INVERSE_CASES] + \
+      [(c, True) for c in cases.FILTER_CASES if c["bam"].endswith(".bam") and c["id"] != "filter_hello_world"]
+
+
+@pytest.mark.parametrize("case,inverse", ALL, ids=[c["id"] + ("/inverse" if inv else "") for c, inv in ALL])
+def test_filter_writes_the_records_the_reader_filter_returns(tmp_path, case, inverse):
+    src = os.path.join(RAW, case["bam"])
+    if not os.path.exists(src):
+        pytest.skip("raw fixture not present")
+    out = str(tmp_path / "out.bam")
+    r = subprocess.run([BIN, "filter", "-b", src, "-o", out, "-t", "3"] + flags_of(case, inverse), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = bamio.read_alignment_file(src)
+    fp = O.FilterParameters(O.FlagFilter(*case["ff"]), case["single"][0], float(np.float32(case["single"][1])), float(np.float32(case["single"][2])),
+                            case["mapq"], case["pair"][0], float(np.float32(case["pair"][1])), float(np.float32(case["pair"][2])))
+    order = [int(i) for i in O.reader_filter(b, fp, filter_out=not inverse)]
+    h_in, r_in = inflate_bam(src)
+    h_out, r_out = inflate_bam(out)
+    assert h_out == h_in                                    # Header::from_template(reader.header()): the same names, lengths and text
+    assert len(r_in) == b.n_records
+    assert r_out == [r_in[i] for i in order]                # byte for byte: names, bases, qualities, tags
+    # and the reference's own expectation where its test states one
+    if not inverse or case in cases.FILTER_INVERSE_CASES:
+        names = [b.qname[i].decode() for i in order]
+        if "count" in case:
+            assert len(names) == case["count"]
+        elif case["exhaustive"]:
+            assert names == case["qnames"]
+        else:
+            assert names[:len(case["qnames"])] == case["qnames"]
+
+
+def test_filter_without_thresholds_and_its_errors(tmp_path):
+    """tests/test_cmdline.rs:97-135: no thresholds = the pair branch with nothing to fail (`1<TAB>99<TAB>seq1` is there); with
+    --min-read-percent-identity-pair 0.99 --proper-pairs-only it is not.  One output per input; a missing input is the reference's message."""
+    src = os.path.join(RAW, "2seqs.bad_read.1.bam")
+    if not os.path.exists(src):
+        pytest.skip("raw fixture not present")
+
+    def view(path):      # qname, flag, reference name — the first three columns of `samtools view`
+        b = bamio.read_alignment_file(path)
+        return ["%s\t%d\t%s" % (b.qname[i].decode(), int(b.flag[i]), b.ref_names[int(b.tid[i])] if b.tid[i] >= 0 else "*") for i in range(b.n_records)]
+    out = str(tmp_path / "all.bam")
+    assert subprocess.run([BIN, "filter", "-b", src, "-o", out], capture_output=True).returncode == 0
+    assert "1\t99\tseq1" in view(out)
+    out2 = str(tmp_path / "strict.bam")
+    assert subprocess.run([BIN, "filter", "--min-read-percent-identity-pair", "0.99", "-b", src, "-o", out2, "--proper-pairs-only"], capture_output=True).returncode == 0
+    assert "1\t99\tseq1" not in view(out2) and len(view(out2)) > 0
+    r = subprocess.run([BIN, "filter", "-b", src, src, "-o", out], capture_output=True, text=True)
+    assert r.returncode != 0 and "The number of input BAM files must be the same as the number output" in r.stderr
+    r = subprocess.run([BIN, "filter", "-b", str(tmp_path / "nope.bam"), "-o", out], capture_output=True, text=True)
+    assert r.returncode != 0 and "Unable to find BAM file" in r.stderr

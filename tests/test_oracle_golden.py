@@ -67,6 +67,29 @@ def test_oracle_filter_golden(case):
         assert got[:len(case["qnames"])] == case["qnames"]
 
 
+@pytest.mark.parametrize("case", cases.FILTER_INVERSE_CASES, ids=[c["id"] for c in cases.FILTER_INVERSE_CASES])
+def test_oracle_filter_inverse_golden(case):
+    """filter.rs's own tests with filter_out = false: what `coverm filter --inverse` returns."""
+    b = load_fixture(case["bam"])
+    fp = O.FilterParameters(O.FlagFilter(*case["ff"]), case["single"][0], case["single"][1], case["single"][2],
+                            case["mapq"], case["pair"][0], case["pair"][1], case["pair"][2])
+    got = [b.qname[i].decode() for i in O.reader_filter(b, fp, filter_out=False)]
+    if case["exhaustive"]:
+        assert got == case["qnames"]
+    else:
+        assert got[:len(case["qnames"])] == case["qnames"]
+
+
+@pytest.mark.parametrize("case", cases.FILTER_CASES, ids=[c["id"] for c in cases.FILTER_CASES])
+def test_oracle_reader_filter_equals_reader_stage_when_filtering_out(case):
+    """The record-by-record restatement (both values of filter_out) against the reader stage the coverage path uses, filter_out = true."""
+    b = load_fixture(case["bam"])
+    fp = O.FilterParameters(O.FlagFilter(*case["ff"]), case["single"][0], case["single"][1], case["single"][2],
+                            case["mapq"], case["pair"][0], case["pair"][1], case["pair"][2])
+    order, prim = O.reader_stage(b, fp)
+    assert list(O.reader_filter(b, fp, True)) == list(order)
+
+
 def _sorted_table(s):
     lines = s.split("\n")
     return [lines[0]] + sorted(lines[1:])
