@@ -79,7 +79,7 @@ std::string g_create_error;
 //                        the fill and drain of the pipeline);
 //   version 1 (COVERM_INFLATE_V=1): k_inflate, one LANE per block, private Huffman tables per lane in LDS — the second implementation the
 //                        tests compare with; a launch is cut to exactly the blocks resident at once (a lane decodes a block serially).
-struct InflateKernel { int version = 3; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ablate = 0; u32 pad_lds = 0; };
+struct InflateKernel { int version = 3; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ablate = 0; };
 
 struct cov_session {
     cov_config cfg{};
@@ -162,7 +162,7 @@ struct cov_session {
     DevBuf<u32> g_ntok, g_ntok2;
     hipStream_t ing_aux = nullptr;                         // k_lz_resolve / k_crc32 of round i run beside k_inflate of round i + 1
     hipStream_t ing_parse = nullptr;                       // record boundaries of window i run beside both
-    hipStream_t ing_ext = nullptr; bool ing_ext_owned = false;   // extraction of verified windows: its own stream (behind nothing but its own predecessors) or the parse stream
+    hipStream_t ing_ext = nullptr;   // extraction of verified windows: the parse stream (a stream of its own made no difference, profiles/r03_tail_variants.log)
     hipEvent_t ing_inf_done[2] = {nullptr, nullptr}, ing_lz_done[2] = {nullptr, nullptr};
     hipEvent_t ing_ver_done[4] = {}, ing_ext_done[3] = {}, ing_cdone[3] = {};
     uint64_t ing_round_start = 0, ing_prev_end = 0, ing_ccap = 0;   // accumulating round: file offset its buffer starts at; end of the last payload seen; bytes a round may span
@@ -186,10 +186,10 @@ struct cov_session {
     uint64_t ing_comp = 0, ing_infl = 0, ing_blocks = 0;
     bool ing_active = false;
     InflateKernel ing_K;
+    u32 wg_per_cu_override = 0;
     hipStream_t ing_copy = nullptr;
     // second upload queue: the halves of a large piece go to HBM through two DMA engines at once (one queue moved ~42 GB/s of
     // 32 MiB pieces between table uploads; the link does 57); joined into ing_copy before anything is recorded there
-    hipStream_t ing_copy2 = nullptr; hipEvent_t ing_c2_done = nullptr; bool ing_c2_dirty = false; int64_t ing_copy2_cleared = -1;
     hipEvent_t ing_ev[COV_INGEST_SLOTS] = {}, ing_fed = nullptr;
     double ing_s_alloc = 0;     // host seconds inside device allocations of the ingest
     double ing_s_part[4] = {0, 0, 0, 0};     // ... inside ingest_drain / launch_round / the upload calls / event waits (COVERM_CLI_TIMING)
@@ -330,8 +330,7 @@ void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
         }
         occ = nb; occ_slot.store(nb, std::memory_order_relaxed);
     }
-    const char *wg_env = getenv("COVERM_WG_PER_CU");
-    const u32 wg_per_cu = wg_env && atoi(wg_env) > 0 ? (u32)atoi(wg_env) : 8u * (u32)occ;
+    const u32 wg_per_cu = s->wg_per_cu_override ? s->wg_per_cu_override : 8u * (u32)occ;
     const u32 grid = std::max(1u, std::min((n_chunks + 3) / 4, (u32)s->n_cus * wg_per_cu));
     hipLaunchKernelGGL((k_pileup_fast<H>), dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
 }
@@ -357,8 +356,7 @@ void launch_stream_t(cov_session *s, const PileupArgs &a, u32 n_tiles, bool slow
         }
         occ = nb; occ_slot.store(nb, std::memory_order_relaxed);
     }
-    const char *wg_env = getenv("COVERM_WG_PER_CU");
-    const u32 wg_per_cu = wg_env && atoi(wg_env) > 0 ? (u32)atoi(wg_env) : 8u * (u32)occ;
+    const u32 wg_per_cu = s->wg_per_cu_override ? s->wg_per_cu_override : 8u * (u32)occ;
     if (slow_list_only) {   // the listed tiles only, one per wave step; the count lives on the device (usually 0: waves exit at once)
         hipLaunchKernelGGL((k_pileup_stream<H, W>), dim3((u32)s->n_cus), dim3(256), smem, s->stream, a, 0u, 1u,
                            (const u32 *)s->d_slow_list.p, (const u32 *)&s->d_glob.p->n_slow);
@@ -436,6 +434,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
         stamp("device attribute");
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
+    if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
     e = hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_prep_done, hipEventDisableTiming);
@@ -467,7 +466,7 @@ void cov_destroy(cov_session *s) {
     s->d_cx_list.release(); s->d_cx_cnt.release(); s->d_cx_cur.release(); s->d_cx_scan.release(); s->d_cx_top.release(); s->d_cx_runs.release();
     if (s->ing_aux) (void)hipStreamSynchronize(s->ing_aux);
     if (s->ing_parse) (void)hipStreamSynchronize(s->ing_parse);
-    if (s->ing_ext) { (void)hipStreamSynchronize(s->ing_ext); if (s->ing_ext_owned) (void)hipStreamDestroy(s->ing_ext); }
+    if (s->ing_ext) (void)hipStreamSynchronize(s->ing_ext);
     ingest_free_buffers(s);
     s->g_result.release();
     if (s->ing_aux) (void)hipStreamDestroy(s->ing_aux);
@@ -479,8 +478,6 @@ void cov_destroy(cov_session *s) {
     s->h_winres = nullptr;
     if (s->h_blocks) (void)hipHostFree(s->h_blocks);
     s->h_blocks = nullptr;
-    if (s->ing_copy2) { (void)hipStreamSynchronize(s->ing_copy2); (void)hipStreamDestroy(s->ing_copy2); }
-    if (s->ing_c2_done) (void)hipEventDestroy(s->ing_c2_done);
     if (s->ing_copy) { (void)hipStreamSynchronize(s->ing_copy); (void)hipStreamDestroy(s->ing_copy); }
     for (int k = 0; k < COV_INGEST_SLOTS; k++) if (s->ing_ev[k]) (void)hipEventDestroy(s->ing_ev[k]);
     if (s->ing_fed) (void)hipEventDestroy(s->ing_fed);
@@ -608,7 +605,7 @@ cov_status cov_ingest_abort(cov_session *s) {
     if (!s->ing_active) return COV_OK;
     HIPCHK(hipSetDevice(s->cfg.device));
     s->ing_active = false;
-    for (hipStream_t st : {s->ing_copy2, s->ing_copy, s->stream, s->ing_aux, s->ing_parse, s->ing_ext})
+    for (hipStream_t st : {s->ing_copy, s->stream, s->ing_aux, s->ing_parse, s->ing_ext})
         if (st) HIPCHK(hipStreamSynchronize(st));
     s->ing_rec_total = s->ing_cig_total = 0; s->ing_round_n = 0; s->ing_fail = 0;
     s->ing_extracted = s->ing_batch;
@@ -1034,7 +1031,6 @@ static InflateKernel choose_inflate_kernel(cov_session *s) {
     // less compressible blocks simply closes earlier
     K.cwin = std::max<u64>((u64)K.round_blocks * 32768u, 1ull << 20);
     if (const char *c = getenv("COVERM_INGEST_CWIN_KB")) { const long v = atol(c); if (v >= 256) K.cwin = (u64)v << 10; }
-    K.pad_lds = (u32)(getenv("COVERM_INFLATE_WAVE_PAD_KB") ? atoi(getenv("COVERM_INFLATE_WAVE_PAD_KB")) : 0) << 10;      // measurements: unused LDS lowers k_inflate_wave's resident waves per CU
     K.ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);      // measurements: stop every block after the tables / pass 1 / pass 2
     return K;
 }
@@ -1045,18 +1041,14 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     HIPCHK(hipSetDevice(s->cfg.device));
     if (!s->ing_copy) {
         HIPCHK(hipStreamCreateWithFlags(&s->ing_copy, hipStreamNonBlocking));
-        if (getenv("COVERM_INGEST_COPY_QUEUES") && atoi(getenv("COVERM_INGEST_COPY_QUEUES")) >= 2) {      // opt-in until measured
-            HIPCHK(hipStreamCreateWithFlags(&s->ing_copy2, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&s->ing_c2_done, hipEventDisableTiming));
-        }
+        // (two upload queues — the halves of a piece on two DMA engines — were measured slower, profiles/r03_copy_queues_50M.log: removed)
         for (int k = 0; k < COV_INGEST_SLOTS; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ev[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ing_fed, hipEventDisableTiming));
         HIPCHK(hipStreamCreateWithFlags(&s->ing_aux, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&s->ing_parse, hipStreamNonBlocking));
         // extraction shares the parse stream unless asked otherwise: a stream costs ~6 ms to create and as much again when the process
         // ends, and extract(w) queued behind the boundary search of w + 1 still finishes long before window w's buffer is needed again
-        if (getenv("COVERM_INGEST_EXT_STREAM") && atoi(getenv("COVERM_INGEST_EXT_STREAM"))) { HIPCHK(hipStreamCreateWithFlags(&s->ing_ext, hipStreamNonBlocking)); s->ing_ext_owned = true; }
-        else { s->ing_ext = s->ing_parse; s->ing_ext_owned = false; }
+        s->ing_ext = s->ing_parse;
         for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_inf_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_lz_done[k], hipEventDisableTiming)); }
         for (int k = 0; k < 4; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ver_done[k], hipEventDisableTiming));
         for (int k = 0; k < 3; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_ext_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_cdone[k], hipEventDisableTiming)); }
@@ -1086,7 +1078,7 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     HIPCHK(hipMemsetAsync(s->g_result.p, 0, (8 + 4 * 8) * sizeof(u64), s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     s->ing_comp = compressed_bytes; s->ing_infl = 0; s->ing_blocks = 0; s->ing_launched = 0; s->ing_active = true;
-    s->ing_round_start = 0; s->ing_prev_end = 0; s->ing_round_n = 0; s->ing_copy_cleared = -1; s->ing_copy2_cleared = -1; s->ing_c2_dirty = false;
+    s->ing_round_start = 0; s->ing_prev_end = 0; s->ing_round_n = 0; s->ing_copy_cleared = -1;
     s->ing_key_lo = 0; s->ing_key_hi = 0x80000000ll; s->ing_search_first = false; s->ing_open_end = false; s->ing_fed_any = false;
     s->ing_span_lo = 0; s->ing_span_hi = compressed_bytes; s->ing_tail_key = ~0ull;
     s->ing_ccap = std::min<u64>(inflate_kernel(s).cwin, compressed_bytes + 65536u + 128u);     // a small file is one buffer: the byte rule never fires
@@ -1209,7 +1201,7 @@ static cov_status launch_round_(cov_session *s, uint64_t n64, bool final) {
         const uint8_t *comp_bias = s->g_cwin[w % 3u].p - s->ing_round_start;     // blocks carry absolute file offsets
         const u32 ablate = K.ablate;
         if (K.version == 3)
-            hipLaunchKernelGGL(covi::k_inflate_wave, dim3(n), dim3(64), K.pad_lds, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, tokb.p, ntokb.p,
+            hipLaunchKernelGGL(covi::k_inflate_wave, dim3(n), dim3(64), 0, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, tokb.p, ntokb.p,
                                s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
         else
             hipLaunchKernelGGL((covi::k_inflate<INF1_LB, INF1_DB, false>), dim3(grid), dim3(64), covi::inflate_smem_bytes(INF1_LB, INF1_DB), s->stream, comp_bias,
@@ -1267,7 +1259,7 @@ static cov_status ingest_copy_range(cov_session *s, u32 r, u64 origin, u64 a, u6
     DevBuf<uint8_t> &cw = s->g_cwin[r % 3u];
     const size_t need = (size_t)s->ing_ccap + 2 * 65536u + 256u;
     if (cw.cap < need) {
-        if (cw.cap) { if (s->ing_copy2) HIPCHK(hipStreamSynchronize(s->ing_copy2)); HIPCHK(hipStreamSynchronize(s->ing_copy)); HIPCHK(hipStreamSynchronize(s->stream)); }      // replaced while possibly in use
+        if (cw.cap) { HIPCHK(hipStreamSynchronize(s->ing_copy)); HIPCHK(hipStreamSynchronize(s->stream)); }      // replaced while possibly in use
         const auto ta0 = std::chrono::steady_clock::now();
         HIPCHK(cw.reserve(need, s->stream));
         s->ing_s_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta0).count();
@@ -1278,17 +1270,6 @@ static cov_status ingest_copy_range(cov_session *s, u32 r, u64 origin, u64 a, u6
     }
     if (a < origin || b - origin > cw.cap) { s->err = "cov_ingest_feed: internal error, bytes outside their round's buffer"; return COV_ERR_STATE; }
     const u64 len = b - a;
-    if (s->ing_copy2 && len >= (8u << 20)) {        // two halves, two queues
-        if ((int64_t)r > s->ing_copy2_cleared) {
-            if (r >= 3) HIPCHK(hipStreamWaitEvent(s->ing_copy2, s->ing_cdone[r % 3u], 0));
-            s->ing_copy2_cleared = (int64_t)r;
-        }
-        const u64 h = (len / 2 + 4095u) & ~4095ull;
-        HIPCHK(hipMemcpyAsync(cw.p + (a - origin), piece + (a - piece_off), h, hipMemcpyHostToDevice, s->ing_copy));
-        HIPCHK(hipMemcpyAsync(cw.p + (a - origin) + h, piece + (a - piece_off) + h, len - h, hipMemcpyHostToDevice, s->ing_copy2));
-        s->ing_c2_dirty = true;
-        return COV_OK;
-    }
     HIPCHK(hipMemcpyAsync(cw.p + (a - origin), piece + (a - piece_off), len, hipMemcpyHostToDevice, s->ing_copy));
     return COV_OK;
 }
@@ -1296,11 +1277,6 @@ static cov_status ingest_copy_range(cov_session *s, u32 r, u64 origin, u64 a, u6
 // Table entries [from, ing_blocks) follow the bytes on the copy stream; ing_fed marks "everything fed so far is on the device"
 // (recorded even without new entries: the bytes in front of it may complete a round).
 static cov_status ingest_upload_table(cov_session *s, u64 from) {
-    if (s->ing_c2_dirty) {       // what the second queue carries belongs in front of everything recorded on the first from here on
-        HIPCHK(hipEventRecord(s->ing_c2_done, s->ing_copy2));
-        HIPCHK(hipStreamWaitEvent(s->ing_copy, s->ing_c2_done, 0));
-        s->ing_c2_dirty = false;
-    }
     if (from < s->ing_blocks)
         HIPCHK(hipMemcpyAsync(s->g_blocks.p + from, s->h_blocks + from, (size_t)(s->ing_blocks - from) * sizeof(covi::BgzfBlock), hipMemcpyHostToDevice, s->ing_copy));
     HIPCHK(hipEventRecord(s->ing_fed, s->ing_copy));
@@ -1319,13 +1295,11 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
         const size_t nc = std::max<size_t>(s->ing_blocks + n_blocks, s->h_blocks_cap * 2 + 4096);
         covi::BgzfBlock *nb = nullptr;
         HIPCHK(hipHostMalloc((void **)&nb, nc * sizeof(covi::BgzfBlock), hipHostMallocDefault));
-        if (s->ing_copy2) HIPCHK(hipStreamSynchronize(s->ing_copy2));
         HIPCHK(hipStreamSynchronize(s->ing_copy));      // earlier uploads still read the old mirror
         if (s->h_blocks) { memcpy(nb, s->h_blocks, s->ing_blocks * sizeof(covi::BgzfBlock)); (void)hipHostFree(s->h_blocks); }
         s->h_blocks = nb; s->h_blocks_cap = nc;
     }
     if (s->ing_blocks + n_blocks > s->g_blocks.cap || s->ing_blocks + n_blocks > s->g_status.cap) {
-        if (s->ing_copy2) HIPCHK(hipStreamSynchronize(s->ing_copy2));
         HIPCHK(hipStreamSynchronize(s->ing_copy)); HIPCHK(hipStreamSynchronize(s->ing_aux)); HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(s->g_blocks.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));
         HIPCHK(s->g_status.reserve(s->ing_blocks + n_blocks, s->stream, s->ing_blocks));

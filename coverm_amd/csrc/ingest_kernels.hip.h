@@ -446,7 +446,7 @@ namespace covi {
 static_assert(covw::TOK_CAP == INF_TOK_CAP && covw::OK == INF_OK && covw::ERR_FORMAT == INF_ERR_FORMAT && covw::ERR_SIZE == INF_ERR_SIZE, "the core mirrors k_inflate's contract");
 // (A cursor of two words and a funnel shift instead of the 64-bit buffer was tried: no fewer instructions per unit; a look-ahead cursor with
 // 16-byte loads was slower; holding the register allocation to five waves per SIMD changed nothing, to six or seven cost 40 % in spills.)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_inflate_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
+__device__ __forceinline__ void inflate_wave_body(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                      uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
                                                      u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
     __shared__ covw::Wave W;
@@ -464,6 +464,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         if (st != INF_OK) atomicAdd(n_failed, 1u);
     }
 }
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_inflate_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
+                                                     uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
+                                                     u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
+    inflate_wave_body(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);
+}
+// (Held to 96 registers = five waves per SIMD, one spilled register: 24.5 ms per round against 22.3 on the same box, profiles/r04_waves5_lzscope.log.)
 
 // Inclusive wave64 prefix sum (DPP row shifts + row broadcasts; VALU latency only).
 __device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {
@@ -483,6 +490,8 @@ __device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {
 // position are copied concurrently (their bytes spread over the 64 lanes), the stores are drained, and the frontier moves
 // on.  Matches mostly reach a record or more back while a window of 64 tokens spans a few records, so a window takes a few
 // rounds instead of 64 dependent load-store round trips.
+// (The source loads at workgroup scope — L1 hits allowed, the bytes were written by this very wave — change nothing: 19.6 ms against 19.7,
+// profiles/r04_waves5_lzscope.log.)
 __global__ __launch_bounds__(256) void k_lz_resolve(const BgzfBlock *__restrict__ blocks, u32 n_blocks, uint8_t *__restrict__ out,
                                                     const tokpos_t *__restrict__ tok, const u32 *__restrict__ n_tok) {
     const int lane = threadIdx.x & 63;
