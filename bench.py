@@ -575,6 +575,7 @@ def main():
                                                          100.0 * abs(kms["k_prep"] - kms["k_pileup"]) / max(kms["k_prep"], kms["k_pileup"], 1e-9))}
         if prof.get("valu_mix"):
             roof["issue_model"] = prof["valu_mix"]
+        roof["ingest"] = ingest_roofline()
         roof.update({"kernel_ms": kms.get(dom), "all_kernels_ms": kms, "kernels": per_kernel,
                      "pipeline": {"algorithmic_bytes": pipe_bytes, "kernels_ms": pipe_ms, "achieved_GBps": pipe_bytes / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0,
                                   "frac_of_8TBps": pipe_bytes / (pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if pipe_ms else 0.0}})
@@ -716,6 +717,37 @@ def sess_tiles(sess, ref):
     """Tiles of the configured pileup kernel: 1024 bases per wave (fast / streaming kernels) unless COVERM_PILEUP=tile."""
     tile = int(os.environ.get("COVERM_TILE", 4096)) if os.environ.get("COVERM_PILEUP") == "tile" else 1024
     return int(((ref.lengths + tile - 1) // tile).sum())
+
+
+def ingest_roofline():
+    """The device ingest's two dominant kernels against the HBM roofline, from the COMMITTED profile of the round-4 build
+    (profiles/r04_ingest_kernel_stats.csv: rocprofv3 --kernel-trace --stats of `coverm-amd contig` over a 20 M-read level-1 BAM = one full
+    round of 81 920 BGZF blocks + one of 12 382; profiles/r04_ingest_pmc_summary.json: separate --pmc passes).  Not measured by this run:
+    the bench's timed region is the coverage path; labelled as such.  Algorithmic bytes per full round: compressed bytes read once +
+    inflated bytes written once (k_inflate_wave); token positions + every match byte read and written once (k_lz_resolve)."""
+    out = {"source": "committed profile of the round-4 build (profiles/r04_ingest_kernel_stats.csv, r04_ingest_pmc_summary.json), not this run",
+           "round_blocks": 81920, "peak_GBps": HBM_PEAK_GBPS}
+    try:
+        import csv
+        full_ms = {}
+        with open(os.path.join(ROOT, "profiles", "r04_ingest_kernel_stats.csv")) as fh:
+            for r in csv.DictReader(fh):
+                full_ms[r["Name"].split("(")[0].replace("void ", "").strip()] = float(r["MaxNs"]) / 1e6      # the full round is the longer of the two launches
+        with open(os.path.join(ROOT, "profiles", "r04_ingest_pmc_summary.json")) as fh:
+            pm = json.load(fh).get("derived_full_round", {})
+        blocks = 81920
+        algo = {"covi::k_inflate_wave": blocks * (21100 + 62900), "covi::k_lz_resolve": blocks * (5900 * 2 + 2 * 50600)}
+        for k, b in algo.items():
+            ms = full_ms.get(k)
+            if not ms:
+                continue
+            ach = b / (ms * 1e-3) / 1e9
+            out[k.split("::")[1]] = {"ms_per_full_round": ms, "algorithmic_bytes": b, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS,
+                                     "hbm_read_bytes_counters": (pm.get(k) or {}).get("hbm_read_bytes_gfx950_corrected"),
+                                     "hbm_write_bytes_counters": (pm.get(k) or {}).get("hbm_write_bytes")}
+    except Exception as ex:
+        out["error"] = repr(ex)[:300]
+    return out
 
 
 def profile_numbers():
