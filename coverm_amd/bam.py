@@ -5,15 +5,32 @@ reference: path in, header + records out (here already as the SoA batch the C AB
 """
 import ctypes as C
 import os
+from dataclasses import dataclass
+from typing import List, Optional
 
 import numpy as np
 
 from . import native
-from .cli import AlignmentFile
 from .engine import RecordBatch
 from .native import CovBatch
 
 _bound = False
+
+
+
+@dataclass
+class AlignmentFile:
+    """A decoded BAM/SAM: header + records in file order (+ mate fields for pair-mode filtering)."""
+    path: str
+    ref_names: List[str]
+    ref_lens: np.ndarray
+    records: "RecordBatch"
+    qname: Optional[List[bytes]] = None
+    mtid: Optional[np.ndarray] = None
+
+    @property
+    def stoit_name(self):  # bam_generator.rs:358-365: file stem
+        return os.path.splitext(os.path.basename(self.path))[0]
 
 
 def _lib():

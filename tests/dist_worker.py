@@ -14,8 +14,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from coverm_amd import cli, distributed, host, synth  # noqa: E402
-from coverm_amd.cli import AlignmentFile  # noqa: E402
+from coverm_amd import distributed, host, synth  # noqa: E402
+from tests import harness_cli as cli  # noqa: E402
+from tests.harness_cli import AlignmentFile  # noqa: E402
 from coverm_amd.host import CoverageEstimator as E  # noqa: E402
 
 

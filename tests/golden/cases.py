@@ -286,7 +286,7 @@ def _rows(prefix, names, vals):
 
 
 # `coverm <mode> --bam-files ...` end-to-end expectations (tests/test_cmdline.rs).  args are the
-# keyword arguments of the CLI restatement (oracle.run_cli / coverm_amd.cli.run).
+# keyword arguments of the CLI restatement (oracle.run_cli / tests/harness_cli.run).
 CLI_CASES = [
     dict(id="cli_relative_abundance_and_mean", cite="tests/test_cmdline.rs:1145-1172", mode="genome",
          bams=[S7 + ".bam"], args=dict(methods=["relative_abundance", "mean"], output_format="sparse", separator="~"),

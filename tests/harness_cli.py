@@ -1,4 +1,6 @@
-"""`coverm contig` / `coverm genome` over --bam-files, on the MI355X engine.
+"""TEST HARNESS (not part of the product: the orchestrator is csrc/host_cli.cpp, the `coverm-amd` binary).
+`coverm contig` / `coverm genome` over --bam-files in Python, driving the product's C++ host layer (and, with a GPU, its sessions) from
+in-memory records, so that the CPU-only suite can run the host layer on the oracle's statistics and tests/dist_worker.py can shard it.
 
 Mirrors the reference orchestrator for this path only (src/bin/coverm.rs): FilterParameters (:1648-1704),
 EstimatorsAndTaker::generate_from_clap (:1315-1504), run_contig (:2088-2131), run_genome (:1539-1628),
@@ -18,28 +20,14 @@ import ctypes as C
 
 import numpy as np
 
-from . import host
-from .engine import FilterConfig, RecordBatch, Session
-from .host import CoverageEstimator, CoverageTaker, SampleResult
+from coverm_amd import host
+from coverm_amd.bam import AlignmentFile  # noqa: F401  (re-exported: the tests take it from here)
+from coverm_amd.engine import FilterConfig, RecordBatch, Session
+from coverm_amd.host import CoverageEstimator, CoverageTaker, SampleResult
 
 CONCATENATED_FASTA_FILE_SEPARATOR = "~"  # lib.rs:46
 UNSORTED_MESSAGE = ("BAM file appears to be unsorted. Input BAM files must be sorted by reference "
                     "(i.e. by samtools sort)")
-
-
-@dataclass
-class AlignmentFile:
-    """A decoded BAM/SAM: header + records in file order (+ mate fields for pair-mode filtering)."""
-    path: str
-    ref_names: List[str]
-    ref_lens: np.ndarray
-    records: RecordBatch
-    qname: Optional[List[bytes]] = None
-    mtid: Optional[np.ndarray] = None
-
-    @property
-    def stoit_name(self):  # bam_generator.rs:358-365: file stem
-        return os.path.splitext(os.path.basename(self.path))[0]
 
 
 @dataclass
@@ -172,8 +160,8 @@ class _PairFilter(C.Structure):   # covh_pair_filter
 
 def pair_mode_order(af: AlignmentFile, fp: FilterParameters, threads: int = 8):
     """Indices of the records ReferenceSortedBamFilter::read returns in pair mode (filter_out = true)."""
-    from . import native
-    from .native import CovBatch
+    from coverm_amd import native
+    from coverm_amd.native import CovBatch
     L = native.lib()
     r = af.records
     n = r.n_records

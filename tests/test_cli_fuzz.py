@@ -4,8 +4,8 @@ zero-row settings on a small paired synthetic sample."""
 import numpy as np
 import pytest
 
-from coverm_amd import cli
-from coverm_amd.cli import AlignmentFile
+from tests import harness_cli as cli
+from tests.harness_cli import AlignmentFile
 from coverm_amd.engine import RecordBatch
 from oracle import oracle as O
 from tests.test_host_golden import _paired_sample

@@ -1,4 +1,4 @@
-"""Per-gene coverage (--gff; src/genes.rs): product host driver (C++ covh_gene_coverage + coverm_amd.cli) against the
+"""Per-gene coverage (--gff; src/genes.rs): product host driver (C++ covh_gene_coverage + tests/harness_cli.py) against the
 reference's golden vectors and against the oracle on synthetic genes.
 
 CPU variant: the contig depth arrays come from the oracle, so GFF parsing, gene resolution, per-gene statistics, read
@@ -10,8 +10,9 @@ import os
 import numpy as np
 import pytest
 
-from coverm_amd import cli, host, synth
-from coverm_amd.cli import AlignmentFile
+from coverm_amd import host, synth
+from tests import harness_cli as cli
+from tests.harness_cli import AlignmentFile
 from coverm_amd.engine import RecordBatch, make_config
 from coverm_amd.host import CoverageEstimator as E
 from oracle import oracle as O

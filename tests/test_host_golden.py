@@ -1,4 +1,4 @@
-"""Host layer (C++ estimators / scan drivers / takers / printers + coverm_amd.cli) against the
+"""Host layer (C++ estimators / scan drivers / takers / printers + tests/harness_cli.py) against the
 reference's golden vectors.
 
 CPU variant: the per-contig integer statistics are supplied by the oracle (so the host logic is
@@ -10,8 +10,9 @@ import os
 import numpy as np
 import pytest
 
-from coverm_amd import cli, host, native
-from coverm_amd.cli import AlignmentFile
+from coverm_amd import host, native
+from tests import harness_cli as cli
+from tests.harness_cli import AlignmentFile
 from coverm_amd.engine import RecordBatch
 from coverm_amd.host import CoverageEstimator as E
 from coverm_amd.host import CoverageTaker, SampleResult

@@ -75,7 +75,7 @@ def test_host_takers_printers(case):
 @pytest.mark.parametrize("name", ["7seqs.definition", "7seqs.definition_with_comments"])
 def test_read_genome_definition_file(name, reader, tmp_path):
     import os
-    from coverm_amd import cli
+    from tests import harness_cli as cli
     from tests.fixtures import FIXDIR
     read = O.read_genome_definition if reader == "oracle" else cli.read_genome_definition
     genomes, c2g = read(os.path.join(FIXDIR, name))

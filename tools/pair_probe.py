@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
 from coverm_amd import native, synth  # noqa: E402
-from coverm_amd.cli import _PairFilter  # noqa: E402
+from tests.harness_cli import _PairFilter  # noqa: E402
 from coverm_amd.native import CovBatch  # noqa: E402
 
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
