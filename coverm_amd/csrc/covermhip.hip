@@ -139,7 +139,7 @@ struct cov_session {
     DevBuf<double> d_ident, d_identp;
     DevBuf<IdChunk> d_idch;
     int id_mode = 1;   // 1 = exact parallel identity sums, 0 = serial chain only (COVERM_IDENTITY=serial)
-    hipStream_t side = nullptr;     // k_identity overlaps k_ranges / k_pileup
+    hipStream_t side = nullptr; bool side_owned = false;     // k_identity overlaps k_ranges / k_pileup (created on first use, or the idle second stream of the ingest)
     hipEvent_t ev_prep_done = nullptr, ev_side_done = nullptr;
     DevBuf<u32> d_arena;
     DevBuf<u64> d_chist;
@@ -436,8 +436,9 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
     if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
-    e = hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_prep_done, hipEventDisableTiming);
+    // (every stream costs ~6 ms to create and as much again when the process ends, tools/ubench/exit_probe: the side stream of the
+    // identity kernels is created by the first cov_finish that wants it, and borrows the ingest's second stream when there is one)
+    e = hipEventCreateWithFlags(&s->ev_prep_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_side_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete s; return COV_ERR_HIP; }
@@ -492,7 +493,7 @@ void cov_destroy(cov_session *s) {
     s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
     s->s_mtid.release(); s->s_qh1.release(); s->s_qh2.release();
     s->d_runs.release(); s->d_part.release(); s->d_ident.release(); s->d_identp.release(); s->d_idch.release();
-    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
+    if (s->side) { (void)hipStreamSynchronize(s->side); if (s->side_owned) (void)hipStreamDestroy(s->side); }
     if (s->ev_prep_done) (void)hipEventDestroy(s->ev_prep_done);
     if (s->ev_side_done) (void)hipEventDestroy(s->ev_side_done); s->d_arena.release(); s->d_chist.release(); s->d_depth.release();
     for (int k = 0; k < COV_K_COUNT; k++)
@@ -774,6 +775,10 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         time_end(s, COV_K_PREP);
         HIPCHK(hipGetLastError());
         if (want_id && nT) {   // depends only on k_prep: run beside k_ranges / k_pileup
+            if (!s->side) {
+                if (s->ing_aux && !s->ing_active) s->side = s->ing_aux;      // idle since cov_ingest_end
+                else { HIPCHK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking)); s->side_owned = true; }
+            }
             HIPCHK(hipEventRecord(s->ev_prep_done, st));
             HIPCHK(hipStreamWaitEvent(s->side, s->ev_prep_done, 0));
             (void)hipEventRecord(s->ev[COV_K_IDENTITY][0], s->side);
@@ -1045,9 +1050,10 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
         for (int k = 0; k < COV_INGEST_SLOTS; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ev[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ing_fed, hipEventDisableTiming));
         HIPCHK(hipStreamCreateWithFlags(&s->ing_aux, hipStreamNonBlocking));
+        // (the boundary search on the LZ / CRC stream — the runtime's four hardware queues put the two on one queue anyway — was measured:
+        // ingest 0.650 s against 0.612 s, the extraction of window w then also waits behind the LZ of w + 1, and the exit is no shorter:
+        // profiles/r04_e2e_200M_runs_*.log)
         HIPCHK(hipStreamCreateWithFlags(&s->ing_parse, hipStreamNonBlocking));
-        // extraction shares the parse stream unless asked otherwise: a stream costs ~6 ms to create and as much again when the process
-        // ends, and extract(w) queued behind the boundary search of w + 1 still finishes long before window w's buffer is needed again
         s->ing_ext = s->ing_parse;
         for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_inf_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_lz_done[k], hipEventDisableTiming)); }
         for (int k = 0; k < 4; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ver_done[k], hipEventDisableTiming));

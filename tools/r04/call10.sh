@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r04_call10; mkdir -p $OUT; rm -f $OUT/*
 cd $R
 ( timeout 250 python -m pytest tests/test_gpu_ingest.py tests/test_gpu_pair_filter.py -m gpu -x -q --timeout 90 2>&1 | tail -6 ) > $OUT/pytest.log 2>&1
-timeout 120 python tools/make_bam.py /dev/shm/e2e.bam 200000000 16 > $OUT/make.log 2>&1
+timeout 240 python tools/make_bam.py /dev/shm/e2e.bam 200000000 16 > $OUT/make.log 2>&1
 CMD="$R/coverm_amd/coverm-amd contig -b /dev/shm/e2e.bam -m mean trimmed_mean covered_fraction variance count --min-read-percent-identity 95 --min-read-aligned-length 50 --proper-pairs-only -t 16 -o /dev/shm/e2e.tsv"
 run() {
   name=$1; shift
