@@ -1144,7 +1144,7 @@ static cov_status ingest_drain_(cov_session *s, int64_t must_upto) {
             covi::BamScan S{};
             S.u = s->g_win[w % 3u].p; S.N = s->ing_win[q].N; S.p0 = s->g_result.p + 6; S.seg_bytes = 32768; S.n_seg = s->ing_win[q].n_seg;
             S.n_ref = (int)s->n_targets; S.ref_len = s->d_tlen.p; S.final = 0; S.key_lo = s->ing_key_lo; S.key_hi = s->ing_key_hi; S.search_first = 0;
-            hipLaunchKernelGGL(covi::k_bam_extract, dim3((S.n_seg + 63) / 64), dim3(64), 0, ps, S, (const covi::SegInfo *)s->g_seg[q].p, (const u64 *)s->g_recbase[q].p,
+            hipLaunchKernelGGL(covi::k_bam_extract, dim3((S.n_seg * covi::EXT_PARTS + 63) / 64), dim3(64), 0, ps, S, (const covi::SegInfo *)s->g_seg[q].p, (const u64 *)s->g_recbase[q].p,
                                (const u64 *)s->g_cigbase[q].p, RS, reinterpret_cast<u32 *>(s->g_result.p + 3) + 1);
             HIPCHK(hipGetLastError());
             s->ing_rec_total += nrec; s->ing_cig_total += ncig;

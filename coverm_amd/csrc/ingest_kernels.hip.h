@@ -673,7 +673,13 @@ struct SegInfo {
     u32 flags;     // bit 1: keys decrease inside the hop (bit 0 was: a CG:B,I record, now resolved by the extraction)
     u32 first_key, last_key;     // keys of the first / last record hopped over (any record, not only the span's); valid when n_hop != 0
     u32 n_hop;                   // records hopped over
+    // The hop's chain cut in EXT_PARTS pieces for the extraction (a lane per piece instead of a lane per segment: k_bam_extract is a chain of
+    // ~37 dependent memory instructions per record and spent 98 % of its wave time waiting at ten waves per CU): piece p + 1 begins at the first
+    // record that starts at or beyond start + (p + 1) * EXT_PIECE bytes — part_off[p] bytes behind `start` — with part_rec[p] / part_cig[p]
+    // of the span's records / CIGAR words in front of it.  Pieces the chain never reaches are empty (part_off = landed - start).
+    u32 part_off[3], part_rec[3], part_cig[3];
 };
+constexpr u32 EXT_PARTS = 4, EXT_PIECE = 8192;
 
 // One wave per segment: lanes test consecutive offsets for an 8-record plausible chain; the lowest hit wins.  The segment that
 // holds *p0 starts there by definition; segments below it are dead.
@@ -755,7 +761,9 @@ __global__ __launch_bounds__(64) void k_bam_hop(BamScan S, SegInfo *__restrict__
     u64 limit = S.N;
     for (u32 j = k + 1; j < S.n_seg; j++) { const u64 st = seg[j].start; if (st != ~0ull) { limit = st; break; } }
     u64 q = s.start; u32 nr = 0, nc = 0, fl = 0, nh = 0, k_first = 0, k_last = 0;
+    u32 part = 0;        // pieces closed so far
     while (q < limit && q + 4 <= S.N) {
+        while (part < EXT_PARTS - 1u && q >= s.start + (u64)(part + 1u) * EXT_PIECE) { s.part_off[part] = (u32)(q - s.start); s.part_rec[part] = nr; s.part_cig[part] = nc; part++; }
         const uint8_t *r = S.u + q;
         const u32 bs = ld32(r);
         if (bs < 32u || q + 4 + (u64)bs > S.N) break;
@@ -773,6 +781,7 @@ __global__ __launch_bounds__(64) void k_bam_hop(BamScan S, SegInfo *__restrict__
         }
         q += 4 + (u64)bs;
     }
+    for (; part < EXT_PARTS - 1u; part++) { s.part_off[part] = (u32)(q - s.start); s.part_rec[part] = nr; s.part_cig[part] = nc; }
     s.landed = q; s.n_rec = nr; s.n_cig = nc; s.flags = fl; s.first_key = k_first; s.last_key = k_last; s.n_hop = nh;
     seg[k] = s;
 }
@@ -910,13 +919,16 @@ __device__ __forceinline__ u32 scan_nm(const uint8_t *p, const uint8_t *end, u32
 // One lane per segment: second hop; every record's fields go straight into the record store.
 __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__restrict__ seg, const u64 *__restrict__ rec_base,
                                                     const u64 *__restrict__ cig_base, RecStore R, u32 *__restrict__ n_bad) {
-    const u32 k = blockIdx.x * 64u + threadIdx.x;
+    const u32 kp = blockIdx.x * 64u + threadIdx.x, k = kp / EXT_PARTS, part = kp % EXT_PARTS;      // one lane per piece of a segment's chain
     if (k >= S.n_seg) return;
     const SegInfo s = seg[k];
     if (s.start == ~0ull) return;
-    u64 q = s.start;
-    u64 ri = R.rec0 + rec_base[k], ci = R.cig0 + cig_base[k];
-    for (u32 j = 0; j < s.n_rec && q < s.landed;) {
+    const u64 q_end = part + 1u < EXT_PARTS ? s.start + s.part_off[part] : s.landed;
+    const u32 rec_lo = part ? s.part_rec[part - 1u] : 0u, cig_lo = part ? s.part_cig[part - 1u] : 0u;
+    const u32 n_mine = (part + 1u < EXT_PARTS ? s.part_rec[part] : s.n_rec) - rec_lo;
+    u64 q = part ? s.start + s.part_off[part - 1u] : s.start;
+    u64 ri = R.rec0 + rec_base[k] + rec_lo, ci = R.cig0 + cig_base[k] + cig_lo;
+    for (u32 j = 0; j < n_mine && q < q_end;) {
         const uint8_t *r = S.u + q;
         const u32 bs = ld32(r);
         const uint8_t *end = r + 4 + bs;
