@@ -682,7 +682,9 @@ def main():
             "cfg2_binary_s": r3((bc.get("config2_contig") or {}).get("seconds")), "cfg3_binary_s": r3((bc.get("config3_genome") or {}).get("seconds")),
             "parity_equal": (out.get("parity_checked") or {}).get("equal"),
             "tables_equal": (bool(e2e.get("tables_equal")) and bool(bc.get("tables_equal"))) if (e2e and bc and "error" not in e2e and "error" not in bc) else None,
-            "device_resident_ms": r3(out["ms_per_step"]), "pileup_kernel_ms": r3(roof.get("kernel_ms")), "roofline_frac": round(float(roof.get("frac") or 0.0), 4),
+            "device_resident_ms": r3(out["ms_per_step"]), "roofline_kernel": roof.get("kernel"), "roofline_frac": round(float(roof.get("frac") or 0.0), 4),
+            "pileup_kernel_ms": r3((roof.get("all_kernels_ms") or {}).get("k_pileup")), "pileup_hbm_frac": round(float(((roof.get("kernels") or {}).get("k_pileup") or {}).get("hbm_frac_of_8TBps") or 0.0), 4),
+            "prep_kernel_ms": r3((roof.get("all_kernels_ms") or {}).get("k_prep")), "prep_hbm_frac": round(float(((roof.get("kernels") or {}).get("k_prep") or {}).get("hbm_frac_of_8TBps") or 0.0), 4),
         })
         print(json.dumps(out), flush=True)
     if dist:

@@ -79,7 +79,7 @@ std::string g_create_error;
 //                        the fill and drain of the pipeline);
 //   version 1 (COVERM_INFLATE_V=1): k_inflate, one LANE per block, private Huffman tables per lane in LDS — the second implementation the
 //                        tests compare with; a launch is cut to exactly the blocks resident at once (a lane decodes a block serially).
-struct InflateKernel { int version = 3; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ablate = 0; };
+struct InflateKernel { int version = 3; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ablate = 0; u32 ext_parts = covi::EXT_PARTS; };
 
 struct cov_session {
     cov_config cfg{};
@@ -1036,6 +1036,7 @@ static InflateKernel choose_inflate_kernel(cov_session *s) {
     // less compressible blocks simply closes earlier
     K.cwin = std::max<u64>((u64)K.round_blocks * 32768u, 1ull << 20);
     if (const char *c = getenv("COVERM_INGEST_CWIN_KB")) { const long v = atol(c); if (v >= 256) K.cwin = (u64)v << 10; }
+    if (const char *e = getenv("COVERM_EXT_PARTS")) K.ext_parts = atoi(e) == 1 ? 1u : covi::EXT_PARTS;      // measurements: the extraction with a lane per segment
     K.ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);      // measurements: stop every block after the tables / pass 1 / pass 2
     return K;
 }
@@ -1144,8 +1145,8 @@ static cov_status ingest_drain_(cov_session *s, int64_t must_upto) {
             covi::BamScan S{};
             S.u = s->g_win[w % 3u].p; S.N = s->ing_win[q].N; S.p0 = s->g_result.p + 6; S.seg_bytes = 32768; S.n_seg = s->ing_win[q].n_seg;
             S.n_ref = (int)s->n_targets; S.ref_len = s->d_tlen.p; S.final = 0; S.key_lo = s->ing_key_lo; S.key_hi = s->ing_key_hi; S.search_first = 0;
-            hipLaunchKernelGGL(covi::k_bam_extract, dim3((S.n_seg * covi::EXT_PARTS + 63) / 64), dim3(64), 0, ps, S, (const covi::SegInfo *)s->g_seg[q].p, (const u64 *)s->g_recbase[q].p,
-                               (const u64 *)s->g_cigbase[q].p, RS, reinterpret_cast<u32 *>(s->g_result.p + 3) + 1);
+            hipLaunchKernelGGL(covi::k_bam_extract, dim3((S.n_seg * s->ing_K.ext_parts + 63) / 64), dim3(64), 0, ps, S, (const covi::SegInfo *)s->g_seg[q].p, (const u64 *)s->g_recbase[q].p,
+                               (const u64 *)s->g_cigbase[q].p, RS, reinterpret_cast<u32 *>(s->g_result.p + 3) + 1, s->ing_K.ext_parts);
             HIPCHK(hipGetLastError());
             s->ing_rec_total += nrec; s->ing_cig_total += ncig;
         }

@@ -918,14 +918,16 @@ __device__ __forceinline__ u32 scan_nm(const uint8_t *p, const uint8_t *end, u32
 
 // One lane per segment: second hop; every record's fields go straight into the record store.
 __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__restrict__ seg, const u64 *__restrict__ rec_base,
-                                                    const u64 *__restrict__ cig_base, RecStore R, u32 *__restrict__ n_bad) {
-    const u32 kp = blockIdx.x * 64u + threadIdx.x, k = kp / EXT_PARTS, part = kp % EXT_PARTS;      // one lane per piece of a segment's chain
+                                                    const u64 *__restrict__ cig_base, RecStore R, u32 *__restrict__ n_bad, u32 parts) {
+    // one lane per piece of a segment's chain (parts = EXT_PARTS), or per segment (parts = 1: the pieces walked by one lane)
+    const u32 kp = blockIdx.x * 64u + threadIdx.x, k = kp / parts, part = parts == 1u ? 0u : kp % parts;
     if (k >= S.n_seg) return;
     const SegInfo s = seg[k];
     if (s.start == ~0ull) return;
-    const u64 q_end = part + 1u < EXT_PARTS ? s.start + s.part_off[part] : s.landed;
+    const bool last = parts == 1u || part + 1u == EXT_PARTS;
+    const u64 q_end = last ? s.landed : s.start + s.part_off[part];
     const u32 rec_lo = part ? s.part_rec[part - 1u] : 0u, cig_lo = part ? s.part_cig[part - 1u] : 0u;
-    const u32 n_mine = (part + 1u < EXT_PARTS ? s.part_rec[part] : s.n_rec) - rec_lo;
+    const u32 n_mine = (last ? s.n_rec : s.part_rec[part]) - rec_lo;
     u64 q = part ? s.start + s.part_off[part - 1u] : s.start;
     u64 ri = R.rec0 + rec_base[k] + rec_lo, ci = R.cig0 + cig_base[k] + cig_lo;
     for (u32 j = 0; j < n_mine && q < q_end;) {

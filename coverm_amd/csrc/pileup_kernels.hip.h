@@ -1772,6 +1772,28 @@ __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, 
     int cur_c = -1;
     u64 hoff = 0; u32 hcap = 0;
     const u64 excl = a.excl;
+    // With the histogram wanted, interior tiles do NOT accumulate sum d, sum d^2, covered, min and max per position: every position's
+    // depth goes into the wave's LDS histogram anyway, and the five are read off its bins when they are moved to the arena (`drain`).
+    // The general loop (contig ends, tiles deeper than the bins) counts per position as before, so the bins hold segments of ONE kind at a
+    // time — lh_explicit says which — and are drained when the kind changes.  All wave-uniform.
+    bool lh_explicit = false;
+    u32 hbound = 0;            // no LDS bin above this was touched since the last drain (depth <= candidate runs of the tile)
+    auto drain = [&](bool derive) {
+        lds_fence();
+        for (u32 b = (u32)lane; b <= hbound; b += 64) {
+            const u32 x = lhist[b];
+            if (x) {
+                atomicAdd(&a.hist_arena[hoff + b], x); lhist[b] = 0u;
+                if (derive) {
+                    const u32 cv = b ? x : 0u;
+                    sum_d += (u64)b * x; sum_d2 += (u64)(b * b) * x; cov_w += cv; cov_f += cv;
+                    mn = min(mn, b); mx = max(mx, b);
+                }
+            }
+        }
+        lds_fence();
+        hbound = 0;
+    };
 
     auto hist_add = [&](u32 d, u32 x) {
         if (__builtin_expect(d < (u32)HBW, 1)) atomicAdd(&lhist[d], x);
@@ -1779,6 +1801,7 @@ __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, 
     };
     auto flush = [&]() {
         if (cur_c >= 0) {
+            if (WANT_HIST && proc_win) drain(!lh_explicit);
             const u64 s1 = wave_sum_u64(sum_d), s2 = wave_sum_u64(sum_d2);
             const u32 c1 = wave_sum_u32(cov_w), c2 = wave_sum_u32(cov_f);
             const u32 m1 = wave_min_u32(mn), m2 = wave_max_u32(mx);
@@ -1794,17 +1817,8 @@ __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, 
                     atomicMax(&C->max_d, m2);
                 }
             }
-            if (WANT_HIST && proc_win) {
-                lds_fence();
-                const u32 hi_b = min(m2, (u32)HBW - 1u);
-                for (u32 b = m1 + (u32)lane; b <= hi_b; b += 64) {
-                    const u32 x = lhist[b];
-                    if (x) { atomicAdd(&a.hist_arena[hoff + b], x); lhist[b] = 0u; }
-                }
-                lds_fence();
-            }
         }
-        sum_d = sum_d2 = 0; proc_win = 0; cov_w = cov_f = 0; mn = 0xffffffffu; mx = 0;
+        sum_d = sum_d2 = 0; proc_win = 0; cov_w = cov_f = 0; mn = 0xffffffffu; mx = 0; hbound = 0; lh_explicit = false;
     };
     auto load_runs = [&](const uint4 &d, uint2 &r0, uint2 &r1) {
         const u32 i0 = d.x + (u32)lane, i1 = i0 + 64u;
@@ -1910,15 +1924,29 @@ __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, 
             if (win_any) proc_win += (u64)(wet - wst);
             const bool interior = has_win && lo >= ws && lo + (u32)TW <= we;
             const u32 cand = ds.y - ds.x + cxn;
-            if (interior && cand < (u32)HBW) {
-                // ---- fast loop: every position is inside the window; depth < 512 so 24-bit multiplies and 32-bit
-                // per-tile sums are exact (16 positions x 2^18 per lane)
-                u32 s1t = 0, s2t = 0, cv = 0;
+            const bool fast_tile = interior && cand < (u32)HBW;
+            if (WANT_HIST) {
+                if (lh_explicit == fast_tile) { if (proc_win) drain(!lh_explicit); lh_explicit = !fast_tile; }   // the bins change kind
+                hbound = max(hbound, min(cand, (u32)HBW - 1u));
+            }
+            if (WANT_HIST && fast_tile) {
+                // ---- fast loop, histogram wanted: every position is inside the window and depth < 512 = the LDS bins: one atomic per
+                // constant-depth segment of the lane's 16 positions and nothing else
                 u32 seg0 = 0;
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     const int dj = (j & 1) ? (int)dl[j >> 1].y : (int)dl[j >> 1].x;
-                    if (WANT_HIST && j > 0 && dj != 0) { atomicAdd(&lhist[(u32)d], (u32)j - seg0); seg0 = (u32)j; }
+                    if (j > 0 && dj != 0) { atomicAdd(&lhist[(u32)d], (u32)j - seg0); seg0 = (u32)j; }
+                    d += dj;
+                }
+                atomicAdd(&lhist[(u32)d], 16u - seg0);
+            } else if (fast_tile) {
+                // ---- fast loop, no histogram: every position is inside the window; depth < 512 so 24-bit multiplies and 32-bit
+                // per-tile sums are exact (16 positions x 2^18 per lane)
+                u32 s1t = 0, s2t = 0, cv = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int dj = (j & 1) ? (int)dl[j >> 1].y : (int)dl[j >> 1].x;
                     d += dj;
                     const u32 du = (u32)d;
                     s1t += du;
@@ -1926,7 +1954,6 @@ __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, 
                     cv += du != 0u ? 1u : 0u;
                     mn = min(mn, du); mx = max(mx, du);
                 }
-                if (WANT_HIST) atomicAdd(&lhist[(u32)d], 16u - seg0);
                 sum_d += s1t; sum_d2 += s2t; cov_w += cv; cov_f += cv;
             } else {
                 // ---- general loop: window and contig-end tests per position, 64-bit sums, histogram overflow
