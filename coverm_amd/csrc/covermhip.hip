@@ -90,6 +90,7 @@ struct cov_session {
     int stream_rows = 4;   // > 0: wave-per-tile kernels (1024-base tiles); 0: k_pileup workgroup-per-tile (COVERM_PILEUP=tile)
     bool use_fast = true;  // k_pileup_fast + k_pileup_stream on the slow-tile list (default); COVERM_PILEUP=stream: k_pileup_stream alone
     int chunk_tiles = 8;   // consecutive tiles walked by one wave (COVERM_CHUNK)
+    bool fast_seven = true;    // k_pileup_fast7 (384 LDS bins, seven waves per SIMD: the default) or k_pileup_fast (512 bins, six; COVERM_FAST_WAVES=6)
     int n_cus = 256;
     uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
 
@@ -311,9 +312,10 @@ void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
 }
 
 // k_pileup_fast over every tile (it skips the ones k_ranges flagged TILE_F_SLOW)
-template <bool H>
-void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    const size_t smem = pileup_fast_smem_bytes(H);
+template <bool H, bool SEVEN>
+void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
+    const auto kern = SEVEN ? &k_pileup_fast7<H> : &k_pileup_fast<H>;
+    const size_t smem = pileup_fast_smem_bytes(H, SEVEN ? FAST_HB7 : FAST_HB);
     // the dynamic-LDS limit and the occupancy are per-device facts, and span mode launches from one thread per device: cached per
     // device id, in atomics (two threads racing for the same device compute the same value)
     static std::atomic<int> occ_dev[64];
@@ -322,9 +324,9 @@ void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
     const u32 chunk = (u32)s->chunk_tiles;
     const u32 n_chunks = (n_tiles + chunk - 1) / chunk;
     if (!occ) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_fast<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_pileup_fast<H>), 256, smem) != hipSuccess || nb < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, smem) != hipSuccess || nb < 1) {
             (void)hipGetLastError();
             nb = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
         }
@@ -332,7 +334,11 @@ void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
     }
     const u32 wg_per_cu = s->wg_per_cu_override ? s->wg_per_cu_override : 8u * (u32)occ;
     const u32 grid = std::max(1u, std::min((n_chunks + 3) / 4, (u32)s->n_cus * wg_per_cu));
-    hipLaunchKernelGGL((k_pileup_fast<H>), dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
+}
+template <bool H>
+void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
+    if (s->fast_seven) launch_fast_v<H, true>(s, a, n_tiles); else launch_fast_v<H, false>(s, a, n_tiles);
 }
 
 template <bool H, bool W>
@@ -434,6 +440,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
         stamp("device attribute");
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
+    if (const char *fw = getenv("COVERM_FAST_WAVES")) s->fast_seven = atoi(fw) != 6;
     if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
     // (every stream costs ~6 ms to create and as much again when the process ends, tools/ubench/exit_probe: the side stream of the

@@ -1748,13 +1748,14 @@ constexpr size_t pileup_stream_smem_bytes() { return (size_t)4 * ((size_t)STREAM
 //     issues in 4.2 cycles per wave where the plain two-operand forms it replaces take 2.4 (profiles/r03_valu_rate.json), so two values per
 //     instruction buy nothing here, and the permuted table layout costs two more address operations per event.  profiles/r04_pileup_packed.log.)
 constexpr int FAST_TW = 1024, FAST_HB = 512;
-constexpr size_t pileup_fast_smem_bytes(bool hist) { return (size_t)4 * ((size_t)FAST_TW * 4 + (hist ? (size_t)FAST_HB * 4 : 0)); }
+constexpr int FAST_HB7 = 384;   // k_pileup_fast7: seven workgroups per CU (22 KiB of LDS each, 72 registers)
+constexpr size_t pileup_fast_smem_bytes(bool hist, int hb = FAST_HB) { return (size_t)4 * ((size_t)FAST_TW * 4 + (hist ? (size_t)hb * 4 : 0)); }
 
 typedef short v2i16 __attribute__((ext_vector_type(2)));
 
-template <bool WANT_HIST>
-__global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
-    constexpr int TW = FAST_TW, HBW = FAST_HB;
+template <bool WANT_HIST, int HB>
+__device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tiles, u32 chunk_tiles) {
+    constexpr int TW = FAST_TW, HBW = HB;
     constexpr size_t WB = (size_t)TW * 4 + (WANT_HIST ? (size_t)HBW * 4 : 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1983,6 +1984,18 @@ __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, 
         if (!have_next) break;
         t = tn; t_end = tn_end; ch = chn; ds = nds; dC1 = ndC1; rw0 = nrw0; rw1 = nrw1;
     }
+}
+
+template <bool WANT_HIST>
+__global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
+    pileup_fast_body<WANT_HIST, FAST_HB>(a, n_tiles, chunk_tiles);
+}
+// The same with 384 LDS bins (22 KiB of LDS per workgroup: seven fit a CU) and the registers capped at 72 for seven waves per SIMD (four
+// loop-invariant dwords go to scratch).  The default: 0.535 ms against 0.590 at BASELINE config 2, alternating runs on one box
+// (profiles/r04_pileup_seven_waves.log); COVERM_FAST_WAVES=6 selects k_pileup_fast, and tests/test_gpu_abi_parity.py runs both.
+template <bool WANT_HIST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k_pileup_fast7(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
+    pileup_fast_body<WANT_HIST, FAST_HB7>(a, n_tiles, chunk_tiles);
 }
 
 // ------------------------------------------------------------------------------------ interval statistics

@@ -420,6 +420,46 @@ def test_stream_kernel_all_tiles(monkeypatch):
                 check_depth=range(min(3, len(ref_lens))))
 
 
+def test_fast_kernel_six_wave_variant(monkeypatch):
+    """COVERM_FAST_WAVES=6: k_pileup_fast (512 LDS histogram bins, six waves per SIMD) instead of the default k_pileup_fast7 (384 bins,
+    seven) — the same body, so the same inputs as the other kernels' tests, plus piles whose depths lie between the two bin counts."""
+    monkeypatch.setenv("COVERM_FAST_WAVES", "6")
+    for name in ["7seqs.reads_for_seq1_and_seq2.bam", "k141_2005182.bam", "eg2.bam"]:
+        compare(load_fixture(name), ff=(True, True, False), excl=75)
+    ref = synth.make_reference(40, 3_000_000, seed=11, min_len=1500, max_len=400_000)
+    b = to_bamdata(synth.make_reads(ref, 60_000, seed=12), ref.lengths, ref.names)
+    compare(b, ff=(True, True, False), excl=75, check_depth=[0, 1, 39], chunks=2)
+    for seed in range(0, 48, 5):
+        ref_lens, batch, rng = _fuzz_case(seed)
+        compare(to_bamdata(batch, ref_lens), ff=(True, True, False), excl=int(rng.choice([0, 75])),
+                check_depth=range(min(3, len(ref_lens))))
+    _piles_between_the_bin_counts()
+
+
+def _piles_between_the_bin_counts():
+    """Contigs whose depth climbs through 384 and 512: interior tiles leave the stripped loop (candidates >= bins) at different depths in
+    the two variants, and the general loop's segments cross from the LDS bins into the arena."""
+    rng = np.random.default_rng(78)
+    ref_lens = np.asarray([30_000, 12_000], dtype=np.int64)
+    n0, n1 = 75_000, 9_000
+    tid = np.concatenate([np.zeros(n0, np.int32), np.ones(n1, np.int32)])
+    # contig 0: density rising along the contig (depth 0 at the start to ~650 at the end); contig 1: flat, ~110
+    u = np.sort(rng.random(n0))
+    pos0 = (np.sqrt(u) * 29_000).astype(np.int32)
+    pos1 = np.sort(rng.integers(0, 11_800, n1)).astype(np.int32)
+    pos = np.concatenate([pos0, pos1])
+    n = len(tid)
+    cig = ((rng.integers(100, 150, n).astype(np.uint32)) << 4)
+    batch = RecordBatch.from_arrays(tid, pos, np.zeros(n, np.uint16), np.full(n, 30, np.uint8), rng.integers(0, 4, n),
+                                    np.ones(n, np.uint8), np.full(n, 150), np.arange(n + 1, dtype=np.uint32), cig)
+    for excl in (0, 75):
+        compare(to_bamdata(batch, ref_lens), ff=(True, True, False), excl=excl, check_depth=[0, 1])
+
+
+def test_fast_kernel_piles_between_the_bin_counts():
+    _piles_between_the_bin_counts()
+
+
 def test_fast_kernel_deep_and_interleaved_tiles():
     """A pile deeper than k_pileup_fast's u16 count tables allow (> 32767 candidate runs in one tile: handed to
     k_pileup_stream through the slow-tile list) and one just below the limit, which stays on the fast kernel with depths
