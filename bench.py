@@ -567,14 +567,16 @@ def main():
         # The rubric's roofline: algorithmic bytes of the dominant kernel / its launch duration (HIP events of THIS run) against the HBM peak.
         # k_pileup_fast keeps the depth array in LDS and is not HBM-bound: what bounds it is reported beside the figure as `issue_model`
         # (profiles/r03_valu_mix.json: instruction classes of the kernel's ISA x measured per-class issue cost x SQ_INSTS_VALU / SIMD-cycles).
-        roof = {"bound": "hbm", "kernel": {"k_pileup": "k_pileup_fast"}.get(dom, dom), "achieved": domk.get("hbm_achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": {"k_pileup": "k_pileup_fast7"}.get(dom, dom), "achieved": domk.get("hbm_achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (domk.get("hbm_achieved_GBps") or 0.0) / HBM_PEAK_GBPS, "traffic": domk.get("hbm_traffic_bytes_from_committed_profile"),
                 "traffic_source": "committed rocprofv3 PMC profile (profiles/pmc_traffic.json, %s), not this run" % prof.get("traffic", {}).get("_source"),
-                "note": "k_prep (HBM-streaming) reaches %.3f of the HBM peak, k_pileup_fast (depth array in LDS, not HBM-bound) %.3f; their launch times differ by %.1f %%; "
+                "note": "k_prep (HBM-streaming) reaches %.3f of the HBM peak, k_pileup_fast7 (depth array in LDS, not HBM-bound) %.3f; their launch times differ by %.1f %%; "
                         "see kernels / issue_model" % (per_kernel["k_prep"]["hbm_frac_of_8TBps"], per_kernel["k_pileup"]["hbm_frac_of_8TBps"],
                                                          100.0 * abs(kms["k_prep"] - kms["k_pileup"]) / max(kms["k_prep"], kms["k_pileup"], 1e-9))}
         if prof.get("valu_mix"):
-            roof["issue_model"] = prof["valu_mix"]
+            roof["issue_model"] = dict(prof["valu_mix"], describes="k_pileup_fast<true> as it was when the counters were collected (r03f / r04a): before the window "
+                                       "statistics were read off the LDS histogram (a third fewer VALU instructions, -4.5 %) and before k_pileup_fast7's seventh "
+                                       "wave per SIMD (-9 %); not re-collected since (DESIGN.md section 4)")
         roof["ingest"] = ingest_roofline()
         roof.update({"kernel_ms": kms.get(dom), "all_kernels_ms": kms, "kernels": per_kernel,
                      "pipeline": {"algorithmic_bytes": pipe_bytes, "kernels_ms": pipe_ms, "achieved_GBps": pipe_bytes / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0,

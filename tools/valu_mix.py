@@ -1,6 +1,6 @@
 """VALU instruction mix of a kernel and the issue-cycle fraction that follows from it.
 
-    python tools/valu_mix.py --kernel k_pileup_fastILb1 [--asm /tmp/cov.s] [--rates profiles/r03_valu_rate.json]
+    python tools/valu_mix.py --kernel k_pileup_fast7ILb1 [--asm /tmp/cov.s] [--rates profiles/r03_valu_rate.json]
                              [--pmc profiles/pmc_pipes.json --pmc-key k_pileup] [--weights loop|flat|<json>] [--json out.json]
 
 What it does, in the order a reader who does not trust any issue-rate assumption would redo it:
@@ -121,7 +121,7 @@ def blocks(body):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", required=True, help="regex on the mangled name, e.g. k_pileup_fastILb1")
+    ap.add_argument("--kernel", required=True, help="regex on the mangled name, e.g. k_pileup_fast7ILb1")
     ap.add_argument("--asm", default=None)
     ap.add_argument("--rates", default=os.path.join(ROOT, "profiles", "r03_valu_rate.json"))
     ap.add_argument("--weights", default="loop")
