@@ -74,6 +74,18 @@ def test_device_ingest_equals_cpu_reader(tmp_path, monkeypatch, with_seq, piece_
     np.testing.assert_array_equal(w.records.pos, b.pos)
 
 
+def test_extraction_with_a_lane_per_segment(tmp_path, monkeypatch):
+    """COVERM_EXT_PARTS=1: k_bam_extract walks a segment's whole chain with one lane (the default gives every quarter of it, cut where
+    k_bam_hop says, to a lane of its own).  Kept for measurements (profiles/r04_extract_parts_ab_200M.log); same records either way."""
+    monkeypatch.setenv("COVERM_EXT_PARTS", "1")
+    ref = synth.make_reference(40, 6_000_000, seed=18, min_len=5000, max_len=800_000)
+    b = synth.make_reads(ref, 120_000, seed=19)
+    p = str(tmp_path / "s.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=2, threads=4)
+    w = _check(p)
+    np.testing.assert_array_equal(w.records.pos, b.pos)
+
+
 @pytest.mark.parametrize("level,block", [(0, 0xFF00), (9, 0xFF00), (6, 700), (1, 90)])
 def test_device_inflate_block_types(tmp_path, level, block):
     """Stored blocks (level 0), long-match streams (level 9), and tiny BGZF blocks, which zlib emits with FIXED Huffman codes."""
