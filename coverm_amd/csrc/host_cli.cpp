@@ -27,6 +27,7 @@
 #include <map>
 #include <mutex>
 #include <stdexcept>
+#include <cerrno>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -41,9 +42,25 @@ std::atomic<bool> g_skip_teardown{false};   // covh_cli_set_fast_exit: a process
 struct Fatal : std::runtime_error { using std::runtime_error::runtime_error; };
 [[noreturn]] void die(const std::string &m) { throw Fatal(m); }
 
-float parse_percentage(const char *v) {   // coverm.rs:1296-1312
+// clap's typed value parsers (u8 / u16 / u32 / u64 / f32 arguments of coverm.rs / cli.rs): a value that is not a number of the argument's
+// type ends the run, it is not read as 0
+uint64_t parse_uint(const std::string &opt, const char *v, uint64_t max) {
+    char *end = nullptr;
+    errno = 0;
+    const unsigned long long x = (v && *v >= '0' && *v <= '9') ? strtoull(v, &end, 10) : 0ull;
+    if (!end || *end || errno || x > max) die(std::string("invalid value '") + (v ? v : "") + "' for '" + opt + "'");
+    return x;
+}
+float parse_f32(const std::string &opt, const char *v) {
+    char *end = nullptr;
+    const float x = (v && *v) ? strtof(v, &end) : 0.0f;
+    if (!end || *end || end == v) die(std::string("invalid value '") + (v ? v : "") + "' for '" + opt + "'");
+    return x;
+}
+
+float parse_percentage(const char *v, const char *opt = "percentage") {   // coverm.rs:1296-1312
     if (!v) return 0.0f;
-    float p = strtof(v, nullptr);
+    float p = parse_f32(opt, v);
     if (p >= 1.0f && p <= 100.0f) p /= 100.0f;
     else if (!(p >= 0.0f && p <= 100.0f)) die(std::string("Invalid alignment percentage: '") + v + "'");
     return p;
@@ -382,21 +399,22 @@ int run_filter(int argc, char **argv) {
         else if (k == "--proper-pairs-only") proper_pairs_only = true;
         else if (k == "--exclude-supplementary") exclude_supplementary = true;
         else if (k == "--include-secondary") include_secondary = true;
-        else if (k == "--min-read-aligned-length") f.len_single = (uint32_t)strtoul(val(), nullptr, 10);
+        else if (k == "--min-read-aligned-length") f.len_single = (uint32_t)parse_uint(k, val(), 0xffffffffull);
         else if (k == "--min-read-percent-identity") pid = val();
         else if (k == "--min-read-aligned-percent") pct = val();
-        else if (k == "--min-read-aligned-length-pair") f.len_pair = (uint32_t)strtoul(val(), nullptr, 10);
+        else if (k == "--min-read-aligned-length-pair") f.len_pair = (uint32_t)parse_uint(k, val(), 0xffffffffull);
         else if (k == "--min-read-percent-identity-pair") pid_pair = val();
         else if (k == "--min-read-aligned-percent-pair") pct_pair = val();
-        else if (k == "--min-mapq") f.mapq = atoi(val());
-        else if (k == "-t" || k == "--threads") threads = atoi(val());
+        else if (k == "--min-mapq") f.mapq = (int)parse_uint(k, val(), 255);
+        else if (k == "-t" || k == "--threads") threads = (int)parse_uint(k, val(), 65535);
         else if (k == "-v" || k == "--verbose" || k == "-q" || k == "--quiet") {}
         else die("unknown argument " + k);
     }
     if (in.empty()) die("--bam-files is required");
     if (in.size() != out.size()) die("The number of input BAM files must be the same as the number output");     // coverm.rs:422-425
     f.improper = !proper_pairs_only; f.supp = !exclude_supplementary; f.sec = include_secondary;
-    f.pid_single = parse_percentage(pid); f.pct_single = parse_percentage(pct); f.pid_pair = parse_percentage(pid_pair); f.pct_pair = parse_percentage(pct_pair);
+    f.pid_single = parse_percentage(pid, "--min-read-percent-identity"); f.pct_single = parse_percentage(pct, "--min-read-aligned-percent");
+    f.pid_pair = parse_percentage(pid_pair, "--min-read-percent-identity-pair"); f.pct_pair = parse_percentage(pct_pair, "--min-read-aligned-percent-pair");
     bool fs = false, fp = false;
     f.mode(fs, fp);
     covh_pair_filter pf; memset(&pf, 0, sizeof pf);
@@ -433,7 +451,7 @@ int run_cli(int argc, char **argv) {
         if (k == "-b" || k == "--bam-files") collect(i, a.bams);
         else if (k == "-m" || k == "--methods") collect(i, a.methods);
         else if (k == "--min-covered-fraction") a.min_covered_fraction = val();
-        else if (k == "--contig-end-exclusion") a.contig_end_exclusion = strtoull(val(), nullptr, 10);
+        else if (k == "--contig-end-exclusion") a.contig_end_exclusion = parse_uint(k, val(), ~0ull);
         else if (k == "--trim-min") a.trim_min = val();
         else if (k == "--trim-max") a.trim_max = val();
         else if (k == "--output-format") a.output_format = val();
@@ -442,20 +460,20 @@ int run_cli(int argc, char **argv) {
         else if (k == "--proper-pairs-only") a.proper_pairs_only = true;
         else if (k == "--exclude-supplementary") a.exclude_supplementary = true;
         else if (k == "--include-secondary") a.include_secondary = true;
-        else if (k == "--min-read-aligned-length") a.min_aligned_length = (uint32_t)strtoul(val(), nullptr, 10);
+        else if (k == "--min-read-aligned-length") a.min_aligned_length = (uint32_t)parse_uint(k, val(), 0xffffffffull);
         else if (k == "--min-read-percent-identity") a.min_pid = val();
         else if (k == "--min-read-aligned-percent") a.min_aligned_pct = val();
-        else if (k == "--min-read-aligned-length-pair") a.min_aligned_length_pair = (uint32_t)strtoul(val(), nullptr, 10);
+        else if (k == "--min-read-aligned-length-pair") a.min_aligned_length_pair = (uint32_t)parse_uint(k, val(), 0xffffffffull);
         else if (k == "--min-read-percent-identity-pair") a.min_pid_pair = val();
         else if (k == "--min-read-aligned-percent-pair") a.min_aligned_pct_pair = val();
-        else if (k == "--min-mapq") a.min_mapq = atoi(val());
+        else if (k == "--min-mapq") a.min_mapq = (int)parse_uint(k, val(), 255);
         else if (k == "-s" || k == "--separator") { a.separator = val()[0]; a.have_separator = true; }
         else if (k == "--single-genome") a.single_genome = true;
         else if (k == "--genome-definition") a.genome_definition = val();
         else if (k == "--gff") a.gff = val();
         else if (k == "--gff-feature-type") { a.gff_feature_type = val(); a.have_gff_feature_type = true; }
-        else if (k == "-t" || k == "--threads") a.threads = atoi(val());
-        else if (k == "--device") { a.devices.assign(1, atoi(val())); }
+        else if (k == "-t" || k == "--threads") a.threads = (int)parse_uint(k, val(), 65535);
+        else if (k == "--device") { a.devices.assign(1, (int)parse_uint(k, val(), 1023)); }
         else if (k == "--devices") {   // 0,1,2 or 0-7
             a.devices.clear();
             std::string v = val();
@@ -482,7 +500,7 @@ int run_cli(int argc, char **argv) {
     if (!a.min_covered_fraction) a.min_covered_fraction = contig ? "0" : "10";            // cli.rs:2528, 2065
 
     // ---- EstimatorsAndTaker::generate_from_clap
-    const float mcf = parse_percentage(a.min_covered_fraction);
+    const float mcf = parse_percentage(a.min_covered_fraction, "--min-covered-fraction");
     const uint64_t excl = a.contig_end_exclusion;
     std::vector<covh_estimator> &est = R.est;
     std::vector<int64_t> norm;
@@ -494,9 +512,9 @@ int run_cli(int argc, char **argv) {
     };
     Filter &f = R.f;
     f.improper = !a.proper_pairs_only; f.supp = !a.exclude_supplementary; f.sec = a.include_secondary;
-    f.len_single = a.min_aligned_length; f.pid_single = parse_percentage(a.min_pid); f.pct_single = parse_percentage(a.min_aligned_pct);
-    f.mapq = a.min_mapq; f.len_pair = a.min_aligned_length_pair; f.pid_pair = parse_percentage(a.min_pid_pair);
-    f.pct_pair = parse_percentage(a.min_aligned_pct_pair);
+    f.len_single = a.min_aligned_length; f.pid_single = parse_percentage(a.min_pid, "--min-read-percent-identity"); f.pct_single = parse_percentage(a.min_aligned_pct, "--min-read-aligned-percent");
+    f.mapq = a.min_mapq; f.len_pair = a.min_aligned_length_pair; f.pid_pair = parse_percentage(a.min_pid_pair, "--min-read-percent-identity-pair");
+    f.pct_pair = parse_percentage(a.min_aligned_pct_pair, "--min-read-aligned-percent-pair");
     const bool metabat = a.methods.size() == 1 && a.methods[0] == "metabat";
     for (auto &m : a.methods) if (m == "metabat" && a.methods.size() > 1) die("Cannot specify the metabat method with any other coverage methods");
     if (metabat) {
@@ -508,7 +526,7 @@ int run_cli(int argc, char **argv) {
             const std::string &m = a.methods[i];
             if (m == "mean") E(COVH_MEAN, mcf, excl);
             else if (m == "coverage_histogram") E(COVH_PILEUP_COUNTS, mcf, excl);
-            else if (m == "trimmed_mean") E(COVH_TRIMMED_MEAN, mcf, excl, parse_percentage(a.trim_min), parse_percentage(a.trim_max));
+            else if (m == "trimmed_mean") E(COVH_TRIMMED_MEAN, mcf, excl, parse_percentage(a.trim_min, "--trim-min"), parse_percentage(a.trim_max, "--trim-max"));
             else if (m == "covered_fraction") E(COVH_COVERED_FRACTION, mcf, 0);
             else if (m == "covered_bases") E(COVH_COVERED_BASES, mcf, 0);
             else if (m == "rpkm") { if (rpkm >= 0) die("The RPKM column cannot be specified more than once"); rpkm = (int64_t)i; E(COVH_RPKM, mcf, 0); }

@@ -122,3 +122,17 @@ def test_filter_without_thresholds_and_its_errors(tmp_path):
     assert r.returncode != 0 and "The number of input BAM files must be the same as the number output" in r.stderr
     r = subprocess.run([BIN, "filter", "-b", str(tmp_path / "nope.bam"), "-o", out], capture_output=True, text=True)
     assert r.returncode != 0 and "Unable to find BAM file" in r.stderr
+
+
+@pytest.mark.parametrize("opt,val", [("--min-mapq", "abc"), ("--min-mapq", "300"), ("--min-mapq", "-1"), ("--min-read-aligned-length", "12x"),
+                                     ("--min-read-percent-identity", "abc"), ("--min-read-aligned-percent-pair", ""), ("--threads", "1.5")])
+def test_numbers_that_are_not_numbers_end_the_run(tmp_path, opt, val):
+    """clap's typed value parsers (cli.rs: u8 / u16 / u32 / f32 arguments) refuse such values; they are not read as 0."""
+    src = os.path.join(RAW, "2seqs.bad_read.1.bam")
+    if not os.path.exists(src):
+        pytest.skip("raw fixture not present")
+    out = str(tmp_path / "o.bam")
+    r = subprocess.run([BIN, "filter", "-b", src, "-o", out, opt, val], capture_output=True, text=True)
+    assert r.returncode != 0 and "invalid value '%s' for '%s'" % (val, opt) in r.stderr and not os.path.exists(out)
+    r = subprocess.run([BIN, "contig", "-b", src, "-m", "mean", opt, val], capture_output=True, text=True)
+    assert r.returncode != 0 and "invalid value '%s' for '%s'" % (val, opt) in r.stderr
