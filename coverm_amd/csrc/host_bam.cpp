@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <unordered_map>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -36,6 +37,7 @@
 #include <vector>
 
 #include "../../include/coverm_host.h"
+#include "reader_filter.h"
 
 namespace {
 
@@ -90,8 +92,6 @@ struct Bam {
     std::string qnames;
     int threads = 1;
     bool want_names = false;
-    bool keep_offsets = false;                 // `coverm filter`: where every record begins in the inflated stream, and where the first one does
-    std::vector<size_t> rec_off; size_t first_record = 0;
 };
 
 inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
@@ -280,6 +280,17 @@ const LibDeflate &libdeflate() { static LibDeflate L; return L; }
 struct TlsDecompressor {
     void *d = nullptr;
     ~TlsDecompressor() { if (d) libdeflate().release(d); }
+};
+// one compressor per thread and level, given back when the thread ends (the writers' loops run on short-lived threads)
+struct TlsCompressor {
+    void *c = nullptr; int level = -1;
+    void *get(int lv) {
+        const LibDeflate &L = libdeflate();
+        if (!L.ok_c) return nullptr;
+        if (!c || level != lv) { if (c) L.release_c(c); c = L.alloc_c(std::max(1, std::min(12, lv))); level = lv; }
+        return c;
+    }
+    ~TlsCompressor() { if (c) libdeflate().release_c(c); }
 };
 
 // ---- BGZF: block table, parallel inflate
@@ -644,7 +655,6 @@ bool parse_bam(Bam &b, const Buf &u) {
         b.err = "truncated BAM record"; return false;
     }
     const size_t R = rec.size();
-    if (b.keep_offsets) { b.first_record = p; b.rec_off.resize(R); for (size_t i = 0; i < R; i++) b.rec_off[i] = rec[i]; }
     b.cigar_off.resize(R + 1);
     if (b.want_names) b.qname_off.resize(R + 1);
     auto ensure = [&](uint64_t ncig, uint64_t nq) { b.cigar.resize(ncig); if (b.want_names) b.qnames.resize(nq); return true; };
@@ -1668,8 +1678,8 @@ int covh_bam_write(const char *path, uint32_t n_targets, const char *const *name
             o.resize(n + n / 8 + 256);
             size_t clen = 0;
             if (LD.ok_c) {
-                thread_local void *cmp = nullptr; thread_local int cmp_level = -1;
-                if (!cmp || cmp_level != level) { if (cmp) LD.release_c(cmp); cmp = LD.alloc_c(std::max(1, std::min(12, level))); cmp_level = level; }
+                thread_local TlsCompressor tc;
+                void *cmp = tc.get(level);
                 clen = cmp ? LD.compress(cmp, &raw[s0], n, o.data() + 18, o.size() - 26) : 0;
             }
             if (clen == 0) {
@@ -1777,82 +1787,221 @@ int covh_bam_write(const char *path, uint32_t n_targets, const char *const *name
 
 namespace {
 
-// `n` bytes as BGZF blocks of 0xff00 bytes (what htslib writes) + the EOF marker, compressed by `threads` threads.
-bool bgzf_write_all(FILE *f, const uint8_t *data, size_t n, int level, int threads) {
-    const size_t BLK = 0xff00, nblk = (n + BLK - 1) / BLK;
-    const size_t WAVE = 4096;                       // blocks compressed before they are written: bounds the memory
-    std::vector<std::vector<uint8_t>> comp(std::min(nblk, WAVE));
-    std::atomic<bool> ok{true};
-    for (size_t b0 = 0; b0 < nblk; b0 += WAVE) {
-        const size_t nb = std::min(WAVE, nblk - b0);
-        parallel_for(nb, threads, [&](size_t k) {
-            const size_t s0 = (b0 + k) * BLK, len = std::min(BLK, n - s0);
-            std::vector<uint8_t> &o = comp[k];
+// A BGZF stream written as it grows: blocks of 0xff00 bytes (what htslib writes), compressed by `threads` threads whenever 1024 of them are
+// full, the last (short) block and the EOF marker at close().  libdeflate when the runtime has it (2-3 x zlib at the same level), as in
+// the synthetic writer above.
+class BgzfOut {
+    FILE *f_; const int level_, threads_;
+    std::vector<uint8_t> pend_;
+    std::vector<std::vector<uint8_t>> comp_;
+    static constexpr size_t BLK = 0xff00, FLUSH_BLOCKS = 1024;
+    bool flush(bool all) {
+        const size_t nblk = all ? (pend_.size() + BLK - 1) / BLK : pend_.size() / BLK;
+        if (!nblk) return true;
+        if (comp_.size() < nblk) comp_.resize(nblk);
+        std::atomic<bool> ok{true};
+        const LibDeflate &LD = libdeflate();
+        const uint8_t *data = pend_.data(); const size_t n = pend_.size(); const int level = level_;
+        parallel_for(nblk, threads_, [&](size_t k) {
+            const size_t s0 = k * BLK, len = std::min(BLK, n - s0);
+            std::vector<uint8_t> &o = comp_[k];
             o.resize(len + len / 8 + 256);
-            z_stream zs; memset(&zs, 0, sizeof zs);
-            if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok = false; return; }
-            zs.next_in = const_cast<uint8_t *>(data + s0); zs.avail_in = (uInt)len; zs.next_out = o.data() + 18; zs.avail_out = (uInt)(o.size() - 26);
-            if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { ok = false; deflateEnd(&zs); return; }
-            const size_t clen = zs.total_out;
-            deflateEnd(&zs);
+            size_t clen = 0;
+            if (LD.ok_c) {
+                thread_local TlsCompressor tc;
+                void *cmp = tc.get(level);
+                clen = cmp ? LD.compress(cmp, data + s0, len, o.data() + 18, o.size() - 26) : 0;
+            }
+            if (clen == 0) {
+                z_stream zs; memset(&zs, 0, sizeof zs);
+                if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok = false; return; }
+                zs.next_in = const_cast<uint8_t *>(data + s0); zs.avail_in = (uInt)len; zs.next_out = o.data() + 18; zs.avail_out = (uInt)(o.size() - 26);
+                if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { ok = false; deflateEnd(&zs); return; }
+                clen = zs.total_out;
+                deflateEnd(&zs);
+            }
             static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
             memcpy(o.data(), hdr, 16);
             const uint16_t bsz = (uint16_t)(clen + 25);
             memcpy(o.data() + 16, &bsz, 2);
-            const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + s0, (uInt)len), isz = (uint32_t)len;
+            const uint32_t crc = LD.ok ? LD.crc32(0, data + s0, len) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + s0, (uInt)len), isz = (uint32_t)len;
             memcpy(o.data() + 18 + clen, &crc, 4); memcpy(o.data() + 22 + clen, &isz, 4);
             o.resize(clen + 26);
         });
         if (!ok) return false;
-        for (size_t k = 0; k < nb; k++) if (fwrite(comp[k].data(), 1, comp[k].size(), f) != comp[k].size()) return false;
+        for (size_t k = 0; k < nblk; k++) if (fwrite(comp_[k].data(), 1, comp_[k].size(), f_) != comp_[k].size()) return false;
+        pend_.erase(pend_.begin(), pend_.begin() + (ptrdiff_t)std::min(pend_.size(), nblk * BLK));
+        return true;
     }
-    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    return fwrite(eof, 1, 28, f) == 28;
-}
+public:
+    BgzfOut(FILE *f, int level, int threads) : f_(f), level_(level), threads_(std::max(1, threads)) {}
+    bool put(const uint8_t *p, size_t n) {
+        pend_.insert(pend_.end(), p, p + n);
+        return pend_.size() < FLUSH_BLOCKS * BLK || flush(false);
+    }
+    bool close() {
+        if (!flush(true)) return false;
+        static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        return fwrite(eof, 1, 28, f_) == 28;
+    }
+};
 
 }  // namespace
 
 extern "C" {
 
-// `coverm filter` (bin/coverm.rs:408-472): bam::Reader -> ReferenceSortedBamFilter -> bam::Writer under the reader's header.  Here: the
-// file inflated on `threads` threads, its records located and their filter fields extracted (the whole-file reader's own passes), the
-// reader filter's selection (covh_reader_filter_order), and the selected records copied byte for byte behind the input's header bytes.
+// `coverm filter` (bin/coverm.rs:408-472): bam::Reader -> ReferenceSortedBamFilter -> bam::Writer under the reader's header, a record at a
+// time.  Here the file goes through in WINDOWS of 64 MiB of BGZF blocks: inflated on `threads` threads behind the cut-off record of the
+// window before, the records' filter fields summarised on `threads` threads, the selection by the reference's own state machine
+// (csrc/reader_filter.h) in file order, the selected records appended byte for byte (names, bases, qualities, tags) to the output
+// stream behind the input's header bytes.  Memory: one window, the output blocks in flight, and — in the pair branch — a copy of every
+// first mate that is still waiting for its second (what the reference's first_set holds).
 int covh_bam_filter_file(const char *in_path, const char *out_path, const covh_pair_filter *f, int filter_pairs, int include_supplementary,
                          int include_secondary, int filter_out, int level, int threads, uint64_t *n_in, uint64_t *n_out, char *err, size_t errcap) {
     auto fail = [&](const std::string &e) { if (err && errcap) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; } return -1; };
     if (!in_path || !out_path || !f) return fail("covh_bam_filter_file: invalid argument");
     if (n_in) *n_in = 0;
     if (n_out) *n_out = 0;
-    Bam b; b.path = in_path; b.threads = std::max(1, threads); b.want_names = true; b.keep_offsets = true;
-    Buf raw, u;
-    if (!read_file(in_path, raw, b.err)) return fail(std::string("Unable to find BAM file ") + in_path);
-    if (raw.size() < 2 || raw[0] != 0x1f || raw[1] != 0x8b) return fail(std::string(in_path) + ": `filter` reads BAM files");
-    if (!bgzf_inflate_all(raw, u, b.threads, b.err)) return fail(b.err);
-    raw.alloc(0);
-    if (!parse_bam(b, u)) return fail(b.err);
-    const uint64_t R = b.tid.size();
-    cov_batch cb; memset(&cb, 0, sizeof cb);
-    cb.tid = b.tid.data(); cb.pos = b.pos.data(); cb.flag = b.flag.data(); cb.mapq = b.mapq.data(); cb.nm = b.nm.data(); cb.nm_kind = b.nm_kind.data();
-    cb.l_seq = b.l_seq.data(); cb.cigar_off = b.cigar_off.data(); cb.cigar = b.cigar.data(); cb.n_records = R;
-    uint64_t *order = nullptr, n_sel = 0;
-    const int rc = covh_reader_filter_order(&cb, b.mtid.data(), b.qname_off.data(), b.qnames.data(), f, filter_pairs, include_supplementary, include_secondary,
-                                            filter_out, &order, &n_sel);
-    if (rc == COV_ERR_NM_MISSING) return fail("Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM format");
-    if (rc == COV_ERR_NM_BADTYPE) return fail("Unexpected data type of NM aux tag");
-    if (rc != COV_OK) return fail("covh_reader_filter_order failed");
-    struct FreeOrd { uint64_t *p; ~FreeOrd() { free(p); } } free_ord{order};
-    // header bytes as they are, then the selected records as they are
-    std::vector<size_t> at(n_sel + 1, 0);
-    for (uint64_t j = 0; j < n_sel; j++) at[j + 1] = at[j] + 4 + (size_t)rd32(u.data() + b.rec_off[order[j]]);
-    Buf outb; outb.alloc(b.first_record + at[n_sel]);
-    memcpy(outb.p, u.data(), b.first_record);
-    parallel_for((size_t)n_sel, b.threads, [&](size_t j) { memcpy(outb.p + b.first_record + at[j], u.data() + b.rec_off[order[j]], at[j + 1] - at[j]); });
-    FILE *fo = fopen(out_path, "wb");
-    if (!fo) return fail(std::string("Failed to write BAM file ") + out_path);
-    const bool ok = bgzf_write_all(fo, outb.p, outb.size(), level, b.threads);
-    const bool werr = ferror(fo) != 0;
-    if (fclose(fo) != 0 || werr || !ok) return fail(std::string("Failed to write BAM file ") + out_path);
-    if (n_in) *n_in = R;
+    const int T = std::max(1, threads);
+    const bool timing = getenv("COVERM_CLI_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now(), t_part[5] = {0, 0, 0, 0, 0};
+    auto stamp = [&](int k) { const double t = now(); t_part[k] += t - t_prev; t_prev = t; };
+    struct File { FILE *f = nullptr; ~File() { if (f) fclose(f); } } fi, fo;
+    fi.f = fopen(in_path, "rb");
+    if (!fi.f) return fail(std::string("Unable to find BAM file ") + in_path);
+    size_t CHUNK = (size_t)64 << 20;
+    if (const char *e = getenv("COVERM_FILTER_WINDOW_KB")) { const long v = atol(e); if (v >= 1) CHUNK = (size_t)v << 10; }      // tests: many small windows
+    std::vector<uint8_t> cbuf, u;       // compressed bytes not yet inflated; inflated bytes not yet consumed (a cut-off record in front)
+    size_t carry = 0;
+    bool eof = false, first_read = true, header_done = false;
+    std::vector<std::string> names; std::vector<uint64_t> lens; std::string header_text, e2;
+    std::unique_ptr<BgzfOut> W;
+    covf::ReaderFilter M(*f, filter_pairs != 0, include_supplementary != 0, include_secondary != 0, filter_out != 0);
+    std::unordered_map<uint64_t, std::vector<uint8_t>> parked;      // first mates waiting for their second, by the id the machine knows them by
+    uint64_t next_id = 0, n_rec = 0, n_sel = 0;
+    std::vector<Blk> blocks;
+    std::vector<size_t> rec;
+    std::vector<covf::RecSum> sums;
+    while (!eof || !cbuf.empty()) {
+        if (!eof) {
+            const size_t old = cbuf.size();
+            cbuf.resize(old + CHUNK);
+            const size_t got = fread(cbuf.data() + old, 1, CHUNK, fi.f);
+            cbuf.resize(old + got);
+            if (got < CHUNK) { if (ferror(fi.f)) return fail(std::string("short read on ") + in_path); eof = true; }
+        }
+        if (first_read) {
+            first_read = false;
+            if (cbuf.size() < 2 || cbuf[0] != 0x1f || cbuf[1] != 0x8b) return fail(std::string(in_path) + ": `filter` reads BAM files");
+        }
+        stamp(0);
+        blocks.clear();
+        size_t p = 0, total = 0;
+        if (!bgzf_block_table(cbuf.data(), cbuf.size(), p, blocks, total, !eof, e2)) return fail(e2);
+        u.resize(carry + total);
+        {
+            std::atomic<bool> ok{true};
+            uint8_t *dst = u.data() + carry; const uint8_t *src = cbuf.data();
+            parallel_for(blocks.size(), T, [&](size_t i) { if (!inflate_block(src, blocks[i], dst + blocks[i].out_off)) ok = false; });
+            if (!ok) return fail("BGZF inflate / CRC failure");
+        }
+        cbuf.erase(cbuf.begin(), cbuf.begin() + (ptrdiff_t)p);
+        stamp(1);
+        const size_t N = u.size();
+        size_t q = 0;
+        if (!header_done) {
+            const int hrc = parse_bam_header(u.data(), N, q, names, lens, header_text, e2);
+            if (hrc < 0) return fail(e2);
+            if (hrc == 0) {
+                if (eof && cbuf.empty()) return fail(N < 12 ? "bad BAM magic" : "truncated BAM header");
+                carry = N;
+                continue;
+            }
+            header_done = true;
+            fo.f = fopen(out_path, "wb");
+            if (!fo.f) return fail(std::string("Failed to write BAM file ") + out_path);
+            W.reset(new BgzfOut(fo.f, level, T));
+            if (!W->put(u.data(), q)) return fail(std::string("Failed to write BAM file ") + out_path);       // the header bytes as they are
+        }
+        // where the records of this window begin; the last one may be cut off by the window's end
+        rec.clear();
+        while (q + 4 <= N) {
+            const uint32_t bs = rd32(u.data() + q);
+            if (bs < 32) return fail("corrupt BAM record");
+            if (q + 4 + (size_t)bs > N) break;
+            rec.push_back(q);
+            q += 4 + (size_t)bs;
+        }
+        const size_t R = rec.size();
+        sums.resize(R);
+        {
+            std::atomic<bool> ok{true};
+            const uint8_t *ub = u.data();
+            parallel_for((R + 4095) / 4096, T, [&](size_t blk) {
+                for (size_t i = blk * 4096, hi = std::min(R, i + 4096); i < hi; i++) {
+                    const uint8_t *r = ub + rec[i], *end = r + 4 + rd32(r);
+                    const uint32_t l_read_name = r[12], n_cig = rd16(r + 16), l_seq = rd32(r + 20);
+                    const uint8_t *cg0 = r + 36 + l_read_name;
+                    if (cg0 + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq > end) { ok = false; return; }
+                    covf::RecSum &s = sums[i];
+                    s.tid = (int32_t)rd32(r + 4); s.mtid = (int32_t)rd32(r + 24); s.flag = rd16(r + 18); s.mapq = r[13]; s.l_seq = l_seq;
+                    s.nm = 0;
+                    s.nm_kind = scan_aux(cg0 + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq, end, s.nm, nullptr, nullptr);
+                    const uint8_t *cig = cg0; uint32_t nc = n_cig, cnt = 0;
+                    if (maybe_long_cigar(r)) if (const uint8_t *cg = real_cigar_from_cg(r, end, cnt)) { cig = cg; nc = cnt; }      // what record.cigar() returns
+                    uint32_t a = 0, d = 0;
+                    for (uint32_t c = 0; c < nc; c++) {
+                        const uint32_t w = rd32(cig + 4ull * c), op = w & 15u, len = w >> 4;
+                        if (op == 0 || op == 1 || op == 7 || op == 8) a += len;
+                        else if (op == 2) d += len;
+                    }
+                    s.aligned_no_del = a; s.aligned_with_del = a + d;
+                }
+            });
+            if (!ok) return fail("corrupt BAM record");
+        }
+        stamp(2);
+        for (size_t i = 0; i < R; i++) {
+            const uint8_t *r = u.data() + rec[i];
+            const size_t len = 4 + (size_t)rd32(r);
+            const uint32_t l_read_name = r[12];
+            uint64_t partner = 0; bool forget = false;
+            const covf::ReaderFilter::Act act = M.push(sums[i], (const char *)r + 36, l_read_name ? l_read_name - 1u : 0u, next_id, &partner, &forget);
+            if (M.err == COV_ERR_NM_MISSING) return fail("Mapping record encountered that does not have an 'NM' auxiliary tag in the SAM/BAM format");
+            if (M.err) return fail("Unexpected data type of NM aux tag");
+            if (forget) parked.clear();
+            bool okw = true;
+            switch (act) {
+            case covf::ReaderFilter::EMIT: okw = W->put(r, len); n_sel++; break;
+            case covf::ReaderFilter::PARK: parked.emplace(next_id++, std::vector<uint8_t>(r, r + len)); break;
+            case covf::ReaderFilter::EMIT_PAIR: {
+                auto it = parked.find(partner);
+                if (it == parked.end()) return fail("covh_bam_filter_file: a parked record is missing");
+                okw = W->put(it->second.data(), it->second.size()) && W->put(r, len);
+                parked.erase(it); n_sel += 2;
+                break;
+            }
+            case covf::ReaderFilter::DROP_PAIR: parked.erase(partner); break;
+            case covf::ReaderFilter::DROP: break;
+            }
+            if (!okw) return fail(std::string("Failed to write BAM file ") + out_path);
+        }
+        n_rec += R;
+        stamp(3);
+        carry = N - q;
+        if (carry && q) memmove(u.data(), u.data() + q, carry);
+    }
+    if (!header_done) return fail("truncated BAM header");
+    if (carry) return fail("truncated BAM record");
+    const bool okc = W->close();
+    const bool werr = ferror(fo.f) != 0;
+    const int crc = fclose(fo.f); fo.f = nullptr;
+    if (crc != 0 || werr || !okc) return fail(std::string("Failed to write BAM file ") + out_path);
+    stamp(4);
+    if (timing) fprintf(stderr, "[coverm-amd] filter %s: file read %.3fs, inflate %.3fs, records %.3fs, reader filter + deflate + write %.3fs, close %.3fs\n", in_path,
+                        t_part[0], t_part[1], t_part[2], t_part[3], t_part[4]);
+    if (n_in) *n_in = n_rec;
     if (n_out) *n_out = n_sel;
     return 0;
 }

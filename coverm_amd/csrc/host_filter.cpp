@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/coverm_host.h"
+#include "reader_filter.h"
 
 namespace {
 
@@ -183,38 +184,17 @@ int covh_reader_filter_order(const cov_batch *b, const int32_t *mtid, const uint
     if (!b || !f || !order_out || !n_out || (b->n_records && (!mtid || !qname_off || !qnames))) return COV_ERR_INVALID_ARG;
     *order_out = nullptr; *n_out = 0;
     const uint64_t R = b->n_records;
-    const bool out = filter_out != 0;
-    Judge J{*b, *f};
+    covf::ReaderFilter M(*f, filter_pairs != 0, include_supplementary != 0, include_secondary != 0, filter_out != 0);
     std::vector<uint64_t> ord;
-    if (f->filter_single && !filter_pairs) {
-        for (uint64_t i = 0; i < R; i++) {
-            const uint16_t flag = b->flag[i];
-            const bool unmapped = flag & 0x4, supp = flag & 0x800, sec = flag & 0x100;
-            if (unmapped && !out) { ord.push_back(i); continue; }
-            const bool p1 = !unmapped && (include_supplementary || !supp) && (include_secondary || !sec);
-            if (p1 && J.single_ok(i) == out) ord.push_back(i);
-            if (J.err) return J.err;
-        }
-    } else {
-        int32_t cur = -1;            // current_reference starts at -1 (filter.rs:76)
-        std::unordered_map<std::string, uint64_t> first;      // first_set: the parked records of the current reference by name
-        for (uint64_t i = 0; i < R; i++) {
-            const uint16_t flag = b->flag[i];
-            if ((flag & 0x4) && !out) { ord.push_back(i); continue; }
-            if (flag & 0x900) continue;
-            if (!(flag & 0x2)) { if (!out) ord.push_back(i); continue; }
-            if (b->tid[i] != cur) { cur = b->tid[i]; first.clear(); }
-            const std::string q(qnames + qname_off[i], qname_off[i + 1] - qname_off[i]);
-            auto it = first.find(q);
-            if (it == first.end()) { if (mtid[i] == cur) first.emplace(q, i); }
-            else {
-                const uint64_t i1 = it->second;
-                first.erase(it);
-                const bool pass = (!f->filter_single || (J.single_ok(i1) && J.single_ok(i))) && J.pair_ok(i, i1);
-                if (J.err) return J.err;
-                if (pass == out) { ord.push_back(i1); ord.push_back(i); }
-            }
-        }
+    for (uint64_t i = 0; i < R; i++) {
+        covf::RecSum r;
+        r.tid = b->tid[i]; r.mtid = mtid[i]; r.flag = b->flag[i]; r.mapq = b->mapq[i]; r.nm_kind = b->nm_kind[i]; r.nm = b->nm[i]; r.l_seq = b->l_seq[i];
+        covf::aligned_lengths(b->cigar + b->cigar_off[i], b->cigar_off[i + 1] - b->cigar_off[i], r.aligned_with_del, r.aligned_no_del);
+        uint64_t partner = 0; bool forget = false;
+        const covf::ReaderFilter::Act act = M.push(r, qnames + qname_off[i], qname_off[i + 1] - qname_off[i], i, &partner, &forget);
+        if (M.err) return M.err;
+        if (act == covf::ReaderFilter::EMIT) ord.push_back(i);
+        else if (act == covf::ReaderFilter::EMIT_PAIR) { ord.push_back(partner); ord.push_back(i); }
     }
     uint64_t *o = (uint64_t *)malloc(std::max<size_t>(1, ord.size()) * sizeof(uint64_t));
     if (!o) return COV_ERR_INVALID_ARG;

@@ -1,7 +1,8 @@
 """`coverm-amd filter` (csrc/host_cli.cpp run_filter -> covh_bam_filter_file) against the oracle's restatement of
 ReferenceSortedBamFilter::read (oracle.reader_filter, pinned on filter.rs's own tests in tests/test_oracle_golden.py) on the reference's
 fixture BAMs: the output must hold exactly the records the filter returns, in its order, byte for byte, under the input's header —
-what `coverm filter` does with a bam::Writer (bin/coverm.rs:408-472).  Host code only: runs without a GPU."""
+what `coverm filter` does with a bam::Writer (bin/coverm.rs:408-472).  The file goes through in windows (bounded memory): the output must
+not depend on where they end.  Host code only: runs without a GPU."""
 import os
 import struct
 import subprocess
@@ -136,3 +137,45 @@ def test_numbers_that_are_not_numbers_end_the_run(tmp_path, opt, val):
     assert r.returncode != 0 and "invalid value '%s' for '%s'" % (val, opt) in r.stderr and not os.path.exists(out)
     r = subprocess.run([BIN, "contig", "-b", src, "-m", "mean", opt, val], capture_output=True, text=True)
     assert r.returncode != 0 and "invalid value '%s' for '%s'" % (val, opt) in r.stderr
+
+
+@pytest.mark.parametrize("window_kb", [1, 7, 300])
+def test_output_does_not_depend_on_the_windows(tmp_path, window_kb):
+    """covh_bam_filter_file streams the file in windows of BGZF blocks (64 MiB by default): with windows of 1 / 7 / 300 KiB — the header,
+    most blocks and many records cut by a window's end, first mates parked across dozens of windows — the output file is the same, byte
+    for byte, in the single-read branch, the pair branch and their inverses."""
+    from coverm_amd import bam as cbam, synth
+    ref = synth.make_reference(12, 3_000_000, seed=5, min_len=2000, max_len=900_000)
+    b = synth.make_reads(ref, 40_000, seed=6)
+    src = str(tmp_path / "pairs.bam")
+    cbam.write_bam(src, ref.names, ref.lengths, b, with_seq=3, threads=2)      # records 2k / 2k + 1 on one reference are mates
+    srcs = [src] + [os.path.join(RAW, n) for n in ("2seqs.bad_read.1.bam", "7seqs.reads_for_seq1_and_seq2.bam") if os.path.exists(os.path.join(RAW, n))]
+    modes = [["--min-read-percent-identity", "97", "--min-read-aligned-length", "50"],
+             ["--min-read-percent-identity", "97", "--inverse"],
+             ["--min-read-percent-identity-pair", "97", "--proper-pairs-only"],
+             ["--min-read-aligned-length-pair", "250", "--min-mapq", "20", "--inverse"],
+             []]
+    for si, sp in enumerate(srcs):
+        for mi, mode in enumerate(modes):
+            want, got = str(tmp_path / ("w%d_%d.bam" % (si, mi))), str(tmp_path / ("g%d_%d.bam" % (si, mi)))
+            env = dict(os.environ); env.pop("COVERM_FILTER_WINDOW_KB", None)
+            r = subprocess.run([BIN, "filter", "-b", sp, "-o", want, "-t", "2"] + mode, capture_output=True, text=True, env=env, timeout=120)
+            assert r.returncode == 0, r.stderr[-1000:]
+            r = subprocess.run([BIN, "filter", "-b", sp, "-o", got, "-t", "3"] + mode, capture_output=True, text=True,
+                               env=dict(env, COVERM_FILTER_WINDOW_KB=str(window_kb)), timeout=300)
+            assert r.returncode == 0, r.stderr[-1000:]
+            assert open(got, "rb").read() == open(want, "rb").read(), (sp, mode)
+            if si == 0 and mi == 2:         # and the pair branch really selects pairs here
+                h, recs = inflate_bam(got)
+                assert len(recs) > 1000 and len(recs) % 2 == 0
+
+
+def test_truncated_input_is_an_error_not_a_short_output(tmp_path):
+    src = os.path.join(RAW, "2seqs.bad_read.1.bam")
+    if not os.path.exists(src):
+        pytest.skip("raw fixture not present")
+    raw = open(src, "rb").read()
+    cut = str(tmp_path / "cut.bam")
+    open(cut, "wb").write(raw[:len(raw) * 2 // 3])
+    r = subprocess.run([BIN, "filter", "-b", cut, "-o", str(tmp_path / "o.bam")], capture_output=True, text=True)
+    assert r.returncode != 0 and ("truncated" in r.stderr or "BGZF" in r.stderr)
