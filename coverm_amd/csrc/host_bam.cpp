@@ -1787,21 +1787,24 @@ int covh_bam_write(const char *path, uint32_t n_targets, const char *const *name
 
 namespace {
 
-// A BGZF stream written as it grows: blocks of 0xff00 bytes (what htslib writes), compressed by `threads` threads whenever 1024 of them are
-// full, the last (short) block and the EOF marker at close().  libdeflate when the runtime has it (2-3 x zlib at the same level), as in
-// the synthetic writer above.
+// A BGZF stream written as it grows: blocks of 0xff00 bytes (what htslib writes); whenever 1024 of them are full they are handed to ONE
+// background task that compresses them on `threads` threads and writes them, while the caller goes on filling the next batch (at most
+// one batch is in flight: memory stays at two batches); the last (short) block and the EOF marker at close().  libdeflate when the
+// runtime has it (2-3 x zlib at the same level), as in the synthetic writer above.
 class BgzfOut {
     FILE *f_; const int level_, threads_;
-    std::vector<uint8_t> pend_;
+    std::vector<uint8_t> pend_, busy_;
     std::vector<std::vector<uint8_t>> comp_;
+    std::thread task_;
+    std::atomic<bool> ok_{true};
     static constexpr size_t BLK = 0xff00, FLUSH_BLOCKS = 1024;
-    bool flush(bool all) {
-        const size_t nblk = all ? (pend_.size() + BLK - 1) / BLK : pend_.size() / BLK;
-        if (!nblk) return true;
+    // busy_ (whole blocks, or everything when `all`) -> compressed -> the file
+    void write_busy() {
+        const size_t n = busy_.size(), nblk = (n + BLK - 1) / BLK;
         if (comp_.size() < nblk) comp_.resize(nblk);
-        std::atomic<bool> ok{true};
         const LibDeflate &LD = libdeflate();
-        const uint8_t *data = pend_.data(); const size_t n = pend_.size(); const int level = level_;
+        const uint8_t *data = busy_.data(); const int level = level_;
+        std::atomic<bool> &ok = ok_;
         parallel_for(nblk, threads_, [&](size_t k) {
             const size_t s0 = k * BLK, len = std::min(BLK, n - s0);
             std::vector<uint8_t> &o = comp_[k];
@@ -1828,19 +1831,29 @@ class BgzfOut {
             memcpy(o.data() + 18 + clen, &crc, 4); memcpy(o.data() + 22 + clen, &isz, 4);
             o.resize(clen + 26);
         });
-        if (!ok) return false;
-        for (size_t k = 0; k < nblk; k++) if (fwrite(comp_[k].data(), 1, comp_[k].size(), f_) != comp_[k].size()) return false;
-        pend_.erase(pend_.begin(), pend_.begin() + (ptrdiff_t)std::min(pend_.size(), nblk * BLK));
+        if (!ok_) return;
+        for (size_t k = 0; k < nblk; k++) if (fwrite(comp_[k].data(), 1, comp_[k].size(), f_) != comp_[k].size()) { ok_ = false; return; }
+    }
+    bool wait() { if (task_.joinable()) task_.join(); return ok_; }
+    bool flush(bool all) {
+        if (!wait()) return false;                       // the batch before this one is on the file
+        const size_t take = all ? pend_.size() : pend_.size() / BLK * BLK;
+        if (!take) return true;
+        busy_.assign(pend_.begin(), pend_.begin() + (ptrdiff_t)take);
+        pend_.erase(pend_.begin(), pend_.begin() + (ptrdiff_t)take);
+        task_ = std::thread([this] { write_busy(); });
         return true;
     }
 public:
     BgzfOut(FILE *f, int level, int threads) : f_(f), level_(level), threads_(std::max(1, threads)) {}
+    BgzfOut(const BgzfOut &) = delete;
+    ~BgzfOut() { if (task_.joinable()) task_.join(); }
     bool put(const uint8_t *p, size_t n) {
         pend_.insert(pend_.end(), p, p + n);
         return pend_.size() < FLUSH_BLOCKS * BLK || flush(false);
     }
     bool close() {
-        if (!flush(true)) return false;
+        if (!flush(true) || !wait()) return false;
         static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         return fwrite(eof, 1, 28, f_) == 28;
     }
