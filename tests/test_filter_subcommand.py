@@ -179,3 +179,68 @@ def test_truncated_input_is_an_error_not_a_short_output(tmp_path):
     open(cut, "wb").write(raw[:len(raw) * 2 // 3])
     r = subprocess.run([BIN, "filter", "-b", cut, "-o", str(tmp_path / "o.bam")], capture_output=True, text=True)
     assert r.returncode != 0 and ("truncated" in r.stderr or "BGZF" in r.stderr)
+
+
+def _adversarial(seed):
+    """Records built to walk every branch of ReferenceSortedBamFilter::read: few read names (so names repeat three and more times on one
+    reference), mates pointing at other references, references that come back later in the file, unmapped / secondary / supplementary /
+    improper flags everywhere, short and long alignments, mapq 255, NM from 0 to more than the aligned length."""
+    rng = np.random.default_rng(seed)
+    n_ref = int(rng.integers(1, 5))
+    ref_lens = rng.integers(500, 5000, n_ref).astype(np.int64)
+    n = int(rng.integers(1, 400))
+    runs = rng.integers(0, n_ref, max(1, n // int(rng.integers(3, 40)) + 1))          # a reference may come back: the parked set is cleared each time
+    tid = np.repeat(runs, rng.integers(1, 60, len(runs)))[:n].astype(np.int32)
+    n = len(tid)
+    flag = np.zeros(n, np.uint16)
+    flag |= np.where(rng.random(n) < 0.75, 0x2, 0).astype(np.uint16)
+    flag |= np.where(rng.random(n) < 0.06, 0x4, 0).astype(np.uint16)
+    flag |= np.where(rng.random(n) < 0.05, 0x100, 0).astype(np.uint16)
+    flag |= np.where(rng.random(n) < 0.05, 0x800, 0).astype(np.uint16)
+    tid = np.where((flag & 0x4) != 0, np.where(rng.random(n) < 0.5, -1, tid), tid).astype(np.int32)
+    mtid = np.where(rng.random(n) < 0.85, tid, rng.integers(-1, n_ref, n)).astype(np.int32)
+    names = [b"q%d" % k for k in rng.integers(0, max(2, n // int(rng.integers(2, 5))), n)]
+    l_seq = rng.integers(1, 200, n).astype(np.int32)
+    ops, off = [], [0]
+    for i in range(n):
+        k = int(rng.integers(0, 5))
+        for _ in range(k):
+            ops.append((int(rng.integers(1, 120)) << 4) | int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 7, 8])))
+        off.append(len(ops))
+    mapq = rng.choice([0, 3, 20, 40, 60, 255], n).astype(np.uint8)
+    nm = rng.integers(0, 30, n).astype(np.uint32)
+    pos = np.zeros(n, np.int32)
+    z = np.zeros(n, np.int32)
+    return bamio.BamData(["r%d" % k for k in range(n_ref)], ref_lens, tid, pos, flag, mapq, l_seq, nm, np.ones(n, np.uint8),
+                         np.asarray(off, np.uint32), np.asarray(ops, np.uint32), mtid, z, z, names, "")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_adversarial_files_against_the_oracle(tmp_path, seed):
+    d = _adversarial(seed)
+    src = str(tmp_path / "in.bam")
+    bamio.write_bam(src, d, level=1)
+    b = bamio.read_alignment_file(src)
+    h_in, r_in = inflate_bam(src)
+    rng = np.random.default_rng(1000 + seed)
+    for trial in range(4):
+        pair = trial % 2 == 1
+        inverse = trial >= 2
+        ff = (bool(rng.random() < 0.5), bool(rng.random() < 0.7), bool(rng.random() < 0.3))
+        case = dict(ff=ff, single=(int(rng.choice([0, 30, 80])), float(rng.choice([0.0, 0.9])), float(rng.choice([0.0, 0.5]))) if not pair else (0, 0.0, 0.0),
+                    pair=(int(rng.choice([0, 60, 150])), float(rng.choice([0.0, 0.9])), float(rng.choice([0.0, 0.5]))) if pair else (0, 0.0, 0.0),
+                    mapq=int(rng.choice([255, 255, 10, 30])))
+        if pair and case["pair"] == (0, 0.0, 0.0) and case["mapq"] == 255:
+            case["pair"] = (60, 0.0, 0.0)
+        if not pair and case["single"] == (0, 0.0, 0.0):
+            case["single"] = (30, 0.0, 0.0)
+        out = str(tmp_path / ("o%d.bam" % trial))
+        r = subprocess.run([BIN, "filter", "-b", src, "-o", out, "-t", "2"] + flags_of(case, inverse), capture_output=True, text=True, timeout=60,
+                           env=dict(os.environ, COVERM_FILTER_WINDOW_KB=str(int(rng.choice([1, 64, 65536])))))
+        assert r.returncode == 0, r.stderr[-1000:]
+        fp = O.FilterParameters(O.FlagFilter(*ff), case["single"][0], float(np.float32(case["single"][1])), float(np.float32(case["single"][2])),
+                                case["mapq"], case["pair"][0], float(np.float32(case["pair"][1])), float(np.float32(case["pair"][2])))
+        order = [int(i) for i in O.reader_filter(b, fp, filter_out=not inverse)]
+        h_out, r_out = inflate_bam(out)
+        assert h_out == h_in
+        assert r_out == [r_in[i] for i in order], (seed, trial, case, inverse)
