@@ -63,9 +63,14 @@ struct EntryAcc {
     u32 win_min_d = 0xffffffffu;
     double sum_identity = 0.0;
     std::vector<u64> hist;  // merged counts; hist.size() == counts.len()
+    // an entry made of ONE contig reads that contig's bins where they lie (no copy); a second contig materialises `hist`
+    const u64 *hview = nullptr; size_t hview_n = 0;
+    size_t hsize() const { return hview ? hview_n : hist.size(); }
+    u64 hat(size_t i) const { return hview ? hview[i] : hist[i]; }
+    void own_hist() { if (hview) { hist.assign(hview, hview + hview_n); hview = nullptr; hview_n = 0; } }
     void reset() {   // keeps hist's capacity: one reset per contig
         win_len = win_sum_d = win_sum_d2 = win_covered = full_len = full_covered = n_reads = mismatches = 0;
-        win_min_d = 0xffffffffu; sum_identity = 0.0; hist.clear(); hist_len_only = 0;
+        win_min_d = 0xffffffffu; sum_identity = 0.0; hist.clear(); hview = nullptr; hview_n = 0; hist_len_only = 0;
     }
     void add_contig(const cov_contig_stats &s, u64 L, u64 excl, u64 n, double identity, const u64 *h) {
         n_reads += n;
@@ -78,8 +83,12 @@ struct EntryAcc {
             win_sum_d += s.win_sum_d; win_sum_d2 += s.win_sum_d2; win_covered += s.win_covered;
             win_min_d = std::min(win_min_d, s.win_min_d);
             if (h && s.hist_len) {
-                if (hist.size() < s.hist_len) hist.resize(s.hist_len, 0);
-                for (u32 d = 0; d < s.hist_len; d++) hist[d] += h[s.hist_off + d];
+                if (!hview && hist.empty()) { hview = h + s.hist_off; hview_n = s.hist_len; }
+                else {
+                    own_hist();
+                    if (hist.size() < s.hist_len) hist.resize(s.hist_len, 0);
+                    for (u32 d = 0; d < s.hist_len; d++) hist[d] += h[s.hist_off + d];
+                }
             } else if (!h) {
                 // no histogram requested: remember only how long counts would be
                 if (hist_len_only < (u64)s.win_max_d + 1) hist_len_only = (u64)s.win_max_d + 1;
@@ -117,8 +126,8 @@ float calculate(const covh_estimator &e, const EntryAcc &a, const u64 *unobs, si
         if (a.win_covered == 0) return 0.0f;
         u64 acc = 0, total = 0;
         bool started = false;
-        for (size_t i = 0; i < a.hist.size(); i++) {
-            const u64 n = a.hist[i] + (i == 0 ? U : 0);  // counts[0] += unobserved (:596)
+        for (size_t i = 0, nh = a.hsize(); i < nh; i++) {
+            const u64 n = a.hat(i) + (i == 0 ? U : 0);  // counts[0] += unobserved (:596)
             acc += n;
             if (acc >= min_index) {
                 if (started) {
@@ -223,7 +232,7 @@ struct covh_taker {
     void reserve(size_t entries, size_t per_entry, size_t name_bytes) {
         if (kind != COVH_TAKER_CACHED) { text.reserve(text.size() + entries * (per_entry * 12 + 24) + name_bytes); return; }
         if (!coverages.empty()) coverages.back().reserve(entries * per_entry);
-        if (entry_names.refs.capacity() < entries) entry_names.refs.reserve(entries);
+        if (entry_names.refs.size() < entries) entry_names.refs.resize(entries);        // unset refs: ids arrive in any order, and not all of them
         if (entry_names.arena.capacity() < name_bytes) entry_names.arena.reserve(name_bytes);
     }
     void start_entry(size_t id, std::string_view name) {
@@ -291,10 +300,10 @@ std::vector<EntryAndCoverages> iterate_cached(const covh_taker &t) {
 
 void print_coverage(const covh_estimator &e, const EntryAcc &a, float coverage, covh_taker &t) {  // estimators.rs:936-969
     if (e.kind != COVH_PILEUP_COUNTS) { t.add_single_coverage(coverage); return; }
-    for (size_t i = 0; i < a.hist.size(); i++) {
+    for (size_t i = 0, nh = a.hsize(); i < nh; i++) {
         u64 cov;
         if (i == 0) { const u64 c = f32_to_usize(std::floor(coverage)); cov = c == 0 ? 0 : c - 1; }
-        else cov = a.hist[i];
+        else cov = a.hat(i);
         t.add_coverage_entry(i, cov);
     }
 }
