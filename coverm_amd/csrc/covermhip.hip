@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/covermhip.h"
+#include "roctx_ranges.h"
 
 using namespace covk;
 
@@ -472,6 +473,11 @@ void cov_destroy(cov_session *s) {
     s->d_tile_first.release(); s->d_tcnt.release(); s->d_fov.release(); s->d_tscan.release(); s->d_ttop.release(); s->d_slow_list.release();
     s->d_ctg_scratch.release(); s->d_depth_all.release(); s->d_depth_off.release(); s->d_iv.release(); s->d_ivst.release(); s->d_ivhist.release();
     s->d_cx_list.release(); s->d_cx_cnt.release(); s->d_cx_cur.release(); s->d_cx_scan.release(); s->d_cx_top.release(); s->d_cx_runs.release();
+    if (s->side) {     // before ing_aux goes: `side` may be that very stream (finish_once borrows the idle ingest stream)
+        (void)hipStreamSynchronize(s->side);
+        if (s->side_owned) (void)hipStreamDestroy(s->side);
+        s->side = nullptr; s->side_owned = false;
+    }
     if (s->ing_aux) (void)hipStreamSynchronize(s->ing_aux);
     if (s->ing_parse) (void)hipStreamSynchronize(s->ing_parse);
     if (s->ing_ext) (void)hipStreamSynchronize(s->ing_ext);
@@ -500,7 +506,6 @@ void cov_destroy(cov_session *s) {
     s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
     s->s_mtid.release(); s->s_qh1.release(); s->s_qh2.release();
     s->d_runs.release(); s->d_part.release(); s->d_ident.release(); s->d_identp.release(); s->d_idch.release();
-    if (s->side) { (void)hipStreamSynchronize(s->side); if (s->side_owned) (void)hipStreamDestroy(s->side); }
     if (s->ev_prep_done) (void)hipEventDestroy(s->ev_prep_done);
     if (s->ev_side_done) (void)hipEventDestroy(s->ev_side_done); s->d_arena.release(); s->d_chist.release(); s->d_depth.release();
     for (int k = 0; k < COV_K_COUNT; k++)
@@ -697,6 +702,7 @@ static cov_status convert_results(cov_session *s, const DevGlobal &G, const DevC
 static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summary *summary, bool &again);
 
 cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summary) {
+    covr::Range rr("cov_finish");
     // The buckets of long-CIGAR records are sized optimistically: a pass that finds them too small has already
     // computed the exact need, grows the buffer and runs once more (at most once per growth of the workload).
     bool again = false;
@@ -1051,6 +1057,7 @@ static inline const InflateKernel &inflate_kernel(cov_session *s) { return s->in
 
 cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t first_record_offset, int check_crc) {
     if (!s) return COV_ERR_INVALID_ARG;
+    covr::Range rr("ingest: buffers, streams, events (cov_ingest_begin)");
     HIPCHK(hipSetDevice(s->cfg.device));
     if (!s->ing_copy) {
         HIPCHK(hipStreamCreateWithFlags(&s->ing_copy, hipStreamNonBlocking));
@@ -1111,7 +1118,7 @@ cov_status cov_ingest_span(cov_session *s, int64_t key_lo, int64_t key_hi, int s
 // k_bam_verify if need be), later ones only if their result is already here.
 static cov_status ingest_drain_(cov_session *s, int64_t must_upto);
 struct PartTimer { double &acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); ~PartTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } };
-static cov_status ingest_drain(cov_session *s, int64_t must_upto) { PartTimer t{s->ing_s_part[0]}; return ingest_drain_(s, must_upto); }
+static cov_status ingest_drain(cov_session *s, int64_t must_upto) { PartTimer t{s->ing_s_part[0]}; covr::Range rr("ingest: verify + extract windows"); return ingest_drain_(s, must_upto); }
 static cov_status ingest_drain_(cov_session *s, int64_t must_upto) {
     hipStream_t ps = s->ing_ext;     // the host has seen the window's verification finish: nothing on the device to wait for
     while (s->ing_extracted < s->ing_batch) {
@@ -1170,7 +1177,7 @@ static cov_status ingest_drain_(cov_session *s, int64_t must_upto) {
 // costs 2 T — measured: 46 ms per launch of ~51 k blocks against 23.5 ms per round of 49 152).
 // Windows bound the memory: the inflated stream of a 200 M-read BAM is 62 GB, and device allocations cost ~30 ms per GB.
 static cov_status launch_round_(cov_session *s, uint64_t n64, bool final);
-static cov_status launch_round(cov_session *s, uint64_t n64, bool final) { PartTimer t{s->ing_s_part[1]}; return launch_round_(s, n64, final); }
+static cov_status launch_round(cov_session *s, uint64_t n64, bool final) { PartTimer t{s->ing_s_part[1]}; covr::Range rr("ingest: inflate round launch"); return launch_round_(s, n64, final); }
 static cov_status launch_round_(cov_session *s, uint64_t n64, bool final) {
     const uint64_t b0 = s->ing_launched;
     n64 = std::min<uint64_t>(n64, s->ing_blocks - b0);
@@ -1301,6 +1308,7 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
                            const cov_bgzf_block *blocks, uint32_t n_blocks) {
     if (!s || !s->ing_active || slot < 0 || slot >= COV_INGEST_SLOTS || (n_bytes && !host_bytes) || (n_blocks && !blocks)) return COV_ERR_INVALID_ARG;
     if (file_offset + n_bytes > s->ing_comp) { s->err = "cov_ingest_feed: bytes beyond the size given to cov_ingest_begin"; return COV_ERR_INVALID_ARG; }
+    covr::Range rr("ingest: window upload (cov_ingest_feed)");
     HIPCHK(hipSetDevice(s->cfg.device));
     { const cov_status d = ingest_drain(s, -1); if (d != COV_OK) return d; }      // extraction of whatever got verified meanwhile
     const InflateKernel &K = inflate_kernel(s);
@@ -1366,6 +1374,7 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
 
 cov_status cov_ingest_end(cov_session *s, uint64_t *n_records_out) {
     if (!s || !s->ing_active) return COV_ERR_INVALID_ARG;
+    covr::Range rr("ingest: last rounds + parse (cov_ingest_end)");
     s->ing_active = false;
     HIPCHK(hipSetDevice(s->cfg.device));
     if (n_records_out) *n_records_out = 0;
@@ -1438,6 +1447,7 @@ static_assert(sizeof(cov_pair_filter) == sizeof(covp::PairFilter) && offsetof(co
 
 cov_status cov_pair_filter_apply(cov_session *s, const cov_pair_filter *f, uint64_t *n_selected, uint64_t *n_primary) {
     if (!s || !f) return COV_ERR_INVALID_ARG;
+    covr::Range rr("pair filter (cov_pair_filter_apply)");
     if (s->adopted || s->ing_active) { s->err = "cov_pair_filter_apply: needs the session's own record store, filled by the device ingest"; return COV_ERR_STATE; }
     if (s->mates_valid != s->n_records) { s->err = "cov_pair_filter_apply: the store holds records without mate columns (cov_ingest_want_mates before every ingest, no cov_push_batch)"; return COV_ERR_STATE; }
     HIPCHK(hipSetDevice(s->cfg.device));

@@ -38,6 +38,7 @@
 
 #include "../../include/coverm_host.h"
 #include "reader_filter.h"
+#include "roctx_ranges.h"
 
 namespace {
 
@@ -833,6 +834,7 @@ struct Stream {
     std::vector<std::unique_ptr<StreamWindow>> wins;
     std::vector<std::unique_ptr<StreamBatch>> bats;
     bool stop = false, i_done = false, p_done = false, failed = false;
+    bool span_unsorted = false;   // the failure is "keys decrease inside a span" (covh_bam_stream_next returns -2)
     StreamBatch *held = nullptr;
     uint64_t n_records = 0;
     std::atomic<uint64_t> peak_bytes{0};
@@ -953,7 +955,10 @@ struct Stream {
                     int64_t prev = span_last_key;
                     for (size_t i = 0; i < i1; i++) {
                         const int64_t k = tid_key((int32_t)rd32(base + rec[i] + 4));
-                        if (k < prev) { fail("BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)"); return; }
+                        if (k < prev) {
+                            { std::lock_guard<std::mutex> lk(m); if (!failed) span_unsorted = true; }
+                            fail("BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)"); return;
+                        }
                         prev = k;
                     }
                     span_last_key = prev;
@@ -1188,7 +1193,7 @@ int covh_bam_stream_next(covh_bam_stream *h, cov_batch *out) {
     std::unique_lock<std::mutex> lk(s.m);
     if (s.held) { s.bat_free.push_back(s.held); s.held = nullptr; s.cv.notify_all(); }
     s.cv.wait(lk, [&] { return !s.bat_full.empty() || s.p_done || s.failed; });
-    if (s.failed) return -1;
+    if (s.failed) return s.span_unsorted ? -2 : -1;
     if (s.bat_full.empty()) return 0;
     s.held = s.bat_full.front(); s.bat_full.pop_front();
     s.held->fill(out);
@@ -1259,7 +1264,8 @@ const char *covh_bam_header_target_name(const covh_bam_header *h, uint32_t i) { 
 uint64_t covh_bam_header_target_len(const covh_bam_header *h, uint32_t i) { return h->h.lens[i]; }
 uint64_t covh_bam_header_first_record(const covh_bam_header *h) { return h->h.first_record; }
 
-// 0 = records are in the session's store; 1 = the file needs the CPU reader (reason in err; nothing appended); -1 = error.
+// 0 = records are in the session's store; 1 = the file needs the CPU reader (reason in err; nothing appended); -1 = error;
+// -2 = the record keys decrease inside the span (the reference's "appears to be unsorted" text in err).
 // timing (optional, 5 doubles): seconds reading the file, waiting for staging slots, in cov_ingest_end, total, in cov_ingest_begin (allocation).
 int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint64_t *n_records,
                         double *timing, char *err, size_t errcap) {
@@ -1273,6 +1279,7 @@ int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const cov
 int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint32_t span_index,
                              uint32_t span_count, uint64_t *n_records, double *timing, char *err, size_t errcap) {
     auto fail = [&](int rc, const std::string &e) { if (err && errcap) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; } return rc; };
+    covr::Range rr("device ingest of one file span (covh_bam_gpu_ingest_span)");
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     if (n_records) *n_records = 0;
@@ -1559,6 +1566,7 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     const double t_end = now() - t0;
     if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; timing[4] = t_begin; timing[5] = t_walk; timing[6] = t_feed; timing[7] = 0; }
     if (rc == COV_ERR_INGEST_FALLBACK) return fail(1, cov_last_error(s));
+    if (rc == COV_ERR_UNSORTED) return fail(-2, cov_last_error(s));      // keys decrease inside the span: the caller may send the file through one device whole
     if (rc != COV_OK) return fail(-1, cov_last_error(s));
     if (n_records) *n_records = nrec;
     return 0;

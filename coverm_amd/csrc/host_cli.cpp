@@ -40,6 +40,7 @@ namespace {
 std::atomic<bool> g_skip_teardown{false};   // covh_cli_set_fast_exit: a process about to exit need not hand ~100 GB of HBM back allocation by allocation
 
 struct Fatal : std::runtime_error { using std::runtime_error::runtime_error; };
+struct SpanUnsorted : Fatal { using Fatal::Fatal; };      // a tid span met keys that decrease (covh_bam_gpu_ingest_span -2, the CPU span reader's same rule)
 [[noreturn]] void die(const std::string &m) { throw Fatal(m); }
 
 // clap's typed value parsers (u8 / u16 / u32 / u64 / f32 arguments of coverm.rs / cli.rs): a value that is not a number of the argument's
@@ -209,6 +210,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         uint64_t nrec = 0; double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         check(s, cov_ingest_want_mates(s, R.fp ? 1 : 0));
         int rc = covh_bam_gpu_ingest_span(S.path.c_str(), threads, s, hd, getenv("COVERM_NO_CRC") ? 0 : 1, span_index, span_count, &nrec, tm, err, sizeof err);
+        if (rc == -2 && span_count > 1) throw SpanUnsorted(err);
         if (rc < 0) die(err);
         uint64_t pair_prim = 0; double t_pair = 0;
         if (rc == 0 && R.fp) {     // the reader-stage pair filter, on the device
@@ -255,6 +257,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         cov_batch b;
         int rc;
         while ((rc = covh_bam_stream_next(st, &b)) == 1) check(s, cov_push_batch(s, &b));
+        if (rc == -2 && span_count > 1) throw SpanUnsorted(covh_bam_stream_error(st));
         if (rc < 0) die(covh_bam_stream_error(st));
         S.n_records = covh_bam_stream_n_records(st);
         S.peak_bytes = covh_bam_stream_peak_bytes(st);
@@ -661,10 +664,12 @@ int run_cli(int argc, char **argv) {
     std::vector<Sample> samples(nb);
     for (size_t i = 0; i < nb; i++) samples[i].path = a.bams[i];
     std::mutex err_mutex; std::string first_error;
+    size_t n_errors = 0, n_span_unsorted = 0;      // a span-mode fallback is taken only when EVERY failed span failed on the order of its keys
     auto guarded = [&](auto fn) {
         try { fn(); }
-        catch (const Fatal &e) { std::lock_guard<std::mutex> lk(err_mutex); if (first_error.empty()) first_error = e.what(); }
-        catch (const std::exception &e) { std::lock_guard<std::mutex> lk(err_mutex); if (first_error.empty()) first_error = e.what(); }
+        catch (const SpanUnsorted &e) { std::lock_guard<std::mutex> lk(err_mutex); n_errors++; n_span_unsorted++; if (first_error.empty()) first_error = e.what(); }
+        catch (const Fatal &e) { std::lock_guard<std::mutex> lk(err_mutex); n_errors++; if (first_error.empty() || n_span_unsorted == n_errors - 1) first_error = e.what(); }
+        catch (const std::exception &e) { std::lock_guard<std::mutex> lk(err_mutex); n_errors++; if (first_error.empty() || n_span_unsorted == n_errors - 1) first_error = e.what(); }
     };
     const bool span_mode = nd > 1 && nb < nd;
     if (!span_mode) {
@@ -709,8 +714,8 @@ int run_cli(int argc, char **argv) {
                 // skip.  The reference only compares the tids of mapped records that passed the flag filters (contig.rs:118-132), so a
                 // file it accepts can be refused here: such a file goes through ONE device whole, where cov_finish judges its order with
                 // the reference's rule (and ends in the same error if it really is unsorted).
-                if (first_error.find("appears to be unsorted") == std::string::npos) die(first_error);
-                first_error.clear();
+                if (n_span_unsorted != n_errors) die(first_error);      // some span failed for another reason: that error is the run's (first_error holds it)
+                first_error.clear(); n_errors = n_span_unsorted = 0;
                 if (timing) fprintf(stderr, "[coverm-amd] %s: keys decrease inside a span; the file goes through one device whole\n", a.bams[bi].c_str());
                 ingest(R, sess[0], samples[bi], a.threads, 0, 1);
                 continue;

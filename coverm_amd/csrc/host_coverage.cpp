@@ -389,6 +389,7 @@ void covh_estimator_setup(covh_estimator_state *s) { s->acc.reset(); s->num_mapp
 void covh_estimator_add_contig_stats(covh_estimator_state *s, const cov_contig_stats *stats, uint64_t target_len, const uint64_t *hist,
                                      uint64_t num_mapped_reads, double sum_identity) {
     s->acc.add_contig(*stats, target_len, s->e.contig_end_exclusion, num_mapped_reads, sum_identity, hist);
+    s->acc.own_hist();   // exported path: the caller's `hist` need not outlive this call (the in-tree scan drivers keep the zero-copy view)
     // Mean/ReadCount/... accumulate, the histogram family assigns (estimators.rs:434): EntryAcc keeps the sum, the assignment
     // only matters to num_mapped_reads()
     if (s->e.kind == COVH_TRIMMED_MEAN || s->e.kind == COVH_PILEUP_COUNTS || s->e.kind == COVH_VARIANCE) s->num_mapped_reads = num_mapped_reads;

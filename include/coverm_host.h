@@ -172,7 +172,8 @@ int covh_bam_write(const char *path, uint32_t n_targets, const char *const *name
  * fall into exactly one span each (records with tid -1 go to the last one).
  *   h = covh_bam_stream_open(path, threads, 0, 1, err, cap);   header accessors are valid at once
  *   while (covh_bam_stream_next(h, &batch) == 1) cov_push_batch(session, &batch);   arrays stay valid until the next call
- * covh_bam_stream_next returns 1 (batch), 0 (end of file / span) or -1 (covh_bam_stream_error). */
+ * covh_bam_stream_next returns 1 (batch), 0 (end of file / span), -1 (covh_bam_stream_error) or -2 (the same, and the error is
+ * "the record keys decrease inside this span": see covh_bam_gpu_ingest_span). */
 typedef struct covh_bam_stream covh_bam_stream;
 covh_bam_stream *covh_bam_stream_open(const char *path, int threads, uint32_t span_index, uint32_t span_count, char *err, size_t errcap);
 uint32_t covh_bam_stream_n_targets(const covh_bam_stream *h);
@@ -198,7 +199,9 @@ const char *covh_bam_header_target_name(const covh_bam_header *h, uint32_t i);
 uint64_t covh_bam_header_target_len(const covh_bam_header *h, uint32_t i);
 uint64_t covh_bam_header_first_record(const covh_bam_header *h); /* offset in the inflated stream */
 /* covh_bam_gpu_ingest_span: one tid span of the file (span definition of covh_bam_stream_open): only the span's part of the file
- * is read and fed; 0 with *n_records = 0 for an empty span. */
+ * is read and fed; 0 with *n_records = 0 for an empty span.  -2 (instead of -1) when the record keys decrease inside the span: a span
+ * trusts the file's order, so the caller decides (coverm-amd then sends the file through one device whole, where the reference's
+ * own rule, contig.rs:118-132, judges it). */
 int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint32_t span_index,
                              uint32_t span_count, uint64_t *n_records, double *timing8, char *err, size_t errcap);
 int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint64_t *n_records,
@@ -272,7 +275,8 @@ void covh_cli_set_fast_exit(int on);
 
 /* ---- trait MosdepthGenomeCoverageEstimator (estimators.rs:245-265), one export per method, for hosts that keep the reference's
  * scan-loop shape (a Rust `impl MosdepthGenomeCoverageEstimator` forwards 1:1).  add_contig takes the contig's
- * integer statistics from cov_finish where the reference passes the delta array. */
+ * integer statistics from cov_finish where the reference passes the delta array.  `hist` is copied by the call (the bins of this
+ * contig only): a binding may hand in a temporary buffer, as the reference's add_contig borrows its slice for the call alone. */
 typedef struct covh_estimator_state covh_estimator_state;
 covh_estimator_state *covh_estimator_new(const covh_estimator *params);                 /* CoverageEstimator::new_estimator_* */
 void covh_estimator_free(covh_estimator_state *s);
