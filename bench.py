@@ -233,6 +233,14 @@ def timing_lines(stderr, n=8):
     return [l for l in stderr.splitlines() if "stream read" in l or "ingest" in l or "VmHWM" in l or "main:" in l or "pair filter" in l][:n]
 
 
+def inflate_backend():
+    """What the host readers inflate with on THIS box (csrc/host_bam.cpp binds libdeflate at run time and falls back to zlib)."""
+    from coverm_amd import bam as cbam
+    L = cbam._lib()
+    L.covh_inflate_backend.restype = C.c_char_p
+    return L.covh_inflate_backend().decode()
+
+
 def cpu_decode(path, threads, reps):
     """The CPU side's decoder (csrc/host_bam.cpp covh_bam_open: threaded libdeflate inflate + parse) `reps` times; (best seconds,
     every run's seconds, records of the last run)."""
@@ -302,11 +310,14 @@ def end_to_end(a, threads):
         want_text = oracle_dense_text(ref.names, cov, rmp, ALL_METHODS, "config5")
         same = gpu_text == want_text
         res.update(
-            gpu=dict(seconds=gpu_s, seconds_is="median of three runs", reads_per_s=reads / gpu_s, rep_seconds=rep_seconds, max_rss_bytes=gpu_rss,
+            gpu=dict(seconds=gpu_s, seconds_is="median of three runs", reads_per_s=rmp[0] / gpu_s, reads_per_s_is="considered (aligned, filter-passing) reads per second: the metric's unit",
+                     records_per_s=reads / gpu_s, rep_seconds=rep_seconds, max_rss_bytes=gpu_rss,
                      command=" ".join(["coverm-amd"] + cmd[1:]), stderr_mapped=mapped[:1], stderr_timing=timing_lines(gpu_err)),
             cpu=dict(decode_s=dec_s, decode_runs=dec_all, scan_s=scan_s, scan_runs=[round(x, 3) for x in scans], seconds_is="best of three runs each",
-                     reads_per_s_serial=reads / (dec_s + scan_s), reads_per_s_overlapped=reads / max(dec_s, scan_s),
-                     decoder="csrc/host_bam.cpp covh_bam_open, %d threads" % threads, scan="oracle/coverm_oracle.c, 1 thread, %s" % oracle_native()[1],
+                     reads_per_s_serial=rmp[0] / (dec_s + scan_s), reads_per_s_overlapped=rmp[0] / max(dec_s, scan_s),
+                     records_per_s_serial=reads / (dec_s + scan_s), records_per_s_overlapped=reads / max(dec_s, scan_s),
+                     inflate_backend=inflate_backend(), nproc=os.cpu_count(), usable_cpus=usable_cpus(), decode_threads=threads, scan_threads=1,
+                     decoder="csrc/host_bam.cpp covh_bam_open, %d threads, %s" % (threads, inflate_backend()), scan="oracle/coverm_oracle.c, 1 thread, %s" % oracle_native()[1],
                      note="the reference overlaps htslib's inflate pool with its single scan thread: its rate lies between the two figures, "
                           "at or below the overlapped one"),
             speedup_vs_cpu_overlapped=(reads / gpu_s) / (reads / max(dec_s, scan_s)), speedup_vs_cpu_serial=(reads / gpu_s) / (reads / (dec_s + scan_s)),
@@ -326,7 +337,7 @@ def end_to_end(a, threads):
             same6 = open(out_tsv).read() == want_text
             d6, d6_all, _ = cpu_decode(p6, threads, 3)
             res["level6"] = dict(bam_bytes=size6, bam_bytes_per_read=size6 / reads, bam_write_s=w6, gpu_seconds=g6, seconds_is="median of three runs", rep_seconds=reps6,
-                                 reads_per_s=reads / g6, max_rss_bytes=rss6, stderr_timing=timing_lines(err6), cpu_decode_s=d6, cpu_decode_runs=d6_all, cpu_scan_s=scan_s,
+                                 reads_per_s=rmp[0] / g6, records_per_s=reads / g6, max_rss_bytes=rss6, cpu_inflate_backend=inflate_backend(), stderr_timing=timing_lines(err6), cpu_decode_s=d6, cpu_decode_runs=d6_all, cpu_scan_s=scan_s,
                                  speedup_vs_cpu_overlapped=(reads / g6) / (reads / max(d6, scan_s)), speedup_vs_cpu_serial=(reads / g6) / (reads / (d6 + scan_s)),
                                  tables_equal=same6)
             res["tables_equal"] = res["tables_equal"] and same6
@@ -355,7 +366,7 @@ def binary_config_legs(a, threads, ref, batch, oracle_cfg2):
         s2, reps2, err2, rss2 = run_binary(cmd2, 3, sleep_s=2.0)
         cov, rmp = oracle_cfg2
         same2 = open(out).read() == oracle_dense_text(ref.names, cov, rmp, METHODS, "sample0")
-        res["config2_contig"] = dict(seconds=s2, seconds_is="median of three runs", rep_seconds=reps2, reads_per_s=batch.n_records / s2, max_rss_bytes=rss2,
+        res["config2_contig"] = dict(seconds=s2, seconds_is="median of three runs", rep_seconds=reps2, reads_per_s=rmp[0] / s2, records_per_s=batch.n_records / s2, max_rss_bytes=rss2,
                                      tables_equal=same2, stderr_timing=timing_lines(err2, 4),
                                      note="also config 4's per-device share (one 50 M-read BAM per device)")
         gd = os.path.join(tmpdir, "genomes.tsv")
@@ -369,7 +380,7 @@ def binary_config_legs(a, threads, ref, batch, oracle_cfg2):
                     batch.cigar_off, batch.cigar, z, z, z, [], "")
         t0 = time.perf_counter()
         want3 = O.run_cli("genome", [path], bams=[b], methods=["relative_abundance", "rpkm", "tpm"], genome_definition=gd)
-        res["config3_genome"] = dict(seconds=s3, seconds_is="median of three runs", rep_seconds=reps3, reads_per_s=batch.n_records / s3, max_rss_bytes=rss3,
+        res["config3_genome"] = dict(seconds=s3, seconds_is="median of three runs", rep_seconds=reps3, reads_per_s=rmp[0] / s3, records_per_s=batch.n_records / s3, max_rss_bytes=rss3,
                                      genomes=len(ref.genomes), tables_equal=got3 == want3, oracle_cli_s=time.perf_counter() - t0, stderr_timing=timing_lines(err3, 4))
         res["tables_equal"] = bool(same2 and got3 == want3)
     finally:
@@ -407,7 +418,7 @@ def multi_device_legs(a, threads, world, devs=None):
         sn, repsn, errn, rssn = run_binary(cmd1 + ["--devices", devs], 3)
         same4 = open(out).read() == text1
         res["config4_samples"] = dict(bams=world, reads=nrec, bam_bytes=nbytes, generation_and_write_s=gen4, seconds=sn, seconds_is="median of three runs", rep_seconds=repsn,
-                                      reads_per_s=nrec / sn, host_read_GBps=nbytes / sn / 1e9, single_device_all_bams_seconds=s1, speedup_vs_single_device=s1 / sn,
+                                      records_per_s=nrec / sn, records_per_s_is="all records of the files (aligned or not); no oracle runs in this leg to count the considered ones", host_read_GBps=nbytes / sn / 1e9, single_device_all_bams_seconds=s1, speedup_vs_single_device=s1 / sn,
                                       max_rss_bytes=rssn, tables_equal=bool(same4),
                                       stderr_timing=[l for l in errn.splitlines() if "device ingest:" in l or "[covermhip] ingest" in l][:2 * world],
                                       note="N distinct BAMs (seeds 10 ..); per device: file read = time its reader threads spent in pread, staging waits = time they "
@@ -424,7 +435,7 @@ def multi_device_legs(a, threads, world, devs=None):
         s1, reps1, _, _ = run_binary(cmd1, 3)
         text1 = open(out).read()
         sn, repsn, errn, rssn = run_binary(cmd1 + ["--devices", devs], 3)
-        res["config5_spans"] = dict(reads=nbig, bam_bytes=os.path.getsize(path), seconds=sn, seconds_is="median of three runs", rep_seconds=repsn, reads_per_s=nbig / sn,
+        res["config5_spans"] = dict(reads=nbig, bam_bytes=os.path.getsize(path), seconds=sn, seconds_is="median of three runs", rep_seconds=repsn, records_per_s=nbig / sn,
                                     single_device_seconds=s1, single_device_rep_seconds=reps1, speedup_vs_single_device=s1 / sn, max_rss_bytes=rssn,
                                     host_read_GBps=os.path.getsize(path) / sn / 1e9, tables_equal=open(out).read() == text1,
                                     stderr_timing=[l for l in errn.splitlines() if "device ingest:" in l or "[covermhip] ingest" in l][:2 * world])
@@ -452,14 +463,21 @@ def main():
                     help="where the end-to-end leg writes its BAM (default: /dev/shm when it has room, so that storage speed is not part of the figure)")
     a = ap.parse_args()
 
+    share = os.environ.get("COVERM_BENCH_SHARE_GPU") == "1"
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # `python bench.py --gpus N` on its own: become N ranks (one per GPU) under torch.distributed.run, as the driver's launch line does
+        check_devices(a.gpus, share)
+        os.execvpe(sys.executable, relaunch_cmd(a.gpus, sys.argv[1:]), dict(os.environ, MASTER_ADDR="127.0.0.1"))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the coverage engine has no CPU fallback")
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE): the line would be mislabelled" % (a.gpus, world))
+    check_devices(world, share)
     # Functional check of the N > 1 path on a single-GPU box: COVERM_BENCH_SHARE_GPU=1 puts every rank on device 0 and
     # exchanges over gloo (RCCL refuses two ranks on one device).  Never set by the driver; such a line is not a measurement.
-    share = os.environ.get("COVERM_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -591,7 +609,8 @@ def main():
                                    "--methods %s, records resident in HBM" % (a.reads, a.contigs,
                                                                              ref.lengths.sum() / 1e9, " ".join(METHODS)),
                        "reads_per_gpu": a.reads, "contigs": a.contigs, "reference_bp": int(ref.lengths.sum()),
-                       "samples": world, "sharding": ("FUNCTIONAL CHECK ONLY: ranks share one GPU, gloo exchange" if share else
+                       "samples": world, "rccl_ranks": (dist.get_world_size() if dist else 1), "exchange_backend": (dist.get_backend() if dist else None),
+                       "sharding": ("FUNCTIONAL CHECK ONLY: ranks share one GPU, gloo exchange" if share else
                                                        "one sample per GPU, RCCL gather of per-contig coverages") if world > 1 else "single GPU"},
             "gbp_per_s": aligned_bp * world * a.steps / elapsed / 1e9,
             "roofline": roof,
@@ -604,7 +623,8 @@ def main():
             if not par["equal"]:
                 exit_code = 3
             cpu_rate = cpu_mapped / cpu_dt
-            out["cpu_baseline"] = dict(value=cpu_rate, unit="aligned reads/s", cores=1, kind="port",
+            out["cpu_baseline"] = dict(value=cpu_rate, unit="aligned reads/s", cores=1, kind="port", nproc=os.cpu_count(), usable_cpus=usable_cpus(),
+                                       inflate_backend=inflate_backend() + " (end-to-end legs only: this leg starts from decoded records)",
                                        sample="100%% of the workload (%d records, whole contigs), %.1f s; oracle/coverm_oracle.c (%s) = literal C port of "
                                               "CoverM 0.8.0's scan loop + estimators, records already decoded in host memory; not the coverm binary"
                                               % (R, cpu_dt, oracle_native()[1]))
@@ -680,7 +700,7 @@ def main():
             "e2e_l1_x_serial": r3(e2e.get("speedup_vs_cpu_serial")),
             "e2e_l6_s": r3(l6.get("gpu_seconds")), "e2e_l6_x_overlapped": r3(l6.get("speedup_vs_cpu_overlapped")), "e2e_l6_x_serial": r3(l6.get("speedup_vs_cpu_serial")),
             "cpu_decode_s": r3((e2e.get("cpu") or {}).get("decode_s")), "cpu_decode_l6_s": r3(l6.get("cpu_decode_s")), "cpu_scan_s": r3((e2e.get("cpu") or {}).get("scan_s")),
-            "cpu_threads": e2e.get("threads"),
+            "cpu_threads": e2e.get("threads"), "cpu_inflate_backend": (e2e.get("cpu") or {}).get("inflate_backend"),
             "cfg2_binary_s": r3((bc.get("config2_contig") or {}).get("seconds")), "cfg3_binary_s": r3((bc.get("config3_genome") or {}).get("seconds")),
             "parity_equal": (out.get("parity_checked") or {}).get("equal"),
             "tables_equal": (bool(e2e.get("tables_equal")) and bool(bc.get("tables_equal"))) if (e2e and bc and "error" not in e2e and "error" not in bc) else None,
@@ -693,6 +713,28 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(exit_code)
+
+
+def relaunch_cmd(n, argv, port=None):
+    """The command `python bench.py --gpus N` turns itself into when no launcher started it: N ranks on this node, rendezvous on
+    127.0.0.1 (the container hostname may not resolve)."""
+    if port is None:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def check_devices(n, share):
+    """N ranks need N GPUs: fewer is an error, not a silently smaller run.  COVERM_BENCH_SHARE_GPU=1 (functional check of the N > 1
+    path on a single-GPU box; never a measurement) puts every rank on device 0."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the coverage engine has no CPU fallback")
+    have = torch.cuda.device_count()
+    if have < n and not share:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (COVERM_BENCH_SHARE_GPU=1 runs the ranks on one device as a functional check)" % (n, have))
 
 
 def default_tmp():

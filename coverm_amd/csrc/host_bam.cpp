@@ -1185,6 +1185,7 @@ uint32_t covh_bam_stream_n_targets(const covh_bam_stream *h) { return (uint32_t)
 const char *covh_bam_stream_target_name(const covh_bam_stream *h, uint32_t i) { return h->s.names[i].c_str(); }
 uint64_t covh_bam_stream_target_len(const covh_bam_stream *h, uint32_t i) { return h->s.lens[i]; }
 const char *covh_bam_stream_error(const covh_bam_stream *h) { return h->s.err.c_str(); }
+const char *covh_inflate_backend(void) { return libdeflate().ok ? "libdeflate" : "zlib"; }
 uint64_t covh_bam_stream_peak_bytes(const covh_bam_stream *h) { return h->s.peak_bytes.load(); }
 uint64_t covh_bam_stream_n_records(const covh_bam_stream *h) { return h->s.n_records; }
 

@@ -181,6 +181,9 @@ const char *covh_bam_stream_target_name(const covh_bam_stream *h, uint32_t i);
 uint64_t covh_bam_stream_target_len(const covh_bam_stream *h, uint32_t i);
 int covh_bam_stream_next(covh_bam_stream *h, cov_batch *out);
 const char *covh_bam_stream_error(const covh_bam_stream *h);
+/* Which inflate the HOST readers of this process use (covh_bam_open, covh_bam_stream_*, coverm-amd filter): "libdeflate" when
+ * libdeflate.so.0 could be bound at run time, else "zlib" — so that a CPU baseline timed with them can say what it was timed on. */
+const char *covh_inflate_backend(void);
 uint64_t covh_bam_stream_n_records(const covh_bam_stream *h);  /* records handed out so far */
 uint64_t covh_bam_stream_peak_bytes(const covh_bam_stream *h); /* largest total of window + batch buffers held */
 void covh_bam_stream_timing(const covh_bam_stream *h, double *out5); /* s: read, inflate, parse, inflate-side wait, parse-side wait */
