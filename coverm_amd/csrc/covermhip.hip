@@ -136,6 +136,26 @@ struct cov_session {
     uint64_t adopted_ncig = 0;
     uint32_t adopted_cig_end = 0;
 
+    // ---- bounded record store.  The reference holds ONE contig's state at a time and flushes when the tid changes (contig.rs:128-155), so it
+    // has no size limit; the store here keeps as many contigs as fit under a cap.  When a push or an extraction would take it past the cap,
+    // the pipeline runs over what the store holds, the contigs that are complete are kept on the host (`spill`), the records from the first
+    // considered record of the contig in flight onwards move to the front, and the session goes on.  cov_finish merges.
+    uint64_t cap_records = 0x80000000ull, cap_cigar = 0x80000000ull;      // COVERM_STORE_CAP_RECORDS / COVERM_STORE_CAP_CIGAR (tests); the hard limit stays 2^32 - 16 each
+    struct Spill {
+        bool active = false;
+        std::vector<cov_contig_stats> stats; std::vector<DevContig> ctg; std::vector<uint8_t> have;     // per target: taken in an earlier spill
+        std::vector<uint64_t> hist;                                       // their histogram bins, stats[c].hist_off indexes this
+        uint64_t prim = 0, cons = 0, records = 0;                         // primaries / considered records / records that left the store
+        int64_t inflight = -1;                                            // contig in flight at the last spill: a later considered contig below it = unsorted
+        uint32_t count = 0;
+        void clear() { active = false; stats.clear(); ctg.clear(); have.clear(); hist.clear(); prim = cons = records = 0; inflight = -1; count = 0; }
+    } spill;
+    std::vector<uint64_t> merged_hist;      // histogram of the last cov_finish when it merged spilled contigs (cov_fetch_hist serves it)
+    bool merged_valid = false;
+    uint64_t merged_records = 0;            // records of the whole sample after a merging finish (cov_gather sends it)
+    DevBuf<uint8_t> d_spill_tmp;
+    uint64_t ing_rec_spilled = 0;           // records of the running ingest that already left the store
+
     DevBuf<uint2> d_runs;
     DevBuf<PrepPartial> d_part;
     DevBuf<double> d_ident, d_identp;
@@ -209,6 +229,8 @@ struct cov_session {
     uint32_t k_launches[COV_K_COUNT] = {};
 };
 
+cov_status spill_store(cov_session *s, bool &progress);      // bounded record store (defined behind finish_once)
+
 namespace {
 
 size_t result_block_bytes(u32 n_targets) { return sizeof(DevGlobal) + (size_t)std::max<u32>(n_targets, 1) * sizeof(DevContig); }
@@ -240,10 +262,17 @@ __global__ void k_rebase_offsets(u32 *off, u32 n, u32 sub, u32 add) {
     if (i < n) off[i] = off[i] - sub + add;
 }
 
+// records [lo, n) with neither the secondary nor the supplementary bit (what num_detected_primary_alignments counts, bam_generator.rs:114-118)
+__global__ void k_count_primary(const uint16_t *__restrict__ flag, u32 lo, u32 n, unsigned long long *out) {
+    u32 cnt = 0;
+    for (u64 i = (u64)lo + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) cnt += (flag[i] & 0x900u) ? 0u : 1u;
+    cnt = wave_sum_u32(cnt);
+    if ((threadIdx.x & 63u) == 0u && cnt) atomicAdd(out, (unsigned long long)cnt);
+}
+
 cov_status append(cov_session *s, const cov_batch *b, bool from_device) {
     const uint64_t n = b->n_records;
     if (n == 0) return COV_OK;
-    if (s->n_records + n >= 0xfffffff0ull) { s->err = "more than 2^32 records in one session"; return COV_ERR_INVALID_ARG; }
     const hipMemcpyKind kind = from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     u32 off0 = 0, offn = 0;
     if (from_device) {
@@ -254,7 +283,14 @@ cov_status append(cov_session *s, const cov_batch *b, bool from_device) {
         off0 = b->cigar_off[0]; offn = b->cigar_off[n];
     }
     const uint64_t ncig = (uint64_t)offn - off0;
-    if (s->n_cigar + ncig >= 0xfffffff0ull) { s->err = "more than 2^32 CIGAR words in one session"; return COV_ERR_INVALID_ARG; }
+    if (s->n_records && (s->n_records + n > s->cap_records || s->n_cigar + ncig > s->cap_cigar)) {
+        // bounded store: the contigs that are complete leave for the host, the contig in flight moves to the front (contig.rs:128-155)
+        bool progress = false;
+        const cov_status sp = spill_store(s, progress);
+        if (sp != COV_OK) return sp;
+    }
+    if (s->n_records + n >= 0xfffffff0ull) { s->err = "more than 2^32 records of one reference (or of one batch) in the record store"; return COV_ERR_INVALID_ARG; }
+    if (s->n_cigar + ncig >= 0xfffffff0ull) { s->err = "more than 2^32 CIGAR words of one reference (or of one batch) in the record store"; return COV_ERR_INVALID_ARG; }
     const uint64_t R = s->n_records, N = R + n;
     hipStream_t st = s->stream;
     HIPCHK(s->s_tid.reserve(N, st, R)); HIPCHK(s->s_pos.reserve(N, st, R)); HIPCHK(s->s_flag.reserve(N, st, R));
@@ -444,6 +480,8 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     if (const char *fw = getenv("COVERM_FAST_WAVES")) s->fast_seven = atoi(fw) != 6;
     if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
+    if (const char *c = getenv("COVERM_STORE_CAP_RECORDS")) { const long long v = atoll(c); if (v >= 1) s->cap_records = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
+    if (const char *c = getenv("COVERM_STORE_CAP_CIGAR")) { const long long v = atoll(c); if (v >= 1) s->cap_cigar = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
     // (every stream costs ~6 ms to create and as much again when the process ends, tools/ubench/exit_probe: the side stream of the
     // identity kernels is created by the first cov_finish that wants it, and borrows the ingest's second stream when there is one)
     e = hipEventCreateWithFlags(&s->ev_prep_done, hipEventDisableTiming);
@@ -622,6 +660,11 @@ cov_status cov_ingest_abort(cov_session *s) {
         if (st) HIPCHK(hipStreamSynchronize(st));
     s->ing_rec_total = s->ing_cig_total = 0; s->ing_round_n = 0; s->ing_fail = 0;
     s->ing_extracted = s->ing_batch;
+    if (s->ing_rec_spilled) {     // the store no longer holds what it held before the ingest: only cov_reset brings the session back
+        s->ing_rec_spilled = 0;
+        s->err = "cov_ingest_abort: part of the file had already left the bounded record store; cov_reset the session";
+        return COV_ERR_STATE;
+    }
     return COV_OK;
 }
 
@@ -629,13 +672,17 @@ cov_status cov_reset(cov_session *s) {
     if (!s) return COV_ERR_INVALID_ARG;
     if (s->ing_active) { const cov_status a = cov_ingest_abort(s); if (a != COV_OK) return a; }
     s->adopted = false; s->n_records = 0; s->n_cigar = 0; s->finished = false; s->depth_all_valid = false; s->mates_valid = 0;
+    s->spill.clear(); s->merged_valid = false; s->merged_hist.clear(); s->ing_rec_spilled = 0;
     return COV_OK;
 }
 
 // Host side of a finished pipeline: error checks in file order, sortedness, DevContig -> cov_contig_stats.  Used for the
 // session's own results and for the blocks cov_gather collected from other ranks.
+// `min_ok_tid` / `rec_base`: the session's own results after a spill (bounded record store) — a considered contig below the contig that
+// was in flight at the last spill breaks the reference's order rule exactly like an interleaving inside one pass, and record indices
+// count from the first record of the sample, not of the store.
 static cov_status convert_results(cov_session *s, const DevGlobal &G, const DevContig *ctg, uint64_t n_records, cov_contig_stats *stats,
-                                  cov_summary *summary) {
+                                  cov_summary *summary, int64_t min_ok_tid = -1, uint64_t rec_base = 0) {
     const u32 nT = s->n_targets;
     const bool want_hist = s->cfg.want & COV_WANT_HIST;
     if (G.internal_error) { s->err = "internal error: depth exceeded its proven bound"; return COV_ERR_STATE; }
@@ -649,6 +696,7 @@ static cov_status convert_results(cov_session *s, const DevGlobal &G, const DevC
         for (u32 c = 0; c < nT; c++) {
             const DevContig &C = ctg[c];
             if (C.n_pass == 0) continue;
+            if ((int64_t)c < min_ok_tid) unsorted_at = std::min<uint64_t>(unsorted_at, C.first_rec);      // tid < last_tid across a spill (contig.rs:129-132)
             if (any && C.first_rec < prev_last) unsorted_at = std::min<uint64_t>(unsorted_at, std::max<uint64_t>(C.first_rec, 0));
             prev_last = any ? std::max<uint64_t>(prev_last, C.last_rec) : C.last_rec;
             any = true;
@@ -665,7 +713,7 @@ static cov_status convert_results(cov_session *s, const DevGlobal &G, const DevC
                          : err_code == 4 ? "aligned block starts at or beyond the end of its reference sequence"
                          : err_code == 7 ? "record refers to a reference id outside the header (Corrupt BAM file?)"
                                          : "invalid CIGAR operation";
-        snprintf(b, sizeof b, "%s (record %llu)", what, (unsigned long long)err_rec);
+        snprintf(b, sizeof b, "%s (record %llu)", what, (unsigned long long)(err_rec + rec_base));
         s->err = b;
         return (cov_status)err_code;
     }
@@ -680,6 +728,7 @@ static cov_status convert_results(cov_session *s, const DevGlobal &G, const DevC
         o.sum_identity_primary = C.id_primary; o.sum_identity_nonsupp = C.id_nonsupp;
         o.win_sum_d = C.sum_d; o.win_sum_d2 = C.sum_d2; o.win_covered = C.cov_win; o.full_covered = C.cov_full;
         o.first_record = C.first_rec; o.last_record = C.last_rec;
+        if (C.n_pass) { o.first_record += rec_base; o.last_record += rec_base; }
         const u64 L = s->h_tlen[c];
         const u64 win_len = 2 * excl < L ? L - 2 * excl : 0;
         if (C.n_pass && win_len) {
@@ -701,14 +750,24 @@ static cov_status convert_results(cov_session *s, const DevGlobal &G, const DevC
 
 static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summary *summary, bool &again);
 
-cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summary) {
-    covr::Range rr("cov_finish");
-    // The buckets of long-CIGAR records are sized optimistically: a pass that finds them too small has already
-    // computed the exact need, grows the buffer and runs once more (at most once per growth of the workload).
+// The pipeline over what the store holds.  The buckets of long-CIGAR records are sized optimistically: a pass that finds them too
+// small has already computed the exact need, grows the buffer and runs once more (at most once per growth of the workload).
+static cov_status finish_store(cov_session *s, cov_contig_stats *stats, cov_summary *summary) {
     bool again = false;
     cov_status st = finish_once(s, stats, summary, again);
     if (st == COV_OK && again) st = finish_once(s, stats, summary, again);
     if (st == COV_OK && again) { s->err = "internal error: bucket sizing did not converge"; return COV_ERR_STATE; }
+    return st;
+}
+
+static cov_status merge_spilled(cov_session *s, cov_contig_stats *stats, cov_summary *summary);
+
+cov_status cov_finish(cov_session *s, cov_contig_stats *stats, cov_summary *summary) {
+    covr::Range rr("cov_finish");
+    if (s) s->merged_valid = false;
+    cov_summary local;
+    cov_status st = finish_store(s, stats, (s && s->spill.active && !summary) ? &local : summary);
+    if (st == COV_OK && s->spill.active) st = merge_spilled(s, stats, summary ? summary : &local);
     return st;
 }
 
@@ -901,11 +960,142 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         s->algo_bytes = (uint64_t)R * 24 + ncig * 4 + (uint64_t)nT * sizeof(DevContig);
     }
 
-    const cov_status cst = convert_results(s, s->h_glob, s->h_ctg, R, stats, summary);
+    const cov_status cst = convert_results(s, s->h_glob, s->h_ctg, R, stats, summary, s->spill.inflight, s->spill.records);
     if (cst != COV_OK) return cst;
     s->last_chist_total = want_hist ? s->h_glob.chist_total : 0;
     s->hist_compacted = want_hist && R != 0;
     s->finished = true;
+    return COV_OK;
+}
+
+
+// ---- bounded record store: spill and merge (see cov_session::spill)
+static cov_status fetch_chunk_hist(cov_session *s, uint64_t *hist);
+
+extern "C++" {
+namespace {
+template <typename T>
+cov_status move_front(cov_session *s, T *p, size_t from, size_t n) {
+    if (!n || !from) return COV_OK;
+    hipStream_t st = s->stream;
+    if (n <= from) { HIPCHK(hipMemcpyAsync(p, p + from, n * sizeof(T), hipMemcpyDeviceToDevice, st)); return COV_OK; }      // disjoint
+    HIPCHK(s->d_spill_tmp.reserve(n * sizeof(T), st));
+    HIPCHK(hipMemcpyAsync(s->d_spill_tmp.p, p + from, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(p, s->d_spill_tmp.p, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+    return COV_OK;
+}
+
+// Runs the pipeline over the store, keeps every contig but the one in flight, moves the records from that contig's first considered
+// record onwards to the front.  The contig in flight = the last considered contig (after the order check: the highest tid with a
+// considered record); every considered record behind its first one is its own (anything else would have failed the order check),
+// so the contigs in front of it are complete — the reference would have flushed them at the tid change (contig.rs:128-155).
+// progress = false: nothing could leave (one contig fills the store, or the store is an adopted batch / carries mate columns).
+cov_status spill_store_impl(cov_session *s, bool &progress) {
+    progress = false;
+    if (s->adopted || s->n_records == 0 || s->want_mates || s->n_targets == 0) return COV_OK;
+    covr::Range rr("bounded store: spill");
+    const u32 nT = s->n_targets;
+    const bool want_hist = s->cfg.want & COV_WANT_HIST;
+    std::vector<cov_contig_stats> st(nT);
+    cov_summary sm{};
+    cov_status rc = finish_store(s, st.data(), &sm);
+    if (rc != COV_OK) return rc;
+    const u64 R = s->n_records;
+    cov_session::Spill &S = s->spill;
+    int64_t cstar = -1; u64 best = 0;
+    for (u32 c = 0; c < nT; c++)
+        if (st[c].n_pass && (cstar < 0 || st[c].last_record >= best)) { cstar = c; best = st[c].last_record; }
+    const u64 keep_from = cstar >= 0 ? st[cstar].first_record - S.records : R;      // (record indices come back counted from the sample's first record)
+    if (keep_from == 0) { s->finished = false; return COV_OK; }
+    if (!S.active) { S.stats.assign(nT, cov_contig_stats{}); S.ctg.assign(nT, DevContig{}); S.have.assign(nT, 0); S.active = true; }
+    std::vector<uint64_t> h;
+    if (want_hist && sm.hist_total) { h.resize(sm.hist_total); rc = fetch_chunk_hist(s, h.data()); if (rc != COV_OK) return rc; }
+    for (u32 c = 0; c < nT; c++) {
+        if ((int64_t)c == cstar || !st[c].n_pass) continue;
+        if (S.have[c]) { s->err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)"; return COV_ERR_UNSORTED; }
+        S.stats[c] = st[c]; S.ctg[c] = s->h_ctg[c]; S.have[c] = 1;
+        if (want_hist && st[c].hist_len) {
+            S.stats[c].hist_off = S.hist.size();
+            S.hist.insert(S.hist.end(), h.begin() + st[c].hist_off, h.begin() + st[c].hist_off + st[c].hist_len);
+        }
+    }
+    hipStream_t q = s->stream;
+    u64 prim_keep = 0;
+    u32 c0 = (u32)s->n_cigar;
+    if (keep_from < R) {
+        unsigned long long *ctr = reinterpret_cast<unsigned long long *>(&s->d_glob.p->pad2[1]);
+        HIPCHK(hipMemsetAsync(ctr, 0, 8, q));
+        hipLaunchKernelGGL(k_count_primary, dim3((u32)std::min<u64>((R - keep_from + 255) / 256, (u64)s->n_cus * 8)), dim3(256), 0, q, (const uint16_t *)s->s_flag.p, (u32)keep_from, (u32)R, ctr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&prim_keep, ctr, 8, hipMemcpyDeviceToHost, q));
+        HIPCHK(hipMemcpyAsync(&c0, s->s_coff.p + keep_from, 4, hipMemcpyDeviceToHost, q));
+        HIPCHK(hipStreamSynchronize(q));
+    }
+    S.prim += sm.num_detected_primary_alignments - prim_keep;
+    S.cons += sm.n_considered - (cstar >= 0 ? st[cstar].n_pass : 0);
+    S.records += keep_from;
+    if (cstar > S.inflight) S.inflight = cstar;
+    S.count++;
+    const u64 n_keep = R - keep_from, cig_keep = s->n_cigar - c0;
+    cov_status m = COV_OK;
+    if ((m = move_front(s, s->s_tid.p, keep_from, n_keep)) || (m = move_front(s, s->s_pos.p, keep_from, n_keep)) || (m = move_front(s, s->s_flag.p, keep_from, n_keep)) ||
+        (m = move_front(s, s->s_mapq.p, keep_from, n_keep)) || (m = move_front(s, s->s_nmk.p, keep_from, n_keep)) || (m = move_front(s, s->s_nm.p, keep_from, n_keep)) ||
+        (m = move_front(s, s->s_lseq.p, keep_from, n_keep)) || (m = move_front(s, s->s_coff.p, keep_from, n_keep + 1)) || (m = move_front(s, s->s_cig.p, c0, cig_keep)))
+        return m;
+    if (n_keep && c0) {
+        hipLaunchKernelGGL(k_rebase_offsets, dim3((u32)((n_keep + 1 + 255) / 256)), dim3(256), 0, q, s->s_coff.p, (u32)(n_keep + 1), c0, 0u);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(q));
+    s->n_records = n_keep; s->n_cigar = cig_keep;
+    s->finished = false; s->depth_all_valid = false;
+    if (getenv("COVERM_CLI_TIMING"))
+        fprintf(stderr, "[covermhip] bounded store: spill %u, %llu records left the store (%llu stay: contig %lld in flight), %llu since the sample began\n", S.count,
+                (unsigned long long)keep_from, (unsigned long long)n_keep, (long long)cstar, (unsigned long long)S.records);
+    progress = true;
+    return COV_OK;
+}
+}  // namespace
+cov_status spill_store(cov_session *s, bool &progress) { return spill_store_impl(s, progress); }
+}  // extern "C++"
+
+// cov_finish after one or more spills: `stats` / `summary` hold the pass over what the store still held; the contigs that left
+// earlier come back from the host, the histogram is re-based into one array (cov_fetch_hist serves it), and the device's result
+// block is rewritten as the merged one so that cov_gather sends the whole sample.
+static cov_status merge_spilled(cov_session *s, cov_contig_stats *stats, cov_summary *summary) {
+    cov_session::Spill &S = s->spill;
+    const u32 nT = s->n_targets;
+    const bool want_hist = s->cfg.want & COV_WANT_HIST;
+    std::vector<uint64_t> h;
+    if (want_hist && summary->hist_total) { h.resize(summary->hist_total); const cov_status rc = fetch_chunk_hist(s, h.data()); if (rc != COV_OK) return rc; }
+    s->merged_hist = S.hist;
+    std::vector<DevContig> m(nT);
+    u32 rank = 0;
+    for (u32 c = 0; c < nT; c++) {
+        if (S.have[c]) {
+            if (stats[c].n_pass) { s->err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)"; return COV_ERR_UNSORTED; }
+            stats[c] = S.stats[c]; m[c] = S.ctg[c];
+        } else {
+            m[c] = s->h_ctg[c];
+            if (want_hist && stats[c].hist_len) {
+                const u64 off = s->merged_hist.size();
+                s->merged_hist.insert(s->merged_hist.end(), h.begin() + stats[c].hist_off, h.begin() + stats[c].hist_off + stats[c].hist_len);
+                stats[c].hist_off = off;
+            }
+        }
+        m[c].chist_off = stats[c].hist_off; m[c].hist_len = stats[c].hist_len;
+        // the block a peer converts (cov_gathered) judges the order from first_rec / last_rec: the merged block carries the contigs' ranks
+        if (m[c].n_pass) { m[c].first_rec = m[c].last_rec = rank++; }
+    }
+    summary->num_detected_primary_alignments += S.prim; summary->n_records += S.records; summary->n_considered += S.cons;
+    summary->hist_total = s->merged_hist.size();
+    s->merged_valid = true; s->merged_records = summary->n_records;
+    DevGlobal g = s->h_glob;
+    g.prim_slots[0] += S.prim; g.cons_slots[0] += S.cons; g.chist_total = s->merged_hist.size();
+    HIPCHK(hipSetDevice(s->cfg.device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(s->d_res.p, &g, sizeof g, hipMemcpyHostToDevice));
+    if (nT) HIPCHK(hipMemcpy(s->d_res.p + sizeof(DevGlobal), m.data(), (size_t)nT * sizeof(DevContig), hipMemcpyHostToDevice));
     return COV_OK;
 }
 
@@ -970,7 +1160,7 @@ cov_status cov_gather(cov_session *const *sessions, uint32_t n, uint32_t root) {
     }
     for (u32 i = 0; i < n; i++) {   // the record count of each rank travels in its block (a padding word of DevGlobal)
         HIPCHK(hipSetDevice(devs[i]));
-        const u64 nr = sessions[i]->n_records;
+        const u64 nr = sessions[i]->merged_valid ? sessions[i]->merged_records : sessions[i]->n_records;
         HIPCHK(hipMemcpyAsync(&sessions[i]->d_glob.p->pad2[0], &nr, 8, hipMemcpyHostToDevice, sessions[i]->stream));
         HIPCHK(hipStreamSynchronize(sessions[i]->stream));
     }
@@ -1082,7 +1272,7 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
         if (a) return a;
     }
     HIPCHK(hipStreamSynchronize(s->stream));     // the record store is about to be written from the parse stream
-    s->ing_batch = 0; s->ing_extracted = 0; s->ing_rec_total = s->ing_cig_total = 0; s->ing_fail = 0;
+    s->ing_batch = 0; s->ing_extracted = 0; s->ing_rec_total = s->ing_cig_total = 0; s->ing_fail = 0; s->ing_rec_spilled = 0;
     s->ing_K = choose_inflate_kernel(s);      // (also sets the kernel's dynamic-LDS limit on this session's device)
     s->ing_first_record = first_record_offset;
     s->ing_check_crc = (check_crc && !getenv("COVERM_NO_CRC")) ? 1 : 0;
@@ -1132,7 +1322,21 @@ static cov_status ingest_drain_(cov_session *s, int64_t must_upto) {
         const bool span = s->ing_key_lo > 0 || s->ing_key_hi < 0x80000000ll || s->ing_search_first || s->ing_open_end;
         if (!span && !s->want_mates) st &= ~64u;       // whole file: cov_finish reports disorder in file order, beside the other per-record errors
         if (st && !s->ing_fail) { s->ing_fail = st; s->ing_fail_dbg[0] = res[4]; s->ing_fail_dbg[1] = res[5]; s->ing_fail_dbg[2] = res[6]; }
-        const u64 R = s->n_records + s->ing_rec_total, Cg = s->n_cigar + s->ing_cig_total;
+        u64 R = s->n_records + s->ing_rec_total, Cg = s->n_cigar + s->ing_cig_total;
+        if (!s->ing_fail && nrec && R && !s->want_mates && (R + nrec > s->cap_records || Cg + ncig > s->cap_cigar)) {
+            // bounded store: what has been extracted so far becomes the store's content, the pipeline runs over it, the complete contigs
+            // leave for the host and the contig in flight moves to the front; this window's records follow it
+            HIPCHK(hipStreamSynchronize(ps));
+            const u32 end_off = (u32)Cg;
+            HIPCHK(hipMemcpyAsync(s->s_coff.p + R, &end_off, sizeof end_off, hipMemcpyHostToDevice, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+            s->n_records = R; s->n_cigar = Cg;
+            s->ing_rec_spilled += s->ing_rec_total; s->ing_rec_total = 0; s->ing_cig_total = 0;
+            bool progress = false;
+            const cov_status sp = spill_store(s, progress);
+            if (sp != COV_OK) return sp;
+            R = s->n_records; Cg = s->n_cigar;
+        }
         if (!s->ing_fail && (R + nrec >= 0xfffffff0ull || Cg + ncig >= 0xfffffff0ull)) s->ing_fail = 16u;
         if (!s->ing_fail && nrec) {
             u64 Nn = R + nrec, Cn = Cg + ncig + 1;
@@ -1143,7 +1347,9 @@ static cov_status ingest_drain_(cov_session *s, int64_t must_upto) {
             if (w == 0 && s->ing_win[0].comp_end && s->ing_win[0].comp_end + 65536u < s->ing_span_hi) {
                 const double scale = (double)(s->ing_span_hi - s->ing_span_lo) / (double)std::max<u64>(1, s->ing_win[0].comp_end - std::min<u64>(s->ing_win[0].comp_end, s->ing_span_lo)) * 1.1;
                 Nn = std::max<u64>(Nn, R + (u64)((double)nrec * scale) + 1024); Cn = std::max<u64>(Cn, Cg + (u64)((double)ncig * scale) + 1024);
-                Nn = std::min<u64>(Nn, 0xfffffff0ull); Cn = std::min<u64>(Cn, 0xfffffff0ull);
+                // (never beyond the store's cap: what would lie behind it is spilled before it is written)
+                Nn = std::max<u64>(R + nrec, std::min<u64>(Nn, std::min<u64>(s->cap_records + 1024, 0xfffffff0ull)));
+                Cn = std::max<u64>(Cg + ncig + 1, std::min<u64>(Cn, std::min<u64>(s->cap_cigar + 1024, 0xfffffff0ull)));
             }
             const auto ta0 = std::chrono::steady_clock::now();
             HIPCHK(s->s_tid.reserve(Nn, ps, R)); HIPCHK(s->s_pos.reserve(Nn, ps, R)); HIPCHK(s->s_flag.reserve(Nn, ps, R));
@@ -1372,7 +1578,19 @@ cov_status cov_ingest_feed(cov_session *s, int slot, const void *host_bytes, uin
     return COV_OK;
 }
 
+static cov_status ingest_end_(cov_session *s, uint64_t *n_records_out);
 cov_status cov_ingest_end(cov_session *s, uint64_t *n_records_out) {
+    const cov_status rc = ingest_end_(s, n_records_out);
+    if (s && s->ing_rec_spilled) {
+        if (rc == COV_OK && n_records_out) *n_records_out += s->ing_rec_spilled;
+        if (rc == COV_ERR_INGEST_FALLBACK) {     // "nothing was appended" no longer holds: part of the file is already in the spilled results
+            s->err += " (after part of the file had left the bounded record store: it cannot be handed to the CPU reader on this session any more)";
+            return COV_ERR_STATE;
+        }
+    }
+    return rc;
+}
+static cov_status ingest_end_(cov_session *s, uint64_t *n_records_out) {
     if (!s || !s->ing_active) return COV_ERR_INVALID_ARG;
     covr::Range rr("ingest: last rounds + parse (cov_ingest_end)");
     s->ing_active = false;
@@ -1403,7 +1621,7 @@ cov_status cov_ingest_end(cov_session *s, uint64_t *n_records_out) {
             s->err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)";
             return COV_ERR_UNSORTED;
         }
-        s->err = (f & 16u) ? "more than 2^32 records in one session"
+        s->err = (f & 16u) ? "more than 2^32 records or CIGAR words of one reference in the record store"
                : (f & 32u) ? "device ingest: the BAM header is longer than the first window of the inflated stream (handing the file to the CPU reader)"
                : (f & 4u) ? "device ingest: a record keeps its CIGAR in CG:B,I (handing the file to the CPU reader)"
                : (f & 8u) ? "device ingest: a record larger than the carry buffer between windows (handing the file to the CPU reader)"
@@ -1449,6 +1667,7 @@ cov_status cov_pair_filter_apply(cov_session *s, const cov_pair_filter *f, uint6
     if (!s || !f) return COV_ERR_INVALID_ARG;
     covr::Range rr("pair filter (cov_pair_filter_apply)");
     if (s->adopted || s->ing_active) { s->err = "cov_pair_filter_apply: needs the session's own record store, filled by the device ingest"; return COV_ERR_STATE; }
+    if (s->spill.active) { s->err = "cov_pair_filter_apply: part of the sample's records already left the bounded record store"; return COV_ERR_STATE; }
     if (s->mates_valid != s->n_records) { s->err = "cov_pair_filter_apply: the store holds records without mate columns (cov_ingest_want_mates before every ingest, no cov_push_batch)"; return COV_ERR_STATE; }
     HIPCHK(hipSetDevice(s->cfg.device));
     hipStream_t st = s->stream;
@@ -1616,6 +1835,7 @@ cov_status cov_pair_filter_apply(cov_session *s, const cov_pair_filter *f, uint6
 // n_records entries, n_records + 1 cigar offsets, n_cigar words; *n_cigar receives the word count when words are not wanted).
 cov_status cov_copy_records(cov_session *s, const cov_batch *host, uint64_t *n_records, uint64_t *n_cigar) {
     if (!s || s->adopted) return COV_ERR_STATE;
+    if (s->spill.active) { s->err = "cov_copy_records: part of the sample's records already left the bounded record store"; return COV_ERR_STATE; }
     HIPCHK(hipSetDevice(s->cfg.device));
     if (n_records) *n_records = s->n_records;
     if (n_cigar) *n_cigar = s->n_cigar;
@@ -1661,6 +1881,19 @@ cov_status cov_ingest_copy_inflated(cov_session *s, uint64_t offset, uint64_t n,
 
 cov_status cov_fetch_hist(cov_session *s, uint64_t *hist) {
     if (!s || !s->finished || !(s->cfg.want & COV_WANT_HIST)) return COV_ERR_STATE;
+    if (s->merged_valid) {      // a finish that merged spilled contigs (bounded record store): the bins were re-based on the host
+        s->hist_fetch_seen = true;
+        if (s->merged_hist.empty()) return COV_OK;
+        if (!hist) return COV_ERR_INVALID_ARG;
+        memcpy(hist, s->merged_hist.data(), s->merged_hist.size() * 8);
+        return COV_OK;
+    }
+    return fetch_chunk_hist(s, hist);
+}
+
+// the compact histogram of the last pass over the store
+static cov_status fetch_chunk_hist(cov_session *s, uint64_t *hist) {
+    if (!s || !s->finished || !(s->cfg.want & COV_WANT_HIST)) return COV_ERR_STATE;
     HIPCHK(hipSetDevice(s->cfg.device));
     const uint64_t total = s->h_glob.chist_total;
     s->hist_fetch_seen = true;
@@ -1684,6 +1917,7 @@ cov_status cov_fetch_hist(cov_session *s, uint64_t *hist) {
 
 cov_status cov_copy_depth(cov_session *s, uint32_t tid, int32_t *depth_out) {
     if (!s || !s->finished) return COV_ERR_STATE;
+    if (s->spill.active) { s->err = "cov_copy_depth: part of the sample's records already left the bounded record store"; return COV_ERR_STATE; }
     if (tid >= s->n_targets || !depth_out) return COV_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(s->cfg.device));
     const u32 L = s->h_tlen[tid];
@@ -1710,6 +1944,7 @@ cov_status cov_copy_depth(cov_session *s, uint32_t tid, int32_t *depth_out) {
 cov_status cov_interval_stats_compute(cov_session *s, const cov_interval *iv, uint64_t n, uint64_t excl, int want_hist,
                                       cov_interval_stats *out, uint64_t *hist_total) {
     if (!s || !s->finished) return COV_ERR_STATE;
+    if (s->spill.active) { s->err = "cov_interval_stats_compute: part of the sample's records already left the bounded record store (per-gene coverage needs them all: raise COVERM_STORE_CAP_*)"; return COV_ERR_STATE; }
     if ((n && (!iv || !out))) return COV_ERR_INVALID_ARG;
     if (hist_total) *hist_total = 0;
     s->ivhist_total = 0;
@@ -1783,6 +2018,8 @@ cov_status cov_kernel_ms(const cov_session *s, cov_kernel_id k, double *ms_total
     if (launches) *launches = s->k_launches[k];
     return COV_OK;
 }
+
+uint32_t cov_store_spills(const cov_session *s) { return s ? s->spill.count : 0u; }
 
 cov_status cov_algorithmic_bytes(const cov_session *s, uint64_t *bytes) {
     if (!s || !bytes) return COV_ERR_INVALID_ARG;

@@ -272,6 +272,18 @@ cov_status cov_kernel_ms(const cov_session *s, cov_kernel_id k, double *ms_total
  * words read once, plus result structs written. */
 cov_status cov_algorithmic_bytes(const cov_session *s, uint64_t *bytes);
 
+/* ---- bounded record store.  The reference holds one contig at a time and flushes it when the tid changes (contig.rs:128-155), so a
+ * sample may be arbitrarily large.  The session's record store keeps as many contigs as fit under a cap (2^31 records / 2^31 CIGAR
+ * words by default; COVERM_STORE_CAP_RECORDS / COVERM_STORE_CAP_CIGAR, read by cov_create).  When cov_push_batch, cov_push_batch_device
+ * or the device ingest would take it past the cap, the pipeline runs over what the store holds, the contigs that are complete stay on
+ * the host, the records from the first considered record of the contig in flight onwards move to the front of the store and the call
+ * goes on ("a spill"); cov_finish / cov_fetch_hist / cov_gather then return the whole sample (record indices count from the sample's first
+ * record).  What remains: ONE reference's records must fit (2^32 - 16 records and CIGAR words); after a spill cov_copy_depth,
+ * cov_interval_stats_compute, cov_copy_records and cov_pair_filter_apply return COV_ERR_STATE (they need every record) and a device ingest
+ * that has to hand its file to the CPU reader fails with COV_ERR_STATE instead of COV_ERR_INGEST_FALLBACK; a store that carries mate
+ * columns (cov_ingest_want_mates) or an adopted device batch is never spilled.  cov_store_spills: spills since the last cov_reset. */
+uint32_t cov_store_spills(const cov_session *s);
+
 
 /* ---- per-interval statistics (per-gene coverage, the reference's src/genes.rs:508-535).  After cov_finish: the depth of
  * every target is materialised once in HBM (4 B per base, kept until the next push / reset / finish) and each interval

@@ -36,6 +36,14 @@ def argv(mode, paths, threads=8, devices=None, **kw):
     return v
 
 
+def run_full(mode, paths, env=None, timeout=900, **kw):
+    """The completed process (stdout = the table, stderr = the run's log); raises with stderr when the binary fails."""
+    r = subprocess.run(argv(mode, paths, **kw), capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
+    if r.returncode != 0:
+        raise RuntimeError("coverm-amd failed (%d): %s" % (r.returncode, r.stderr[-3000:]))
+    return r
+
+
 def run(mode, paths, env=None, timeout=900, **kw):
     """stdout of the run; raises with stderr when the binary fails."""
     r = subprocess.run(argv(mode, paths, **kw), capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
