@@ -10,8 +10,9 @@ Workload (BASELINE.json configs[1] at N = 1; configs[3] shape — one BAM per GP
 `value` is measured on basis (i) below, as the bench contract prescribes (inputs resident in HBM when the clock starts); the same
 JSON line carries the two wider bases, each beside a CPU figure taken on the SAME basis (`bases`):
 
-  (i)   device_resident  one step = cov_finish (filter + CIGAR expansion + LDS pileup + statistics on the GPU) + histogram fetch +
-                         C++ finalisation of every estimator for every contig; CPU = oracle scan over records in host memory
+  (i)   device_resident  one step = cov_finish (filter + CIGAR expansion + LDS pileup + statistics + every estimator's calculate_coverage
+                         for every contig, all on the GPU) + fetch of the floats + the C++ scan loop's control flow (zero rows, ReadsMapped,
+                         taker); --host-estimates: histogram fetch + C++ calculate_coverage instead; CPU = oracle scan over records in host memory
   (ii)  push_inclusive   records in page-locked HOST memory -> cov_push_batch -> cov_finish -> fetch -> finalise; CPU = the same scan
   (iii) end_to_end       BAM FILE -> TSV through the coverm-amd binary (streamed ingest) on a realistic-entropy BAM (random bases,
                          Phred-like qualities) of BASELINE config 5's size and flags; CPU = the same decoder (t threads) + oracle scan
@@ -196,10 +197,12 @@ def pinned_copy(batch):
     return RecordBatch(**out), ptrs
 
 
-def finalise(ref, est, stats, summ, hist, name="sample0"):
+def finalise(ref, est, stats, summ, hist, name="sample0", estimates=None):
+    """contig.rs:40-104 over one sample's device results: zero rows, ReadsMapped, the taker.  `estimates`: calculate_coverage already
+    evaluated on the device (Session.estimates()), else the host evaluates it from the integer statistics + histogram."""
     taker = host.CoverageTaker.new_cached_single_float_coverage_taker(len(est))
     sample = host.SampleResult(name, stats, hist, int(summ.num_detected_primary_alignments))
-    rm = host.contig_coverage(ref.names, ref.lengths, [sample], taker, est, True)
+    rm = host.contig_coverage(ref.names, ref.lengths, [sample], taker, est, True, estimates=None if estimates is None else [estimates])
     return taker, rm
 
 
@@ -458,6 +461,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-level6", action="store_true", help="skip the second end-to-end line (same records written at BGZF level 6)")
     ap.add_argument("--no-binary-legs", action="store_true", help="skip configs 2 / 3 at full size through the coverm-amd binary")
+    ap.add_argument("--host-estimates", action="store_true", help="evaluate calculate_coverage on the host from the integer statistics + histogram (the path before cov_set_estimators), for A/B")
     ap.add_argument("--no-multi-device-e2e", action="store_true", help="N > 1: skip the coverm-amd --devices legs (configs 4 and 5 through the product's multi-GPU path)")
     ap.add_argument("--tmp", default=os.environ.get("COVERM_BENCH_TMP", default_tmp()),
                     help="where the end-to-end leg writes its BAM (default: /dev/shm when it has room, so that storage speed is not part of the figure)")
@@ -515,14 +519,21 @@ def main():
     want_hist, want_id = host.wants(est)
     sess = Session(local_rank, FilterConfig(), 75, want_hist, want_id)
     sess.set_targets(ref.lengths)
+    dev_est = not a.host_estimates
+    if dev_est:
+        sess.set_estimators(est)      # CoverageEstimator::calculate_coverage of every contig inside cov_finish (k_estimate)
     sess.push_device(dt, batch.n_records)
     n_cov = len(ref.lengths) * len(est)
     gather_buf = [torch.empty(n_cov, dtype=torch.float32, device=xdev) for _ in range(world)] if (dist and rank == 0) else None
 
     def step():
         stats, summ = sess.finish()
-        hist = sess.hist()
-        taker, rm = finalise(ref, est, stats, summ, hist, "sample%d" % rank)
+        if dev_est:
+            hist = None
+            taker, rm = finalise(ref, est, stats, summ, None, "sample%d" % rank, estimates=sess.estimates())
+        else:
+            hist = sess.hist()
+            taker, rm = finalise(ref, est, stats, summ, hist, "sample%d" % rank)
         if dist:
             # per-contig coverages of this sample -> rank 0 (one gather over RCCL/xGMI)
             cov = taker.cached_coverages(0)   # n_contigs x n_estimators f32, contig order (zeros printed)
@@ -556,6 +567,8 @@ def main():
     else:
         total_reads = considered
     gpu_cov = taker.cached_coverages(0)
+    if hist is None:
+        hist = sess.hist()        # (for the parity check of the integer statistics: the step itself no longer needs the bins on the host)
     pipe_bytes = sess.algorithmic_bytes()
     n_tiles = sess_tiles(sess, ref)
     sess.close()
@@ -604,6 +617,7 @@ def main():
             "value": total_reads * a.steps / elapsed, "unit": "aligned reads/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32 depth / u64 sums / f32 estimators", "data": "synthetic",
+            "estimators_evaluated_on": "device (k_estimate inside cov_finish: the reference's f32 expressions, one rounding per operation; floats checked bit for bit against the oracle in parity_checked)" if dev_est else "host (csrc/host_coverage.cpp calculate)",
             "value_basis": "(i) device_resident: records already in HBM when the clock starts (bench contract); bases (ii) and (iii) below include the host side",
             "config": {"workload": "coverm contig, %d-read synthetic sorted BAM over %d contigs (%.2f Gbp) per GPU, "
                                    "--methods %s, records resident in HBM" % (a.reads, a.contigs,
@@ -632,6 +646,8 @@ def main():
             hb, ptrs = pinned_copy(batch)
             s2 = Session(local_rank, FilterConfig(), 75, want_hist, want_id)
             s2.set_targets(ref.lengths)
+            if dev_est:
+                s2.set_estimators(est)
             push_s = []
             for it in range(4):
                 torch.cuda.synchronize()
@@ -639,8 +655,10 @@ def main():
                 s2.reset()
                 s2.push(hb)
                 st2, su2 = s2.finish()
-                h2 = s2.hist()
-                finalise(ref, est, st2, su2, h2)
+                if dev_est:
+                    finalise(ref, est, st2, su2, None, estimates=s2.estimates())
+                else:
+                    finalise(ref, est, st2, su2, s2.hist())
                 push_s.append(time.perf_counter() - t0)
             s2.close()
             L = native.lib()

@@ -34,6 +34,8 @@ static_assert(sizeof(cov_contig_stats) == 128 && offsetof(cov_contig_stats, sum_
               offsetof(cov_contig_stats, hist_off) == 120, "cov_contig_stats layout");
 static_assert(sizeof(cov_summary) == 32 && offsetof(cov_summary, hist_total) == 24, "cov_summary layout");
 static_assert(sizeof(cov_interval) == 24 && sizeof(cov_interval_stats) == 56, "interval struct layout");
+static_assert(sizeof(cov_estimator) == sizeof(covk::DevEstimator) && offsetof(cov_estimator, contig_end_exclusion) == offsetof(covk::DevEstimator, excl) &&
+              offsetof(cov_estimator, trim_max) == offsetof(covk::DevEstimator, trim_max) && COV_EST_MAX == covk::EST_MAX && COV_EST_ANIR == covk::EST_ANIR, "cov_estimator mirrors the device struct");
 
 namespace {
 
@@ -91,6 +93,8 @@ struct cov_session {
     int stream_rows = 4;   // > 0: wave-per-tile kernels (1024-base tiles); 0: k_pileup workgroup-per-tile (COVERM_PILEUP=tile)
     bool use_fast = true;  // k_pileup_fast + k_pileup_stream on the slow-tile list (default); COVERM_PILEUP=stream: k_pileup_stream alone
     int chunk_tiles = 8;   // consecutive tiles walked by one wave (COVERM_CHUNK)
+    int prep_v = 2;        // k_prep2 (adjacent pairs per lane) where its conditions hold, else k_prep; COVERM_PREP_V=1: k_prep everywhere
+    int prep_waves = 0;    // COVERM_PREP_WAVES=6 | 8: the amdgpu_waves_per_eu builds (measurement switch)
     bool fast_seven = true;    // k_pileup_fast7 (384 LDS bins, seven waves per SIMD: the default) or k_pileup_fast (512 bins, six; COVERM_FAST_WAVES=6)
     int n_cus = 256;
     uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
@@ -150,6 +154,10 @@ struct cov_session {
         uint32_t count = 0;
         void clear() { active = false; stats.clear(); ctg.clear(); have.clear(); hist.clear(); prim = cons = records = 0; inflight = -1; count = 0; }
     } spill;
+    // CoverageEstimator::calculate_coverage on the device (cov_set_estimators): parameters, device rows, page-locked copy of the last finish
+    EstParams est{};
+    DevBuf<float> d_estf; float *h_estf = nullptr; size_t h_estf_cap = 0; bool est_valid = false;
+    std::vector<float> spill_est;           // rows of the contigs that left in a spill (n_targets x est.n, filled as they leave)
     std::vector<uint64_t> merged_hist;      // histogram of the last cov_finish when it merged spilled contigs (cov_fetch_hist serves it)
     bool merged_valid = false;
     uint64_t merged_records = 0;            // records of the whole sample after a merging finish (cov_gather sends it)
@@ -478,6 +486,8 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
     if (const char *fw = getenv("COVERM_FAST_WAVES")) s->fast_seven = atoi(fw) != 6;
+    if (const char *pv = getenv("COVERM_PREP_V")) s->prep_v = atoi(pv) == 1 ? 1 : 2;
+    if (const char *pw = getenv("COVERM_PREP_WAVES")) s->prep_waves = atoi(pw);
     if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
     if (const char *c = getenv("COVERM_STORE_CAP_RECORDS")) { const long long v = atoll(c); if (v >= 1) s->cap_records = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
@@ -540,6 +550,8 @@ void cov_destroy(cov_session *s) {
     s->h_res = nullptr; s->h_res_cap = 0; s->h_ctg = nullptr;
     if (s->h_chist) (void)hipHostFree(s->h_chist);
     s->h_chist = nullptr; s->h_chist_cap = 0;
+    if (s->h_estf) (void)hipHostFree(s->h_estf);
+    s->h_estf = nullptr; s->h_estf_cap = 0; s->d_estf.release(); s->d_spill_tmp.release();
     s->s_tid.release(); s->s_pos.release(); s->s_flag.release(); s->s_mapq.release(); s->s_nmk.release();
     s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
     s->s_mtid.release(); s->s_qh1.release(); s->s_qh2.release();
@@ -672,7 +684,7 @@ cov_status cov_reset(cov_session *s) {
     if (!s) return COV_ERR_INVALID_ARG;
     if (s->ing_active) { const cov_status a = cov_ingest_abort(s); if (a != COV_OK) return a; }
     s->adopted = false; s->n_records = 0; s->n_cigar = 0; s->finished = false; s->depth_all_valid = false; s->mates_valid = 0;
-    s->spill.clear(); s->merged_valid = false; s->merged_hist.clear(); s->ing_rec_spilled = 0;
+    s->spill.clear(); s->merged_valid = false; s->merged_hist.clear(); s->ing_rec_spilled = 0; s->spill_est.clear(); s->est_valid = false;
     return COV_OK;
 }
 
@@ -782,6 +794,8 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     const u32 R = (u32)s->n_records;
     const bool want_hist = s->cfg.want & COV_WANT_HIST, want_id = s->cfg.want & COV_WANT_IDENTITY;
     for (int k = 0; k < COV_K_COUNT; k++) { s->k_launches[k] = 0; s->k_ms[k] = 0.f; }
+    bool compacted = false;      // the compact histogram was built by this pass (else: by the first cov_fetch_hist)
+    s->est_valid = false;
 
     HIPCHK(s->d_runs.reserve(std::max<size_t>(1, R), st));
     // k_prep geometry: 8 passes of 512 records per workgroup for short reads; one pass when CIGARs are long, where the
@@ -826,8 +840,16 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
 
     if (R) {
         time_begin(s, COV_K_PREP);
+        // k_prep2 wants the short-read geometry and columns it can load two records at a time (the session's own store always is; an adopted
+        // batch is the caller's memory)
+        auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+        const bool pair = s->prep_v == 2 && !long_cigars && al16(r.tid) && al16(r.pos) && al16(r.flag) && al16(r.mapq) && al16(r.nm) && al16(r.nm_kind) &&
+                          al16(r.l_seq) && al16(r.cigar_off) && al16(r.cigar) && al16(s->d_runs.p);
+        const int pw = s->prep_waves;
 #define COV_LAUNCH_PREP(ID, FI, MA)                                                                                                       \
-        hipLaunchKernelGGL((k_prep<ID, FI, MA>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f, s->d_ctg.p, s->d_glob.p, \
+        hipLaunchKernelGGL((pair ? (pw == 8 ? &k_prep2w8<ID, FI, MA> : pw == 6 ? &k_prep2w6<ID, FI, MA> : pw == 5 ? &k_prep2w5<ID, FI, MA> : &k_prep2<ID, FI, MA>)           \
+                                 : (pw == 8 ? &k_prep8<ID, FI, MA> : pw == 6 ? &k_prep6<ID, FI, MA> : &k_prep<ID, FI, MA>)),              \
+                           dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f, s->d_ctg.p, s->d_glob.p,                       \
                            s->d_runs.p, idp, idn, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap)
         {
             const int key = (want_id ? 4 : 0) | (s->cfg.filter_single ? 2 : 0) | (mask != nullptr ? 1 : 0);
@@ -908,26 +930,31 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
                                (u64)s->cfg.contig_end_exclusion, s->d_glob.p);
             // the compact histogram right behind its layout (its size is only known on the device: the buffer takes the arena's
             // bound), and as many of its bins as the previous finish had already on their way to page-locked memory, so that
-            // cov_fetch_hist is no second launch + round trip (0.08 ms of a 1.9 ms step at BASELINE config 2)
-            HIPCHK(s->d_chist.reserve((size_t)R + nT + 1, st));
-            time_begin(s, COV_K_HIST_COMPACT);
-            hipLaunchKernelGGL(k_hist_compact, dim3(nT), dim3(256), 0, st, s->d_ctg.p, nT, s->d_tlen.p, (u64)s->cfg.contig_end_exclusion, s->d_arena.p, s->d_chist.p);
-            time_end(s, COV_K_HIST_COMPACT);
-            HIPCHK(hipGetLastError());
+            // cov_fetch_hist is no second launch + round trip (0.08 ms of a 1.9 ms step at BASELINE config 2).  With the estimators
+            // evaluated on the device (cov_set_estimators) nobody may ever ask for the bins: they are then compacted by the first
+            // cov_fetch_hist instead, unless the caller fetched them after the finish before this one.
+            compacted = s->est.n == 0 || s->hist_fetch_seen;
             s->hist_prefetched = 0;
-            // (only for a caller that fetched the histogram after the finish before this one: a caller that never does pays no copy)
-            const u64 guess = s->hist_fetch_seen ? std::min<u64>({s->last_chist_total + s->last_chist_total / 16, (u64)R + nT + 1, (u64)(64u << 20) / 8}) : 0;
-            s->hist_fetch_seen = false;
-            if (guess) {
-                if (guess > s->h_chist_cap) {
-                    if (s->h_chist) (void)hipHostFree(s->h_chist);
-                    s->h_chist = nullptr; s->h_chist_cap = 0;
-                    HIPCHK(hipHostMalloc((void **)&s->h_chist, (size_t)guess * 8, hipHostMallocDefault));
-                    s->h_chist_cap = guess;
+            if (compacted) {
+                HIPCHK(s->d_chist.reserve((size_t)R + nT + 1, st));
+                time_begin(s, COV_K_HIST_COMPACT);
+                hipLaunchKernelGGL(k_hist_compact, dim3(nT), dim3(256), 0, st, s->d_ctg.p, nT, s->d_tlen.p, (u64)s->cfg.contig_end_exclusion, s->d_arena.p, s->d_chist.p);
+                time_end(s, COV_K_HIST_COMPACT);
+                HIPCHK(hipGetLastError());
+                // (only for a caller that fetched the histogram after the finish before this one: a caller that never does pays no copy)
+                const u64 guess = s->hist_fetch_seen ? std::min<u64>({s->last_chist_total + s->last_chist_total / 16, (u64)R + nT + 1, (u64)(64u << 20) / 8}) : 0;
+                if (guess) {
+                    if (guess > s->h_chist_cap) {
+                        if (s->h_chist) (void)hipHostFree(s->h_chist);
+                        s->h_chist = nullptr; s->h_chist_cap = 0;
+                        HIPCHK(hipHostMalloc((void **)&s->h_chist, (size_t)guess * 8, hipHostMallocDefault));
+                        s->h_chist_cap = guess;
+                    }
+                    HIPCHK(hipMemcpyAsync(s->h_chist, s->d_chist.p, (size_t)guess * 8, hipMemcpyDeviceToHost, st));
+                    s->hist_prefetched = guess;
                 }
-                HIPCHK(hipMemcpyAsync(s->h_chist, s->d_chist.p, (size_t)guess * 8, hipMemcpyDeviceToHost, st));
-                s->hist_prefetched = guess;
             }
+            s->hist_fetch_seen = false;
         }
     }
     {
@@ -941,6 +968,22 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         s->h_ctg = (DevContig *)(s->h_res + sizeof(DevGlobal));
     }
     if (want_id && R && nT) HIPCHK(hipStreamWaitEvent(st, s->ev_side_done, 0));
+    if (s->est.n && nT) {      // CoverageEstimator::calculate_coverage of every contig (k_init left n_pass = 0 everywhere when nothing ran: rows of zeros)
+        const size_t nf = (size_t)nT * s->est.n;
+        HIPCHK(s->d_estf.reserve(nf, st));
+        if (nf > s->h_estf_cap) {
+            if (s->h_estf) (void)hipHostFree(s->h_estf);
+            s->h_estf = nullptr; s->h_estf_cap = 0;
+            HIPCHK(hipHostMalloc((void **)&s->h_estf, nf * sizeof(float), hipHostMallocDefault));
+            s->h_estf_cap = nf;
+        }
+        time_begin(s, COV_K_ESTIMATE);
+        hipLaunchKernelGGL(k_estimate, dim3((nT + 3) / 4), dim3(256), 0, st, (const DevContig *)s->d_ctg.p, nT, (const u32 *)s->d_tlen.p, (u64)s->cfg.contig_end_exclusion,
+                           (const u32 *)s->d_arena.p, s->est, s->d_estf.p);
+        time_end(s, COV_K_ESTIMATE);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(s->h_estf, s->d_estf.p, nf * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(hipMemcpyAsync(s->h_res, s->d_res.p, sizeof(DevGlobal) + (size_t)nT * sizeof(DevContig), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     memcpy(&s->h_glob, s->h_res, sizeof(DevGlobal));
@@ -963,7 +1006,8 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     const cov_status cst = convert_results(s, s->h_glob, s->h_ctg, R, stats, summary, s->spill.inflight, s->spill.records);
     if (cst != COV_OK) return cst;
     s->last_chist_total = want_hist ? s->h_glob.chist_total : 0;
-    s->hist_compacted = want_hist && R != 0;
+    s->hist_compacted = compacted;
+    s->est_valid = s->est.n != 0;
     s->finished = true;
     return COV_OK;
 }
@@ -1014,6 +1058,10 @@ cov_status spill_store_impl(cov_session *s, bool &progress) {
         if ((int64_t)c == cstar || !st[c].n_pass) continue;
         if (S.have[c]) { s->err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)"; return COV_ERR_UNSORTED; }
         S.stats[c] = st[c]; S.ctg[c] = s->h_ctg[c]; S.have[c] = 1;
+        if (s->est.n) {
+            if (s->spill_est.size() != (size_t)nT * s->est.n) s->spill_est.assign((size_t)nT * s->est.n, 0.0f);
+            memcpy(&s->spill_est[(size_t)c * s->est.n], s->h_estf + (size_t)c * s->est.n, s->est.n * sizeof(float));
+        }
         if (want_hist && st[c].hist_len) {
             S.stats[c].hist_off = S.hist.size();
             S.hist.insert(S.hist.end(), h.begin() + st[c].hist_off, h.begin() + st[c].hist_off + st[c].hist_len);
@@ -1075,6 +1123,8 @@ static cov_status merge_spilled(cov_session *s, cov_contig_stats *stats, cov_sum
         if (S.have[c]) {
             if (stats[c].n_pass) { s->err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)"; return COV_ERR_UNSORTED; }
             stats[c] = S.stats[c]; m[c] = S.ctg[c];
+            if (s->est.n && s->est_valid && s->spill_est.size() == (size_t)nT * s->est.n)
+                memcpy(s->h_estf + (size_t)c * s->est.n, &s->spill_est[(size_t)c * s->est.n], s->est.n * sizeof(float));
         } else {
             m[c] = s->h_ctg[c];
             if (want_hist && stats[c].hist_len) {
@@ -2020,6 +2070,37 @@ cov_status cov_kernel_ms(const cov_session *s, cov_kernel_id k, double *ms_total
 }
 
 uint32_t cov_store_spills(const cov_session *s) { return s ? s->spill.count : 0u; }
+
+cov_status cov_set_estimators(cov_session *s, const cov_estimator *est, uint32_t n_est) {
+    if (!s || (n_est && !est)) return COV_ERR_INVALID_ARG;
+    if (n_est > COV_EST_MAX) { s->err = "cov_set_estimators: more than COV_EST_MAX estimators"; return COV_ERR_INVALID_ARG; }
+    if (s->spill.active) { s->err = "cov_set_estimators: set them before the sample's first records (part of it already left the bounded record store)"; return COV_ERR_STATE; }
+    for (uint32_t k = 0; k < n_est; k++) {
+        const int kind = est[k].kind;
+        if (kind < 0 || kind > COV_EST_ANIR || kind == COV_EST_TPM || kind == COV_EST_PILEUP_COUNTS) {
+            s->err = "cov_set_estimators: this estimator is evaluated on the host (TPM: f64 exp / ln of the host's libm; coverage histogram: prints the histogram itself)";
+            return COV_ERR_INVALID_ARG;
+        }
+        if (kind == COV_EST_TRIMMED_MEAN && !(s->cfg.want & COV_WANT_HIST)) { s->err = "cov_set_estimators: a trimmed mean needs COV_WANT_HIST"; return COV_ERR_INVALID_ARG; }
+        if (kind == COV_EST_ANIR && (!(s->cfg.want & COV_WANT_IDENTITY) || (s->cfg.want & COV_WANT_IDENTITY_NONSUPP_ONLY))) {
+            s->err = "cov_set_estimators: ANIr needs COV_WANT_IDENTITY with the primary-read sum"; return COV_ERR_INVALID_ARG;
+        }
+    }
+    s->est = EstParams{};
+    for (uint32_t k = 0; k < n_est; k++) memcpy(&s->est.e[k], &est[k], sizeof(cov_estimator));
+    s->est.n = n_est;
+    s->est_valid = false;
+    return COV_OK;
+}
+
+cov_status cov_fetch_estimates(cov_session *s, float *out) {
+    if (!s || !s->finished || !s->est_valid) { if (s) s->err = "cov_fetch_estimates: cov_set_estimators, then cov_finish"; return COV_ERR_STATE; }
+    if (s->have_mask) { s->err = "cov_fetch_estimates: with a target mask the entries are genomes: aggregate on the host"; return COV_ERR_STATE; }
+    const size_t nf = (size_t)s->n_targets * s->est.n;
+    if (nf && !out) return COV_ERR_INVALID_ARG;
+    if (nf) memcpy(out, s->h_estf, nf * sizeof(float));
+    return COV_OK;
+}
 
 cov_status cov_algorithmic_bytes(const cov_session *s, uint64_t *bytes) {
     if (!s || !bytes) return COV_ERR_INVALID_ARG;

@@ -106,6 +106,7 @@ struct Sample {
     std::vector<int32_t> genome_of_tid;
     std::vector<cov_contig_stats> stats;
     std::vector<uint64_t> hist;
+    std::vector<float> estimates;      // calculate_coverage of every contig, evaluated on the device (Run::dev_est): n_targets x estimators
     uint64_t prim = 0, n_records = 0;
     covh_reads_mapped gene_rm{0, 0};
     double t_open = 0, t_ingest = 0, t_finish = 0; uint64_t peak_bytes = 0; bool streamed = false, device_ingest = false;
@@ -125,6 +126,7 @@ struct Run {
     Filter f;
     bool contig = true, by_names = false, per_gene = false, fs = false, fp = false;
     std::vector<covh_estimator> est;
+    bool dev_est = false;      // `coverm contig` with estimators the device evaluates (cov_set_estimators): no per-contig finalisation, no histogram fetch on the host
     uint32_t want = 0;
     cov_config cfg{};
     std::vector<std::string> genomes;
@@ -168,6 +170,15 @@ bool is_bgzf(const std::string &path) {
     const size_t n = fread(m, 1, 2, f);
     fclose(f);
     return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
+}
+
+// What the host keeps of a finished session: the estimators' floats when the device evaluated them, else the histogram bins the host's
+// calculate_coverage needs.
+void fetch_results(Run &R, cov_session *s, Sample &S, const cov_summary &summ) {
+    if (R.dev_est) {
+        S.estimates.resize(S.tlen.size() * R.est.size());
+        check(s, cov_fetch_estimates(s, S.estimates.data()));
+    } else if (R.want & COV_WANT_HIST) { S.hist.resize(summ.hist_total); check(s, cov_fetch_hist(s, S.hist.data())); }
 }
 
 // Decode + push + finish of one BAM (or one tid span of it) on one session.  Leaves the session finished.
@@ -235,7 +246,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
             S.stats.resize(S.tlen.size());
             cov_summary summ;
             check(s, cov_finish(s, S.stats.data(), &summ));
-            if (R.want & COV_WANT_HIST) { S.hist.resize(summ.hist_total); check(s, cov_fetch_hist(s, S.hist.data())); }
+            fetch_results(R, s, S, summ);
             S.prim = R.fp ? pair_prim : summ.num_detected_primary_alignments;      // filter.rs:129-131 counts every primary record of the input
             S.t_finish = now() - t0 - S.t_ingest;
             return;
@@ -270,7 +281,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         S.stats.resize(S.tlen.size());
         cov_summary summ;
         check(s, cov_finish(s, S.stats.data(), &summ));
-        if (R.want & COV_WANT_HIST) { S.hist.resize(summ.hist_total); check(s, cov_fetch_hist(s, S.hist.data())); }
+        fetch_results(R, s, S, summ);
         S.prim = summ.num_detected_primary_alignments;
         S.t_finish = now() - t0 - S.t_ingest;
         return;
@@ -361,7 +372,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
     S.stats.resize(nt);
     cov_summary summ;
     check(s, cov_finish(s, S.stats.data(), &summ));
-    if (R.want & COV_WANT_HIST) { S.hist.resize(summ.hist_total); check(s, cov_fetch_hist(s, S.hist.data())); }
+    fetch_results(R, s, S, summ);
     if (!prim_from_host) S.prim = summ.num_detected_primary_alignments;
     if (R.per_gene) {   // genes.rs:182-344: per-gene reductions over this sample's depth, while the session holds it
         std::lock_guard<std::mutex> lk(R.taker_mutex);
@@ -654,6 +665,15 @@ int run_cli(int argc, char **argv) {
         for (auto &t : th) t.join();
         for (size_t d = 0; d < nd; d++) if (rc[d] != COV_OK) die(emsg[d]);
     }
+    {
+        // CoverageEstimator::calculate_coverage on the device for `coverm contig` (one entry per contig) when every estimator asked for is
+        // one the device evaluates (all but TPM and the coverage histogram); COVERM_HOST_ESTIMATES=1 keeps the host's evaluation
+        static_assert(sizeof(covh_estimator) == sizeof(cov_estimator) && offsetof(covh_estimator, trim_max) == offsetof(cov_estimator, trim_max), "estimator structs share one layout");
+        bool ok = contig && !R.per_gene && !getenv("COVERM_HOST_ESTIMATES") && !est.empty() && est.size() <= COV_EST_MAX;
+        for (const covh_estimator &e : est) ok = ok && e.kind != COVH_TPM && e.kind != COVH_PILEUP_COUNTS;
+        R.dev_est = ok;
+        if (ok) for (size_t d = 0; d < nd; d++) check(sess[d], cov_set_estimators(sess[d], reinterpret_cast<const cov_estimator *>(est.data()), (uint32_t)est.size()));
+    }
     const double t_sessions = now();
     covh_bam_set_pinned(1);
     // (measured, profiles/r03_tail_variants.log: releasing the staging slots beside the last rounds shortens the exit by ~0.03 s and
@@ -726,6 +746,7 @@ int run_cli(int argc, char **argv) {
             const uint32_t nt = (uint32_t)S.tlen.size();
             check(sess[0], cov_gather(sess.data(), (uint32_t)nd, 0));
             S.stats.assign(nt, cov_contig_stats{});
+            if (R.dev_est) S.estimates.assign((size_t)nt * est.size(), 0.0f);
             std::vector<cov_contig_stats> tmp(nt);
             for (size_t d = 0; d < nd; d++) {
                 cov_summary summ;
@@ -737,7 +758,9 @@ int run_cli(int argc, char **argv) {
                     if (tmp[t].n_pass == 0) continue;
                     if (S.stats[t].n_pass != 0) die("internal error: contig " + S.target_name(t) + " was seen by two spans");
                     S.stats[t] = tmp[t];
-                    if (R.want & COV_WANT_HIST) {   // histogram bins stay with the rank that built them: re-based into one array
+                    if (R.dev_est) {                // the floats stay with the rank that evaluated them, like the histogram bins
+                        std::copy(part[d].estimates.begin() + (size_t)t * est.size(), part[d].estimates.begin() + (size_t)(t + 1) * est.size(), S.estimates.begin() + (size_t)t * est.size());
+                    } else if (R.want & COV_WANT_HIST) {   // histogram bins stay with the rank that built them: re-based into one array
                         S.stats[t].hist_off = S.hist.size();
                         S.hist.insert(S.hist.end(), part[d].hist.begin() + tmp[t].hist_off, part[d].hist.begin() + tmp[t].hist_off + tmp[t].hist_len);
                     }
@@ -772,7 +795,8 @@ int run_cli(int argc, char **argv) {
         covh_sample hs; hs.stoit_name = S.stoit.c_str(); hs.stats = S.stats.data(); hs.hist = S.hist.empty() ? nullptr : S.hist.data();
         hs.num_detected_primary_alignments = S.prim;
         int rc;
-        if (contig) rc = covh_contig_coverage(&hdr, &hs, 1, taker, est.data(), est.size(), !a.no_zeros, &rm[bi]);
+        const float *ef = S.estimates.empty() ? nullptr : S.estimates.data();
+        if (contig) rc = covh_contig_coverage_estimated(&hdr, &hs, 1, taker, est.data(), est.size(), !a.no_zeros, &rm[bi], R.dev_est ? &ef : nullptr);
         else if (a.have_separator || a.single_genome)
             rc = covh_genome_coverage_separator(&hdr, &hs, 1, (uint8_t)(a.single_genome ? '0' : a.separator), taker, !a.no_zeros, est.data(), est.size(),
                                                 a.single_genome, &rm[bi]);

@@ -466,7 +466,19 @@ ContigWorkers &contig_workers() { static ContigWorkers w; return w; }
 
 int covh_contig_coverage(const covh_header *h, const covh_sample *samples, size_t n_samples, covh_taker *taker,
                          const covh_estimator *est, size_t n_est, int print_zero, covh_reads_mapped *rm_out) {
+    return covh_contig_coverage_estimated(h, samples, n_samples, taker, est, n_est, print_zero, rm_out, nullptr);
+}
+
+// The same scan loop with calculate_coverage already done on the device for some or all samples (cov_set_estimators /
+// cov_fetch_estimates: the same floats, bit for bit): what is left here is contig.rs:40-104's control flow — zero rows, ReadsMapped,
+// the taker calls — in target order.
+int covh_contig_coverage_estimated(const covh_header *h, const covh_sample *samples, size_t n_samples, covh_taker *taker,
+                                   const covh_estimator *est, size_t n_est, int print_zero, covh_reads_mapped *rm_out,
+                                   const float *const *estimates) {
     if (!check_excl(est, n_est)) { g_err = "estimators disagree on contig_end_exclusion"; return COV_ERR_INVALID_ARG; }
+    if (estimates)
+        for (size_t k = 0; k < n_est; k++)
+            if (est[k].kind == COVH_PILEUP_COUNTS || est[k].kind == COVH_TPM) { g_err = "covh_contig_coverage_estimated: coverage histogram and TPM are evaluated on the host"; return COV_ERR_INVALID_ARG; }
     const u64 excl = session_excl(est, n_est);
     const u64 zero = 0;
     std::vector<float> cov(n_est);
@@ -479,10 +491,11 @@ int covh_contig_coverage(const covh_header *h, const covh_sample *samples, size_
         taker->reserve(h->n_targets, n_est, h->name_off[h->n_targets]);
         u64 mapped_total = 0;
         int64_t prev = -1;
-        if (!needs_acc_to_print && h->n_targets >= 1024) {
-            // phase 1 (contigs in parallel): the coverages; phase 2 (in order): zero rows, reads mapped, the taker
-            all.resize((size_t)h->n_targets * n_est);
-            contig_workers().run(h->n_targets, [&](size_t lo, size_t hi) {
+        const float *ext = estimates ? estimates[si] : nullptr;
+        if (ext || (!needs_acc_to_print && h->n_targets >= 1024)) {
+            // phase 1 (contigs in parallel, or done on the device): the coverages; phase 2 (in order): zero rows, reads mapped, the taker
+            if (!ext) all.resize((size_t)h->n_targets * n_est);
+            if (!ext) contig_workers().run(h->n_targets, [&](size_t lo, size_t hi) {
                 EntryAcc acc;
                 for (size_t t = lo; t < hi; t++) {
                     const cov_contig_stats &s = S.stats[t];
@@ -503,7 +516,7 @@ int covh_contig_coverage(const covh_header *h, const covh_sample *samples, size_
                 const cov_contig_stats &s = S.stats[t];
                 if (s.n_pass == 0) continue;
                 if (print_zero) zero_rows2(prev, t);
-                const float *c = &all[(size_t)t * n_est];
+                const float *c = ext ? ext + (size_t)t * n_est : &all[(size_t)t * n_est];
                 bool nonzero = false;
                 for (size_t k = 0; k < n_est; k++) nonzero |= c[k] > 0.0f;
                 if (nonzero) mapped_total += s.n_primary;           // :67-72

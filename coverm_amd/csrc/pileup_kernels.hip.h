@@ -348,12 +348,23 @@ __device__ __forceinline__ void prep_flush(DevContig *ctg, int cur, PrepAcc &a) 
 
 // FILTER: the reader-stage single-read filter is on (filter.rs:88-116); MASKED: a target mask is set (genome.rs:170-171).
 // Both are compile-time so that the common `coverm contig` shape carries neither the loads (mapq, l_seq, mask) nor the code.
-template <bool WANT_IDENTITY, bool FILTER, bool MASKED>
-__global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__ tlen, u32 n_targets,
-                                              const uint8_t *__restrict__ mask, FilterCfg f, DevContig *ctg,
-                                              DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ identp,
-                                              double *__restrict__ identn, PrepPartial *__restrict__ part, TileIdx ti,
-                                              int passes, int b_active, u32 *__restrict__ cx_list, u32 cx_list_cap) {
+// PAIR (k_prep2, the short-read geometry only: b_active = 2): a lane takes two ADJACENT records (2 l, 2 l + 1 of the wave's 128) instead
+// of records 256 apart.  tid / pos / nm / cigar_off then come in as 8-byte loads, flag as one dword, nm_kind (mapq) as one short, the
+// two run words leave as one 16-byte store; a record's neighbours in file order (position-order checks) are the lane's other record or
+// the neighbouring lane's (one DPP move; the wave's two edge records by one uniform load each) instead of three more loads per record;
+// contig length / first tile / mask are loaded once when both records share the tid (a wave-uniform test: contig boundaries are rare)
+// and the first three CIGAR words of each record as one 12-byte load.  15 memory instructions per pair instead of 36.  The host only
+// launches it over columns aligned to 16 bytes; the last, partial pass of the store takes the clamped per-element loads.
+struct __attribute__((packed, aligned(4))) PrepU3 { u32 a, b, c; };
+template <class V, int ALIGN>
+__device__ __forceinline__ V prep_ld(const void *p) { V v; __builtin_memcpy(&v, __builtin_assume_aligned(p, ALIGN), sizeof(V)); return v; }
+
+template <bool WANT_IDENTITY, bool FILTER, bool MASKED, bool PAIR>
+__device__ __forceinline__ void prep_body(const Records &r, const u32 *__restrict__ tlen, u32 n_targets,
+                                          const uint8_t *__restrict__ mask, const FilterCfg &f, DevContig *ctg,
+                                          DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ identp,
+                                          double *__restrict__ identn, PrepPartial *__restrict__ part, const TileIdx &ti,
+                                          int passes, int b_active, u32 *__restrict__ cx_list, u32 cx_list_cap) {
     __shared__ u32 blk_cnt[2][4];
     __shared__ PrepPartial wpart[4];
     bool flushed_early = false;   // this wave already sent sums for an earlier contig through atomics
@@ -378,36 +389,98 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
     uint2 *runs_c = runs + chunk;
 
     for (int ps = 0; ps < passes; ps++) {
-        const u32 l0 = (u32)(ps * b_active) * 256u + threadIdx.x;
+        // chunk-relative index of the lane's first record, and the distance to its second
+        const u32 l0 = PAIR ? (u32)ps * 512u + 2u * threadIdx.x : (u32)(ps * b_active) * 256u + threadIdx.x;
+        constexpr u32 KSTRIDE = PAIR ? 1u : 256u;
         const u32 i0 = chunk + l0;
         if (!__any(i0 < r.n)) break;
         // ---- phase A: every independent field of PREP_B records, issued back to back (clamped, branch-free)
         u32 fl[PREP_B], mq[PREP_B], nmk[PREP_B], nmv32[PREP_B], lsq[PREP_B], co0[PREP_B], co1[PREP_B];
         int td[PREP_B], ps_[PREP_B], ptid[PREP_B], ppos[PREP_B], ntid[PREP_B];
+        const bool pass_full = PAIR && chunk + (u32)ps * 512u + 512u <= r.n;      // workgroup-uniform: every pair of this pass lies inside the store
+        if (PAIR && pass_full) {
+            const int2 t2 = prep_ld<int2, 8>(tid_c + l0), p2 = prep_ld<int2, 8>(pos_c + l0);
+            const uint2 n2 = prep_ld<uint2, 8>(nm_c + l0), c2 = prep_ld<uint2, 8>(coff_c + l0);
+            const u32 c3 = coff_c[l0 + 2u];
+            const u32 f2 = prep_ld<u32, 4>(flag_c + l0);
+            const u32 k2 = prep_ld<uint16_t, 2>(nmk_c + l0);
+            td[0] = t2.x; td[1] = t2.y; ps_[0] = p2.x; ps_[1] = p2.y; nmv32[0] = n2.x; nmv32[1] = n2.y;
+            co0[0] = c2.x; co1[0] = c2.y; co0[1] = c2.y; co1[1] = c3;
+            fl[0] = f2 & 0xffffu; fl[1] = f2 >> 16; nmk[0] = k2 & 0xffu; nmk[1] = k2 >> 8;
+            if (FILTER) {
+                const u32 m2 = prep_ld<uint16_t, 2>(mapq_c + l0);
+                const uint2 s2 = prep_ld<uint2, 8>(lseq_c + l0);
+                mq[0] = m2 & 0xffu; mq[1] = m2 >> 8; lsq[0] = s2.x; lsq[1] = s2.y;
+            } else { mq[0] = mq[1] = 0u; lsq[0] = lsq[1] = 0u; }
+        } else {
 #pragma unroll
-        for (int k = 0; k < PREP_B; k++) {
-            const u32 lc = min(l0 + (u32)k * 256u, lmax) & (u32)(PREP_CHUNK - 1);   // the mask is a no-op that bounds lc for the compiler
-            const u32 ic = chunk + lc;
-            fl[k] = flag_c[lc]; td[k] = tid_c[lc]; ps_[k] = pos_c[lc]; mq[k] = FILTER ? mapq_c[lc] : 0u; nmk[k] = nmk_c[lc];
-            nmv32[k] = nm_c[lc]; lsq[k] = FILTER ? lseq_c[lc] : 0u; co0[k] = coff_c[lc]; co1[k] = coff_c[lc + 1u];
-            const u32 lp = (lc + (ic > 0u ? 0u : 1u)) & (u32)(2 * PREP_CHUNK - 1), ln = (lc + (ic < nlast ? 1u : 0u)) & (u32)(2 * PREP_CHUNK - 1);
-            ptid[k] = tid_m[lp]; ppos[k] = pos_m[lp]; ntid[k] = tid_c[ln];
+            for (int k = 0; k < PREP_B; k++) {
+                const u32 lc = min(l0 + (u32)k * KSTRIDE, lmax) & (u32)(PREP_CHUNK - 1);   // the mask is a no-op that bounds lc for the compiler
+                fl[k] = flag_c[lc]; td[k] = tid_c[lc]; ps_[k] = pos_c[lc]; mq[k] = FILTER ? mapq_c[lc] : 0u; nmk[k] = nmk_c[lc];
+                nmv32[k] = nm_c[lc]; lsq[k] = FILTER ? lseq_c[lc] : 0u; co0[k] = coff_c[lc]; co1[k] = coff_c[lc + 1u];
+            }
+        }
+        if (PAIR) {
+            // neighbours in file order: the lane's other record, or the neighbouring lane's by one DPP move; the records in front of the
+            // wave's first and behind its last by one uniform load each (clamped at the ends of the store: those values are not looked at)
+            const u32 w0 = chunk + (u32)ps * 512u + (u32)w * 128u;                 // the wave's first record
+            const u32 e_prev = min(w0 ? w0 - 1u : 0u, nlast), e_next = min(w0 + 128u, nlast);
+            const int et = r.tid[e_prev], ep = r.pos[e_prev], en = r.tid[e_next];
+            ptid[0] = __builtin_amdgcn_update_dpp(et, td[1], 0x138, 0xf, 0xf, false);      // wave_shr:1, lane 0 keeps the edge value
+            ppos[0] = __builtin_amdgcn_update_dpp(ep, ps_[1], 0x138, 0xf, 0xf, false);
+            ntid[0] = td[1];
+            ptid[1] = td[0]; ppos[1] = ps_[0];
+            ntid[1] = __builtin_amdgcn_update_dpp(en, td[0], 0x130, 0xf, 0xf, false);      // wave_shl:1, lane 63 keeps the edge value
+        } else {
+#pragma unroll
+            for (int k = 0; k < PREP_B; k++) {
+                const u32 lc = min(l0 + (u32)k * KSTRIDE, lmax) & (u32)(PREP_CHUNK - 1);
+                const u32 ic = chunk + lc;
+                const u32 lp = (lc + (ic > 0u ? 0u : 1u)) & (u32)(2 * PREP_CHUNK - 1), ln = (lc + (ic < nlast ? 1u : 0u)) & (u32)(2 * PREP_CHUNK - 1);
+                ptid[k] = tid_m[lp]; ppos[k] = pos_m[lp]; ntid[k] = tid_c[ln];
+            }
         }
         // ---- phase B: loads that depend on phase A (first three CIGAR words, contig length, mask)
         u32 cw[PREP_B][3], Lc[PREP_B], mk[PREP_B], t0[PREP_B];
+        if (PAIR) {
+            {
+                const bool tok = td[0] >= 0 && (u32)td[0] < n_targets;
+                Lc[0] = tok ? tlen[td[0]] : 0u; t0[0] = tok ? ti.tile_first[td[0]] : 0u; mk[0] = (MASKED && tok) ? mask[td[0]] : 1u;
+            }
+            Lc[1] = Lc[0]; t0[1] = t0[0]; mk[1] = mk[0];
+            if (__any(td[1] != td[0])) {       // a contig boundary inside the wave's 128 records: rare
+                const bool tok = td[1] >= 0 && (u32)td[1] < n_targets;
+                Lc[1] = tok ? tlen[td[1]] : 0u; t0[1] = tok ? ti.tile_first[td[1]] : 0u; mk[1] = (MASKED && tok) ? mask[td[1]] : 1u;
+            }
+            // three words per record as one 12-byte load when no lane's words can lie behind the end of the array
+            if (r.cigar_end >= 3u && __all(max(co0[0], co0[1]) <= r.cigar_end - 3u)) {
 #pragma unroll
-        for (int k = 0; k < PREP_B; k++) {
-            const bool tok = td[k] >= 0 && (u32)td[k] < n_targets;
-            Lc[k] = tok ? tlen[td[k]] : 0u;
-            t0[k] = tok ? ti.tile_first[td[k]] : 0u;
-            mk[k] = (MASKED && tok) ? mask[td[k]] : 1u;
+                for (int k = 0; k < PREP_B; k++) {
+                    const PrepU3 q = prep_ld<PrepU3, 4>(r.cigar + co0[k]);
+                    cw[k][0] = q.a; cw[k][1] = q.b; cw[k][2] = q.c;
+                }
+            } else {
 #pragma unroll
-            for (int c = 0; c < 3; c++) cw[k][c] = r.cigar_end ? r.cigar[min(co0[k] + (u32)c, cig_last)] : 0u;
+                for (int k = 0; k < PREP_B; k++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) cw[k][c] = r.cigar_end ? r.cigar[min(co0[k] + (u32)c, cig_last)] : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PREP_B; k++) {
+                const bool tok = td[k] >= 0 && (u32)td[k] < n_targets;
+                Lc[k] = tok ? tlen[td[k]] : 0u;
+                t0[k] = tok ? ti.tile_first[td[k]] : 0u;
+                mk[k] = (MASKED && tok) ? mask[td[k]] : 1u;
+#pragma unroll
+                for (int c = 0; c < 3; c++) cw[k][c] = r.cigar_end ? r.cigar[min(co0[k] + (u32)c, cig_last)] : 0u;
+            }
         }
         // ---- phase C: per-record logic
+        uint2 rws[PREP_B];
 #pragma unroll
         for (int k = 0; k < PREP_B; k++) {
-            const u32 i = i0 + (u32)k * 256u;
+            const u32 i = i0 + (u32)k * KSTRIDE;
             const bool in = i < r.n && k < b_active;
             const u32 flag = in ? fl[k] : 0x904u;
             const int tid = in ? td[k] : -1;
@@ -538,7 +611,8 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                         rw.y = (is_bucket ? RW_BUCKET : RW_COMPLEX) << 30;
                     }
                 }
-                runs_c[i - chunk] = rw;
+                if (PAIR && pass_full) rws[k] = rw;      // both run words of the pair leave as one 16-byte store behind the loop
+                else runs_c[i - chunk] = rw;
                 if (WANT_IDENTITY) {   // a NULL stream is one the caller does not need (COV_WANT_IDENTITY_*_ONLY)
                     if (identn != nullptr) identn[i] = (masked_in && !supp) ? idv : 0.0;
                     if (identp != nullptr) identp[i] = (masked_in && !supp && !sec) ? idv : 0.0;
@@ -619,6 +693,7 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
                 }
             }
         }
+        if (PAIR && pass_full) *reinterpret_cast<uint4 *>(runs_c + l0) = make_uint4(rws[0].x, rws[0].y, rws[1].x, rws[1].y);
     }
     // End of chunk: if all four waves stayed inside the same single contig, publish ONE partial record for the
     // workgroup (reduced by k_prep_reduce); otherwise fall back to atomics.
@@ -665,6 +740,24 @@ __global__ __launch_bounds__(256) void k_prep(Records r, const u32 *__restrict__
         if (c) atomicAdd(&g->cons_slots[slot], (u64)c);
     }
 }
+
+#define COV_PREP_KERNEL(NAME, PAIR, ATTR)                                                                                                        \
+    template <bool WANT_IDENTITY, bool FILTER, bool MASKED>                                                                                      \
+    __global__ __launch_bounds__(256) ATTR void NAME(Records r, const u32 *__restrict__ tlen, u32 n_targets, const uint8_t *__restrict__ mask,   \
+                                                     FilterCfg f, DevContig *ctg, DevGlobal *g, uint2 *__restrict__ runs,                        \
+                                                     double *__restrict__ identp, double *__restrict__ identn, PrepPartial *__restrict__ part,   \
+                                                     TileIdx ti, int passes, int b_active, u32 *__restrict__ cx_list, u32 cx_list_cap) {         \
+        prep_body<WANT_IDENTITY, FILTER, MASKED, PAIR>(r, tlen, n_targets, mask, f, ctg, g, runs, identp, identn, part, ti, passes, b_active,    \
+                                                       cx_list, cx_list_cap);                                                                    \
+    }
+COV_PREP_KERNEL(k_prep, false, )                                                   // records 256 apart per lane: every geometry, any alignment
+COV_PREP_KERNEL(k_prep6, false, __attribute__((amdgpu_waves_per_eu(6))))           // (COVERM_PREP_WAVES=6 / 8: measurement switches)
+COV_PREP_KERNEL(k_prep8, false, __attribute__((amdgpu_waves_per_eu(8))))
+COV_PREP_KERNEL(k_prep2, true, )                                                   // adjacent pairs per lane: the short-read geometry
+COV_PREP_KERNEL(k_prep2w5, true, __attribute__((amdgpu_waves_per_eu(5))))
+COV_PREP_KERNEL(k_prep2w6, true, __attribute__((amdgpu_waves_per_eu(6))))
+COV_PREP_KERNEL(k_prep2w8, true, __attribute__((amdgpu_waves_per_eu(8))))
+#undef COV_PREP_KERNEL
 
 // One wave per contig: adds the partial records of the workgroups that lay entirely inside it.
 __global__ __launch_bounds__(64) void k_prep_reduce(DevContig *ctg, u32 n_targets, const PrepPartial *__restrict__ part,
@@ -2002,6 +2095,147 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k
 // Per-interval (per-gene, genes.rs:508-535) statistics over a materialised depth arena: one wave per interval.
 // The window is the interval shrunk by `excl` at both of ITS ends (the reference hands the gene's own delta array to
 // add_contig); covered bases without exclusion.  k_interval_hist fills each interval's histogram slice afterwards.
+// ------------------------------------------------------------------------------------ k_estimate
+// CoverageEstimator::calculate_coverage (estimators.rs:530-839) on the device, for `coverm contig`: one entry = one contig, the
+// unobserved lengths are [0] (contig.rs:62-66), so an estimator sees exactly one add_contig (estimators.rs:366-528).  One WAVE per
+// contig.  Everything but the trimmed mean is a handful of f32 operations of lane 0 — the reference's own expressions in the reference's
+// order, every operation rounded once (no contraction into fused multiply-adds: the host evaluates them with separate operations), so
+// the floats are the host path's bit for bit (tests/test_gpu_estimates.py).  The trimmed mean walks the depth histogram; its loop
+// (estimators.rs:596-640) is restated over the inclusive prefix sums of the bins, which the wave builds 64 bins at a time:
+//     s = first bin whose prefix reaches min_index:  total  = (min(prefix_s, max_index) - min_index + 1) * s   [the reference's two branches]
+//     the bins behind s while their prefix stays <= max_index:  total += count_i * i
+//     e = first bin behind s whose prefix exceeds max_index:    total += (max_index >= prefix_{e-1} ? max_index - prefix_{e-1} + 1 : 0) * e
+// — integers throughout, so the order of the additions does not matter.  TPM (f64 exp / ln of the host's libm) and the coverage
+// histogram (it prints the histogram itself) stay on the host: cov_set_estimators refuses them.
+struct DevEstimator { int kind; float min_frac; u64 excl; int exclude_mismatches; float trim_min, trim_max; u32 pad; };
+static_assert(sizeof(DevEstimator) == 32, "DevEstimator mirrors cov_estimator");
+constexpr u32 EST_MAX = 16;
+struct EstParams { DevEstimator e[EST_MAX]; u32 n; u32 pad; };
+enum { EST_MEAN = 0, EST_TRIMMED_MEAN = 1, EST_PILEUP_COUNTS = 2, EST_COVERED_FRACTION = 3, EST_COVERED_BASES = 4, EST_RPKM = 5, EST_TPM = 6,
+       EST_VARIANCE = 7, EST_LENGTH = 8, EST_READ_COUNT = 9, EST_READS_PER_BASE = 10, EST_ANIR = 11 };
+
+__device__ __forceinline__ float est_f32(u64 x) { return __ull2float_rn(x); }          // Rust `x as f32`: round to nearest even
+__device__ __forceinline__ u64 est_f32_to_usize(float x) {                             // Rust `x as usize`: saturating, NaN -> 0
+    if (!(x == x) || x <= 0.0f) return 0ull;
+    if (x >= 18446744073709551616.0f) return ~0ull;
+    return (u64)x;
+}
+__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 t = __shfl_up(v, o);
+        if (lane_id() >= o) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_estimate(const DevContig *__restrict__ ctg, u32 n_targets, const u32 *__restrict__ tlen, u64 excl,
+                                                  const u32 *__restrict__ arena, EstParams P, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    const u32 c = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (c >= n_targets) return;
+    const int lane = lane_id();
+    const DevContig *C = &ctg[c];
+    float *o = out + (size_t)c * P.n;
+    if (C->n_pass == 0) { if ((u32)lane < P.n) o[lane] = 0.0f; return; }     // (the host prints such a contig through print_zero_coverage)
+    // the integer statistics as convert_results + EntryAcc::add_contig would hand them to calculate (host_coverage.cpp)
+    const u64 L = tlen[c];
+    const bool has_win = 2 * excl < L;
+    const u64 win_len = has_win ? L - 2 * excl : 0;
+    const u64 win_sum_d = has_win ? C->sum_d : 0, win_sum_d2 = has_win ? C->sum_d2 : 0, win_covered = has_win ? C->cov_win : 0;
+    const u64 win_min_d = has_win ? ((C->proc_win < win_len || C->min_d == 0xffffffffu) ? 0u : C->min_d) : 0xffffffffu;
+    const u64 full_len = L, full_covered = C->cov_full, n_reads = C->n_primary, mismatches = C->sum_nm - C->sum_indel;
+    const u32 nh = has_win ? C->hist_len : 0u;
+    const u64 bin0_extra = win_len - C->proc_win;       // window positions of tiles no record touched: depth 0 (k_hist_compact adds the same)
+    const u32 *bins = arena + C->hist_off;
+    for (u32 k = 0; k < P.n; k++) {
+        const DevEstimator e = P.e[k];
+        float r = 0.0f;
+        switch (e.kind) {
+        case EST_MEAN: {
+            const u64 T = win_len;
+            if (T == 0 || (est_f32(win_covered) / est_f32(T)) < e.min_frac) break;
+            const float num = e.exclude_mismatches ? est_f32(win_sum_d - mismatches) : est_f32(win_sum_d);
+            r = num / est_f32(T);
+            break;
+        }
+        case EST_TRIMMED_MEAN: {
+            const u64 T = win_len;
+            if (T == 0) break;
+            if ((est_f32(win_covered) / est_f32(T)) < e.min_frac) break;
+            const u64 min_index = est_f32_to_usize(__builtin_floorf(e.trim_min * est_f32(T)));
+            const u64 max_index = est_f32_to_usize(__builtin_ceilf(e.trim_max * est_f32(T)));
+            if (win_covered == 0) break;
+            u64 total = 0, carry = 0;        // carry = prefix of the bins in front of this batch (wave-uniform)
+            int state = 0;                   // 0: before s, 1: between s and e, 2: done
+            for (u32 b = 0; b < nh && state < 2; b += 64) {
+                const u32 i = b + (u32)lane;
+                u64 n = i < nh ? (u64)bins[i] : 0ull;
+                if (i == 0) n += bin0_extra;
+                const u64 acc = carry + wave_incl_scan_u64(n);
+                const bool valid = i < nh;
+                int first = 0;                                   // first lane of this batch that still adds n * i
+                if (state == 0) {
+                    const u64 sm = __ballot(valid && acc >= min_index);
+                    if (sm == 0) { carry = bcast_u64(acc, 63); continue; }
+                    const int ls = __ffsll((long long)sm) - 1;
+                    const u64 acc_s = bcast_u64(acc, ls);
+                    total = (acc_s > max_index ? max_index - min_index + 1 : acc_s - min_index + 1) * (u64)(b + (u32)ls);
+                    state = 1; first = ls + 1;
+                }
+                // state 1: the bins from `first` on add n * i until the first one whose prefix exceeds max_index
+                const u64 em = __ballot(valid && lane >= first && acc > max_index);
+                const int le = em ? __ffsll((long long)em) - 1 : 64;
+                u64 part = (valid && lane >= first && lane < le) ? n * (u64)i : 0ull;
+                if (em && lane == le) {
+                    const u64 excess = acc - n;
+                    part = (max_index >= excess ? max_index - excess + 1 : 0ull) * (u64)i;
+                }
+                total += wave_sum_u64(part);
+                if (em) state = 2;
+                carry = bcast_u64(acc, 63);
+            }
+            r = est_f32(total) / est_f32(max_index - min_index);
+            break;
+        }
+        case EST_COVERED_FRACTION: {
+            const u64 T = full_len;
+            if (T == 0 || (est_f32(full_covered) / est_f32(T)) < e.min_frac) break;
+            r = est_f32(full_covered) / est_f32(T);
+            break;
+        }
+        case EST_COVERED_BASES: {
+            const u64 T = full_len;
+            if (T == 0 || (est_f32(full_covered) / est_f32(T)) < e.min_frac) break;
+            r = est_f32(full_covered);
+            break;
+        }
+        case EST_RPKM: {
+            const u64 T = full_len;
+            if (T == 0 || (est_f32(full_covered) / est_f32(T)) < e.min_frac) break;
+            r = est_f32(n_reads * 1000000000ull) / est_f32(T);
+            break;
+        }
+        case EST_VARIANCE: {
+            const u64 T = win_len;
+            if (T == 0) break;
+            if ((est_f32(win_covered) / est_f32(T)) < e.min_frac || T < 3 || win_len == 0) break;
+            const u64 kk = win_min_d, N = win_len;
+            const u64 ex = win_sum_d - kk * N;
+            const u64 ex2 = win_sum_d2 - 2 * kk * win_sum_d + kk * kk * N;
+            r = (est_f32(ex2) - est_f32(ex * ex) / est_f32(T)) / est_f32(T - 1);
+            break;
+        }
+        case EST_LENGTH: r = est_f32(full_len); break;
+        case EST_READ_COUNT: r = est_f32(n_reads); break;
+        case EST_READS_PER_BASE: r = est_f32(n_reads) / est_f32(full_len); break;
+        case EST_ANIR: r = n_reads == 0 ? 0.0f : (float)(C->id_primary / (double)n_reads); break;
+        default: break;
+        }
+        if (lane == 0) o[k] = r;
+    }
+}
+
 struct DevInterval { u32 tid, pad; u64 start, end; };
 struct DevIntervalStats { u64 win_sum_d, win_sum_d2, win_covered, full_covered; u32 win_min_d, win_max_d, hist_len, pad; u64 hist_off; };
 

@@ -176,6 +176,20 @@ class Session:
         self._check(self._lib.cov_copy_depth(self._h, tid, d.ctypes.data if d.size else None))
         return d
 
+    def set_estimators(self, estimators):
+        """cov_set_estimators: CoverageEstimator::calculate_coverage of every contig on the device at each finish (contig mode).
+        `estimators`: coverm_amd.host.CoverageEstimator structures (same layout as cov_estimator); [] turns it off."""
+        n = len(estimators)
+        arr = (type(estimators[0]) * n)(*estimators) if n else None
+        self._n_est = n
+        self._check(self._lib.cov_set_estimators(self._h, arr, C.c_uint32(n)))
+
+    def estimates(self):
+        """cov_fetch_estimates: n_targets x n_estimators f32 of the last finish."""
+        out = np.zeros((self.n_targets, getattr(self, "_n_est", 0)), dtype=np.float32)
+        self._check(self._lib.cov_fetch_estimates(self._h, out.ctypes.data if out.size else None))
+        return out
+
     def kernel_ms(self):
         out = {}
         for k, name in native.KERNEL_NAMES.items():

@@ -302,14 +302,23 @@ def _finish(rc, rm, n):
 
 
 def contig_coverage(names, target_len, samples, coverage_taker: CoverageTaker, coverage_estimators,
-                    print_zero_coverage_contigs: bool) -> List[ReadsMapped]:
-    """contig.rs:13-253 over device results instead of BAM readers."""
+                    print_zero_coverage_contigs: bool, estimates=None) -> List[ReadsMapped]:
+    """contig.rs:13-253 over device results instead of BAM readers.  `estimates`: per sample the n_targets x n_estimators f32
+    array Session.estimates() returned (calculate_coverage done on the device) or None."""
     h, k1 = _header(names, target_len)
     sa, k2 = _samples(samples)
     rm = (_ReadsMapped * max(1, len(samples)))()
-    rc = _lib().covh_contig_coverage(C.byref(h), sa, C.c_size_t(len(samples)), coverage_taker._h,
-                                     _est_array(coverage_estimators), C.c_size_t(len(coverage_estimators)),
-                                     C.c_int(int(print_zero_coverage_contigs)), rm)
+    L = _lib()
+    if estimates is None:
+        rc = L.covh_contig_coverage(C.byref(h), sa, C.c_size_t(len(samples)), coverage_taker._h,
+                                    _est_array(coverage_estimators), C.c_size_t(len(coverage_estimators)),
+                                    C.c_int(int(print_zero_coverage_contigs)), rm)
+    else:
+        keep = [None if e is None else np.ascontiguousarray(e, np.float32) for e in estimates]
+        ptrs = (C.c_void_p * max(1, len(samples)))(*[None if e is None else e.ctypes.data for e in keep])
+        rc = L.covh_contig_coverage_estimated(C.byref(h), sa, C.c_size_t(len(samples)), coverage_taker._h,
+                                              _est_array(coverage_estimators), C.c_size_t(len(coverage_estimators)),
+                                              C.c_int(int(print_zero_coverage_contigs)), rm, ptrs)
     return _finish(rc, rm, len(samples))
 
 

@@ -16,9 +16,9 @@ ERR_UNSORTED, ERR_NM_MISSING, ERR_NM_BADTYPE, ERR_POS_OOB, ERR_BAD_CIGAR, ERR_BA
 ERR_INVALID_ARG, ERR_HIP, ERR_STATE = 16, 17, 18
 WANT_HIST, WANT_IDENTITY = 1, 2
 WANT_IDENTITY_PRIMARY_ONLY, WANT_IDENTITY_NONSUPP_ONLY = 4, 8
-K_PREP, K_RANGES, K_PILEUP, K_IDENTITY, K_HIST, K_HIST_COMPACT, K_COUNT = 0, 1, 2, 3, 4, 5, 6
+K_PREP, K_RANGES, K_PILEUP, K_IDENTITY, K_HIST, K_HIST_COMPACT, K_ESTIMATE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
 KERNEL_NAMES = {K_PREP: "k_prep", K_RANGES: "k_ranges", K_PILEUP: "k_pileup", K_IDENTITY: "k_identity",
-                K_HIST: "k_hist", K_HIST_COMPACT: "k_hist_compact"}
+                K_HIST: "k_hist", K_HIST_COMPACT: "k_hist_compact", K_ESTIMATE: "k_estimate"}
 
 
 class CovConfig(C.Structure):
@@ -101,6 +101,8 @@ def lib():
     L.cov_reset.argtypes = [C.c_void_p]
     L.cov_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.cov_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.cov_set_estimators.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.cov_fetch_estimates.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

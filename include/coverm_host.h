@@ -109,6 +109,13 @@ uint32_t covh_wants(const covh_estimator *est, size_t n_est);
 int covh_contig_coverage(const covh_header *h, const covh_sample *samples, size_t n_samples, covh_taker *taker,
                          const covh_estimator *est, size_t n_est, int print_zero_coverage_contigs,
                          covh_reads_mapped *reads_mapped_out);
+/* The same loop with calculate_coverage already evaluated on the device: estimates[i] = the n_targets x n_est floats cov_fetch_estimates
+ * returned for sample i (after cov_set_estimators with these estimators), or NULL for a sample to evaluate here; estimates itself may be
+ * NULL.  The floats are the same bit for bit, so rows, zero rows and ReadsMapped (contig.rs:40-104) are those of covh_contig_coverage.
+ * COVH_PILEUP_COUNTS and COVH_TPM are never evaluated on the device: COV_ERR_INVALID_ARG when floats are given with one of them. */
+int covh_contig_coverage_estimated(const covh_header *h, const covh_sample *samples, size_t n_samples, covh_taker *taker,
+                                   const covh_estimator *est, size_t n_est, int print_zero, covh_reads_mapped *rm_out,
+                                   const float *const *estimates);
 int covh_genome_coverage_with_contig_names(const covh_header *h, const covh_sample *samples, size_t n_samples,
                                            const int32_t *genome_of_tid, const char *const *genome_names,
                                            size_t n_genomes, covh_taker *taker, int print_zero_coverage_genomes,

@@ -145,7 +145,8 @@ typedef enum {
     COV_K_IDENTITY = 3, /* ordered f64 identity sums */
     COV_K_HIST = 4,     /* histogram arena layout + zero fill (before the pileup) */
     COV_K_HIST_COMPACT = 5, /* compact histogram (behind the pileup) */
-    COV_K_COUNT = 6
+    COV_K_ESTIMATE = 6, /* CoverageEstimator::calculate_coverage of every contig (cov_set_estimators) */
+    COV_K_COUNT = 7
 } cov_kernel_id;
 
 /* --- lifecycle ------------------------------------------------------------------------------- */
@@ -271,6 +272,38 @@ cov_status cov_kernel_ms(const cov_session *s, cov_kernel_id k, double *ms_total
 /* Algorithmic HBM bytes of the last cov_finish (DESIGN.md "Algorithmic bytes"): record SoA + CIGAR
  * words read once, plus result structs written. */
 cov_status cov_algorithmic_bytes(const cov_session *s, uint64_t *bytes);
+
+/* ---- CoverageEstimator::calculate_coverage on the device (estimators.rs:530-839), for `coverm contig`: one entry per contig, unobserved
+ * lengths [0] (contig.rs:62-66).  cov_set_estimators before cov_finish; cov_finish then also evaluates every estimator for every contig
+ * (one wave per contig, the reference's float expressions in the reference's order, one rounding per operation) and
+ * cov_fetch_estimates copies the n_targets x n_est floats out (row = contig, 0 for a contig without a considered record; RPKM before the
+ * printer's normalisation, as calculate_coverage returns it).  The floats equal the host path's (coverm_host.h covh_contig_coverage over
+ * cov_contig_stats) bit for bit; a host that takes them skips the per-contig finalisation and, unless it prints histograms, the
+ * histogram fetch.  Kinds = enum CoverageEstimator's variant order (coverm_host.h covh_kind).  Not offered: COV_EST_TPM (f64 exp / ln of the
+ * host's libm) and COV_EST_PILEUP_COUNTS (prints the histogram itself) — COV_ERR_INVALID_ARG, evaluate those on the host.  Needs
+ * COV_WANT_HIST for a trimmed mean and COV_WANT_IDENTITY for ANIr, no target mask (genome modes aggregate contigs first: host). */
+typedef struct {
+    int32_t kind;                      /* COV_EST_* */
+    float min_fraction_covered_bases;
+    uint64_t contig_end_exclusion;     /* as the session's cov_config.contig_end_exclusion */
+    int32_t exclude_mismatches;
+    float trim_min, trim_max;
+} cov_estimator;                       /* same layout as coverm_host.h's covh_estimator */
+#define COV_EST_MEAN 0
+#define COV_EST_TRIMMED_MEAN 1
+#define COV_EST_PILEUP_COUNTS 2
+#define COV_EST_COVERED_FRACTION 3
+#define COV_EST_COVERED_BASES 4
+#define COV_EST_RPKM 5
+#define COV_EST_TPM 6
+#define COV_EST_VARIANCE 7
+#define COV_EST_LENGTH 8
+#define COV_EST_READ_COUNT 9
+#define COV_EST_READS_PER_BASE 10
+#define COV_EST_ANIR 11
+#define COV_EST_MAX 16
+cov_status cov_set_estimators(cov_session *s, const cov_estimator *est, uint32_t n_est); /* n_est = 0: off (the default) */
+cov_status cov_fetch_estimates(cov_session *s, float *out);                              /* after cov_finish: n_targets * n_est floats */
 
 /* ---- bounded record store.  The reference holds one contig at a time and flushes it when the tid changes (contig.rs:128-155), so a
  * sample may be arbitrarily large.  The session's record store keeps as many contigs as fit under a cap (2^31 records / 2^31 CIGAR
