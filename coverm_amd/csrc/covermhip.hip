@@ -94,8 +94,8 @@ struct cov_session {
     bool use_fast = true;  // k_pileup_fast + k_pileup_stream on the slow-tile list (default); COVERM_PILEUP=stream: k_pileup_stream alone
     int chunk_tiles = 8;   // consecutive tiles walked by one wave (COVERM_CHUNK)
     int prep_v = 2;        // k_prep2 (adjacent pairs per lane) where its conditions hold, else k_prep; COVERM_PREP_V=1: k_prep everywhere
-    int prep_waves = 0;    // COVERM_PREP_WAVES=6 | 8: the amdgpu_waves_per_eu builds (measurement switch)
-    bool fast_seven = true;    // k_pileup_fast7 (384 LDS bins, seven waves per SIMD: the default) or k_pileup_fast (512 bins, six; COVERM_FAST_WAVES=6)
+    int prep_waves = -1;   // COVERM_PREP_WAVES=0 | 5 | 6 | 8: the amdgpu_waves_per_eu builds (measurement switch); -1: k_prep2 at five waves (96 registers, no scratch), k_prep as it compiles
+    int fast_waves = 7;        // 6 / 7 / 8: which of the three builds below (COVERM_FAST_WAVES)
     int n_cus = 256;
     uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
 
@@ -357,10 +357,10 @@ void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
 }
 
 // k_pileup_fast over every tile (it skips the ones k_ranges flagged TILE_F_SLOW)
-template <bool H, bool SEVEN>
+template <bool H, int WAVES>
 void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    const auto kern = SEVEN ? &k_pileup_fast7<H> : &k_pileup_fast<H>;
-    const size_t smem = pileup_fast_smem_bytes(H, SEVEN ? FAST_HB7 : FAST_HB);
+    const auto kern = WAVES == 8 ? &k_pileup_fast8<H> : WAVES == 7 ? &k_pileup_fast7<H> : &k_pileup_fast<H>;
+    const size_t smem = pileup_fast_smem_bytes(H, WAVES == 8 ? FAST_HB8 : WAVES == 7 ? FAST_HB7 : FAST_HB);
     // the dynamic-LDS limit and the occupancy are per-device facts, and span mode launches from one thread per device: cached per
     // device id, in atomics (two threads racing for the same device compute the same value)
     static std::atomic<int> occ_dev[64];
@@ -383,7 +383,9 @@ void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
 }
 template <bool H>
 void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    if (s->fast_seven) launch_fast_v<H, true>(s, a, n_tiles); else launch_fast_v<H, false>(s, a, n_tiles);
+    if (s->fast_waves == 8) launch_fast_v<H, 8>(s, a, n_tiles);
+    else if (s->fast_waves == 7) launch_fast_v<H, 7>(s, a, n_tiles);
+    else launch_fast_v<H, 6>(s, a, n_tiles);
 }
 
 template <bool H, bool W>
@@ -485,7 +487,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
         stamp("device attribute");
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
-    if (const char *fw = getenv("COVERM_FAST_WAVES")) s->fast_seven = atoi(fw) != 6;
+    if (const char *fw = getenv("COVERM_FAST_WAVES")) { const int v = atoi(fw); s->fast_waves = v == 6 || v == 8 ? v : 7; }
     if (const char *pv = getenv("COVERM_PREP_V")) s->prep_v = atoi(pv) == 1 ? 1 : 2;
     if (const char *pw = getenv("COVERM_PREP_WAVES")) s->prep_waves = atoi(pw);
     if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
@@ -845,7 +847,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
         const bool pair = s->prep_v == 2 && !long_cigars && al16(r.tid) && al16(r.pos) && al16(r.flag) && al16(r.mapq) && al16(r.nm) && al16(r.nm_kind) &&
                           al16(r.l_seq) && al16(r.cigar_off) && al16(r.cigar) && al16(s->d_runs.p);
-        const int pw = s->prep_waves;
+        const int pw = s->prep_waves >= 0 ? s->prep_waves : (pair ? 5 : 0);
 #define COV_LAUNCH_PREP(ID, FI, MA)                                                                                                       \
         hipLaunchKernelGGL((pair ? (pw == 8 ? &k_prep2w8<ID, FI, MA> : pw == 6 ? &k_prep2w6<ID, FI, MA> : pw == 5 ? &k_prep2w5<ID, FI, MA> : &k_prep2<ID, FI, MA>)           \
                                  : (pw == 8 ? &k_prep8<ID, FI, MA> : pw == 6 ? &k_prep6<ID, FI, MA> : &k_prep<ID, FI, MA>)),              \

@@ -1842,6 +1842,7 @@ constexpr size_t pileup_stream_smem_bytes() { return (size_t)4 * ((size_t)STREAM
 //     instruction buy nothing here, and the permuted table layout costs two more address operations per event.  profiles/r04_pileup_packed.log.)
 constexpr int FAST_TW = 1024, FAST_HB = 512;
 constexpr int FAST_HB7 = 384;   // k_pileup_fast7: seven workgroups per CU (22 KiB of LDS each, 72 registers)
+constexpr int FAST_HB8 = 256;   // k_pileup_fast8: eight (20 KiB, 64 registers; the stripped loop takes tiles with < 256 candidate runs)
 constexpr size_t pileup_fast_smem_bytes(bool hist, int hb = FAST_HB) { return (size_t)4 * ((size_t)FAST_TW * 4 + (hist ? (size_t)hb * 4 : 0)); }
 
 typedef short v2i16 __attribute__((ext_vector_type(2)));
@@ -2089,6 +2090,13 @@ __global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, 
 template <bool WANT_HIST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k_pileup_fast7(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
     pileup_fast_body<WANT_HIST, FAST_HB7>(a, n_tiles, chunk_tiles);
+}
+
+// COVERM_FAST_WAVES=8: 256 bins and 64 registers (12 dwords of scratch) for eight waves per SIMD — the same step once more, as a
+// measurement switch (profiles/r05_prep_pileup_ab.log).
+template <bool WANT_HIST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k_pileup_fast8(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
+    pileup_fast_body<WANT_HIST, FAST_HB8>(a, n_tiles, chunk_tiles);
 }
 
 // ------------------------------------------------------------------------------------ interval statistics
