@@ -93,9 +93,8 @@ struct cov_session {
     int stream_rows = 4;   // > 0: wave-per-tile kernels (1024-base tiles); 0: k_pileup workgroup-per-tile (COVERM_PILEUP=tile)
     bool use_fast = true;  // k_pileup_fast + k_pileup_stream on the slow-tile list (default); COVERM_PILEUP=stream: k_pileup_stream alone
     int chunk_tiles = 8;   // consecutive tiles walked by one wave (COVERM_CHUNK)
-    int prep_v = 2;        // k_prep2 (adjacent pairs per lane) where its conditions hold, else k_prep; COVERM_PREP_V=1: k_prep everywhere
-    int prep_waves = -1;   // COVERM_PREP_WAVES=0 | 5 | 6 | 8: the amdgpu_waves_per_eu builds (measurement switch); -1: k_prep2 at five waves (96 registers, no scratch), k_prep as it compiles
-    int fast_waves = 7;        // 6 / 7 / 8: which of the three builds below (COVERM_FAST_WAVES)
+    int prep_waves = 6;    // k_prep6 (80 registers, six waves per SIMD: the default) or k_prep as it compiles (88 registers, five; COVERM_PREP_WAVES=5)
+    int fast_waves = 7;        // k_pileup_fast7 (384 LDS bins, seven waves per SIMD: the default) or k_pileup_fast (512 bins, six; COVERM_FAST_WAVES=6)
     int n_cus = 256;
     uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
 
@@ -115,6 +114,7 @@ struct cov_session {
     DevBuf<int32_t> d_depth_all; DevBuf<u64> d_depth_off; bool depth_all_valid = false;
     DevBuf<DevInterval> d_iv; DevBuf<DevIntervalStats> d_ivst; DevBuf<unsigned long long> d_ivhist; uint64_t ivhist_total = 0;
     DevBuf<uint8_t> d_mask;
+    std::vector<uint8_t> h_mask;       // host copy (convert_results lays the compact histogram out itself)
     bool have_mask = false;
     // results of the device pipeline live in ONE block [DevGlobal][DevContig x n_targets] (d_res): one DMA brings them to
     // the host, and cov_gather sends the same block over RCCL.  d_glob / d_ctg are views into it (never freed themselves).
@@ -359,8 +359,8 @@ void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
 // k_pileup_fast over every tile (it skips the ones k_ranges flagged TILE_F_SLOW)
 template <bool H, int WAVES>
 void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    const auto kern = WAVES == 8 ? &k_pileup_fast8<H> : WAVES == 7 ? &k_pileup_fast7<H> : &k_pileup_fast<H>;
-    const size_t smem = pileup_fast_smem_bytes(H, WAVES == 8 ? FAST_HB8 : WAVES == 7 ? FAST_HB7 : FAST_HB);
+    const auto kern = WAVES == 7 ? &k_pileup_fast7<H> : &k_pileup_fast<H>;
+    const size_t smem = pileup_fast_smem_bytes(H, WAVES == 7 ? FAST_HB7 : FAST_HB);
     // the dynamic-LDS limit and the occupancy are per-device facts, and span mode launches from one thread per device: cached per
     // device id, in atomics (two threads racing for the same device compute the same value)
     static std::atomic<int> occ_dev[64];
@@ -383,8 +383,7 @@ void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
 }
 template <bool H>
 void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    if (s->fast_waves == 8) launch_fast_v<H, 8>(s, a, n_tiles);
-    else if (s->fast_waves == 7) launch_fast_v<H, 7>(s, a, n_tiles);
+    if (s->fast_waves == 7) launch_fast_v<H, 7>(s, a, n_tiles);
     else launch_fast_v<H, 6>(s, a, n_tiles);
 }
 
@@ -487,9 +486,8 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
         stamp("device attribute");
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
-    if (const char *fw = getenv("COVERM_FAST_WAVES")) { const int v = atoi(fw); s->fast_waves = v == 6 || v == 8 ? v : 7; }
-    if (const char *pv = getenv("COVERM_PREP_V")) s->prep_v = atoi(pv) == 1 ? 1 : 2;
-    if (const char *pw = getenv("COVERM_PREP_WAVES")) s->prep_waves = atoi(pw);
+    if (const char *fw = getenv("COVERM_FAST_WAVES")) { const int v = atoi(fw); s->fast_waves = v == 6 ? 6 : 7; }
+    if (const char *pw = getenv("COVERM_PREP_WAVES")) s->prep_waves = atoi(pw) == 5 ? 5 : 6;
     if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
     if (const char *c = getenv("COVERM_STORE_CAP_RECORDS")) { const long long v = atoll(c); if (v >= 1) s->cap_records = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
@@ -615,7 +613,8 @@ cov_status cov_set_targets(cov_session *s, uint32_t n_targets, const uint64_t *t
 cov_status cov_set_target_mask(cov_session *s, const uint8_t *mask) {
     if (!s) return COV_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(s->cfg.device));
-    if (!mask) { s->have_mask = false; return COV_OK; }
+    if (!mask) { s->have_mask = false; s->h_mask.clear(); return COV_OK; }
+    s->h_mask.assign(mask, mask + s->n_targets);
     HIPCHK(s->d_mask.reserve(std::max<size_t>(1, s->n_targets), s->stream));
     if (s->n_targets) HIPCHK(hipMemcpyAsync(s->d_mask.p, mask, s->n_targets, hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -749,7 +748,10 @@ static cov_status convert_results(cov_session *s, const DevGlobal &G, const DevC
             o.win_max_d = C.max_d;
             o.win_min_d = (C.proc_win < win_len || C.min_d == 0xffffffffu) ? 0u : C.min_d;
         }
-        if (want_hist) { o.hist_len = C.hist_len; o.hist_off = C.chist_off; hist_total += C.hist_len; }
+        if (want_hist) {      // the compact histogram's layout (what k_hist_layout<1> computes on the device when the bins are compacted there)
+            const bool live = C.n_pass != 0 && (!s->have_mask || s->h_mask[c]);
+            o.hist_len = (live && win_len) ? C.max_d + 1u : 0u; o.hist_off = hist_total; hist_total += o.hist_len;
+        }
     }
     if (summary) {
         uint64_t prim = 0, cons = 0;
@@ -842,17 +844,9 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
 
     if (R) {
         time_begin(s, COV_K_PREP);
-        // k_prep2 wants the short-read geometry and columns it can load two records at a time (the session's own store always is; an adopted
-        // batch is the caller's memory)
-        auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-        const bool pair = s->prep_v == 2 && !long_cigars && al16(r.tid) && al16(r.pos) && al16(r.flag) && al16(r.mapq) && al16(r.nm) && al16(r.nm_kind) &&
-                          al16(r.l_seq) && al16(r.cigar_off) && al16(r.cigar) && al16(s->d_runs.p);
-        const int pw = s->prep_waves >= 0 ? s->prep_waves : (pair ? 5 : 0);
 #define COV_LAUNCH_PREP(ID, FI, MA)                                                                                                       \
-        hipLaunchKernelGGL((pair ? (pw == 8 ? &k_prep2w8<ID, FI, MA> : pw == 6 ? &k_prep2w6<ID, FI, MA> : pw == 5 ? &k_prep2w5<ID, FI, MA> : &k_prep2<ID, FI, MA>)           \
-                                 : (pw == 8 ? &k_prep8<ID, FI, MA> : pw == 6 ? &k_prep6<ID, FI, MA> : &k_prep<ID, FI, MA>)),              \
-                           dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f, s->d_ctg.p, s->d_glob.p,                       \
-                           s->d_runs.p, idp, idn, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap)
+        hipLaunchKernelGGL((s->prep_waves == 5 ? &k_prep<ID, FI, MA> : &k_prep6<ID, FI, MA>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f, s->d_ctg.p, \
+                           s->d_glob.p, s->d_runs.p, idp, idn, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap)
         {
             const int key = (want_id ? 4 : 0) | (s->cfg.filter_single ? 2 : 0) | (mask != nullptr ? 1 : 0);
             switch (key) {
@@ -867,7 +861,12 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
             }
         }
 #undef COV_LAUNCH_PREP
-        if (nT) hipLaunchKernelGGL(k_prep_reduce, dim3(nT), dim3(64), 0, st, s->d_ctg.p, nT, s->d_part.p, prep_grid, prep_chunk);
+        if (nT) {   // what depends on k_prep alone, one launch: the workgroups' partial counters to their contigs (the identity kernels read them),
+                    // and the long-CIGAR bucket counts per tile (waves stride over the RW_BUCKET list; nothing to do for short reads)
+            const u32 n_red = (nT + 3u) / 4u, cx_grid0 = (u32)s->n_cus * 8u;
+            hipLaunchKernelGGL(k_post_prep, dim3(n_red + cx_grid0), dim3(256), 0, st, r, s->d_tlen.p, s->d_glob.p, cx, ti, s->d_ctg.p, nT, (const PrepPartial *)s->d_part.p,
+                               prep_grid, prep_chunk, n_red);
+        }
         time_end(s, COV_K_PREP);
         HIPCHK(hipGetLastError());
         if (want_id && nT) {   // depends only on k_prep: run beside k_ranges / k_pileup
@@ -896,11 +895,11 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         time_begin(s, COV_K_RANGES);
         const u32 n_blocks = (s->n_tiles + 1023u) / 1024u;
         const u32 cx_grid = (u32)s->n_cus * 8u;     // waves stride over the RW_BUCKET list; nothing to do for short reads
-        hipLaunchKernelGGL((k_cx_expand<false>), dim3(cx_grid), dim3(256), 0, st, r, s->d_tlen.p, s->d_glob.p, cx, ti);
-        hipLaunchKernelGGL(k_tile_scan1, dim3(n_blocks), dim3(1024), 0, st, s->d_tcnt.p, s->n_tiles, s->d_tscan.p, s->d_ttop.p);
-        hipLaunchKernelGGL(k_tile_scan2, dim3(1), dim3(1024), 0, st, s->d_ttop.p, n_blocks, (u64 *)nullptr);
-        hipLaunchKernelGGL(k_tile_scan1, dim3(n_blocks), dim3(1024), 0, st, s->d_cx_cnt.p, s->n_tiles, s->d_cx_scan.p, s->d_cx_top.p);
-        hipLaunchKernelGGL(k_tile_scan2, dim3(1), dim3(1024), 0, st, s->d_cx_top.p, n_blocks, &s->d_glob.p->cx_total);
+        ScanPair sp{};
+        sp.cnt[0] = s->d_tcnt.p; sp.scan[0] = s->d_tscan.p; sp.top[0] = s->d_ttop.p; sp.total[0] = nullptr;
+        sp.cnt[1] = s->d_cx_cnt.p; sp.scan[1] = s->d_cx_scan.p; sp.top[1] = s->d_cx_top.p; sp.total[1] = &s->d_glob.p->cx_total;
+        hipLaunchKernelGGL(k_tile_scan1, dim3(2u * n_blocks), dim3(1024), 0, st, sp, s->n_tiles, n_blocks);
+        hipLaunchKernelGGL(k_tile_scan2, dim3(2), dim3(1024), 0, st, sp, n_blocks);
         hipLaunchKernelGGL((k_cx_expand<true>), dim3(cx_grid), dim3(256), 0, st, r, s->d_tlen.p, s->d_glob.p, cx, ti);
         u32 *slow_list = (s->stream_rows && s->use_fast) ? s->d_slow_list.p : nullptr;
         if (want_hist)
@@ -928,18 +927,12 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         time_end(s, COV_K_PILEUP);
         HIPCHK(hipGetLastError());
         if (want_hist) {
-            hipLaunchKernelGGL((k_hist_layout<1>), dim3(1), dim3(1024), 0, st, s->d_ctg.p, nT, s->d_tlen.p, mask,
-                               (u64)s->cfg.contig_end_exclusion, s->d_glob.p);
-            // the compact histogram right behind its layout (its size is only known on the device: the buffer takes the arena's
-            // bound), and as many of its bins as the previous finish had already on their way to page-locked memory, so that
-            // cov_fetch_hist is no second launch + round trip (0.08 ms of a 1.9 ms step at BASELINE config 2).  With the estimators
-            // evaluated on the device (cov_set_estimators) nobody may ever ask for the bins: they are then compacted by the first
-            // cov_fetch_hist instead, unless the caller fetched them after the finish before this one.
             compacted = s->est.n == 0 || s->hist_fetch_seen;
             s->hist_prefetched = 0;
             if (compacted) {
                 HIPCHK(s->d_chist.reserve((size_t)R + nT + 1, st));
                 time_begin(s, COV_K_HIST_COMPACT);
+                hipLaunchKernelGGL((k_hist_layout<1>), dim3(1), dim3(1024), 0, st, s->d_ctg.p, nT, s->d_tlen.p, mask, (u64)s->cfg.contig_end_exclusion, s->d_glob.p);
                 hipLaunchKernelGGL(k_hist_compact, dim3(nT), dim3(256), 0, st, s->d_ctg.p, nT, s->d_tlen.p, (u64)s->cfg.contig_end_exclusion, s->d_arena.p, s->d_chist.p);
                 time_end(s, COV_K_HIST_COMPACT);
                 HIPCHK(hipGetLastError());
@@ -1007,7 +1000,8 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
 
     const cov_status cst = convert_results(s, s->h_glob, s->h_ctg, R, stats, summary, s->spill.inflight, s->spill.records);
     if (cst != COV_OK) return cst;
-    s->last_chist_total = want_hist ? s->h_glob.chist_total : 0;
+    s->last_chist_total = 0;
+    if (want_hist) for (u32 c = 0; c < nT; c++) s->last_chist_total += stats[c].hist_len;      // (the host laid the compact histogram out: convert_results)
     s->hist_compacted = compacted;
     s->est_valid = s->est.n != 0;
     s->finished = true;
@@ -1947,16 +1941,18 @@ cov_status cov_fetch_hist(cov_session *s, uint64_t *hist) {
 static cov_status fetch_chunk_hist(cov_session *s, uint64_t *hist) {
     if (!s || !s->finished || !(s->cfg.want & COV_WANT_HIST)) return COV_ERR_STATE;
     HIPCHK(hipSetDevice(s->cfg.device));
-    const uint64_t total = s->h_glob.chist_total;
+    const uint64_t total = s->last_chist_total;
     s->hist_fetch_seen = true;
     if (total == 0) return COV_OK;
     if (!hist) return COV_ERR_INVALID_ARG;
-    if (!s->hist_compacted) {      // (a finish that had nothing to launch)
+    if (!s->hist_compacted) {      // the finish left the bins in the arena (its estimators were evaluated on the device): lay them out and compact them now
         HIPCHK(s->d_chist.reserve(total, s->stream));
+        hipLaunchKernelGGL((k_hist_layout<1>), dim3(1), dim3(1024), 0, s->stream, s->d_ctg.p, s->n_targets, s->d_tlen.p, s->have_mask ? (const uint8_t *)s->d_mask.p : (const uint8_t *)nullptr,
+                           (u64)s->cfg.contig_end_exclusion, s->d_glob.p);
         hipLaunchKernelGGL(k_hist_compact, dim3(s->n_targets), dim3(256), 0, s->stream, s->d_ctg.p, s->n_targets, s->d_tlen.p,
                            (u64)s->cfg.contig_end_exclusion, s->d_arena.p, s->d_chist.p);
         HIPCHK(hipGetLastError());
-        s->hist_prefetched = 0;
+        s->hist_prefetched = 0; s->hist_compacted = true;
     }
     const u64 have = std::min<u64>(total, s->hist_prefetched);      // arrived with cov_finish's own synchronisation
     if (have) memcpy(hist, s->h_chist, (size_t)have * 8);

@@ -348,18 +348,13 @@ __device__ __forceinline__ void prep_flush(DevContig *ctg, int cur, PrepAcc &a) 
 
 // FILTER: the reader-stage single-read filter is on (filter.rs:88-116); MASKED: a target mask is set (genome.rs:170-171).
 // Both are compile-time so that the common `coverm contig` shape carries neither the loads (mapq, l_seq, mask) nor the code.
-// PAIR (k_prep2, the short-read geometry only: b_active = 2): a lane takes two ADJACENT records (2 l, 2 l + 1 of the wave's 128) instead
-// of records 256 apart.  tid / pos / nm / cigar_off then come in as 8-byte loads, flag as one dword, nm_kind (mapq) as one short, the
-// two run words leave as one 16-byte store; a record's neighbours in file order (position-order checks) are the lane's other record or
-// the neighbouring lane's (one DPP move; the wave's two edge records by one uniform load each) instead of three more loads per record;
-// contig length / first tile / mask are loaded once when both records share the tid (a wave-uniform test: contig boundaries are rare)
-// and the first three CIGAR words of each record as one 12-byte load.  15 memory instructions per pair instead of 36.  The host only
-// launches it over columns aligned to 16 bytes; the last, partial pass of the store takes the clamped per-element loads.
-struct __attribute__((packed, aligned(4))) PrepU3 { u32 a, b, c; };
-template <class V, int ALIGN>
-__device__ __forceinline__ V prep_ld(const void *p) { V v; __builtin_memcpy(&v, __builtin_assume_aligned(p, ALIGN), sizeof(V)); return v; }
-
-template <bool WANT_IDENTITY, bool FILTER, bool MASKED, bool PAIR>
+// (k_prep2 — a lane taking two ADJACENT records: 8-byte loads of tid / pos / nm / cigar_off, one dword of flags, neighbours in file order by
+// DPP, 12-byte CIGAR loads, one 16-byte store of both run words: 17 memory instructions per pair instead of 36 — was built and measured in
+// round 5, alternating with this kernel on one box: 0.76-0.78 ms against 0.61, profiles/r05_prep_pileup_ab.log.  Its counters say why: 43 %
+// fewer memory instructions and 6 % fewer VALU instructions, but the SIMDs are busy ISSUING — 29 % of a wave's time executing at 4.3 waves per
+// SIMD — not waiting for bytes, and the 64-bit address arithmetic of the wide loads plus the wave-wide DPP moves cost more issue slots than
+// the narrow loads they replaced.  Removed; what did pay is one more wave per SIMD, k_prep6 below.)
+template <bool WANT_IDENTITY, bool FILTER, bool MASKED>
 __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restrict__ tlen, u32 n_targets,
                                           const uint8_t *__restrict__ mask, const FilterCfg &f, DevContig *ctg,
                                           DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ identp,
@@ -389,98 +384,36 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
     uint2 *runs_c = runs + chunk;
 
     for (int ps = 0; ps < passes; ps++) {
-        // chunk-relative index of the lane's first record, and the distance to its second
-        const u32 l0 = PAIR ? (u32)ps * 512u + 2u * threadIdx.x : (u32)(ps * b_active) * 256u + threadIdx.x;
-        constexpr u32 KSTRIDE = PAIR ? 1u : 256u;
+        const u32 l0 = (u32)(ps * b_active) * 256u + threadIdx.x;
         const u32 i0 = chunk + l0;
         if (!__any(i0 < r.n)) break;
         // ---- phase A: every independent field of PREP_B records, issued back to back (clamped, branch-free)
         u32 fl[PREP_B], mq[PREP_B], nmk[PREP_B], nmv32[PREP_B], lsq[PREP_B], co0[PREP_B], co1[PREP_B];
         int td[PREP_B], ps_[PREP_B], ptid[PREP_B], ppos[PREP_B], ntid[PREP_B];
-        const bool pass_full = PAIR && chunk + (u32)ps * 512u + 512u <= r.n;      // workgroup-uniform: every pair of this pass lies inside the store
-        if (PAIR && pass_full) {
-            const int2 t2 = prep_ld<int2, 8>(tid_c + l0), p2 = prep_ld<int2, 8>(pos_c + l0);
-            const uint2 n2 = prep_ld<uint2, 8>(nm_c + l0), c2 = prep_ld<uint2, 8>(coff_c + l0);
-            const u32 c3 = coff_c[l0 + 2u];
-            const u32 f2 = prep_ld<u32, 4>(flag_c + l0);
-            const u32 k2 = prep_ld<uint16_t, 2>(nmk_c + l0);
-            td[0] = t2.x; td[1] = t2.y; ps_[0] = p2.x; ps_[1] = p2.y; nmv32[0] = n2.x; nmv32[1] = n2.y;
-            co0[0] = c2.x; co1[0] = c2.y; co0[1] = c2.y; co1[1] = c3;
-            fl[0] = f2 & 0xffffu; fl[1] = f2 >> 16; nmk[0] = k2 & 0xffu; nmk[1] = k2 >> 8;
-            if (FILTER) {
-                const u32 m2 = prep_ld<uint16_t, 2>(mapq_c + l0);
-                const uint2 s2 = prep_ld<uint2, 8>(lseq_c + l0);
-                mq[0] = m2 & 0xffu; mq[1] = m2 >> 8; lsq[0] = s2.x; lsq[1] = s2.y;
-            } else { mq[0] = mq[1] = 0u; lsq[0] = lsq[1] = 0u; }
-        } else {
 #pragma unroll
-            for (int k = 0; k < PREP_B; k++) {
-                const u32 lc = min(l0 + (u32)k * KSTRIDE, lmax) & (u32)(PREP_CHUNK - 1);   // the mask is a no-op that bounds lc for the compiler
-                fl[k] = flag_c[lc]; td[k] = tid_c[lc]; ps_[k] = pos_c[lc]; mq[k] = FILTER ? mapq_c[lc] : 0u; nmk[k] = nmk_c[lc];
-                nmv32[k] = nm_c[lc]; lsq[k] = FILTER ? lseq_c[lc] : 0u; co0[k] = coff_c[lc]; co1[k] = coff_c[lc + 1u];
-            }
-        }
-        if (PAIR) {
-            // neighbours in file order: the lane's other record, or the neighbouring lane's by one DPP move; the records in front of the
-            // wave's first and behind its last by one uniform load each (clamped at the ends of the store: those values are not looked at)
-            const u32 w0 = chunk + (u32)ps * 512u + (u32)w * 128u;                 // the wave's first record
-            const u32 e_prev = min(w0 ? w0 - 1u : 0u, nlast), e_next = min(w0 + 128u, nlast);
-            const int et = r.tid[e_prev], ep = r.pos[e_prev], en = r.tid[e_next];
-            ptid[0] = __builtin_amdgcn_update_dpp(et, td[1], 0x138, 0xf, 0xf, false);      // wave_shr:1, lane 0 keeps the edge value
-            ppos[0] = __builtin_amdgcn_update_dpp(ep, ps_[1], 0x138, 0xf, 0xf, false);
-            ntid[0] = td[1];
-            ptid[1] = td[0]; ppos[1] = ps_[0];
-            ntid[1] = __builtin_amdgcn_update_dpp(en, td[0], 0x130, 0xf, 0xf, false);      // wave_shl:1, lane 63 keeps the edge value
-        } else {
-#pragma unroll
-            for (int k = 0; k < PREP_B; k++) {
-                const u32 lc = min(l0 + (u32)k * KSTRIDE, lmax) & (u32)(PREP_CHUNK - 1);
-                const u32 ic = chunk + lc;
-                const u32 lp = (lc + (ic > 0u ? 0u : 1u)) & (u32)(2 * PREP_CHUNK - 1), ln = (lc + (ic < nlast ? 1u : 0u)) & (u32)(2 * PREP_CHUNK - 1);
-                ptid[k] = tid_m[lp]; ppos[k] = pos_m[lp]; ntid[k] = tid_c[ln];
-            }
+        for (int k = 0; k < PREP_B; k++) {
+            const u32 lc = min(l0 + (u32)k * 256u, lmax) & (u32)(PREP_CHUNK - 1);   // the mask is a no-op that bounds lc for the compiler
+            const u32 ic = chunk + lc;
+            fl[k] = flag_c[lc]; td[k] = tid_c[lc]; ps_[k] = pos_c[lc]; mq[k] = FILTER ? mapq_c[lc] : 0u; nmk[k] = nmk_c[lc];
+            nmv32[k] = nm_c[lc]; lsq[k] = FILTER ? lseq_c[lc] : 0u; co0[k] = coff_c[lc]; co1[k] = coff_c[lc + 1u];
+            const u32 lp = (lc + (ic > 0u ? 0u : 1u)) & (u32)(2 * PREP_CHUNK - 1), ln = (lc + (ic < nlast ? 1u : 0u)) & (u32)(2 * PREP_CHUNK - 1);
+            ptid[k] = tid_m[lp]; ppos[k] = pos_m[lp]; ntid[k] = tid_c[ln];
         }
         // ---- phase B: loads that depend on phase A (first three CIGAR words, contig length, mask)
         u32 cw[PREP_B][3], Lc[PREP_B], mk[PREP_B], t0[PREP_B];
-        if (PAIR) {
-            {
-                const bool tok = td[0] >= 0 && (u32)td[0] < n_targets;
-                Lc[0] = tok ? tlen[td[0]] : 0u; t0[0] = tok ? ti.tile_first[td[0]] : 0u; mk[0] = (MASKED && tok) ? mask[td[0]] : 1u;
-            }
-            Lc[1] = Lc[0]; t0[1] = t0[0]; mk[1] = mk[0];
-            if (__any(td[1] != td[0])) {       // a contig boundary inside the wave's 128 records: rare
-                const bool tok = td[1] >= 0 && (u32)td[1] < n_targets;
-                Lc[1] = tok ? tlen[td[1]] : 0u; t0[1] = tok ? ti.tile_first[td[1]] : 0u; mk[1] = (MASKED && tok) ? mask[td[1]] : 1u;
-            }
-            // three words per record as one 12-byte load when no lane's words can lie behind the end of the array
-            if (r.cigar_end >= 3u && __all(max(co0[0], co0[1]) <= r.cigar_end - 3u)) {
-#pragma unroll
-                for (int k = 0; k < PREP_B; k++) {
-                    const PrepU3 q = prep_ld<PrepU3, 4>(r.cigar + co0[k]);
-                    cw[k][0] = q.a; cw[k][1] = q.b; cw[k][2] = q.c;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < PREP_B; k++)
-#pragma unroll
-                    for (int c = 0; c < 3; c++) cw[k][c] = r.cigar_end ? r.cigar[min(co0[k] + (u32)c, cig_last)] : 0u;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < PREP_B; k++) {
-                const bool tok = td[k] >= 0 && (u32)td[k] < n_targets;
-                Lc[k] = tok ? tlen[td[k]] : 0u;
-                t0[k] = tok ? ti.tile_first[td[k]] : 0u;
-                mk[k] = (MASKED && tok) ? mask[td[k]] : 1u;
-#pragma unroll
-                for (int c = 0; c < 3; c++) cw[k][c] = r.cigar_end ? r.cigar[min(co0[k] + (u32)c, cig_last)] : 0u;
-            }
-        }
-        // ---- phase C: per-record logic
-        uint2 rws[PREP_B];
 #pragma unroll
         for (int k = 0; k < PREP_B; k++) {
-            const u32 i = i0 + (u32)k * KSTRIDE;
+            const bool tok = td[k] >= 0 && (u32)td[k] < n_targets;
+            Lc[k] = tok ? tlen[td[k]] : 0u;
+            t0[k] = tok ? ti.tile_first[td[k]] : 0u;
+            mk[k] = (MASKED && tok) ? mask[td[k]] : 1u;
+#pragma unroll
+            for (int c = 0; c < 3; c++) cw[k][c] = r.cigar_end ? r.cigar[min(co0[k] + (u32)c, cig_last)] : 0u;
+        }
+        // ---- phase C: per-record logic
+#pragma unroll
+        for (int k = 0; k < PREP_B; k++) {
+            const u32 i = i0 + (u32)k * 256u;
             const bool in = i < r.n && k < b_active;
             const u32 flag = in ? fl[k] : 0x904u;
             const int tid = in ? td[k] : -1;
@@ -530,11 +463,12 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
                 const u32 nops = hard ? 0u : nops_all;
                 const u32 L = Lc[k];
                 u32 cursor = (u32)pos, cur_e = 0, al32 = 0, in32 = 0;
-                auto step = [&](u32 wd, bool act) {
+                // (an operation the record does not have comes in as 0S — no flag set, no length — so no step tests whether it is active)
+                auto step = [&](u32 wd) {
                     const u32 len = wd >> 4, bit = 1u << (wd & 15u);
-                    big |= act && len >= (1u << 24);
-                    const bool m = act && (bit & 0x181u);                      // M = X   (contig.rs:171-186)
-                    badcig |= act && (bit & 0xfe00u);
+                    big |= len >= (1u << 24);
+                    const bool m = (bit & 0x181u) != 0u;                       // M = X   (contig.rs:171-186)
+                    badcig |= (bit & 0xfe00u) != 0u;
                     oob |= m && cursor >= L;                                   // negative cursors wrap to >= 2^31 > L
                     const bool ext = m && n_runs > 0u && cursor == cur_e;      // continues the open merged run
                     n_runs += (m && !ext) ? 1u : 0u;
@@ -544,17 +478,14 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
                     run_len = r1 ? (ext ? run_len : 0u) + len : run_len;
                     run2_len = r2 ? (ext ? run2_len : 0u) + len : run2_len;
                     cur_e = m ? cursor + len : cur_e;
-                    cursor += (act && (bit & 0x18du)) ? len : 0u;              // M D N = X consume the reference
-                    al32 += (act && (bit & 0x187u)) ? len : 0u;                // M I D = X   (:187-199)
-                    in32 += (act && (bit & 0x006u)) ? len : 0u;                // I D
+                    cursor += (bit & 0x18du) ? len : 0u;                       // M D N = X consume the reference
+                    al32 += (bit & 0x187u) ? len : 0u;                         // M I D = X   (:187-199)
+                    in32 += (bit & 0x006u) ? len : 0u;                         // I D
                 };
-                step(cw[k][0], 0u < nops);
-                step(cw[k][1], 1u < nops);
-                step(cw[k][2], 2u < nops);
-                for (u32 c = 3; __any(c < nops); c++) {
-                    const bool act = c < nops;
-                    step(act ? r.cigar[co0[k] + c] : 0u, act);
-                }
+                step(0u < nops ? cw[k][0] : 4u);
+                step(1u < nops ? cw[k][1] : 4u);
+                step(2u < nops ? cw[k][2] : 4u);
+                for (u32 c = 3; __any(c < nops); c++) step(c < nops ? r.cigar[co0[k] + c] : 4u);
                 aligned = al32; indel = in32;
                 span = cursor - (u32)pos;
                 hard |= big;
@@ -611,8 +542,7 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
                         rw.y = (is_bucket ? RW_BUCKET : RW_COMPLEX) << 30;
                     }
                 }
-                if (PAIR && pass_full) rws[k] = rw;      // both run words of the pair leave as one 16-byte store behind the loop
-                else runs_c[i - chunk] = rw;
+                runs_c[i - chunk] = rw;
                 if (WANT_IDENTITY) {   // a NULL stream is one the caller does not need (COV_WANT_IDENTITY_*_ONLY)
                     if (identn != nullptr) identn[i] = (masked_in && !supp) ? idv : 0.0;
                     if (identp != nullptr) identp[i] = (masked_in && !supp && !sec) ? idv : 0.0;
@@ -693,7 +623,6 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
                 }
             }
         }
-        if (PAIR && pass_full) *reinterpret_cast<uint4 *>(runs_c + l0) = make_uint4(rws[0].x, rws[0].y, rws[1].x, rws[1].y);
     }
     // End of chunk: if all four waves stayed inside the same single contig, publish ONE partial record for the
     // workgroup (reduced by k_prep_reduce); otherwise fall back to atomics.
@@ -741,28 +670,24 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
     }
 }
 
-#define COV_PREP_KERNEL(NAME, PAIR, ATTR)                                                                                                        \
+#define COV_PREP_KERNEL(NAME, ATTR)                                                                                                              \
     template <bool WANT_IDENTITY, bool FILTER, bool MASKED>                                                                                      \
     __global__ __launch_bounds__(256) ATTR void NAME(Records r, const u32 *__restrict__ tlen, u32 n_targets, const uint8_t *__restrict__ mask,   \
                                                      FilterCfg f, DevContig *ctg, DevGlobal *g, uint2 *__restrict__ runs,                        \
                                                      double *__restrict__ identp, double *__restrict__ identn, PrepPartial *__restrict__ part,   \
                                                      TileIdx ti, int passes, int b_active, u32 *__restrict__ cx_list, u32 cx_list_cap) {         \
-        prep_body<WANT_IDENTITY, FILTER, MASKED, PAIR>(r, tlen, n_targets, mask, f, ctg, g, runs, identp, identn, part, ti, passes, b_active,    \
-                                                       cx_list, cx_list_cap);                                                                    \
+        prep_body<WANT_IDENTITY, FILTER, MASKED>(r, tlen, n_targets, mask, f, ctg, g, runs, identp, identn, part, ti, passes, b_active, cx_list, \
+                                                 cx_list_cap);                                                                                   \
     }
-COV_PREP_KERNEL(k_prep, false, )                                                   // records 256 apart per lane: every geometry, any alignment
-COV_PREP_KERNEL(k_prep6, false, __attribute__((amdgpu_waves_per_eu(6))))           // (COVERM_PREP_WAVES=6 / 8: measurement switches)
-COV_PREP_KERNEL(k_prep8, false, __attribute__((amdgpu_waves_per_eu(8))))
-COV_PREP_KERNEL(k_prep2, true, )                                                   // adjacent pairs per lane: the short-read geometry
-COV_PREP_KERNEL(k_prep2w5, true, __attribute__((amdgpu_waves_per_eu(5))))
-COV_PREP_KERNEL(k_prep2w6, true, __attribute__((amdgpu_waves_per_eu(6))))
-COV_PREP_KERNEL(k_prep2w8, true, __attribute__((amdgpu_waves_per_eu(8))))
+// k_prep6 (the default): the registers capped at 80 for six waves per SIMD (two to six dwords of scratch): 0.585 ms against 0.607 at
+// BASELINE config 2, alternating runs on one box (profiles/r05_prep_pileup_ab.log); at eight waves (64 registers, 72-100 bytes of
+// scratch) the scratch traffic costs more than the waves hide.  COVERM_PREP_WAVES=5 selects k_prep as it compiles (88 registers).
+COV_PREP_KERNEL(k_prep, )
+COV_PREP_KERNEL(k_prep6, __attribute__((amdgpu_waves_per_eu(6))))
 #undef COV_PREP_KERNEL
 
 // One wave per contig: adds the partial records of the workgroups that lay entirely inside it.
-__global__ __launch_bounds__(64) void k_prep_reduce(DevContig *ctg, u32 n_targets, const PrepPartial *__restrict__ part,
-                                                    u32 n_parts, u32 chunk_recs) {
-    const u32 c = blockIdx.x;
+__device__ __forceinline__ void prep_reduce_body(u32 c, DevContig *ctg, u32 n_targets, const PrepPartial *__restrict__ part, u32 n_parts, u32 chunk_recs) {
     if (c >= n_targets) return;
     DevContig *C = &ctg[c];
     const u32 rs = C->rec_start, re = C->rec_end;
@@ -796,10 +721,14 @@ __device__ __forceinline__ u32 lower_bound_pos(const int32_t *__restrict__ pos, 
 // Tile descriptor, two uint4 per tile: [2t] = (first candidate record, last, contig length, flags — bit 0: records
 // of other contigs may be interleaved in the range, check tid); [2t+1] = (contig, tile start, 0, 0).
 // Exclusive prefix sums of tcnt over all tiles: per 1024-tile block (k_tile_scan1) + over the block totals (k_tile_scan2).
-__global__ __launch_bounds__(1024) void k_tile_scan1(const u32 *__restrict__ tcnt, u32 n_tiles, u32 *__restrict__ tscan,
-                                                     u32 *__restrict__ ttop) {
+// Two arrays per launch (the tile counts and the long-CIGAR bucket counts: both are ready once k_post_prep has run): blocks
+// [0, n_blocks) scan the first, [n_blocks, 2 n_blocks) the second.
+struct ScanPair { const u32 *cnt[2]; u32 *scan[2]; u32 *top[2]; u64 *total[2]; };
+__global__ __launch_bounds__(1024) void k_tile_scan1(ScanPair sp, u32 n_tiles, u32 n_blocks) {
     __shared__ u32 wtot[16];
-    const u32 t = blockIdx.x * 1024u + threadIdx.x;
+    const u32 which = blockIdx.x >= n_blocks ? 1u : 0u, blk = blockIdx.x - which * n_blocks;
+    const u32 *__restrict__ tcnt = sp.cnt[which];
+    const u32 t = blk * 1024u + threadIdx.x;
     const int lane = lane_id(), w = threadIdx.x >> 6;
     const u32 v = t < n_tiles ? tcnt[t] : 0u;
     const u32 inc = (u32)wave_incl_scan((int)v);
@@ -807,13 +736,15 @@ __global__ __launch_bounds__(1024) void k_tile_scan1(const u32 *__restrict__ tcn
     __syncthreads();
     u32 wbase = 0, tot = 0;
     for (int k = 0; k < 16; k++) { const u32 x = wtot[k]; if (k < w) wbase += x; tot += x; }
-    if (t < n_tiles) tscan[t] = wbase + inc - v;
-    if (threadIdx.x == 0) ttop[blockIdx.x] = tot;
+    if (t < n_tiles) sp.scan[which][t] = wbase + inc - v;
+    if (threadIdx.x == 0) sp.top[which][blk] = tot;
 }
 
-__global__ __launch_bounds__(1024) void k_tile_scan2(u32 *ttop, u32 n_blocks, u64 *total) {
+__global__ __launch_bounds__(1024) void k_tile_scan2(ScanPair sp, u32 n_blocks) {
     __shared__ u32 wtot[16];
     __shared__ u32 carry_s;
+    u32 *ttop = sp.top[blockIdx.x];
+    u64 *total = sp.total[blockIdx.x];
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     const int lane = lane_id(), w = threadIdx.x >> 6;
@@ -838,11 +769,10 @@ __global__ __launch_bounds__(1024) void k_tile_scan2(u32 *ttop, u32 n_blocks, u6
 // cigar_walk_wave does) and, for every M/=/X operation, visits the tiles it overlaps: FILL = false counts entries per
 // tile, FILL = true writes (start, end) at the tile's cursor.  Lanes that hit the same tile share one atomic.
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_cx_expand(Records r, const u32 *__restrict__ tlen, DevGlobal *g, CxIdx cx, TileIdx ti) {
+__device__ __forceinline__ void cx_expand_body(const Records &r, const u32 *__restrict__ tlen, DevGlobal *g, const CxIdx &cx, const TileIdx &ti, u32 wave, u32 n_waves) {
     const int lane = lane_id();
     const u32 n = min(g->n_cx, cx.list_cap);
     if (FILL && g->cx_total > cx.runs_cap) return;     // the host grows the buffer and runs the pipeline again
-    const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
     const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (u32 j = wave; j < n; j += n_waves) {
         const u32 i = cx.list[j];
@@ -883,6 +813,19 @@ __global__ __launch_bounds__(256) void k_cx_expand(Records r, const u32 *__restr
             cur0 += (long long)__builtin_amdgcn_readlane(incl, 63);
         }
     }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_cx_expand(Records r, const u32 *__restrict__ tlen, DevGlobal *g, CxIdx cx, TileIdx ti) {
+    cx_expand_body<FILL>(r, tlen, g, cx, ti, blockIdx.x * 4u + (threadIdx.x >> 6), gridDim.x * 4u);
+}
+
+// What depends on k_prep alone, in one launch: blocks [0, n_red) add the workgroups' partial counters to their contigs (one wave per
+// contig), the blocks behind them count the long-CIGAR bucket entries per tile (k_cx_expand<false>; nothing to do for short reads).
+__global__ __launch_bounds__(256) void k_post_prep(Records r, const u32 *__restrict__ tlen, DevGlobal *g, CxIdx cx, TileIdx ti, DevContig *ctg, u32 n_targets,
+                                                   const PrepPartial *__restrict__ part, u32 n_parts, u32 chunk_recs, u32 n_red) {
+    if (blockIdx.x < n_red) prep_reduce_body(blockIdx.x * 4u + (threadIdx.x >> 6), ctg, n_targets, part, n_parts, chunk_recs);
+    else cx_expand_body<false>(r, tlen, g, cx, ti, (blockIdx.x - n_red) * 4u + (threadIdx.x >> 6), (gridDim.x - n_red) * 4u);
 }
 
 // One thread per tile: candidate record range [x, y) from the tile counts (see TileIdx), contig length, generic flag.
@@ -1842,7 +1785,6 @@ constexpr size_t pileup_stream_smem_bytes() { return (size_t)4 * ((size_t)STREAM
 //     instruction buy nothing here, and the permuted table layout costs two more address operations per event.  profiles/r04_pileup_packed.log.)
 constexpr int FAST_TW = 1024, FAST_HB = 512;
 constexpr int FAST_HB7 = 384;   // k_pileup_fast7: seven workgroups per CU (22 KiB of LDS each, 72 registers)
-constexpr int FAST_HB8 = 256;   // k_pileup_fast8: eight (20 KiB, 64 registers; the stripped loop takes tiles with < 256 candidate runs)
 constexpr size_t pileup_fast_smem_bytes(bool hist, int hb = FAST_HB) { return (size_t)4 * ((size_t)FAST_TW * 4 + (hist ? (size_t)hb * 4 : 0)); }
 
 typedef short v2i16 __attribute__((ext_vector_type(2)));
@@ -2092,12 +2034,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k
     pileup_fast_body<WANT_HIST, FAST_HB7>(a, n_tiles, chunk_tiles);
 }
 
-// COVERM_FAST_WAVES=8: 256 bins and 64 registers (12 dwords of scratch) for eight waves per SIMD — the same step once more, as a
-// measurement switch (profiles/r05_prep_pileup_ab.log).
-template <bool WANT_HIST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k_pileup_fast8(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
-    pileup_fast_body<WANT_HIST, FAST_HB8>(a, n_tiles, chunk_tiles);
-}
+// (The same step once more — 256 bins, 64 registers with 12 dwords of scratch, eight waves per SIMD — was measured in round 5: 0.816 ms
+// against 0.535, alternating runs on one box, profiles/r05_prep_pileup_ab.log: the stripped loop then only takes tiles with fewer than 256
+// candidate runs and the scratch traffic sits in the per-position loop.  Removed.)
 
 // ------------------------------------------------------------------------------------ interval statistics
 // Per-interval (per-gene, genes.rs:508-535) statistics over a materialised depth arena: one wave per interval.
@@ -2153,7 +2092,7 @@ __global__ __launch_bounds__(256) void k_estimate(const DevContig *__restrict__ 
     const u64 win_sum_d = has_win ? C->sum_d : 0, win_sum_d2 = has_win ? C->sum_d2 : 0, win_covered = has_win ? C->cov_win : 0;
     const u64 win_min_d = has_win ? ((C->proc_win < win_len || C->min_d == 0xffffffffu) ? 0u : C->min_d) : 0xffffffffu;
     const u64 full_len = L, full_covered = C->cov_full, n_reads = C->n_primary, mismatches = C->sum_nm - C->sum_indel;
-    const u32 nh = has_win ? C->hist_len : 0u;
+    const u32 nh = has_win ? C->max_d + 1u : 0u;          // = the compact histogram's length (k_hist_layout<1>; no target mask here)
     const u64 bin0_extra = win_len - C->proc_win;       // window positions of tiles no record touched: depth 0 (k_hist_compact adds the same)
     const u32 *bins = arena + C->hist_off;
     for (u32 k = 0; k < P.n; k++) {

@@ -60,7 +60,7 @@ def test_push_path_short_reads_spill_and_equal_the_oracle(small_caps):
 
 def test_push_path_long_reads_spill_on_the_cigar_cap(small_caps):
     ref = synth.make_reference(40, 12_000_000, seed=75, min_len=200_000, max_len=900_000)
-    batch = _long_read_batch(ref.lengths, 2_500, 30_000, seed=76)
+    batch = _long_read_batch(ref.lengths, 6_000, 30_000, seed=76)
     assert int(batch.cigar_off[-1]) > 3 * 200_000
     compare(to_bamdata(batch, ref.lengths), excl=0, chunks=23)
     compare(to_bamdata(batch, ref.lengths), ff=(True, False, True), excl=75, chunks=5)
@@ -71,7 +71,7 @@ def test_filter_and_mask_with_spills(small_caps):
     b = to_bamdata(batch, ref.lengths, ref.names)
     fp = dict(min_aligned_length_single=50, min_percent_identity_single=0.95, min_aligned_percent_single=0.0, min_mapq=10,
               min_aligned_length_pair=0, min_percent_identity_pair=0.0, min_aligned_percent_pair=0.0)
-    compare(b, ff=(False, True, False), fp=fp, excl=75, chunks=31)
+    compare(b, ff=(True, True, False), fp=fp, excl=75, chunks=31)
     mask = (np.arange(len(ref.lengths)) % 3 != 0).astype(np.uint8)
     compare(b, excl=0, mask=mask, chunks=17)
 
