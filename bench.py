@@ -596,18 +596,14 @@ def main():
                              "hbm_traffic_bytes_from_committed_profile": prof.get("traffic", {}).get(k), "pipes_from_committed_profile": prof.get("pipes", {}).get(k)}
         domk = per_kernel.get(dom, {})
         # The rubric's roofline: algorithmic bytes of the dominant kernel / its launch duration (HIP events of THIS run) against the HBM peak.
-        # k_pileup_fast keeps the depth array in LDS and is not HBM-bound: what bounds it is reported beside the figure as `issue_model`
-        # (profiles/r03_valu_mix.json: instruction classes of the kernel's ISA x measured per-class issue cost x SQ_INSTS_VALU / SIMD-cycles).
-        roof = {"bound": "hbm", "kernel": {"k_pileup": "k_pileup_fast7"}.get(dom, dom), "achieved": domk.get("hbm_achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        # Neither kernel is HBM-bound: k_pileup_fast7 keeps the depth array in LDS (LDS pipe + VALU issue), k_prep6 is bound by instruction issue;
+        # what the counters of the committed profile say about both is carried beside the figure (`kernels.*.pipes_from_committed_profile`).
+        roof = {"bound": "hbm", "kernel": {"k_pileup": "k_pileup_fast7", "k_prep": "k_prep6"}.get(dom, dom), "achieved": domk.get("hbm_achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (domk.get("hbm_achieved_GBps") or 0.0) / HBM_PEAK_GBPS, "traffic": domk.get("hbm_traffic_bytes_from_committed_profile"),
                 "traffic_source": "committed rocprofv3 PMC profile (profiles/pmc_traffic.json, %s), not this run" % prof.get("traffic", {}).get("_source"),
-                "note": "k_prep (HBM-streaming) reaches %.3f of the HBM peak, k_pileup_fast7 (depth array in LDS, not HBM-bound) %.3f; their launch times differ by %.1f %%; "
-                        "see kernels / issue_model" % (per_kernel["k_prep"]["hbm_frac_of_8TBps"], per_kernel["k_pileup"]["hbm_frac_of_8TBps"],
+                "note": "k_prep6 (streams the record store) reaches %.3f of the HBM peak, k_pileup_fast7 (depth array in LDS, not HBM-bound) %.3f; their launch times differ by %.1f %%; "
+                        "see kernels" % (per_kernel["k_prep"]["hbm_frac_of_8TBps"], per_kernel["k_pileup"]["hbm_frac_of_8TBps"],
                                                          100.0 * abs(kms["k_prep"] - kms["k_pileup"]) / max(kms["k_prep"], kms["k_pileup"], 1e-9))}
-        if prof.get("valu_mix"):
-            roof["issue_model"] = dict(prof["valu_mix"], describes="k_pileup_fast<true> as it was when the counters were collected (r03f / r04a): before the window "
-                                       "statistics were read off the LDS histogram (a third fewer VALU instructions, -4.5 %) and before k_pileup_fast7's seventh "
-                                       "wave per SIMD (-9 %); not re-collected since (DESIGN.md section 4)")
         roof["ingest"] = ingest_roofline()
         roof.update({"kernel_ms": kms.get(dom), "all_kernels_ms": kms, "kernels": per_kernel,
                      "pipeline": {"algorithmic_bytes": pipe_bytes, "kernels_ms": pipe_ms, "achieved_GBps": pipe_bytes / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0,
@@ -794,10 +790,13 @@ def ingest_roofline():
     try:
         import csv
         full_ms = {}
-        with open(os.path.join(ROOT, "profiles", "r04_ingest_kernel_stats.csv")) as fh:
+        stats = next(p for p in ("r05_ingest_kernel_stats.csv", "r04_ingest_kernel_stats.csv") if os.path.exists(os.path.join(ROOT, "profiles", p)))
+        pmc = next(p for p in ("r05_ingest_pmc_summary.json", "r04_ingest_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", p)))
+        out["source"] = "committed profile (profiles/%s, %s), not this run" % (stats, pmc)
+        with open(os.path.join(ROOT, "profiles", stats)) as fh:
             for r in csv.DictReader(fh):
                 full_ms[r["Name"].split("(")[0].replace("void ", "").strip()] = float(r["MaxNs"]) / 1e6      # the full round is the longer of the two launches
-        with open(os.path.join(ROOT, "profiles", "r04_ingest_pmc_summary.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", pmc)) as fh:
             pm = json.load(fh).get("derived_full_round", {})
         blocks = 81920
         algo = {"covi::k_inflate_wave": blocks * (21100 + 62900), "covi::k_lz_resolve": blocks * (5900 * 2 + 2 * 50600)}
@@ -818,7 +817,7 @@ def profile_numbers():
     """Per-kernel HBM bytes and pipe utilisation from the committed rocprofv3 PMC summary of this workload (profiles/), if present.
     They describe the committed build, not this run — labelled as such in the JSON."""
     out = {}
-    for name, key in (("pmc_traffic.json", "traffic"), ("pmc_pipes.json", "pipes"), ("r03_valu_mix.json", "valu_mix")):
+    for name, key in (("pmc_traffic.json", "traffic"), ("pmc_pipes.json", "pipes")):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 out[key] = json.load(fh)

@@ -459,7 +459,32 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
             // lengths) is redone by the literal 64-bit walk below.
             bool hard = nops_all > CIG_FAST_OPS;
             bool big = false;   // an operation of >= 2^24 bases: such a record never takes the bucket path
-            {
+            if (__all(nops_all <= 3u)) {
+                // Every record of this wave step has at most three operations (all but a few per mille of a short-read sample: kM, kM iI jM,
+                // kM dD jM, sS kM): the state machine below in closed form — a third fewer instructions than three of its steps.  With
+                // c_j the cursor in front of operation j and an absent operation read as 0S:  consecutive M/=/X operations always merge
+                // (an M consumes what it aligns), so the only second run is M, <D or N of positive length>, M; everything else is one run
+                // that starts at the first M/=/X operation.
+                const u32 w0 = 0u < nops_all ? cw[k][0] : 4u, w1 = 1u < nops_all ? cw[k][1] : 4u, w2 = 2u < nops_all ? cw[k][2] : 4u;
+                const u32 len0 = w0 >> 4, len1 = w1 >> 4, len2 = w2 >> 4;
+                const u32 bit0 = 1u << (w0 & 15u), bit1 = 1u << (w1 & 15u), bit2 = 1u << (w2 & 15u);
+                const bool m0 = (bit0 & 0x181u) != 0u, m1 = (bit1 & 0x181u) != 0u, m2 = (bit2 & 0x181u) != 0u;       // M = X   (contig.rs:171-186)
+                const u32 ref0 = (bit0 & 0x18du) ? len0 : 0u, ref1 = (bit1 & 0x18du) ? len1 : 0u, ref2 = (bit2 & 0x18du) ? len2 : 0u;
+                const u32 c0 = (u32)pos, c1 = c0 + ref0, c2 = c1 + ref1;
+                const u32 L = Lc[k];
+                span = ref0 + ref1 + ref2;
+                aligned = ((bit0 & 0x187u) ? len0 : 0u) + ((bit1 & 0x187u) ? len1 : 0u) + ((bit2 & 0x187u) ? len2 : 0u);     // M I D = X   (:187-199)
+                indel = ((bit0 & 0x006u) ? len0 : 0u) + ((bit1 & 0x006u) ? len1 : 0u) + ((bit2 & 0x006u) ? len2 : 0u);       // I D
+                oob = (m0 && c0 >= L) || (m1 && c1 >= L) || (m2 && c2 >= L);       // negative cursors wrap to >= 2^31 > L
+                badcig = ((bit0 | bit1 | bit2) & 0xfe00u) != 0u;
+                big = ((w0 | w1 | w2) >> 28) != 0u;                                // a length of >= 2^24
+                const bool second = m0 && !m1 && m2 && ref1 != 0u;
+                n_runs = ((m0 || m1 || m2) ? 1u : 0u) + (second ? 1u : 0u);
+                run_start = m0 ? c0 : (m1 ? c1 : c2);
+                run_len = (m0 ? len0 : 0u) + (m1 ? len1 : 0u) + ((m2 && !second) ? len2 : 0u);
+                run2_start = second ? c2 : 0u; run2_len = second ? len2 : 0u;
+                hard = big;
+            } else {
                 const u32 nops = hard ? 0u : nops_all;
                 const u32 L = Lc[k];
                 u32 cursor = (u32)pos, cur_e = 0, al32 = 0, in32 = 0;
