@@ -82,7 +82,7 @@ std::string g_create_error;
 //                        the fill and drain of the pipeline);
 //   version 1 (COVERM_INFLATE_V=1): k_inflate, one LANE per block, private Huffman tables per lane in LDS — the second implementation the
 //                        tests compare with; a launch is cut to exactly the blocks resident at once (a lane decodes a block serially).
-struct InflateKernel { int version = 3; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ablate = 0; u32 ext_parts = covi::EXT_PARTS; };
+struct InflateKernel { int version = 3; int lz_version = 2; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ablate = 0; u32 ext_parts = covi::EXT_PARTS; };
 
 struct cov_session {
     cov_config cfg{};
@@ -156,7 +156,7 @@ struct cov_session {
     } spill;
     // CoverageEstimator::calculate_coverage on the device (cov_set_estimators): parameters, device rows, page-locked copy of the last finish
     EstParams est{};
-    DevBuf<float> d_estf; float *h_estf = nullptr; size_t h_estf_cap = 0; bool est_valid = false;
+    float *h_estf = nullptr; bool est_valid = false;      // (views: device rows behind the result block in d_res, host rows behind it in h_res)
     std::vector<float> spill_est;           // rows of the contigs that left in a spill (n_targets x est.n, filled as they leave)
     std::vector<uint64_t> merged_hist;      // histogram of the last cov_finish when it merged spilled contigs (cov_fetch_hist serves it)
     bool merged_valid = false;
@@ -233,6 +233,8 @@ struct cov_session {
     uint64_t algo_bytes = 0;
 
     hipEvent_t ev[COV_K_COUNT][2] = {};
+    hipEvent_t ev_begin[COV_K_COUNT] = {};      // the event a group's time is measured from (its own, or the previous group's end)
+    int ev_fresh = -1;                          // group whose end event is the last thing on the stream (-1: something else followed)
     float k_ms[COV_K_COUNT] = {};
     uint32_t k_launches[COV_K_COUNT] = {};
 };
@@ -242,8 +244,10 @@ cov_status spill_store(cov_session *s, bool &progress);      // bounded record s
 namespace {
 
 size_t result_block_bytes(u32 n_targets) { return sizeof(DevGlobal) + (size_t)std::max<u32>(n_targets, 1) * sizeof(DevContig); }
+// [DevGlobal][DevContig x n_targets] (the block cov_gather sends) and, behind it, room for the estimators' floats (COV_EST_MAX per target):
+// both come to the host in one copy
 hipError_t bind_result_block(cov_session *s, u32 n_targets) {
-    hipError_t e = s->d_res.reserve(result_block_bytes(n_targets), s->stream);
+    hipError_t e = s->d_res.reserve(result_block_bytes(n_targets) + (size_t)std::max<u32>(n_targets, 1) * COV_EST_MAX * sizeof(float), s->stream);
     if (e != hipSuccess) return e;
     s->d_glob.p = reinterpret_cast<DevGlobal *>(s->d_res.p); s->d_glob.cap = 1;
     s->d_ctg.p = reinterpret_cast<DevContig *>(s->d_res.p + sizeof(DevGlobal)); s->d_ctg.cap = std::max<u32>(n_targets, 1);
@@ -331,8 +335,14 @@ void timing_events(cov_session *s) {
     for (int k = 0; k < COV_K_COUNT; k++)
         for (int j = 0; j < 2; j++) (void)hipEventCreate(&s->ev[k][j]);
 }
-void time_begin(cov_session *s, int k) { (void)hipEventRecord(s->ev[k][0], s->stream); }
-void time_end(cov_session *s, int k) { (void)hipEventRecord(s->ev[k][1], s->stream); s->k_launches[k]++; }
+// Timing brackets of the kernel groups.  An event record costs the stream ~5 us (profiles/r05b_bench_kernel_trace: the gaps of a step sat
+// exactly where its eleven records were), so a group that begins where the previous one ended takes that group's end event for its
+// beginning: six records per finish instead of eleven.
+void time_begin(cov_session *s, int k) {
+    if (s->ev_fresh >= 0) { s->ev_begin[k] = s->ev[s->ev_fresh][1]; return; }
+    (void)hipEventRecord(s->ev[k][0], s->stream); s->ev_begin[k] = s->ev[k][0];
+}
+void time_end(cov_session *s, int k) { (void)hipEventRecord(s->ev[k][1], s->stream); s->k_launches[k]++; s->ev_fresh = k; }
 
 template <int TL, int NT, bool H, bool W>
 void launch_pileup_t(cov_session *s, const PileupArgs &a, u32 grid) {
@@ -550,8 +560,7 @@ void cov_destroy(cov_session *s) {
     s->h_res = nullptr; s->h_res_cap = 0; s->h_ctg = nullptr;
     if (s->h_chist) (void)hipHostFree(s->h_chist);
     s->h_chist = nullptr; s->h_chist_cap = 0;
-    if (s->h_estf) (void)hipHostFree(s->h_estf);
-    s->h_estf = nullptr; s->h_estf_cap = 0; s->d_estf.release(); s->d_spill_tmp.release();
+    s->h_estf = nullptr; s->d_spill_tmp.release();
     s->s_tid.release(); s->s_pos.release(); s->s_flag.release(); s->s_mapq.release(); s->s_nmk.release();
     s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
     s->s_mtid.release(); s->s_qh1.release(); s->s_qh2.release();
@@ -800,6 +809,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     for (int k = 0; k < COV_K_COUNT; k++) { s->k_launches[k] = 0; s->k_ms[k] = 0.f; }
     bool compacted = false;      // the compact histogram was built by this pass (else: by the first cov_fetch_hist)
     s->est_valid = false;
+    s->ev_fresh = -1;
 
     HIPCHK(s->d_runs.reserve(std::max<size_t>(1, R), st));
     // k_prep geometry: 8 passes of 512 records per workgroup for short reads; one pass when CIGARs are long, where the
@@ -952,8 +962,9 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
             s->hist_fetch_seen = false;
         }
     }
+    const size_t block = result_block_bytes(nT), nf = (size_t)nT * s->est.n;
     {
-        const size_t need = sizeof(DevGlobal) + (size_t)std::max<u32>(nT, 1) * sizeof(DevContig);
+        const size_t need = block + (size_t)std::max<u32>(nT, 1) * COV_EST_MAX * sizeof(float);
         if (need > s->h_res_cap) {
             if (s->h_res) (void)hipHostFree(s->h_res);
             s->h_res = nullptr; s->h_res_cap = 0;
@@ -961,25 +972,31 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
             s->h_res_cap = need + need / 2;
         }
         s->h_ctg = (DevContig *)(s->h_res + sizeof(DevGlobal));
+        s->h_estf = reinterpret_cast<float *>(s->h_res + block);
     }
-    if (want_id && R && nT) HIPCHK(hipStreamWaitEvent(st, s->ev_side_done, 0));
-    if (s->est.n && nT) {      // CoverageEstimator::calculate_coverage of every contig (k_init left n_pass = 0 everywhere when nothing ran: rows of zeros)
-        const size_t nf = (size_t)nT * s->est.n;
-        HIPCHK(s->d_estf.reserve(nf, st));
-        if (nf > s->h_estf_cap) {
-            if (s->h_estf) (void)hipHostFree(s->h_estf);
-            s->h_estf = nullptr; s->h_estf_cap = 0;
-            HIPCHK(hipHostMalloc((void **)&s->h_estf, nf * sizeof(float), hipHostMallocDefault));
-            s->h_estf_cap = nf;
-        }
+    if (want_id && R && nT) { HIPCHK(hipStreamWaitEvent(st, s->ev_side_done, 0)); s->ev_fresh = -1; }      // (the wait is not the next group's time)
+    if (nf) {      // CoverageEstimator::calculate_coverage of every contig (k_init left n_pass = 0 everywhere when nothing ran: rows of zeros)
         time_begin(s, COV_K_ESTIMATE);
         hipLaunchKernelGGL(k_estimate, dim3((nT + 3) / 4), dim3(256), 0, st, (const DevContig *)s->d_ctg.p, nT, (const u32 *)s->d_tlen.p, (u64)s->cfg.contig_end_exclusion,
-                           (const u32 *)s->d_arena.p, s->est, s->d_estf.p);
+                           (const u32 *)s->d_arena.p, s->est, reinterpret_cast<float *>(s->d_res.p + block));
         time_end(s, COV_K_ESTIMATE);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(s->h_estf, s->d_estf.p, nf * sizeof(float), hipMemcpyDeviceToHost, st));
     }
-    HIPCHK(hipMemcpyAsync(s->h_res, s->d_res.p, sizeof(DevGlobal) + (size_t)nT * sizeof(DevContig), hipMemcpyDeviceToHost, st));
+    // one copy: the result block and, behind it, the estimators' floats
+    HIPCHK(hipMemcpyAsync(s->h_res, s->d_res.p, sizeof(DevGlobal) + (size_t)nT * sizeof(DevContig) + (nf ? (block - sizeof(DevGlobal) - (size_t)nT * sizeof(DevContig)) + nf * sizeof(float) : 0),
+                          hipMemcpyDeviceToHost, st));
+    // (c) a finish is a millisecond: the host looks for its end itself for a while before it asks to be woken
+    {
+        const auto t_spin = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+            (void)hipGetLastError();
+            if (std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(4)) break;
+            __builtin_ia32_pause();
+        }
+    }
     HIPCHK(hipStreamSynchronize(st));
     memcpy(&s->h_glob, s->h_res, sizeof(DevGlobal));
     if (s->h_glob.cx_total > s->d_cx_runs.cap) {
@@ -990,7 +1007,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         return COV_OK;
     }
     for (int k = 0; k < COV_K_COUNT; k++)
-        if (s->k_launches[k]) (void)hipEventElapsedTime(&s->k_ms[k], s->ev[k][0], s->ev[k][1]);
+        if (s->k_launches[k]) (void)hipEventElapsedTime(&s->k_ms[k], k == COV_K_IDENTITY ? s->ev[k][0] : s->ev_begin[k], s->ev[k][1]);
 
     // algorithmic bytes: each record's SoA fields and CIGAR words are needed once; results written once
     {
@@ -1270,6 +1287,7 @@ static InflateKernel choose_inflate_kernel(cov_session *s) {
     InflateKernel K;
     const char *ve = getenv("COVERM_INFLATE_V");
     K.version = ve && atoi(ve) == 1 ? 1 : 3;
+    if (const char *lz = getenv("COVERM_LZ_V")) K.lz_version = atoi(lz) == 1 ? 1 : 2;      // 1: k_lz_resolve (rounds through global memory), 2: k_lz_stage (batches staged in LDS)
     if (K.version == 1) {
         int per_cu = 0;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&covi::k_inflate<INF1_LB, INF1_DB, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1483,8 +1501,12 @@ static cov_status launch_round_(cov_session *s, uint64_t n64, bool final) {
         HIPCHK(hipEventRecord(s->ing_inf_done[bb], s->stream));
         HIPCHK(hipEventRecord(s->ing_cdone[w % 3u], s->stream));      // this round's compressed buffer may be overwritten (three rounds on)
         HIPCHK(hipStreamWaitEvent(s->ing_aux, s->ing_inf_done[bb], 0));
-        hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
-                           (const covi::tokpos_t *)tokb.p, (const u32 *)ntokb.p);
+        if (K.lz_version == 1)
+            hipLaunchKernelGGL(covi::k_lz_resolve, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
+                               (const covi::tokpos_t *)tokb.p, (const u32 *)ntokb.p);
+        else
+            hipLaunchKernelGGL(covi::k_lz_stage, dim3((n + 3u) / 4u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
+                               (const covi::tokpos_t *)tokb.p, (const u32 *)ntokb.p);
         // the window's bytes are final once the matches are resolved: the boundary search (parse stream) starts here, beside the
         // CRC-32 pass, whose verdict is only looked at in cov_ingest_end (the aux stream is in order, so CRC(w) is done before LZ(w + 1)
         // and with it before anything may overwrite window w)

@@ -555,6 +555,127 @@ __global__ __launch_bounds__(256) void k_lz_resolve(const BgzfBlock *__restrict_
     }
 }
 
+// k_lz_stage (the default from round 5; k_lz_resolve above = COVERM_LZ_V=1, the second implementation the tests compare with).
+// k_lz_resolve pays a global store -> drain -> load round trip for every LEVEL of dependency inside a batch of 64 tokens — ~940 rounds per
+// block, 70 % of its wave time waiting (profiles/r05_ingest_pmc_summary.json) — although the dependencies that force a new round are
+// between tokens a few hundred bytes apart.  Here a batch is the run of consecutive tokens whose output fits LZ_SPAN bytes; that span of the
+// block is staged in LDS (2 KiB per wave: the occupancy stays), and
+//   phase A  every token whose source lies entirely IN FRONT of the span (final bytes: earlier batches, literals) is copied global -> LDS,
+//            all of them at once, their bytes concatenated over the lanes as in k_lz_resolve: ONE round trip per batch;
+//   phase B  the tokens whose source lies inside the span are executed in order, one after the other, each by the whole wave (a lane per
+//            byte, LDS -> LDS): an LDS instruction of a wave sees what the wave's earlier LDS instructions wrote, so there is no
+//            dependency analysis and nothing to drain; a token costs ~15 instructions, most of them scalar (its fields come through
+//            v_readlane), an overlapping match (distance < length) reads its first `distance` bytes repeatedly (final before it begins);
+//   then the span goes back to global memory with aligned dword stores (byte stores at its two ends: the bytes next to it may be another
+//   wave's).  Three round trips per batch, ~90 batches per block, instead of ~940.
+constexpr u32 LZ_SPAN = 2048;
+constexpr u32 LZ_LDS = LZ_SPAN + 16;
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k_lz_stage(const BgzfBlock *__restrict__ blocks, u32 n_blocks, uint8_t *__restrict__ out,
+                                                  const tokpos_t *__restrict__ tok, const u32 *__restrict__ n_tok) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][LZ_LDS];
+    const int lane = threadIdx.x & 63;
+    uint8_t *L = lds_all[threadIdx.x >> 6];
+    const u32 b = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (b >= n_blocks) return;
+    const u32 nt = n_tok[b];
+    if (nt == 0u) return;
+    uint8_t *dst = out + blocks[b].out_off;
+    const tokpos_t *my = tok + (size_t)b * INF_TOK_CAP;
+    u32 t0 = 0;
+    while (t0 < nt) {
+        const u32 t = t0 + (u32)lane;
+        const bool have = t < nt;
+        const u32 pos = have ? (u32)my[t] : 0xffffffffu;
+        u32 t24 = 0;
+        if (have) { const uint8_t *tp = dst + pos; t24 = (u32)tp[0] | ((u32)tp[1] << 8) | ((u32)tp[2] << 16); }    // written by k_inflate (the kernel before this one)
+        const u32 len = have ? ((t24 >> 15) & 0xffu) + 3u : 0u, dist = have ? (t24 & 0x7fffu) + 1u : 1u;
+        const u32 dst_end = pos + len;
+        // the span: from the first token's first byte (moved down to a 4-byte boundary of the ADDRESS, so that the staging loads and the
+        // write-back stores are aligned dwords) over as many consecutive tokens as end inside LZ_SPAN bytes; offsets are relative to the
+        // block and may be negative by up to 3 at its very beginning (bytes of the block in front: read, never written)
+        const int P0 = (int)__builtin_amdgcn_readfirstlane((int)pos);
+        const int mis = (int)((uintptr_t)(dst + P0) & 3u);
+        const int P0a = P0 - mis;
+        const u64 fm = __ballot(have && (int)dst_end <= P0a + (int)LZ_SPAN);
+        const u32 n_take = ~fm ? (u32)__builtin_ctzll(~fm) : 64u;        // tokens' ends increase with the lane: the ones that fit are the first n_take (>= 1: a match is <= 258 bytes)
+        const bool mine = (u32)lane < n_take;
+        const int P1 = (int)__builtin_amdgcn_readlane((int)dst_end, (int)n_take - 1);
+        const u32 span = (u32)(P1 - P0a);
+        // ---- stage the span: aligned dwords, read at agent scope (the dword in front of P0 may hold bytes this wave's previous batch wrote)
+#pragma unroll 2
+        for (u32 o = (u32)lane * 4u; o < span; o += 256u)
+            *reinterpret_cast<u32 *>(L + o) = __hip_atomic_load(reinterpret_cast<const u32 *>(dst + P0a + (int)o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- phase A: sources entirely in front of the span, all at once (their bytes are final)
+        const int src = (int)pos - (int)dist;
+        const bool far = mine && src + (int)len <= P0a;
+        {
+            const u32 glen = far ? len : 0u;
+            const u32 incl = wave_incl_scan_u32(glen), excl = incl - glen;
+            const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            for (u32 base = 0; base < total; base += 64u) {
+                const u32 x = base + (u32)lane;
+                u32 o = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const u32 v = (u32)__shfl((int)incl, (int)(o + step - 1));
+                    if (v <= x) o += step;
+                }
+                const u32 oc = min(o, 63u);
+                const u32 po = (u32)__shfl((int)pos, (int)oc), so = (u32)__shfl(src, (int)oc), ex = (u32)__shfl((int)excl, (int)oc);
+                if (x < total) {
+                    const u32 k = x - ex;
+                    L[(int)(po + k) - P0a] = __hip_atomic_load(dst + so + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // ---- phase B: the others in order, each by the whole wave
+        for (u64 todo = __ballot(mine && !far); todo != 0; todo &= todo - 1) {
+            const int j = __builtin_ctzll(todo);
+            const int pj = (int)__builtin_amdgcn_readlane((int)pos, j), lj = (int)__builtin_amdgcn_readlane((int)len, j), dj = (int)__builtin_amdgcn_readlane((int)dist, j);
+            const int sj = pj - dj;
+            uint8_t *D = L + (pj - P0a);
+            if (sj >= P0a) {                     // the source lies inside the span (or in the staged bytes in front of it)
+                const uint8_t *S = L + (sj - P0a);
+                if (dj >= lj) {
+#pragma unroll 1
+                    for (int k = lane; k < lj; k += 64) D[k] = S[k];
+                } else {                         // overlapping: the first dj bytes, final before the match begins, repeat
+                    const float inv = 1.0f / (float)dj;
+#pragma unroll 1
+                    for (int k = lane; k < lj; k += 64) {
+                        int q = (int)((float)k * inv);
+                        int r = k - q * dj;
+                        r = r < 0 ? r + dj : (r >= dj ? r - dj : r);
+                        D[k] = S[r];
+                    }
+                }
+            } else {                             // the source begins in front of the span and reaches into it (rare): byte by byte from where it lies
+#pragma unroll 1
+                for (int k = lane; k < lj; k += 64) {
+                    const int r = dj >= lj ? k : k % dj;
+                    const int sp = sj + r;
+                    D[k] = sp >= P0a ? L[sp - P0a] : __hip_atomic_load(dst + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // ---- the span goes back: bytes [P0, P1), aligned dwords in the middle
+        {
+            const u32 n = (u32)(P1 - P0);
+            const u32 head = min(mis ? 4u - (u32)mis : 0u, n);
+            const u32 nd = (n - head) >> 2, tail = (n - head) & 3u;
+            if ((u32)lane < head) dst[P0 + lane] = L[mis + lane];
+            uint8_t *g = dst + P0 + (int)head;
+            const uint8_t *l = L + mis + head;
+#pragma unroll 2
+            for (u32 i = (u32)lane; i < nd; i += 64u) *reinterpret_cast<u32 *>(g + 4u * i) = *reinterpret_cast<const u32 *>(l + 4u * i);
+            if ((u32)lane < tail) g[4u * nd + (u32)lane] = l[4u * nd + (u32)lane];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the next batch stages (and phase A reads) at agent scope what this one wrote
+        t0 += n_take;
+    }
+}
+
 // (A SLIDING window of 64 consecutive tokens — token k held by lane k mod 64, the window following the block's lowest unfinished token —
 // cuts the rounds from ~940 to ~660 per block and was slower on the device, 25.2 ms per round against 19.4: the dependency search then
 // runs every round instead of once per batch, and about half of this kernel's time is instruction issue, not latency.

@@ -158,7 +158,7 @@ class Session:
         self._keep.clear()
 
     def finish(self):
-        stats = np.zeros(self.n_targets, dtype=native.CONTIG_STATS_DTYPE)
+        stats = np.empty(self.n_targets, dtype=native.CONTIG_STATS_DTYPE)      # (cov_finish writes every entry)
         summ = CovSummary()
         self._check(self._lib.cov_finish(self._h, stats.ctypes.data if self.n_targets else None, C.byref(summ)))
         self.stats = stats
@@ -186,7 +186,7 @@ class Session:
 
     def estimates(self):
         """cov_fetch_estimates: n_targets x n_estimators f32 of the last finish."""
-        out = np.zeros((self.n_targets, getattr(self, "_n_est", 0)), dtype=np.float32)
+        out = np.empty((self.n_targets, getattr(self, "_n_est", 0)), dtype=np.float32)
         self._check(self._lib.cov_fetch_estimates(self._h, out.ctypes.data if out.size else None))
         return out
 
