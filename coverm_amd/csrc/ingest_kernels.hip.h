@@ -582,13 +582,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
     if (nt == 0u) return;
     uint8_t *dst = out + blocks[b].out_off;
     const tokpos_t *my = tok + (size_t)b * INF_TOK_CAP;
-    u32 t0 = 0;
+    // A token's fields: its position from the block's list, its (length, distance) from the three bytes k_inflate left at that position.
+    // Both are two dependent trips to memory, so the NEXT 64 tokens' fields are fetched while a batch is worked on (they lie behind the
+    // batch's span: nothing the batch writes can change them), and a batch begins with what the previous one fetched.
+    // (in two steps, each issued where the loads in front of it are waited for anyway: positions at the top of a batch, the token bytes once
+    // the span is staged)
+    auto fetch_pos = [&](u32 first) { const u32 t = first + (u32)lane; return t < nt ? (u32)my[t] : 0xffffffffu; };
+    auto fetch_tok = [&](u32 p) {
+        u32 w = 0;
+        if (p != 0xffffffffu) { const uint8_t *tp = dst + p; w = (u32)tp[0] | ((u32)tp[1] << 8) | ((u32)tp[2] << 16); }    // written by k_inflate (the kernel before this one)
+        return w;
+    };
+    u32 t0 = 0, pos = fetch_pos(0u), t24 = fetch_tok(pos);
     while (t0 < nt) {
-        const u32 t = t0 + (u32)lane;
-        const bool have = t < nt;
-        const u32 pos = have ? (u32)my[t] : 0xffffffffu;
-        u32 t24 = 0;
-        if (have) { const uint8_t *tp = dst + pos; t24 = (u32)tp[0] | ((u32)tp[1] << 8) | ((u32)tp[2] << 16); }    // written by k_inflate (the kernel before this one)
+        const u32 npos = fetch_pos(t0 + 64u);
+        const bool have = t0 + (u32)lane < nt;
         const u32 len = have ? ((t24 >> 15) & 0xffu) + 3u : 0u, dist = have ? (t24 & 0x7fffu) + 1u : 1u;
         const u32 dst_end = pos + len;
         // the span: from the first token's first byte (moved down to a 4-byte boundary of the ADDRESS, so that the staging loads and the
@@ -606,6 +614,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
 #pragma unroll 2
         for (u32 o = (u32)lane * 4u; o < span; o += 256u)
             *reinterpret_cast<u32 *>(L + o) = __hip_atomic_load(reinterpret_cast<const u32 *>(dst + P0a + (int)o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32 nt24 = fetch_tok(npos);
         // ---- phase A: sources entirely in front of the span, all at once (their bytes are final)
         const int src = (int)pos - (int)dist;
         const bool far = mine && src + (int)len <= P0a;
@@ -673,6 +682,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the next batch stages (and phase A reads) at agent scope what this one wrote
         t0 += n_take;
+        if (n_take == 64u) { pos = npos; t24 = nt24; }
+        else {     // the tokens that did not fit stay, the fetched ones move up behind them
+            const int from = lane + (int)n_take;
+            const u32 a = (u32)__shfl((int)pos, from & 63), c = (u32)__shfl((int)t24, from & 63);
+            const u32 d = (u32)__shfl((int)npos, from & 63), e = (u32)__shfl((int)nt24, from & 63);
+            pos = from < 64 ? a : d; t24 = from < 64 ? c : e;
+        }
     }
 }
 
