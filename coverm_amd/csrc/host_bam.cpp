@@ -47,6 +47,7 @@ namespace {
 // from anonymous mappings advised to use transparent huge pages.
 std::atomic<bool> g_pinned_records{false};   // covh_bam_set_pinned
 std::atomic<bool> g_release_staging{false};  // covh_bam_set_release_staging
+std::atomic<int> g_feeders{1};               // covh_bam_set_concurrent_feeders: device ingests the caller runs at once
 
 template <class T>
 struct RecAlloc {
@@ -1325,8 +1326,16 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     //         (tools/ubench/io_probe: 57 GB/s against 42-54 GB/s through staging slots), but inside the running pipeline
     //         hipHostRegister drops to ~20 GB/s, the copies take longer to enqueue and unregistering 20 GB at the end costs
     //         another 0.4 s (profiles/r03_io_modes.log: 200 M reads 1.78 s against 0.98 s): kept as an option, not the default.
+    //   More than two devices fed at once (covh_bam_set_concurrent_feeders; coverm-amd --devices) change the balance: a staged byte crosses
+    //   the host's memory three times (page cache -> pinned slot by the CPU, slot -> link by the DMA engine, and the page cache fill), a
+    //   mapped one once, and N feeders share one memory system (at 8 x 50 GB/s the staged path asks for ~1.2 TB/s).
+    //   With > 2 feeders and no COVERM_INGEST_IO the mapping is chosen, and its span is registered ONCE, up front, before the first
+    //   upload — the registration that ran at 20 GB/s beside a busy pipeline runs at its idle rate, and the reader threads only hop
+    //   block headers.  UNMEASURED on more than one device (the build environment has one); `--devices 0,0,0,0` checks that it works.
     const char *io = getenv("COVERM_INGEST_IO");
-    bool use_map = io && !strcmp(io, "mmap");
+    const bool many = g_feeders.load() > 2;
+    bool use_map = io ? !strcmp(io, "mmap") || !strcmp(io, "mmap-upfront") : many;
+    const bool map_upfront = use_map && (io ? !strcmp(io, "mmap-upfront") : many);
     uint8_t *map = nullptr;
     const uint64_t PG = 4096, map_len = (file_size + PG - 1) / PG * PG;
     if (use_map) {
@@ -1372,7 +1381,7 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
         reg_hi = hi;
         return true;
     };
-    if (use_map && !register_piece(f_lo, std::min<uint64_t>(piece, size - f_lo))) {     // refused: staging slots instead
+    if (use_map && !register_piece(f_lo, map_upfront ? size - f_lo : std::min<uint64_t>(piece, size - f_lo))) {     // refused: staging slots instead
         use_map = false;
         if (!getenv("COVERM_INGEST_PIECE_KB")) piece = (size_t)32 << 20;
     }
@@ -1565,7 +1574,7 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
         cov_host_trim();
     }
     const double t_end = now() - t0;
-    if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; timing[4] = t_begin; timing[5] = t_walk; timing[6] = t_feed; timing[7] = 0; }
+    if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; timing[4] = t_begin; timing[5] = t_walk; timing[6] = t_feed; timing[7] = use_map ? (map_upfront ? 2 : 1) : 0; }      /* [7]: where the DMA read the bytes: 0 staging slots, 1 mapped file, 2 mapped and registered up front */
     if (rc == COV_ERR_INGEST_FALLBACK) return fail(1, cov_last_error(s));
     if (rc == COV_ERR_UNSORTED) return fail(-2, cov_last_error(s));      // keys decrease inside the span: the caller may send the file through one device whole
     if (rc != COV_OK) return fail(-1, cov_last_error(s));
@@ -1613,6 +1622,7 @@ void covh_bam_close(covh_bam *h) { delete h; }
 void covh_bam_set_buffer_cache(int on) { g_map_cache.set(on != 0); }
 void covh_bam_set_pinned(int on) { g_pinned_records.store(on != 0); }
 void covh_bam_set_release_staging(int on) { g_release_staging.store(on != 0); }
+void covh_bam_set_concurrent_feeders(int n) { g_feeders.store(n < 1 ? 1 : n); }
 uint32_t covh_bam_n_targets(const covh_bam *h) { return (uint32_t)h->b.names.size(); }
 const char *covh_bam_target_name(const covh_bam *h, uint32_t i) { return h->b.names[i].c_str(); }
 uint64_t covh_bam_target_len(const covh_bam *h, uint32_t i) { return h->b.lens[i]; }

@@ -172,6 +172,9 @@ bool is_bgzf(const std::string &path) {
     return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
 }
 
+// device ingests that run at once: every device in span mode (nb < nd) and with at least as many files as devices
+size_t span_mode_feeders(size_t nb, size_t nd) { return nb < nd ? nd : std::min(nb, nd); }
+
 // What the host keeps of a finished session: the estimators' floats when the device evaluated them, else the histogram bins the host's
 // calculate_coverage needs.
 void fetch_results(Run &R, cov_session *s, Sample &S, const cov_summary &summ) {
@@ -240,8 +243,9 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         if (rc == 0) {
             S.n_records = nrec; S.device_ingest = true;
             if (getenv("COVERM_CLI_TIMING"))
-                fprintf(stderr, "[coverm-amd] %s span %u/%u: device ingest: buffers %.3fs, file read %.3fs, staging waits %.3fs, header walk %.3fs, feed calls %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records\n",
-                        S.stoit.c_str(), span_index, span_count, tm[4], tm[0], tm[1], tm[5], tm[6], tm[2], tm[3], (unsigned long long)nrec);
+                fprintf(stderr, "[coverm-amd] %s span %u/%u: device ingest: buffers %.3fs, file read %.3fs, staging waits %.3fs, header walk %.3fs, feed calls %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records, bytes from %s\n",
+                        S.stoit.c_str(), span_index, span_count, tm[4], tm[0], tm[1], tm[5], tm[6], tm[2], tm[3], (unsigned long long)nrec,
+                        tm[7] == 2 ? "the mapped file (registered up front)" : tm[7] == 1 ? "the mapped file" : "staging slots");
             S.t_ingest = now() - t0;
             S.stats.resize(S.tlen.size());
             cov_summary summ;
@@ -680,6 +684,7 @@ int run_cli(int argc, char **argv) {
     // lengthens the tail by as much — hipHostFree waits for the device — so it stays opt-in)
     covh_bam_set_release_staging(getenv("COVERM_RELEASE_STAGING") && atoi(getenv("COVERM_RELEASE_STAGING")) && nb <= nd ? 1 : 0);
     if (nb > 1) covh_bam_set_buffer_cache(1);
+    covh_bam_set_concurrent_feeders((int)std::min(nd, span_mode_feeders(nb, nd)));      // > 2 at once: mapped files, registered up front (host memory traffic / 3)
     const bool timing = getenv("COVERM_CLI_TIMING") != nullptr;
     std::vector<Sample> samples(nb);
     for (size_t i = 0; i < nb; i++) samples[i].path = a.bams[i];

@@ -155,6 +155,11 @@ void covh_bam_set_pinned(int on);
  * that reads no further file; page-locked memory still held at process exit costs ~0.13 s per GiB).  Default 0: the slots are parked for
  * the next file. */
 void covh_bam_set_release_staging(int on);
+/* How many device ingests (covh_bam_gpu_ingest*) the caller runs at once, one per GPU.  With more than two and no COVERM_INGEST_IO the
+ * file is mapped and its span registered with the device once, up front, instead of copied through page-locked staging slots: N feeders
+ * share one host memory system, and a staged byte crosses it three times, a mapped one once (unmeasured on more
+ * than one device).  Default 1. */
+void covh_bam_set_concurrent_feeders(int n);
 uint32_t covh_bam_n_targets(const covh_bam *h);
 const char *covh_bam_target_name(const covh_bam *h, uint32_t i);
 uint64_t covh_bam_target_len(const covh_bam *h, uint32_t i);
@@ -215,7 +220,7 @@ uint64_t covh_bam_header_first_record(const covh_bam_header *h); /* offset in th
 int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint32_t span_index,
                              uint32_t span_count, uint64_t *n_records, double *timing8, char *err, size_t errcap);
 int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint64_t *n_records,
-                        double *timing8, char *err, size_t errcap);   /* s: file read, staging waits, cov_ingest_end, total, buffers, block-header walk, cov_ingest_feed, 0 */
+                        double *timing8, char *err, size_t errcap);   /* s: file read, staging waits, cov_ingest_end, total, buffers, block-header walk, cov_ingest_feed; [7] = where the DMA read the bytes (0 staging slots, 1 the mapped file, 2 mapped and registered up front) */
 
 /* ---- reader-stage PAIR filter (ReferenceSortedBamFilter::read pair branch, filter.rs:117-228, filter_out = true).
  * The single-read branch runs on the device (cov_config.filter_single); the pair branch needs read names, which never

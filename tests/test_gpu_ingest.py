@@ -321,6 +321,27 @@ def test_spans_leave_a_file_only_the_reference_would_accept_to_one_device(tmp_pa
     assert binary.run("contig", [p], devices="0,0", **args) == want
 
 
+def test_more_than_two_feeders_read_the_mapped_file(tmp_path):
+    """With more than two device ingests at once the file is mapped and its spans registered with the device once, up front, instead
+    of copied through staging slots (coverm_host.h covh_bam_set_concurrent_feeders; DESIGN.md section 7: N feeders share one host memory
+    system).  One GPU here, so four spans of one file on device 0: a functional check of that mode, the table must be the one-device one."""
+    from oracle import oracle as O
+    from tests import binary
+    ref = synth.make_reference(80, 8_000_000, seed=31, min_len=5000, max_len=400_000)
+    b = synth.make_reads(ref, 300_000, seed=32)
+    p = str(tmp_path / "four_feeders.bam")
+    cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=2, threads=4)
+    args = dict(methods=["mean", "trimmed_mean", "variance", "count"])
+    want = O.run_cli("contig", [p], bams=[bamio.read_alignment_file(p)], **args)
+    r = binary.run_full("contig", [p], env={"COVERM_CLI_TIMING": "1"}, devices="0,0,0,0", **args)
+    assert r.stdout == want
+    assert r.stderr.count("bytes from the mapped file (registered up front)") == 4
+    r = binary.run_full("contig", [p], env={"COVERM_CLI_TIMING": "1"}, devices="0,0", **args)
+    assert r.stdout == want and r.stderr.count("bytes from staging slots") == 2
+    r = binary.run_full("contig", [p], env={"COVERM_CLI_TIMING": "1", "COVERM_INGEST_IO": "pread"}, devices="0,0,0,0", **args)
+    assert r.stdout == want and r.stderr.count("bytes from staging slots") == 4
+
+
 RAW = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raw")
 
 

@@ -41,6 +41,19 @@ __global__ __launch_bounds__(64) void k_load(const uint8_t *__restrict__ in, uin
     if (acc == 0x123456789abcdefull) sink[0] = acc;      // never true for this data: keeps the loads alive
 }
 
+// Is the cost of a scattered store instruction per INSTRUCTION or per active LANE?  (Round 5: pass 3 of k_inflate_wave stores in ~390 of its
+// lock-steps per block with about a third of the lanes active each time; queueing the lanes' segments and flushing them together would cut
+// the instructions, not the lane-stores.)  Every iteration a different subset of `active` lanes stores 8 bytes into its own KiB.
+__global__ __launch_bounds__(64) void k_store_part(uint8_t *__restrict__ out, uint32_t active, uint32_t n_iter) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint8_t *p = out + (size_t)blockIdx.x * 65536u + lane * 1024u;
+    uint64_t v = 0x0102030405060708ull * (threadIdx.x + 1u);
+    for (uint32_t k = 0; k < n_iter; k++) {
+        if (((lane * 7u + k * 13u) & 63u) < active) { __builtin_memcpy(p, &v, 8); p += 8; if (p >= out + (size_t)blockIdx.x * 65536u + lane * 1024u + 1016u) p -= 1016u; }
+        v = v * 6364136223846793005ull + 1442695040888963407ull;
+    }
+}
+
 int main() {
     const uint32_t blocks = 81920;                                   // one round of the ingest
     uint8_t *out;
@@ -75,6 +88,21 @@ int main() {
         const double wave_stores = (double)blocks * n;
         printf("width %2d  misaligned by %u  advance %2u: %8.3f ms  %7.1f ns per wave-store per CU  %7.1f GB/s payload  (%u stores per lane)\n", c.width, c.mis, c.advance,
                best, best * 1e6 / (wave_stores / cus), (double)blocks * 64 * n * c.advance / best / 1e6, n);
+    }
+    printf("partial stores: 8 bytes, 240 iterations, a different subset of the lanes active in each\n");
+    for (uint32_t active : {4u, 8u, 16u, 21u, 32u, 48u, 64u}) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; rep++) {
+            CHK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(k_store_part, dim3(blocks), dim3(64), 0, 0, out, active, 240u);
+            CHK(hipEventRecord(e1, 0));
+            CHK(hipEventSynchronize(e1));
+            float ms = 0;
+            CHK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        printf("active lanes %2u of 64: %8.3f ms  %7.1f ns per wave-store instruction per CU  %6.2f ns per lane-store per CU\n", active, best,
+               best * 1e6 / ((double)blocks * 240 / cus), best * 1e6 / ((double)blocks * 240 * active / cus));
     }
     uint64_t *sink;
     CHK(hipMalloc(&sink, 8));
