@@ -302,7 +302,7 @@ COVW_FN void store_bytes(u8 *d, u64 v, u32 n) {        // exactly n <= 8 bytes o
 // memory pipeline whatever its width (profiles/r04_store_probe.log), so the policy with the fewest store INSTRUCTIONS per lock-step wins.)
 struct Sink {
     u8 *out; u16 *tok; u64 obuf, tbuf; u32 on, tn, last_k;
-    COVW_FN void init(u8 *o, u16 *t) { out = o; tok = t; obuf = 0; tbuf = 0; on = 0; tn = 0; last_k = 0; }
+    COVW_FN void init(u8 *o, u16 *t, u32 /* own_end */) { out = o; tok = t; obuf = 0; tbuf = 0; on = 0; tn = 0; last_k = 0; }
     COVW_FN void literal(u32 p, u32 b) {
         obuf |= (u64)b << (8u * on);
         if (++on == 8u) { store8(out + p - 7u, obuf); obuf = 0; on = 0; }
@@ -326,6 +326,51 @@ struct Sink {
     COVW_FN void finish(u32 p) {
         if (on) store_bytes(out + p - on, obuf, on);
         if (tn) store_bytes(reinterpret_cast<u8 *>(tok + last_k + 1u - tn), tbuf, 2u * tn);
+    }
+};
+
+COVW_FN void store16(u8 *d, u64 a, u64 b) { COVW_TRACE_STORE(d, 16); const u64 x[2] = {a, b}; __builtin_memcpy(d, x, 16); }
+// ---- Sink16 (round 5, the default): a 16-byte window per lane instead of 8 pending bytes.  tools/ubench/store_probe (profiles/
+// r05_store_probe.log) settled what a scattered store costs: ~1.1 ns of a CU's memory pipeline per LANE that stores, whatever the width up to
+// 16 bytes and however many lanes take part in the instruction — so the only way to make pass 3's stores cheaper is to make them FEWER.
+// A lane's bytes come in short segments (a couple of literals and a match's 3-byte token) separated by the rest of the match, which
+// k_lz_resolve / k_lz_stage fill in later and which this lane may therefore overwrite with anything: all segments that begin inside
+// the same 16 bytes leave as ONE store.  The window starts at the first byte put into it and is flushed when the next byte does not
+// fit; a flush is one store of 4, 8 or 16 bytes (the padding lies in front of own_end: bytes this lane or the match resolution write
+// later), exact stores only where the lane's range ends.
+struct Sink16 {
+    u8 *out; u16 *tok; u64 lo, hi, tbuf, tbuf2; u32 base, on, own_end, tn, last_k;
+    COVW_FN void init(u8 *o, u16 *t, u32 end) { out = o; tok = t; lo = 0; hi = 0; tbuf = 0; tbuf2 = 0; base = 0; on = 0; own_end = end; tn = 0; last_k = 0; }
+    COVW_FN void flush() {
+        if (!on) return;
+        u8 *d = out + base;
+        if (on > 8u) { if (base + 16u <= own_end) store16(d, lo, hi); else { store8(d, lo); store_bytes(d + 8, hi, on - 8u); } }
+        else if (on > 4u) { if (base + 8u <= own_end) store8(d, lo); else store_bytes(d, lo, on); }
+        else { if (base + 4u <= own_end) store4(d, (u32)lo); else store_bytes(d, lo, on); }
+        lo = 0; hi = 0; on = 0;
+    }
+    COVW_FN void put(u32 p, u32 v, u32 n) {               // the n = 1 or 3 low bytes of v belong at p (positions only ever grow)
+        if (on && p - base + n > 16u) flush();
+        if (!on) base = p;
+        const u32 rel = p - base, sh = 8u * (rel & 7u);
+        if (rel < 8u) { lo |= (u64)v << sh; if (rel + n > 8u) hi |= (u64)v >> (64u - sh); }      // (a token that straddles the halves: rel = 6 or 7)
+        else hi |= (u64)v << sh;
+        on = rel + n;
+    }
+    COVW_FN void literal(u32 p, u32 b) { put(p, b, 1u); }
+    COVW_FN void match(u32 p, u32 len, u32 t24, u32 k) {
+        (void)len;
+        put(p, t24, 3u);
+        if (tn < 4u) tbuf |= (u64)p << (16u * tn); else tbuf2 |= (u64)p << (16u * (tn - 4u));       // token positions leave eight at a time
+        if (++tn == 8u) { store16(reinterpret_cast<u8 *>(tok + k - 7u), tbuf, tbuf2); tbuf = 0; tbuf2 = 0; tn = 0; }
+        last_k = k;
+    }
+    COVW_FN void finish(u32) {
+        flush();
+        if (tn) {
+            u8 *d = reinterpret_cast<u8 *>(tok + last_k + 1u - tn);
+            if (tn > 4u) { store8(d, tbuf); store_bytes(d + 8, tbuf2, 2u * (tn - 4u)); } else store_bytes(d, tbuf, 2u * tn);
+        }
     }
 };
 
@@ -419,6 +464,7 @@ COVW_FN u32 share_begin_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
 // One BGZF block.  comp_words: aligned words holding the raw DEFLATE payload from bit `bit0` on; out: the block's `isize` output
 // bytes; tok: its token-position list.  *status = OK / ERR_*, *n_tok = matches written (0 unless OK).
 // stop_after (measurements only, 0 in production): 1 = give up after the tables are built, 2 = after pass 1, 3 = after pass 2.
+template <class SinkT = Sink16>
 COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0) {
     Src s; s.w = comp_words; s.total_bits = bit0 + payload_bits;
     u32 pos = bit0, opos = 0, ntok = 0, err = OK, nblk = 0, chunk_bits = 0;
@@ -578,7 +624,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                     const u32 from = lane ? W.end[lane - 1u] : cur;
                     const u32 ge = share_begin_of(cur, S, lane + 1u, span_end);
                     u32 f, nb, nt, e2 = OK;
-                    Sink sink; sink.init(out, tok);
+                    SinkT sink; sink.init(out, tok, opos + W.obase[lane] + W.nbytes[lane]);
                     if (from < ge) (void)run_share<2>(W.T, s, from, ge, &f, &nb, &nt, sink, opos + W.obase[lane], 0, ntok + W.tbase[lane], &e2);
                     if (e2 != OK) W.hdr[6] = e2;
                 }

@@ -37,7 +37,11 @@ int covw_host_inflate(const uint8_t *payload, uint32_t nbytes, uint32_t misalign
     uint32_t status = 0;
     covw::Wave &W = g_wave;
     W.rounds = 0;
+#ifdef COVW_SINK_OLD      // the 8-byte sink (k_inflate_wave8, COVERM_INFLATE_SINK=8)
+    covw::inflate_block<covw::Sink>(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status, 0);
+#else
     covw::inflate_block(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status, 0);
+#endif
     if (rounds) *rounds = W.rounds;
     for (int k = 0; k < 8; k++) if (out[k] != 0xC3 || out[8 + isize + k] != 0xC3) return -1;
     return (int)status;
