@@ -67,7 +67,6 @@ constexpr u32 NO_EOB = 0xffffffffu;
 // fewer lanes.  OVERLAP: p99 of that distance is 50 units (~480 bits), the largest seen 670 bits.
 constexpr u32 MIN_SHARE_BITS = 512, OVERLAP_BITS = 768;
 constexpr u32 DIST_INVALID = 0x80000000u;
-constexpr u32 RING_WORDS = 8;             // 32 bytes per lane and refill: 2 KiB of the wave's state
 
 struct Tables {
     union {
@@ -98,7 +97,6 @@ struct Wave {                             // wave-shared state (LDS on the devic
     u32 changed, n_valid, eob_at, rounds; // rounds: pass-2 rounds of the last Huffman block (statistics)
     u32 n_deflate_blocks, n_chunks, pad_[2];   // DEFLATE blocks in the payload, chunks they were decoded in (statistics)
     u32 cnt[32], start[32];               // symbols per code length and where each length begins in sorted[]: [0, 16) literal/length, [16, 32) distance
-    u32 ring[RING_WORDS * 64];            // pass 3's window of the bit stream: RING_WORDS words per lane, word k of lane l at ring[(k % RING_WORDS) * 64 + l]
     u16 climit[16], coff[16];             // the code-length code ...
     u8 csorted[32], cl[32];
     u8 cltab[128];                        // ... and its lookup table: (symbol << 3) | code length by the next 7 bits, 0 = no code
@@ -111,7 +109,7 @@ COVW_FN u32 bits_at(u32 x, u32 off, u32 n) { return (x >> off) & ((1u << n) - 1u
 // Bit cursor of one lane: `cnt` valid bits of the stream at `pos` in buf, the next word already requested.
 struct Cursor {
     const u32 *w; u64 buf; u32 cnt, wi, ahead, pos;
-    COVW_FN void init(const Src &s, u32 p, u32 * = nullptr) {
+    COVW_FN void init(const Src &s, u32 p) {
         w = s.w; pos = p;
         const u32 i = p >> 5, d = p & 31u;
         buf = ((u64)w[i] | ((u64)w[i + 1u] << 32)) >> d; cnt = 64u - d;
@@ -123,39 +121,10 @@ struct Cursor {
     COVW_FN u32 low32() const { return (u32)buf; }
     COVW_FN void drop(u32 n) { buf >>= n; cnt -= n; pos += n; }
 };
-// The same cursor fed through a small window in the wave's LDS instead of one global load per word (pass 3 only).  Why: on gfx9 loads and
-// stores share ONE in-order counter (vmcnt), so a wave that stores in nearly every lock-step — pass 3 — cannot wait for its next word of the
-// bit stream without also waiting for every store it issued before that load, and a store's acknowledgement takes far longer than a load
-// that hits.  (Round 5 measured what the stores cost by lane and by instruction, tools/ubench/store_probe, and halved the lane-stores,
-// Sink16: the kernel did not move, profiles/r05_sink16_ab.log — it is this coupling, not the memory pipeline's throughput.)  With the
-// window a lane touches global memory once per RING_WORDS words — two 16-byte loads, one wait — and reads its words from LDS, whose counter
-// the stores do not touch; a lane's 344-byte share is 11 such refills instead of 86 loads, and every cache line of the payload is
-// fetched once per lane instead of sixteen times.
-struct RingCursor {
-    const u32 *w; u32 *ring; u64 buf; u32 cnt, wi, ahead, pos, have_end;
-    COVW_FN u32 get(u32 i) {
-        if (i >= have_end) {                  // the next RING_WORDS words (have_end is a multiple of RING_WORDS: the slots they go to are the ones just used up)
-            u32 t[RING_WORDS];
-            __builtin_memcpy(t, w + have_end, sizeof t);
-            for (u32 k = 0; k < RING_WORDS; k++) ring[k * 64u] = t[k];
-            have_end += RING_WORDS;
-        }
-        return ring[(i % RING_WORDS) * 64u];
-    }
-    COVW_FN void init(const Src &s, u32 p, u32 *lane_ring) {
-        w = s.w; pos = p; ring = lane_ring;
-        const u32 i = p >> 5, d = p & 31u;
-        have_end = i / RING_WORDS * RING_WORDS;
-        const u32 a = get(i), b = get(i + 1u);
-        buf = ((u64)a | ((u64)b << 32)) >> d; cnt = 64u - d;
-        wi = i + 2u; ahead = get(wi);
-    }
-    COVW_FN void refill() {               // afterwards cnt >= 33
-        if (cnt <= 32u) { buf |= (u64)ahead << cnt; cnt += 32u; wi++; ahead = get(wi); }
-    }
-    COVW_FN u32 low32() const { return (u32)buf; }
-    COVW_FN void drop(u32 n) { buf >>= n; cnt -= n; pos += n; }
-};
+// (RingCursor — pass 3 reading its words through an 8-word window per lane in the wave's LDS, two 16-byte loads per refill, on the theory
+// that waiting for the next word also waits for the stores issued in front of it (gfx9 counts loads and stores with one in-order counter) —
+// was built, passed this file's CPU emulation and the device tests, and measured SLOWER: 21.3 ms per full round against 19.4 with plain
+// loads, profiles/r05_inflate_sink_ring_kernel_times.log (128 registers instead of 100, eight LDS writes and a branch per refill).  Removed.)
 // ---- canonical code of `n` symbols with code lengths lens[0 .. n): per-length limits / offsets and the symbols sorted by (length, value).
 // Serial; false when the set is over-subscribed.
 template <class WS>
@@ -365,7 +334,8 @@ struct Sink {
 };
 
 COVW_FN void store16(u8 *d, u64 a, u64 b) { COVW_TRACE_STORE(d, 16); const u64 x[2] = {a, b}; __builtin_memcpy(d, x, 16); }
-// ---- Sink16 (round 5, the default): a 16-byte window per lane instead of 8 pending bytes.  tools/ubench/store_probe (profiles/
+// ---- Sink16 (round 5, the default: 19.4 ms per full round against 20.7 with the 8-byte sink, ingest of 100 M reads 0.331 s against 0.344,
+// alternating runs on one box, profiles/r05_inflate_sink_ring_*.log): a 16-byte window per lane instead of 8 pending bytes.  tools/ubench/store_probe (profiles/
 // r05_store_probe.log) settled what a scattered store costs: ~1.1 ns of a CU's memory pipeline per LANE that stores, whatever the width up to
 // 16 bytes and however many lanes take part in the instruction — so the only way to make pass 3's stores cheaper is to make them FEWER.
 // A lane's bytes come in short segments (a couple of literals and a match's 3-byte token) separated by the rest of the match, which
@@ -420,12 +390,9 @@ struct NoSink {      // passes 1 and 2 write nothing
 };
 // (SinkT: where pass 3's bytes go — Sink: the block's place in global memory.  opos: position of the
 // lane's first byte in the sink's coordinates, pmin: position of the block's first byte — a match may not reach in front of it.)
-template <int MODE, bool RING> struct CursorOf { typedef Cursor type; };      // passes 1 and 2 store nothing: a global load per word
-template <> struct CursorOf<2, true> { typedef RingCursor type; };             // pass 3: through the wave's LDS window (see RingCursor)
-template <int MODE, class SinkT, bool RING = true>
-COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, SinkT &sink, u32 opos, u32 pmin, u32 tpos, u32 *err,
-                      u32 *lane_ring = nullptr) {
-    typename CursorOf<MODE, RING>::type c; c.init(s, from, lane_ring);
+template <int MODE, class SinkT>
+COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, SinkT &sink, u32 opos, u32 pmin, u32 tpos, u32 *err) {
+    Cursor c; c.init(s, from);
     u32 f = 0, bytes = 0, toks = 0;
     // (Bounds in MODE 2: pass 2 counted this lane's bytes and matches with the same decoder and inflate_block checked the block's totals
     // against isize and TOK_CAP before pass 3, so only a match's distance is left to check here.)
@@ -457,7 +424,7 @@ COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *f
                 if (MODE == 0) continue;           // (a guessed start may see an end-of-block that is none; a true one ends what anybody uses of this lane)
                 f |= 1u; break;
             }
-            if (MODE == 0 && unit_at + 1u < until) { c.init(s, unit_at + 1u, lane_ring); continue; }
+            if (MODE == 0 && unit_at + 1u < until) { c.init(s, unit_at + 1u); continue; }
             f |= 2u; break;
         }
         const u32 le = (e >> 12) & 7u;
@@ -478,7 +445,7 @@ COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *f
         const u32 dist = ((ed >> 8) & 0x7fffu) + bits_at(x, dl, de);      // dl + de <= 28
         c.drop(dl + de);
         if ((ed & DIST_INVALID) != 0u) {            // no code of the set / symbols 30, 31
-            if (MODE == 0 && unit_at + 1u < until) { c.init(s, unit_at + 1u, lane_ring); continue; }
+            if (MODE == 0 && unit_at + 1u < until) { c.init(s, unit_at + 1u); continue; }
             f |= 2u; break;
         }
         if (MODE == 2) {
@@ -502,7 +469,7 @@ COVW_FN u32 share_begin_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
 // One BGZF block.  comp_words: aligned words holding the raw DEFLATE payload from bit `bit0` on; out: the block's `isize` output
 // bytes; tok: its token-position list.  *status = OK / ERR_*, *n_tok = matches written (0 unless OK).
 // stop_after (measurements only, 0 in production): 1 = give up after the tables are built, 2 = after pass 1, 3 = after pass 2.
-template <class SinkT = Sink16, bool RING = true>
+template <class SinkT = Sink16>
 COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0) {
     Src s; s.w = comp_words; s.total_bits = bit0 + payload_bits;
     u32 pos = bit0, opos = 0, ntok = 0, err = OK, nblk = 0, chunk_bits = 0;
@@ -663,7 +630,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                     const u32 ge = share_begin_of(cur, S, lane + 1u, span_end);
                     u32 f, nb, nt, e2 = OK;
                     SinkT sink; sink.init(out, tok, opos + W.obase[lane] + W.nbytes[lane]);
-                    if (from < ge) (void)run_share<2, SinkT, RING>(W.T, s, from, ge, &f, &nb, &nt, sink, opos + W.obase[lane], 0, ntok + W.tbase[lane], &e2, W.ring + lane);
+                    if (from < ge) (void)run_share<2>(W.T, s, from, ge, &f, &nb, &nt, sink, opos + W.obase[lane], 0, ntok + W.tbase[lane], &e2);
                     if (e2 != OK) W.hdr[6] = e2;
                 }
             }
