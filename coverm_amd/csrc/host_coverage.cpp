@@ -235,6 +235,22 @@ struct covh_taker {
         if (entry_names.refs.size() < entries) entry_names.refs.resize(entries);        // unset refs: ids arrive in any order, and not all of them
         if (entry_names.arena.capacity() < name_bytes) entry_names.arena.reserve(name_bytes);
     }
+    // Cached taker, every target of a header an entry (zero rows printed): the name table in one pass.  True when the table now holds exactly
+    // these names under ids 0 .. n - 1 (it was empty, or already held this very header); false: the caller goes entry by entry.
+    bool names_bulk(const char *blob, const uint32_t *off, size_t n) {
+        if (kind != COVH_TAKER_CACHED) return false;
+        const size_t bytes = off[n] - off[0];
+        if (entry_names.refs.empty() || (entry_names.arena.empty() && entry_names.refs.size() <= n)) {
+            entry_names.arena.assign(blob + off[0], bytes);
+            entry_names.refs.resize(n);
+            for (size_t i = 0; i < n; i++) { entry_names.refs[i].off = (int64_t)(off[i] - off[0]); entry_names.refs[i].len = off[i + 1] - off[i]; }
+            return true;
+        }
+        if (entry_names.refs.size() != n || entry_names.arena.size() != bytes || memcmp(entry_names.arena.data(), blob + off[0], bytes) != 0) return false;
+        for (size_t i = 0; i < n; i++)
+            if (entry_names.refs[i].off != (int64_t)(off[i] - off[0]) || entry_names.refs[i].len != off[i + 1] - off[i]) return false;
+        return true;
+    }
     void start_entry(size_t id, std::string_view name) {
         if (kind == COVH_TAKER_STREAM) { text += cur_stoit; text += '\t'; text.append(name); }
         else if (kind == COVH_TAKER_PILEUP) cur_entry_name.assign(name);
@@ -512,6 +528,28 @@ int covh_contig_coverage_estimated(const covh_header *h, const covh_sample *samp
                     taker->finish_entry();
                 }
             };
+            if (print_zero && taker->names_bulk(h->names, h->name_off, h->n_targets)) {
+                // every target is an entry of a cached taker: the (entry, coverage) pairs are written in place — the same pairs in the same
+                // order as the calls below would append (zero rows through print_zero_coverage's values: the length for COVH_LENGTH, else 0)
+                auto &v = taker->coverages[taker->cur_stoit_i];
+                const size_t base = v.size();
+                v.resize(base + (size_t)h->n_targets * n_est);
+                std::pair<size_t, float> *o = v.data() + base;
+                for (u32 t = 0; t < h->n_targets; t++, o += n_est) {
+                    const cov_contig_stats &s = S.stats[t];
+                    if (s.n_pass == 0) {
+                        for (size_t k = 0; k < n_est; k++) o[k] = {t, est[k].kind == COVH_LENGTH ? (float)h->target_len[t] : 0.0f};
+                        continue;
+                    }
+                    const float *c = ext ? ext + (size_t)t * n_est : &all[(size_t)t * n_est];
+                    bool nonzero = false;
+                    for (size_t k = 0; k < n_est; k++) { nonzero |= c[k] > 0.0f; o[k] = {t, c[k]}; }
+                    if (nonzero) mapped_total += s.n_primary;           // :67-72
+                }
+                taker->cur_entry_i = h->n_targets ? h->n_targets - 1 : 0;
+                if (rm_out) { rm_out[si].num_mapped_reads = mapped_total; rm_out[si].num_reads = S.num_detected_primary_alignments; }
+                continue;
+            }
             for (u32 t = 0; t < h->n_targets; t++) {
                 const cov_contig_stats &s = S.stats[t];
                 if (s.n_pass == 0) continue;
