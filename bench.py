@@ -784,7 +784,8 @@ def ingest_roofline():
     (profiles/r04_ingest_kernel_stats.csv: rocprofv3 --kernel-trace --stats of `coverm-amd contig` over a 20 M-read level-1 BAM = one full
     round of 81 920 BGZF blocks + one of 12 382; profiles/r04_ingest_pmc_summary.json: separate --pmc passes).  Not measured by this run:
     the bench's timed region is the coverage path; labelled as such.  Algorithmic bytes per full round: compressed bytes read once +
-    inflated bytes written once (k_inflate_wave); token positions + every match byte read and written once (k_lz_resolve)."""
+    inflated bytes written once (k_inflate_wave); token positions + every match byte read and written once (k_lz_stage; k_lz_resolve in profiles
+    that predate it)."""
     out = {"source": "committed profile of the round-4 build (profiles/r04_ingest_kernel_stats.csv, r04_ingest_pmc_summary.json), not this run",
            "round_blocks": 81920, "peak_GBps": HBM_PEAK_GBPS}
     try:
@@ -799,7 +800,7 @@ def ingest_roofline():
         with open(os.path.join(ROOT, "profiles", pmc)) as fh:
             pm = json.load(fh).get("derived_full_round", {})
         blocks = 81920
-        algo = {"covi::k_inflate_wave": blocks * (21100 + 62900), "covi::k_lz_resolve": blocks * (5900 * 2 + 2 * 50600)}
+        algo = {"covi::k_inflate_wave": blocks * (21100 + 62900), "covi::k_lz_stage": blocks * (5900 * 2 + 2 * 50600), "covi::k_lz_resolve": blocks * (5900 * 2 + 2 * 50600)}
         for k, b in algo.items():
             ms = full_ms.get(k)
             if not ms:
