@@ -18,16 +18,16 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar")
 
 
-@pytest.fixture(autouse=True, params=["default", "lane-per-block", "lz-rounds", "sink-8"])
+@pytest.fixture(autouse=True, params=["default", "lane-per-block", "lz-rounds", "sink-8", "sink-16one"])
 def inflate_version(request, monkeypatch):
     """Every test of this file runs with the kernels that ship (k_inflate_wave: one wave per BGZF block; k_lz_stage: the matches of a
     batch resolved in LDS), with the second inflate implementation (k_inflate: one lane per block) and with the second match
-    resolution (k_lz_resolve: rounds through global memory) and with pass 3's 8-byte store policy (k_inflate_wave8).  cov_ingest_begin reads the switches, so sessions of one process may differ."""
+    resolution (k_lz_resolve: rounds through global memory) and with k_inflate_wave's two other builds (k_inflate_wave8: pass 3's 8-byte store policy; k_inflate_wave_one: one unit per lock-step).  cov_ingest_begin reads the switches, so sessions of one process may differ."""
     monkeypatch.delenv("COVERM_INFLATE_V", raising=False)
     monkeypatch.delenv("COVERM_LZ_V", raising=False)
     monkeypatch.delenv("COVERM_INFLATE_SINK", raising=False)
-    if request.param == "sink-8":
-        monkeypatch.setenv("COVERM_INFLATE_SINK", "8")
+    if request.param in ("sink-8", "sink-16one"):
+        monkeypatch.setenv("COVERM_INFLATE_SINK", request.param[5:])
     elif request.param == "lane-per-block":
         monkeypatch.setenv("COVERM_INFLATE_V", "1")
     elif request.param == "lz-rounds":
