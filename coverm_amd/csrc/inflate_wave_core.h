@@ -390,7 +390,7 @@ struct NoSink {      // passes 1 and 2 write nothing
 };
 // (SinkT: where pass 3's bytes go — Sink: the block's place in global memory.  opos: position of the
 // lane's first byte in the sink's coordinates, pmin: position of the block's first byte — a match may not reach in front of it.)
-template <int MODE, class SinkT, bool TWO = true>
+template <int MODE, class SinkT, int EXTRA = 1>
 COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, SinkT &sink, u32 opos, u32 pmin, u32 tpos, u32 *err) {
     Cursor c; c.init(s, from);
     u32 f = 0, bytes = 0, toks = 0;
@@ -415,17 +415,20 @@ COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *f
             c.drop(n);
             if (MODE == 2) sink.literal(opos + bytes, e >> 4);
             bytes++;
-            // A second literal in the same lock-step (two thirds of a BAM block's units are literals, and a wave's step costs what its
-            // slowest lane's does): the next unit begins inside the share, >= 18 of the >= 33 refilled bits are left, and a table entry
-            // that says "literal" is at most LB <= 18 bits long.  Anything else is left to the next step as it stands.
-            if (TWO && c.pos < until) {
+            // More literals in the same lock-step (two thirds of a BAM block's units are literals, in runs of 2.4 on average, and a wave's
+            // step costs what its slowest lane's does): up to EXTRA more while the next unit begins inside the share and a table entry
+            // says "literal" — such a code is at most LB bits long, and 33 refilled bits minus (1 + EXTRA) codes of <= LB leave >= LB for
+            // the next lookup as long as (1 + EXTRA) * LB + LB <= 33, i.e. EXTRA <= 1 at LB = 10; beyond that the cursor is refilled first.
+            // Anything else is left to the next step as it stands.
+            for (int r = 0; r < EXTRA; r++) {
+                if (c.pos >= until) break;
+                if (r >= 1) c.refill();
                 const u32 e2 = T.lit[c.low32() & ((1u << LB) - 1u)];
-                if ((e2 & 15u) != 0u && !(e2 & 0x8000u)) {
-                    COVW_TRACE_UNIT(MODE, 0u);
-                    c.drop(e2 & 15u);
-                    if (MODE == 2) sink.literal(opos + bytes, e2 >> 4);
-                    bytes++;
-                }
+                if ((e2 & 15u) == 0u || (e2 & 0x8000u)) break;
+                COVW_TRACE_UNIT(MODE, 0u);
+                c.drop(e2 & 15u);
+                if (MODE == 2) sink.literal(opos + bytes, e2 >> 4);
+                bytes++;
             }
             continue;
         }
@@ -481,7 +484,7 @@ COVW_FN u32 share_begin_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
 // One BGZF block.  comp_words: aligned words holding the raw DEFLATE payload from bit `bit0` on; out: the block's `isize` output
 // bytes; tok: its token-position list.  *status = OK / ERR_*, *n_tok = matches written (0 unless OK).
 // stop_after (measurements only, 0 in production): 1 = give up after the tables are built, 2 = after pass 1, 3 = after pass 2.
-template <class SinkT = Sink16, bool TWO = true>
+template <class SinkT = Sink16, int EXTRA = 1>
 COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0) {
     Src s; s.w = comp_words; s.total_bits = bit0 + payload_bits;
     u32 pos = bit0, opos = 0, ntok = 0, err = OK, nblk = 0, chunk_bits = 0;
@@ -582,7 +585,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                 NoSink ns;
                 const u32 g = share_begin_of(cur, S, lane, span_end);
                 if (lane) W.end[lane - 1u] = g >= span_end ? span_end
-                                                           : run_share<0, NoSink, TWO>(W.T, s, g - cur > OVERLAP_BITS ? g - OVERLAP_BITS : cur, g, &f, &nb, &nt, ns, 0, 0, 0, nullptr);
+                                                           : run_share<0, NoSink, EXTRA>(W.T, s, g - cur > OVERLAP_BITS ? g - OVERLAP_BITS : cur, g, &f, &nb, &nt, ns, 0, 0, 0, nullptr);
                 if (lane == 63u) W.end[63] = span_end;
             }
             COVW_SYNC();
@@ -595,7 +598,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                     const u32 ge = share_begin_of(cur, S, lane + 1u, span_end);
                     u32 f = 0, nb = 0, nt = 0, e = from;
                     NoSink ns;
-                    if (from < ge) e = run_share<1, NoSink, TWO>(W.T, s, from, ge, &f, &nb, &nt, ns, 0, 0, 0, nullptr);
+                    if (from < ge) e = run_share<1, NoSink, EXTRA>(W.T, s, from, ge, &f, &nb, &nt, ns, 0, 0, 0, nullptr);
                     W.flags[lane] = f; W.nbytes[lane] = nb; W.ntok[lane] = nt; W.tmp[lane] = e;
                 }
                 COVW_SYNC();          // every lane has read its neighbour's old end
@@ -642,7 +645,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                     const u32 ge = share_begin_of(cur, S, lane + 1u, span_end);
                     u32 f, nb, nt, e2 = OK;
                     SinkT sink; sink.init(out, tok, opos + W.obase[lane] + W.nbytes[lane]);
-                    if (from < ge) (void)run_share<2, SinkT, TWO>(W.T, s, from, ge, &f, &nb, &nt, sink, opos + W.obase[lane], 0, ntok + W.tbase[lane], &e2);
+                    if (from < ge) (void)run_share<2, SinkT, EXTRA>(W.T, s, from, ge, &f, &nb, &nt, sink, opos + W.obase[lane], 0, ntok + W.tbase[lane], &e2);
                     if (e2 != OK) W.hdr[6] = e2;
                 }
             }

@@ -446,7 +446,7 @@ namespace covi {
 static_assert(covw::TOK_CAP == INF_TOK_CAP && covw::OK == INF_OK && covw::ERR_FORMAT == INF_ERR_FORMAT && covw::ERR_SIZE == INF_ERR_SIZE, "the core mirrors k_inflate's contract");
 // (A cursor of two words and a funnel shift instead of the 64-bit buffer was tried: no fewer instructions per unit; a look-ahead cursor with
 // 16-byte loads was slower; holding the register allocation to five waves per SIMD changed nothing, to six or seven cost 40 % in spills.)
-template <class SinkT, bool TWO>
+template <class SinkT, int EXTRA>
 __device__ __forceinline__ void inflate_wave_body(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                      uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
                                                      u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
@@ -457,7 +457,7 @@ __device__ __forceinline__ void inflate_wave_body(const uint8_t *__restrict__ co
     u32 st = INF_OK, nt = 0;
     if (B.isize != 0u) {
         const u32 mis = (u32)((u64)(comp + B.in_off) & 3u);
-        covw::inflate_block<SinkT, TWO>(W, reinterpret_cast<const u32 *>(comp + B.in_off - mis), 8u * mis, 8u * B.in_len, out + B.out_off, B.isize,
+        covw::inflate_block<SinkT, EXTRA>(W, reinterpret_cast<const u32 *>(comp + B.in_off - mis), 8u * mis, 8u * B.in_len, out + B.out_off, B.isize,
                             tok + (size_t)b * INF_TOK_CAP, &nt, &st, stop_after);
     }
     if ((threadIdx.x & 63u) == 0u) {
@@ -469,19 +469,28 @@ __device__ __forceinline__ void inflate_wave_body(const uint8_t *__restrict__ co
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_inflate_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                      uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
                                                      u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
-    inflate_wave_body<covw::Sink16, true>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);
+    inflate_wave_body<covw::Sink16, 1>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);
 }
+#define COVI_INFLATE_EXTRA(NAME, N)                                                                                                               \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void NAME(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks, \
+                                                     uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,          \
+                                                     u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {                 \
+        inflate_wave_body<covw::Sink16, N>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);                           \
+    }
+COVI_INFLATE_EXTRA(k_inflate_wave_x2, 2)      // COVERM_INFLATE_SINK=16x2 / 16x3: up to two / three more literals per lock-step (measurement)
+COVI_INFLATE_EXTRA(k_inflate_wave_x3, 3)
+#undef COVI_INFLATE_EXTRA
 // COVERM_INFLATE_SINK=16one: one unit per lock-step (no second literal), the measurement's other side
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_inflate_wave_one(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                      uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
                                                      u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
-    inflate_wave_body<covw::Sink16, false>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);
+    inflate_wave_body<covw::Sink16, 0>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);
 }
 // The same with the 8-byte sink of rounds 3-4 (COVERM_INFLATE_SINK=8): the measurement's other side, and a second store policy under the tests.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_inflate_wave8(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                      uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
                                                      u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
-    inflate_wave_body<covw::Sink, false>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);
+    inflate_wave_body<covw::Sink, 0>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);
 }
 // (Held to 96 registers = five waves per SIMD, one spilled register: 24.5 ms per round against 22.3 on the same box, profiles/r04_waves5_lzscope.log.)
 

@@ -18,12 +18,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-@pytest.fixture(scope="module", params=["lanes 0..63", "lanes 63..0", "lanes 0..63, 8-byte sink", "lanes 63..0, 8-byte sink"])
+@pytest.fixture(scope="module", params=["lanes 0..63", "lanes 63..0", "lanes 0..63, 8-byte sink", "lanes 63..0, 8-byte sink", "lanes 63..0, 3 extra literals"])
 def host(request, tmp_path_factory):
     # the lanes of a COVW_PARFOR region run concurrently on the device; here they run one after the other, in both orders
     so = str(tmp_path_factory.mktemp("covw") / "covw_host.so")
     subprocess.check_call(["g++", "-O2", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "c", "inflate_wave_host.cpp")]
-                          + (["-DCOVW_REVERSE"] if "..0" in request.param else []) + (["-DCOVW_SINK_OLD"] if "8-byte" in request.param else []))
+                          + (["-DCOVW_REVERSE"] if "..0" in request.param else []) + (["-DCOVW_SINK_OLD"] if "8-byte" in request.param else []) + (["-DCOVW_EXTRA_LITS=3"] if "extra" in request.param else []))
     L = C.CDLL(so)
     L.covw_host_inflate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.covw_host_inflate.restype = C.c_int
