@@ -471,15 +471,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                                                      u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
     inflate_wave_body<covw::Sink16, 1>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);
 }
-#define COVI_INFLATE_EXTRA(NAME, N)                                                                                                               \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void NAME(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks, \
-                                                     uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,          \
-                                                     u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {                 \
-        inflate_wave_body<covw::Sink16, N>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);                           \
-    }
-COVI_INFLATE_EXTRA(k_inflate_wave_x2, 2)      // COVERM_INFLATE_SINK=16x2 / 16x3: up to two / three more literals per lock-step (measurement)
-COVI_INFLATE_EXTRA(k_inflate_wave_x3, 3)
-#undef COVI_INFLATE_EXTRA
+// (Up to two and three more literals per lock-step were measured as well — 18.0 and 20.3 ms per full round against 17.1 with one more, ingest
+// of 100 M reads 0.339 / 0.328 s against 0.320, profiles/r05_extra_literals_*.log: every further literal slot is another dependent table
+// lookup, and a refill, in the path every lock-step takes.  One more it is.)
 // COVERM_INFLATE_SINK=16one: one unit per lock-step (no second literal), the measurement's other side
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_inflate_wave_one(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                      uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
