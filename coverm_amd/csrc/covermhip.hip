@@ -82,7 +82,7 @@ std::string g_create_error;
 //                        the fill and drain of the pipeline);
 //   version 1 (COVERM_INFLATE_V=1): k_inflate, one LANE per block, private Huffman tables per lane in LDS — the second implementation the
 //                        tests compare with; a launch is cut to exactly the blocks resident at once (a lane decodes a block serially).
-struct InflateKernel { int version = 3; int lz_version = 2; bool sink8 = false, one_unit = false, after_match = false; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ablate = 0; u32 ext_parts = covi::EXT_PARTS; };
+struct InflateKernel { int version = 3; int lz_version = 2; bool sink8 = false, one_unit = false; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ablate = 0; u32 ext_parts = covi::EXT_PARTS; };
 
 struct cov_session {
     cov_config cfg{};
@@ -1287,7 +1287,7 @@ static InflateKernel choose_inflate_kernel(cov_session *s) {
     InflateKernel K;
     const char *ve = getenv("COVERM_INFLATE_V");
     K.version = ve && atoi(ve) == 1 ? 1 : 3;
-    if (const char *sk = getenv("COVERM_INFLATE_SINK")) { K.sink8 = !strcmp(sk, "8"); K.one_unit = !strcmp(sk, "16one"); K.after_match = !strcmp(sk, "16am"); }      // k_inflate_wave8: pass 3 through the 8-byte sink (rounds 3-4) instead of the 16-byte window
+    if (const char *sk = getenv("COVERM_INFLATE_SINK")) { K.sink8 = !strcmp(sk, "8"); K.one_unit = !strcmp(sk, "16one"); }      // k_inflate_wave8: pass 3 through the 8-byte sink (rounds 3-4) instead of the 16-byte window
     if (const char *lz = getenv("COVERM_LZ_V")) K.lz_version = atoi(lz) == 1 ? 1 : 2;      // 1: k_lz_resolve (rounds through global memory), 2: k_lz_stage (batches staged in LDS)
     if (K.version == 1) {
         int per_cu = 0;
@@ -1493,7 +1493,7 @@ static cov_status launch_round_(cov_session *s, uint64_t n64, bool final) {
         const uint8_t *comp_bias = s->g_cwin[w % 3u].p - s->ing_round_start;     // blocks carry absolute file offsets
         const u32 ablate = K.ablate;
         if (K.version == 3)
-            hipLaunchKernelGGL((K.sink8 ? covi::k_inflate_wave8 : K.one_unit ? covi::k_inflate_wave_one : K.after_match ? covi::k_inflate_wave_am : covi::k_inflate_wave), dim3(n), dim3(64), 0, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
+            hipLaunchKernelGGL((K.sink8 ? covi::k_inflate_wave8 : K.one_unit ? covi::k_inflate_wave_one : covi::k_inflate_wave), dim3(n), dim3(64), 0, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
                                tokb.p, ntokb.p, s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
         else
             hipLaunchKernelGGL((covi::k_inflate<INF1_LB, INF1_DB, false>), dim3(grid), dim3(64), covi::inflate_smem_bytes(INF1_LB, INF1_DB), s->stream, comp_bias,

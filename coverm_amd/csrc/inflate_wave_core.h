@@ -390,7 +390,7 @@ struct NoSink {      // passes 1 and 2 write nothing
 };
 // (SinkT: where pass 3's bytes go — Sink: the block's place in global memory.  opos: position of the
 // lane's first byte in the sink's coordinates, pmin: position of the block's first byte — a match may not reach in front of it.)
-template <int MODE, class SinkT, int EXTRA = 1, bool AFTER_MATCH = false>
+template <int MODE, class SinkT, int EXTRA = 1>
 COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *flags, u32 *nb, u32 *nt, SinkT &sink, u32 opos, u32 pmin, u32 tpos, u32 *err) {
     Cursor c; c.init(s, from);
     u32 f = 0, bytes = 0, toks = 0;
@@ -469,16 +469,8 @@ COVW_FN u32 run_share(const Tables &T, const Src &s, u32 from, u32 until, u32 *f
             sink.match(p, len, (dist - 1u) | ((len - 3u) << 15), tpos + toks);      // k_lz_resolve's token
         }
         bytes += len; toks++;
-        if (AFTER_MATCH && c.pos < until) {      // a literal behind the match in the same lock-step (seven matches in ten are followed by one)
-            c.refill();
-            const u32 e2 = T.lit[c.low32() & ((1u << LB) - 1u)];
-            if ((e2 & 15u) != 0u && !(e2 & 0x8000u)) {
-                COVW_TRACE_UNIT(MODE, 0u);
-                c.drop(e2 & 15u);
-                if (MODE == 2) sink.literal(opos + bytes, e2 >> 4);
-                bytes++;
-            }
-        }
+        // (A literal behind the match in the same lock-step — seven matches in ten are followed by one — was measured too: 20.0 ms per full
+        // round against 17.8, profiles/r05_literal_after_match_*.log: it lengthens the match path, which nearly every lock-step takes.)
     }
     if (MODE != 0 && c.pos > s.total_bits) f |= 2u;      // only a lane's last unit can run off the payload: `until` lies inside it
     if (MODE == 2) sink.finish(opos + bytes);
@@ -494,7 +486,7 @@ COVW_FN u32 share_begin_of(u32 B0, u32 S, u32 lane, u32 total_bits) {
 // One BGZF block.  comp_words: aligned words holding the raw DEFLATE payload from bit `bit0` on; out: the block's `isize` output
 // bytes; tok: its token-position list.  *status = OK / ERR_*, *n_tok = matches written (0 unless OK).
 // stop_after (measurements only, 0 in production): 1 = give up after the tables are built, 2 = after pass 1, 3 = after pass 2.
-template <class SinkT = Sink16, int EXTRA = 1, bool AFTER_MATCH = false>
+template <class SinkT = Sink16, int EXTRA = 1>
 COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload_bits, u8 *out, u32 isize, u16 *tok, u32 *n_tok, u32 *status, u32 stop_after = 0) {
     Src s; s.w = comp_words; s.total_bits = bit0 + payload_bits;
     u32 pos = bit0, opos = 0, ntok = 0, err = OK, nblk = 0, chunk_bits = 0;
@@ -595,7 +587,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                 NoSink ns;
                 const u32 g = share_begin_of(cur, S, lane, span_end);
                 if (lane) W.end[lane - 1u] = g >= span_end ? span_end
-                                                           : run_share<0, NoSink, EXTRA, AFTER_MATCH>(W.T, s, g - cur > OVERLAP_BITS ? g - OVERLAP_BITS : cur, g, &f, &nb, &nt, ns, 0, 0, 0, nullptr);
+                                                           : run_share<0, NoSink, EXTRA>(W.T, s, g - cur > OVERLAP_BITS ? g - OVERLAP_BITS : cur, g, &f, &nb, &nt, ns, 0, 0, 0, nullptr);
                 if (lane == 63u) W.end[63] = span_end;
             }
             COVW_SYNC();
@@ -608,7 +600,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                     const u32 ge = share_begin_of(cur, S, lane + 1u, span_end);
                     u32 f = 0, nb = 0, nt = 0, e = from;
                     NoSink ns;
-                    if (from < ge) e = run_share<1, NoSink, EXTRA, AFTER_MATCH>(W.T, s, from, ge, &f, &nb, &nt, ns, 0, 0, 0, nullptr);
+                    if (from < ge) e = run_share<1, NoSink, EXTRA>(W.T, s, from, ge, &f, &nb, &nt, ns, 0, 0, 0, nullptr);
                     W.flags[lane] = f; W.nbytes[lane] = nb; W.ntok[lane] = nt; W.tmp[lane] = e;
                 }
                 COVW_SYNC();          // every lane has read its neighbour's old end
@@ -655,7 +647,7 @@ COVW_FN void inflate_block(Wave &W, const u32 *comp_words, u32 bit0, u32 payload
                     const u32 ge = share_begin_of(cur, S, lane + 1u, span_end);
                     u32 f, nb, nt, e2 = OK;
                     SinkT sink; sink.init(out, tok, opos + W.obase[lane] + W.nbytes[lane]);
-                    if (from < ge) (void)run_share<2, SinkT, EXTRA, AFTER_MATCH>(W.T, s, from, ge, &f, &nb, &nt, sink, opos + W.obase[lane], 0, ntok + W.tbase[lane], &e2);
+                    if (from < ge) (void)run_share<2, SinkT, EXTRA>(W.T, s, from, ge, &f, &nb, &nt, sink, opos + W.obase[lane], 0, ntok + W.tbase[lane], &e2);
                     if (e2 != OK) W.hdr[6] = e2;
                 }
             }

@@ -39,8 +39,8 @@ int covw_host_inflate(const uint8_t *payload, uint32_t nbytes, uint32_t misalign
     W.rounds = 0;
 #ifdef COVW_SINK_OLD      // the 8-byte sink (k_inflate_wave8, COVERM_INFLATE_SINK=8)
     covw::inflate_block<covw::Sink>(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status, 0);
-#elif defined(COVW_EXTRA_LITS)      // more literals per lock-step than the shipped kernel takes, and one behind a match
-    covw::inflate_block<covw::Sink16, COVW_EXTRA_LITS, true>(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status, 0);
+#elif defined(COVW_EXTRA_LITS)      // more literals per lock-step than the shipped kernel takes
+    covw::inflate_block<covw::Sink16, COVW_EXTRA_LITS>(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status, 0);
 #else
     covw::inflate_block(W, words.data(), 8u * misalign, 8u * nbytes, out + 8, isize, tok, n_tok, &status, 0);
 #endif
