@@ -1087,6 +1087,35 @@ __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__
     const u32 n_mine = (last ? s.n_rec : s.part_rec[part]) - rec_lo;
     u64 q = part ? s.start + s.part_off[part - 1u] : s.start;
     u64 ri = R.rec0 + rec_base[k] + rec_lo, ci = R.cig0 + cig_base[k] + cig_lo;
+    // A lane's records are consecutive in the store, so their fields wait in LDS four records at a time (96 bytes per lane; registers
+    // would have to be indexed by a counter: 175 of them, two waves per SIMD, in a kernel that lives on its occupancy) and every column
+    // leaves as ONE store per four records (16 bytes of tid / pos / l_seq / cigar_off / nm, 8 of flags, 4 of mapq and of the NM kind)
+    // instead of four partial-line stores each: the lanes of a wave write ~100 bytes apart, and a line that is written four bytes at a
+    // time is evicted several times before it is complete (5.0 GB of WRITE_SIZE for 0.9 GB of store output in round 4's counters).
+    // Mate columns (pair-mode filters only) are written one record at a time as before.
+    __shared__ __attribute__((aligned(16))) u32 lbuf[64][24];      // per lane: tid[4] pos[4] l_seq[4] cigar_off[4] nm[4] flag[4 x u16] mapq[4 x u8] nm_kind[4 x u8]
+    u32 *B = lbuf[threadIdx.x & 63];
+    uint16_t *Bf = reinterpret_cast<uint16_t *>(B + 20);
+    uint8_t *Bm = reinterpret_cast<uint8_t *>(B + 22), *Bk = reinterpret_cast<uint8_t *>(B + 23);
+    u32 nb = 0;
+    auto flush = [&](u64 at) {       // the buffered records are records at .. at + nb - 1 of the store
+        if (nb == 4u) {
+            *reinterpret_cast<uint4 *>(R.tid + at) = *reinterpret_cast<const uint4 *>(B);
+            *reinterpret_cast<uint4 *>(R.pos + at) = *reinterpret_cast<const uint4 *>(B + 4);
+            *reinterpret_cast<uint4 *>(R.l_seq + at) = *reinterpret_cast<const uint4 *>(B + 8);
+            *reinterpret_cast<uint4 *>(R.cigar_off + at) = *reinterpret_cast<const uint4 *>(B + 12);
+            *reinterpret_cast<uint4 *>(R.nm + at) = *reinterpret_cast<const uint4 *>(B + 16);
+            *reinterpret_cast<uint2 *>(R.flag + at) = *reinterpret_cast<const uint2 *>(B + 20);
+            *reinterpret_cast<u32 *>(R.mapq + at) = B[22];
+            *reinterpret_cast<u32 *>(R.nm_kind + at) = B[23];
+        } else {
+            for (u32 x = 0; x < nb; x++) {
+                R.tid[at + x] = (int32_t)B[x]; R.pos[at + x] = (int32_t)B[4 + x]; R.l_seq[at + x] = B[8 + x]; R.cigar_off[at + x] = B[12 + x];
+                R.nm[at + x] = B[16 + x]; R.flag[at + x] = Bf[x]; R.mapq[at + x] = Bm[x]; R.nm_kind[at + x] = Bk[x];
+            }
+        }
+        nb = 0;
+    };
     for (u32 j = 0; j < n_mine && q < q_end;) {
         const uint8_t *r = S.u + q;
         const u32 bs = ld32(r);
@@ -1095,9 +1124,7 @@ __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__
         if (key < S.key_lo || key >= S.key_hi) { q += 4 + (u64)bs; continue; }
         j++;
         const u32 l_read_name = r[12], n_cig = ld16(r + 16), l_seq = ld32(r + 20);
-        R.tid[ri] = (int32_t)ld32(r + 4); R.pos[ri] = (int32_t)ld32(r + 8);
-        R.mapq[ri] = r[13]; R.flag[ri] = (uint16_t)ld16(r + 18); R.l_seq[ri] = l_seq;
-        R.cigar_off[ri] = (u32)ci;
+        B[nb] = ld32(r + 4); B[4 + nb] = ld32(r + 8); Bm[nb] = r[13]; Bf[nb] = (uint16_t)ld16(r + 18); B[8 + nb] = l_seq; B[12 + nb] = (u32)ci;
         if (R.mtid) {      // filter.rs:164-176 needs the mate's reference and the read name (without its NUL)
             R.mtid[ri] = (int32_t)ld32(r + 24);
             u64 k1; u32 k2;
@@ -1115,11 +1142,13 @@ __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__
             for (u32 x = 0; x < words; x++) R.cigar[ci + x] = ld32(c + 4ull * x);
         }
         u32 nm = 0;
-        R.nm_kind[ri] = (uint8_t)scan_nm(aux, end, nm);
-        R.nm[ri] = nm;
-        ri++; ci += words;
+        Bk[nb] = (uint8_t)scan_nm(aux, end, nm);
+        B[16 + nb] = nm;
+        nb++; ri++; ci += words;
+        if (nb == 4u) flush(ri - 4);
         q += 4 + (u64)bs;
     }
+    if (nb) flush(ri - nb);
 }
 
 }  // namespace covi
