@@ -1093,8 +1093,17 @@ __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__
     // instead of four partial-line stores each: the lanes of a wave write ~100 bytes apart, and a line that is written four bytes at a
     // time is evicted several times before it is complete (5.0 GB of WRITE_SIZE for 0.9 GB of store output in round 4's counters).
     // Mate columns (pair-mode filters only) are written one record at a time as before.
-    __shared__ __attribute__((aligned(16))) u32 lbuf[64][24];      // per lane: tid[4] pos[4] l_seq[4] cigar_off[4] nm[4] flag[4 x u16] mapq[4 x u8] nm_kind[4 x u8]
+    __shared__ __attribute__((aligned(16))) u32 lbuf[64][32];      // per lane: tid[4] pos[4] l_seq[4] cigar_off[4] nm[4] flag[4 x u16] mapq[4 x u8] nm_kind[4 x u8] | 8 CIGAR words
     u32 *B = lbuf[threadIdx.x & 63];
+    u32 *Cw = B + 24;          // CIGAR words of the lane's records, consecutive in the store like the records: they leave four at a time too
+    u32 ncw = 0;               // words waiting in Cw; they belong at cigar[ci - ncw ..)
+    auto flush_cigar = [&](u64 ci_now, bool all) {
+        u64 at = ci_now - ncw;
+        u32 done = 0;
+        while (ncw - done >= 4u) { *reinterpret_cast<uint4 *>(R.cigar + at + done) = make_uint4(Cw[done], Cw[done + 1], Cw[done + 2], Cw[done + 3]); done += 4u; }
+        if (all) { for (; done < ncw; done++) R.cigar[at + done] = Cw[done]; ncw = 0; }
+        else { const u32 left = ncw - done; for (u32 x = 0; x < left; x++) Cw[x] = Cw[done + x]; ncw = left; }
+    };
     uint16_t *Bf = reinterpret_cast<uint16_t *>(B + 20);
     uint8_t *Bm = reinterpret_cast<uint8_t *>(B + 22), *Bk = reinterpret_cast<uint8_t *>(B + 23);
     u32 nb = 0;
@@ -1134,12 +1143,19 @@ __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__
         const uint8_t *c = r + 36 + l_read_name;
         const uint8_t *aux = c + 4ull * n_cig + ((u64)l_seq + 1ull) / 2 + l_seq;
         u32 words = n_cig;
-        if (aux > end) { atomicAdd(n_bad, 1u); aux = end; }
+        if (aux > end) { atomicAdd(n_bad, 1u); aux = end; if (ncw) flush_cigar(ci, true); }     // (its words are skipped, not written: what waits goes out first)
         else {
             u32 cnt = 0;
             const uint8_t *cg = n_cig == 2u ? cg_cigar(r, end, cnt) : nullptr;      // (the same test k_bam_hop counted the words with)
             if (cg) { words = cnt; c = cg; }
-            for (u32 x = 0; x < words; x++) R.cigar[ci + x] = ld32(c + 4ull * x);
+            if (words <= 4u) {         // short reads: the words wait with those of the lane's neighbouring records
+                for (u32 x = 0; x < words; x++) Cw[ncw + x] = ld32(c + 4ull * x);
+                ncw += words;
+                if (ncw >= 4u) flush_cigar(ci + words, false);
+            } else {                   // a long CIGAR goes out directly, behind whatever was waiting
+                if (ncw) flush_cigar(ci, true);
+                for (u32 x = 0; x < words; x++) R.cigar[ci + x] = ld32(c + 4ull * x);
+            }
         }
         u32 nm = 0;
         Bk[nb] = (uint8_t)scan_nm(aux, end, nm);
@@ -1149,6 +1165,7 @@ __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__
         q += 4 + (u64)bs;
     }
     if (nb) flush(ri - nb);
+    if (ncw) flush_cigar(ci, true);
 }
 
 }  // namespace covi
