@@ -231,6 +231,12 @@ class CoverageTaker:
     def finish_entry(self):
         _lib().covh_taker_finish_entry(self._h)
 
+    def names_mismatch(self) -> bool:
+        """An entry id arrived with two different names (coverage_takers.rs:140-148: CoverM stops there)."""
+        L = _lib()
+        L.covh_taker_names_mismatch.argtypes = [C.c_void_p]
+        return bool(L.covh_taker_names_mismatch(self._h))
+
     def iterate(self, num_coverages: int):
         """CoverageTakerTypeIterator: list of (entry_index, stoit_index, [coverages])."""
         L = _lib()

@@ -43,3 +43,39 @@ def test_histogram_and_tpm_estimators_are_refused_with_floats():
         t = CoverageTaker.new_cached_single_float_coverage_taker(1)
         with pytest.raises(Exception):
             host.contig_coverage(af.ref_names, af.ref_lens, [sample], t, [bad], True, estimates=[np.zeros((len(af.ref_lens), 1), np.float32)])
+
+
+def _stats(n, zero_every=0):
+    from coverm_amd import native
+    st = np.zeros(n, dtype=native.CONTIG_STATS_DTYPE)
+    st["n_pass"] = 3
+    st["n_primary"] = 2
+    if zero_every:
+        st["n_pass"][::zero_every] = 0
+    return st
+
+
+def test_bulk_fill_of_a_cached_taker_over_several_samples():
+    """Every target an entry of a cached taker: names and (entry, coverage) pairs are written in one pass (covh_taker::names_bulk).  A
+    second sample over the same header takes the same path; one over other names must still be noticed
+    (coverage_takers.rs:140-148: CoverM stops when the reference sets differ)."""
+    n = 1500
+    names = ["contig_%d" % i for i in range(n)]
+    lens = np.full(n, 5000, np.int64)
+    est = [E.new_estimator_mean(0.0, 0, False), E.new_estimator_length()]
+    rng = np.random.default_rng(3)
+    taker = CoverageTaker.new_cached_single_float_coverage_taker(len(est))
+    want = []
+    for k in range(3):
+        st = _stats(n, zero_every=5 + k)
+        ef = rng.random((n, 2)).astype(np.float32)
+        rm = host.contig_coverage(names, lens, [host.SampleResult("s%d" % k, st, None, 7)], taker, est, True, estimates=[ef])
+        exp = np.where((st["n_pass"] > 0)[:, None], ef, np.asarray([0.0, 5000.0], np.float32)[None, :]).astype(np.float32)   # zero rows: 0 and the length
+        want.append(exp)
+        assert rm[0].num_mapped_reads == int((((exp[:, :1] > 0) | (exp[:, 1:] > 0)).ravel() * (st["n_pass"] > 0) * st["n_primary"]).sum())
+    for k in range(3):
+        np.testing.assert_array_equal(taker.cached_coverages(k).reshape(n, 2).view(np.uint32), want[k].view(np.uint32))
+    assert not taker.names_mismatch()
+    other = ["other_%d" % i for i in range(n)]
+    host.contig_coverage(other, lens, [host.SampleResult("s3", _stats(n), None, 7)], taker, est, True, estimates=[np.zeros((n, 2), np.float32)])
+    assert taker.names_mismatch()
