@@ -93,7 +93,7 @@ struct cov_session {
     int stream_rows = 4;   // > 0: wave-per-tile kernels (1024-base tiles); 0: k_pileup workgroup-per-tile (COVERM_PILEUP=tile)
     bool use_fast = true;  // k_pileup_fast + k_pileup_stream on the slow-tile list (default); COVERM_PILEUP=stream: k_pileup_stream alone
     int chunk_tiles = 8;   // consecutive tiles walked by one wave (COVERM_CHUNK)
-    int prep_waves = 6;    // k_prep6 (80 registers, six waves per SIMD: the default) or k_prep as it compiles (88 registers, five; COVERM_PREP_WAVES=5)
+    int prep_kernel = 0;   // 0 = k_prep5p (tid / cigar_off one pass ahead, five waves per SIMD: the default), 6 = k_prep6, 5 = k_prep (COVERM_PREP_KERNEL)
     int fast_waves = 7;        // k_pileup_fast7 (384 LDS bins, seven waves per SIMD: the default) or k_pileup_fast (512 bins, six; COVERM_FAST_WAVES=6)
     int n_cus = 256;
     uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
@@ -497,7 +497,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
     if (const char *fw = getenv("COVERM_FAST_WAVES")) { const int v = atoi(fw); s->fast_waves = v == 6 ? 6 : 7; }
-    if (const char *pw = getenv("COVERM_PREP_WAVES")) s->prep_waves = atoi(pw) == 5 ? 5 : 6;
+    if (const char *pk = getenv("COVERM_PREP_KERNEL")) s->prep_kernel = atoi(pk) == 6 ? 6 : (atoi(pk) == 5 ? 5 : 0);
     if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
     if (const char *c = getenv("COVERM_STORE_CAP_RECORDS")) { const long long v = atoll(c); if (v >= 1) s->cap_records = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
@@ -855,7 +855,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     if (R) {
         time_begin(s, COV_K_PREP);
 #define COV_LAUNCH_PREP(ID, FI, MA)                                                                                                       \
-        hipLaunchKernelGGL((s->prep_waves == 5 ? &k_prep<ID, FI, MA> : &k_prep6<ID, FI, MA>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f, s->d_ctg.p, \
+        hipLaunchKernelGGL((s->prep_kernel == 6 ? &k_prep6<ID, FI, MA> : s->prep_kernel == 5 ? &k_prep<ID, FI, MA> : &k_prep5p<ID, FI, MA>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f, s->d_ctg.p, \
                            s->d_glob.p, s->d_runs.p, idp, idn, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap)
         {
             const int key = (want_id ? 4 : 0) | (s->cfg.filter_single ? 2 : 0) | (mask != nullptr ? 1 : 0);

@@ -353,8 +353,8 @@ __device__ __forceinline__ void prep_flush(DevContig *ctg, int cur, PrepAcc &a) 
 // round 5, alternating with this kernel on one box: 0.76-0.78 ms against 0.61, profiles/r05_prep_pileup_ab.log.  Its counters say why: 43 %
 // fewer memory instructions and 6 % fewer VALU instructions, but the SIMDs are busy ISSUING — 29 % of a wave's time executing at 4.3 waves per
 // SIMD — not waiting for bytes, and the 64-bit address arithmetic of the wide loads plus the wave-wide DPP moves cost more issue slots than
-// the narrow loads they replaced.  Removed; what did pay is one more wave per SIMD, k_prep6 below.)
-template <bool WANT_IDENTITY, bool FILTER, bool MASKED>
+// the narrow loads they replaced.  Removed.)
+template <bool WANT_IDENTITY, bool FILTER, bool MASKED, bool PREFETCH>
 __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restrict__ tlen, u32 n_targets,
                                           const uint8_t *__restrict__ mask, const FilterCfg &f, DevContig *ctg,
                                           DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ identp,
@@ -383,6 +383,23 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
     const int *tid_m = r.tid + chunk - 1; const int *pos_m = r.pos + chunk - 1;   // [x + 1] = record x (never read below 0)
     uint2 *runs_c = runs + chunk;
 
+    // PREFETCH: the two fields the dependent loads of a pass hang on (tid -> contig length, first tile, mask; cigar_off -> the CIGAR words)
+    // are loaded ONE PASS AHEAD, behind the current pass's loads, so that a pass has one load phase instead of two dependent ones; four
+    // registers stay live across the per-record logic for it.  0.580 ms against 0.587 without at the same five waves per SIMD, and against
+    // 0.592 for k_prep6, alternating on one box (profiles/r05_prep_prefetch_ab.log): small, because the kernel is bound by instruction issue
+    // more than by these trips.  (The same through LDS — global_load_lds_dword, no register held — measured 0.607 at five and at six waves:
+    // the compiler drains every load before the first use of an ordinary one while an LDS-bound load is in flight, and the pass begins with a
+    // wait for the previous pass's stores.  At six waves the four registers spill INSIDE the load phase, which serialises it: not built.)
+    int td_n[PREP_B]; u32 co0_n[PREP_B];
+    auto prefetch = [&](u32 l0n) {
+#pragma unroll
+        for (int k = 0; k < PREP_B; k++) {   // clamped to the chunk's last record: always in bounds, unused after the last pass
+            const u32 lc = min(l0n + (u32)k * 256u, lmax) & (u32)(PREP_CHUNK - 1);
+            td_n[k] = tid_c[lc]; co0_n[k] = coff_c[lc];
+        }
+    };
+    if (PREFETCH) prefetch(threadIdx.x);
+
     for (int ps = 0; ps < passes; ps++) {
         const u32 l0 = (u32)(ps * b_active) * 256u + threadIdx.x;
         const u32 i0 = chunk + l0;
@@ -394,8 +411,8 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
         for (int k = 0; k < PREP_B; k++) {
             const u32 lc = min(l0 + (u32)k * 256u, lmax) & (u32)(PREP_CHUNK - 1);   // the mask is a no-op that bounds lc for the compiler
             const u32 ic = chunk + lc;
-            fl[k] = flag_c[lc]; td[k] = tid_c[lc]; ps_[k] = pos_c[lc]; mq[k] = FILTER ? mapq_c[lc] : 0u; nmk[k] = nmk_c[lc];
-            nmv32[k] = nm_c[lc]; lsq[k] = FILTER ? lseq_c[lc] : 0u; co0[k] = coff_c[lc]; co1[k] = coff_c[lc + 1u];
+            fl[k] = flag_c[lc]; td[k] = PREFETCH ? td_n[k] : tid_c[lc]; ps_[k] = pos_c[lc]; mq[k] = FILTER ? mapq_c[lc] : 0u; nmk[k] = nmk_c[lc];
+            nmv32[k] = nm_c[lc]; lsq[k] = FILTER ? lseq_c[lc] : 0u; co0[k] = PREFETCH ? co0_n[k] : coff_c[lc]; co1[k] = coff_c[lc + 1u];
             const u32 lp = (lc + (ic > 0u ? 0u : 1u)) & (u32)(2 * PREP_CHUNK - 1), ln = (lc + (ic < nlast ? 1u : 0u)) & (u32)(2 * PREP_CHUNK - 1);
             ptid[k] = tid_m[lp]; ppos[k] = pos_m[lp]; ntid[k] = tid_c[ln];
         }
@@ -410,6 +427,7 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
 #pragma unroll
             for (int c = 0; c < 3; c++) cw[k][c] = r.cigar_end ? r.cigar[min(co0[k] + (u32)c, cig_last)] : 0u;
         }
+        if (PREFETCH) prefetch(l0 + (u32)b_active * 256u);
         // ---- phase C: per-record logic
 #pragma unroll
         for (int k = 0; k < PREP_B; k++) {
@@ -695,20 +713,23 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
     }
 }
 
-#define COV_PREP_KERNEL(NAME, ATTR)                                                                                                              \
+#define COV_PREP_KERNEL(NAME, ATTR, PF)                                                                                                           \
     template <bool WANT_IDENTITY, bool FILTER, bool MASKED>                                                                                      \
     __global__ __launch_bounds__(256) ATTR void NAME(Records r, const u32 *__restrict__ tlen, u32 n_targets, const uint8_t *__restrict__ mask,   \
                                                      FilterCfg f, DevContig *ctg, DevGlobal *g, uint2 *__restrict__ runs,                        \
                                                      double *__restrict__ identp, double *__restrict__ identn, PrepPartial *__restrict__ part,   \
                                                      TileIdx ti, int passes, int b_active, u32 *__restrict__ cx_list, u32 cx_list_cap) {         \
-        prep_body<WANT_IDENTITY, FILTER, MASKED>(r, tlen, n_targets, mask, f, ctg, g, runs, identp, identn, part, ti, passes, b_active, cx_list, \
+        prep_body<WANT_IDENTITY, FILTER, MASKED, PF>(r, tlen, n_targets, mask, f, ctg, g, runs, identp, identn, part, ti, passes, b_active, cx_list, \
                                                  cx_list_cap);                                                                                   \
     }
-// k_prep6 (the default): the registers capped at 80 for six waves per SIMD (two to six dwords of scratch): 0.585 ms against 0.607 at
-// BASELINE config 2, alternating runs on one box (profiles/r05_prep_pileup_ab.log); at eight waves (64 registers, 72-100 bytes of
-// scratch) the scratch traffic costs more than the waves hide.  COVERM_PREP_WAVES=5 selects k_prep as it compiles (88 registers).
-COV_PREP_KERNEL(k_prep, )
-COV_PREP_KERNEL(k_prep6, __attribute__((amdgpu_waves_per_eu(6))))
+// k_prep5p (the default): the roots of the dependent loads one pass ahead, as it compiles (92-96 registers: five waves per SIMD).
+// k_prep6 (COVERM_PREP_KERNEL=6; the default of round 5 before the prefetch): no prefetch, the registers capped at 80 for six waves per SIMD
+// (two to six dwords of scratch): 0.585 ms against 0.607 for k_prep (COVERM_PREP_KERNEL=5: no prefetch, as it compiles, 88 registers) on one
+// box, 0.592 against 0.587 on another (profiles/r05_prep_pileup_ab.log, r05_prep_prefetch_ab.log); at eight waves (64 registers, 72-100
+// bytes of scratch) the scratch traffic costs more than the waves hide.
+COV_PREP_KERNEL(k_prep, , false)
+COV_PREP_KERNEL(k_prep6, __attribute__((amdgpu_waves_per_eu(6))), false)
+COV_PREP_KERNEL(k_prep5p, __attribute__((amdgpu_waves_per_eu(5))), true)
 #undef COV_PREP_KERNEL
 
 // One wave per contig: adds the partial records of the workgroups that lay entirely inside it.
