@@ -354,7 +354,7 @@ __device__ __forceinline__ void prep_flush(DevContig *ctg, int cur, PrepAcc &a) 
 // fewer memory instructions and 6 % fewer VALU instructions, but the SIMDs are busy ISSUING — 29 % of a wave's time executing at 4.3 waves per
 // SIMD — not waiting for bytes, and the 64-bit address arithmetic of the wide loads plus the wave-wide DPP moves cost more issue slots than
 // the narrow loads they replaced.  Removed.)
-template <bool WANT_IDENTITY, bool FILTER, bool MASKED, bool PREFETCH>
+template <bool WANT_IDENTITY, bool FILTER, bool MASKED, int PREFETCH>
 __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restrict__ tlen, u32 n_targets,
                                           const uint8_t *__restrict__ mask, const FilterCfg &f, DevContig *ctg,
                                           DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ identp,
@@ -385,20 +385,30 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
 
     // PREFETCH: the two fields the dependent loads of a pass hang on (tid -> contig length, first tile, mask; cigar_off -> the CIGAR words)
     // are loaded ONE PASS AHEAD, behind the current pass's loads, so that a pass has one load phase instead of two dependent ones; four
-    // registers stay live across the per-record logic for it.  0.580 ms against 0.587 without at the same five waves per SIMD, and against
-    // 0.592 for k_prep6, alternating on one box (profiles/r05_prep_prefetch_ab.log): small, because the kernel is bound by instruction issue
-    // more than by these trips.  (The same through LDS — global_load_lds_dword, no register held — measured 0.607 at five and at six waves:
+    // registers stay live across the per-record logic for it.  0.552-0.555 ms against 0.576-0.580 without at the same five waves per SIMD and
+    // 0.577-0.582 for k_prep6, alternating on two boxes (profiles/r05_prep_prefetch_ab.log): 4-5 %, because the kernel is bound by instruction
+    // issue more than by these trips.  (The same through LDS — global_load_lds_dword, no register held — measured 0.607 at five and at six waves:
     // the compiler drains every load before the first use of an ordinary one while an LDS-bound load is in flight, and the pass begins with a
     // wait for the previous pass's stores.  At six waves the four registers spill INSIDE the load phase, which serialises it: not built.)
-    int td_n[PREP_B]; u32 co0_n[PREP_B];
-    auto prefetch = [&](u32 l0n) {
-#pragma unroll
-        for (int k = 0; k < PREP_B; k++) {   // clamped to the chunk's last record: always in bounds, unused after the last pass
-            const u32 lc = min(l0n + (u32)k * 256u, lmax) & (u32)(PREP_CHUNK - 1);
-            td_n[k] = tid_c[lc]; co0_n[k] = coff_c[lc];
+    // (PREFETCH == 2, EVERY independent field one pass ahead — 20 to 24 more registers: 0.594 ms at four waves per SIMD, 0.609 at five with 12-64
+    // bytes of scratch, against 0.555: what the kernel lacks is waves to issue from, not loads in flight.  The kernels are not built.)
+    struct PhaseA { u32 fl, mq, nmk, nmv32, lsq, co0, co1; int td, ps_, ptid, ppos, ntid; };
+    auto load_a = [&](u32 l0x, int k, bool roots, bool rest, PhaseA &A) {   // clamped to the chunk's last record: always in bounds
+        const u32 lc = min(l0x + (u32)k * 256u, lmax) & (u32)(PREP_CHUNK - 1);   // the mask is a no-op that bounds lc for the compiler
+        const u32 ic = chunk + lc;
+        if (roots) { A.td = tid_c[lc]; A.co0 = coff_c[lc]; }
+        if (rest) {
+            A.fl = flag_c[lc]; A.ps_ = pos_c[lc]; A.mq = FILTER ? mapq_c[lc] : 0u; A.nmk = nmk_c[lc];
+            A.nmv32 = nm_c[lc]; A.lsq = FILTER ? lseq_c[lc] : 0u; A.co1 = coff_c[lc + 1u];
+            const u32 lp = (lc + (ic > 0u ? 0u : 1u)) & (u32)(2 * PREP_CHUNK - 1), ln = (lc + (ic < nlast ? 1u : 0u)) & (u32)(2 * PREP_CHUNK - 1);
+            A.ptid = tid_m[lp]; A.ppos = pos_m[lp]; A.ntid = tid_c[ln];
         }
     };
-    if (PREFETCH) prefetch(threadIdx.x);
+    PhaseA nx[PREP_B];
+    if (PREFETCH) {
+#pragma unroll
+        for (int k = 0; k < PREP_B; k++) load_a(threadIdx.x, k, true, PREFETCH == 2, nx[k]);
+    }
 
     for (int ps = 0; ps < passes; ps++) {
         const u32 l0 = (u32)(ps * b_active) * 256u + threadIdx.x;
@@ -409,12 +419,10 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
         int td[PREP_B], ps_[PREP_B], ptid[PREP_B], ppos[PREP_B], ntid[PREP_B];
 #pragma unroll
         for (int k = 0; k < PREP_B; k++) {
-            const u32 lc = min(l0 + (u32)k * 256u, lmax) & (u32)(PREP_CHUNK - 1);   // the mask is a no-op that bounds lc for the compiler
-            const u32 ic = chunk + lc;
-            fl[k] = flag_c[lc]; td[k] = PREFETCH ? td_n[k] : tid_c[lc]; ps_[k] = pos_c[lc]; mq[k] = FILTER ? mapq_c[lc] : 0u; nmk[k] = nmk_c[lc];
-            nmv32[k] = nm_c[lc]; lsq[k] = FILTER ? lseq_c[lc] : 0u; co0[k] = PREFETCH ? co0_n[k] : coff_c[lc]; co1[k] = coff_c[lc + 1u];
-            const u32 lp = (lc + (ic > 0u ? 0u : 1u)) & (u32)(2 * PREP_CHUNK - 1), ln = (lc + (ic < nlast ? 1u : 0u)) & (u32)(2 * PREP_CHUNK - 1);
-            ptid[k] = tid_m[lp]; ppos[k] = pos_m[lp]; ntid[k] = tid_c[ln];
+            PhaseA A = nx[k];
+            load_a(l0, k, PREFETCH == 0, PREFETCH != 2, A);
+            fl[k] = A.fl; td[k] = A.td; ps_[k] = A.ps_; mq[k] = A.mq; nmk[k] = A.nmk; nmv32[k] = A.nmv32; lsq[k] = A.lsq; co0[k] = A.co0; co1[k] = A.co1;
+            ptid[k] = A.ptid; ppos[k] = A.ppos; ntid[k] = A.ntid;
         }
         // ---- phase B: loads that depend on phase A (first three CIGAR words, contig length, mask)
         u32 cw[PREP_B][3], Lc[PREP_B], mk[PREP_B], t0[PREP_B];
@@ -427,7 +435,10 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
 #pragma unroll
             for (int c = 0; c < 3; c++) cw[k][c] = r.cigar_end ? r.cigar[min(co0[k] + (u32)c, cig_last)] : 0u;
         }
-        if (PREFETCH) prefetch(l0 + (u32)b_active * 256u);
+        if (PREFETCH) {
+#pragma unroll
+            for (int k = 0; k < PREP_B; k++) load_a(l0 + (u32)b_active * 256u, k, true, PREFETCH == 2, nx[k]);
+        }
         // ---- phase C: per-record logic
 #pragma unroll
         for (int k = 0; k < PREP_B; k++) {
@@ -727,9 +738,9 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
 // (two to six dwords of scratch): 0.585 ms against 0.607 for k_prep (COVERM_PREP_KERNEL=5: no prefetch, as it compiles, 88 registers) on one
 // box, 0.592 against 0.587 on another (profiles/r05_prep_pileup_ab.log, r05_prep_prefetch_ab.log); at eight waves (64 registers, 72-100
 // bytes of scratch) the scratch traffic costs more than the waves hide.
-COV_PREP_KERNEL(k_prep, , false)
-COV_PREP_KERNEL(k_prep6, __attribute__((amdgpu_waves_per_eu(6))), false)
-COV_PREP_KERNEL(k_prep5p, __attribute__((amdgpu_waves_per_eu(5))), true)
+COV_PREP_KERNEL(k_prep, , 0)
+COV_PREP_KERNEL(k_prep6, __attribute__((amdgpu_waves_per_eu(6))), 0)
+COV_PREP_KERNEL(k_prep5p, __attribute__((amdgpu_waves_per_eu(5))), 1)
 #undef COV_PREP_KERNEL
 
 // One wave per contig: adds the partial records of the workgroups that lay entirely inside it.

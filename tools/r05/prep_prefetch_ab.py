@@ -25,6 +25,7 @@ FIELDS = ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "
 VARIANTS = [("k_prep6: no prefetch, 6 waves", {"COVERM_PREP_KERNEL": "6"}),          # the default until this measurement; the byte comparison's base
             ("k_prep5p: register prefetch, 5 waves", {}),                              # the default after it
             ("k_prep: no prefetch, 5 waves", {"COVERM_PREP_KERNEL": "5"})]
+# (third run: also k_prep4a / k_prep5a, every independent field one pass ahead at four / five waves, COVERM_PREP_KERNEL=4 / 55 of that build — slower, removed)
 KEYS = ("COVERM_PREP_KERNEL",)
 # (first run, profiles/r05_prep_prefetch_ab.log: also the prefetch through LDS at five and six waves, COVERM_PREP_PREFETCH=2 of that build — slower, removed)
 
