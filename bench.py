@@ -596,12 +596,12 @@ def main():
                              "hbm_traffic_bytes_from_committed_profile": prof.get("traffic", {}).get(k), "pipes_from_committed_profile": prof.get("pipes", {}).get(k)}
         domk = per_kernel.get(dom, {})
         # The rubric's roofline: algorithmic bytes of the dominant kernel / its launch duration (HIP events of THIS run) against the HBM peak.
-        # Neither kernel is HBM-bound: k_pileup_fast7 keeps the depth array in LDS (LDS pipe + VALU issue), k_prep5p is bound by instruction issue;
+        # Neither kernel is HBM-bound: k_pileup_fast7 keeps the depth array in LDS (LDS pipe + VALU issue), k_prep8s is bound by instruction issue;
         # what the counters of the committed profile say about both is carried beside the figure (`kernels.*.pipes_from_committed_profile`).
-        roof = {"bound": "hbm", "kernel": {"k_pileup": "k_pileup_fast7", "k_prep": "k_prep5p"}.get(dom, dom), "achieved": domk.get("hbm_achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": {"k_pileup": "k_pileup_fast7", "k_prep": "k_prep8s"}.get(dom, dom), "achieved": domk.get("hbm_achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (domk.get("hbm_achieved_GBps") or 0.0) / HBM_PEAK_GBPS, "traffic": domk.get("hbm_traffic_bytes_from_committed_profile"),
                 "traffic_source": "committed rocprofv3 PMC profile (profiles/pmc_traffic.json, %s), not this run" % prof.get("traffic", {}).get("_source"),
-                "note": "k_prep5p (streams the record store) reaches %.3f of the HBM peak, k_pileup_fast7 (depth array in LDS, not HBM-bound) %.3f; their launch times differ by %.1f %%; "
+                "note": "k_prep8s (streams the record store) reaches %.3f of the HBM peak, k_pileup_fast7 (depth array in LDS, not HBM-bound) %.3f; their launch times differ by %.1f %%; "
                         "see kernels" % (per_kernel["k_prep"]["hbm_frac_of_8TBps"], per_kernel["k_pileup"]["hbm_frac_of_8TBps"],
                                                          100.0 * abs(kms["k_prep"] - kms["k_pileup"]) / max(kms["k_prep"], kms["k_pileup"], 1e-9))}
         roof["ingest"] = ingest_roofline()

@@ -93,7 +93,7 @@ struct cov_session {
     int stream_rows = 4;   // > 0: wave-per-tile kernels (1024-base tiles); 0: k_pileup workgroup-per-tile (COVERM_PILEUP=tile)
     bool use_fast = true;  // k_pileup_fast + k_pileup_stream on the slow-tile list (default); COVERM_PILEUP=stream: k_pileup_stream alone
     int chunk_tiles = 8;   // consecutive tiles walked by one wave (COVERM_CHUNK)
-    int prep_kernel = 0;   // 0 = k_prep5p (tid / cigar_off one pass ahead, five waves per SIMD: the default), 6 = k_prep6, 5 = k_prep (COVERM_PREP_KERNEL)
+    int prep_kernel = 0;   // 0 = by shape (k_prep8s without reader-stage filter and identity streams, else k_prep7s); COVERM_PREP_KERNEL = 8 | 7 | 6 (k_prep6) | 5 (k_prep5p) forces one
     int fast_waves = 7;        // k_pileup_fast7 (384 LDS bins, seven waves per SIMD: the default) or k_pileup_fast (512 bins, six; COVERM_FAST_WAVES=6)
     int n_cus = 256;
     uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
@@ -497,7 +497,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
     if (const char *fw = getenv("COVERM_FAST_WAVES")) { const int v = atoi(fw); s->fast_waves = v == 6 ? 6 : 7; }
-    if (const char *pk = getenv("COVERM_PREP_KERNEL")) s->prep_kernel = atoi(pk) == 6 ? 6 : (atoi(pk) == 5 ? 5 : 0);
+    if (const char *pk = getenv("COVERM_PREP_KERNEL")) { const int v = atoi(pk); s->prep_kernel = (v >= 5 && v <= 8) ? v : 0; }
     if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
     if (const char *c = getenv("COVERM_STORE_CAP_RECORDS")) { const long long v = atoll(c); if (v >= 1) s->cap_records = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
@@ -812,11 +812,13 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     s->ev_fresh = -1;
 
     HIPCHK(s->d_runs.reserve(std::max<size_t>(1, R), st));
-    // k_prep geometry: 8 passes of 512 records per workgroup for short reads; one pass when CIGARs are long, where the
+    // k_prep geometry: 4096 records per workgroup for short reads (16 passes of 256 with k_prep8s / k_prep7s, 8 of 512 with k_prep6 / k_prep5p); one pass when CIGARs are long, where the
     // work per record is large and records are few (long-read mappings), so that every CU gets workgroups
     const uint64_t ncig_all = s->adopted ? s->adopted_ncig : s->n_cigar;
     const bool long_cigars = R && ncig_all / R >= 16;
-    const int prep_passes = long_cigars ? 1 : PREP_PASSES, prep_b = long_cigars ? 1 : PREP_B;
+    const int prep_kernel = s->prep_kernel ? s->prep_kernel : ((want_id || s->cfg.filter_single) ? 7 : 8);
+    const bool prep_single = prep_kernel >= 7;     // one record per thread and pass (k_prep8s / k_prep7s): 16 passes
+    const int prep_passes = long_cigars ? 1 : (prep_single ? 2 * PREP_PASSES : PREP_PASSES), prep_b = (long_cigars || prep_single) ? 1 : PREP_B;
     const u32 prep_chunk = (u32)(256 * prep_b * prep_passes);
     const u32 prep_grid = (R + prep_chunk - 1) / prep_chunk;
     HIPCHK(s->d_part.reserve((size_t)prep_grid + 2, st));
@@ -855,7 +857,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     if (R) {
         time_begin(s, COV_K_PREP);
 #define COV_LAUNCH_PREP(ID, FI, MA)                                                                                                       \
-        hipLaunchKernelGGL((s->prep_kernel == 6 ? &k_prep6<ID, FI, MA> : s->prep_kernel == 5 ? &k_prep<ID, FI, MA> : &k_prep5p<ID, FI, MA>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f, s->d_ctg.p, \
+        hipLaunchKernelGGL((prep_kernel == 8 ? &k_prep8s<ID, FI, MA> : prep_kernel == 7 ? &k_prep7s<ID, FI, MA> : prep_kernel == 6 ? &k_prep6<ID, FI, MA> : &k_prep5p<ID, FI, MA>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f, s->d_ctg.p, \
                            s->d_glob.p, s->d_runs.p, idp, idn, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap)
         {
             const int key = (want_id ? 4 : 0) | (s->cfg.filter_single ? 2 : 0) | (mask != nullptr ? 1 : 0);

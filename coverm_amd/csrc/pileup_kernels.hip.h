@@ -320,6 +320,7 @@ struct PrepPartial {
     u64 nm, indel;
 };
 
+// (prim / pass / nons are WAVE totals — sums of ballot popcounts, so they live in scalar registers —, the others per lane)
 struct PrepAcc {
     u32 prim, pass, nons, span, first, last;
     u64 nm, indel;
@@ -328,7 +329,7 @@ struct PrepAcc {
 
 __device__ __forceinline__ void prep_flush(DevContig *ctg, int cur, PrepAcc &a) {
     if (cur >= 0) {
-        const u32 prim = wave_sum_u32(a.prim), pass = wave_sum_u32(a.pass), nons = wave_sum_u32(a.nons);
+        const u32 prim = a.prim, pass = a.pass, nons = a.nons;
         const u32 span = wave_max_u32(a.span), first = wave_min_u32(a.first), last = wave_max_u32(a.last);
         const u64 nm = wave_sum_u64(a.nm), indel = wave_sum_u64(a.indel);
         if (lane_id() == 0 && pass) {
@@ -354,7 +355,7 @@ __device__ __forceinline__ void prep_flush(DevContig *ctg, int cur, PrepAcc &a) 
 // fewer memory instructions and 6 % fewer VALU instructions, but the SIMDs are busy ISSUING — 29 % of a wave's time executing at 4.3 waves per
 // SIMD — not waiting for bytes, and the 64-bit address arithmetic of the wide loads plus the wave-wide DPP moves cost more issue slots than
 // the narrow loads they replaced.  Removed.)
-template <bool WANT_IDENTITY, bool FILTER, bool MASKED, int PREFETCH>
+template <bool WANT_IDENTITY, bool FILTER, bool MASKED, int PREFETCH, int PB>
 __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restrict__ tlen, u32 n_targets,
                                           const uint8_t *__restrict__ mask, const FilterCfg &f, DevContig *ctg,
                                           DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ identp,
@@ -365,7 +366,7 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
     bool flushed_early = false;   // this wave already sent sums for an earlier contig through atomics
     const int lane = lane_id(), w = threadIdx.x >> 6;
     // records per workgroup: the host picks one pass of one record per thread for long CIGARs (few records, each a lot
-    // of work: more, smaller workgroups), 8 passes of PREP_B records for short reads
+    // of work: more, smaller workgroups), 8 passes of PB records for short reads
     const u32 chunk_recs = 256u * (u32)b_active * (u32)passes;
     const u32 chunk = blockIdx.x * chunk_recs;
     PrepAcc acc; acc.reset();
@@ -384,14 +385,12 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
     uint2 *runs_c = runs + chunk;
 
     // PREFETCH: the two fields the dependent loads of a pass hang on (tid -> contig length, first tile, mask; cigar_off -> the CIGAR words)
-    // are loaded ONE PASS AHEAD, behind the current pass's loads, so that a pass has one load phase instead of two dependent ones; four
-    // registers stay live across the per-record logic for it.  0.552-0.555 ms against 0.576-0.580 without at the same five waves per SIMD and
-    // 0.577-0.582 for k_prep6, alternating on two boxes (profiles/r05_prep_prefetch_ab.log): 4-5 %, because the kernel is bound by instruction
-    // issue more than by these trips.  (The same through LDS — global_load_lds_dword, no register held — measured 0.607 at five and at six waves:
-    // the compiler drains every load before the first use of an ordinary one while an LDS-bound load is in flight, and the pass begins with a
-    // wait for the previous pass's stores.  At six waves the four registers spill INSIDE the load phase, which serialises it: not built.)
-    // (PREFETCH == 2, EVERY independent field one pass ahead — 20 to 24 more registers: 0.594 ms at four waves per SIMD, 0.609 at five with 12-64
-    // bytes of scratch, against 0.555: what the kernel lacks is waves to issue from, not loads in flight.  The kernels are not built.)
+    // are loaded ONE PASS AHEAD, behind the current pass's loads, so that a pass has one load phase instead of two dependent ones; two
+    // registers per record stay live across the per-record logic for it (4-5 % at equal waves per SIMD).  (The same through LDS —
+    // global_load_lds_dword, no register held — measured slower at five and at six waves: the compiler drains every load before the first
+    // use of an ordinary one while an LDS-bound load is in flight, and the pass begins with a wait for the previous pass's stores.  EVERY
+    // independent field one pass ahead, 20-24 more registers, lost at four and at five waves.  profiles/r05_prep_prefetch_ab.log.)
+    // PB: records per thread and pass, their loads issued together.
     struct PhaseA { u32 fl, mq, nmk, nmv32, lsq, co0, co1; int td, ps_, ptid, ppos, ntid; };
     auto load_a = [&](u32 l0x, int k, bool roots, bool rest, PhaseA &A) {   // clamped to the chunk's last record: always in bounds
         const u32 lc = min(l0x + (u32)k * 256u, lmax) & (u32)(PREP_CHUNK - 1);   // the mask is a no-op that bounds lc for the compiler
@@ -404,30 +403,30 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
             A.ptid = tid_m[lp]; A.ppos = pos_m[lp]; A.ntid = tid_c[ln];
         }
     };
-    PhaseA nx[PREP_B];
+    PhaseA nx[PB];
     if (PREFETCH) {
 #pragma unroll
-        for (int k = 0; k < PREP_B; k++) load_a(threadIdx.x, k, true, PREFETCH == 2, nx[k]);
+        for (int k = 0; k < PB; k++) load_a(threadIdx.x, k, true, PREFETCH == 2, nx[k]);
     }
 
     for (int ps = 0; ps < passes; ps++) {
         const u32 l0 = (u32)(ps * b_active) * 256u + threadIdx.x;
         const u32 i0 = chunk + l0;
         if (!__any(i0 < r.n)) break;
-        // ---- phase A: every independent field of PREP_B records, issued back to back (clamped, branch-free)
-        u32 fl[PREP_B], mq[PREP_B], nmk[PREP_B], nmv32[PREP_B], lsq[PREP_B], co0[PREP_B], co1[PREP_B];
-        int td[PREP_B], ps_[PREP_B], ptid[PREP_B], ppos[PREP_B], ntid[PREP_B];
+        // ---- phase A: every independent field of PB records, issued back to back (clamped, branch-free)
+        u32 fl[PB], mq[PB], nmk[PB], nmv32[PB], lsq[PB], co0[PB], co1[PB];
+        int td[PB], ps_[PB], ptid[PB], ppos[PB], ntid[PB];
 #pragma unroll
-        for (int k = 0; k < PREP_B; k++) {
+        for (int k = 0; k < PB; k++) {
             PhaseA A = nx[k];
             load_a(l0, k, PREFETCH == 0, PREFETCH != 2, A);
             fl[k] = A.fl; td[k] = A.td; ps_[k] = A.ps_; mq[k] = A.mq; nmk[k] = A.nmk; nmv32[k] = A.nmv32; lsq[k] = A.lsq; co0[k] = A.co0; co1[k] = A.co1;
             ptid[k] = A.ptid; ppos[k] = A.ppos; ntid[k] = A.ntid;
         }
         // ---- phase B: loads that depend on phase A (first three CIGAR words, contig length, mask)
-        u32 cw[PREP_B][3], Lc[PREP_B], mk[PREP_B], t0[PREP_B];
+        u32 cw[PB][3], Lc[PB], mk[PB], t0[PB];
 #pragma unroll
-        for (int k = 0; k < PREP_B; k++) {
+        for (int k = 0; k < PB; k++) {
             const bool tok = td[k] >= 0 && (u32)td[k] < n_targets;
             Lc[k] = tok ? tlen[td[k]] : 0u;
             t0[k] = tok ? ti.tile_first[td[k]] : 0u;
@@ -437,18 +436,18 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
         }
         if (PREFETCH) {
 #pragma unroll
-            for (int k = 0; k < PREP_B; k++) load_a(l0 + (u32)b_active * 256u, k, true, PREFETCH == 2, nx[k]);
+            for (int k = 0; k < PB; k++) load_a(l0 + (u32)b_active * 256u, k, true, PREFETCH == 2, nx[k]);
         }
         // ---- phase C: per-record logic
 #pragma unroll
-        for (int k = 0; k < PREP_B; k++) {
+        for (int k = 0; k < PB; k++) {
             const u32 i = i0 + (u32)k * 256u;
             const bool in = i < r.n && k < b_active;
             const u32 flag = in ? fl[k] : 0x904u;
             const int tid = in ? td[k] : -1;
             const int pos = ps_[k];
             // every record read counts towards num_detected_primary_alignments when !secondary && !supplementary
-            g_prim += (in && !(flag & 0x900u)) ? 1u : 0u;
+            g_prim += (u32)__popcll(__ballot(in && !(flag & 0x900u)));      // (wave totals: scalar registers)
             const bool tid_ok = in && tid >= 0 && (u32)tid < n_targets;
             // span of records carrying this tid + grouping / position-order checks (all records, considered or not)
             if (tid_ok) {
@@ -645,17 +644,17 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
 
             // per-contig counters: accumulate per lane while the wave stays inside one contig
             const bool cnt = considered && tid_ok;
-            g_cons += cnt ? 1u : 0u;
             const u64 m = __ballot(cnt);
+            g_cons += (u32)__popcll(m);
             if (m != 0) {
                 const int ftid = __shfl(tid, __ffsll((long long)m) - 1);
                 const bool uni = __all(!cnt || tid == ftid);
                 if (uni) {
                     if (ftid != cur) { if (cur >= 0) flushed_early = true; prep_flush(ctg, cur, acc); cur = ftid; }
+                    acc.prim += (u32)__popcll(__ballot(cnt && !supp && !sec));
+                    acc.pass += (u32)__popcll(m);
+                    acc.nons += (u32)__popcll(__ballot(cnt && !supp));
                     if (cnt) {
-                        acc.prim += (!supp && !sec) ? 1u : 0u;
-                        acc.pass += 1u;
-                        acc.nons += supp ? 0u : 1u;
                         acc.first = min(acc.first, i); acc.last = max(acc.last, i);
                         if (masked_in) { acc.nm += nmv; acc.indel += indel; acc.span = max(acc.span, span); }
                     }
@@ -683,12 +682,11 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
     {
         PrepPartial pw;
         pw.tid = flushed_early ? -2 : cur;
-        pw.prim = wave_sum_u32(acc.prim); pw.pass = wave_sum_u32(acc.pass); pw.nons = wave_sum_u32(acc.nons);
+        pw.prim = acc.prim; pw.pass = acc.pass; pw.nons = acc.nons;
         pw.span = wave_max_u32(acc.span); pw.first = wave_min_u32(acc.first); pw.last = wave_max_u32(acc.last);
         pw.nm = wave_sum_u64(acc.nm); pw.indel = wave_sum_u64(acc.indel); pw.pad = 0;
         if (lane == 0) wpart[w] = pw;
     }
-    g_prim = wave_sum_u32(g_prim); g_cons = wave_sum_u32(g_cons);
     if (lane == 0) { blk_cnt[0][w] = g_prim; blk_cnt[1][w] = g_cons; }
     __syncthreads();
     bool uniform_wg = true;
@@ -724,23 +722,30 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
     }
 }
 
-#define COV_PREP_KERNEL(NAME, ATTR, PF)                                                                                                           \
+#define COV_PREP_KERNEL(NAME, ATTR, PF, PB)                                                                                                           \
     template <bool WANT_IDENTITY, bool FILTER, bool MASKED>                                                                                      \
     __global__ __launch_bounds__(256) ATTR void NAME(Records r, const u32 *__restrict__ tlen, u32 n_targets, const uint8_t *__restrict__ mask,   \
                                                      FilterCfg f, DevContig *ctg, DevGlobal *g, uint2 *__restrict__ runs,                        \
                                                      double *__restrict__ identp, double *__restrict__ identn, PrepPartial *__restrict__ part,   \
                                                      TileIdx ti, int passes, int b_active, u32 *__restrict__ cx_list, u32 cx_list_cap) {         \
-        prep_body<WANT_IDENTITY, FILTER, MASKED, PF>(r, tlen, n_targets, mask, f, ctg, g, runs, identp, identn, part, ti, passes, b_active, cx_list, \
+        prep_body<WANT_IDENTITY, FILTER, MASKED, PF, PB>(r, tlen, n_targets, mask, f, ctg, g, runs, identp, identn, part, ti, passes, b_active, cx_list, \
                                                  cx_list_cap);                                                                                   \
     }
-// k_prep5p (the default): the roots of the dependent loads one pass ahead, as it compiles (92-96 registers: five waves per SIMD).
-// k_prep6 (COVERM_PREP_KERNEL=6; the default of round 5 before the prefetch): no prefetch, the registers capped at 80 for six waves per SIMD
-// (two to six dwords of scratch): 0.585 ms against 0.607 for k_prep (COVERM_PREP_KERNEL=5: no prefetch, as it compiles, 88 registers) on one
-// box, 0.592 against 0.587 on another (profiles/r05_prep_pileup_ab.log, r05_prep_prefetch_ab.log); at eight waves (64 registers, 72-100
-// bytes of scratch) the scratch traffic costs more than the waves hide.
-COV_PREP_KERNEL(k_prep, , 0)
-COV_PREP_KERNEL(k_prep6, __attribute__((amdgpu_waves_per_eu(6))), 0)
-COV_PREP_KERNEL(k_prep5p, __attribute__((amdgpu_waves_per_eu(5))), 1)
+// Four compilations of one body (profiles/r05_prep_prefetch_ab.log, each run alternating on one box, BASELINE config 2):
+//   k_prep8s  one record per thread and pass (16 passes), the roots one pass ahead, 64 registers = eight waves per SIMD: 0.535 ms — the
+//             default where it compiles without scratch (no reader-stage filter, no identity streams);
+//   k_prep7s  the same at seven waves (65-72 registers, no scratch in any shape): 0.541 — the default for the other shapes;
+//   k_prep6   two records per pass, no prefetch, capped at 80 registers for six waves: 0.544 (0.577-0.588 before the wave totals of the
+//             counters moved to scalar registers and freed seven vector registers: it no longer spills) — COVERM_PREP_KERNEL=6;
+//   k_prep5p  two records per pass, the roots one pass ahead, five waves (84-94 registers): 0.553 — COVERM_PREP_KERNEL=5.
+// What the kernel lacks is waves to issue from: every step up in waves per SIMD that did not cost scratch paid, every one that did lost (eight
+// waves at 16 bytes of scratch: 0.656; two records per pass with the prefetch at six waves, 12 bytes: 0.572), and more loads in flight at
+// fewer waves lost too (every independent field one pass ahead: 0.594 at four waves).  Also measured and not kept: one record per pass without
+// the prefetch (0.568 at seven waves, 0.550 at eight), with it at six waves (0.552), two records per pass as it compiles at five (0.592).
+COV_PREP_KERNEL(k_prep6, __attribute__((amdgpu_waves_per_eu(6))), 0, PREP_B)
+COV_PREP_KERNEL(k_prep5p, __attribute__((amdgpu_waves_per_eu(5))), 1, PREP_B)
+COV_PREP_KERNEL(k_prep8s, __attribute__((amdgpu_waves_per_eu(8))), 1, 1)
+COV_PREP_KERNEL(k_prep7s, __attribute__((amdgpu_waves_per_eu(7))), 1, 1)
 #undef COV_PREP_KERNEL
 
 // One wave per contig: adds the partial records of the workgroups that lay entirely inside it.

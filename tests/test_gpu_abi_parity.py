@@ -436,6 +436,30 @@ def test_fast_kernel_six_wave_variant(monkeypatch):
     _piles_between_the_bin_counts()
 
 
+@pytest.mark.parametrize("kernel", ["8", "7", "6", "5"])
+def test_prep_kernel_compilations(kernel, monkeypatch):
+    """COVERM_PREP_KERNEL: the four compilations of k_prep's body (k_prep8s / k_prep7s: one record per thread and pass, eight / seven waves
+    per SIMD; k_prep6 / k_prep5p: two records per pass) forced for every shape — flag filters, the reader-stage filter, a target mask,
+    identity sums, long CIGARs, chunks that end inside a pass — where the session would pick 8 or 7 by shape."""
+    monkeypatch.setenv("COVERM_PREP_KERNEL", kernel)
+    for name in ["7seqs.reads_for_seq1_and_seq2.bam", "2seqs.bad_read.1.with_supplementary.bam", "k141_2005182.bam", "eg2.bam"]:
+        compare(load_fixture(name), ff=(True, True, False), excl=75)
+        compare(load_fixture(name), ff=(False, True, True), excl=0)
+    compare(load_fixture("eg2.bam"), ff=(True, True, True), excl=75,
+            fp=dict(min_aligned_length_single=100, min_aligned_percent_single=0.9, min_percent_identity_single=0.95))
+    ref = synth.make_reference(40, 3_000_000, seed=11, min_len=1500, max_len=400_000)
+    b = to_bamdata(synth.make_reads(ref, 60_000, seed=12), ref.lengths, ref.names)
+    compare(b, ff=(True, True, False), excl=75, check_depth=[0, 1, 39], chunks=2)
+    compare(b, ff=(False, False, False), excl=0, fp=dict(min_percent_identity_single=0.95, min_aligned_length_single=50), chunks=3)
+    mask = (np.arange(40) % 3 != 0).astype(np.uint8)
+    compare(b, ff=(True, True, False), excl=75, mask=mask)
+    ref_lens = np.asarray([300_000, 1_200_000, 80_000, 2_000_000], dtype=np.int64)
+    compare(to_bamdata(_long_read_batch(ref_lens, 300, 5_000, seed=5), ref_lens), ff=(True, True, False), excl=75, check_depth=range(4))
+    for seed in range(0, 48, 7):
+        ref_lens, batch, rng = _fuzz_case(seed)
+        compare(to_bamdata(batch, ref_lens), ff=(True, True, False), excl=int(rng.choice([0, 75])), check_depth=range(min(3, len(ref_lens))))
+
+
 def _piles_between_the_bin_counts():
     """Contigs whose depth climbs through 384 and 512: interior tiles leave the stripped loop (candidates >= bins) at different depths in
     the two variants, and the general loop's segments cross from the LDS bins into the arena."""

@@ -1,5 +1,5 @@
 """Round 5, last A/B: k_prep with tid / cigar_off loaded ONE PASS AHEAD (in registers: k_prep5p; in its first run also through LDS by
-global_load_lds) against k_prep6, in ONE process on ONE sample (BASELINE config 2: 50 M reads, 5 000 contigs), variants alternating.
+global_load_lds), with one record per thread and pass at seven and eight waves per SIMD, against k_prep6, in ONE process on ONE sample (BASELINE config 2: 50 M reads, 5 000 contigs), variants alternating.
 
 Every variant's integer statistics, histogram and estimator floats are compared byte for byte with k_prep6's (which bench.py
 checks against the oracle at this size), and the same comparison runs once per variant with the reader-stage filter on, with a target
@@ -22,12 +22,15 @@ from coverm_amd.engine import FilterConfig, RecordBatch, Session  # noqa: E402
 from coverm_amd.host import CoverageEstimator as E  # noqa: E402
 
 FIELDS = ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar")
-VARIANTS = [("k_prep6: no prefetch, 6 waves", {"COVERM_PREP_KERNEL": "6"}),          # the default until this measurement; the byte comparison's base
-            ("k_prep5p: register prefetch, 5 waves", {}),                              # the default after it
-            ("k_prep: no prefetch, 5 waves", {"COVERM_PREP_KERNEL": "5"})]
-# (third run: also k_prep4a / k_prep5a, every independent field one pass ahead at four / five waves, COVERM_PREP_KERNEL=4 / 55 of that build — slower, removed)
+VARIANTS = [("k_prep6: 2 records/pass, no prefetch, 6 w", {"COVERM_PREP_KERNEL": "6"}),      # the default until these measurements; the byte comparison's base
+            ("k_prep5p: 2 records/pass, prefetch, 5 w", {"COVERM_PREP_KERNEL": "5"}),
+            ("k_prep7s: 1 record/pass, prefetch, 7 w", {"COVERM_PREP_KERNEL": "7"}),
+            ("k_prep8s: 1 record/pass, prefetch, 8 w", {"COVERM_PREP_KERNEL": "8"}),
+            ("default (by shape)", {})]
 KEYS = ("COVERM_PREP_KERNEL",)
-# (first run, profiles/r05_prep_prefetch_ab.log: also the prefetch through LDS at five and six waves, COVERM_PREP_PREFETCH=2 of that build — slower, removed)
+# (profiles/r05_prep_prefetch_ab.log holds the earlier runs, whose builds had more compilations — the prefetch through LDS, every independent
+# field ahead, one record per pass at six waves and without the prefetch, two records per pass with it at six waves — under other values of the
+# environment variables; all slower, removed)
 
 
 def session(env, ref, dt, n, est, filt=None, mask=None, want_id=False):
