@@ -355,7 +355,7 @@ __device__ __forceinline__ void prep_flush(DevContig *ctg, int cur, PrepAcc &a) 
 // fewer memory instructions and 6 % fewer VALU instructions, but the SIMDs are busy ISSUING — 29 % of a wave's time executing at 4.3 waves per
 // SIMD — not waiting for bytes, and the 64-bit address arithmetic of the wide loads plus the wave-wide DPP moves cost more issue slots than
 // the narrow loads they replaced.  Removed.)
-template <bool WANT_IDENTITY, bool FILTER, bool MASKED, int PREFETCH, int PB>
+template <bool WANT_IDENTITY, bool FILTER, bool MASKED, bool PREFETCH, int PB>
 __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restrict__ tlen, u32 n_targets,
                                           const uint8_t *__restrict__ mask, const FilterCfg &f, DevContig *ctg,
                                           DevGlobal *g, uint2 *__restrict__ runs, double *__restrict__ identp,
@@ -406,7 +406,7 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
     PhaseA nx[PB];
     if (PREFETCH) {
 #pragma unroll
-        for (int k = 0; k < PB; k++) load_a(threadIdx.x, k, true, PREFETCH == 2, nx[k]);
+        for (int k = 0; k < PB; k++) load_a(threadIdx.x, k, true, false, nx[k]);
     }
 
     for (int ps = 0; ps < passes; ps++) {
@@ -419,7 +419,7 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
 #pragma unroll
         for (int k = 0; k < PB; k++) {
             PhaseA A = nx[k];
-            load_a(l0, k, PREFETCH == 0, PREFETCH != 2, A);
+            load_a(l0, k, !PREFETCH, true, A);
             fl[k] = A.fl; td[k] = A.td; ps_[k] = A.ps_; mq[k] = A.mq; nmk[k] = A.nmk; nmv32[k] = A.nmv32; lsq[k] = A.lsq; co0[k] = A.co0; co1[k] = A.co1;
             ptid[k] = A.ptid; ppos[k] = A.ppos; ntid[k] = A.ntid;
         }
@@ -436,7 +436,7 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
         }
         if (PREFETCH) {
 #pragma unroll
-            for (int k = 0; k < PB; k++) load_a(l0 + (u32)b_active * 256u, k, true, PREFETCH == 2, nx[k]);
+            for (int k = 0; k < PB; k++) load_a(l0 + (u32)b_active * 256u, k, true, false, nx[k]);
         }
         // ---- phase C: per-record logic
 #pragma unroll
@@ -742,10 +742,10 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
 // waves at 16 bytes of scratch: 0.656; two records per pass with the prefetch at six waves, 12 bytes: 0.572), and more loads in flight at
 // fewer waves lost too (every independent field one pass ahead: 0.594 at four waves).  Also measured and not kept: one record per pass without
 // the prefetch (0.568 at seven waves, 0.550 at eight), with it at six waves (0.552), two records per pass as it compiles at five (0.592).
-COV_PREP_KERNEL(k_prep6, __attribute__((amdgpu_waves_per_eu(6))), 0, PREP_B)
-COV_PREP_KERNEL(k_prep5p, __attribute__((amdgpu_waves_per_eu(5))), 1, PREP_B)
-COV_PREP_KERNEL(k_prep8s, __attribute__((amdgpu_waves_per_eu(8))), 1, 1)
-COV_PREP_KERNEL(k_prep7s, __attribute__((amdgpu_waves_per_eu(7))), 1, 1)
+COV_PREP_KERNEL(k_prep6, __attribute__((amdgpu_waves_per_eu(6))), false, PREP_B)
+COV_PREP_KERNEL(k_prep5p, __attribute__((amdgpu_waves_per_eu(5))), true, PREP_B)
+COV_PREP_KERNEL(k_prep8s, __attribute__((amdgpu_waves_per_eu(8))), true, 1)
+COV_PREP_KERNEL(k_prep7s, __attribute__((amdgpu_waves_per_eu(7))), true, 1)
 #undef COV_PREP_KERNEL
 
 // One wave per contig: adds the partial records of the workgroups that lay entirely inside it.
