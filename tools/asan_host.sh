@@ -1,6 +1,7 @@
 #!/bin/bash
-# Host layer (BAM reader, estimators/drivers/printers, pair filter, gene driver) under AddressSanitizer + UBSan:
-# a host-only build of the three C++ files with stubs for the device ABI, swapped in for the CPU test run.
+# Host layer (BAM reader, estimators/drivers/printers — the device-estimate path's taker included —, pair filter, gene driver, the
+# orchestrator with its `filter` subcommand through the coverm-amd binary) under AddressSanitizer + UBSan: a host-only build of the four
+# C++ files with stubs for the device ABI, swapped in for the CPU test run (226 tests, round 5).
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
@@ -82,6 +83,14 @@ cov_status cov_ingest_end(cov_session *s, uint64_t *n_records) {
 cov_status cov_ingest_release(cov_session *) { return COV_OK; }
 cov_status cov_ingest_abort(cov_session *s) { if (s) s->active = false; return COV_OK; }
 int cov_bind_thread_to_device_node(int) { return -1; }
+cov_status cov_reserve(cov_session *, uint64_t, uint64_t) { return COV_ERR_HIP; }
+cov_status cov_ingest_copy_inflated(cov_session *, uint64_t, uint64_t, void *) { return COV_ERR_HIP; }
+cov_status cov_copy_records(cov_session *, const cov_batch *, uint64_t *, uint64_t *) { return COV_ERR_HIP; }
+cov_status cov_gather(cov_session *const *, uint32_t, uint32_t) { return COV_ERR_HIP; }
+cov_status cov_gathered(cov_session *, uint32_t, cov_contig_stats *, cov_summary *) { return COV_ERR_HIP; }
+cov_status cov_set_estimators(cov_session *, const cov_estimator *, uint32_t) { return COV_ERR_HIP; }
+cov_status cov_fetch_estimates(cov_session *, float *) { return COV_ERR_HIP; }
+uint32_t cov_store_spills(const cov_session *) { return 0; }
 cov_status cov_ingest_want_mates(cov_session *, int) { return COV_OK; }
 cov_status cov_pair_filter_apply(cov_session *, const cov_pair_filter *, uint64_t *, uint64_t *) { return COV_ERR_HIP; }
 // registration of the mapped file: accepted (the mock's feed reads the mapping like any host memory), or refused to exercise the
@@ -99,11 +108,11 @@ cov_status cov_host_unregister(cov_session *s, void *p) {
 }
 EOS
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -shared -fPIC -I$R/include \
-    $R/coverm_amd/csrc/host_bam.cpp $R/coverm_amd/csrc/host_coverage.cpp $R/coverm_amd/csrc/host_filter.cpp $T/stubs.cpp \
+    $R/coverm_amd/csrc/host_bam.cpp $R/coverm_amd/csrc/host_coverage.cpp $R/coverm_amd/csrc/host_filter.cpp $R/coverm_amd/csrc/host_cli.cpp $T/stubs.cpp \
     -o $T/libcovermhip_asan.so -lz -lpthread -ldl
 cp $R/coverm_amd/libcovermhip.so $T/real.so
 trap 'cp $T/real.so $R/coverm_amd/libcovermhip.so' EXIT
 cp $T/libcovermhip_asan.so $R/coverm_amd/libcovermhip.so
 cd $R
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 \
-    COVERM_MOCK_INGEST=1 python -m pytest tests/test_bam_reader.py tests/test_host_golden.py tests/test_genes.py tests/test_ingest_driver_mock.py -q -m "not gpu" -p no:cacheprovider -k "not exports_every_declared_symbol"
+    COVERM_MOCK_INGEST=1 python -m pytest tests/test_bam_reader.py tests/test_host_golden.py tests/test_genes.py tests/test_ingest_driver_mock.py tests/test_host_estimated.py tests/test_takers_printers.py tests/test_filter_subcommand.py -q -m "not gpu" -p no:cacheprovider -k "not exports_every_declared_symbol"
