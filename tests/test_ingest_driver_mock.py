@@ -54,23 +54,31 @@ t = (C.c_double * 8)()
 rc = L.covh_bam_gpu_ingest(p.encode(), 3, sess, hd, 1, C.byref(n), t, err, 512)
 assert rc == 0, (rc, err.value)
 assert n.value == n_expect, (n.value, n_expect)
-print("MOCK_OK", mode, n.value)
+print("MOCK_OK", mode, n.value, "io=" + str(int(t[7])))
 '''
 
 
-@pytest.mark.parametrize("io", ["mmap", "pread", "mmap_refused"])
+# what timing[7] must say afterwards: 0 staging slots, 1 mapped file registered piece by piece, 2 mapped and registered up front
+IO_MODES = {"default": ({}, 0), "pread": ({"COVERM_INGEST_IO": "pread"}, 0), "mmap": ({"COVERM_INGEST_IO": "mmap"}, 1),
+            "mmap-upfront": ({"COVERM_INGEST_IO": "mmap-upfront"}, 2),
+            "mmap_refused": ({"COVERM_INGEST_IO": "mmap", "COVERM_MOCK_NO_REGISTER": "1"}, 0),
+            "mmap-upfront_refused": ({"COVERM_INGEST_IO": "mmap-upfront", "COVERM_MOCK_NO_REGISTER": "1"}, 0)}
+
+
+@pytest.mark.parametrize("io", sorted(IO_MODES))
 @pytest.mark.parametrize("mode,piece_kb", [("synth", 0), ("synth", 64), ("synth", 200), ("tiny_blocks", 64), ("tiny_blocks", 0)])
 def test_ingest_driver_feeds_consistent_blocks(tmp_path, mode, piece_kb, io):
-    """io: the bytes come from the registered mapping of the file (default), from staging slots filled by pread, or the mapping is
-    refused by the runtime and the driver switches to staging slots by itself."""
+    """io: the bytes come from staging slots filled by pread (the default for one or two feeders), from the registered mapping of the file
+    (registered piece by piece, or the whole span up front: the default for more than two feeders), or the mapping is refused by the runtime
+    and the driver switches to staging slots by itself.  The driver reports which it used (timing[7])."""
     if not _has_mock():
         pytest.skip("needs the sanitizer build's CPU mock of cov_ingest_* (tools/asan_host.sh); the GPU suite covers the driver otherwise")
     env = dict(os.environ)
+    env.pop("COVERM_INGEST_IO", None)
     if piece_kb:
         env["COVERM_INGEST_PIECE_KB"] = str(piece_kb)
-    if io == "pread":
-        env["COVERM_INGEST_IO"] = "pread"
-    if io == "mmap_refused":
-        env["COVERM_MOCK_NO_REGISTER"] = "1"
+    extra, code = IO_MODES[io]
+    env.update(extra)
     r = subprocess.run([sys.executable, "-c", WORKER % ROOT, mode, str(tmp_path)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0 and "MOCK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "io=%d" % code in r.stdout, r.stdout[-500:]
