@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (round 3): the lane-per-block inflate's table-size and sort variants this sweeps (COVERM_INFLATE_BITS / _DIST_BITS / _SORT8) were
+# deleted in round 4 with the measurements that decided them (profiles/r03_*); today every pass runs the default.
 # Per-variant kernel times of the device ingest (rocprofv3 --kernel-trace --stats of one coverm-amd run each) over one synthetic BAM:
 # tools/inflate_kernel_times.sh <reads> "<lit,dist,sort8> ..."
 R=$GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORICAL (round 3): COVERM_NO_CRC_PROBE no longer exists; COVERM_INFLATE_ABLATE is still read by the lane-per-block kernel only.
 # k_inflate ablations (results are wrong by construction; only the kernel time matters)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (round 3): COVERM_INFLATE_BITS / _DIST_BITS / _SORT8 no longer exist (the losing variants were deleted in round 4); today
+# every pass runs the default.  The round-5 equivalents are tools/r05/call*.sh (COVERM_INFLATE_SINK, COVERM_LZ_V).
 # coverm-amd wall time over one synthetic BAM on tmpfs for several k_inflate table sizes: tools/ingest_variants.sh <reads> "<lb,db> ..." [reps]
 R=$GRAFT_REPO_ROOT
 READS=${1:-50000000}; VARS=${2:-"8,6 7,6 7,5 6,5"}; REPS=${3:-2}
