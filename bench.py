@@ -693,7 +693,7 @@ def main():
                 out["multi_device_end_to_end_functional_check"] = {"error": repr(ex)[:1000]}
                 exit_code = 3
         if world > 1 and not a.no_multi_device_e2e and not share:
-            # the product's own multi-GPU path (one process, N devices): run by rank 0 while the other ranks wait at the barrier below
+            # the product's own multi-GPU path (one process, N devices): run by rank 0 while the other ranks wait on the host (wait_for_root below)
             try:
                 threads = max(1, int(os.environ.get("COVERM_BENCH_THREADS", usable_cpus())))
                 out["multi_device_end_to_end"] = multi_device_legs(a, threads, world)
@@ -724,6 +724,10 @@ def main():
         })
         print(json.dumps(out), flush=True)
     if dist:
+        # rank 0 comes here after the product's multi-device legs; the others wait for it on the host (a key in the group's store), not
+        # inside a collective: an RCCL barrier would spin on their GPUs while coverm-amd --devices uses them
+        from coverm_amd import distributed as cdist
+        cdist.wait_for_root(dist, rank, "coverm_bench_legs_done")
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(exit_code)

@@ -162,3 +162,20 @@ def gather_tid_shards(local: SampleResult, tid_range: Tuple[int, int], dist, dev
         prim += p.num_detected_primary_alignments
     hist = np.concatenate(hists) if hists else None
     return SampleResult(got[0][0].stoit_name, merged, hist, prim)
+
+
+def wait_for_root(dist, rank: int, key: str = "coverm_root_done", minutes: float = 45.0, root: int = 0) -> bool:
+    """Ranks other than `root` wait ON THE HOST until `root` calls this: a key in the process group's store, not a collective.  A barrier
+    of the nccl (= RCCL) backend is a kernel that spins on every waiting rank's GPU — while rank 0 of `bench.py --gpus N` runs the product's
+    own multi-device legs on those very GPUs.  True when the store was used; on any failure of that path the caller's next barrier still
+    orders the ranks (the store is an optimisation of WHERE they wait, not of correctness)."""
+    import datetime
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        if rank == root:
+            store.set(key, "1")
+        else:
+            store.wait([key], datetime.timedelta(minutes=minutes))
+        return True
+    except Exception:
+        return False

@@ -116,6 +116,17 @@ def main():
         assert (rm[0].num_mapped_reads, rm[0].num_reads) == (rm2[0].num_mapped_reads, rm2[0].num_reads)
         assert sum(h - l for l, h in shards) == len(ref.lengths)
         print("DIST_OK world=%d backend=%s" % (world, backend), flush=True)
+    # ---- the host-side wait bench.py ends with (ranks > 0 must not return before rank 0 arrives, and no collective is involved)
+    import time
+    t0 = time.time()
+    if rank == 0:
+        time.sleep(1.5)
+    used_store = distributed.wait_for_root(dist, rank, "dist_worker_done", minutes=2)
+    waited = time.time() - t0
+    assert used_store, "the process group's store was not reachable"
+    assert rank == 0 or waited >= 1.0, "rank %d returned after %.2f s, before rank 0 arrived" % (rank, waited)
+    if rank == world - 1:
+        print("WAIT_OK rank=%d waited=%.2f" % (rank, waited), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -26,6 +26,7 @@ def test_two_rank_gloo_sharding():
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "DIST_OK world=2 backend=gloo" in p.stdout
+    assert "WAIT_OK rank=1" in p.stdout        # coverm_amd.distributed.wait_for_root: rank 1 waited on the host for rank 0
 
 
 import pytest
