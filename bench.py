@@ -391,6 +391,55 @@ def binary_config_legs(a, threads, ref, batch, oracle_cfg2):
     return res
 
 
+SAMPLE_WRITER = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+from coverm_amd import bam as cbam, synth
+contigs, bp, reads, seed, threads, path = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
+ref = synth.make_reference(contigs, bp, seed=1)
+b = synth.make_reads(ref, reads, seed=seed)
+cbam.write_bam(path, ref.names, ref.lengths, b, with_seq=2, level=1, threads=threads)
+print("N_RECORDS %d" % b.n_records, flush=True)
+'''
+
+
+def sample_writers(n_samples, reads, threads):
+    """How many samples to generate at once: bounded by the samples, by the CPUs (a generator is one numpy thread, then `threads` / P
+    compressor threads) and by the memory a 50 M-read sample takes while it is built (~120 bytes per read)."""
+    avail = 1 << 62
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    return max(1, min(n_samples, max(1, threads // 2), int(avail // 2 // max(1, reads * 120))))
+
+
+def write_samples(a, seeds, paths, threads):
+    """The N distinct samples of config 4 (one synthetic BAM per seed), written by up to P processes at once — at N = 8 the samples cost
+    4-5 minutes one after the other (20 s of single-threaded numpy + the BGZF writer each) and the other ranks' CPUs are idle meanwhile.
+    Same bytes as synth.make_reads + bam.write_bam in this process (the writer's output does not depend on its thread count).  Returns the
+    records written."""
+    P = sample_writers(len(seeds), a.reads, threads)
+    per = max(1, threads // P)
+    todo = list(zip(seeds, paths))
+    running, nrec = [], 0
+    while todo or running:
+        while todo and len(running) < P:
+            seed, path = todo.pop(0)
+            running.append(subprocess.Popen([sys.executable, "-c", SAMPLE_WRITER, ROOT, str(a.contigs), str(a.bp), str(a.reads), str(seed), str(per), path],
+                                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        pr = running.pop(0)
+        so, se = pr.communicate()
+        if pr.returncode != 0 or "N_RECORDS" not in so:
+            for q in running:
+                q.kill()
+            raise RuntimeError("sample writer failed: " + se[-1500:])
+        nrec += int(so.split("N_RECORDS")[1].split()[0])
+    return nrec, P
+
+
 def multi_device_legs(a, threads, world, devs=None):
     """The PRODUCT's multi-GPU path (coverm-amd --devices 0..N-1, one process, one reader + session per device; SURVEY 8e) at N > 1:
     config 4 (N BAMs x 50 M reads, one per device) and config 5 (one 200 M-read BAM cut into N tid spans, RCCL gather of the
@@ -404,16 +453,12 @@ def multi_device_legs(a, threads, world, devs=None):
         ref = synth.make_reference(a.contigs, a.bp, seed=1)
         # ---- config 4: N DISTINCT samples (seeds 10 .. 10 + N - 1), one per device: N readers pull N different files through
         # the host's memory system at once — what N devices really contend for (N names for one file would share one page-cache copy)
-        paths, nrec, nbytes = [], 0, 0
         t0 = time.time()
-        for k in range(world):
-            batch = synth.make_reads(ref, a.reads, seed=10 + k)
-            paths.append(os.path.join(tmpdir, "sample%d.bam" % k))
-            cbam.write_bam(paths[-1], ref.names, ref.lengths, batch, with_seq=2, level=1, threads=threads)
-            nrec += batch.n_records
-            nbytes += os.path.getsize(paths[-1])
-            del batch
+        paths = [os.path.join(tmpdir, "sample%d.bam" % k) for k in range(world)]
+        nrec, writers = write_samples(a, [10 + k for k in range(world)], paths, threads)
+        nbytes = sum(os.path.getsize(q) for q in paths)
         gen4 = time.time() - t0
+        res["sample_writers_at_once"] = writers
         out = os.path.join(tmpdir, "out.tsv")
         cmd1 = [BIN, "contig", "-b"] + paths + ["-m"] + METHODS + ["-t", str(threads), "-o", out]
         s1, _, _, _ = run_binary(cmd1 + ["--devices", devs.split(",")[0].split("-")[0]], 1)      # the same files, one device, one after the other
