@@ -3,6 +3,7 @@
 // (pileup_kernels.hip.h).  There is deliberately no CPU fallback: without a usable HIP device every
 // entry point fails with COV_ERR_HIP.
 #include "pileup_kernels.hip.h"
+#include "prep_lean.hip.h"
 #include "ingest_kernels.hip.h"
 
 #include <algorithm>
@@ -93,7 +94,7 @@ struct cov_session {
     int stream_rows = 4;   // > 0: wave-per-tile kernels (1024-base tiles); 0: k_pileup workgroup-per-tile (COVERM_PILEUP=tile)
     bool use_fast = true;  // k_pileup_fast + k_pileup_stream on the slow-tile list (default); COVERM_PILEUP=stream: k_pileup_stream alone
     int chunk_tiles = 8;   // consecutive tiles walked by one wave (COVERM_CHUNK)
-    int prep_kernel = 0;   // 0 = by shape (k_prep8s without reader-stage filter and identity streams, else k_prep7s); COVERM_PREP_KERNEL = 8 | 7 | 6 (k_prep6) | 5 (k_prep5p) forces one
+    int prep_kernel = 0;   // 0 = k_prep_lean (prep_lean.hip.h); COVERM_PREP_KERNEL=7 forces k_prep7s, the second implementation (tests)
     int fast_waves = 7;        // k_pileup_fast7 (384 LDS bins, seven waves per SIMD: the default) or k_pileup_fast (512 bins, six; COVERM_FAST_WAVES=6)
     int n_cus = 256;
     uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
@@ -166,6 +167,8 @@ struct cov_session {
 
     DevBuf<uint2> d_runs;
     DevBuf<PrepPartial> d_part;
+    DevBuf<u32> d_gen_list;            // steps k_prep_lean leaves to k_prep_generic
+    DevBuf<PrepArgs> d_prep_args;      // k_prep_lean's arguments in device memory (its rare branches read them there), written by k_init
     DevBuf<double> d_ident, d_identp;
     DevBuf<IdChunk> d_idch;
     int id_mode = 1;   // 1 = exact parallel identity sums, 0 = serial chain only (COVERM_IDENTITY=serial)
@@ -497,7 +500,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
     if (const char *fw = getenv("COVERM_FAST_WAVES")) { const int v = atoi(fw); s->fast_waves = v == 6 ? 6 : 7; }
-    if (const char *pk = getenv("COVERM_PREP_KERNEL")) { const int v = atoi(pk); s->prep_kernel = (v >= 5 && v <= 8) ? v : 0; }
+    if (const char *pk = getenv("COVERM_PREP_KERNEL")) s->prep_kernel = atoi(pk) == 7 ? 7 : 0;
     if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
     if (const char *c = getenv("COVERM_STORE_CAP_RECORDS")) { const long long v = atoll(c); if (v >= 1) s->cap_records = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
@@ -564,7 +567,7 @@ void cov_destroy(cov_session *s) {
     s->s_tid.release(); s->s_pos.release(); s->s_flag.release(); s->s_mapq.release(); s->s_nmk.release();
     s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
     s->s_mtid.release(); s->s_qh1.release(); s->s_qh2.release();
-    s->d_runs.release(); s->d_part.release(); s->d_ident.release(); s->d_identp.release(); s->d_idch.release();
+    s->d_runs.release(); s->d_part.release(); s->d_prep_args.release(); s->d_gen_list.release(); s->d_ident.release(); s->d_identp.release(); s->d_idch.release();
     if (s->ev_prep_done) (void)hipEventDestroy(s->ev_prep_done);
     if (s->ev_side_done) (void)hipEventDestroy(s->ev_side_done); s->d_arena.release(); s->d_chist.release(); s->d_depth.release();
     for (int k = 0; k < COV_K_COUNT; k++)
@@ -692,7 +695,14 @@ cov_status cov_ingest_abort(cov_session *s) {
 
 cov_status cov_reset(cov_session *s) {
     if (!s) return COV_ERR_INVALID_ARG;
-    if (s->ing_active) { const cov_status a = cov_ingest_abort(s); if (a != COV_OK) return a; }
+    if (s->ing_active) {
+        // an ingest that had already spilled part of its file: the abort drains the device and says "cov_reset the session" (COV_ERR_STATE) —
+        // this IS that reset, so the status is expected here and everything below still has to be cleared
+        const bool spilled = s->ing_rec_spilled != 0;
+        const cov_status a = cov_ingest_abort(s);
+        if (a != COV_OK && !(spilled && a == COV_ERR_STATE)) return a;
+        if (a != COV_OK) s->err.clear();
+    }
     s->adopted = false; s->n_records = 0; s->n_cigar = 0; s->finished = false; s->depth_all_valid = false; s->mates_valid = 0;
     s->spill.clear(); s->merged_valid = false; s->merged_hist.clear(); s->ing_rec_spilled = 0; s->spill_est.clear(); s->est_valid = false;
     return COV_OK;
@@ -812,13 +822,13 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     s->ev_fresh = -1;
 
     HIPCHK(s->d_runs.reserve(std::max<size_t>(1, R), st));
-    // k_prep geometry: 4096 records per workgroup for short reads (16 passes of 256 with k_prep8s / k_prep7s, 8 of 512 with k_prep6 / k_prep5p); one pass when CIGARs are long, where the
-    // work per record is large and records are few (long-read mappings), so that every CU gets workgroups
+    // k_prep geometry: 4096 records per workgroup for short reads (k_prep_lean: each of the four waves walks 16 steps of 64 consecutive records;
+    // k_prep7s: 16 passes of 256); one step / pass when CIGARs are long, where the work per record is large and records are few (long-read
+    // mappings), so that every CU gets workgroups
     const uint64_t ncig_all = s->adopted ? s->adopted_ncig : s->n_cigar;
     const bool long_cigars = R && ncig_all / R >= 16;
-    const int prep_kernel = s->prep_kernel ? s->prep_kernel : ((want_id || s->cfg.filter_single) ? 7 : 8);
-    const bool prep_single = prep_kernel >= 7;     // one record per thread and pass (k_prep8s / k_prep7s): 16 passes
-    const int prep_passes = long_cigars ? 1 : (prep_single ? 2 * PREP_PASSES : PREP_PASSES), prep_b = (long_cigars || prep_single) ? 1 : PREP_B;
+    const int prep_kernel = s->prep_kernel;
+    const int prep_passes = long_cigars ? 1 : 2 * PREP_PASSES, prep_b = 1;
     const u32 prep_chunk = (u32)(256 * prep_b * prep_passes);
     const u32 prep_grid = (R + prep_chunk - 1) / prep_chunk;
     HIPCHK(s->d_part.reserve((size_t)prep_grid + 2, st));
@@ -830,7 +840,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     if (want_hist) HIPCHK(s->d_arena.reserve((size_t)R + nT + 1, st));
 
     TileIdx ti{};
-    ti.tile_first = s->d_tile_first.p; ti.tcnt = s->d_tcnt.p; ti.fov = s->d_fov.p; ti.shift = s->tile_shift; ti.n_tiles = s->n_tiles; ti.ablate = s->ablate >> 8;
+    ti.tile_first = s->d_tile_first.p; ti.tcnt = s->d_tcnt.p; ti.fov = s->d_fov.p; ti.shift = s->tile_shift; ti.n_tiles = s->n_tiles;
     CxIdx cx{};
     {
         const uint64_t ncig_now = s->adopted ? s->adopted_ncig : s->n_cigar;
@@ -839,26 +849,48 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         cx.cnt = s->d_cx_cnt.p; cx.cur = s->d_cx_cur.p; cx.cscan = s->d_cx_scan.p; cx.ctop = s->d_cx_top.p;
         cx.runs = s->d_cx_runs.p; cx.runs_cap = s->d_cx_runs.cap;
     }
-    hipLaunchKernelGGL(k_init, dim3((std::max(std::max(nT, COUNTER_SLOTS * 8), s->n_tiles) + 255) / 256), dim3(256), 0, st, s->d_ctg.p,
-                       nT, s->d_glob.p, ti, cx);
-    HIPCHK(hipGetLastError());
-
+    const Records r = records_of(s);
+    const uint8_t *mask = s->have_mask ? s->d_mask.p : nullptr;
     FilterCfg f{};
     f.include_improper_pairs = s->cfg.include_improper_pairs; f.include_supplementary = s->cfg.include_supplementary;
     f.include_secondary = s->cfg.include_secondary; f.filter_single = s->cfg.filter_single;
     f.min_mapq = s->cfg.min_mapq; f.min_aligned_length = s->cfg.min_aligned_length;
     f.min_percent_identity = s->cfg.min_percent_identity; f.min_aligned_percent = s->cfg.min_aligned_percent;
-    const Records r = records_of(s);
-    const uint8_t *mask = s->have_mask ? s->d_mask.p : nullptr;
     // identity streams actually needed (NULL = skipped by k_prep and the k_id_* kernels)
     double *idp = (want_id && !(s->cfg.want & COV_WANT_IDENTITY_NONSUPP_ONLY)) ? s->d_identp.p : nullptr;
     double *idn = (want_id && !(s->cfg.want & COV_WANT_IDENTITY_PRIMARY_ONLY)) ? s->d_ident.p : nullptr;
+    HIPCHK(s->d_prep_args.reserve(1, st));
+    HIPCHK(s->d_gen_list.reserve((size_t)R / 64 + 2, st));
+    PrepArgs pa{};
+    {
+        PrepHot &ph = pa.hot;
+        ph.tid = r.tid; ph.pos = r.pos; ph.flag = r.flag; ph.nmk = r.nm_kind; ph.nm = r.nm; ph.coff = r.cigar_off; ph.cigar = r.cigar; ph.mapq = r.mapq; ph.lseq = r.l_seq;
+        ph.runs = s->d_runs.p; ph.tcnt = ti.tcnt; ph.fov = ti.fov; ph.identp = idp; ph.identn = idn;
+        ph.n = r.n; ph.cigar_end = r.cigar_end; ph.n_targets = nT; ph.shift = ti.shift; ph.steps = (u32)prep_chunk / 256u;
+        ph.gate_mask = 0x4u | (f.include_secondary ? 0u : 0x100u) | (f.include_supplementary ? 0u : 0x800u) | (f.include_improper_pairs ? 0u : 0x2u);
+        ph.p1_mask = 0x4u | (f.include_secondary ? 0u : 0x100u) | (f.include_supplementary ? 0u : 0x800u);
+        ph.min_mapq = f.min_mapq; ph.min_aligned_length = f.min_aligned_length; ph.min_percent_identity = f.min_percent_identity; ph.min_aligned_percent = f.min_aligned_percent;
+        PrepCold &pc = pa.cold;
+        pc.ctg = s->d_ctg.p; pc.g = s->d_glob.p; pc.part = s->d_part.p; pc.cx_list = cx.list; pc.mask = mask; pc.tlen = s->d_tlen.p; pc.tile_first = s->d_tile_first.p;
+        pc.cx_list_cap = cx.list_cap; pc.gen_list = s->d_gen_list.p;
+    }
+    hipLaunchKernelGGL(k_init, dim3((std::max(std::max(nT, COUNTER_SLOTS * 8), s->n_tiles) + 255) / 256), dim3(256), 0, st, s->d_ctg.p,
+                       nT, s->d_glob.p, ti, cx, s->d_prep_args.p, pa);
+    HIPCHK(hipGetLastError());
 
     if (R) {
         time_begin(s, COV_K_PREP);
+        const u32 gen_grid = std::min<u32>((u32)s->n_cus * 8u, (R / 64u + 4u) / 4u);      // waves stride over the listed steps
 #define COV_LAUNCH_PREP(ID, FI, MA)                                                                                                       \
-        hipLaunchKernelGGL((prep_kernel == 8 ? &k_prep8s<ID, FI, MA> : prep_kernel == 7 ? &k_prep7s<ID, FI, MA> : prep_kernel == 6 ? &k_prep6<ID, FI, MA> : &k_prep5p<ID, FI, MA>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f, s->d_ctg.p, \
-                           s->d_glob.p, s->d_runs.p, idp, idn, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap)
+        do {                                                                                                                              \
+            if (prep_kernel == 7)                                                                                                         \
+                hipLaunchKernelGGL((k_prep7s<ID, FI, MA>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f, s->d_ctg.p,   \
+                                   s->d_glob.p, s->d_runs.p, idp, idn, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap);      \
+            else {                                                                                                                        \
+                hipLaunchKernelGGL((k_prep_lean<ID, FI, MA>), dim3(prep_grid), dim3(256), 0, st, pa.hot, (const PrepArgs *)s->d_prep_args.p); \
+                hipLaunchKernelGGL((k_prep_generic<ID, FI, MA>), dim3(gen_grid), dim3(256), 0, st, (const PrepArgs *)s->d_prep_args.p);  \
+            }                                                                                                                             \
+        } while (0)
         {
             const int key = (want_id ? 4 : 0) | (s->cfg.filter_single ? 2 : 0) | (mask != nullptr ? 1 : 0);
             switch (key) {

@@ -63,7 +63,7 @@ struct DevGlobal {
     u32 n_cx;            // RW_BUCKET records appended to CxIdx::list
     u64 cx_total;        // (operation, tile) pairs they expand to = entries needed in CxIdx::runs
     u32 n_slow;          // tiles k_ranges left to k_pileup_stream (TILE_F_SLOW), listed in slow_list
-    u32 pad_s;
+    u32 n_gen;           // steps k_prep_lean left to k_prep_generic, listed in PrepCold::gen_list
     u64 pad2[2];
     u64 prim_slots[COUNTER_SLOTS * 8];  // sum = num_detected_primary_alignments (bam_generator.rs:114-118)
     u64 cons_slots[COUNTER_SLOTS * 8];  // sum = number of considered records
@@ -161,7 +161,6 @@ struct TileIdx {
     u32 *tcnt, *fov;
     u32 shift;               // log2(tile width)
     u32 n_tiles;
-    u32 ablate;              // experiment switches (COVERM_ABLATE >> 8); 0 in production
 };
 
 // Per-tile buckets of expanded M/=/X operations of RW_BUCKET records (k_cx_expand): cnt[t] entries at
@@ -173,12 +172,41 @@ struct CxIdx {
     uint2 *runs; u64 runs_cap;   // (start, end) in contig coordinates
 };
 
-__global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g, TileIdx ti, CxIdx cx) {
+// Arguments of k_prep_lean (prep_lean.hip.h).  PrepHot is what its loop reads every step (passed by value: scalar registers); PrepCold what
+// only rare branches read.  k_init, which runs in front of every k_prep, writes both into one block in device memory (PrepArgs): the
+// out-of-line generic step and the rare branches fetch their arguments from there instead of holding registers for them.
+struct PrepPartial;
+struct PrepCold {
+    DevContig *ctg; DevGlobal *g; PrepPartial *part; u32 *cx_list;
+    const uint8_t *mask; const u32 *tlen; const u32 *tile_first;
+    u32 *gen_list;        // first record of every step k_prep_lean leaves to k_prep_generic (capacity: one entry per 64 records)
+    u32 cx_list_cap, pad;
+};
+struct PrepHot {
+    const int32_t *tid, *pos;
+    const uint16_t *flag;
+    const uint8_t *nmk;
+    const u32 *nm, *coff, *cigar;
+    const uint8_t *mapq;
+    const u32 *lseq;
+    uint2 *runs;
+    u32 *tcnt, *fov;
+    double *identp, *identn;
+    u32 n, cigar_end, n_targets, shift, steps;
+    u32 gate_mask;        // scan-stage gate: a record passes iff ((flag ^ 2) & gate_mask) == 0  (FlagFilter::passes, lib.rs:67-78, + !unmapped, contig.rs:125)
+    u32 p1_mask;          // reader stage, filter.rs:100-102: passes_filter1 iff (flag & p1_mask) == 0
+    u32 min_mapq, min_aligned_length;
+    float min_percent_identity, min_aligned_percent;
+};
+struct PrepArgs { PrepHot hot; PrepCold cold; };
+
+__global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g, TileIdx ti, CxIdx cx, PrepArgs *pa_out, PrepArgs pa) {
     u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && pa_out != nullptr) *pa_out = pa;
     if (c < ti.n_tiles) { ti.tcnt[c] = 0u; ti.fov[c] = 0xffffffffu; cx.cnt[c] = 0u; cx.cur[c] = 0u; }
     if (c == 0) {
         g->first_error = ~0ull; g->hist_cap_total = 0; g->chist_total = 0; g->internal_error = 0;
-        g->n_cx = 0; g->cx_total = 0; g->n_slow = 0;
+        g->n_cx = 0; g->cx_total = 0; g->n_slow = 0; g->n_gen = 0;
     }
     if (c < COUNTER_SLOTS * 8) { g->prim_slots[c] = 0; g->cons_slots[c] = 0; }
     if (c < 8 * 16) g->chunk_ctr[c] = 0;
@@ -623,7 +651,7 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
                 const u32 pk = (u32)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)key, 0x138, 0xf, 0xf, false);   // wave_shr:1
                 const bool lead = tv && (lane == 0 || key != pk);
                 const u64 bm = __ballot(lead) | ~__ballot(tv);              // lanes where a run of equal keys ends
-                if (lead && !(ti.ablate & 1u)) {
+                if (lead) {
                     const u64 rest = (bm >> lane) >> 1;
                     const u32 follow = rest ? (u32)__builtin_ctzll(rest) : (u32)(63 - lane);
                     atomicAdd(&ti.tcnt[key], 1u + follow);
@@ -633,7 +661,7 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
                 const u32 te = (tv && span > 0u) ? (e - 1u) >> ti.shift : 0u;
                 const bool cross = tv && masked_in && n_runs > 0u && span > 0u && te > tl && !is_bucket;   // buckets deliver those
                 const u64 cm = __ballot(cross);
-                if (cm != 0 && !(ti.ablate & 2u)) {
+                if (cm != 0) {
                     const int fl0 = __ffsll((long long)cm) - 1;
                     const u32 tgt = key + 1u, tgt0 = __builtin_amdgcn_readlane(tgt, fl0);
                     // usual case: all of them enter the same single tile, and the lowest lane has the smallest index
@@ -731,21 +759,11 @@ __device__ __forceinline__ void prep_body(const Records &r, const u32 *__restric
         prep_body<WANT_IDENTITY, FILTER, MASKED, PF, PB>(r, tlen, n_targets, mask, f, ctg, g, runs, identp, identn, part, ti, passes, b_active, cx_list, \
                                                  cx_list_cap);                                                                                   \
     }
-// Four compilations of one body (profiles/r05_prep_prefetch_ab.log, each run alternating on one box, BASELINE config 2):
-//   k_prep8s  one record per thread and pass (16 passes), the roots one pass ahead, 64 registers = eight waves per SIMD: 0.535 ms — the
-//             default where it compiles without scratch (no reader-stage filter, no identity streams);
-//   k_prep7s  the same at seven waves (65-72 registers, no scratch in any shape): 0.541 — the default for the other shapes;
-//   k_prep6   two records per pass, no prefetch, capped at 80 registers for six waves: 0.544 (0.577-0.588 before the wave totals of the
-//             counters moved to scalar registers and freed seven vector registers: it no longer spills) — COVERM_PREP_KERNEL=6;
-//   k_prep5p  two records per pass, the roots one pass ahead, five waves (84-94 registers): 0.553 — COVERM_PREP_KERNEL=5.
-// What the kernel lacks is waves to issue from: every step up in waves per SIMD that did not cost scratch paid, every one that did lost (eight
-// waves at 16 bytes of scratch: 0.656; two records per pass with the prefetch at six waves, 12 bytes: 0.572), and more loads in flight at
-// fewer waves lost too (every independent field one pass ahead: 0.594 at four waves).  Also measured and not kept: one record per pass without
-// the prefetch (0.568 at seven waves, 0.550 at eight), with it at six waves (0.552), two records per pass as it compiles at five (0.592).
-COV_PREP_KERNEL(k_prep6, __attribute__((amdgpu_waves_per_eu(6))), false, PREP_B)
-COV_PREP_KERNEL(k_prep5p, __attribute__((amdgpu_waves_per_eu(5))), true, PREP_B)
-COV_PREP_KERNEL(k_prep8s, __attribute__((amdgpu_waves_per_eu(8))), true, 1)
-COV_PREP_KERNEL(k_prep7s, __attribute__((amdgpu_waves_per_eu(7))), true, 1)
+// ONE compilation of this body ships, as the second implementation the tests force with COVERM_PREP_KERNEL=7 (the default is k_prep_lean,
+// prep_lean.hip.h): one record per thread and pass, the roots of the dependent loads one pass ahead, seven waves per SIMD (65-72 registers, no
+// scratch in any shape).  Round 5 measured four compilations of it (k_prep8s 0.535 ms, k_prep7s 0.541, k_prep6 0.544, k_prep5p 0.553 at BASELINE
+// config 2, profiles/r05_prep_prefetch_ab.log): 2 % apart, all issue-bound on the same ~500 instructions per 64 records.
+COV_PREP_KERNEL(k_prep7s, __attribute__((amdgpu_waves_per_eu(7, 7))), true, 1)
 #undef COV_PREP_KERNEL
 
 // One wave per contig: adds the partial records of the workgroups that lay entirely inside it.

@@ -436,12 +436,15 @@ def test_fast_kernel_six_wave_variant(monkeypatch):
     _piles_between_the_bin_counts()
 
 
-@pytest.mark.parametrize("kernel", ["8", "7", "6", "5"])
+@pytest.mark.parametrize("kernel", ["lean", "7"])
 def test_prep_kernel_compilations(kernel, monkeypatch):
-    """COVERM_PREP_KERNEL: the four compilations of k_prep's body (k_prep8s / k_prep7s: one record per thread and pass, eight / seven waves
-    per SIMD; k_prep6 / k_prep5p: two records per pass) forced for every shape — flag filters, the reader-stage filter, a target mask,
-    identity sums, long CIGARs, chunks that end inside a pass — where the session would pick 8 or 7 by shape."""
-    monkeypatch.setenv("COVERM_PREP_KERNEL", kernel)
+    """The two implementations of k_prep — k_prep_lean + k_prep_generic (the default: a wave walks consecutive records, common steps in the
+    loop, the others listed for the second launch) and k_prep7s (COVERM_PREP_KERNEL=7: round 5's body, every step per lane) — over every
+    shape: flag filters, the reader-stage filter, a target mask, identity sums, long CIGARs, chunks that end inside a step."""
+    if kernel == "7":
+        monkeypatch.setenv("COVERM_PREP_KERNEL", kernel)
+    else:
+        monkeypatch.delenv("COVERM_PREP_KERNEL", raising=False)
     for name in ["7seqs.reads_for_seq1_and_seq2.bam", "2seqs.bad_read.1.with_supplementary.bam", "k141_2005182.bam", "eg2.bam"]:
         compare(load_fixture(name), ff=(True, True, False), excl=75)
         compare(load_fixture(name), ff=(False, True, True), excl=0)
