@@ -18,6 +18,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/covermhip.h"
@@ -95,7 +96,7 @@ struct cov_session {
     bool use_fast = true;  // k_pileup_fast + k_pileup_stream on the slow-tile list (default); COVERM_PILEUP=stream: k_pileup_stream alone
     int chunk_tiles = 8;   // consecutive tiles walked by one wave (COVERM_CHUNK)
     int prep_kernel = 0;   // 0 = k_prep_lean (prep_lean.hip.h); COVERM_PREP_KERNEL=7 forces k_prep7s, the second implementation (tests)
-    int fast_waves = 7;        // k_pileup_fast7 (384 LDS bins, seven waves per SIMD: the default) or k_pileup_fast (512 bins, six; COVERM_FAST_WAVES=6)
+    int fast_tables = 1;       // k_pileup_fast (one table of biased deltas: the default) or k_pileup_fast2t (two count tables; COVERM_FAST_TABLES=2)
     int n_cus = 256;
     uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
 
@@ -175,6 +176,7 @@ struct cov_session {
     hipStream_t side = nullptr; bool side_owned = false;     // k_identity overlaps k_ranges / k_pileup (created on first use, or the idle second stream of the ingest)
     hipEvent_t ev_prep_done = nullptr, ev_side_done = nullptr;
     DevBuf<u32> d_arena;
+    DevBuf<u64> d_hist_top;            // k_hist_sum / k_hist_off: bins per block of 1024 contigs
     DevBuf<u64> d_chist;
     u64 *h_chist = nullptr; u64 h_chist_cap = 0, hist_prefetched = 0, last_chist_total = 0; bool hist_compacted = false, hist_fetch_seen = false;
     DevBuf<int32_t> d_depth;
@@ -370,10 +372,10 @@ void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
 }
 
 // k_pileup_fast over every tile (it skips the ones k_ranges flagged TILE_F_SLOW)
-template <bool H, int WAVES>
+template <bool H, int TABLES>
 void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    const auto kern = WAVES == 7 ? &k_pileup_fast7<H> : &k_pileup_fast<H>;
-    const size_t smem = pileup_fast_smem_bytes(H, WAVES == 7 ? FAST_HB7 : FAST_HB);
+    const auto kern = TABLES == 1 ? &k_pileup_fast<H> : &k_pileup_fast2t<H>;
+    const size_t smem = pileup_fast_smem_bytes(H, TABLES == 1 ? FAST_HB : FAST_HB7, TABLES);
     // the dynamic-LDS limit and the occupancy are per-device facts, and span mode launches from one thread per device: cached per
     // device id, in atomics (two threads racing for the same device compute the same value)
     static std::atomic<int> occ_dev[64];
@@ -396,8 +398,8 @@ void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
 }
 template <bool H>
 void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    if (s->fast_waves == 7) launch_fast_v<H, 7>(s, a, n_tiles);
-    else launch_fast_v<H, 6>(s, a, n_tiles);
+    if (s->fast_tables == 2) launch_fast_v<H, 2>(s, a, n_tiles);
+    else launch_fast_v<H, 1>(s, a, n_tiles);
 }
 
 template <bool H, bool W>
@@ -499,7 +501,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
         stamp("device attribute");
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
-    if (const char *fw = getenv("COVERM_FAST_WAVES")) { const int v = atoi(fw); s->fast_waves = v == 6 ? 6 : 7; }
+    if (const char *ft = getenv("COVERM_FAST_TABLES")) s->fast_tables = atoi(ft) == 2 ? 2 : 1;
     if (const char *pk = getenv("COVERM_PREP_KERNEL")) s->prep_kernel = atoi(pk) == 7 ? 7 : 0;
     if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
@@ -567,7 +569,7 @@ void cov_destroy(cov_session *s) {
     s->s_tid.release(); s->s_pos.release(); s->s_flag.release(); s->s_mapq.release(); s->s_nmk.release();
     s->s_nm.release(); s->s_lseq.release(); s->s_coff.release(); s->s_cig.release();
     s->s_mtid.release(); s->s_qh1.release(); s->s_qh2.release();
-    s->d_runs.release(); s->d_part.release(); s->d_prep_args.release(); s->d_gen_list.release(); s->d_ident.release(); s->d_identp.release(); s->d_idch.release();
+    s->d_runs.release(); s->d_part.release(); s->d_prep_args.release(); s->d_gen_list.release(); s->d_hist_top.release(); s->d_ident.release(); s->d_identp.release(); s->d_idch.release();
     if (s->ev_prep_done) (void)hipEventDestroy(s->ev_prep_done);
     if (s->ev_side_done) (void)hipEventDestroy(s->ev_side_done); s->d_arena.release(); s->d_chist.release(); s->d_depth.release();
     for (int k = 0; k < COV_K_COUNT; k++)
@@ -721,18 +723,54 @@ static cov_status convert_results(cov_session *s, const DevGlobal &G, const DevC
     // errors in file order (the reference panics at the first offending record)
     uint64_t err_rec = ~0ull; int err_code = 0;
     if (G.first_error != ~0ull) { err_rec = G.first_error >> 8; err_code = (int)(G.first_error & 0xff); }
+    // The two passes below walk every contig; above 64 k contigs (assemblies: 10^5 - 10^7 of them) they run on a few threads — each chunk
+    // first leaves what the chunks behind it need from it (its largest last record, its histogram bins), then every chunk runs the
+    // serial loop from the prefix of the chunks in front of it.  (One thread until round 6: 2 M contigs cost ~50 ms per finish.)
+    const u32 n_chunks = nT >= 65536u ? std::min<u32>(8u, std::max<u32>(1u, std::thread::hardware_concurrency())) : 1u;
+    const u32 per_chunk = (nT + n_chunks - 1) / std::max<u32>(n_chunks, 1u);
+    auto chunked = [&](auto fn) {
+        if (n_chunks <= 1) { fn(0u, 0u, nT); return; }
+        std::vector<std::thread> th;
+        for (u32 k = 1; k < n_chunks; k++) th.emplace_back([&, k] { fn(k, std::min(nT, k * per_chunk), std::min(nT, (k + 1) * per_chunk)); });
+        fn(0u, 0u, std::min(nT, per_chunk));
+        for (auto &t : th) t.join();
+    };
+    const bool want_hist_bins = want_hist;
+    const u64 excl = s->cfg.contig_end_exclusion;
+    std::vector<uint64_t> ch_last(n_chunks, 0), ch_bins(n_chunks, 0), ch_unsorted(n_chunks, ~0ull);
+    std::vector<uint8_t> ch_any(n_chunks, 0);
+    if (n_chunks > 1)
+        chunked([&](u32 k, u32 lo, u32 hi) {
+            uint64_t last = 0, bins = 0; bool any = false;
+            for (u32 c = lo; c < hi; c++) {
+                const DevContig &C = ctg[c];
+                if (C.n_pass == 0) continue;
+                last = any ? std::max<uint64_t>(last, C.last_rec) : C.last_rec; any = true;
+                if (want_hist_bins) {
+                    const u64 L = s->h_tlen[c];
+                    if (2 * excl < L && (!s->have_mask || s->h_mask[c])) bins += C.max_d + 1u;
+                }
+            }
+            ch_last[k] = last; ch_bins[k] = bins; ch_any[k] = any;
+        });
     // sortedness: the considered records of successive touched contigs must not interleave
     // (contig.rs:129-132 panics when a considered record has tid < the previous considered tid)
     {
-        uint64_t prev_last = 0; bool any = false; uint64_t unsorted_at = ~0ull;
-        for (u32 c = 0; c < nT; c++) {
-            const DevContig &C = ctg[c];
-            if (C.n_pass == 0) continue;
-            if ((int64_t)c < min_ok_tid) unsorted_at = std::min<uint64_t>(unsorted_at, C.first_rec);      // tid < last_tid across a spill (contig.rs:129-132)
-            if (any && C.first_rec < prev_last) unsorted_at = std::min<uint64_t>(unsorted_at, std::max<uint64_t>(C.first_rec, 0));
-            prev_last = any ? std::max<uint64_t>(prev_last, C.last_rec) : C.last_rec;
-            any = true;
-        }
+        chunked([&](u32 k, u32 lo, u32 hi) {
+            uint64_t prev_last = 0; bool any = false; uint64_t unsorted_at = ~0ull;
+            for (u32 j = 0; j < k; j++) if (ch_any[j]) { prev_last = any ? std::max(prev_last, ch_last[j]) : ch_last[j]; any = true; }
+            for (u32 c = lo; c < hi; c++) {
+                const DevContig &C = ctg[c];
+                if (C.n_pass == 0) continue;
+                if ((int64_t)c < min_ok_tid) unsorted_at = std::min<uint64_t>(unsorted_at, C.first_rec);      // tid < last_tid across a spill (contig.rs:129-132)
+                if (any && C.first_rec < prev_last) unsorted_at = std::min<uint64_t>(unsorted_at, std::max<uint64_t>(C.first_rec, 0));
+                prev_last = any ? std::max<uint64_t>(prev_last, C.last_rec) : C.last_rec;
+                any = true;
+            }
+            ch_unsorted[k] = unsorted_at;
+        });
+        uint64_t unsorted_at = ~0ull;
+        for (u32 k = 0; k < n_chunks; k++) unsorted_at = std::min(unsorted_at, ch_unsorted[k]);
         if (unsorted_at != ~0ull && unsorted_at <= err_rec) {
             s->err = "BAM file appears to be unsorted. Input BAM files must be sorted by reference (i.e. by samtools sort)";
             return COV_ERR_UNSORTED;
@@ -749,29 +787,35 @@ static cov_status convert_results(cov_session *s, const DevGlobal &G, const DevC
         s->err = b;
         return (cov_status)err_code;
     }
-    const u64 excl = s->cfg.contig_end_exclusion;
     uint64_t hist_total = 0;
-    for (u32 c = 0; c < nT; c++) {
-        const DevContig &C = ctg[c];
-        cov_contig_stats &o = stats[c];
-        memset(&o, 0, sizeof o);
-        o.n_primary = C.n_primary; o.n_pass = C.n_pass; o.n_nonsupp = C.n_nonsupp;
-        o.sum_nm = C.sum_nm; o.sum_indel = C.sum_indel;
-        o.sum_identity_primary = C.id_primary; o.sum_identity_nonsupp = C.id_nonsupp;
-        o.win_sum_d = C.sum_d; o.win_sum_d2 = C.sum_d2; o.win_covered = C.cov_win; o.full_covered = C.cov_full;
-        o.first_record = C.first_rec; o.last_record = C.last_rec;
-        if (C.n_pass) { o.first_record += rec_base; o.last_record += rec_base; }
-        const u64 L = s->h_tlen[c];
-        const u64 win_len = 2 * excl < L ? L - 2 * excl : 0;
-        if (C.n_pass && win_len) {
-            o.win_max_d = C.max_d;
-            o.win_min_d = (C.proc_win < win_len || C.min_d == 0xffffffffu) ? 0u : C.min_d;
+    std::vector<uint64_t> ch_total(n_chunks, 0);
+    chunked([&](u32 k, u32 lo, u32 hi) {
+        uint64_t hist_run = 0;
+        for (u32 j = 0; j < k; j++) hist_run += ch_bins[j];
+        for (u32 c = lo; c < hi; c++) {
+            const DevContig &C = ctg[c];
+            cov_contig_stats &o = stats[c];
+            memset(&o, 0, sizeof o);
+            o.n_primary = C.n_primary; o.n_pass = C.n_pass; o.n_nonsupp = C.n_nonsupp;
+            o.sum_nm = C.sum_nm; o.sum_indel = C.sum_indel;
+            o.sum_identity_primary = C.id_primary; o.sum_identity_nonsupp = C.id_nonsupp;
+            o.win_sum_d = C.sum_d; o.win_sum_d2 = C.sum_d2; o.win_covered = C.cov_win; o.full_covered = C.cov_full;
+            o.first_record = C.first_rec; o.last_record = C.last_rec;
+            if (C.n_pass) { o.first_record += rec_base; o.last_record += rec_base; }
+            const u64 L = s->h_tlen[c];
+            const u64 win_len = 2 * excl < L ? L - 2 * excl : 0;
+            if (C.n_pass && win_len) {
+                o.win_max_d = C.max_d;
+                o.win_min_d = (C.proc_win < win_len || C.min_d == 0xffffffffu) ? 0u : C.min_d;
+            }
+            if (want_hist) {      // the compact histogram's layout (what k_hist_off<1> computes on the device when the bins are compacted there)
+                const bool live = C.n_pass != 0 && (!s->have_mask || s->h_mask[c]);
+                o.hist_len = (live && win_len) ? C.max_d + 1u : 0u; o.hist_off = hist_run; hist_run += o.hist_len;
+            }
         }
-        if (want_hist) {      // the compact histogram's layout (what k_hist_layout<1> computes on the device when the bins are compacted there)
-            const bool live = C.n_pass != 0 && (!s->have_mask || s->h_mask[c]);
-            o.hist_len = (live && win_len) ? C.max_d + 1u : 0u; o.hist_off = hist_total; hist_total += o.hist_len;
-        }
-    }
+        ch_total[k] = hist_run;
+    });
+    hist_total = ch_total[n_chunks - 1];
     if (summary) {
         uint64_t prim = 0, cons = 0;
         for (u32 k = 0; k < COUNTER_SLOTS * 8; k++) { prim += G.prim_slots[k]; cons += G.cons_slots[k]; }
@@ -880,15 +924,21 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
 
     if (R) {
         time_begin(s, COV_K_PREP);
-        const u32 gen_grid = std::min<u32>((u32)s->n_cus * 8u, (R / 64u + 4u) / 4u);      // waves stride over the listed steps
+        // k_prep_lean's loop takes the steps of 64 records that lie inside one contig; a sample with fewer than ~128 records per contig has few
+        // of those, and k_prep_generic then walks every step itself (no list, no partial records for k_post_prep to add)
+        const u32 n_steps = (R + 63u) / 64u;
+        const bool gen_all = prep_kernel != 7 && (uint64_t)R < (uint64_t)nT * 128u;
+        const u32 gen_grid = gen_all ? std::min<u32>((u32)s->n_cus * 64u, (n_steps + 3u) / 4u) : std::min<u32>((u32)s->n_cus * 8u, (n_steps + 3u) / 4u);      // waves stride over the steps
 #define COV_LAUNCH_PREP(ID, FI, MA)                                                                                                       \
         do {                                                                                                                              \
             if (prep_kernel == 7)                                                                                                         \
                 hipLaunchKernelGGL((k_prep7s<ID, FI, MA>), dim3(prep_grid), dim3(256), 0, st, r, s->d_tlen.p, nT, mask, f, s->d_ctg.p,   \
                                    s->d_glob.p, s->d_runs.p, idp, idn, s->d_part.p, ti, prep_passes, prep_b, cx.list, cx.list_cap);      \
+            else if (gen_all)                                                                                                             \
+                hipLaunchKernelGGL((k_prep_generic<ID, FI, MA>), dim3(gen_grid), dim3(256), 0, st, (const PrepArgs *)s->d_prep_args.p, n_steps); \
             else {                                                                                                                        \
                 hipLaunchKernelGGL((k_prep_lean<ID, FI, MA>), dim3(prep_grid), dim3(256), 0, st, pa.hot, (const PrepArgs *)s->d_prep_args.p); \
-                hipLaunchKernelGGL((k_prep_generic<ID, FI, MA>), dim3(gen_grid), dim3(256), 0, st, (const PrepArgs *)s->d_prep_args.p);  \
+                hipLaunchKernelGGL((k_prep_generic<ID, FI, MA>), dim3(gen_grid), dim3(256), 0, st, (const PrepArgs *)s->d_prep_args.p, 0u); \
             }                                                                                                                             \
         } while (0)
         {
@@ -907,7 +957,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
 #undef COV_LAUNCH_PREP
         if (nT) {   // what depends on k_prep alone, one launch: the workgroups' partial counters to their contigs (the identity kernels read them),
                     // and the long-CIGAR bucket counts per tile (waves stride over the RW_BUCKET list; nothing to do for short reads)
-            const u32 n_red = (nT + 3u) / 4u, cx_grid0 = (u32)s->n_cus * 8u;
+            const u32 n_red = gen_all ? 0u : (nT + 3u) / 4u, cx_grid0 = (u32)s->n_cus * 8u;
             hipLaunchKernelGGL(k_post_prep, dim3(n_red + cx_grid0), dim3(256), 0, st, r, s->d_tlen.p, s->d_glob.p, cx, ti, s->d_ctg.p, nT, (const PrepPartial *)s->d_part.p,
                                prep_grid, prep_chunk, n_red);
         }
@@ -958,8 +1008,10 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         HIPCHK(hipGetLastError());
         if (want_hist) {
             time_begin(s, COV_K_HIST);
-            hipLaunchKernelGGL((k_hist_layout<0>), dim3(1), dim3(1024), 0, st, s->d_ctg.p, nT, s->d_tlen.p, mask,
-                               (u64)s->cfg.contig_end_exclusion, s->d_glob.p);
+            const u32 hb = (nT + 1023u) / 1024u;
+            HIPCHK(s->d_hist_top.reserve(hb, st));
+            hipLaunchKernelGGL((k_hist_sum<0>), dim3(hb), dim3(1024), 0, st, (const DevContig *)s->d_ctg.p, nT, s->d_tlen.p, mask, (u64)s->cfg.contig_end_exclusion, s->d_hist_top.p);
+            hipLaunchKernelGGL((k_hist_off<0>), dim3(hb), dim3(1024), 0, st, s->d_ctg.p, nT, s->d_tlen.p, mask, (u64)s->cfg.contig_end_exclusion, (const u64 *)s->d_hist_top.p, s->d_glob.p);
             hipLaunchKernelGGL(k_zero_u32, dim3(2048), dim3(256), 0, st, s->d_arena.p, &s->d_glob.p->hist_cap_total);
             time_end(s, COV_K_HIST);
             HIPCHK(hipGetLastError());
@@ -976,8 +1028,10 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
             if (compacted) {
                 HIPCHK(s->d_chist.reserve((size_t)R + nT + 1, st));
                 time_begin(s, COV_K_HIST_COMPACT);
-                hipLaunchKernelGGL((k_hist_layout<1>), dim3(1), dim3(1024), 0, st, s->d_ctg.p, nT, s->d_tlen.p, mask, (u64)s->cfg.contig_end_exclusion, s->d_glob.p);
-                hipLaunchKernelGGL(k_hist_compact, dim3(nT), dim3(256), 0, st, s->d_ctg.p, nT, s->d_tlen.p, (u64)s->cfg.contig_end_exclusion, s->d_arena.p, s->d_chist.p);
+                const u32 hb = (nT + 1023u) / 1024u;
+                hipLaunchKernelGGL((k_hist_sum<1>), dim3(hb), dim3(1024), 0, st, (const DevContig *)s->d_ctg.p, nT, s->d_tlen.p, mask, (u64)s->cfg.contig_end_exclusion, s->d_hist_top.p);
+                hipLaunchKernelGGL((k_hist_off<1>), dim3(hb), dim3(1024), 0, st, s->d_ctg.p, nT, s->d_tlen.p, mask, (u64)s->cfg.contig_end_exclusion, (const u64 *)s->d_hist_top.p, s->d_glob.p);
+                hipLaunchKernelGGL(k_hist_compact, dim3((nT + 3u) / 4u), dim3(256), 0, st, s->d_ctg.p, nT, s->d_tlen.p, (u64)s->cfg.contig_end_exclusion, s->d_arena.p, s->d_chist.p);
                 time_end(s, COV_K_HIST_COMPACT);
                 HIPCHK(hipGetLastError());
                 // (only for a caller that fetched the histogram after the finish before this one: a caller that never does pays no copy)
@@ -2004,9 +2058,12 @@ static cov_status fetch_chunk_hist(cov_session *s, uint64_t *hist) {
     if (!hist) return COV_ERR_INVALID_ARG;
     if (!s->hist_compacted) {      // the finish left the bins in the arena (its estimators were evaluated on the device): lay them out and compact them now
         HIPCHK(s->d_chist.reserve(total, s->stream));
-        hipLaunchKernelGGL((k_hist_layout<1>), dim3(1), dim3(1024), 0, s->stream, s->d_ctg.p, s->n_targets, s->d_tlen.p, s->have_mask ? (const uint8_t *)s->d_mask.p : (const uint8_t *)nullptr,
-                           (u64)s->cfg.contig_end_exclusion, s->d_glob.p);
-        hipLaunchKernelGGL(k_hist_compact, dim3(s->n_targets), dim3(256), 0, s->stream, s->d_ctg.p, s->n_targets, s->d_tlen.p,
+        const uint8_t *mask = s->have_mask ? (const uint8_t *)s->d_mask.p : (const uint8_t *)nullptr;
+        const u32 hb = (s->n_targets + 1023u) / 1024u;
+        HIPCHK(s->d_hist_top.reserve(hb, s->stream));
+        hipLaunchKernelGGL((k_hist_sum<1>), dim3(hb), dim3(1024), 0, s->stream, (const DevContig *)s->d_ctg.p, s->n_targets, s->d_tlen.p, mask, (u64)s->cfg.contig_end_exclusion, s->d_hist_top.p);
+        hipLaunchKernelGGL((k_hist_off<1>), dim3(hb), dim3(1024), 0, s->stream, s->d_ctg.p, s->n_targets, s->d_tlen.p, mask, (u64)s->cfg.contig_end_exclusion, (const u64 *)s->d_hist_top.p, s->d_glob.p);
+        hipLaunchKernelGGL(k_hist_compact, dim3((s->n_targets + 3u) / 4u), dim3(256), 0, s->stream, s->d_ctg.p, s->n_targets, s->d_tlen.p,
                            (u64)s->cfg.contig_end_exclusion, s->d_arena.p, s->d_chist.p);
         HIPCHK(hipGetLastError());
         s->hist_prefetched = 0; s->hist_compacted = true;

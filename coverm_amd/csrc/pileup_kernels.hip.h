@@ -40,7 +40,7 @@ struct DevContig {
     u64 n_primary, n_pass, n_nonsupp, sum_nm, sum_indel;   // k_prep
     double id_primary, id_nonsupp;                          // k_identity
     u64 sum_d, sum_d2, cov_win, cov_full, proc_win;         // k_pileup
-    u64 hist_off;                                           // k_hist_layout
+    u64 hist_off;                                           // k_hist_off<0>
     u32 first_rec, last_rec;                                // considered records (file order)
     u32 rec_start, rec_end;                                 // span of ALL records carrying this tid
     u32 n_groups;                                           // number of maximal runs of this tid in file order
@@ -961,36 +961,21 @@ __global__ __launch_bounds__(256) void k_ranges(const u32 *__restrict__ tile_con
 }
 
 // ------------------------------------------------------------------------------------ histogram layout
-// Single workgroup: exclusive scan of per-contig bin counts -> offsets.  MODE 0: arena layout from
-// hist_cap (an upper bound on depth); MODE 1: compact layout from the realised max depth.
+// Exclusive scan of per-contig bin counts -> offsets, in contig order.  MODE 0: arena layout from hist_cap (an upper bound on depth);
+// MODE 1: compact layout from the realised max depth.  Two launches over blocks of 1024 contigs (one contig per thread): k_hist_sum leaves
+// every block's total, k_hist_off adds the totals of the blocks in front of it (every block sums them itself: nT / 1024 values at most)
+// to its own exclusive scan.  (Until round 6 ONE workgroup walked all contigs: 17 us at 5 000 contigs, 1.06 ms at 200 000, 19.3 ms at
+// 2 000 000 — profiles/r06_contig_sweep_before.log.)
 template <int MODE>
-__global__ __launch_bounds__(1024) void k_hist_layout(DevContig *ctg, u32 n_targets, const u32 *__restrict__ tlen,
-                                                      const uint8_t *__restrict__ mask, u64 excl, DevGlobal *g) {
-    // Each thread owns a run of consecutive contigs (its loads are independent and issued together), then one block scan
-    // of the per-thread totals: a single latency round instead of one per 1024 contigs.
-    constexpr u32 HL_MAX = 16;                       // contigs per thread in the register-resident fast case
-    __shared__ u64 wtot[16];
+__device__ __forceinline__ u64 hist_bins_of(const DevContig *C, u32 c, const u32 *__restrict__ tlen, const uint8_t *__restrict__ mask, u64 excl) {
+    const bool live = C->n_pass != 0 && (mask == nullptr || mask[c]);
+    if (MODE == 0) return live ? (u64)C->hist_cap + 1 : 0;
+    return (live && 2 * excl < (u64)tlen[c]) ? (u64)C->max_d + 1 : 0;
+}
+// inclusive scan over the 1024 threads of a block (16 waves); returns this thread's inclusive prefix, `total` = the block's sum
+__device__ __forceinline__ u64 block_incl_scan_u64(u64 v, u64 *wtot, u64 &total) {
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    const u32 per = (n_targets + 1023u) / 1024u;
-    const u32 c0 = threadIdx.x * per, c1 = min(n_targets, c0 + per);
-    auto value = [&](u32 c) -> u64 {
-        DevContig *C = &ctg[c];
-        const bool live = C->n_pass != 0 && (mask == nullptr || mask[c]);
-        if (MODE == 0) return live ? (u64)C->hist_cap + 1 : 0;
-        const bool has_win = 2 * excl < (u64)tlen[c];
-        const u64 v = (live && has_win) ? (u64)C->max_d + 1 : 0;
-        C->hist_len = (u32)v;
-        return v;
-    };
-    u64 vals[HL_MAX];
-    u64 mine = 0;
-    if (per <= HL_MAX) {
-#pragma unroll
-        for (u32 k = 0; k < HL_MAX; k++) { vals[k] = (k < per && c0 + k < c1) ? value(c0 + k) : 0; mine += vals[k]; }
-    } else {
-        for (u32 c = c0; c < c1; c++) mine += value(c);
-    }
-    u64 inc = mine;
+    u64 inc = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const u64 t = __shfl_up(inc, o);
@@ -998,25 +983,37 @@ __global__ __launch_bounds__(1024) void k_hist_layout(DevContig *ctg, u32 n_targ
     }
     if (lane == 63) wtot[w] = inc;
     __syncthreads();
-    u64 wbase = 0, total = 0;
+    u64 wbase = 0; total = 0;
     for (int k = 0; k < 16; k++) { const u64 x = wtot[k]; if (k < w) wbase += x; total += x; }
-    u64 run = wbase + inc - mine;                     // exclusive prefix of this thread's first contig
-    if (per <= HL_MAX) {
-#pragma unroll
-        for (u32 k = 0; k < HL_MAX; k++)
-            if (k < per && c0 + k < c1) {
-                if (MODE == 0) ctg[c0 + k].hist_off = run; else ctg[c0 + k].chist_off = run;
-                run += vals[k];
-            }
-    } else {
-        for (u32 c = c0; c < c1; c++) {
-            const u64 v = MODE == 0 ? ((ctg[c].n_pass != 0 && (mask == nullptr || mask[c])) ? (u64)ctg[c].hist_cap + 1 : 0) : (u64)ctg[c].hist_len;
-            if (MODE == 0) ctg[c].hist_off = run; else ctg[c].chist_off = run;
-            run += v;
-        }
+    __syncthreads();
+    return wbase + inc;
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_hist_sum(const DevContig *__restrict__ ctg, u32 n_targets, const u32 *__restrict__ tlen,
+                                                   const uint8_t *__restrict__ mask, u64 excl, u64 *__restrict__ top) {
+    __shared__ u64 wtot[16];
+    const u32 c = blockIdx.x * 1024u + threadIdx.x;
+    u64 total;
+    (void)block_incl_scan_u64(c < n_targets ? hist_bins_of<MODE>(&ctg[c], c, tlen, mask, excl) : 0, wtot, total);
+    if (threadIdx.x == 0) top[blockIdx.x] = total;
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_hist_off(DevContig *ctg, u32 n_targets, const u32 *__restrict__ tlen, const uint8_t *__restrict__ mask,
+                                                   u64 excl, const u64 *__restrict__ top, DevGlobal *g) {
+    __shared__ u64 wtot[16];
+    u64 mine = 0, base;
+    for (u32 b = threadIdx.x; b < blockIdx.x; b += 1024u) mine += top[b];
+    (void)block_incl_scan_u64(mine, wtot, base);          // base = bins of all contigs in front of this block
+    const u32 c = blockIdx.x * 1024u + threadIdx.x;
+    const u64 v = c < n_targets ? hist_bins_of<MODE>(&ctg[c], c, tlen, mask, excl) : 0;
+    u64 total;
+    const u64 inc = block_incl_scan_u64(v, wtot, total);
+    if (c < n_targets) {
+        if (MODE == 0) ctg[c].hist_off = base + inc - v;
+        else { ctg[c].chist_off = base + inc - v; ctg[c].hist_len = (u32)v; }
     }
-    if (threadIdx.x == 0) {
-        if (MODE == 0) g->hist_cap_total = total; else g->chist_total = total;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        if (MODE == 0) g->hist_cap_total = base + total; else g->chist_total = base + total;
     }
 }
 
@@ -1030,12 +1027,13 @@ __global__ void k_zero_u32(u32 *__restrict__ p, const u64 *__restrict__ n_ptr) {
 __global__ __launch_bounds__(256) void k_hist_compact(const DevContig *__restrict__ ctg, u32 n_targets,
                                                       const u32 *__restrict__ tlen, u64 excl,
                                                       const u32 *__restrict__ arena, u64 *__restrict__ out) {
-    const u32 c = blockIdx.x;
+    const u32 c = blockIdx.x * 4u + (threadIdx.x >> 6);      // one wave per contig (a workgroup per contig until round 6: 2 M workgroups for an assembly)
+    if (c >= n_targets) return;
     const DevContig *C = &ctg[c];
     const u32 n = C->hist_len;
     if (n == 0) return;
     const u64 win_len = (u64)tlen[c] - 2 * excl;
-    for (u32 d = threadIdx.x; d < n; d += blockDim.x) {
+    for (u32 d = threadIdx.x & 63u; d < n; d += 64u) {
         u64 v = arena[C->hist_off + d];
         if (d == 0) v += win_len - C->proc_win;
         out[C->chist_off + d] = v;
@@ -1864,20 +1862,25 @@ constexpr size_t pileup_stream_smem_bytes() { return (size_t)4 * ((size_t)STREAM
 //     issues in 4.2 cycles per wave where the plain two-operand forms it replaces take 2.4 (profiles/r03_valu_rate.json), so two values per
 //     instruction buy nothing here, and the permuted table layout costs two more address operations per event.  profiles/r04_pileup_packed.log.)
 constexpr int FAST_TW = 1024, FAST_HB = 512;
-constexpr int FAST_HB7 = 384;   // k_pileup_fast7: seven workgroups per CU (22 KiB of LDS each, 72 registers)
-constexpr size_t pileup_fast_smem_bytes(bool hist, int hb = FAST_HB) { return (size_t)4 * ((size_t)FAST_TW * 4 + (hist ? (size_t)hb * 4 : 0)); }
+constexpr int FAST_HB7 = 384;   // k_pileup_fast2t: seven workgroups per CU (22 KiB of LDS each, 72 registers)
+constexpr size_t pileup_fast_smem_bytes(bool hist, int hb = FAST_HB, int tables = 2) { return (size_t)4 * ((size_t)FAST_TW * 2 * tables + (hist ? (size_t)hb * 4 : 0)); }
 
 typedef short v2i16 __attribute__((ext_vector_type(2)));
 
-template <bool WANT_HIST, int HB>
+// TABLES = 2: the two count tables described above (rounds 3-5).  TABLES = 1 (round 6, the default): ONE table of 16-bit DELTAS, every
+// field biased by 0x8000 — a start adds 1 to its field, an end subtracts 1 (ds_add_u32 / ds_sub_u32 of 1 or 0x10000: a biased field never
+// reaches 0 or 0xffff with fewer than 32768 candidates, so nothing carries into or borrows from the neighbouring field) —: half the bytes
+// to preset and to read back per tile (two ds_write_b128 + two ds_read_b128 instead of four each), an xor with 0x80008000 instead of the
+// packed subtraction of the two tables, the same events.
+template <bool WANT_HIST, int HB, int TABLES>
 __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tiles, u32 chunk_tiles) {
     constexpr int TW = FAST_TW, HBW = HB;
-    constexpr size_t WB = (size_t)TW * 4 + (WANT_HIST ? (size_t)HBW * 4 : 0);
+    constexpr size_t WB = (size_t)TW * 2 * TABLES + (WANT_HIST ? (size_t)HBW * 4 : 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     u32 *S = reinterpret_cast<u32 *>(smem + (size_t)w * WB);   // 512 dwords = 1024 u16
-    u32 *E = S + TW / 2;
-    u32 *lhist = E + TW / 2;
+    u32 *E = TABLES == 2 ? S + TW / 2 : S;
+    u32 *lhist = S + (TW / 2) * TABLES;
     uint4 *S4 = reinterpret_cast<uint4 *>(S), *E4 = reinterpret_cast<uint4 *>(E);
     const u32 wave_id = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (u32)w)), n_waves = gridDim.x * 4u;
     if (WANT_HIST) {
@@ -1974,15 +1977,20 @@ __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tile
                 if (WANT_HIST) { hoff = a.ctg[c].hist_off; hcap = a.ctg[c].hist_cap; }
             }
             // ---- zero, scatter, read back: three LDS phases of one wave, served in order
-            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-            S4[2 * lane] = z4; S4[2 * lane + 1] = z4; E4[2 * lane] = z4; E4[2 * lane + 1] = z4;
+            const u32 zb = TABLES == 2 ? 0u : 0x80008000u;
+            const uint4 z4 = make_uint4(zb, zb, zb, zb);
+            S4[2 * lane] = z4; S4[2 * lane + 1] = z4;
+            if (TABLES == 2) { E4[2 * lane] = z4; E4[2 * lane + 1] = z4; }
             asm volatile("" ::: "memory");
             const u32 hi = lo + TW;
             auto add_run = [&](u32 s, u32 e) {
                 if (s < hi && e > lo) {
                     const u32 s0 = s > lo ? s - lo : 0u;
                     atomicAdd(&S[s0 >> 1], 1u << ((s0 & 1u) << 4));
-                    if (e < hi) { const u32 e0 = e - lo; atomicAdd(&E[e0 >> 1], 1u << ((e0 & 1u) << 4)); }
+                    if (e < hi) {
+                        const u32 e0 = e - lo;
+                        if (TABLES == 2) atomicAdd(&E[e0 >> 1], 1u << ((e0 & 1u) << 4)); else atomicSub(&E[e0 >> 1], 1u << ((e0 & 1u) << 4));
+                    }
                 }
             };
             auto apply = [&](const uint2 rw, u32 i) {
@@ -2014,7 +2022,8 @@ __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tile
             }
             for (u32 j = (u32)lane; j < cxn; j += 64) { const uint2 q = a.cx_runs[(u64)cxo + j]; add_run(q.x, q.y); }   // long reads
             asm volatile("" ::: "memory");
-            sv0 = S4[2 * lane]; sv1 = S4[2 * lane + 1]; ev0 = E4[2 * lane]; ev1 = E4[2 * lane + 1];
+            sv0 = S4[2 * lane]; sv1 = S4[2 * lane + 1];
+            if (TABLES == 2) { ev0 = E4[2 * lane]; ev1 = E4[2 * lane + 1]; }
         }
         // ---- next tile's run words: in flight during this tile's statistics
         uint2 nrw0 = make_uint2(0u, 0u), nrw1 = make_uint2(0u, 0u);
@@ -2023,10 +2032,11 @@ __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tile
         if (live) {
             // packed i16 deltas of the 16 positions this lane owns
             const u32 sw[8] = {sv0.x, sv0.y, sv0.z, sv0.w, sv1.x, sv1.y, sv1.z, sv1.w};
-            const u32 ew[8] = {ev0.x, ev0.y, ev0.z, ev0.w, ev1.x, ev1.y, ev1.z, ev1.w};
+            u32 ew[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            if (TABLES == 2) { ew[0] = ev0.x; ew[1] = ev0.y; ew[2] = ev0.z; ew[3] = ev0.w; ew[4] = ev1.x; ew[5] = ev1.y; ew[6] = ev1.z; ew[7] = ev1.w; }
             v2i16 dl[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) dl[k] = __builtin_bit_cast(v2i16, sw[k]) - __builtin_bit_cast(v2i16, ew[k]);
+            for (int k = 0; k < 8; k++) dl[k] = TABLES == 2 ? __builtin_bit_cast(v2i16, sw[k]) - __builtin_bit_cast(v2i16, ew[k]) : __builtin_bit_cast(v2i16, sw[k] ^ 0x80008000u);
             int net = 0;
             const v2i16 one2 = {1, 1};
 #pragma unroll
@@ -2102,16 +2112,17 @@ __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tile
     }
 }
 
+// The default (round 6): ONE table of biased deltas, 512 LDS bins (16 KiB of LDS per workgroup), seven waves per SIMD: 0.475 ms at BASELINE
+// config 2 against 0.531 for the two-table kernel below, alternating runs on one box (profiles/r06_lean_onetable_ab_5k.log; 384 bins 0.481,
+// eight waves with 28 bytes of scratch 0.521).
 template <bool WANT_HIST>
-__global__ __launch_bounds__(256) void k_pileup_fast(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
-    pileup_fast_body<WANT_HIST, FAST_HB>(a, n_tiles, chunk_tiles);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_pileup_fast(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
+    pileup_fast_body<WANT_HIST, FAST_HB, 1>(a, n_tiles, chunk_tiles);
 }
-// The same with 384 LDS bins (22 KiB of LDS per workgroup: seven fit a CU) and the registers capped at 72 for seven waves per SIMD (four
-// loop-invariant dwords go to scratch).  The default: 0.535 ms against 0.590 at BASELINE config 2, alternating runs on one box
-// (profiles/r04_pileup_seven_waves.log); COVERM_FAST_WAVES=6 selects k_pileup_fast, and tests/test_gpu_abi_parity.py runs both.
+// The second implementation (COVERM_FAST_TABLES=2; rounds 4-5's default): two u16 count tables, 384 bins, 72 registers = seven waves per SIMD.
 template <bool WANT_HIST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k_pileup_fast7(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
-    pileup_fast_body<WANT_HIST, FAST_HB7>(a, n_tiles, chunk_tiles);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k_pileup_fast2t(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
+    pileup_fast_body<WANT_HIST, FAST_HB7, 2>(a, n_tiles, chunk_tiles);
 }
 
 // (The same step once more — 256 bins, 64 registers with 12 dwords of scratch, eight waves per SIMD — was measured in round 5: 0.816 ms
@@ -2172,7 +2183,7 @@ __global__ __launch_bounds__(256) void k_estimate(const DevContig *__restrict__ 
     const u64 win_sum_d = has_win ? C->sum_d : 0, win_sum_d2 = has_win ? C->sum_d2 : 0, win_covered = has_win ? C->cov_win : 0;
     const u64 win_min_d = has_win ? ((C->proc_win < win_len || C->min_d == 0xffffffffu) ? 0u : C->min_d) : 0xffffffffu;
     const u64 full_len = L, full_covered = C->cov_full, n_reads = C->n_primary, mismatches = C->sum_nm - C->sum_indel;
-    const u32 nh = has_win ? C->max_d + 1u : 0u;          // = the compact histogram's length (k_hist_layout<1>; no target mask here)
+    const u32 nh = has_win ? C->max_d + 1u : 0u;          // = the compact histogram's length (k_hist_off<1>; no target mask here)
     const u64 bin0_extra = win_len - C->proc_win;       // window positions of tiles no record touched: depth 0 (k_hist_compact adds the same)
     const u32 *bins = arena + C->hist_off;
     for (u32 k = 0; k < P.n; k++) {

@@ -235,21 +235,43 @@ __device__ __forceinline__ void prep_step_generic(const PrepArgs *__restrict__ p
         if (masked_in && cs.n_runs > 0u && cs.span > 0u && te > tl && !is_bucket)           // buckets deliver those
             for (u32 t2 = tl + 1u; t2 <= te; t2++) atomicMin(&h.fov[t0v + t2], i);
     }
-    // ---- per-contig counters
+    // ---- per-contig counters: one set of atomics per RUN of records of one contig, not per record (a hot accumulator line takes ~12 ns per
+    // atomic, and a step at a contig border — or every step of an assembly with more contigs than records per step — has a few runs of
+    // many records each).  Wave-uniform loop over the distinct contigs of the step's considered records; counts are popcounts of ballots,
+    // the three sums one DPP prefix sum each.
     const bool cnt = considered && tid_ok;
     const u64 cm = __ballot(cnt);
-    if (cnt) {
-        DevContig *C = &cd.ctg[tid];
-        if (!supp && !sec) atomicAdd(&C->n_primary, 1ull);
-        atomicAdd(&C->n_pass, 1ull);
-        if (!supp) atomicAdd(&C->n_nonsupp, 1ull);
-        if (masked_in) {
-            if (nmv) atomicAdd(&C->sum_nm, nmv);
-            if (cs.indel) atomicAdd(&C->sum_indel, cs.indel);
-            atomicMax(&C->max_span, cs.span);
+    {
+        const u64 pm = __ballot(cnt && !(flag & 0x900u)), nsm = __ballot(cnt && !supp);
+        const u32 nm_c = masked_in ? (u32)nmv : 0u, in_c = masked_in ? (u32)cs.indel : 0u, sp_c = masked_in ? cs.span : 0u;
+        const bool wide = __any(masked_in && (nmv32 >= (1u << 25) || cs.indel >= (1ull << 25)));      // 64 such values could pass 2^31: 64-bit sums then
+        for (u64 todo = cm; todo != 0ull;) {
+            const int fl = __builtin_ctzll(todo);
+            const int t = __builtin_amdgcn_readlane(tid, fl);
+            const bool mine = cnt && tid == t;
+            const u64 m = __ballot(mine);
+            todo &= ~m;
+            u64 s_nm, s_in;
+            if (!wide) {
+                s_nm = (u32)__builtin_amdgcn_readlane(wave_incl_scan((int)(mine ? nm_c : 0u)), 63);
+                s_in = (u32)__builtin_amdgcn_readlane(wave_incl_scan((int)(mine ? in_c : 0u)), 63);
+            } else {
+                s_nm = wave_sum_u64(mine && masked_in ? nmv : 0ull); s_in = wave_sum_u64(mine && masked_in ? cs.indel : 0ull);
+            }
+            const u32 s_sp = wave_max_u32(mine ? sp_c : 0u);
+            if (lane == fl) {
+                DevContig *C = &cd.ctg[t];
+                const u32 np = (u32)__popcll(m & pm), nn = (u32)__popcll(m & nsm);
+                if (np) atomicAdd(&C->n_primary, (u64)np);
+                atomicAdd(&C->n_pass, (u64)__popcll(m));
+                if (nn) atomicAdd(&C->n_nonsupp, (u64)nn);
+                if (s_nm) atomicAdd(&C->sum_nm, s_nm);
+                if (s_in) atomicAdd(&C->sum_indel, s_in);
+                if (s_sp) atomicMax(&C->max_span, s_sp);
+                atomicMin(&C->first_rec, i0 + (u32)__builtin_ctzll(m));
+                atomicMax(&C->last_rec, i0 + 63u - (u32)__builtin_clzll(m));
+            }
         }
-        atomicMin(&C->first_rec, i);
-        atomicMax(&C->last_rec, i);
     }
     if (lane == 0) {
         const u32 slot = ((i0 >> 6) % COUNTER_SLOTS) * 8u;
@@ -502,13 +524,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     prep_lean_body<WANT_IDENTITY, FILTER, MASKED>(h, pa);
 }
 
-// The steps k_prep_lean listed: waves stride over the list, a whole wave per step.
+// The steps k_prep_lean listed: waves stride over the list, a whole wave per step.  all_steps != 0: every step of the store, no list (the
+// host launches this kernel alone when the sample has so many contigs that few steps would be common ones).
 template <bool WANT_IDENTITY, bool FILTER, bool MASKED>
-__global__ __launch_bounds__(256) void k_prep_generic(const PrepArgs *__restrict__ pa) {
-    const u32 n = pa->cold.g->n_gen;
+__global__ __launch_bounds__(256) void k_prep_generic(const PrepArgs *__restrict__ pa, u32 all_steps) {
+    const u32 n = all_steps ? all_steps : pa->cold.g->n_gen;
     const u32 *__restrict__ list = pa->cold.gen_list;
     for (u32 j = blockIdx.x * 4u + (threadIdx.x >> 6); j < n; j += gridDim.x * 4u)
-        prep_step_generic<WANT_IDENTITY, FILTER, MASKED>(pa, (u32)__builtin_amdgcn_readfirstlane((int)list[j]));
+        prep_step_generic<WANT_IDENTITY, FILTER, MASKED>(pa, all_steps ? j * 64u : (u32)__builtin_amdgcn_readfirstlane((int)list[j]));
 }
 
 }  // namespace covk

@@ -420,10 +420,11 @@ def test_stream_kernel_all_tiles(monkeypatch):
                 check_depth=range(min(3, len(ref_lens))))
 
 
-def test_fast_kernel_six_wave_variant(monkeypatch):
-    """COVERM_FAST_WAVES=6: k_pileup_fast (512 LDS histogram bins, six waves per SIMD) instead of the default k_pileup_fast7 (384 bins,
-    seven) — the same body, so the same inputs as the other kernels' tests, plus piles whose depths lie between the two bin counts."""
-    monkeypatch.setenv("COVERM_FAST_WAVES", "6")
+def test_fast_kernel_two_table_variant(monkeypatch):
+    """COVERM_FAST_TABLES=2: k_pileup_fast2t (two u16 count tables, 384 LDS histogram bins) instead of the default k_pileup_fast (one table
+    of biased deltas, 512 bins) — the same body, so the same inputs as the other kernels' tests, plus piles whose depths lie between the
+    two bin counts."""
+    monkeypatch.setenv("COVERM_FAST_TABLES", "2")
     for name in ["7seqs.reads_for_seq1_and_seq2.bam", "k141_2005182.bam", "eg2.bam"]:
         compare(load_fixture(name), ff=(True, True, False), excl=75)
     ref = synth.make_reference(40, 3_000_000, seed=11, min_len=1500, max_len=400_000)
