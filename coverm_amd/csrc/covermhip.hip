@@ -96,6 +96,7 @@ struct cov_session {
     bool use_fast = true;  // k_pileup_fast + k_pileup_stream on the slow-tile list (default); COVERM_PILEUP=stream: k_pileup_stream alone
     int chunk_tiles = 8;   // consecutive tiles walked by one wave (COVERM_CHUNK)
     int prep_kernel = 0;   // 0 = k_prep_lean (prep_lean.hip.h); COVERM_PREP_KERNEL=7 forces k_prep7s, the second implementation (tests)
+    int est_lanes = -1;        // k_estimate_lanes (a lane per contig) from 65 536 contigs on; COVERM_EST_LANES=1 | 0 forces it on / off (tests)
     int fast_tables = 1;       // k_pileup_fast (one table of biased deltas: the default) or k_pileup_fast2t (two count tables; COVERM_FAST_TABLES=2)
     int n_cus = 256;
     uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
@@ -374,8 +375,8 @@ void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
 // k_pileup_fast over every tile (it skips the ones k_ranges flagged TILE_F_SLOW)
 template <bool H, int TABLES>
 void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    const auto kern = TABLES == 1 ? &k_pileup_fast<H> : &k_pileup_fast2t<H>;
-    const size_t smem = pileup_fast_smem_bytes(H, TABLES == 1 ? FAST_HB : FAST_HB7, TABLES);
+    const auto kern = TABLES == 1 ? &k_pileup_fast<H> : TABLES == 4 ? &k_pileup_wide<H> : &k_pileup_fast2t<H>;
+    const size_t smem = TABLES == 4 ? pileup_wide_smem_bytes(H, FAST_HB7) : pileup_fast_smem_bytes(H, TABLES == 1 ? FAST_HB : FAST_HB7, TABLES);
     // the dynamic-LDS limit and the occupancy are per-device facts, and span mode launches from one thread per device: cached per
     // device id, in atomics (two threads racing for the same device compute the same value)
     static std::atomic<int> occ_dev[64];
@@ -399,6 +400,7 @@ void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
 template <bool H>
 void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
     if (s->fast_tables == 2) launch_fast_v<H, 2>(s, a, n_tiles);
+    else if (s->fast_tables == 4) launch_fast_v<H, 4>(s, a, n_tiles);
     else launch_fast_v<H, 1>(s, a, n_tiles);
 }
 
@@ -501,7 +503,8 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
         stamp("device attribute");
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
-    if (const char *ft = getenv("COVERM_FAST_TABLES")) s->fast_tables = atoi(ft) == 2 ? 2 : 1;
+    if (const char *el = getenv("COVERM_EST_LANES")) s->est_lanes = atoi(el) ? 1 : 0;
+    if (const char *ft = getenv("COVERM_FAST_TABLES")) s->fast_tables = atoi(ft) == 2 ? 2 : atoi(ft) == 4 ? 4 : 1;
     if (const char *pk = getenv("COVERM_PREP_KERNEL")) s->prep_kernel = atoi(pk) == 7 ? 7 : 0;
     if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
@@ -1065,8 +1068,12 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     if (want_id && R && nT) { HIPCHK(hipStreamWaitEvent(st, s->ev_side_done, 0)); s->ev_fresh = -1; }      // (the wait is not the next group's time)
     if (nf) {      // CoverageEstimator::calculate_coverage of every contig (k_init left n_pass = 0 everywhere when nothing ran: rows of zeros)
         time_begin(s, COV_K_ESTIMATE);
-        hipLaunchKernelGGL(k_estimate, dim3((nT + 3) / 4), dim3(256), 0, st, (const DevContig *)s->d_ctg.p, nT, (const u32 *)s->d_tlen.p, (u64)s->cfg.contig_end_exclusion,
-                           (const u32 *)s->d_arena.p, s->est, reinterpret_cast<float *>(s->d_res.p + block));
+        if (s->est_lanes < 0 ? nT >= 65536u : s->est_lanes == 1)      // an assembly: a lane per contig (pileup_kernels.hip.h, estimate_body)
+            hipLaunchKernelGGL(k_estimate_lanes, dim3((nT + 255) / 256), dim3(256), 0, st, (const DevContig *)s->d_ctg.p, nT, (const u32 *)s->d_tlen.p, (u64)s->cfg.contig_end_exclusion,
+                               (const u32 *)s->d_arena.p, s->est, reinterpret_cast<float *>(s->d_res.p + block));
+        else
+            hipLaunchKernelGGL(k_estimate, dim3((nT + 3) / 4), dim3(256), 0, st, (const DevContig *)s->d_ctg.p, nT, (const u32 *)s->d_tlen.p, (u64)s->cfg.contig_end_exclusion,
+                               (const u32 *)s->d_arena.p, s->est, reinterpret_cast<float *>(s->d_res.p + block));
         time_end(s, COV_K_ESTIMATE);
         HIPCHK(hipGetLastError());
     }

@@ -2112,6 +2112,247 @@ __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tile
     }
 }
 
+// The same kernel on a WIDE table (round 6): one i32 per position holding 4 x the delta — a start adds 4, an end subtracts 4 —, 4 KiB per wave
+// (+ a sink slot) instead of 2 KiB.  What it buys is instructions: an event's address is base + 4 x position and its value a constant (no
+// half-word shift, no field select), the ends of a run are clamped instead of tested (see add_run), the running depth IS the byte offset of
+// its histogram bin, the deltas need no unpacking.  What it costs: four ds_write_b128 + four ds_read_b128 per tile instead of two each, and
+// 384 bins instead of 512 to stay at seven workgroups per CU.
+constexpr size_t pileup_wide_wave_bytes(bool hist, int hb) { return (size_t)FAST_TW * 4 + 16 + (hist ? (size_t)hb * 4 : 0); }
+constexpr size_t pileup_wide_smem_bytes(bool hist, int hb) { return 4 * pileup_wide_wave_bytes(hist, hb); }
+template <bool WANT_HIST, int HB>
+__device__ __forceinline__ void pileup_wide_body(const PileupArgs &a, u32 n_tiles, u32 chunk_tiles) {
+    constexpr int TW = FAST_TW, HBW = HB;
+    constexpr size_t WB = pileup_wide_wave_bytes(WANT_HIST, HB);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32 *S = reinterpret_cast<u32 *>(smem + (size_t)w * WB);   // 1024 i32 deltas (x 4) + the sink
+    u32 *lhist = S + TW + 4;
+    uint4 *S4 = reinterpret_cast<uint4 *>(S);
+    const u32 wave_id = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (u32)w)), n_waves = gridDim.x * 4u;
+    if (WANT_HIST) {
+#pragma unroll
+        for (int b = lane; b < HBW; b += 64) lhist[b] = 0u;
+    }
+    u64 sum_d = 0, sum_d2 = 0, proc_win = 0;
+    u32 cov_w = 0, cov_f = 0, mn = 0xffffffffu, mx = 0;
+    int cur_c = -1;
+    u64 hoff = 0; u32 hcap = 0;
+    const u64 excl = a.excl;
+    // With the histogram wanted, interior tiles do NOT accumulate sum d, sum d^2, covered, min and max per position: every position's
+    // depth goes into the wave's LDS histogram anyway, and the five are read off its bins when they are moved to the arena (`drain`).
+    // The general loop (contig ends, tiles deeper than the bins) counts per position as before, so the bins hold segments of ONE kind at a
+    // time — lh_explicit says which — and are drained when the kind changes.  All wave-uniform.
+    bool lh_explicit = false;
+    u32 hbound = 0;            // no LDS bin above this was touched since the last drain (depth <= candidate runs of the tile)
+    auto drain = [&](bool derive) {
+        lds_fence();
+        for (u32 b = (u32)lane; b <= hbound; b += 64) {
+            const u32 x = lhist[b];
+            if (x) {
+                atomicAdd(&a.hist_arena[hoff + b], x); lhist[b] = 0u;
+                if (derive) {
+                    const u32 cv = b ? x : 0u;
+                    sum_d += (u64)b * x; sum_d2 += (u64)(b * b) * x; cov_w += cv; cov_f += cv;
+                    mn = min(mn, b); mx = max(mx, b);
+                }
+            }
+        }
+        lds_fence();
+        hbound = 0;
+    };
+
+    auto hist_add = [&](u32 d, u32 x) {
+        if (__builtin_expect(d < (u32)HBW, 1)) atomicAdd(&lhist[d], x);
+        else hist_add_overflow(a.hist_arena, hoff, hcap, a.g, d, x);
+    };
+    auto flush = [&]() {
+        if (cur_c >= 0) {
+            if (WANT_HIST && proc_win) drain(!lh_explicit);
+            const u64 s1 = wave_sum_u64(sum_d), s2 = wave_sum_u64(sum_d2);
+            const u32 c1 = wave_sum_u32(cov_w), c2 = wave_sum_u32(cov_f);
+            const u32 m1 = wave_min_u32(mn), m2 = wave_max_u32(mx);
+            DevContig *C = &a.ctg[cur_c];
+            if (lane == 0) {
+                if (s1) atomicAdd(&C->sum_d, s1);
+                if (s2) atomicAdd(&C->sum_d2, s2);
+                if (c1) atomicAdd(&C->cov_win, (u64)c1);
+                if (c2) atomicAdd(&C->cov_full, (u64)c2);
+                if (proc_win) {
+                    atomicAdd(&C->proc_win, proc_win);
+                    atomicMin(&C->min_d, m1);
+                    atomicMax(&C->max_d, m2);
+                }
+            }
+        }
+        sum_d = sum_d2 = 0; proc_win = 0; cov_w = cov_f = 0; mn = 0xffffffffu; mx = 0; hbound = 0; lh_explicit = false;
+    };
+    auto load_runs = [&](const uint4 &d, uint2 &r0, uint2 &r1) {
+        const u32 i0 = d.x + (u32)lane, i1 = i0 + 64u;
+        r0 = i0 < d.y ? a.runs[i0] : make_uint2(0u, 0u);
+        r1 = i1 < d.y ? a.runs[i1] : make_uint2(0u, 0u);
+    };
+    // tile sequence of this wave: chunks wave_id, wave_id + n_waves, ... of chunk_tiles consecutive tiles each
+    const u32 n_chunks = (n_tiles + chunk_tiles - 1) / chunk_tiles;
+    if (wave_id >= n_chunks) return;
+    u32 ch = wave_id;
+    u32 t = ch * chunk_tiles, t_end = min(t + chunk_tiles, n_tiles);
+    uint4 ds = a.desc[2 * (size_t)(a.tile_base + t)], dC1 = a.desc[2 * (size_t)(a.tile_base + t) + 1];
+    uint2 rw0, rw1;
+    load_runs(ds, rw0, rw1);
+    for (;;) {
+        // ---- next tile of the sequence (wave-uniform), its descriptor requested now
+        u32 tn = t + 1, tn_end = t_end, chn = ch;
+        bool chunk_end = false;
+        if (tn >= t_end) {
+            chunk_end = true;
+            chn = ch + n_waves;
+            tn = chn < n_chunks ? chn * chunk_tiles : 0xffffffffu;
+            tn_end = chn < n_chunks ? min(tn + chunk_tiles, n_tiles) : 0u;
+        }
+        const bool have_next = tn != 0xffffffffu;
+        uint4 nds = make_uint4(0u, 0u, 0u, 0u), ndC1 = make_uint4(0u, 0u, 0u, 0u);
+        if (have_next) { nds = a.desc[2 * (size_t)(a.tile_base + tn)]; ndC1 = a.desc[2 * (size_t)(a.tile_base + tn) + 1]; }
+
+        const u32 c = dC1.x, lo = dC1.y, L = ds.z, cxo = dC1.z, cxn = dC1.w;
+        const bool live = (ds.x < ds.y || cxn != 0u) && !(ds.w & TILE_F_SLOW);
+        uint4 sv0, sv1, sv2, sv3;
+        if (live) {
+            if ((int)c != cur_c) {
+                flush();
+                cur_c = (int)c;
+                if (WANT_HIST) { hoff = a.ctg[c].hist_off; hcap = a.ctg[c].hist_cap; }
+            }
+            // ---- zero, scatter, read back: three LDS phases of one wave, served in order
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+            S4[4 * lane] = z4; S4[4 * lane + 1] = z4; S4[4 * lane + 2] = z4; S4[4 * lane + 3] = z4;
+            asm volatile("" ::: "memory");
+            // no test decides whether a run touches the tile: its two ends are clamped into [0, TW] — slot TW is a sink nobody reads — so a run
+            // that lies in front of the tile adds and subtracts at slot 0, one behind it at the sink, and a run that only starts (ends) outside
+            // leaves its other end where it belongs: two saturating subtractions, two minima, two shifted adds, two atomics
+            auto add_run = [&](u32 s, u32 e) {
+                const u32 s0 = min(s > lo ? s - lo : 0u, (u32)TW), e0 = min(e > lo ? e - lo : 0u, (u32)TW);
+                atomicAdd(&S[s0], 4u);
+                atomicSub(&S[e0], 4u);
+            };
+            auto apply = [&](const uint2 rw, u32 i) {
+                if (rw.y == 0u) return;
+                const u32 type = rw.y >> 30;
+                if (type <= RW_DOUBLE) {
+                    const bool dbl = type == RW_DOUBLE;
+                    const u32 l1 = dbl ? (rw.y & 1023u) : rw.y;
+                    add_run(rw.x, rw.x + l1);
+                    if (dbl) {
+                        const u32 s2 = rw.x + l1 + ((rw.y >> 10) & 255u);
+                        add_run(s2, s2 + ((rw.y >> 18) & 1023u));
+                    }
+                } else if (type == RW_COMPLEX) {
+                    u32 cursor = (u32)a.r.pos[i];
+                    const u32 c0 = a.r.cigar_off[i], c1 = a.r.cigar_off[i + 1];
+                    for (u32 k = c0; k < c1; k++) {
+                        const u32 wd = a.r.cigar[k];
+                        const u32 op = wd & 15u, len = wd >> 4;
+                        if (op == 0u || op == 7u || op == 8u) { add_run(cursor, cursor + len); cursor += len; }
+                        else if (op == 2u || op == 3u) cursor += len;
+                    }
+                }   // RW_BUCKET: delivered through the tile's bucket
+            };
+            apply(rw0, ds.x + (u32)lane);
+            if (ds.y - ds.x > 64u) {     // wave-uniform: more than half of the tiles of a 7x-deep sample stop here
+                apply(rw1, ds.x + 64u + (u32)lane);
+                for (u32 i = ds.x + 128u + (u32)lane; i < ds.y; i += 64) apply(a.runs[i], i);   // deep tiles only
+            }
+            for (u32 j = (u32)lane; j < cxn; j += 64) { const uint2 q = a.cx_runs[(u64)cxo + j]; add_run(q.x, q.y); }   // long reads
+            asm volatile("" ::: "memory");
+            sv0 = S4[4 * lane]; sv1 = S4[4 * lane + 1]; sv2 = S4[4 * lane + 2]; sv3 = S4[4 * lane + 3];
+        }
+        // ---- next tile's run words: in flight during this tile's statistics
+        uint2 nrw0 = make_uint2(0u, 0u), nrw1 = make_uint2(0u, 0u);
+        if (have_next) load_runs(nds, nrw0, nrw1);
+
+        if (live) {
+            // the deltas (x 4) of the 16 positions this lane owns
+            const int dl[16] = {(int)sv0.x, (int)sv0.y, (int)sv0.z, (int)sv0.w, (int)sv1.x, (int)sv1.y, (int)sv1.z, (int)sv1.w,
+                                (int)sv2.x, (int)sv2.y, (int)sv2.z, (int)sv2.w, (int)sv3.x, (int)sv3.y, (int)sv3.z, (int)sv3.w};
+            int net = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) net += dl[k];
+            int d = wave_incl_scan(net) - net;       // 4 x the depth just left of this lane's first position = the byte offset of its bin
+
+            const bool has_win = 2 * excl < (u64)L;
+            const u32 tlen_t = min((u32)TW, L - lo);
+            const u32 ws = has_win ? (u32)excl : 0u, we = has_win ? (u32)(L - excl) : 0u;
+            const u32 wst = max(ws, lo), wet = min(we, lo + tlen_t);
+            const bool win_any = has_win && wst < wet;
+            if (win_any) proc_win += (u64)(wet - wst);
+            const bool interior = has_win && lo >= ws && lo + (u32)TW <= we;
+            const u32 cand = ds.y - ds.x + cxn;
+            const bool fast_tile = interior && cand < (u32)HBW;
+            if (WANT_HIST) {
+                if (lh_explicit == fast_tile) { if (proc_win) drain(!lh_explicit); lh_explicit = !fast_tile; }   // the bins change kind
+                hbound = max(hbound, min(cand, (u32)HBW - 1u));
+            }
+            if (WANT_HIST && fast_tile) {
+                // ---- fast loop, histogram wanted: every position is inside the window and depth < 512 = the LDS bins: one atomic per
+                // constant-depth segment of the lane's 16 positions and nothing else
+                u32 seg0 = 0;
+                char *lh = reinterpret_cast<char *>(lhist);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int dj = dl[j];
+                    if (j > 0 && dj != 0) { atomicAdd(reinterpret_cast<u32 *>(lh + (u32)d), (u32)j - seg0); seg0 = (u32)j; }
+                    d += dj;
+                }
+                atomicAdd(reinterpret_cast<u32 *>(lh + (u32)d), 16u - seg0);
+            } else if (fast_tile) {
+                // ---- fast loop, no histogram: every position is inside the window; depth < 512 so 24-bit multiplies and 32-bit
+                // per-tile sums are exact (16 positions x 2^18 per lane)
+                u32 s1t = 0, s2t = 0, cv = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int dj = dl[j];
+                    d += dj;
+                    const u32 du = (u32)d >> 2;
+                    s1t += du;
+                    s2t = __umul24(du, du) + s2t;
+                    cv += du != 0u ? 1u : 0u;
+                    mn = min(mn, du); mx = max(mx, du);
+                }
+                sum_d += s1t; sum_d2 += s2t; cov_w += cv; cov_f += cv;
+            } else {
+                // ---- general loop: window and contig-end tests per position, 64-bit sums, histogram overflow
+                const u32 p0 = lo + 16u * (u32)lane;
+                u32 seg0 = 0;          // first window position (lane-relative) of the open constant-depth segment
+                bool seg_open = false;
+#pragma unroll 4
+                for (int j = 0; j < 16; j++) {
+                    const int dj = dl[j];
+                    const u32 p = p0 + (u32)j;
+                    const bool in_w = win_any && p >= wst && p < wet;
+                    if (WANT_HIST && seg_open && (dj != 0 || !in_w)) { hist_add((u32)d >> 2, (u32)j - seg0); seg_open = false; }
+                    d += dj;
+                    const u32 du = (u32)d >> 2;
+                    if (p < L) cov_f += du != 0u ? 1u : 0u;
+                    if (in_w) {
+                        sum_d += du; sum_d2 += (u64)du * du;
+                        cov_w += du != 0u ? 1u : 0u;
+                        mn = min(mn, du); mx = max(mx, du);
+                        if (WANT_HIST && !seg_open) { seg_open = true; seg0 = (u32)j; }
+                    }
+                }
+                if (WANT_HIST && seg_open) hist_add((u32)d >> 2, 16u - seg0);
+            }
+        }
+        if (chunk_end) { flush(); cur_c = -1; }
+        if (!have_next) break;
+        t = tn; t_end = tn_end; ch = chn; ds = nds; dC1 = ndC1; rw0 = nrw0; rw1 = nrw1;
+    }
+}
+
+template <bool WANT_HIST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_pileup_wide(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
+    pileup_wide_body<WANT_HIST, FAST_HB7>(a, n_tiles, chunk_tiles);
+}
+
 // The default (round 6): ONE table of biased deltas, 512 LDS bins (16 KiB of LDS per workgroup), seven waves per SIMD: 0.475 ms at BASELINE
 // config 2 against 0.531 for the two-table kernel below, alternating runs on one box (profiles/r06_lean_onetable_ab_5k.log; 384 bins 0.481,
 // eight waves with 28 bytes of scratch 0.521).
@@ -2129,10 +2370,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k
 // against 0.535, alternating runs on one box, profiles/r05_prep_pileup_ab.log: the stripped loop then only takes tiles with fewer than 256
 // candidate runs and the scratch traffic sits in the per-position loop.  Removed.)
 
-// ------------------------------------------------------------------------------------ interval statistics
-// Per-interval (per-gene, genes.rs:508-535) statistics over a materialised depth arena: one wave per interval.
-// The window is the interval shrunk by `excl` at both of ITS ends (the reference hands the gene's own delta array to
-// add_contig); covered bases without exclusion.  k_interval_hist fills each interval's histogram slice afterwards.
 // ------------------------------------------------------------------------------------ k_estimate
 // CoverageEstimator::calculate_coverage (estimators.rs:530-839) on the device, for `coverm contig`: one entry = one contig, the
 // unobserved lengths are [0] (contig.rs:62-66), so an estimator sees exactly one add_contig (estimators.rs:366-528).  One WAVE per
@@ -2167,15 +2404,60 @@ __device__ __forceinline__ u64 wave_incl_scan_u64(u64 v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_estimate(const DevContig *__restrict__ ctg, u32 n_targets, const u32 *__restrict__ tlen, u64 excl,
-                                                  const u32 *__restrict__ arena, EstParams P, float *__restrict__ out) {
-#pragma clang fp contract(off)
-    const u32 c = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (c >= n_targets) return;
+// The trimmed mean's total (estimators.rs:596-640, restated over prefix sums as described above) by the WHOLE wave for one contig: 64 bins per
+// step.  Every argument is wave-uniform; every lane returns the total.
+__device__ __forceinline__ u64 trimmed_total_wave(const u32 *__restrict__ bins, u32 nh, u64 bin0_extra, u64 min_index, u64 max_index) {
     const int lane = lane_id();
+    u64 total = 0, carry = 0;        // carry = prefix of the bins in front of this batch (wave-uniform)
+    int state = 0;                   // 0: before s, 1: between s and e, 2: done
+    for (u32 b = 0; b < nh && state < 2; b += 64) {
+        const u32 i = b + (u32)lane;
+        u64 n = i < nh ? (u64)bins[i] : 0ull;
+        if (i == 0) n += bin0_extra;
+        const u64 acc = carry + wave_incl_scan_u64(n);
+        const bool valid = i < nh;
+        int first = 0;                                   // first lane of this batch that still adds n * i
+        if (state == 0) {
+            const u64 sm = __ballot(valid && acc >= min_index);
+            if (sm == 0) { carry = bcast_u64(acc, 63); continue; }
+            const int ls = __ffsll((long long)sm) - 1;
+            const u64 acc_s = bcast_u64(acc, ls);
+            total = (acc_s > max_index ? max_index - min_index + 1 : acc_s - min_index + 1) * (u64)(b + (u32)ls);
+            state = 1; first = ls + 1;
+        }
+        // state 1: the bins from `first` on add n * i until the first one whose prefix exceeds max_index
+        const u64 em = __ballot(valid && lane >= first && acc > max_index);
+        const int le = em ? __ffsll((long long)em) - 1 : 64;
+        u64 part = (valid && lane >= first && lane < le) ? n * (u64)i : 0ull;
+        if (em && lane == le) {
+            const u64 excess = acc - n;
+            part = (max_index >= excess ? max_index - excess + 1 : 0ull) * (u64)i;
+        }
+        total += wave_sum_u64(part);
+        if (em) state = 2;
+        carry = bcast_u64(acc, 63);
+    }
+    return total;
+}
+
+// LANES = false: one WAVE per contig (lane 0 evaluates, the wave walks the histogram); LANES = true: one LANE per contig — for assemblies
+// (10^5 - 10^7 contigs, a few dozen bins each: a wave per contig is 2 M nearly idle waves, 1.46 ms at 2 M contigs) — where a lane walks
+// its own contig's bins one by one (the same integers in the same order of bins; integer sums, so the floats are the same bits) and the few
+// contigs with more than EST_SERIAL_BINS bins are walked by the whole wave, one after the other.
+constexpr u32 EST_SERIAL_BINS = 96;
+template <bool LANES>
+__device__ __forceinline__ void estimate_body(const DevContig *__restrict__ ctg, u32 n_targets, const u32 *__restrict__ tlen, u64 excl,
+                                              const u32 *__restrict__ arena, const EstParams &P, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    const int lane = lane_id();
+    const u32 c_raw = LANES ? blockIdx.x * 256u + threadIdx.x : blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (!LANES && c_raw >= n_targets) return;
+    const bool in = c_raw < n_targets;
+    const u32 c = in ? c_raw : n_targets - 1u;        // (LANES: lanes behind the last contig walk along, write nothing)
     const DevContig *C = &ctg[c];
     float *o = out + (size_t)c * P.n;
-    if (C->n_pass == 0) { if ((u32)lane < P.n) o[lane] = 0.0f; return; }     // (the host prints such a contig through print_zero_coverage)
+    const bool touched = C->n_pass != 0;
+    if (!LANES && !touched) { if ((u32)lane < P.n) o[lane] = 0.0f; return; }     // (the host prints such a contig through print_zero_coverage)
     // the integer statistics as convert_results + EntryAcc::add_contig would hand them to calculate (host_coverage.cpp)
     const u64 L = tlen[c];
     const bool has_win = 2 * excl < L;
@@ -2199,39 +2481,40 @@ __global__ __launch_bounds__(256) void k_estimate(const DevContig *__restrict__ 
         }
         case EST_TRIMMED_MEAN: {
             const u64 T = win_len;
-            if (T == 0) break;
-            if ((est_f32(win_covered) / est_f32(T)) < e.min_frac) break;
+            const bool walk = (!LANES || (in && touched)) && T != 0 && !((est_f32(win_covered) / est_f32(T)) < e.min_frac) && win_covered != 0;
             const u64 min_index = est_f32_to_usize(__builtin_floorf(e.trim_min * est_f32(T)));
             const u64 max_index = est_f32_to_usize(__builtin_ceilf(e.trim_max * est_f32(T)));
-            if (win_covered == 0) break;
-            u64 total = 0, carry = 0;        // carry = prefix of the bins in front of this batch (wave-uniform)
-            int state = 0;                   // 0: before s, 1: between s and e, 2: done
-            for (u32 b = 0; b < nh && state < 2; b += 64) {
-                const u32 i = b + (u32)lane;
-                u64 n = i < nh ? (u64)bins[i] : 0ull;
-                if (i == 0) n += bin0_extra;
-                const u64 acc = carry + wave_incl_scan_u64(n);
-                const bool valid = i < nh;
-                int first = 0;                                   // first lane of this batch that still adds n * i
-                if (state == 0) {
-                    const u64 sm = __ballot(valid && acc >= min_index);
-                    if (sm == 0) { carry = bcast_u64(acc, 63); continue; }
-                    const int ls = __ffsll((long long)sm) - 1;
-                    const u64 acc_s = bcast_u64(acc, ls);
-                    total = (acc_s > max_index ? max_index - min_index + 1 : acc_s - min_index + 1) * (u64)(b + (u32)ls);
-                    state = 1; first = ls + 1;
+            u64 total = 0;
+            if (!LANES) {
+                if (!walk) break;
+                total = trimmed_total_wave(bins, nh, bin0_extra, min_index, max_index);
+            } else {
+                // a lane's own walk, bin by bin (the reference's loop over the prefix sums, as in trimmed_total_wave)
+                const bool serial = walk && nh <= EST_SERIAL_BINS;
+                u64 acc = 0;
+                int state = serial ? 0 : 2;
+                for (u32 i = 0; __any(state < 2 && i < nh); i++) {
+                    if (state < 2 && i < nh) {
+                        u64 n = bins[i];
+                        if (i == 0) n += bin0_extra;
+                        acc += n;
+                        if (state == 0) {
+                            if (acc >= min_index) { total = (acc > max_index ? max_index - min_index + 1 : acc - min_index + 1) * (u64)i; state = 1; }
+                        } else if (acc > max_index) {
+                            const u64 excess = acc - n;
+                            total += (max_index >= excess ? max_index - excess + 1 : 0ull) * (u64)i;
+                            state = 2;
+                        } else total += n * (u64)i;
+                    }
                 }
-                // state 1: the bins from `first` on add n * i until the first one whose prefix exceeds max_index
-                const u64 em = __ballot(valid && lane >= first && acc > max_index);
-                const int le = em ? __ffsll((long long)em) - 1 : 64;
-                u64 part = (valid && lane >= first && lane < le) ? n * (u64)i : 0ull;
-                if (em && lane == le) {
-                    const u64 excess = acc - n;
-                    part = (max_index >= excess ? max_index - excess + 1 : 0ull) * (u64)i;
+                for (u64 bm = __ballot(walk && !serial); bm != 0; bm &= bm - 1) {      // deep contigs: the whole wave on each
+                    const int l = __builtin_ctzll(bm);
+                    const u64 bp = bcast_u64((u64)(uintptr_t)bins, l);
+                    const u64 t = trimmed_total_wave(reinterpret_cast<const u32 *>((uintptr_t)bp), __builtin_amdgcn_readlane(nh, l), bcast_u64(bin0_extra, l),
+                                                     bcast_u64(min_index, l), bcast_u64(max_index, l));
+                    if (lane == l) total = t;
                 }
-                total += wave_sum_u64(part);
-                if (em) state = 2;
-                carry = bcast_u64(acc, 63);
+                if (!walk) break;
             }
             r = est_f32(total) / est_f32(max_index - min_index);
             break;
@@ -2270,10 +2553,23 @@ __global__ __launch_bounds__(256) void k_estimate(const DevContig *__restrict__ 
         case EST_ANIR: r = n_reads == 0 ? 0.0f : (float)(C->id_primary / (double)n_reads); break;
         default: break;
         }
-        if (lane == 0) o[k] = r;
+        if (LANES) { if (in) o[k] = touched ? r : 0.0f; }
+        else if (lane == 0) o[k] = r;
     }
 }
+__global__ __launch_bounds__(256) void k_estimate(const DevContig *__restrict__ ctg, u32 n_targets, const u32 *__restrict__ tlen, u64 excl,
+                                                  const u32 *__restrict__ arena, EstParams P, float *__restrict__ out) {
+    estimate_body<false>(ctg, n_targets, tlen, excl, arena, P, out);
+}
+__global__ __launch_bounds__(256) void k_estimate_lanes(const DevContig *__restrict__ ctg, u32 n_targets, const u32 *__restrict__ tlen, u64 excl,
+                                                        const u32 *__restrict__ arena, EstParams P, float *__restrict__ out) {
+    estimate_body<true>(ctg, n_targets, tlen, excl, arena, P, out);
+}
 
+// ------------------------------------------------------------------------------------ interval statistics
+// Per-interval (per-gene, genes.rs:508-535) statistics over a materialised depth arena: one wave per interval.
+// The window is the interval shrunk by `excl` at both of ITS ends (the reference hands the gene's own delta array to
+// add_contig); covered bases without exclusion.  k_interval_hist fills each interval's histogram slice afterwards.
 struct DevInterval { u32 tid, pad; u64 start, end; };
 struct DevIntervalStats { u64 win_sum_d, win_sum_d2, win_covered, full_covered; u32 win_min_d, win_max_d, hist_len, pad; u64 hist_off; };
 

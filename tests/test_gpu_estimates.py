@@ -90,6 +90,36 @@ def test_short_read_sample_and_long_reads():
         assert_same(both_ways(["c%d" % i for i in range(len(lens))], lens, lb, est, 0))
 
 
+def test_a_lane_per_contig(monkeypatch):
+    """k_estimate_lanes (the session's choice from 65 536 contigs on, forced here): a lane walks its contig's bins one by one, the whole wave
+    the contigs with more than 96 bins — fixtures, deep contigs (histograms of several hundred bins beside shallow ones in one wave), contigs
+    shorter than the end exclusion."""
+    monkeypatch.setenv("COVERM_EST_LANES", "1")
+    for name in ["7seqs.reads_for_seq1_and_seq2.bam", "2seqs.reads_for_seq1.bam", "k141_2005182.bam", "eg2.bam"]:
+        b = load_fixture(name)
+        for excl in (0, 75):
+            for est in estimator_sets(excl):
+                assert_same(both_ways(list(b.ref_names), np.asarray(b.ref_lens, np.int64), to_batch(b), est, excl))
+    ref = synth.make_reference(12, 60_000, seed=3, min_len=900, max_len=9_000)
+    batch = synth.make_reads(ref, 180_000, seed=4)
+    for excl in (0, 75, 600):
+        for est in estimator_sets(excl):
+            assert_same(both_ways(ref.names, ref.lengths, batch, est, excl, chunks=3))
+    ref = synth.make_reference(700, 30_000_000, seed=7, min_len=120, max_len=500_000)
+    batch = synth.make_reads(ref, 300_000, seed=8)
+    for est in estimator_sets(75):
+        assert_same(both_ways(ref.names, ref.lengths, batch, est, 75, ff=(True, False, True)))
+
+
+def test_an_assembly_of_many_short_contigs():
+    """More contigs than k_prep_lean's loop is launched for (fewer than 128 records per contig: k_prep_generic walks every step), the
+    session's own choice of k_estimate_lanes (>= 65 536 contigs), the histogram layout over many blocks, convert_results on threads."""
+    ref = synth.make_reference(70_000, 90_000_000, seed=21, min_len=1000, max_len=40_000)
+    batch = synth.make_reads(ref, 900_000, seed=22)
+    for est in estimator_sets(75)[:2]:
+        assert_same(both_ways(ref.names, ref.lengths, batch, est, 75))
+
+
 def test_with_spills_of_the_bounded_store(monkeypatch):
     monkeypatch.setenv("COVERM_STORE_CAP_RECORDS", "40000")
     ref = synth.make_reference(150, 12_000_000, seed=11, min_len=1500, max_len=300_000)
