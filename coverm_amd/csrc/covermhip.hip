@@ -375,8 +375,8 @@ void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
 // k_pileup_fast over every tile (it skips the ones k_ranges flagged TILE_F_SLOW)
 template <bool H, int TABLES>
 void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    const auto kern = TABLES == 1 ? &k_pileup_fast<H> : TABLES == 4 ? &k_pileup_wide<H> : &k_pileup_fast2t<H>;
-    const size_t smem = TABLES == 4 ? pileup_wide_smem_bytes(H, FAST_HB7) : pileup_fast_smem_bytes(H, TABLES == 1 ? FAST_HB : FAST_HB7, TABLES);
+    const auto kern = TABLES == 1 ? &k_pileup_fast<H> : &k_pileup_fast2t<H>;
+    const size_t smem = pileup_fast_smem_bytes(H, TABLES == 1 ? FAST_HB : FAST_HB7, TABLES);
     // the dynamic-LDS limit and the occupancy are per-device facts, and span mode launches from one thread per device: cached per
     // device id, in atomics (two threads racing for the same device compute the same value)
     static std::atomic<int> occ_dev[64];
@@ -400,7 +400,6 @@ void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
 template <bool H>
 void launch_fast_t(cov_session *s, const PileupArgs &a, u32 n_tiles) {
     if (s->fast_tables == 2) launch_fast_v<H, 2>(s, a, n_tiles);
-    else if (s->fast_tables == 4) launch_fast_v<H, 4>(s, a, n_tiles);
     else launch_fast_v<H, 1>(s, a, n_tiles);
 }
 
@@ -504,7 +503,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     }
     if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
     if (const char *el = getenv("COVERM_EST_LANES")) s->est_lanes = atoi(el) ? 1 : 0;
-    if (const char *ft = getenv("COVERM_FAST_TABLES")) s->fast_tables = atoi(ft) == 2 ? 2 : atoi(ft) == 4 ? 4 : 1;
+    if (const char *ft = getenv("COVERM_FAST_TABLES")) s->fast_tables = atoi(ft) == 2 ? 2 : 1;
     if (const char *pk = getenv("COVERM_PREP_KERNEL")) s->prep_kernel = atoi(pk) == 7 ? 7 : 0;
     if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;

@@ -31,7 +31,7 @@ constexpr int hist_bins(int tile) { return tile >= 16384 ? 2048 : 1024; }  // LD
 constexpr u32 F_POS_UNSORTED = 1u;
 // run-word types (top two bits of .y)
 constexpr u32 RW_SINGLE = 0u, RW_DOUBLE = 1u, RW_COMPLEX = 2u, RW_BUCKET = 3u;
-constexpr u32 FAST_MAX_CAND = 32767u;    // tiles with more candidate runs than this go to k_pileup_stream (u16 count tables of k_pileup_fast)
+constexpr u32 FAST_MAX_CAND = 8191u;     // tiles with more candidate runs than this go to k_pileup_stream (k_pileup_fast's table holds 16-bit fields of 4 x the delta)
 constexpr u32 TILE_F_GENERIC = 1u, TILE_F_SLOW = 2u;   // tile descriptor flags (desc[2t].w)
 constexpr u32 CX_MIN_OPS = 16;   // RW_COMPLEX records with more CIGAR operations than this go through the per-tile buckets
 
@@ -133,6 +133,18 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, (u32)__shfl_xor(v, o));
     return v;
 }
+
+// Wave totals by DPP prefix sums (VALU only; the __shfl_xor versions above go through the LDS crossbar, twelve round trips for a u64).  Every lane
+// returns the total.  wave_sum_u56: the values must be below 2^56 (two 24-bit-apart halves, each summed in 32 bits).
+__device__ __forceinline__ u32 wave_sum_u32_dpp(u32 v) { return (u32)__builtin_amdgcn_readlane(wave_incl_scan((int)v), 63); }
+__device__ __forceinline__ u64 wave_sum_u56(u64 v) {
+    const u32 lo = (u32)v & 0xffffffu, hi = (u32)(v >> 24);
+    return (u64)wave_sum_u32_dpp(lo) + ((u64)wave_sum_u32_dpp(hi) << 24);
+}
+__device__ __forceinline__ u32 wave_max_u32_dpp(u32 v) {      // (wave_incl_max compares as signed: flip the top bit)
+    return (u32)__builtin_amdgcn_readlane(wave_incl_max((int)(v ^ 0x80000000u)), 63) ^ 0x80000000u;
+}
+__device__ __forceinline__ u32 wave_min_u32_dpp(u32 v) { return ~wave_max_u32_dpp(~v); }
 
 // broadcast of lane q's value through the scalar unit (v_readlane), far cheaper than a ds_bpermute shuffle
 __device__ __forceinline__ double bcast_f64(double v, int q) {
@@ -1866,6 +1878,11 @@ constexpr int FAST_HB7 = 384;   // k_pileup_fast2t: seven workgroups per CU (22 
 constexpr size_t pileup_fast_smem_bytes(bool hist, int hb = FAST_HB, int tables = 2) { return (size_t)4 * ((size_t)FAST_TW * 2 * tables + (hist ? (size_t)hb * 4 : 0)); }
 
 typedef short v2i16 __attribute__((ext_vector_type(2)));
+// LDS by byte address (the 32-bit offset inside the workgroup's allocation): the histogram loops keep "address of the bin of the running depth"
+// as their running value — base + 4 x depth, advanced by 4 x delta — so that an atomic needs no address arithmetic of its own
+typedef __attribute__((address_space(3))) u32 lds_u32_t;
+__device__ __forceinline__ u32 lds_addr_of(const u32 *p) { return (u32)(uintptr_t)(lds_u32_t *)p; }
+__device__ __forceinline__ void lds_atomic_add(u32 addr, u32 x) { (void)__hip_atomic_fetch_add((lds_u32_t *)(uintptr_t)addr, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // TABLES = 2: the two count tables described above (rounds 3-5).  TABLES = 1 (round 6, the default): ONE table of 16-bit DELTAS, every
 // field biased by 0x8000 — a start adds 1 to its field, an end subtracts 1 (ds_add_u32 / ds_sub_u32 of 1 or 0x10000: a biased field never
@@ -1875,6 +1892,7 @@ typedef short v2i16 __attribute__((ext_vector_type(2)));
 template <bool WANT_HIST, int HB, int TABLES>
 __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tiles, u32 chunk_tiles) {
     constexpr int TW = FAST_TW, HBW = HB;
+    constexpr int DS = TABLES == 1 ? 2 : 0;      // the one-table kernel counts in units of 1/4: an event adds or subtracts 4, so the running depth IS the byte offset of its bin
     constexpr size_t WB = (size_t)TW * 2 * TABLES + (WANT_HIST ? (size_t)HBW * 4 : 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1922,9 +1940,11 @@ __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tile
     auto flush = [&]() {
         if (cur_c >= 0) {
             if (WANT_HIST && proc_win) drain(!lh_explicit);
-            const u64 s1 = wave_sum_u64(sum_d), s2 = wave_sum_u64(sum_d2);
-            const u32 c1 = wave_sum_u32(cov_w), c2 = wave_sum_u32(cov_f);
-            const u32 m1 = wave_min_u32(mn), m2 = wave_max_u32(mx);
+            // (DPP sums: a contig of an assembly is a tile or two, so this runs as often as the tile loop does)
+            const bool narrow = !__any((sum_d | sum_d2) >> 56);
+            const u64 s1 = narrow ? wave_sum_u56(sum_d) : wave_sum_u64(sum_d), s2 = narrow ? wave_sum_u56(sum_d2) : wave_sum_u64(sum_d2);
+            const u32 c1 = wave_sum_u32_dpp(cov_w), c2 = wave_sum_u32_dpp(cov_f);
+            const u32 m1 = wave_min_u32_dpp(mn), m2 = wave_max_u32_dpp(mx);
             DevContig *C = &a.ctg[cur_c];
             if (lane == 0) {
                 if (s1) atomicAdd(&C->sum_d, s1);
@@ -1986,10 +2006,10 @@ __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tile
             auto add_run = [&](u32 s, u32 e) {
                 if (s < hi && e > lo) {
                     const u32 s0 = s > lo ? s - lo : 0u;
-                    atomicAdd(&S[s0 >> 1], 1u << ((s0 & 1u) << 4));
+                    atomicAdd(&S[s0 >> 1], (1u << DS) << ((s0 & 1u) << 4));
                     if (e < hi) {
                         const u32 e0 = e - lo;
-                        if (TABLES == 2) atomicAdd(&E[e0 >> 1], 1u << ((e0 & 1u) << 4)); else atomicSub(&E[e0 >> 1], 1u << ((e0 & 1u) << 4));
+                        if (TABLES == 2) atomicAdd(&E[e0 >> 1], 1u << ((e0 & 1u) << 4)); else atomicSub(&E[e0 >> 1], (1u << DS) << ((e0 & 1u) << 4));
                     }
                 }
             };
@@ -2041,7 +2061,7 @@ __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tile
             const v2i16 one2 = {1, 1};
 #pragma unroll
             for (int k = 0; k < 8; k++) net = __builtin_amdgcn_sdot2(dl[k], one2, net, false);   // sum of 16 i16 in 32 bits
-            int d = wave_incl_scan(net) - net;       // depth just left of this lane's first position
+            int d = wave_incl_scan(net) - net;       // depth (<< DS) just left of this lane's first position
 
             const bool has_win = 2 * excl < (u64)L;
             const u32 tlen_t = min((u32)TW, L - lo);
@@ -2052,21 +2072,54 @@ __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tile
             const bool interior = has_win && lo >= ws && lo + (u32)TW <= we;
             const u32 cand = ds.y - ds.x + cxn;
             const bool fast_tile = interior && cand < (u32)HBW;
+            const bool derive_tile = fast_tile || cand < (u32)HBW;      // (with the histogram wanted) the tile's statistics come off the bins
             if (WANT_HIST) {
-                if (lh_explicit == fast_tile) { if (proc_win) drain(!lh_explicit); lh_explicit = !fast_tile; }   // the bins change kind
+                if (lh_explicit == derive_tile) { if (proc_win) drain(!lh_explicit); lh_explicit = !derive_tile; }   // the bins change kind
                 hbound = max(hbound, min(cand, (u32)HBW - 1u));
             }
             if (WANT_HIST && fast_tile) {
                 // ---- fast loop, histogram wanted: every position is inside the window and depth < 512 = the LDS bins: one atomic per
                 // constant-depth segment of the lane's 16 positions and nothing else
                 u32 seg0 = 0;
+                u32 da = lds_addr_of(lhist) + ((u32)d << (2 - DS));      // address of bin d
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     const int dj = (j & 1) ? (int)dl[j >> 1].y : (int)dl[j >> 1].x;
-                    if (j > 0 && dj != 0) { atomicAdd(&lhist[(u32)d], (u32)j - seg0); seg0 = (u32)j; }
-                    d += dj;
+                    if (j > 0 && dj != 0) { lds_atomic_add(da, (u32)j - seg0); seg0 = (u32)j; }
+                    da += (u32)(dj << (2 - DS));
                 }
-                atomicAdd(&lhist[(u32)d], 16u - seg0);
+                lds_atomic_add(da, 16u - seg0);
+            } else if (WANT_HIST && cand < (u32)HBW) {
+                // ---- a tile at an end of its contig (or of the end-exclusion window), shallow enough for the LDS bins: the same loop with every
+                // segment clipped to the lane's part [wa, wb) of the window, so that the bins still hold window positions only and the window
+                // statistics still come off them (`drain`); the covered positions of the contig OUTSIDE the window — the full-length covered
+                // count has no end exclusion (estimators.rs:467-502) — are counted from a 16-bit mask of the lane's covered positions.
+                // (Until round 6 such tiles took the general loop below: ~20 instructions per position where this takes ~8; an assembly
+                // of short contigs has no other tiles.)
+                const u32 p0 = lo + 16u * (u32)lane;
+                const u32 wa = win_any ? min(max(wst, p0) - p0, 16u) : 0u, wb = win_any ? min(max(wet, p0) - p0, 16u) : 0u;
+                const u32 le = min(max(L, p0) - p0, 16u);          // this lane's positions inside the contig
+                u32 seg0 = 0, covm = 0;
+                const u32 da0 = lds_addr_of(lhist);
+                u32 da = da0 + ((u32)d << (2 - DS));      // address of bin d
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int dj = (j & 1) ? (int)dl[j >> 1].y : (int)dl[j >> 1].x;
+                    if (j > 0 && dj != 0) {
+                        const u32 s_ = max(seg0, wa), e_ = min((u32)j, wb);
+                        if (e_ > s_) lds_atomic_add(da, e_ - s_);
+                        seg0 = (u32)j;
+                    }
+                    da += (u32)(dj << (2 - DS));
+                    covm = covm + covm + (da != da0 ? 1u : 0u);       // bit 15 - j: position j is covered
+                }
+                {
+                    const u32 s_ = max(seg0, wa);
+                    if (wb > s_) lds_atomic_add(da, wb - s_);
+                }
+                // positions [0, le) without [wa, wb), as bits 15 - j
+                const u32 in_ctg = 0xffffu & ~(0xffffu >> le), in_win = (0xffffu >> wa) & ~(0xffffu >> wb);
+                cov_f += (u32)__popc(covm & in_ctg & ~in_win);
             } else if (fast_tile) {
                 // ---- fast loop, no histogram: every position is inside the window; depth < 512 so 24-bit multiplies and 32-bit
                 // per-tile sums are exact (16 positions x 2^18 per lane)
@@ -2075,7 +2128,7 @@ __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tile
                 for (int j = 0; j < 16; j++) {
                     const int dj = (j & 1) ? (int)dl[j >> 1].y : (int)dl[j >> 1].x;
                     d += dj;
-                    const u32 du = (u32)d;
+                    const u32 du = (u32)d >> DS;
                     s1t += du;
                     s2t = __umul24(du, du) + s2t;
                     cv += du != 0u ? 1u : 0u;
@@ -2092,9 +2145,9 @@ __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tile
                     const int dj = (j & 1) ? (int)dl[j >> 1].y : (int)dl[j >> 1].x;
                     const u32 p = p0 + (u32)j;
                     const bool in_w = win_any && p >= wst && p < wet;
-                    if (WANT_HIST && seg_open && (dj != 0 || !in_w)) { hist_add((u32)d, (u32)j - seg0); seg_open = false; }
+                    if (WANT_HIST && seg_open && (dj != 0 || !in_w)) { hist_add((u32)d >> DS, (u32)j - seg0); seg_open = false; }
                     d += dj;
-                    const u32 du = (u32)d;
+                    const u32 du = (u32)d >> DS;
                     if (p < L) cov_f += du != 0u ? 1u : 0u;
                     if (in_w) {
                         sum_d += du; sum_d2 += (u64)du * du;
@@ -2103,254 +2156,13 @@ __device__ __forceinline__ void pileup_fast_body(const PileupArgs &a, u32 n_tile
                         if (WANT_HIST && !seg_open) { seg_open = true; seg0 = (u32)j; }
                     }
                 }
-                if (WANT_HIST && seg_open) hist_add((u32)d, 16u - seg0);
+                if (WANT_HIST && seg_open) hist_add((u32)d >> DS, 16u - seg0);
             }
         }
         if (chunk_end) { flush(); cur_c = -1; }
         if (!have_next) break;
         t = tn; t_end = tn_end; ch = chn; ds = nds; dC1 = ndC1; rw0 = nrw0; rw1 = nrw1;
     }
-}
-
-// The same kernel on a WIDE table (round 6): one i32 per position holding 4 x the delta — a start adds 4, an end subtracts 4 —, 4 KiB per wave
-// (+ a sink slot) instead of 2 KiB.  What it buys is instructions: an event's address is base + 4 x position and its value a constant (no
-// half-word shift, no field select), the ends of a run are clamped instead of tested (see add_run), the running depth IS the byte offset of
-// its histogram bin, the deltas need no unpacking.  What it costs: four ds_write_b128 + four ds_read_b128 per tile instead of two each, and
-// 384 bins instead of 512 to stay at seven workgroups per CU.
-constexpr size_t pileup_wide_wave_bytes(bool hist, int hb) { return (size_t)FAST_TW * 4 + 16 + (hist ? (size_t)hb * 4 : 0); }
-constexpr size_t pileup_wide_smem_bytes(bool hist, int hb) { return 4 * pileup_wide_wave_bytes(hist, hb); }
-template <bool WANT_HIST, int HB>
-__device__ __forceinline__ void pileup_wide_body(const PileupArgs &a, u32 n_tiles, u32 chunk_tiles) {
-    constexpr int TW = FAST_TW, HBW = HB;
-    constexpr size_t WB = pileup_wide_wave_bytes(WANT_HIST, HB);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    u32 *S = reinterpret_cast<u32 *>(smem + (size_t)w * WB);   // 1024 i32 deltas (x 4) + the sink
-    u32 *lhist = S + TW + 4;
-    uint4 *S4 = reinterpret_cast<uint4 *>(S);
-    const u32 wave_id = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (u32)w)), n_waves = gridDim.x * 4u;
-    if (WANT_HIST) {
-#pragma unroll
-        for (int b = lane; b < HBW; b += 64) lhist[b] = 0u;
-    }
-    u64 sum_d = 0, sum_d2 = 0, proc_win = 0;
-    u32 cov_w = 0, cov_f = 0, mn = 0xffffffffu, mx = 0;
-    int cur_c = -1;
-    u64 hoff = 0; u32 hcap = 0;
-    const u64 excl = a.excl;
-    // With the histogram wanted, interior tiles do NOT accumulate sum d, sum d^2, covered, min and max per position: every position's
-    // depth goes into the wave's LDS histogram anyway, and the five are read off its bins when they are moved to the arena (`drain`).
-    // The general loop (contig ends, tiles deeper than the bins) counts per position as before, so the bins hold segments of ONE kind at a
-    // time — lh_explicit says which — and are drained when the kind changes.  All wave-uniform.
-    bool lh_explicit = false;
-    u32 hbound = 0;            // no LDS bin above this was touched since the last drain (depth <= candidate runs of the tile)
-    auto drain = [&](bool derive) {
-        lds_fence();
-        for (u32 b = (u32)lane; b <= hbound; b += 64) {
-            const u32 x = lhist[b];
-            if (x) {
-                atomicAdd(&a.hist_arena[hoff + b], x); lhist[b] = 0u;
-                if (derive) {
-                    const u32 cv = b ? x : 0u;
-                    sum_d += (u64)b * x; sum_d2 += (u64)(b * b) * x; cov_w += cv; cov_f += cv;
-                    mn = min(mn, b); mx = max(mx, b);
-                }
-            }
-        }
-        lds_fence();
-        hbound = 0;
-    };
-
-    auto hist_add = [&](u32 d, u32 x) {
-        if (__builtin_expect(d < (u32)HBW, 1)) atomicAdd(&lhist[d], x);
-        else hist_add_overflow(a.hist_arena, hoff, hcap, a.g, d, x);
-    };
-    auto flush = [&]() {
-        if (cur_c >= 0) {
-            if (WANT_HIST && proc_win) drain(!lh_explicit);
-            const u64 s1 = wave_sum_u64(sum_d), s2 = wave_sum_u64(sum_d2);
-            const u32 c1 = wave_sum_u32(cov_w), c2 = wave_sum_u32(cov_f);
-            const u32 m1 = wave_min_u32(mn), m2 = wave_max_u32(mx);
-            DevContig *C = &a.ctg[cur_c];
-            if (lane == 0) {
-                if (s1) atomicAdd(&C->sum_d, s1);
-                if (s2) atomicAdd(&C->sum_d2, s2);
-                if (c1) atomicAdd(&C->cov_win, (u64)c1);
-                if (c2) atomicAdd(&C->cov_full, (u64)c2);
-                if (proc_win) {
-                    atomicAdd(&C->proc_win, proc_win);
-                    atomicMin(&C->min_d, m1);
-                    atomicMax(&C->max_d, m2);
-                }
-            }
-        }
-        sum_d = sum_d2 = 0; proc_win = 0; cov_w = cov_f = 0; mn = 0xffffffffu; mx = 0; hbound = 0; lh_explicit = false;
-    };
-    auto load_runs = [&](const uint4 &d, uint2 &r0, uint2 &r1) {
-        const u32 i0 = d.x + (u32)lane, i1 = i0 + 64u;
-        r0 = i0 < d.y ? a.runs[i0] : make_uint2(0u, 0u);
-        r1 = i1 < d.y ? a.runs[i1] : make_uint2(0u, 0u);
-    };
-    // tile sequence of this wave: chunks wave_id, wave_id + n_waves, ... of chunk_tiles consecutive tiles each
-    const u32 n_chunks = (n_tiles + chunk_tiles - 1) / chunk_tiles;
-    if (wave_id >= n_chunks) return;
-    u32 ch = wave_id;
-    u32 t = ch * chunk_tiles, t_end = min(t + chunk_tiles, n_tiles);
-    uint4 ds = a.desc[2 * (size_t)(a.tile_base + t)], dC1 = a.desc[2 * (size_t)(a.tile_base + t) + 1];
-    uint2 rw0, rw1;
-    load_runs(ds, rw0, rw1);
-    for (;;) {
-        // ---- next tile of the sequence (wave-uniform), its descriptor requested now
-        u32 tn = t + 1, tn_end = t_end, chn = ch;
-        bool chunk_end = false;
-        if (tn >= t_end) {
-            chunk_end = true;
-            chn = ch + n_waves;
-            tn = chn < n_chunks ? chn * chunk_tiles : 0xffffffffu;
-            tn_end = chn < n_chunks ? min(tn + chunk_tiles, n_tiles) : 0u;
-        }
-        const bool have_next = tn != 0xffffffffu;
-        uint4 nds = make_uint4(0u, 0u, 0u, 0u), ndC1 = make_uint4(0u, 0u, 0u, 0u);
-        if (have_next) { nds = a.desc[2 * (size_t)(a.tile_base + tn)]; ndC1 = a.desc[2 * (size_t)(a.tile_base + tn) + 1]; }
-
-        const u32 c = dC1.x, lo = dC1.y, L = ds.z, cxo = dC1.z, cxn = dC1.w;
-        const bool live = (ds.x < ds.y || cxn != 0u) && !(ds.w & TILE_F_SLOW);
-        uint4 sv0, sv1, sv2, sv3;
-        if (live) {
-            if ((int)c != cur_c) {
-                flush();
-                cur_c = (int)c;
-                if (WANT_HIST) { hoff = a.ctg[c].hist_off; hcap = a.ctg[c].hist_cap; }
-            }
-            // ---- zero, scatter, read back: three LDS phases of one wave, served in order
-            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-            S4[4 * lane] = z4; S4[4 * lane + 1] = z4; S4[4 * lane + 2] = z4; S4[4 * lane + 3] = z4;
-            asm volatile("" ::: "memory");
-            // no test decides whether a run touches the tile: its two ends are clamped into [0, TW] — slot TW is a sink nobody reads — so a run
-            // that lies in front of the tile adds and subtracts at slot 0, one behind it at the sink, and a run that only starts (ends) outside
-            // leaves its other end where it belongs: two saturating subtractions, two minima, two shifted adds, two atomics
-            auto add_run = [&](u32 s, u32 e) {
-                const u32 s0 = min(s > lo ? s - lo : 0u, (u32)TW), e0 = min(e > lo ? e - lo : 0u, (u32)TW);
-                atomicAdd(&S[s0], 4u);
-                atomicSub(&S[e0], 4u);
-            };
-            auto apply = [&](const uint2 rw, u32 i) {
-                if (rw.y == 0u) return;
-                const u32 type = rw.y >> 30;
-                if (type <= RW_DOUBLE) {
-                    const bool dbl = type == RW_DOUBLE;
-                    const u32 l1 = dbl ? (rw.y & 1023u) : rw.y;
-                    add_run(rw.x, rw.x + l1);
-                    if (dbl) {
-                        const u32 s2 = rw.x + l1 + ((rw.y >> 10) & 255u);
-                        add_run(s2, s2 + ((rw.y >> 18) & 1023u));
-                    }
-                } else if (type == RW_COMPLEX) {
-                    u32 cursor = (u32)a.r.pos[i];
-                    const u32 c0 = a.r.cigar_off[i], c1 = a.r.cigar_off[i + 1];
-                    for (u32 k = c0; k < c1; k++) {
-                        const u32 wd = a.r.cigar[k];
-                        const u32 op = wd & 15u, len = wd >> 4;
-                        if (op == 0u || op == 7u || op == 8u) { add_run(cursor, cursor + len); cursor += len; }
-                        else if (op == 2u || op == 3u) cursor += len;
-                    }
-                }   // RW_BUCKET: delivered through the tile's bucket
-            };
-            apply(rw0, ds.x + (u32)lane);
-            if (ds.y - ds.x > 64u) {     // wave-uniform: more than half of the tiles of a 7x-deep sample stop here
-                apply(rw1, ds.x + 64u + (u32)lane);
-                for (u32 i = ds.x + 128u + (u32)lane; i < ds.y; i += 64) apply(a.runs[i], i);   // deep tiles only
-            }
-            for (u32 j = (u32)lane; j < cxn; j += 64) { const uint2 q = a.cx_runs[(u64)cxo + j]; add_run(q.x, q.y); }   // long reads
-            asm volatile("" ::: "memory");
-            sv0 = S4[4 * lane]; sv1 = S4[4 * lane + 1]; sv2 = S4[4 * lane + 2]; sv3 = S4[4 * lane + 3];
-        }
-        // ---- next tile's run words: in flight during this tile's statistics
-        uint2 nrw0 = make_uint2(0u, 0u), nrw1 = make_uint2(0u, 0u);
-        if (have_next) load_runs(nds, nrw0, nrw1);
-
-        if (live) {
-            // the deltas (x 4) of the 16 positions this lane owns
-            const int dl[16] = {(int)sv0.x, (int)sv0.y, (int)sv0.z, (int)sv0.w, (int)sv1.x, (int)sv1.y, (int)sv1.z, (int)sv1.w,
-                                (int)sv2.x, (int)sv2.y, (int)sv2.z, (int)sv2.w, (int)sv3.x, (int)sv3.y, (int)sv3.z, (int)sv3.w};
-            int net = 0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) net += dl[k];
-            int d = wave_incl_scan(net) - net;       // 4 x the depth just left of this lane's first position = the byte offset of its bin
-
-            const bool has_win = 2 * excl < (u64)L;
-            const u32 tlen_t = min((u32)TW, L - lo);
-            const u32 ws = has_win ? (u32)excl : 0u, we = has_win ? (u32)(L - excl) : 0u;
-            const u32 wst = max(ws, lo), wet = min(we, lo + tlen_t);
-            const bool win_any = has_win && wst < wet;
-            if (win_any) proc_win += (u64)(wet - wst);
-            const bool interior = has_win && lo >= ws && lo + (u32)TW <= we;
-            const u32 cand = ds.y - ds.x + cxn;
-            const bool fast_tile = interior && cand < (u32)HBW;
-            if (WANT_HIST) {
-                if (lh_explicit == fast_tile) { if (proc_win) drain(!lh_explicit); lh_explicit = !fast_tile; }   // the bins change kind
-                hbound = max(hbound, min(cand, (u32)HBW - 1u));
-            }
-            if (WANT_HIST && fast_tile) {
-                // ---- fast loop, histogram wanted: every position is inside the window and depth < 512 = the LDS bins: one atomic per
-                // constant-depth segment of the lane's 16 positions and nothing else
-                u32 seg0 = 0;
-                char *lh = reinterpret_cast<char *>(lhist);
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int dj = dl[j];
-                    if (j > 0 && dj != 0) { atomicAdd(reinterpret_cast<u32 *>(lh + (u32)d), (u32)j - seg0); seg0 = (u32)j; }
-                    d += dj;
-                }
-                atomicAdd(reinterpret_cast<u32 *>(lh + (u32)d), 16u - seg0);
-            } else if (fast_tile) {
-                // ---- fast loop, no histogram: every position is inside the window; depth < 512 so 24-bit multiplies and 32-bit
-                // per-tile sums are exact (16 positions x 2^18 per lane)
-                u32 s1t = 0, s2t = 0, cv = 0;
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int dj = dl[j];
-                    d += dj;
-                    const u32 du = (u32)d >> 2;
-                    s1t += du;
-                    s2t = __umul24(du, du) + s2t;
-                    cv += du != 0u ? 1u : 0u;
-                    mn = min(mn, du); mx = max(mx, du);
-                }
-                sum_d += s1t; sum_d2 += s2t; cov_w += cv; cov_f += cv;
-            } else {
-                // ---- general loop: window and contig-end tests per position, 64-bit sums, histogram overflow
-                const u32 p0 = lo + 16u * (u32)lane;
-                u32 seg0 = 0;          // first window position (lane-relative) of the open constant-depth segment
-                bool seg_open = false;
-#pragma unroll 4
-                for (int j = 0; j < 16; j++) {
-                    const int dj = dl[j];
-                    const u32 p = p0 + (u32)j;
-                    const bool in_w = win_any && p >= wst && p < wet;
-                    if (WANT_HIST && seg_open && (dj != 0 || !in_w)) { hist_add((u32)d >> 2, (u32)j - seg0); seg_open = false; }
-                    d += dj;
-                    const u32 du = (u32)d >> 2;
-                    if (p < L) cov_f += du != 0u ? 1u : 0u;
-                    if (in_w) {
-                        sum_d += du; sum_d2 += (u64)du * du;
-                        cov_w += du != 0u ? 1u : 0u;
-                        mn = min(mn, du); mx = max(mx, du);
-                        if (WANT_HIST && !seg_open) { seg_open = true; seg0 = (u32)j; }
-                    }
-                }
-                if (WANT_HIST && seg_open) hist_add((u32)d >> 2, 16u - seg0);
-            }
-        }
-        if (chunk_end) { flush(); cur_c = -1; }
-        if (!have_next) break;
-        t = tn; t_end = tn_end; ch = chn; ds = nds; dC1 = ndC1; rw0 = nrw0; rw1 = nrw1;
-    }
-}
-
-template <bool WANT_HIST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_pileup_wide(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
-    pileup_wide_body<WANT_HIST, FAST_HB7>(a, n_tiles, chunk_tiles);
 }
 
 // The default (round 6): ONE table of biased deltas, 512 LDS bins (16 KiB of LDS per workgroup), seven waves per SIMD: 0.475 ms at BASELINE
@@ -2360,9 +2172,9 @@ template <bool WANT_HIST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_pileup_fast(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
     pileup_fast_body<WANT_HIST, FAST_HB, 1>(a, n_tiles, chunk_tiles);
 }
-// The second implementation (COVERM_FAST_TABLES=2; rounds 4-5's default): two u16 count tables, 384 bins, 72 registers = seven waves per SIMD.
+// The second implementation (COVERM_FAST_TABLES=2; rounds 4-5's default): two u16 count tables, 384 bins; six waves per SIMD (with the clipped loop for contig ends the body no longer fits 72 registers without scratch).
 template <bool WANT_HIST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k_pileup_fast2t(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_pileup_fast2t(PileupArgs a, u32 n_tiles, u32 chunk_tiles) {
     pileup_fast_body<WANT_HIST, FAST_HB7, 2>(a, n_tiles, chunk_tiles);
 }
 
