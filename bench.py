@@ -508,9 +508,13 @@ def main():
     ap.add_argument("--no-binary-legs", action="store_true", help="skip configs 2 / 3 at full size through the coverm-amd binary")
     ap.add_argument("--host-estimates", action="store_true", help="evaluate calculate_coverage on the host from the integer statistics + histogram (the path before cov_set_estimators), for A/B")
     ap.add_argument("--no-multi-device-e2e", action="store_true", help="N > 1: skip the coverm-amd --devices legs (configs 4 and 5 through the product's multi-GPU path)")
+    ap.add_argument("--time-limit", type=float, default=float(os.environ.get("COVERM_BENCH_TIME_LIMIT", 1500)),
+                    help="seconds this command may take: the plan (legs and what each is expected to cost) is printed up front, and a leg that cannot finish inside what is left is skipped and recorded as skipped instead of dying in the caller's timeout")
     ap.add_argument("--tmp", default=os.environ.get("COVERM_BENCH_TMP", default_tmp()),
                     help="where the end-to-end leg writes its BAM (default: /dev/shm when it has room, so that storage speed is not part of the figure)")
     a = ap.parse_args()
+    BUDGET["t0"] = time.time() - float(os.environ.get("COVERM_BENCH_ELAPSED", 0))      # (the relaunch below hands over what it used)
+    BUDGET["limit"] = a.time_limit
 
     share = os.environ.get("COVERM_BENCH_SHARE_GPU") == "1"
     if a.gpus < 1:
@@ -518,13 +522,15 @@ def main():
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         # `python bench.py --gpus N` on its own: become N ranks (one per GPU) under torch.distributed.run, as the driver's launch line does
         check_devices(a.gpus, share)
-        os.execvpe(sys.executable, relaunch_cmd(a.gpus, sys.argv[1:]), dict(os.environ, MASTER_ADDR="127.0.0.1"))
+        os.execvpe(sys.executable, relaunch_cmd(a.gpus, sys.argv[1:]), dict(os.environ, MASTER_ADDR="127.0.0.1", COVERM_BENCH_ELAPSED=str(time.time() - BUDGET["t0"])))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE): the line would be mislabelled" % (a.gpus, world))
     check_devices(world, share)
+    if rank == 0:
+        print_plan(a, world, share)
     # Functional check of the N > 1 path on a single-GPU box: COVERM_BENCH_SHARE_GPU=1 puts every rank on device 0 and
     # exchanges over gloo (RCCL refuses two ranks on one device).  Never set by the driver; such a line is not a measurement.
     if share:
@@ -641,12 +647,13 @@ def main():
                              "hbm_traffic_bytes_from_committed_profile": prof.get("traffic", {}).get(k), "pipes_from_committed_profile": prof.get("pipes", {}).get(k)}
         domk = per_kernel.get(dom, {})
         # The rubric's roofline: algorithmic bytes of the dominant kernel / its launch duration (HIP events of THIS run) against the HBM peak.
-        # Neither kernel is HBM-bound: k_pileup_fast7 keeps the depth array in LDS (LDS pipe + VALU issue), k_prep8s is bound by instruction issue;
-        # what the counters of the committed profile say about both is carried beside the figure (`kernels.*.pipes_from_committed_profile`).
-        roof = {"bound": "hbm", "kernel": {"k_pileup": "k_pileup_fast7", "k_prep": "k_prep8s"}.get(dom, dom), "achieved": domk.get("hbm_achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        # k_prep_lean streams the record store (round 6: ~0.65 of the HBM peak by its algorithmic bytes, VALU issue ~80 % busy); k_pileup_fast keeps the
+        # depth array in LDS and is bound by VALU issue (~86 % busy), not by HBM: its figure against the HBM peak is small by construction.  What the
+        # counters of the committed profile say about both is carried beside the figure (`kernels.*.pipes_from_committed_profile`).
+        roof = {"bound": "hbm", "kernel": {"k_pileup": "k_pileup_fast", "k_prep": "k_prep_lean (+ k_prep_generic, k_post_prep: one timed group)"}.get(dom, dom), "achieved": domk.get("hbm_achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (domk.get("hbm_achieved_GBps") or 0.0) / HBM_PEAK_GBPS, "traffic": domk.get("hbm_traffic_bytes_from_committed_profile"),
                 "traffic_source": "committed rocprofv3 PMC profile (profiles/pmc_traffic.json, %s), not this run" % prof.get("traffic", {}).get("_source"),
-                "note": "k_prep8s (streams the record store) reaches %.3f of the HBM peak, k_pileup_fast7 (depth array in LDS, not HBM-bound) %.3f; their launch times differ by %.1f %%; "
+                "note": "the k_prep group (k_prep_lean streams the record store) reaches %.3f of the HBM peak, k_pileup_fast (depth array in LDS, VALU-bound, not HBM-bound) %.3f; their launch times differ by %.1f %%; "
                         "see kernels" % (per_kernel["k_prep"]["hbm_frac_of_8TBps"], per_kernel["k_pileup"]["hbm_frac_of_8TBps"],
                                                          100.0 * abs(kms["k_prep"] - kms["k_pileup"]) / max(kms["k_prep"], kms["k_pileup"], 1e-9))}
         roof["ingest"] = ingest_roofline()
@@ -714,14 +721,18 @@ def main():
                                    "cpu_reads_per_s": cpu_rate, "cpu": "oracle scan, 1 thread, records in host memory (same starting point)",
                                    "speedup_vs_cpu": considered / best / cpu_rate},
             }
-            if not a.no_binary_legs:
+            if not a.no_binary_legs and not leg_allowed("binary_configs", a, world, out):
+                pass
+            elif not a.no_binary_legs:
                 try:
                     out["binary_configs"] = binary_config_legs(a, threads, ref, batch, oracle_cfg2)
                     if not out["binary_configs"].get("tables_equal", False):
                         exit_code = 3
                 except Exception as ex:
                     out["binary_configs"] = {"error": repr(ex)[:1000]}
-            if not a.no_e2e and world == 1:
+            if not a.no_e2e and world == 1 and not leg_allowed("end_to_end", a, world, out["bases"]):
+                pass
+            elif not a.no_e2e and world == 1:
                 try:
                     out["bases"]["end_to_end"] = end_to_end(a, threads)
                     if not out["bases"]["end_to_end"].get("tables_equal", False):
@@ -737,7 +748,9 @@ def main():
             except Exception as ex:
                 out["multi_device_end_to_end_functional_check"] = {"error": repr(ex)[:1000]}
                 exit_code = 3
-        if world > 1 and not a.no_multi_device_e2e and not share:
+        if world > 1 and not a.no_multi_device_e2e and not share and not leg_allowed("multi_device_end_to_end", a, world, out):
+            pass
+        elif world > 1 and not a.no_multi_device_e2e and not share:
             # the product's own multi-GPU path (one process, N devices): run by rank 0 while the other ranks wait on the host (wait_for_root below)
             try:
                 threads = max(1, int(os.environ.get("COVERM_BENCH_THREADS", usable_cpus())))
@@ -762,7 +775,7 @@ def main():
             "cpu_threads": e2e.get("threads"), "cpu_inflate_backend": (e2e.get("cpu") or {}).get("inflate_backend"),
             "cfg2_binary_s": r3((bc.get("config2_contig") or {}).get("seconds")), "cfg3_binary_s": r3((bc.get("config3_genome") or {}).get("seconds")),
             "parity_equal": (out.get("parity_checked") or {}).get("equal"),
-            "tables_equal": (bool(e2e.get("tables_equal")) and bool(bc.get("tables_equal"))) if (e2e and bc and "error" not in e2e and "error" not in bc) else None,
+            "tables_equal": (bool(e2e.get("tables_equal")) and bool(bc.get("tables_equal"))) if (e2e and bc and "error" not in e2e and "error" not in bc and "skipped" not in e2e and "skipped" not in bc) else None,
             "device_resident_ms": r3(out["ms_per_step"]), "roofline_kernel": roof.get("kernel"), "roofline_frac": round(float(roof.get("frac") or 0.0), 4),
             "pileup_kernel_ms": r3((roof.get("all_kernels_ms") or {}).get("k_pileup")), "pileup_hbm_frac": round(float(((roof.get("kernels") or {}).get("k_pileup") or {}).get("hbm_frac_of_8TBps") or 0.0), 4),
             "prep_kernel_ms": r3((roof.get("all_kernels_ms") or {}).get("k_prep")), "prep_hbm_frac": round(float(((roof.get("kernels") or {}).get("k_prep") or {}).get("hbm_frac_of_8TBps") or 0.0), 4),
@@ -776,6 +789,45 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(exit_code)
+
+
+# ---- time budget: what a leg is expected to cost on a lease box with ~16 usable CPUs, from the rounds' own runs
+# (generation of a 50 M-read sample ~25 s, of the 200 M-read one ~100 s + ~60 s per BGZF level to write it; CPU decode legs 3 x 9 s per level)
+BUDGET = {"t0": time.time(), "limit": 1500.0}
+
+
+def leg_estimates(a, world):
+    scale = a.reads / 50e6
+    e2e = a.e2e_reads / 200e6
+    est = {"sample + device-resident steps": 45 * scale + 10}
+    if world == 1 and not a.no_cpu_baseline:
+        est["parity + cpu baseline + push-inclusive"] = 40 * scale
+        if not a.no_binary_legs:
+            est["binary_configs"] = 75 * scale
+        if not a.no_e2e:
+            est["end_to_end"] = (190 if a.no_level6 else 330) * e2e
+    if world > 1 and not a.no_multi_device_e2e:
+        est["multi_device_end_to_end"] = (60 + 35 * world) * scale + 260 * e2e
+    return est
+
+
+def print_plan(a, world, share):
+    est = leg_estimates(a, world)
+    tot = sum(est.values())
+    print("[bench] time limit %.0f s; plan for N = %d%s: %s = ~%.0f s%s" % (
+        BUDGET["limit"], world, " (ranks share one GPU: functional check)" if share else "", ", ".join("%s ~%.0f s" % kv for kv in est.items()), tot,
+        "" if tot <= BUDGET["limit"] else " -- MORE than the limit: the last legs will be skipped and recorded as skipped"), file=sys.stderr, flush=True)
+
+
+def leg_allowed(name, a, world, record):
+    """True when `name` can still finish inside the limit; else writes the reason into record[name] and says so on stderr."""
+    need = leg_estimates(a, world).get(name, 0.0)
+    left = BUDGET["limit"] - (time.time() - BUDGET["t0"])
+    if need * 1.15 <= left:
+        return True
+    record[name] = {"skipped": "time budget", "estimate_s": round(need, 1), "left_s": round(left, 1), "time_limit_s": BUDGET["limit"]}
+    print("[bench] skipping %s: needs ~%.0f s, %.0f s of the %.0f s limit are left" % (name, need, left, BUDGET["limit"]), file=sys.stderr, flush=True)
+    return False
 
 
 def relaunch_cmd(n, argv, port=None):

@@ -77,29 +77,33 @@ struct DevBuf {
 
 std::string g_create_error;
 
+// COVERM_CLI_TIMING: the library's and the host layer's stamps on stderr (read once per process)
+bool cov_timing_on() { static const bool on = getenv("COVERM_CLI_TIMING") != nullptr; return on; }
+
 }  // namespace
+
+extern "C" int covh_timing_on(void) { return cov_timing_on() ? 1 : 0; }
 
 // Which inflate kernel runs, how many blocks make one round (= one launch = one window of the inflated stream) and the size of the carry area.
 //   version 3 (default): k_inflate_wave, one wave per BGZF block; a round is as long as the parse wants it (windows bound the memory and set
 //                        the fill and drain of the pipeline);
 //   version 1 (COVERM_INFLATE_V=1): k_inflate, one LANE per block, private Huffman tables per lane in LDS — the second implementation the
 //                        tests compare with; a launch is cut to exactly the blocks resident at once (a lane decodes a block serially).
-struct InflateKernel { int version = 3; int lz_version = 2; bool sink8 = false, one_unit = false; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ablate = 0; u32 ext_parts = covi::EXT_PARTS; };
+struct InflateKernel { int version = 3; int lz_version = 2; u32 round_blocks = 0; u64 carry = 16ull << 20; u64 cwin = 0; u32 ext_parts = covi::EXT_PARTS; };
 
 struct cov_session {
     cov_config cfg{};
     hipStream_t stream = nullptr;
     std::string err;
     int tile = 4096;  // bases per k_pileup workgroup (COVERM_TILE = 4096 | 8192 | 16384)
-    int nt = 256;     // k_pileup workgroup size (COVERM_PILEUP_NT)
+    int nt = 256;     // k_pileup workgroup size
     int stream_rows = 4;   // > 0: wave-per-tile kernels (1024-base tiles); 0: k_pileup workgroup-per-tile (COVERM_PILEUP=tile)
     bool use_fast = true;  // k_pileup_fast + k_pileup_stream on the slow-tile list (default); COVERM_PILEUP=stream: k_pileup_stream alone
-    int chunk_tiles = 8;   // consecutive tiles walked by one wave (COVERM_CHUNK)
+    int chunk_tiles = 8;   // consecutive tiles walked by one wave (swept in round 4: 4 -> 0.627 ms, 8 -> 0.596, 16 -> 0.642, 32 -> 0.866)
     int prep_kernel = 0;   // 0 = k_prep_lean (prep_lean.hip.h); COVERM_PREP_KERNEL=7 forces k_prep7s, the second implementation (tests)
     int est_lanes = -1;        // k_estimate_lanes (a lane per contig) from 65 536 contigs on; COVERM_EST_LANES=1 | 0 forces it on / off (tests)
     int fast_tables = 1;       // k_pileup_fast (one table of biased deltas: the default) or k_pileup_fast2t (two count tables; COVERM_FAST_TABLES=2)
     int n_cus = 256;
-    uint32_t ablate = 0;  // COVERM_ABLATE experiment knob, see PileupArgs
 
     // targets
     uint32_t n_targets = 0;
@@ -166,6 +170,7 @@ struct cov_session {
     uint64_t merged_records = 0;            // records of the whole sample after a merging finish (cov_gather sends it)
     DevBuf<uint8_t> d_spill_tmp;
     uint64_t ing_rec_spilled = 0;           // records of the running ingest that already left the store
+    uint64_t spill_retry_at = 0;            // after a spill that could move nothing: no further attempt below this many records
 
     DevBuf<uint2> d_runs;
     DevBuf<PrepPartial> d_part;
@@ -222,7 +227,6 @@ struct cov_session {
     uint64_t ing_comp = 0, ing_infl = 0, ing_blocks = 0;
     bool ing_active = false;
     InflateKernel ing_K;
-    u32 wg_per_cu_override = 0;
     hipStream_t ing_copy = nullptr;
     // second upload queue: the halves of a large piece go to HBM through two DMA engines at once (one queue moved ~42 GB/s of
     // 32 MiB pieces between table uploads; the link does 57); joined into ing_copy before anything is recorded there
@@ -301,11 +305,13 @@ cov_status append(cov_session *s, const cov_batch *b, bool from_device) {
         off0 = b->cigar_off[0]; offn = b->cigar_off[n];
     }
     const uint64_t ncig = (uint64_t)offn - off0;
-    if (s->n_records && (s->n_records + n > s->cap_records || s->n_cigar + ncig > s->cap_cigar)) {
+    if (s->n_records && (s->n_records + n > s->cap_records || s->n_cigar + ncig > s->cap_cigar) && s->n_records >= s->spill_retry_at) {
         // bounded store: the contigs that are complete leave for the host, the contig in flight moves to the front (contig.rs:128-155)
         bool progress = false;
         const cov_status sp = spill_store(s, progress);
         if (sp != COV_OK) return sp;
+        // one reference already fills the store: a spill is a whole pass over it that moves nothing — not again before the store has doubled
+        s->spill_retry_at = progress ? 0 : 2 * s->n_records;
     }
     if (s->n_records + n >= 0xfffffff0ull) { s->err = "more than 2^32 records of one reference (or of one batch) in the record store"; return COV_ERR_INVALID_ARG; }
     if (s->n_cigar + ncig >= 0xfffffff0ull) { s->err = "more than 2^32 CIGAR words of one reference (or of one batch) in the record store"; return COV_ERR_INVALID_ARG; }
@@ -393,7 +399,7 @@ void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
         }
         occ = nb; occ_slot.store(nb, std::memory_order_relaxed);
     }
-    const u32 wg_per_cu = s->wg_per_cu_override ? s->wg_per_cu_override : 8u * (u32)occ;
+    const u32 wg_per_cu = 8u * (u32)occ;
     const u32 grid = std::max(1u, std::min((n_chunks + 3) / 4, (u32)s->n_cus * wg_per_cu));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s->stream, a, n_tiles, chunk);
 }
@@ -424,7 +430,7 @@ void launch_stream_t(cov_session *s, const PileupArgs &a, u32 n_tiles, bool slow
         }
         occ = nb; occ_slot.store(nb, std::memory_order_relaxed);
     }
-    const u32 wg_per_cu = s->wg_per_cu_override ? s->wg_per_cu_override : 8u * (u32)occ;
+    const u32 wg_per_cu = 8u * (u32)occ;
     if (slow_list_only) {   // the listed tiles only, one per wave step; the count lives on the device (usually 0: waves exit at once)
         hipLaunchKernelGGL((k_pileup_stream<H, W>), dim3((u32)s->n_cus), dim3(256), smem, s->stream, a, 0u, 1u,
                            (const u32 *)s->d_slow_list.p, (const u32 *)&s->d_glob.p->n_slow);
@@ -448,7 +454,7 @@ PileupArgs pileup_args(cov_session *s) {
     PileupArgs a{};
     a.tile_contig = s->d_tile_contig.p; a.tile_start = s->d_tile_start.p; a.desc = s->d_desc.p;
     a.runs = s->d_runs.p; a.cx_runs = s->d_cx_runs.p; a.r = records_of(s); a.ctg = s->d_ctg.p; a.g = s->d_glob.p;
-    a.hist_arena = s->d_arena.p; a.excl = s->cfg.contig_end_exclusion; a.depth_out = nullptr; a.tile_base = 0; a.ablate = s->ablate;
+    a.hist_arena = s->d_arena.p; a.excl = s->cfg.contig_end_exclusion; a.depth_out = nullptr; a.tile_base = 0;
     return a;
 }
 
@@ -463,7 +469,7 @@ const char *cov_last_error(const cov_session *s) { return s ? s->err.c_str() : g
 cov_status cov_create(const cov_config *cfg, cov_session **out) {
     if (!cfg || !out) { g_create_error = "null argument"; return COV_ERR_INVALID_ARG; }
     *out = nullptr;
-    const bool timing = getenv("COVERM_CLI_TIMING") != nullptr;
+    const bool timing = cov_timing_on();
     const auto tc0 = std::chrono::steady_clock::now();
     auto stamp = [&](const char *what) { if (timing) fprintf(stderr, "[covermhip] cov_create: %s at %.4fs\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count()); };
     int ndev = 0;
@@ -480,32 +486,28 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     cov_session *s = new cov_session();
     s->cfg = *cfg;
     {
-        const char *tl = getenv("COVERM_TILE"), *nt = getenv("COVERM_PILEUP_NT");
-        int t = tl ? atoi(tl) : 4096, n = nt ? atoi(nt) : 0;
+        const char *tl = getenv("COVERM_TILE");      // (tile of the workgroup-per-tile cross-check kernel, COVERM_PILEUP=tile)
+        int t = tl ? atoi(tl) : 4096, n = 0;
         if (t != 4096 && t != 8192 && t != 16384) t = 4096;
         if (t == 16384) n = (n == 1024) ? 1024 : 512;
         else if (t == 8192) n = (n == 256) ? 256 : 512;
         else n = (n == 128) ? 128 : 256;
         s->tile = t; s->nt = n;
-        const char *mode = getenv("COVERM_PILEUP"), *rows = getenv("COVERM_ROWS"), *chk = getenv("COVERM_CHUNK");
+        const char *mode = getenv("COVERM_PILEUP");
         if (mode && !strcmp(mode, "stream")) s->use_fast = false;
         if (mode && !strcmp(mode, "tile")) s->stream_rows = 0;
         else {
-            (void)rows;
             s->stream_rows = 4;
             s->tile = STREAM_TW;
         }
-        if (chk && atoi(chk) > 0) s->chunk_tiles = atoi(chk);
         stamp("hipSetDevice");
         int cus = 0;      // (hipGetDeviceProperties fills a kilobyte of fields from many driver queries; one attribute is all that is needed)
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) s->n_cus = cus;
         stamp("device attribute");
     }
-    if (const char *ab = getenv("COVERM_ABLATE")) s->ablate = (uint32_t)atoi(ab);
     if (const char *el = getenv("COVERM_EST_LANES")) s->est_lanes = atoi(el) ? 1 : 0;
     if (const char *ft = getenv("COVERM_FAST_TABLES")) s->fast_tables = atoi(ft) == 2 ? 2 : 1;
     if (const char *pk = getenv("COVERM_PREP_KERNEL")) s->prep_kernel = atoi(pk) == 7 ? 7 : 0;
-    if (const char *wg = getenv("COVERM_WG_PER_CU")) s->wg_per_cu_override = atoi(wg) > 0 ? (u32)atoi(wg) : 0u;      // (read here, once: not in the launch path)
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
     if (const char *c = getenv("COVERM_STORE_CAP_RECORDS")) { const long long v = atoll(c); if (v >= 1) s->cap_records = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
     if (const char *c = getenv("COVERM_STORE_CAP_CIGAR")) { const long long v = atoll(c); if (v >= 1) s->cap_cigar = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
@@ -708,7 +710,7 @@ cov_status cov_reset(cov_session *s) {
         if (a != COV_OK) s->err.clear();
     }
     s->adopted = false; s->n_records = 0; s->n_cigar = 0; s->finished = false; s->depth_all_valid = false; s->mates_valid = 0;
-    s->spill.clear(); s->merged_valid = false; s->merged_hist.clear(); s->ing_rec_spilled = 0; s->spill_est.clear(); s->est_valid = false;
+    s->spill.clear(); s->merged_valid = false; s->merged_hist.clear(); s->ing_rec_spilled = 0; s->spill_retry_at = 0; s->spill_est.clear(); s->est_valid = false;
     return COV_OK;
 }
 
@@ -1052,7 +1054,9 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
             s->hist_fetch_seen = false;
         }
     }
-    const size_t block = result_block_bytes(nT), nf = (size_t)nT * s->est.n;
+    // (with a target mask the entries are genomes, aggregated on the host: masked-out contigs have no bins in the arena, and nobody may fetch
+    // per-contig floats — no k_estimate launch, no floats in the copy)
+    const size_t block = result_block_bytes(nT), nf = s->have_mask ? 0 : (size_t)nT * s->est.n;
     {
         const size_t need = block + (size_t)std::max<u32>(nT, 1) * COV_EST_MAX * sizeof(float);
         if (need > s->h_res_cap) {
@@ -1114,7 +1118,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     s->last_chist_total = 0;
     if (want_hist) for (u32 c = 0; c < nT; c++) s->last_chist_total += stats[c].hist_len;      // (the host laid the compact histogram out: convert_results)
     s->hist_compacted = compacted;
-    s->est_valid = s->est.n != 0;
+    s->est_valid = s->est.n != 0 && !s->have_mask;
     s->finished = true;
     return COV_OK;
 }
@@ -1204,7 +1208,7 @@ cov_status spill_store_impl(cov_session *s, bool &progress) {
     HIPCHK(hipStreamSynchronize(q));
     s->n_records = n_keep; s->n_cigar = cig_keep;
     s->finished = false; s->depth_all_valid = false;
-    if (getenv("COVERM_CLI_TIMING"))
+    if (cov_timing_on())
         fprintf(stderr, "[covermhip] bounded store: spill %u, %llu records left the store (%llu stay: contig %lld in flight), %llu since the sample began\n", S.count,
                 (unsigned long long)keep_from, (unsigned long long)n_keep, (long long)cstar, (unsigned long long)S.records);
     progress = true;
@@ -1381,7 +1385,6 @@ static InflateKernel choose_inflate_kernel(cov_session *s) {
     InflateKernel K;
     const char *ve = getenv("COVERM_INFLATE_V");
     K.version = ve && atoi(ve) == 1 ? 1 : 3;
-    if (const char *sk = getenv("COVERM_INFLATE_SINK")) { K.sink8 = !strcmp(sk, "8"); K.one_unit = !strcmp(sk, "16one"); }      // k_inflate_wave8: pass 3 through the 8-byte sink (rounds 3-4) instead of the 16-byte window
     if (const char *lz = getenv("COVERM_LZ_V")) K.lz_version = atoi(lz) == 1 ? 1 : 2;      // 1: k_lz_resolve (rounds through global memory), 2: k_lz_stage (batches staged in LDS)
     if (K.version == 1) {
         int per_cu = 0;
@@ -1398,8 +1401,6 @@ static InflateKernel choose_inflate_kernel(cov_session *s) {
     // less compressible blocks simply closes earlier
     K.cwin = std::max<u64>((u64)K.round_blocks * 32768u, 1ull << 20);
     if (const char *c = getenv("COVERM_INGEST_CWIN_KB")) { const long v = atol(c); if (v >= 256) K.cwin = (u64)v << 10; }
-    if (const char *e = getenv("COVERM_EXT_PARTS")) K.ext_parts = atoi(e) == 1 ? 1u : covi::EXT_PARTS;      // measurements: the extraction with a lane per segment
-    K.ablate = (u32)(getenv("COVERM_INFLATE_ABLATE") ? atoi(getenv("COVERM_INFLATE_ABLATE")) : 0);      // measurements: stop every block after the tables / pass 1 / pass 2
     return K;
 }
 static inline const InflateKernel &inflate_kernel(cov_session *s) { return s->ing_K; }
@@ -1585,14 +1586,13 @@ static cov_status launch_round_(cov_session *s, uint64_t n64, bool final) {
         if (w >= 3) HIPCHK(hipStreamWaitEvent(s->stream, s->ing_ext_done[w % 3u], 0));
         const u32 grid = (n + 63u) / 64u;
         const uint8_t *comp_bias = s->g_cwin[w % 3u].p - s->ing_round_start;     // blocks carry absolute file offsets
-        const u32 ablate = K.ablate;
         if (K.version == 3)
-            hipLaunchKernelGGL((K.sink8 ? covi::k_inflate_wave8 : K.one_unit ? covi::k_inflate_wave_one : covi::k_inflate_wave), dim3(n), dim3(64), 0, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
-                               tokb.p, ntokb.p, s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
+            hipLaunchKernelGGL(covi::k_inflate_wave, dim3(n), dim3(64), 0, s->stream, comp_bias, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias,
+                               tokb.p, ntokb.p, s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), 0u);
         else
             hipLaunchKernelGGL((covi::k_inflate<INF1_LB, INF1_DB, false>), dim3(grid), dim3(64), covi::inflate_smem_bytes(INF1_LB, INF1_DB), s->stream, comp_bias,
                                (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, out_bias, s->g_scratch.p, tokb.p, ntokb.p,
-                               s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3), ablate);
+                               s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
         HIPCHK(hipEventRecord(s->ing_inf_done[bb], s->stream));
         HIPCHK(hipEventRecord(s->ing_cdone[w % 3u], s->stream));      // this round's compressed buffer may be overwritten (three rounds on)
         HIPCHK(hipStreamWaitEvent(s->ing_aux, s->ing_inf_done[bb], 0));
@@ -1768,7 +1768,7 @@ static cov_status ingest_end_(cov_session *s, uint64_t *n_records_out) {
     HIPCHK(hipMemcpyAsync(glob, s->g_result.p, sizeof glob, hipMemcpyDeviceToHost, s->ing_parse));
     HIPCHK(hipStreamSynchronize(s->ing_parse));
     HIPCHK(hipStreamSynchronize(s->stream));
-    if (getenv("COVERM_CLI_TIMING"))
+    if (cov_timing_on())
         fprintf(stderr, "[covermhip] ingest: %llu blocks in %u windows of %u, device allocations %.3fs; host time in drain %.3fs (waiting for a verification %.3fs), in launches %.3fs (drains inside included), in upload calls %.3fs\n",
                 (unsigned long long)s->ing_blocks, s->ing_batch, K.round_blocks, s->ing_s_alloc, s->ing_s_part[0], s->ing_s_part[3], s->ing_s_part[1], s->ing_s_part[2]);
     const u32 inflate_fail = (u32)(glob[3] & 0xffffffffu);
@@ -2101,7 +2101,6 @@ cov_status cov_copy_depth(cov_session *s, uint32_t tid, int32_t *depth_out) {
     a.depth_out = s->d_depth.p;
     a.tile_base = s->h_tile_first[tid];
     const u32 grid = s->h_tile_first[tid + 1] - s->h_tile_first[tid];
-    HIPCHK(hipMemsetAsync(&s->d_glob.p->chunk_ctr[0], 0, sizeof(u32) * 8 * 16, s->stream));
     launch_any_pileup<false, true>(s, a, grid);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(depth_out, s->d_depth.p, (size_t)L * 4, hipMemcpyDeviceToHost, s->stream));
@@ -2136,7 +2135,6 @@ cov_status cov_interval_stats_compute(cov_session *s, const cov_interval *iv, ui
             HIPCHK(hipMemcpyAsync(s->d_ctg_scratch.p, s->d_ctg.p, (size_t)s->n_targets * sizeof(DevContig), hipMemcpyDeviceToDevice, st));
             a.ctg = s->d_ctg_scratch.p;
             a.depth_out = s->d_depth_all.p; a.depth_off = s->d_depth_off.p; a.tile_base = 0;
-            HIPCHK(hipMemsetAsync(&s->d_glob.p->chunk_ctr[0], 0, sizeof(u32) * 8 * 16, st));
             launch_any_pileup<false, true>(s, a, s->n_tiles);
             HIPCHK(hipGetLastError());
         }
@@ -2289,7 +2287,6 @@ cov_status cov_host_unregister(cov_session *s, void *p) {
 // reads: 0.87-0.88 s on the device's node, 0.99-1.00 s on the other one, 0.90-0.93 s unbound; profiles/r03_reader_sweep_200M.log).
 // Returns the node, or -1 when nothing was changed (one node, no sysfs entry, affinity not permitted, COVERM_NUMA_BIND=0).
 int cov_bind_thread_to_device_node(int device) {
-    if (const char *e = getenv("COVERM_NUMA_BIND")) if (!atoi(e)) return -1;
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
     for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');

@@ -1370,7 +1370,8 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     // (tools/ubench/exit_probe), so the slots are as small as the reader's rate allows: 4 x 32 MiB in 2 MiB chunks read 5 GB in
     // 0.098 s inside the pipeline, 4 x 64 MiB in 4 MiB chunks in 0.114 s (profiles/r03_reader_sweep_50M.log)
     size_t piece = use_map ? (size_t)256 << 20 : (size_t)32 << 20;
-    if (const char *pb = getenv("COVERM_INGEST_PIECE_KB")) { const long v = atol(pb); if (v >= 64) piece = (size_t)v << 10; }
+    const char *piece_env = getenv("COVERM_INGEST_PIECE_KB");      // tests: many small pieces
+    if (piece_env) { const long v = atol(piece_env); if (v >= 64) piece = (size_t)v << 10; }
     // registered so far: [reg_lo0, reg_hi) of the mapping, in whole pages; a piece registers what of its pages is not registered yet
     uint64_t reg_hi = f_lo / PG * PG;
     auto register_piece = [&](uint64_t off, uint64_t n) -> bool {
@@ -1383,7 +1384,7 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     };
     if (use_map && !register_piece(f_lo, map_upfront ? size - f_lo : std::min<uint64_t>(piece, size - f_lo))) {     // refused: staging slots instead
         use_map = false;
-        if (!getenv("COVERM_INGEST_PIECE_KB")) piece = (size_t)32 << 20;
+        if (!piece_env) piece = (size_t)32 << 20;
     }
     const double t_begin = now() - t_start;
     std::vector<cov_bgzf_block> blocks;
@@ -1399,7 +1400,6 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     // chunks well below a piece / threads: a piece ends in a barrier, and with one chunk per thread the slowest thread sets its
     // pace (64 MiB pieces: 4 MiB chunks 0.114 s per 5 GB, 1 MiB chunks 0.091 s; the coordinator hops the blocks that straddle chunks)
     size_t chunk = 512u << 10;
-    if (const char *cb = getenv("COVERM_INGEST_CHUNK_KB")) { const long v = atol(cb); if (v >= 64) chunk = (size_t)v << 10; }
     struct PreBlock { uint64_t hdr; uint32_t bsize, crc, isize; };
     struct PreChunk { uint64_t first = ~0ull, next = 0; std::vector<PreBlock> blocks; };
     const size_t chunks_per_piece = (piece + chunk - 1) / chunk;
@@ -1589,7 +1589,7 @@ extern "C" {
 struct covh_bam { Bam b; };
 
 covh_bam *covh_bam_open(const char *path, int threads, int want_names, char *err, size_t errcap) {
-    const bool timing = getenv("COVERM_BAM_TIMING") != nullptr;
+    const bool timing = covh_timing_on();
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now(), t1 = t0, t2 = t0, t3 = t0;
     covh_bam *h = new covh_bam();
@@ -1895,7 +1895,7 @@ int covh_bam_filter_file(const char *in_path, const char *out_path, const covh_p
     if (n_in) *n_in = 0;
     if (n_out) *n_out = 0;
     const int T = std::max(1, threads);
-    const bool timing = getenv("COVERM_CLI_TIMING") != nullptr;
+    const bool timing = covh_timing_on();
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now(), t_part[5] = {0, 0, 0, 0, 0};
     auto stamp = [&](int k) { const double t = now(); t_part[k] += t - t_prev; t_prev = t; };

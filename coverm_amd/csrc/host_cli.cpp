@@ -115,7 +115,10 @@ struct Sample {
 };
 
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-bool timing_on() { static const bool on = getenv("COVERM_CLI_TIMING") != nullptr; return on; }
+bool timing_on() { return covh_timing_on() != 0; }
+// COVERM_NO_GPU_INGEST: every file through the CPU readers (tests compare the two paths); COVERM_PAIR_ON_HOST: the pair-mode reader filter on the host
+bool no_gpu_ingest() { static const bool v = getenv("COVERM_NO_GPU_INGEST") != nullptr; return v; }
+bool pair_on_host() { static const bool v = getenv("COVERM_PAIR_ON_HOST") != nullptr; return v; }
 
 struct HeaderAhead { covh_bam_header *hd = nullptr; std::string err; };
 
@@ -190,14 +193,14 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
     // pair-mode filtering (filter.rs:117-228) runs on the device over what the device ingest extracted (mate reference + read-name
     // hash per record, cov_pair_filter_apply); only when that path declines the file does the whole file come to the host
     const bool bgzf = is_bgzf(S.path);
-    const bool pair_dev = R.fp && !a.no_stream && !R.per_gene && bgzf && !getenv("COVERM_NO_GPU_INGEST") && !getenv("COVERM_PAIR_ON_HOST");
+    const bool pair_dev = R.fp && !a.no_stream && !R.per_gene && bgzf && !no_gpu_ingest() && !pair_on_host();
     const bool stream = !a.no_stream && (!R.fp || pair_dev) && !R.per_gene && bgzf;
     if (span_count > 1 && !stream) die("--devices with fewer BAM files than devices needs streamable input (BAM, no --gff)");
     S.stoit = stoit_of(S.path); S.streamed = stream && !R.fp;
     const double t0 = now();
     std::vector<uint8_t> mask;
     check(s, cov_reset(s));
-    if (stream && !getenv("COVERM_NO_GPU_INGEST")) {
+    if (stream && !no_gpu_ingest()) {
         // ---- device ingest: the compressed file goes to HBM, the GPU inflates, finds the records and fills its own store
         char err[512] = {0};
         covh_bam_header *hd = nullptr;
@@ -223,7 +226,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         S.t_open = now() - t0;
         uint64_t nrec = 0; double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         check(s, cov_ingest_want_mates(s, R.fp ? 1 : 0));
-        int rc = covh_bam_gpu_ingest_span(S.path.c_str(), threads, s, hd, getenv("COVERM_NO_CRC") ? 0 : 1, span_index, span_count, &nrec, tm, err, sizeof err);
+        int rc = covh_bam_gpu_ingest_span(S.path.c_str(), threads, s, hd, 1, span_index, span_count, &nrec, tm, err, sizeof err);
         if (rc == -2 && span_count > 1) throw SpanUnsorted(err);
         if (rc < 0) die(err);
         uint64_t pair_prim = 0; double t_pair = 0;
@@ -242,7 +245,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         }
         if (rc == 0) {
             S.n_records = nrec; S.device_ingest = true;
-            if (getenv("COVERM_CLI_TIMING"))
+            if (timing_on())
                 fprintf(stderr, "[coverm-amd] %s span %u/%u: device ingest: buffers %.3fs, file read %.3fs, staging waits %.3fs, header walk %.3fs, feed calls %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records, bytes from %s\n",
                         S.stoit.c_str(), span_index, span_count, tm[4], tm[0], tm[1], tm[5], tm[6], tm[2], tm[3], (unsigned long long)nrec,
                         tm[7] == 2 ? "the mapped file (registered up front)" : tm[7] == 1 ? "the mapped file" : "staging slots");
@@ -255,7 +258,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
             S.t_finish = now() - t0 - S.t_ingest;
             return;
         }
-        if (getenv("COVERM_CLI_TIMING")) fprintf(stderr, "[coverm-amd] %s: %s\n", S.stoit.c_str(), err);
+        if (timing_on()) fprintf(stderr, "[coverm-amd] %s: %s\n", S.stoit.c_str(), err);
         check(s, cov_reset(s));       // the CPU reader takes the file
         if (R.fp && span_count > 1) die(std::string("--devices with fewer BAM files than devices and a pair-mode filter needs the device ingest, which declined this file: ") + err);
     }
@@ -276,7 +279,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         if (rc < 0) die(covh_bam_stream_error(st));
         S.n_records = covh_bam_stream_n_records(st);
         S.peak_bytes = covh_bam_stream_peak_bytes(st);
-        if (getenv("COVERM_CLI_TIMING")) {
+        if (timing_on()) {
             double t[5]; covh_bam_stream_timing(st, t);
             fprintf(stderr, "[coverm-amd] %s span %u/%u: stream read %.3fs inflate %.3fs parse %.3fs (coordinator waits: inflate %.3fs parse %.3fs), %llu records, buffers %.0f MB\n",
                     S.stoit.c_str(), span_index, span_count, t[0], t[1], t[2], t[3], t[4], (unsigned long long)S.n_records, S.peak_bytes / 1e6);
@@ -297,7 +300,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
     cov_batch batch; memset(&batch, 0, sizeof batch);
     struct HostRecords { std::vector<int32_t> tid, pos; std::vector<uint16_t> flag; std::vector<uint8_t> mapq, nmk; std::vector<uint32_t> nm, lseq, coff, cig; } hr;
     bool have_records = false, prim_from_host = false;
-    if (R.per_gene && bgzf && !a.no_stream && span_count == 1 && !getenv("COVERM_NO_GPU_INGEST") && !getenv("COVERM_GENES_DECODE_ON_HOST") && !getenv("COVERM_PAIR_ON_HOST")) {
+    if (R.per_gene && bgzf && !a.no_stream && span_count == 1 && !no_gpu_ingest() && !getenv("COVERM_GENES_DECODE_ON_HOST") && !pair_on_host()) {
         covh_bam_header *hd = covh_bam_read_header(S.path.c_str(), err, sizeof err);
         if (!hd) die(err);
         struct HdFree { covh_bam_header *p; ~HdFree() { covh_bam_header_free(p); } } hdfree{hd};
@@ -307,7 +310,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         if (R.by_names) { genome_table(R, S, mask); check(s, cov_set_target_mask(s, mask.data())); }
         check(s, cov_ingest_want_mates(s, R.fp ? 1 : 0));
         uint64_t nrec = 0; double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int rc = covh_bam_gpu_ingest_span(S.path.c_str(), threads, s, hd, getenv("COVERM_NO_CRC") ? 0 : 1, 0, 1, &nrec, tm, err, sizeof err);
+        int rc = covh_bam_gpu_ingest_span(S.path.c_str(), threads, s, hd, 1, 0, 1, &nrec, tm, err, sizeof err);
         if (rc < 0) die(err);
         S.n_records = nrec;
         if (rc == 0 && R.fp) {
@@ -641,7 +644,7 @@ int run_cli(int argc, char **argv) {
         cfg.min_percent_identity = f.pid_single; cfg.min_aligned_percent = f.pct_single;
     }
     const size_t nd = a.devices.size(), nb = a.bams.size();
-    if (!a.no_stream && !R.per_gene && !getenv("COVERM_NO_GPU_INGEST"))
+    if (!a.no_stream && !R.per_gene && !no_gpu_ingest())
         for (size_t i = 0; i < std::min<size_t>(nb, std::max<size_t>(nd, 2)); i++) {      // (the file type is checked by covh_bam_read_header itself)
             const std::string path = a.bams[i];
             if (R.hdr_ahead.count(path) || !is_bgzf(path)) continue;
@@ -682,10 +685,10 @@ int run_cli(int argc, char **argv) {
     covh_bam_set_pinned(1);
     // (measured, profiles/r03_tail_variants.log: releasing the staging slots beside the last rounds shortens the exit by ~0.03 s and
     // lengthens the tail by as much — hipHostFree waits for the device — so it stays opt-in)
-    covh_bam_set_release_staging(getenv("COVERM_RELEASE_STAGING") && atoi(getenv("COVERM_RELEASE_STAGING")) && nb <= nd ? 1 : 0);
+    covh_bam_set_release_staging(0);
     if (nb > 1) covh_bam_set_buffer_cache(1);
     covh_bam_set_concurrent_feeders((int)std::min(nd, span_mode_feeders(nb, nd)));      // > 2 at once: mapped files, registered up front (host memory traffic / 3)
-    const bool timing = getenv("COVERM_CLI_TIMING") != nullptr;
+    const bool timing = timing_on();
     std::vector<Sample> samples(nb);
     for (size_t i = 0; i < nb; i++) samples[i].path = a.bams[i];
     std::mutex err_mutex; std::string first_error;
@@ -720,9 +723,6 @@ int run_cli(int argc, char **argv) {
             });
         for (auto &t : th) t.join();
         if (!first_error.empty()) die(first_error);
-        if (nd > 1 && getenv("COVERM_GATHER_CHECK")) {   // exercise the RCCL gather on the last sample of each device (results must agree)
-            check(sess[0], cov_gather(sess.data(), (uint32_t)lanes, 0));
-        }
     } else {
         // every BAM cut into nd tid spans; the per-contig result blocks meet on device 0 through one RCCL gather
         const int thr = std::min(std::max(1, a.threads), std::max(6, a.threads / (int)nd));      // (as above)

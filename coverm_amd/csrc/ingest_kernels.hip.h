@@ -258,7 +258,7 @@ __device__ __forceinline__ int decode_sym(BitReader &br, const Huff &H, int lane
 template <int INF_LIT_BITS, int INF_DIST_BITS, bool SORT8>
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
                                                 uint8_t *__restrict__ out, uint8_t *__restrict__ scratch, tokpos_t *__restrict__ tok,
-                                                u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 ablate) {
+                                                u32 *__restrict__ n_tok, u32 *__restrict__ status, u32 *__restrict__ n_failed) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     constexpr int INF_LIT_N = 1 << INF_LIT_BITS;
     const int lane = threadIdx.x & 63;
@@ -287,8 +287,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
             uint8_t *d = dst + pos - on;
             // one 8-byte store: the zero bytes behind the literals land on positions this lane (later literals) or k_lz_resolve
             // (the match that follows) writes afterwards; byte stores only where the 8 bytes would leave the block
-            if (ablate & 1u) {}
-            else if (pos - on + 8u <= B.isize) __builtin_memcpy(d, &obuf, 8);
+            if (pos - on + 8u <= B.isize) __builtin_memcpy(d, &obuf, 8);
             else for (u32 k = 0; k < on; k++) d[k] = (uint8_t)(obuf >> (8u * k));
             obuf = 0; on = 0;
         }
@@ -385,7 +384,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
                     if (pos >= B.isize) { err = INF_ERR_SIZE; break; }
                     obuf |= (u64)(u32)sym << (8u * on);
                     on++; pos++;
-                    if (on == 8u) { if (!(ablate & 1u)) __builtin_memcpy(dst + pos - 8u, &obuf, 8); obuf = 0; on = 0; }
+                    if (on == 8u) { __builtin_memcpy(dst + pos - 8u, &obuf, 8); obuf = 0; on = 0; }
                     continue;
                 }
                 flush_out();
@@ -404,7 +403,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
                 // (no refill here: the one in front of the distance code left >= 33 bits, a code and its extra bits take <= 28)
                 const u32 dist = (dsu < 4u ? 1u + dsu : 1u + ((2u + (dsu & 1u)) << de)) + (de ? br.take(de) : 0u);
                 if (dist > pos || pos + len > B.isize || nt >= INF_TOK_CAP) { err = INF_ERR_FORMAT; break; }
-                if (!(ablate & 2u)) {
+                {
                     tbuf |= (u64)pos << (16u * (nt & 3u));
                     if ((nt & 3u) == 3u) { __builtin_memcpy(my_tok + (nt - 3u), &tbuf, 8); tbuf = 0; }
                     const u32 t24 = (dist - 1u) | ((len - 3u) << 15);
@@ -421,7 +420,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
         flush_out();
         if (err == INF_OK && pos != B.isize) err = INF_ERR_SIZE;
     }
-    if ((nt & 3u) && !(ablate & 2u)) __builtin_memcpy(my_tok + (nt & ~3u), &tbuf, 8);     // INF_TOK_CAP is a multiple of four: the store stays inside the block's list
+    if (nt & 3u) __builtin_memcpy(my_tok + (nt & ~3u), &tbuf, 8);     // INF_TOK_CAP is a multiple of four: the store stays inside the block's list
     n_tok[b] = err == INF_OK ? nt : 0u;
     status[b] = err;
     if (err != INF_OK) atomicAdd(n_failed, 1u);
@@ -473,19 +472,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 }
 // (Up to two and three more literals per lock-step were measured as well — 18.0 and 20.3 ms per full round against 17.1 with one more, ingest
 // of 100 M reads 0.339 / 0.328 s against 0.320, profiles/r05_extra_literals_*.log: every further literal slot is another dependent table
-// lookup, and a refill, in the path every lock-step takes.  One more it is.)
-// COVERM_INFLATE_SINK=16one: one unit per lock-step (no second literal), the measurement's other side
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_inflate_wave_one(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
-                                                     uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
-                                                     u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
-    inflate_wave_body<covw::Sink16, 0>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);
-}
-// The same with the 8-byte sink of rounds 3-4 (COVERM_INFLATE_SINK=8): the measurement's other side, and a second store policy under the tests.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_inflate_wave8(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, u32 n_blocks,
-                                                     uint8_t *__restrict__ out, tokpos_t *__restrict__ tok, u32 *__restrict__ n_tok,
-                                                     u32 *__restrict__ status, u32 *__restrict__ n_failed, u32 stop_after) {
-    inflate_wave_body<covw::Sink, 0>(comp, blocks, n_blocks, out, tok, n_tok, status, n_failed, stop_after);
-}
+// lookup, and a refill, in the path every lock-step takes.  One more it is.  The builds with one unit per lock-step and with the 8-byte sink
+// of rounds 3-4 — the measurements' other sides — left the library in round 6; csrc/inflate_wave_core.h still takes both as template
+// arguments and tests/test_inflate_wave_core.py runs them on the CPU.)
 // (Held to 96 registers = five waves per SIMD, one spilled register: 24.5 ms per round against 22.3 on the same box, profiles/r04_waves5_lzscope.log.)
 
 // Inclusive wave64 prefix sum (DPP row shifts + row broadcasts; VALU latency only).
@@ -1093,6 +1082,12 @@ __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__
     // instead of four partial-line stores each: the lanes of a wave write ~100 bytes apart, and a line that is written four bytes at a
     // time is evicted several times before it is complete (5.0 GB of WRITE_SIZE for 0.9 GB of store output in round 4's counters).
     // Mate columns (pair-mode filters only) are written one record at a time as before.
+    // The store's columns are addressed at an arbitrary record index, so the wide stores below are only as aligned as the column's element type
+    // (4, 2, 1 bytes): they go through vector types DECLARED with that alignment (gfx950 global memory takes unaligned accesses; the
+    // compiler must not be told 16).
+    typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef u32 u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
+    typedef u32 u32_a1 __attribute__((aligned(1)));
     __shared__ __attribute__((aligned(16))) u32 lbuf[64][32];      // per lane: tid[4] pos[4] l_seq[4] cigar_off[4] nm[4] flag[4 x u16] mapq[4 x u8] nm_kind[4 x u8] | 8 CIGAR words
     u32 *B = lbuf[threadIdx.x & 63];
     u32 *Cw = B + 24;          // CIGAR words of the lane's records, consecutive in the store like the records: they leave four at a time too
@@ -1100,7 +1095,7 @@ __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__
     auto flush_cigar = [&](u64 ci_now, bool all) {
         u64 at = ci_now - ncw;
         u32 done = 0;
-        while (ncw - done >= 4u) { *reinterpret_cast<uint4 *>(R.cigar + at + done) = make_uint4(Cw[done], Cw[done + 1], Cw[done + 2], Cw[done + 3]); done += 4u; }
+        while (ncw - done >= 4u) { const u32x4_a4 v = {Cw[done], Cw[done + 1], Cw[done + 2], Cw[done + 3]}; *reinterpret_cast<u32x4_a4 *>(R.cigar + at + done) = v; done += 4u; }
         if (all) { for (; done < ncw; done++) R.cigar[at + done] = Cw[done]; ncw = 0; }
         else { const u32 left = ncw - done; for (u32 x = 0; x < left; x++) Cw[x] = Cw[done + x]; ncw = left; }
     };
@@ -1109,14 +1104,15 @@ __global__ __launch_bounds__(64) void k_bam_extract(BamScan S, const SegInfo *__
     u32 nb = 0;
     auto flush = [&](u64 at) {       // the buffered records are records at .. at + nb - 1 of the store
         if (nb == 4u) {
-            *reinterpret_cast<uint4 *>(R.tid + at) = *reinterpret_cast<const uint4 *>(B);
-            *reinterpret_cast<uint4 *>(R.pos + at) = *reinterpret_cast<const uint4 *>(B + 4);
-            *reinterpret_cast<uint4 *>(R.l_seq + at) = *reinterpret_cast<const uint4 *>(B + 8);
-            *reinterpret_cast<uint4 *>(R.cigar_off + at) = *reinterpret_cast<const uint4 *>(B + 12);
-            *reinterpret_cast<uint4 *>(R.nm + at) = *reinterpret_cast<const uint4 *>(B + 16);
-            *reinterpret_cast<uint2 *>(R.flag + at) = *reinterpret_cast<const uint2 *>(B + 20);
-            *reinterpret_cast<u32 *>(R.mapq + at) = B[22];
-            *reinterpret_cast<u32 *>(R.nm_kind + at) = B[23];
+            const u32x4_a4 *B4 = reinterpret_cast<const u32x4_a4 *>(B);      // (the LDS side IS 16-byte aligned)
+            *reinterpret_cast<u32x4_a4 *>(R.tid + at) = B4[0];
+            *reinterpret_cast<u32x4_a4 *>(R.pos + at) = B4[1];
+            *reinterpret_cast<u32x4_a4 *>(R.l_seq + at) = B4[2];
+            *reinterpret_cast<u32x4_a4 *>(R.cigar_off + at) = B4[3];
+            *reinterpret_cast<u32x4_a4 *>(R.nm + at) = B4[4];
+            { const u32x2_a2 v = {B[20], B[21]}; *reinterpret_cast<u32x2_a2 *>(R.flag + at) = v; }
+            *reinterpret_cast<u32_a1 *>(R.mapq + at) = B[22];
+            *reinterpret_cast<u32_a1 *>(R.nm_kind + at) = B[23];
         } else {
             for (u32 x = 0; x < nb; x++) {
                 R.tid[at + x] = (int32_t)B[x]; R.pos[at + x] = (int32_t)B[4 + x]; R.l_seq[at + x] = B[8 + x]; R.cigar_off[at + x] = B[12 + x];

@@ -67,7 +67,7 @@ struct DevGlobal {
     u64 pad2[2];
     u64 prim_slots[COUNTER_SLOTS * 8];  // sum = num_detected_primary_alignments (bam_generator.rs:114-118)
     u64 cons_slots[COUNTER_SLOTS * 8];  // sum = number of considered records
-    u32 chunk_ctr[8 * 16];              // k_pileup_stream work queues: one dequeue counter per shard, 64 B apart
+    u32 pad_q[8 * 16];                  // (k_pileup_stream's work-queue counters until round 6; kept so that the block's size does not change)
 };
 
 struct FilterCfg {
@@ -221,7 +221,6 @@ __global__ void k_init(DevContig *ctg, u32 n_targets, DevGlobal *g, TileIdx ti, 
         g->n_cx = 0; g->cx_total = 0; g->n_slow = 0; g->n_gen = 0;
     }
     if (c < COUNTER_SLOTS * 8) { g->prim_slots[c] = 0; g->cons_slots[c] = 0; }
-    if (c < 8 * 16) g->chunk_ctr[c] = 0;
     if (c >= n_targets) return;
     DevContig z;
     z.n_primary = z.n_pass = z.n_nonsupp = z.sum_nm = z.sum_indel = 0;
@@ -1362,7 +1361,6 @@ struct PileupArgs {
     int32_t *depth_out;   // WRITE_DEPTH: depth of one contig, or of every contig when depth_off is set
     const u64 *depth_off; // WRITE_DEPTH over all tiles: offset of each contig in depth_out (NULL = depth_out is one contig)
     u32 tile_base;        // first tile index handled by blockIdx 0
-    u32 ablate;           // experiment knob (COVERM_ABLATE): 1 no events, 2 no stats loop, 4 no hist, 8 no result atomics
 };
 
 constexpr size_t pileup_smem_bytes(int tile, int nt, bool hist) {
@@ -1416,7 +1414,6 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
             if (e < hi) atomicAdd(&tile[e - lo], -1);
         }
     };
-    if (!(a.ablate & 1u))
     for (u32 i = ds.x + tid; i < ds.y; i += NT) {
         const uint2 rw = a.runs[i];
         if (rw.y == 0u) continue;
@@ -1439,7 +1436,6 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
             }
         }   // RW_BUCKET: delivered through the tile's bucket below
     }
-    if (!(a.ablate & 1u))
     for (u32 j = tid; j < ds1.w; j += NT) { const uint2 q = a.cx_runs[(u64)ds1.z + j]; add_run(q.x, q.y); }
     __syncthreads();
 
@@ -1483,7 +1479,7 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
     };
 #pragma unroll
     for (int rr = 0; rr < ROWS; rr++) {
-        if (rr >= rows_used || (a.ablate & 2u)) break;
+        if (rr >= rows_used) break;
         const int base = __shfl(pre, rr * NW + w) + ex[rr];
         const u32 p0 = lo + 4u * (u32)(rr * NT + tid);
         const int dl[4] = {v[rr].x, v[rr].y, v[rr].z, v[rr].w};
@@ -1558,7 +1554,7 @@ __global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
         a0 = wave_sum_u64(a0); a1 = wave_sum_u64(a1);
         b0 = wave_sum_u32(b0); b1 = wave_sum_u32(b1);
         b2 = wave_min_u32(b2); b3 = wave_max_u32(b3);
-        if (lane == 0 && !(a.ablate & 8u)) {
+        if (lane == 0) {
             if (a0) atomicAdd(&C->sum_d, a0);
             if (a1) atomicAdd(&C->sum_d2, a1);
             if (b0) atomicAdd(&C->cov_win, (u64)b0);
@@ -1665,31 +1661,12 @@ __global__ __launch_bounds__(256) void k_pileup_stream(PileupArgs a, u32 n_tiles
         r0 = i0 < d.y ? a.runs[i0] : make_uint2(0u, 0u);
         r1 = i1 < d.y ? a.runs[i1] : make_uint2(0u, 0u);
     };
-    // Dynamic scheduling: depth is heavy-tailed across contigs, so chunks differ in cost by >10x and any static
-    // assignment leaves the launch waiting for its unluckiest wave.  Chunks are handed out from 8 sharded
-    // counters (one per XCD-sized slice of the chunk range, 64 B apart); a wave drains its home shard, then
-    // steals from the others.  The NEXT chunk id is requested before the current chunk is processed, so the
-    // ~1 us dequeue latency is hidden.
+    // Static round-robin over chunks.  (Chunks handed out from eight sharded counters — a wave draining its home shard, then stealing — were
+    // built in round 2 and measured ~10 % slower on the benchmark workload: dequeue latency, hot counters.  Removed in round 6.)
     const u32 n_chunks = (n_tiles + chunk_tiles - 1) / chunk_tiles;
-    const u32 shard_sz = (n_chunks + 7u) / 8u;
-    u32 shard = blockIdx.x & 7u, tried = 0;
-    auto dequeue = [&]() -> u32 {   // returns a chunk id, or 0xffffffff when every shard is empty
-        for (;;) {
-            u32 c = 0;
-            if (lane == 0) c = atomicAdd(&a.g->chunk_ctr[shard * 16u], 1u);
-            c = __builtin_amdgcn_readfirstlane(c);
-            const u32 base = shard * shard_sz;
-            if (c < shard_sz && base + c < n_chunks) return base + c;
-            if (++tried >= 8u) return 0xffffffffu;
-            shard = (shard + 1u) & 7u;
-        }
-    };
-    // a.ablate bit 5 (COVERM_ABLATE=32) selects the dynamic queue; the default is static round-robin over
-    // chunks, which measured ~10 % faster on the benchmark workload (no dequeue latency, no hot counters).
-    const bool dynamic = a.ablate & 32u;
-    u32 ch = dynamic ? dequeue() : (wave_id < n_chunks ? wave_id : 0xffffffffu);
+    u32 ch = wave_id < n_chunks ? wave_id : 0xffffffffu;
     while (ch != 0xffffffffu) {
-        const u32 ch_next = dynamic ? dequeue() : (ch + n_waves < n_chunks ? ch + n_waves : 0xffffffffu);
+        const u32 ch_next = ch + n_waves < n_chunks ? ch + n_waves : 0xffffffffu;
         const u32 t0 = a.tile_base + ch * chunk_tiles, t1 = a.tile_base + min((ch + 1) * chunk_tiles, n_tiles);
         for (u32 tq = t0; tq < t1; tq++) {
             const u32 t = tile_list != nullptr ? tile_list[tq] : tq;

@@ -18,7 +18,7 @@
 //     three CIGAR operations (all but ~2 % of the steps of a 5 000-contig short-read sample): the contig's length, first tile and mask bit
 //     are scalar registers, no record starts or ends a group, every per-contig counter is a wave total in a scalar register (ballot +
 //     popcount, first / last record by s_ff1 / s_flbit).  Any other step — a contig border, the store's first or last records, a longer
-//     CIGAR — is put on a list and left WHOLE to k_prep_generic, a second small launch that does such steps per lane with atomics (the old
+//     CIGAR — is flagged and left WHOLE to k_prep_generic, a second small launch that does such steps per lane with atomics (the old
 //     body's logic for one step); its registers and its arguments cost the loop nothing (an out-of-line call inside the loop was built
 //     first: the call's register convention put the loop's own values into scratch);
 //   * the tile index no longer counts records per tile with a per-lane "how many lanes follow me" (64-bit shifts per lane): a record whose
@@ -309,6 +309,7 @@ __device__ __forceinline__ void lean_flush(DevContig *ctg, int cur, LeanAcc &a) 
 template <bool WANT_IDENTITY, bool FILTER, bool MASKED>
 __device__ __forceinline__ void prep_lean_body(const PrepHot &h, const PrepArgs *__restrict__ pa) {
     __shared__ u32 blk_cnt[2][4];
+    __shared__ u32 wmask[4];
     __shared__ PrepPartial wpart[4];
     const PrepCold *cold = &pa->cold;
     const int lane = lane_id();
@@ -319,6 +320,7 @@ __device__ __forceinline__ void prep_lean_body(const PrepHot &h, const PrepArgs 
     LeanAcc acc; acc.reset();
     int cur = -1;                 // contig the running sums belong to
     u32 g_prim = 0, g_cons = 0;
+    u32 left_mask = 0;            // bit s: step s of this wave's records is left to k_prep_generic (h.steps <= 32)
 
     if (base < h.n) {
         const u32 nlast = h.n - 1u;
@@ -332,7 +334,7 @@ __device__ __forceinline__ void prep_lean_body(const PrepHot &h, const PrepArgs 
 
         int ptid_e = -2, ppos_e = 0;                   // the record in front of this step's first one
         if (base > 0) { ptid_e = h.tid[base - 1u]; ppos_e = h.pos[base - 1u]; }
-        int cur_tid = -1; u32 cur_L = 0, cur_t0 = 0, cur_mk = 1u;      // the contig of the last common step: length, first tile, mask bit
+        u32 cur_L = 0, cur_t0 = 0, cur_mk = 1u;      // the contig `cur` of the last common step: length, first tile, mask bit
         // the two roots of the dependent loads, one step ahead
         int td; u32 co0;
         { const u32 l = (u32)lane; td = tid_w[min(l, lmax) & LM]; co0 = coff_w[min(l, lmax + 1u) & LM]; }
@@ -379,12 +381,16 @@ __device__ __forceinline__ void prep_lean_body(const PrepHot &h, const PrepArgs 
             common = common && __ballot(nops_all > 3u || moved) == 0ull;
             CigSum cs;
             if (common) {
-                if (tu != cur_tid) { cur_tid = tu; cur_L = cold->tlen[tu]; cur_t0 = cold->tile_first[tu]; cur_mk = MASKED ? (u32)cold->mask[tu] : 1u; }
+                if (tu != cur) {      // a new contig: the running sums of the one before leave, this one's length, first tile and mask bit come in
+                    if (cur >= 0) flushed_early = true;
+                    lean_flush(cold->ctg, cur, acc); cur = tu;
+                    cur_L = cold->tlen[tu]; cur_t0 = cold->tile_first[tu]; cur_mk = MASKED ? (u32)cold->mask[tu] : 1u;
+                }
                 cigar_sum3(0u < nops_all ? cw0 : 4u, 1u < nops_all ? cw1 : 4u, 2u < nops_all ? cw2 : 4u, pos, cur_L, cs);
                 common = __ballot(cs.big) == 0ull;           // (an operation of >= 2^24 bases: the literal 64-bit walk)
             }
-            if (!common) {      // left to k_prep_generic
-                if (lane == 0) { DevGlobal *g = cold->g; cold->gen_list[atomicAdd(&g->n_gen, 1u)] = i0; }
+            if (!common) {      // left to k_prep_generic: a bit in the wave's mask (a scalar register; stored once, behind the loop)
+                left_mask |= 1u << (s & 31u);
                 ptid_e = __builtin_amdgcn_readlane(td, 63);
                 ppos_e = full ? h.pos[i0 + 63u] : 0;
                 td = tdn; co0 = con;
@@ -460,7 +466,6 @@ __device__ __forceinline__ void prep_lean_body(const PrepHot &h, const PrepArgs 
             const u64 cm = __ballot(considered);
             if (cm != 0ull) {
                 g_cons += (u32)__popcll(cm);
-                if (tu != cur) { if (cur >= 0) flushed_early = true; lean_flush(cold->ctg, cur, acc); cur = tu; }
                 acc.prim += (u32)__popcll(__ballot(considered && !(flag & 0x900u)));
                 acc.pass += (u32)__popcll(cm);
                 acc.nons += (u32)__popcll(__ballot(considered && !supp));
@@ -483,8 +488,27 @@ __device__ __forceinline__ void prep_lean_body(const PrepHot &h, const PrepArgs 
         pw.nm = wave_sum_u64(acc.nm); pw.indel = wave_sum_u64(acc.indel); pw.pad = 0;
         if (lane == 0) wpart[w] = pw;
     }
-    if (lane == 0) { blk_cnt[0][w] = g_prim; blk_cnt[1][w] = g_cons; }
+    if (lane == 0) { blk_cnt[0][w] = g_prim; blk_cnt[1][w] = g_cons; wmask[w] = left_mask; }
     __syncthreads();
+    // The steps this workgroup leaves to k_prep_generic go on its list with ONE atomic per workgroup (most workgroups of a 5 000-contig sample
+    // have none).  (One atomic per STEP was built first: 15 000 appends at 5 000 contigs went unnoticed, 300 000 at 200 000 contigs
+    // serialised on the counter's cache line and this kernel took 1.6 ms instead of 0.33 — profiles/r06_c200k_kernel_stats.csv; a flag per
+    // step and a mask per wave, read by k_prep_generic itself, left that kernel with 64 x fewer busy waves: 0.11 ms instead of 0.014.)
+    if (w == 0u) {
+        const u32 m0 = wmask[0], m1 = wmask[1], m2 = wmask[2], m3 = wmask[3];
+        const u32 c0 = (u32)__popc(m0), c1 = c0 + (u32)__popc(m1), c2 = c1 + (u32)__popc(m2), total = c2 + (u32)__popc(m3);
+        if (total) {
+            u32 at = 0;
+            if (lane == 0) at = atomicAdd(&cold->g->n_gen, total);
+            at = (u32)__builtin_amdgcn_readfirstlane((int)at);
+            for (u32 e = (u32)lane; e < total; e += 64u) {      // entry e: the (e - c_{k-1})-th set bit of wave k's mask
+                const u32 k = e < c0 ? 0u : e < c1 ? 1u : e < c2 ? 2u : 3u;
+                u32 m = k == 0u ? m0 : k == 1u ? m1 : k == 2u ? m2 : m3;
+                for (u32 r = e - (k == 0u ? 0u : k == 1u ? c0 : k == 2u ? c1 : c2); r != 0u; r--) m &= m - 1u;
+                cold->gen_list[at + e] = (blockIdx.x * 4u + k) * wave_recs + (u32)__builtin_ctz(m) * 64u;
+            }
+        }
+    }
     bool uniform_wg = true;
     {
         int t0 = -1;
@@ -523,9 +547,8 @@ template <bool WANT_IDENTITY, bool FILTER, bool MASKED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_prep_lean(PrepHot h, const PrepArgs *__restrict__ pa) {
     prep_lean_body<WANT_IDENTITY, FILTER, MASKED>(h, pa);
 }
-
-// The steps k_prep_lean listed: waves stride over the list, a whole wave per step.  all_steps != 0: every step of the store, no list (the
-// host launches this kernel alone when the sample has so many contigs that few steps would be common ones).
+// The steps k_prep_lean listed: waves stride over the list, a whole wave per step.  all_steps != 0: every step of the store, no list (the host
+// launches this kernel alone when the sample has so many contigs that few steps would be common ones).
 template <bool WANT_IDENTITY, bool FILTER, bool MASKED>
 __global__ __launch_bounds__(256) void k_prep_generic(const PrepArgs *__restrict__ pa, u32 all_steps) {
     const u32 n = all_steps ? all_steps : pa->cold.g->n_gen;

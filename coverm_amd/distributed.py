@@ -170,12 +170,21 @@ def wait_for_root(dist, rank: int, key: str = "coverm_root_done", minutes: float
     own multi-device legs on those very GPUs.  True when the store was used; on any failure of that path the caller's next barrier still
     orders the ranks (the store is an optimisation of WHERE they wait, not of correctness)."""
     import datetime
+    import sys
+    # every call of a process uses its own key (the calls of all ranks pair up in order): a key that was set once would let the second wait
+    # on it return at once
+    n = _WAIT_CALLS[key] = _WAIT_CALLS.get(key, 0) + 1
+    k = "%s#%d" % (key, n)
     try:
         store = dist.distributed_c10d._get_default_store()
         if rank == root:
-            store.set(key, "1")
+            store.set(k, "1")
         else:
-            store.wait([key], datetime.timedelta(minutes=minutes))
+            store.wait([k], datetime.timedelta(minutes=minutes))
         return True
-    except Exception:
+    except Exception as ex:      # (a real timeout included: say so, the caller's barrier still orders the ranks)
+        print("[coverm_amd.distributed] wait_for_root(%s): %s: %s" % (k, type(ex).__name__, str(ex)[:200]), file=sys.stderr, flush=True)
         return False
+
+
+_WAIT_CALLS = {}

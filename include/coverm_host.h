@@ -155,6 +155,8 @@ void covh_bam_set_pinned(int on);
  * that reads no further file; page-locked memory still held at process exit costs ~0.13 s per GiB).  Default 0: the slots are parked for
  * the next file. */
 void covh_bam_set_release_staging(int on);
+/* 1 when COVERM_CLI_TIMING is set: the library's and the host layer's timing stamps go to stderr (read once per process). */
+int covh_timing_on(void);
 /* How many device ingests (covh_bam_gpu_ingest*) the caller runs at once, one per GPU.  With more than two and no COVERM_INGEST_IO the
  * file is mapped and its span registered with the device once, up front, instead of copied through page-locked staging slots: N feeders
  * share one host memory system, and a staged byte crosses it three times, a mapped one once (unmeasured on more

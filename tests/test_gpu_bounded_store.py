@@ -148,6 +148,81 @@ def test_device_ingest_through_the_binary_with_small_windows_and_caps(tmp_path):
     assert binary.run("genome", [path], env=env, **args) == O.run_cli("genome", [path], bams=[b], **args)
 
 
+def test_reset_in_the_middle_of_an_ingest_that_already_spilled(tmp_path, monkeypatch):
+    """cov_reset on a session whose open device ingest has already spilled part of its file.  The abort it runs first
+    answers COV_ERR_STATE ("cov_reset the session") — which IS this call: it must go on and clear the store, the spill and the merged state, and
+    the session must then take a sample as if nothing had happened.  Drives the raw cov_ingest_* calls of include/covermhip.h (what
+    covh_bam_gpu_ingest does) with the file's own BGZF block table."""
+    import zlib
+    for k, v in dict(CAPS, COVERM_INGEST_ROUND_BLOCKS="64").items():
+        monkeypatch.setenv(k, v)
+    ref, batch = short_sample(220_000, 120, seed=141)
+    path = _bam(tmp_path, ref, batch, "reset")
+    raw = open(path, "rb").read()
+
+    class Blk(C.Structure):
+        _fields_ = [("in_off", C.c_uint64), ("out_off", C.c_uint64), ("in_len", C.c_uint32), ("isize", C.c_uint32), ("crc", C.c_uint32), ("pad", C.c_uint32)]
+    blocks, ends, off, out = [], [], 0, 0
+    while off < len(raw):
+        assert raw[off:off + 4] == b"\x1f\x8b\x08\x04" and raw[off + 12:off + 16] == b"BC\x02\x00"      # our writer's 18-byte BGZF header
+        bsize = int.from_bytes(raw[off + 16:off + 18], "little") + 1
+        isize = int.from_bytes(raw[off + bsize - 4:off + bsize], "little")
+        if isize:
+            blocks.append((off + 18, out, bsize - 26, isize, int.from_bytes(raw[off + bsize - 8:off + bsize - 4], "little")))
+            ends.append(off + bsize)
+        out += isize
+        off += bsize
+    head = b""
+    for b in blocks[:64]:      # the BAM header: magic, l_text, text, n_ref, references
+        head += zlib.decompress(raw[b[0]:b[0] + b[2]], -15)
+    l_text = int.from_bytes(head[4:8], "little"); p = 8 + l_text
+    n_ref = int.from_bytes(head[p:p + 4], "little"); p += 4
+    for _ in range(n_ref):
+        p += 4 + int.from_bytes(head[p:p + 4], "little") + 4
+    first_record = p
+
+    with Session(0, FilterConfig(), 75, want_hist=True) as s:
+        L = s._lib
+        L.cov_ingest_begin.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+        L.cov_ingest_slot_wait.argtypes = [C.c_void_p, C.c_int]
+        L.cov_ingest_feed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32]
+        s.set_targets(ref.lengths)
+        assert L.cov_ingest_begin(s._h, len(raw), first_record, 1) == 0
+        buf = C.create_string_buffer(raw, len(raw))
+        step = 48                                     # blocks per piece: a window (64 blocks) closes every other piece
+        fed, k = 0, 0
+        for lo in range(0, len(blocks) * 3 // 4, step):      # three quarters of the file: the ingest stays open
+            hi = min(lo + step, len(blocks))
+            arr = (Blk * (hi - lo))(*[Blk(*b, 0) for b in blocks[lo:hi]])
+            assert L.cov_ingest_slot_wait(s._h, k % 4) == 0
+            assert L.cov_ingest_feed(s._h, k % 4, C.byref(buf, fed), fed, ends[hi - 1] - fed, arr, hi - lo) == 0, L.cov_last_error(s._h)
+            fed = ends[hi - 1]; k += 1
+        import time
+        t0 = time.time()
+        while spills(s) == 0 and time.time() - t0 < 20:      # the windows are verified and extracted as further calls drain them
+            assert L.cov_ingest_slot_wait(s._h, 0) == 0
+            lo = hi; hi = min(lo + 8, len(blocks))
+            if lo >= hi:
+                break
+            arr = (Blk * (hi - lo))(*[Blk(*b, 0) for b in blocks[lo:hi]])
+            assert L.cov_ingest_feed(s._h, 0, C.byref(buf, fed), fed, ends[hi - 1] - fed, arr, hi - lo) == 0
+            fed = ends[hi - 1]
+        assert spills(s) >= 1, "the ingest did not spill: the test needs smaller caps"
+        s.reset()                                      # COV_OK (Session.reset raises otherwise)
+        assert spills(s) == 0
+        # the session is as good as new: the whole sample, pushed, equals the oracle
+        s.push(batch)
+        st, summ = s.finish()
+        hist = s.hist()
+        assert int(summ.n_records) == batch.n_records
+    with Session(0, FilterConfig(), 75, want_hist=True) as s2:      # a fresh session on the same sample
+        s2.set_targets(ref.lengths)
+        s2.push(batch)
+        st2, summ2 = s2.finish()
+        assert st.tobytes() == st2.tobytes() and (hist == s2.hist()).all() and int(summ.n_considered) == int(summ2.n_considered)
+    compare(to_bamdata(batch, ref.lengths, ref.names), excl=75, chunks=3)
+
+
 def merge_sorted(a, b):
     """Two record batches merged into one coordinate-sorted batch."""
     tid = np.concatenate([a.tid, b.tid]); pos = np.concatenate([a.pos, b.pos])

@@ -18,17 +18,16 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar")
 
 
-@pytest.fixture(autouse=True, params=["default", "lane-per-block", "lz-rounds", "sink-8", "sink-16one"])
+@pytest.fixture(autouse=True, params=["default", "lane-per-block", "lz-rounds"])
 def inflate_version(request, monkeypatch):
     """Every test of this file runs with the kernels that ship (k_inflate_wave: one wave per BGZF block; k_lz_stage: the matches of a
     batch resolved in LDS), with the second inflate implementation (k_inflate: one lane per block) and with the second match
-    resolution (k_lz_resolve: rounds through global memory) and with k_inflate_wave's two other builds (k_inflate_wave8: pass 3's 8-byte store policy; k_inflate_wave_one: one unit per lock-step).  cov_ingest_begin reads the switches, so sessions of one process may differ."""
+    resolution (k_lz_resolve: rounds through global memory).  cov_ingest_begin reads the switches, so sessions of one process may differ.
+    (k_inflate_wave's builds with the 8-byte sink and with one unit per lock-step left the library in round 6; the CPU emulation of
+    csrc/inflate_wave_core.h still runs both, tests/test_inflate_wave_core.py.)"""
     monkeypatch.delenv("COVERM_INFLATE_V", raising=False)
     monkeypatch.delenv("COVERM_LZ_V", raising=False)
-    monkeypatch.delenv("COVERM_INFLATE_SINK", raising=False)
-    if request.param in ("sink-8", "sink-16one"):
-        monkeypatch.setenv("COVERM_INFLATE_SINK", request.param[5:])
-    elif request.param == "lane-per-block":
+    if request.param == "lane-per-block":
         monkeypatch.setenv("COVERM_INFLATE_V", "1")
     elif request.param == "lz-rounds":
         monkeypatch.setenv("COVERM_LZ_V", "1")
@@ -76,18 +75,6 @@ def test_device_ingest_equals_cpu_reader(tmp_path, monkeypatch, with_seq, piece_
     b = synth.make_reads(ref, 120_000, seed=19)
     p = str(tmp_path / "s.bam")
     cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=with_seq, threads=4)
-    w = _check(p)
-    np.testing.assert_array_equal(w.records.pos, b.pos)
-
-
-def test_extraction_with_a_lane_per_segment(tmp_path, monkeypatch):
-    """COVERM_EXT_PARTS=1: k_bam_extract walks a segment's whole chain with one lane (the default gives every quarter of it, cut where
-    k_bam_hop says, to a lane of its own).  Kept for measurements (profiles/r04_extract_parts_ab_200M.log); same records either way."""
-    monkeypatch.setenv("COVERM_EXT_PARTS", "1")
-    ref = synth.make_reference(40, 6_000_000, seed=18, min_len=5000, max_len=800_000)
-    b = synth.make_reads(ref, 120_000, seed=19)
-    p = str(tmp_path / "s.bam")
-    cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=2, threads=4)
     w = _check(p)
     np.testing.assert_array_equal(w.records.pos, b.pos)
 

@@ -89,8 +89,9 @@ def main():
             exe = os.path.join(ROOT, "coverm_amd", "coverm-amd")
             runs = []
             for k in range(3):
+                time.sleep(4.0)      # (a process that held 30 GB of device memory is still being reaped when the next one starts: bench.py's run_binary waits too)
                 t0 = time.perf_counter()
-                p = subprocess.run(["/usr/bin/time", "-v", exe, "contig", "-b", path, "-m", "mean", "trimmed_mean", "covered_fraction", "variance", "-o", os.path.join(a.tmp, "r06_sweep.tsv"), "-t", "16"],
+                p = subprocess.run([exe, "contig", "-b", path, "-m", "mean", "trimmed_mean", "covered_fraction", "variance", "-o", os.path.join(a.tmp, "r06_sweep.tsv"), "-t", "16"],
                                    env=dict(os.environ, COVERM_CLI_TIMING="1"), capture_output=True, text=True)
                 wall = time.perf_counter() - t0
                 err = p.stderr
@@ -98,7 +99,7 @@ def main():
                 runs.append({"wall_s": round(wall, 3), "rc": p.returncode,
                              "sessions_s": g(r"arguments \+ device sessions ([0-9.]+)s"), "samples_s": g(r"samples ([0-9.]+)s"), "scan_drivers_and_table_s": g(r"scan drivers \+ table ([0-9.]+)s"),
                              "ingest_s": g(r"ingest \(decode\+push\) ([0-9.]+)s"), "finish_fetch_s": g(r"finish\+fetch ([0-9.]+)s"),
-                             "max_rss_kb": g(r"Maximum resident set size \(kbytes\): (\d+)")})
+                             "vm_hwm_kb": g(r"VmHWM:\s+(\d+) kB")})
                 if p.returncode != 0:
                     print(err[-2000:], flush=True)
             row["binary_runs"] = runs

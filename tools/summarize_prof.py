@@ -26,7 +26,7 @@ summ = {k: {c: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for 
         for k, cs in sorted(acc.items())}
 json.dump(summ, open(os.path.join(dst, tag + "_bench_pmc_summary.json"), "w"), indent=1)
 traffic = {"_source": tag, "_formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB -> bytes, per launch (MI355X_MICROARCH.md, gfx950 correction)"}
-short = {"k_prep<": "k_prep", "k_prep6<": "k_prep", "k_prep5p<": "k_prep", "k_prep8s<": "k_prep", "k_prep7s<": "k_prep", "k_post_prep": "k_post_prep", "k_estimate": "k_estimate", "k_ranges<": "k_ranges", "k_pileup_fast": "k_pileup", "k_pileup_stream": "k_pileup_slow_tiles", "k_cx_expand": "k_cx_expand",
+short = {"k_prep_lean<": "k_prep", "k_prep_generic<": "k_prep", "k_prep<": "k_prep", "k_prep6<": "k_prep", "k_prep5p<": "k_prep", "k_prep8s<": "k_prep", "k_prep7s<": "k_prep", "k_post_prep": "k_post_prep", "k_estimate": "k_estimate", "k_ranges<": "k_ranges", "k_pileup_fast": "k_pileup", "k_pileup_stream": "k_pileup_slow_tiles", "k_cx_expand": "k_cx_expand",
          "k_tile_scan": "k_tile_scan"}
 for k, cs in summ.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
@@ -43,7 +43,7 @@ kstats = {}
 for row in csv.DictReader(open(ks[0])):
     kstats[row["Name"].split("(")[0].replace("void ", "").strip()] = float(row["AverageNs"]) / 1e6
 for k, cs in summ.items():
-    key = "k_pileup" if "k_pileup_fast" in k else "k_prep" if ("k_prep<" in k or "k_prep6<" in k or "k_prep5p<" in k or "k_prep8s<" in k or "k_prep7s<" in k) else None
+    key = "k_pileup" if "k_pileup_fast" in k else "k_prep" if ("k_prep_lean<" in k or "k_prep<" in k or "k_prep6<" in k or "k_prep5p<" in k or "k_prep8s<" in k or "k_prep7s<" in k) else None
     if not key or "SQ_BUSY_CU_CYCLES" not in cs:
         continue
     g = lambda c: cs.get(c, {}).get("mean_per_dispatch")
