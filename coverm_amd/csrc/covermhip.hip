@@ -987,6 +987,8 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
             s->k_launches[COV_K_IDENTITY]++;
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(s->ev_side_done, s->side));   // joined just before the results are copied back
+            s->ev_fresh = -1;      // the host worked between the groups (a stream created on first use, five launches on it): the next group's
+                                   // time starts at its own event, not at k_prep's end (smoke() used to print k_ranges 7.8 ms for 80 k records)
         }
     }
     if (R && s->n_tiles) {
