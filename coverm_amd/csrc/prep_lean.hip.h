@@ -245,12 +245,19 @@ __device__ __forceinline__ void prep_step_generic(const PrepArgs *__restrict__ p
         const u64 pm = __ballot(cnt && !(flag & 0x900u)), nsm = __ballot(cnt && !supp);
         const u32 nm_c = masked_in ? (u32)nmv : 0u, in_c = masked_in ? (u32)cs.indel : 0u, sp_c = masked_in ? cs.span : 0u;
         const bool wide = __any(masked_in && (nmv32 >= (1u << 25) || cs.indel >= (1ull << 25)));      // 64 such values could pass 2^31: 64-bit sums then
+        // the loop leaves every run's totals in the registers of the run's FIRST lane; the atomics follow it, all first lanes at once: eight
+        // memory instructions per step whatever the number of runs (one per run and counter before: ~50 memory instructions per step of an
+        // assembly, and the CU's one address path, not the L2's atomic units, set k_prep_generic's time — profiles/r06_c2M_pmc.json)
+        u32 r_np = 0, r_n = 0, r_nn = 0, r_sp = 0, r_first = 0, r_last = 0;
+        u64 r_nm = 0, r_in = 0;
+        u64 heads = 0;
         for (u64 todo = cm; todo != 0ull;) {
             const int fl = __builtin_ctzll(todo);
             const int t = __builtin_amdgcn_readlane(tid, fl);
             const bool mine = cnt && tid == t;
             const u64 m = __ballot(mine);
             todo &= ~m;
+            heads |= 1ull << fl;
             u64 s_nm, s_in;
             if (!wide) {
                 s_nm = (u32)__builtin_amdgcn_readlane(wave_incl_scan((int)(mine ? nm_c : 0u)), 63);
@@ -258,19 +265,23 @@ __device__ __forceinline__ void prep_step_generic(const PrepArgs *__restrict__ p
             } else {
                 s_nm = wave_sum_u64(mine && masked_in ? nmv : 0ull); s_in = wave_sum_u64(mine && masked_in ? cs.indel : 0ull);
             }
-            const u32 s_sp = wave_max_u32(mine ? sp_c : 0u);
+            const u32 s_sp = wave_max_u32_dpp(mine ? sp_c : 0u);
             if (lane == fl) {
-                DevContig *C = &cd.ctg[t];
-                const u32 np = (u32)__popcll(m & pm), nn = (u32)__popcll(m & nsm);
-                if (np) atomicAdd(&C->n_primary, (u64)np);
-                atomicAdd(&C->n_pass, (u64)__popcll(m));
-                if (nn) atomicAdd(&C->n_nonsupp, (u64)nn);
-                if (s_nm) atomicAdd(&C->sum_nm, s_nm);
-                if (s_in) atomicAdd(&C->sum_indel, s_in);
-                if (s_sp) atomicMax(&C->max_span, s_sp);
-                atomicMin(&C->first_rec, i0 + (u32)__builtin_ctzll(m));
-                atomicMax(&C->last_rec, i0 + 63u - (u32)__builtin_clzll(m));
+                r_np = (u32)__popcll(m & pm); r_n = (u32)__popcll(m); r_nn = (u32)__popcll(m & nsm);
+                r_nm = s_nm; r_in = s_in; r_sp = s_sp;
+                r_first = i0 + (u32)__builtin_ctzll(m); r_last = i0 + 63u - (u32)__builtin_clzll(m);
             }
+        }
+        if ((heads >> lane) & 1ull) {
+            DevContig *C = &cd.ctg[tid];
+            if (r_np) atomicAdd(&C->n_primary, (u64)r_np);
+            atomicAdd(&C->n_pass, (u64)r_n);
+            if (r_nn) atomicAdd(&C->n_nonsupp, (u64)r_nn);
+            if (r_nm) atomicAdd(&C->sum_nm, r_nm);
+            if (r_in) atomicAdd(&C->sum_indel, r_in);
+            if (r_sp) atomicMax(&C->max_span, r_sp);
+            atomicMin(&C->first_rec, r_first);
+            atomicMax(&C->last_rec, r_last);
         }
     }
     if (lane == 0) {
