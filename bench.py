@@ -881,13 +881,14 @@ def sess_tiles(sess, ref):
 
 
 def ingest_roofline():
-    """The device ingest's two dominant kernels against the HBM roofline, from the COMMITTED profile of the round-4 build
-    (profiles/r04_ingest_kernel_stats.csv: rocprofv3 --kernel-trace --stats of `coverm-amd contig` over a 20 M-read level-1 BAM = one full
-    round of 81 920 BGZF blocks + one of 12 382; profiles/r04_ingest_pmc_summary.json: separate --pmc passes).  Not measured by this run:
+    """The device ingest's two dominant kernels against the HBM roofline, from the newest COMMITTED ingest profile (the files are named in
+    `source`: profiles/r05_ingest_kernel_stats.csv — rocprofv3 --kernel-trace --stats of `coverm-amd contig` over a 20 M-read level-1 BAM = one
+    full round of 81 920 BGZF blocks + one of 12 382 — and profiles/r05_ingest_pmc_summary.json — separate --pmc passes; the ingest kernels
+    did not change in round 6).  Not measured by this run:
     the bench's timed region is the coverage path; labelled as such.  Algorithmic bytes per full round: compressed bytes read once +
     inflated bytes written once (k_inflate_wave); token positions + every match byte read and written once (k_lz_stage; k_lz_resolve in profiles
     that predate it)."""
-    out = {"source": "committed profile of the round-4 build (profiles/r04_ingest_kernel_stats.csv, r04_ingest_pmc_summary.json), not this run",
+    out = {"source": "no committed ingest profile found",
            "round_blocks": 81920, "peak_GBps": HBM_PEAK_GBPS}
     try:
         import csv

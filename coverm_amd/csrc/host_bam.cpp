@@ -1326,16 +1326,15 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     //         (tools/ubench/io_probe: 57 GB/s against 42-54 GB/s through staging slots), but inside the running pipeline
     //         hipHostRegister drops to ~20 GB/s, the copies take longer to enqueue and unregistering 20 GB at the end costs
     //         another 0.4 s (profiles/r03_io_modes.log: 200 M reads 1.78 s against 0.98 s): kept as an option, not the default.
-    //   More than two devices fed at once (covh_bam_set_concurrent_feeders; coverm-amd --devices) change the balance: a staged byte crosses
-    //   the host's memory three times (page cache -> pinned slot by the CPU, slot -> link by the DMA engine, and the page cache fill), a
-    //   mapped one once, and N feeders share one memory system (at 8 x 50 GB/s the staged path asks for ~1.2 TB/s).
-    //   With > 2 feeders and no COVERM_INGEST_IO the mapping is chosen, and its span is registered ONCE, up front, before the first
-    //   upload — the registration that ran at 20 GB/s beside a busy pipeline runs at its idle rate, and the reader threads only hop
-    //   block headers.  UNMEASURED on more than one device (the build environment has one); `--devices 0,0,0,0` checks that it works.
+    //   More than two devices fed at once (covh_bam_set_concurrent_feeders; coverm-amd --devices): until round 6 the mapping, registered up
+    //   front, was the default there, on a model (a staged byte crosses the host's memory three times, a mapped one once).  Measured with eight
+    //   feeders on the one-GPU box (profiles/r06_eight_feeders_io.json): the eight registrations do NOT run beside one another — 0.2 to 1.2 s
+    //   per 2.6 GB span, 20.6 GB in ~1.2 s all told = 17 GB/s for the process —, which alone is longer than the whole single-device run
+    //   (0.76-0.96 s), while eight staged readers under the same 16-CPU quota copy at the one reader's rate (~49 GB/s in aggregate).  The
+    //   staging slots are therefore the default for any number of feeders; COVERM_INGEST_IO=mmap-upfront | mmap remain as options.
     const char *io = getenv("COVERM_INGEST_IO");
-    const bool many = g_feeders.load() > 2;
-    bool use_map = io ? !strcmp(io, "mmap") || !strcmp(io, "mmap-upfront") : many;
-    const bool map_upfront = use_map && (io ? !strcmp(io, "mmap-upfront") : many);
+    bool use_map = io && (!strcmp(io, "mmap") || !strcmp(io, "mmap-upfront"));
+    const bool map_upfront = use_map && !strcmp(io, "mmap-upfront");
     uint8_t *map = nullptr;
     const uint64_t PG = 4096, map_len = (file_size + PG - 1) / PG * PG;
     if (use_map) {

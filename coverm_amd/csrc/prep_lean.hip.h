@@ -79,23 +79,34 @@ __device__ __forceinline__ uint2 run_word(const CigSum &c, u32 nops_all, bool &i
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // One step of 64 records starting at i0, per lane, every counter through atomics: what the loop of k_prep_lean leaves on the list (see above).
+// (the step's independent loads are a function of their own: k_prep_generic issues the NEXT step's in front of the current step's work — a step
+// is a chain of dependent round trips (fields -> length / first tile / CIGAR words -> atomics), ~15 us per step and wave at 2 M contigs)
+struct GenFields { u32 fl_raw, nk, nmv32, mq, lsq, co0, co1; int td, pos, pt, ppos, nt; };
+template <bool FILTER>
+__device__ __forceinline__ void gen_load(const PrepHot &h, u32 i0, GenFields &f) {
+    const u32 n = h.n, nlast = n - 1u;
+    const u32 i = i0 + (u32)lane_id();
+    const bool in = i < n;
+    const u32 ic = min(i, nlast);
+    f.fl_raw = h.flag[ic];
+    f.td = h.tid[ic]; f.pos = h.pos[ic];
+    f.nk = h.nmk[ic]; f.nmv32 = h.nm[ic];
+    f.mq = FILTER ? (u32)h.mapq[ic] : 0u; f.lsq = FILTER ? h.lseq[ic] : 0u;
+    f.co0 = h.coff[ic]; f.co1 = h.coff[ic + 1u];
+    f.pt = (in && i > 0u) ? h.tid[ic - 1u] : -2;
+    f.ppos = (in && i > 0u) ? h.pos[ic - 1u] : 0;
+    f.nt = (in && i + 1u < n) ? h.tid[ic + 1u] : -2;
+}
 template <bool WANT_IDENTITY, bool FILTER, bool MASKED>
-__device__ __forceinline__ void prep_step_generic(const PrepArgs *__restrict__ pa, u32 i0) {
+__device__ __forceinline__ void prep_step_generic(const PrepArgs *__restrict__ pa, u32 i0, const GenFields &f) {
     const PrepHot &h = pa->hot;
     const PrepCold &cd = pa->cold;
     const int lane = lane_id();
-    const u32 n = h.n, nlast = n - 1u;
+    const u32 n = h.n;
     const u32 i = i0 + (u32)lane;
     const bool in = i < n;
-    const u32 ic = min(i, nlast);
-    const u32 fl_raw = h.flag[ic];
-    const int td = h.tid[ic], pos = h.pos[ic];
-    const u32 nk = h.nmk[ic], nmv32 = h.nm[ic];
-    const u32 mq = FILTER ? (u32)h.mapq[ic] : 0u, lsq = FILTER ? h.lseq[ic] : 0u;
-    const u32 co0 = h.coff[ic], co1 = h.coff[ic + 1u];
-    const int pt = (in && i > 0u) ? h.tid[ic - 1u] : -2;
-    const int ppos = (in && i > 0u) ? h.pos[ic - 1u] : 0;
-    const int nt = (in && i + 1u < n) ? h.tid[ic + 1u] : -2;
+    const u32 fl_raw = f.fl_raw, nk = f.nk, nmv32 = f.nmv32, mq = f.mq, lsq = f.lsq, co0 = f.co0, co1 = f.co1;
+    const int td = f.td, pos = f.pos, pt = f.pt, ppos = f.ppos, nt = f.nt;
     const u32 flag = in ? fl_raw : 0x904u;
     const int tid = in ? td : -1;
     const bool tid_ok = tid >= 0 && (u32)tid < h.n_targets;
@@ -564,8 +575,23 @@ template <bool WANT_IDENTITY, bool FILTER, bool MASKED>
 __global__ __launch_bounds__(256) void k_prep_generic(const PrepArgs *__restrict__ pa, u32 all_steps) {
     const u32 n = all_steps ? all_steps : pa->cold.g->n_gen;
     const u32 *__restrict__ list = pa->cold.gen_list;
-    for (u32 j = blockIdx.x * 4u + (threadIdx.x >> 6); j < n; j += gridDim.x * 4u)
-        prep_step_generic<WANT_IDENTITY, FILTER, MASKED>(pa, all_steps ? j * 64u : (u32)__builtin_amdgcn_readfirstlane((int)list[j]));
+    const u32 stride = gridDim.x * 4u;
+    u32 j = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (j >= n) return;
+    auto first_record = [&](u32 q) { return all_steps ? q * 64u : (u32)__builtin_amdgcn_readfirstlane((int)list[q]); };
+    u32 i0 = first_record(j);
+    GenFields f;
+    gen_load<FILTER>(pa->hot, i0, f);
+    for (;;) {
+        const u32 jn = j + stride;
+        const bool more = jn < n;
+        const u32 i0n = more ? first_record(jn) : i0;
+        GenFields fn;
+        gen_load<FILTER>(pa->hot, i0n, fn);              // the next step's fields are on their way while this step works
+        prep_step_generic<WANT_IDENTITY, FILTER, MASKED>(pa, i0, f);
+        if (!more) break;
+        j = jn; i0 = i0n; f = fn;
+    }
 }
 
 }  // namespace covk

@@ -311,10 +311,11 @@ def test_spans_leave_a_file_only_the_reference_would_accept_to_one_device(tmp_pa
     assert binary.run("contig", [p], devices="0,0", **args) == want
 
 
-def test_more_than_two_feeders_read_the_mapped_file(tmp_path):
-    """With more than two device ingests at once the file is mapped and its spans registered with the device once, up front, instead
-    of copied through staging slots (coverm_host.h covh_bam_set_concurrent_feeders; DESIGN.md section 7: N feeders share one host memory
-    system).  One GPU here, so four spans of one file on device 0: a functional check of that mode, the table must be the one-device one."""
+def test_four_feeders_through_staging_slots_and_through_the_mapped_file(tmp_path):
+    """Four device ingests at once (four spans of one file on device 0: one GPU here, a functional check): through staging slots — the
+    default for any number of feeders since round 6's measurement with eight (profiles/r06_eight_feeders_io.json: eight up-front
+    registrations do not run beside one another) — and with the file mapped and its spans registered with the device once, up front
+    (COVERM_INGEST_IO=mmap-upfront).  The table must be the one-device one either way."""
     from oracle import oracle as O
     from tests import binary
     ref = synth.make_reference(80, 8_000_000, seed=31, min_len=5000, max_len=400_000)
@@ -323,9 +324,11 @@ def test_more_than_two_feeders_read_the_mapped_file(tmp_path):
     cbam.write_bam(p, ref.names, ref.lengths, b, with_seq=2, threads=4)
     args = dict(methods=["mean", "trimmed_mean", "variance", "count"])
     want = O.run_cli("contig", [p], bams=[bamio.read_alignment_file(p)], **args)
-    r = binary.run_full("contig", [p], env={"COVERM_CLI_TIMING": "1"}, devices="0,0,0,0", **args)
+    r = binary.run_full("contig", [p], env={"COVERM_CLI_TIMING": "1", "COVERM_INGEST_IO": "mmap-upfront"}, devices="0,0,0,0", **args)
     assert r.stdout == want
     assert r.stderr.count("bytes from the mapped file (registered up front)") == 4
+    r = binary.run_full("contig", [p], env={"COVERM_CLI_TIMING": "1"}, devices="0,0,0,0", **args)
+    assert r.stdout == want and r.stderr.count("bytes from staging slots") == 4
     r = binary.run_full("contig", [p], env={"COVERM_CLI_TIMING": "1"}, devices="0,0", **args)
     assert r.stdout == want and r.stderr.count("bytes from staging slots") == 2
     r = binary.run_full("contig", [p], env={"COVERM_CLI_TIMING": "1", "COVERM_INGEST_IO": "pread"}, devices="0,0,0,0", **args)
