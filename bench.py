@@ -875,8 +875,8 @@ def usable_cpus():
 
 
 def sess_tiles(sess, ref):
-    """Tiles of the configured pileup kernel: 1024 bases per wave (fast / streaming kernels) unless COVERM_PILEUP=tile."""
-    tile = int(os.environ.get("COVERM_TILE", 4096)) if os.environ.get("COVERM_PILEUP") == "tile" else 1024
+    """Tiles of the pileup kernels: 1024 bases per wave."""
+    tile = 1024
     return int(((ref.lengths + tile - 1) // tile).sum())
 
 

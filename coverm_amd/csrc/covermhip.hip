@@ -95,9 +95,7 @@ struct cov_session {
     cov_config cfg{};
     hipStream_t stream = nullptr;
     std::string err;
-    int tile = 4096;  // bases per k_pileup workgroup (COVERM_TILE = 4096 | 8192 | 16384)
-    int nt = 256;     // k_pileup workgroup size
-    int stream_rows = 4;   // > 0: wave-per-tile kernels (1024-base tiles); 0: k_pileup workgroup-per-tile (COVERM_PILEUP=tile)
+    int tile = 1024;  // bases per tile (one wave per tile: STREAM_TW)
     bool use_fast = true;  // k_pileup_fast + k_pileup_stream on the slow-tile list (default); COVERM_PILEUP=stream: k_pileup_stream alone
     int chunk_tiles = 8;   // consecutive tiles walked by one wave (swept in round 4: 4 -> 0.627 ms, 8 -> 0.596, 16 -> 0.642, 32 -> 0.866)
     int prep_kernel = 0;   // 0 = k_prep_lean (prep_lean.hip.h); COVERM_PREP_KERNEL=7 forces k_prep7s, the second implementation (tests)
@@ -356,28 +354,6 @@ void time_begin(cov_session *s, int k) {
 }
 void time_end(cov_session *s, int k) { (void)hipEventRecord(s->ev[k][1], s->stream); s->k_launches[k]++; s->ev_fresh = k; }
 
-template <int TL, int NT, bool H, bool W>
-void launch_pileup_t(cov_session *s, const PileupArgs &a, u32 grid) {
-    const size_t smem = pileup_smem_bytes(TL, NT, H);
-    // per launch, not once per process: the limit is a per-device attribute and this (non-default) kernel is the only one that
-    // can need more than the 64 KiB every device grants without it
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup<TL, NT, H, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((k_pileup<TL, NT, H, W>), dim3(grid), dim3(NT), smem, s->stream, a);
-}
-// (tile, workgroup) geometries compiled in; session picks one (default 4096 x 256)
-template <bool H, bool W>
-void launch_pileup(cov_session *s, const PileupArgs &a, u32 grid) {
-    const int key = s->tile * 10000 + s->nt;
-    switch (key) {
-    case 16384 * 10000 + 1024: launch_pileup_t<16384, 1024, H, W>(s, a, grid); break;
-    case 16384 * 10000 + 512: launch_pileup_t<16384, 512, H, W>(s, a, grid); break;
-    case 8192 * 10000 + 512: launch_pileup_t<8192, 512, H, W>(s, a, grid); break;
-    case 8192 * 10000 + 256: launch_pileup_t<8192, 256, H, W>(s, a, grid); break;
-    case 4096 * 10000 + 128: launch_pileup_t<4096, 128, H, W>(s, a, grid); break;
-    default: launch_pileup_t<4096, 256, H, W>(s, a, grid); break;
-    }
-}
-
 // k_pileup_fast over every tile (it skips the ones k_ranges flagged TILE_F_SLOW)
 template <bool H, int TABLES>
 void launch_fast_v(cov_session *s, const PileupArgs &a, u32 n_tiles) {
@@ -443,11 +419,10 @@ void launch_stream_t(cov_session *s, const PileupArgs &a, u32 n_tiles, bool slow
 // dispatches to the configured pileup kernel
 template <bool H, bool W>
 void launch_any_pileup(cov_session *s, const PileupArgs &a, u32 n_tiles) {
-    if (s->stream_rows && s->use_fast && !W) {
+    if (s->use_fast && !W) {
         launch_fast_t<H>(s, a, n_tiles);
         launch_stream_t<H, W>(s, a, n_tiles, true);
-    } else if (s->stream_rows) launch_stream_t<H, W>(s, a, n_tiles);
-    else launch_pileup<H, W>(s, a, n_tiles);
+    } else launch_stream_t<H, W>(s, a, n_tiles);
 }
 
 PileupArgs pileup_args(cov_session *s) {
@@ -486,20 +461,9 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     cov_session *s = new cov_session();
     s->cfg = *cfg;
     {
-        const char *tl = getenv("COVERM_TILE");      // (tile of the workgroup-per-tile cross-check kernel, COVERM_PILEUP=tile)
-        int t = tl ? atoi(tl) : 4096, n = 0;
-        if (t != 4096 && t != 8192 && t != 16384) t = 4096;
-        if (t == 16384) n = (n == 1024) ? 1024 : 512;
-        else if (t == 8192) n = (n == 256) ? 256 : 512;
-        else n = (n == 128) ? 128 : 256;
-        s->tile = t; s->nt = n;
-        const char *mode = getenv("COVERM_PILEUP");
+        const char *mode = getenv("COVERM_PILEUP");      // "stream": k_pileup_stream over every tile (the second kernel behind k_pileup_fast, alone: tests)
         if (mode && !strcmp(mode, "stream")) s->use_fast = false;
-        if (mode && !strcmp(mode, "tile")) s->stream_rows = 0;
-        else {
-            s->stream_rows = 4;
-            s->tile = STREAM_TW;
-        }
+        s->tile = STREAM_TW;
         stamp("hipSetDevice");
         int cus = 0;      // (hipGetDeviceProperties fills a kilobyte of fields from many driver queries; one attribute is all that is needed)
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) s->n_cus = cus;
@@ -1001,7 +965,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         hipLaunchKernelGGL(k_tile_scan1, dim3(2u * n_blocks), dim3(1024), 0, st, sp, s->n_tiles, n_blocks);
         hipLaunchKernelGGL(k_tile_scan2, dim3(2), dim3(1024), 0, st, sp, n_blocks);
         hipLaunchKernelGGL((k_cx_expand<true>), dim3(cx_grid), dim3(256), 0, st, r, s->d_tlen.p, s->d_glob.p, cx, ti);
-        u32 *slow_list = (s->stream_rows && s->use_fast) ? s->d_slow_list.p : nullptr;
+        u32 *slow_list = s->use_fast ? s->d_slow_list.p : nullptr;
         if (want_hist)
             hipLaunchKernelGGL((k_ranges<true>), dim3((s->n_tiles + 255) / 256), dim3(256), 0, st, s->d_tile_contig.p,
                                s->d_tile_start.p, s->n_tiles, s->d_tlen.p, mask, s->d_ctg.p, s->d_desc.p, ti, s->d_tscan.p,

@@ -27,7 +27,6 @@ typedef unsigned int u32;
 
 // Tile = bases handled by one workgroup, resident in LDS as i32 (TILE * 4 bytes).  Smaller tiles put more
 // workgroups on a CU (160 KiB LDS), which is what hides the dependent global-load latency of the event phase.
-constexpr int hist_bins(int tile) { return tile >= 16384 ? 2048 : 1024; }  // LDS histogram bins per tile
 constexpr u32 F_POS_UNSORTED = 1u;
 // run-word types (top two bits of .y)
 constexpr u32 RW_SINGLE = 0u, RW_DOUBLE = 1u, RW_COMPLEX = 2u, RW_BUCKET = 3u;
@@ -1363,221 +1362,8 @@ struct PileupArgs {
     u32 tile_base;        // first tile index handled by blockIdx 0
 };
 
-constexpr size_t pileup_smem_bytes(int tile, int nt, bool hist) {
-    return (size_t)tile * 4 + 256 + (size_t)(nt / 64) * 32 + 16 + (hist ? (size_t)hist_bins(tile) * 4 : 0);
-}
-
-template <int TILE, int NT, bool WANT_HIST, bool WRITE_DEPTH>
-__global__ __launch_bounds__(NT) void k_pileup(PileupArgs a) {
-    constexpr int NW = NT / 64;
-    constexpr int ROWS = TILE / (4 * NT);   // quads per thread
-    constexpr int HB = hist_bins(TILE);
-    static_assert(ROWS >= 1 && NW * ROWS <= 64, "cross-wave prefix is resolved by one 64-lane scan");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *tile = reinterpret_cast<int *>(smem);                       // TILE i32
-    int *wtot = reinterpret_cast<int *>(smem + TILE * 4);            // <= 64 (row, wave) totals
-    u64 *red64 = reinterpret_cast<u64 *>(smem + TILE * 4 + 256);     // NW * 2
-    u32 *red32 = reinterpret_cast<u32 *>(smem + TILE * 4 + 256 + NW * 16);  // NW * 4 (+2 broadcast)
-    u32 *lhist = reinterpret_cast<u32 *>(smem + TILE * 4 + 256 + NW * 16 + NW * 16 + 16);
-
-    const u32 t = a.tile_base + blockIdx.x;
-    const uint4 ds = a.desc[2 * t];
-    const uint4 ds1 = a.desc[2 * t + 1];
-    if (ds.x >= ds.y && ds1.w == 0u) return;  // no record can touch this tile: depth 0 everywhere, accounted on the host side
-    const u32 lo = a.tile_start[t];
-    const u32 c = a.tile_contig[t];
-    const u32 L = ds.z;
-    const bool generic = ds.w & 1u;
-    const u32 tlen_t = min((u32)TILE, L - lo);
-    const u64 dbase = (WRITE_DEPTH && a.depth_off != nullptr) ? a.depth_off[c] : 0ull;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int rows_used = (int)((tlen_t + 4 * NT - 1) / (4 * NT));
-
-    // ---- zero the tile (and the LDS histogram)
-    {
-        int4 z = make_int4(0, 0, 0, 0);
-        int4 *t4 = reinterpret_cast<int4 *>(tile);
-#pragma unroll
-        for (int rr = 0; rr < ROWS; rr++)
-            if (rr < rows_used) t4[rr * NT + tid] = z;
-        if (WANT_HIST)
-            for (int b = tid; b < HB; b += NT) lhist[b] = 0u;
-    }
-    __syncthreads();
-
-    // ---- events: +1 at the (clipped) start, -1 at the end of every M/=/X run that overlaps the tile
-    const u32 hi = lo + TILE;
-    auto add_run = [&](u32 s, u32 e) {
-        if (s < hi && e > lo) {
-            const u32 s0 = s > lo ? s - lo : 0u;
-            atomicAdd(&tile[s0], 1);
-            if (e < hi) atomicAdd(&tile[e - lo], -1);
-        }
-    };
-    for (u32 i = ds.x + tid; i < ds.y; i += NT) {
-        const uint2 rw = a.runs[i];
-        if (rw.y == 0u) continue;
-        if (generic && a.r.tid[i] != (int)c) continue;
-        const u32 type = rw.y >> 30;
-        if (type == RW_SINGLE) {
-            add_run(rw.x, rw.x + rw.y);
-        } else if (type == RW_DOUBLE) {
-            const u32 l1 = rw.y & 1023u, gap = (rw.y >> 10) & 255u, l2 = (rw.y >> 18) & 1023u;
-            add_run(rw.x, rw.x + l1);
-            add_run(rw.x + l1 + gap, rw.x + l1 + gap + l2);
-        } else if (type == RW_COMPLEX) {  // re-walk the CIGAR (contig.rs:166-202)
-            u32 cursor = (u32)a.r.pos[i];
-            const u32 c0 = a.r.cigar_off[i], c1 = a.r.cigar_off[i + 1];
-            for (u32 k = c0; k < c1; k++) {
-                const u32 wd = a.r.cigar[k];
-                const u32 op = wd & 15u, len = wd >> 4;
-                if (op == 0u || op == 7u || op == 8u) { add_run(cursor, cursor + len); cursor += len; }
-                else if (op == 2u || op == 3u) cursor += len;
-            }
-        }   // RW_BUCKET: delivered through the tile's bucket below
-    }
-    for (u32 j = tid; j < ds1.w; j += NT) { const uint2 q = a.cx_runs[(u64)ds1.z + j]; add_run(q.x, q.y); }
-    __syncthreads();
-
-    // ---- block-wide prefix sum.  Thread `tid` owns quad q = row * NT + tid of every row (striped, so the
-    // ds_read_b128 is bank-conflict free); rows are resolved with one wave scan each plus one 64-entry scan.
-    int4 v[ROWS];
-    int ex[ROWS];
-    {
-        const int4 *t4 = reinterpret_cast<const int4 *>(tile);
-#pragma unroll
-        for (int rr = 0; rr < ROWS; rr++) {
-            if (rr < rows_used) v[rr] = t4[rr * NT + tid]; else v[rr] = make_int4(0, 0, 0, 0);
-            const int s3 = v[rr].x + v[rr].y + v[rr].z + v[rr].w;
-            const int inc = wave_incl_scan(s3);
-            ex[rr] = inc - s3;
-            if (lane == 63) wtot[rr * NW + w] = inc;
-        }
-    }
-    __syncthreads();
-    int pre;  // exclusive prefix of (row, wave) totals in row-major order, one entry per lane
-    {
-        const int tot = lane < NW * ROWS ? wtot[lane] : 0;
-        pre = wave_incl_scan(tot) - tot;
-    }
-
-    // ---- statistics
-    const u64 excl = a.excl;
-    const bool has_win = 2 * excl < (u64)L;
-    const u32 ws = has_win ? (u32)excl : 0u, we = has_win ? (u32)(L - excl) : 0u;  // window [ws, we)
-    const u32 wst = max(ws, lo), wet = min(we, lo + tlen_t);                       // window ∩ tile
-    const bool win_any = has_win && wst < wet;
-    const bool interior = has_win && lo >= ws && lo + TILE <= we;                   // implies tlen_t == TILE
-    u64 sum_d = 0, sum_d2 = 0;
-    u32 cov_w = 0, cov_f = 0, mn = 0xffffffffu, mx = 0;
-    DevContig *C = &a.ctg[c];
-    const u64 hoff = WANT_HIST ? C->hist_off : 0;
-    const u32 hcap = WANT_HIST ? C->hist_cap : 0;
-    auto hist_add = [&](u32 d, u32 x) {
-        if (__builtin_expect(d < (u32)HB, 1)) atomicAdd(&lhist[d], x);
-        else hist_add_overflow(a.hist_arena, hoff, hcap, a.g, d, x);
-    };
-#pragma unroll
-    for (int rr = 0; rr < ROWS; rr++) {
-        if (rr >= rows_used) break;
-        const int base = __shfl(pre, rr * NW + w) + ex[rr];
-        const u32 p0 = lo + 4u * (u32)(rr * NT + tid);
-        const int dl[4] = {v[rr].x, v[rr].y, v[rr].z, v[rr].w};
-        int d = base;
-        if (interior) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int prev = d;
-                d += dl[j];
-                const u32 du = (u32)d;
-                sum_d += du;
-                sum_d2 += (u64)du * du;
-                cov_w += d > 0;
-                mn = min(mn, du); mx = max(mx, du);
-                if (WANT_HIST && dl[j] != 0) {
-                    const u32 rel = p0 + j - wst;
-                    if (rel) { hist_add((u32)prev, rel); hist_add(du, 0u - rel); }
-                }
-                if (WRITE_DEPTH) a.depth_out[dbase + p0 + j] = d;
-            }
-            cov_f = cov_w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int prev = d;
-                d += dl[j];
-                const u32 p = p0 + j;
-                const u32 du = (u32)d;
-                if (p < L) {
-                    cov_f += d > 0;
-                    if (WRITE_DEPTH) a.depth_out[dbase + p] = d;
-                    if (win_any && p >= wst && p < wet) {
-                        sum_d += du;
-                        sum_d2 += (u64)du * du;
-                        cov_w += d > 0;
-                        mn = min(mn, du); mx = max(mx, du);
-                        if (WANT_HIST && dl[j] != 0) {
-                            const u32 rel = p - wst;
-                            if (rel) { hist_add((u32)prev, rel); hist_add(du, 0u - rel); }
-                        }
-                    }
-                }
-            }
-        }
-        // closing term of the change-point histogram: the last window position of this tile
-        if (WANT_HIST && win_any) {
-            const u32 last = wet - 1;
-            if (last >= p0 && last < p0 + 4) {
-                int dd = base;
-                for (u32 j = 0; j <= last - p0; j++) dd += dl[j];
-                hist_add((u32)dd, wet - wst);
-            }
-        }
-    }
-
-    // ---- workgroup reduction, then one set of global atomics per tile
-    sum_d = wave_sum_u64(sum_d);
-    sum_d2 = wave_sum_u64(sum_d2);
-    cov_w = wave_sum_u32(cov_w);
-    cov_f = wave_sum_u32(cov_f);
-    mn = wave_min_u32(mn);
-    mx = wave_max_u32(mx);
-    if (lane == 0) {
-        red64[w * 2 + 0] = sum_d; red64[w * 2 + 1] = sum_d2;
-        red32[w * 4 + 0] = cov_w; red32[w * 4 + 1] = cov_f; red32[w * 4 + 2] = mn; red32[w * 4 + 3] = mx;
-    }
-    __syncthreads();
-    if (w == 0) {
-        u64 a0 = lane < NW ? red64[lane * 2 + 0] : 0, a1 = lane < NW ? red64[lane * 2 + 1] : 0;
-        u32 b0 = lane < NW ? red32[lane * 4 + 0] : 0, b1 = lane < NW ? red32[lane * 4 + 1] : 0;
-        u32 b2 = lane < NW ? red32[lane * 4 + 2] : 0xffffffffu, b3 = lane < NW ? red32[lane * 4 + 3] : 0;
-        a0 = wave_sum_u64(a0); a1 = wave_sum_u64(a1);
-        b0 = wave_sum_u32(b0); b1 = wave_sum_u32(b1);
-        b2 = wave_min_u32(b2); b3 = wave_max_u32(b3);
-        if (lane == 0) {
-            if (a0) atomicAdd(&C->sum_d, a0);
-            if (a1) atomicAdd(&C->sum_d2, a1);
-            if (b0) atomicAdd(&C->cov_win, (u64)b0);
-            if (b1) atomicAdd(&C->cov_full, (u64)b1);
-            if (win_any) {
-                atomicAdd(&C->proc_win, (u64)(wet - wst));
-                atomicMin(&C->min_d, b2);
-                atomicMax(&C->max_d, b3);
-            }
-        }
-        if (lane == 0) { red32[NW * 4 + 0] = b2; red32[NW * 4 + 1] = b3; }
-    }
-    if (WANT_HIST) {
-        __syncthreads();
-        if (win_any) {
-            const u32 dmin = red32[NW * 4 + 0], dmax = min(red32[NW * 4 + 1], (u32)HB - 1);
-            for (u32 b = dmin + tid; b <= dmax; b += NT) {
-                const u32 x = lhist[b];
-                if (x) atomicAdd(&a.hist_arena[hoff + b], x);
-            }
-        }
-    }
-}
+// (k_pileup<TILE, NT> — round 1's kernel, one workgroup per 4096 / 8192 / 16384-base tile with the tile's i32 depth array in LDS; the tests'
+// third pileup implementation until round 6 — is gone: k_pileup_fast2t and k_pileup_stream (COVERM_PILEUP=stream) are the cross-checks.)
 
 // ------------------------------------------------------------------------------------ k_pileup_stream
 // Barrier-free variant: every WAVE owns a private LDS tile of TW = 1024 bases (+ a private 512-bin histogram)

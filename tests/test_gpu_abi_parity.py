@@ -385,26 +385,6 @@ def test_fuzz_small_cases(seed):
     compare(b, ff=ff, fp=fp, excl=excl, mask=mask, check_depth=depth_of, chunks=int(rng.integers(1, 4)))
 
 
-@pytest.mark.parametrize("tile", ["4096", "16384"])
-def test_workgroup_per_tile_kernel(tile, monkeypatch):
-    """The simpler cross-check implementation (COVERM_PILEUP=tile: one workgroup per 4096/16384-base tile) must agree
-    with the oracle on the same inputs as the default wave-per-tile streaming kernel."""
-    monkeypatch.setenv("COVERM_PILEUP", "tile")
-    monkeypatch.setenv("COVERM_TILE", tile)
-    for name in ["7seqs.reads_for_seq1_and_seq2.bam", "k141_2005182.bam", "eg2.bam"]:
-        compare(load_fixture(name), ff=(True, True, False), excl=75)
-    ref = synth.make_reference(40, 3_000_000, seed=11, min_len=1500, max_len=400_000)
-    b = to_bamdata(synth.make_reads(ref, 60_000, seed=12), ref.lengths, ref.names)
-    compare(b, ff=(True, True, False), excl=75, check_depth=[0, 1, 39], chunks=2)
-    ref_lens = np.asarray([300_000, 1_200_000, 80_000], dtype=np.int64)
-    compare(to_bamdata(_long_read_batch(ref_lens, 400, 5_000, seed=5), ref_lens), ff=(True, True, False), excl=75,
-            check_depth=range(3))
-    for seed in range(0, 48, 5):
-        ref_lens, batch, rng = _fuzz_case(seed)
-        compare(to_bamdata(batch, ref_lens), ff=(True, True, False), excl=int(rng.choice([0, 75])),
-                check_depth=range(min(3, len(ref_lens))))
-
-
 def test_stream_kernel_all_tiles(monkeypatch):
     """COVERM_PILEUP=stream: k_pileup_stream (round 1's default, now the slow-tile kernel behind k_pileup_fast) over every
     tile must agree with the oracle on the same inputs as the default pair of kernels."""
