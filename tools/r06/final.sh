@@ -9,3 +9,4 @@ cat $OUT/pytest_gpu.log
 ( timeout 1400 python bench.py > $OUT/bench_line.json 2> $OUT/bench_err.log ); echo "bench rc $?" >> $OUT/bench_err.log
 tail -c 1800 $OUT/bench_line.json; tail -4 $OUT/bench_err.log
 timeout 900 tools/prof_bench.sh $TAG > $OUT/prof_bench.log 2>&1; tail -3 $OUT/prof_bench.log
+[ -n "$FINAL_SWEEP" ] && { timeout 1700 python tools/r06/contig_sweep.py --out $R/gpurun_out/r06_contig_sweep.json > $OUT/sweep.log 2> $OUT/sweep.err; tail -8 $OUT/sweep.log; tail -3 $OUT/sweep.err; }
