@@ -238,6 +238,7 @@ struct cov_session {
     uint8_t *h_res = nullptr; size_t h_res_cap = 0;
     DevContig *h_ctg = nullptr;
     DevGlobal h_glob{};
+    bool last_gen_all = false;         // the last finish ran k_prep_generic over every step (cov_last_paths)
     uint64_t algo_bytes = 0;
 
     hipEvent_t ev[COV_K_COUNT][2] = {};
@@ -896,6 +897,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         // of those, and k_prep_generic then walks every step itself (no list, no partial records for k_post_prep to add)
         const u32 n_steps = (R + 63u) / 64u;
         const bool gen_all = prep_kernel != 7 && (uint64_t)R < (uint64_t)nT * 128u;
+        s->last_gen_all = gen_all;
         const u32 gen_grid = gen_all ? std::min<u32>((u32)s->n_cus * 64u, (n_steps + 3u) / 4u) : std::min<u32>((u32)s->n_cus * 8u, (n_steps + 3u) / 4u);      // waves stride over the steps
 #define COV_LAUNCH_PREP(ID, FI, MA)                                                                                                       \
         do {                                                                                                                              \
@@ -2148,6 +2150,13 @@ cov_status cov_kernel_ms(const cov_session *s, cov_kernel_id k, double *ms_total
     if (!s || k < 0 || k >= COV_K_COUNT) return COV_ERR_INVALID_ARG;
     if (ms_total) *ms_total = s->k_ms[k];
     if (launches) *launches = s->k_launches[k];
+    return COV_OK;
+}
+
+cov_status cov_last_paths(const cov_session *s, cov_path_counts *out) {
+    if (!s || !out) return COV_ERR_INVALID_ARG;
+    out->listed_steps = s->h_glob.n_gen; out->generic_only = s->last_gen_all ? 1u : 0u;
+    out->slow_tiles = s->h_glob.n_slow; out->bucket_records = s->h_glob.n_cx;
     return COV_OK;
 }
 

@@ -199,6 +199,12 @@ class Session:
             out[name] = (ms.value, n.value)
         return out
 
+    def last_paths(self):
+        """cov_last_paths: which branches of the device pipeline the last finish took (diagnostics for the parity tests)."""
+        v = (C.c_uint32 * 4)()
+        self._check(self._lib.cov_last_paths(self._h, C.byref(v)))
+        return dict(listed_steps=int(v[0]), generic_only=bool(v[1]), slow_tiles=int(v[2]), bucket_records=int(v[3]))
+
     def algorithmic_bytes(self):
         b = C.c_uint64(0)
         self._check(self._lib.cov_algorithmic_bytes(self._h, C.byref(b)))

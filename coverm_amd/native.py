@@ -50,7 +50,7 @@ assert CONTIG_STATS_DTYPE.itemsize == 128
 
 EXPORTS = ["cov_abi_version", "cov_create", "cov_destroy", "cov_last_error", "cov_set_targets",
            "cov_set_target_mask", "cov_push_batch", "cov_push_batch_device", "cov_finish", "cov_fetch_hist",
-           "cov_copy_depth", "cov_reset", "cov_kernel_ms", "cov_algorithmic_bytes"]
+           "cov_copy_depth", "cov_reset", "cov_kernel_ms", "cov_algorithmic_bytes", "cov_last_paths"]
 
 _lib = None
 
@@ -101,6 +101,7 @@ def lib():
     L.cov_reset.argtypes = [C.c_void_p]
     L.cov_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.cov_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.cov_last_paths.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 4)]
     L.cov_set_estimators.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.cov_fetch_estimates.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L

@@ -269,6 +269,12 @@ cov_status cov_gathered(cov_session *root_session, uint32_t rank, cov_contig_sta
 /* Average duration (ms) of one launch of kernel `k` during the last cov_finish, measured with HIP
  * events recorded on the session's stream around that kernel; *launches receives the count. */
 cov_status cov_kernel_ms(const cov_session *s, cov_kernel_id k, double *ms_total, uint32_t *launches);
+/* Which paths the last cov_finish took — diagnostics, so that a parity case built for one branch of the device pipeline can assert that the
+ * branch ran (tests/test_gpu_step_shapes.py).  listed_steps: steps of 64 records k_prep_lean left to k_prep_generic (generic_only = 1: a
+ * sample of fewer than 128 records per contig, k_prep_generic walked all of them and nothing was listed); slow_tiles: tiles k_pileup_fast
+ * left to k_pileup_stream; bucket_records: records whose CIGAR went through the bucket list (CX_MIN_OPS operations and more). */
+typedef struct { uint32_t listed_steps, generic_only, slow_tiles, bucket_records; } cov_path_counts;
+cov_status cov_last_paths(const cov_session *s, cov_path_counts *out);
 /* Algorithmic HBM bytes of the last cov_finish (DESIGN.md "Algorithmic bytes"): record SoA + CIGAR
  * words read once, plus result structs written. */
 cov_status cov_algorithmic_bytes(const cov_session *s, uint64_t *bytes);

@@ -30,7 +30,7 @@ def to_bamdata(batch: RecordBatch, ref_lens, names=None) -> BamData:
                    [b"r%d" % i for i in range(n)] if n < 100000 else [], "")
 
 
-def compare(b: BamData, ff=(True, True, False), fp=None, excl=75, mask=None, check_depth=(), chunks=1):
+def compare(b: BamData, ff=(True, True, False), fp=None, excl=75, mask=None, check_depth=(), chunks=1, paths_out=None):
     off = O.FlagFilter(*ff)
     ofp = None
     filt = FilterConfig(*ff)
@@ -51,6 +51,8 @@ def compare(b: BamData, ff=(True, True, False), fp=None, excl=75, mask=None, che
         for lo, hi in zip(edges[:-1], edges[1:]):
             s.push(batch.slice(lo, hi))
         st, summ = s.finish()
+        if paths_out is not None:
+            paths_out.update(s.last_paths())        # cov_last_paths: which branches of the pipeline this finish took
         hist = s.hist()
         assert summ.num_detected_primary_alignments == prim
         live = exp["seen"] == 1 if mask is None else (exp["seen"] == 1) & (np.asarray(mask) != 0)
