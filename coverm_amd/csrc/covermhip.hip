@@ -23,6 +23,7 @@
 
 #include "../../include/covermhip.h"
 #include "roctx_ranges.h"
+#include "knobs.h"
 
 using namespace covk;
 
@@ -474,8 +475,8 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     if (const char *ft = getenv("COVERM_FAST_TABLES")) s->fast_tables = atoi(ft) == 2 ? 2 : 1;
     if (const char *pk = getenv("COVERM_PREP_KERNEL")) s->prep_kernel = atoi(pk) == 7 ? 7 : 0;
     if (const char *im = getenv("COVERM_IDENTITY")) s->id_mode = strcmp(im, "serial") ? 1 : 0;
-    if (const char *c = getenv("COVERM_STORE_CAP_RECORDS")) { const long long v = atoll(c); if (v >= 1) s->cap_records = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
-    if (const char *c = getenv("COVERM_STORE_CAP_CIGAR")) { const long long v = atoll(c); if (v >= 1) s->cap_cigar = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
+    { long long v; if (covknob::get("store_cap_records", v) && v >= 1) s->cap_records = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
+    { long long v; if (covknob::get("store_cap_cigar", v) && v >= 1) s->cap_cigar = std::min<uint64_t>((uint64_t)v, 0xfffffff0ull); }
     // (every stream costs ~6 ms to create and as much again when the process ends, tools/ubench/exit_probe: the side stream of the
     // identity kernels is created by the first cov_finish that wants it, and borrows the ingest's second stream when there is one)
     e = hipEventCreateWithFlags(&s->ev_prep_done, hipEventDisableTiming);
@@ -1362,13 +1363,13 @@ static InflateKernel choose_inflate_kernel(cov_session *s) {
         if (per_cu <= 0) per_cu = 2;
         K.round_blocks = (u32)s->n_cus * (u32)per_cu * 64u;
     } else K.round_blocks = WAVE_ROUND_BLOCKS;
-    if (const char *w = getenv("COVERM_INGEST_ROUND_BLOCKS")) { const long v = atol(w); if (v >= 64) K.round_blocks = (u32)v / 64u * 64u; }   // tests: many small windows
-    if (const char *c = getenv("COVERM_INGEST_CARRY_KB")) { const long v = atol(c); if (v >= 1) K.carry = (u64)v << 10; }
+    { long long v; if (covknob::get("ingest_round_blocks", v) && v >= 64) K.round_blocks = (u32)v / 64u * 64u; }   // tests: many small windows
+    { long long v; if (covknob::get("ingest_carry_kb", v) && v >= 1) K.carry = (u64)v << 10; }
     K.carry = (K.carry + 63u) & ~63ull;
     // compressed bytes one round may span: 32 KiB per block on average (BGZF blocks of BAM files compress to 15-25 KiB); a round of
     // less compressible blocks simply closes earlier
     K.cwin = std::max<u64>((u64)K.round_blocks * 32768u, 1ull << 20);
-    if (const char *c = getenv("COVERM_INGEST_CWIN_KB")) { const long v = atol(c); if (v >= 256) K.cwin = (u64)v << 10; }
+    { long long v; if (covknob::get("ingest_cwin_kb", v) && v >= 256) K.cwin = (u64)v << 10; }
     return K;
 }
 static inline const InflateKernel &inflate_kernel(cov_session *s) { return s->ing_K; }
@@ -1403,7 +1404,7 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     s->ing_batch = 0; s->ing_extracted = 0; s->ing_rec_total = s->ing_cig_total = 0; s->ing_fail = 0; s->ing_rec_spilled = 0;
     s->ing_K = choose_inflate_kernel(s);      // (also sets the kernel's dynamic-LDS limit on this session's device)
     s->ing_first_record = first_record_offset;
-    s->ing_check_crc = (check_crc && !getenv("COVERM_NO_CRC")) ? 1 : 0;
+    s->ing_check_crc = check_crc ? 1 : 0;
     HIPCHK(s->g_result.reserve(8 + 4 * 8, s->stream));
     HIPCHK(s->g_carry.reserve(inflate_kernel(s).carry, s->stream));
     HIPCHK(s->g_blocks.reserve(compressed_bytes / 8192 + 1024, s->stream));
@@ -1814,7 +1815,7 @@ cov_status cov_pair_filter_apply(cov_session *s, const cov_pair_filter *f, uint6
     // chunks of whole references (a pair never spans two), about T records each: the table of a chunk stays small enough for the
     // last-level cache, where the scattered atomics of the join are served
     u32 T = 4u << 20;
-    if (const char *e = getenv("COVERM_PAIR_CHUNK")) { const long v = atol(e); if (v >= 1024) T = (u32)std::min<long>(v, 1l << 30); }
+    { long long v; if (covknob::get("pair_chunk", v) && v >= 1024) T = (u32)std::min<long long>(v, 1ll << 30); }
     const u32 n_chunks = (u32)(((u64)R + T - 1) / T);
     DevBuf<u32> d_cuts, d_partner, d_bsum, d_order, d_cnt;       // d_cnt: [0] members listed by k_pair_collect, [1] table overflow, [2 + c] entries of chunk c with more than two records
     DevBuf<u64> d_w;        // [0] primaries, [1] first error, [2] selected slots, [3] selected CIGAR words

@@ -39,6 +39,7 @@
 #include "../../include/coverm_host.h"
 #include "reader_filter.h"
 #include "roctx_ranges.h"
+#include "knobs.h"
 
 namespace {
 
@@ -264,7 +265,6 @@ struct LibDeflate {
     void (*release_c)(void *) = nullptr;
     bool ok = false, ok_c = false;
     LibDeflate() {
-        if (getenv("COVERM_NO_LIBDEFLATE")) return;
         void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
         if (!h) return;
         alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
@@ -1143,7 +1143,7 @@ covh_bam_stream *covh_bam_stream_open(const char *path, int threads, uint32_t sp
     if (s.file_size == 0) return bail(h, std::string(path) + ": empty file (no BAM/SAM header)");
     uint8_t magic[2] = {0, 0};
     if (pread(s.fd, magic, 2, 0) != 2 || magic[0] != 0x1f || magic[1] != 0x8b) return bail(h, "not a BGZF file (the streamed reader takes BAM only)");
-    if (const char *wb = getenv("COVERM_STREAM_WINDOW_KB")) { const long v = atol(wb); if (v >= 64) s.window_comp = (size_t)v << 10; }
+    { long long v; if (covknob::get("stream_window_kb", v) && v >= 64) s.window_comp = (size_t)v << 10; }
     // header: inflate from the start until the reference dictionary is complete
     {
         std::vector<uint8_t> u; std::string e;
@@ -1369,8 +1369,9 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     // (tools/ubench/exit_probe), so the slots are as small as the reader's rate allows: 4 x 32 MiB in 2 MiB chunks read 5 GB in
     // 0.098 s inside the pipeline, 4 x 64 MiB in 4 MiB chunks in 0.114 s (profiles/r03_reader_sweep_50M.log)
     size_t piece = use_map ? (size_t)256 << 20 : (size_t)32 << 20;
-    const char *piece_env = getenv("COVERM_INGEST_PIECE_KB");      // tests: many small pieces
-    if (piece_env) { const long v = atol(piece_env); if (v >= 64) piece = (size_t)v << 10; }
+    long long piece_kb = 0;
+    const bool piece_env = covknob::get("ingest_piece_kb", piece_kb);      // tests: many small pieces
+    if (piece_env && piece_kb >= 64) piece = (size_t)piece_kb << 10;
     // registered so far: [reg_lo0, reg_hi) of the mapping, in whole pages; a piece registers what of its pages is not registered yet
     uint64_t reg_hi = f_lo / PG * PG;
     auto register_piece = [&](uint64_t off, uint64_t n) -> bool {
@@ -1902,7 +1903,7 @@ int covh_bam_filter_file(const char *in_path, const char *out_path, const covh_p
     fi.f = fopen(in_path, "rb");
     if (!fi.f) return fail(std::string("Unable to find BAM file ") + in_path);
     size_t CHUNK = (size_t)64 << 20;
-    if (const char *e = getenv("COVERM_FILTER_WINDOW_KB")) { const long v = atol(e); if (v >= 1) CHUNK = (size_t)v << 10; }      // tests: many small windows
+    { long long v; if (covknob::get("filter_window_kb", v) && v >= 1) CHUNK = (size_t)v << 10; }      // tests: many small windows
     std::vector<uint8_t> cbuf, u;       // compressed bytes not yet inflated; inflated bytes not yet consumed (a cut-off record in front)
     size_t carry = 0;
     bool eof = false, first_read = true, header_done = false;

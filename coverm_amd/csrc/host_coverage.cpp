@@ -2,6 +2,7 @@
 // statistics, the three scan drivers, CoverageTaker implementations and CoveragePrinter.
 // Pure C++17, no HIP: this is where the reference's Rust `calculate_coverage` / takers / printers sit.
 #include "../../include/coverm_host.h"
+#include "knobs.h"
 
 #include <algorithm>
 #include <mutex>
@@ -465,7 +466,7 @@ public:
     void run(size_t n, std::function<void(size_t, size_t)> fn) {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         size_t want = std::min<size_t>({(size_t)4, (size_t)hw, n / 512 + 1});
-        if (const char *e = getenv("COVERM_FINALISE_THREADS")) want = std::max(1, atoi(e));
+        { long long v; if (covknob::get("finalise_threads", v)) want = (size_t)std::max<long long>(1, v); }
         if (want <= 1) { fn(0, n); return; }
         std::lock_guard<std::mutex> rl(run_m_);
         while (th_.size() + 1 < want) { uint64_t g; { std::lock_guard<std::mutex> lk(m_); g = gen_; } th_.emplace_back([this, g] { worker(g); }); }

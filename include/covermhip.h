@@ -313,7 +313,7 @@ cov_status cov_fetch_estimates(cov_session *s, float *out);                     
 
 /* ---- bounded record store.  The reference holds one contig at a time and flushes it when the tid changes (contig.rs:128-155), so a
  * sample may be arbitrarily large.  The session's record store keeps as many contigs as fit under a cap (2^31 records / 2^31 CIGAR
- * words by default; COVERM_STORE_CAP_RECORDS / COVERM_STORE_CAP_CIGAR, read by cov_create).  When cov_push_batch, cov_push_batch_device
+ * words by default; COVERM_KNOBS="store_cap_records=N,store_cap_cigar=M", read by cov_create).  When cov_push_batch, cov_push_batch_device
  * or the device ingest would take it past the cap, the pipeline runs over what the store holds, the contigs that are complete stay on
  * the host, the records from the first considered record of the contig in flight onwards move to the front of the store and the call
  * goes on ("a spill"); cov_finish / cov_fetch_hist / cov_gather then return the whole sample (record indices count from the sample's first

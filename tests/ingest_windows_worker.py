@@ -1,5 +1,5 @@
 """Runs in its own process (the window size of the device ingest is read once per process): tests/test_gpu_ingest.py sets
-COVERM_INGEST_ROUND_BLOCKS / COVERM_INGEST_CARRY_KB so that small files are parsed in many windows.
+COVERM_KNOBS ingest_round_blocks / ingest_carry_kb so that small files are parsed in many windows.
 argv: mode (short | long | carry_overflow) and a scratch directory."""
 import os
 import sys

@@ -10,6 +10,7 @@ from coverm_amd import synth
 from oracle import bamio
 from tests.fixtures import load_fixture
 from tests.golden import cases
+from tests.knobs import set_knobs
 
 REF_DATA = "/root/reference/tests/data"
 FIELDS = ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "cigar_off", "cigar")
@@ -155,7 +156,7 @@ def _same_records(a, b):
 def test_streamed_reader_equals_whole_file_reader(tmp_path, monkeypatch, window_kb, threads, with_seq):
     """Window by window (windows far smaller than the file, so records and BGZF blocks straddle every boundary) the
     streamed reader must hand out exactly the records covh_bam_open decodes, in order."""
-    monkeypatch.setenv("COVERM_STREAM_WINDOW_KB", str(window_kb))
+    set_knobs(monkeypatch, stream_window_kb=window_kb)
     ref = synth.make_reference(30, 5_000_000, seed=8, min_len=5000, max_len=800_000)
     b = synth.make_reads(ref, 60_000, seed=9)
     p = str(tmp_path / "s.bam")
@@ -174,7 +175,7 @@ def test_streamed_reader_equals_whole_file_reader(tmp_path, monkeypatch, window_
 
 def test_streamed_reader_fixtures_and_big_header(tmp_path, monkeypatch):
     """Reference fixtures re-encoded (tiny BGZF blocks; eg2 has a 54 579-sequence header that spans many windows)."""
-    monkeypatch.setenv("COVERM_STREAM_WINDOW_KB", "64")
+    set_knobs(monkeypatch, stream_window_kb=64)
     for name in ["7seqs.reads_for_seq1_and_seq2.bam", "k141_2005182.bam", "eg2.bam", "2seqs.reads_for_seq1.with_unmapped.bam"]:
         d = load_fixture(name)
         p = str(tmp_path / (name + ".re.bam"))
@@ -189,7 +190,7 @@ def test_streamed_reader_fixtures_and_big_header(tmp_path, monkeypatch):
 def test_streamed_spans_partition_the_file(tmp_path, monkeypatch, spans):
     """span k of n: every record in exactly one span, spans cut at tid changes, concatenation == the whole file; records
     without a reference (tid -1, at the end of a sorted BAM) go to the last span."""
-    monkeypatch.setenv("COVERM_STREAM_WINDOW_KB", "128")
+    set_knobs(monkeypatch, stream_window_kb=128)
     ref = synth.make_reference(40, 6_000_000, seed=18, min_len=5000, max_len=800_000)
     b = synth.make_reads(ref, 80_000, seed=19)
     n_un = 500                                      # unplaced unmapped reads at the end
@@ -216,7 +217,7 @@ def test_streamed_spans_partition_the_file(tmp_path, monkeypatch, spans):
 
 
 def test_streamed_reader_errors(tmp_path, monkeypatch):
-    monkeypatch.setenv("COVERM_STREAM_WINDOW_KB", "64")
+    set_knobs(monkeypatch, stream_window_kb=64)
     b = load_fixture("7seqs.reads_for_seq1_and_seq2.bam")
     good = str(tmp_path / "good.bam")
     bamio.write_bam(good, b, block=700)

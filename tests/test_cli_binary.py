@@ -8,6 +8,7 @@ import pytest
 from oracle import bamio
 from tests.fixtures import FIXDIR, load_fixture
 from tests.golden import cases
+from tests.knobs import with_knobs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "coverm_amd", "coverm-amd")
@@ -189,7 +190,7 @@ def test_cli_binary_streamed_equals_whole_file_and_oracle(tmp_path):
     p = str(tmp_path / "s.bam")
     cbam.write_bam(p, ref.names, ref.lengths, batch, with_seq=2)
     methods = ["mean", "trimmed_mean", "covered_fraction", "covered_bases", "variance", "length", "count", "reads_per_base", "rpkm", "tpm", "anir"]
-    env = dict(os.environ, COVERM_STREAM_WINDOW_KB="256", COVERM_CLI_TIMING="1", COVERM_NO_GPU_INGEST="1")
+    env = with_knobs(dict(os.environ, COVERM_CLI_TIMING="1", COVERM_NO_GPU_INGEST="1"), stream_window_kb=256)
     a = subprocess.run([BIN, "contig", "-b", p, "-t", "6", "-m"] + methods, capture_output=True, text=True, timeout=300, env=env)
     b = subprocess.run([BIN, "contig", "-b", p, "-t", "6", "--no-stream", "-m"] + methods, capture_output=True, text=True, timeout=300)
     assert a.returncode == 0, a.stderr
@@ -198,7 +199,7 @@ def test_cli_binary_streamed_equals_whole_file_and_oracle(tmp_path):
     assert a.stdout == b.stdout
     assert a.stdout == O.run_cli("contig", [p], bams=[_bamdata(ref, batch)], methods=methods)
     # default: device ingest (GPU inflate + parse), small staging pieces so that blocks straddle them
-    env2 = dict(os.environ, COVERM_INGEST_PIECE_KB="512", COVERM_CLI_TIMING="1")
+    env2 = with_knobs(dict(os.environ, COVERM_CLI_TIMING="1"), ingest_piece_kb=512)
     c = subprocess.run([BIN, "contig", "-b", p, "-t", "6", "-m"] + methods, capture_output=True, text=True, timeout=300, env=env2)
     assert c.returncode == 0, c.stderr
     assert "device ingest" in c.stderr and c.stdout == a.stdout
@@ -245,7 +246,7 @@ def test_cli_binary_span_sharded_devices(tmp_path, mode):
     p = str(tmp_path / "s.bam")
     cbam.write_bam(p, ref.names, ref.lengths, batch, with_seq=2)
     extra = ["-m", "mean", "trimmed_mean", "variance", "count", "anir"] if mode == "contig" else ["-s", "~", "-m", "relative_abundance", "mean", "variance"]
-    env = dict(os.environ, COVERM_STREAM_WINDOW_KB="512")
+    env = with_knobs(os.environ, stream_window_kb=512)
     one = subprocess.run([BIN, mode, "-b", p, "-t", "4"] + extra, capture_output=True, text=True, timeout=300, env=env)
     three = subprocess.run([BIN, mode, "-b", p, "-t", "6", "--devices", "0,0,0"] + extra, capture_output=True, text=True, timeout=300, env=env)
     assert one.returncode == 0, one.stderr

@@ -13,6 +13,7 @@ import pytest
 
 from oracle import bamio, oracle as O
 from tests.golden import cases
+from tests.knobs import with_knobs
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 RAW = os.path.join(HERE, "golden", "raw")
@@ -158,11 +159,11 @@ def test_output_does_not_depend_on_the_windows(tmp_path, window_kb):
     for si, sp in enumerate(srcs):
         for mi, mode in enumerate(modes):
             want, got = str(tmp_path / ("w%d_%d.bam" % (si, mi))), str(tmp_path / ("g%d_%d.bam" % (si, mi)))
-            env = dict(os.environ); env.pop("COVERM_FILTER_WINDOW_KB", None)
+            env = with_knobs(os.environ, filter_window_kb=None)
             r = subprocess.run([BIN, "filter", "-b", sp, "-o", want, "-t", "2"] + mode, capture_output=True, text=True, env=env, timeout=120)
             assert r.returncode == 0, r.stderr[-1000:]
             r = subprocess.run([BIN, "filter", "-b", sp, "-o", got, "-t", "3"] + mode, capture_output=True, text=True,
-                               env=dict(env, COVERM_FILTER_WINDOW_KB=str(window_kb)), timeout=300)
+                               env=with_knobs(env, filter_window_kb=window_kb), timeout=300)
             assert r.returncode == 0, r.stderr[-1000:]
             assert open(got, "rb").read() == open(want, "rb").read(), (sp, mode)
             if si == 0 and mi == 2:         # and the pair branch really selects pairs here
@@ -236,7 +237,7 @@ def test_random_adversarial_files_against_the_oracle(tmp_path, seed):
             case["single"] = (30, 0.0, 0.0)
         out = str(tmp_path / ("o%d.bam" % trial))
         r = subprocess.run([BIN, "filter", "-b", src, "-o", out, "-t", "2"] + flags_of(case, inverse), capture_output=True, text=True, timeout=60,
-                           env=dict(os.environ, COVERM_FILTER_WINDOW_KB=str(int(rng.choice([1, 64, 65536])))))
+                           env=with_knobs(os.environ, filter_window_kb=int(rng.choice([1, 64, 65536]))))
         assert r.returncode == 0, r.stderr[-1000:]
         fp = O.FilterParameters(O.FlagFilter(*ff), case["single"][0], float(np.float32(case["single"][1])), float(np.float32(case["single"][2])),
                                 case["mapq"], case["pair"][0], float(np.float32(case["pair"][1])), float(np.float32(case["pair"][2])))

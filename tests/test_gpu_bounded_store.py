@@ -16,16 +16,16 @@ from coverm_amd.native import CovError, ERR_NM_MISSING, ERR_UNSORTED
 from oracle import oracle as O
 from tests import binary
 from tests.test_gpu_abi_parity import _long_read_batch, compare, to_bamdata, to_batch
+from tests.knobs import set_knobs, with_knobs
 
 pytestmark = pytest.mark.gpu
 
-CAPS = {"COVERM_STORE_CAP_RECORDS": "50000", "COVERM_STORE_CAP_CIGAR": "200000"}
+CAPS = dict(store_cap_records=50000, store_cap_cigar=200000)      # COVERM_KNOBS names (csrc/knobs.h)
 
 
 @pytest.fixture
 def small_caps(monkeypatch):
-    for k, v in CAPS.items():
-        monkeypatch.setenv(k, v)       # read by cov_create
+    set_knobs(monkeypatch, **CAPS)       # read by cov_create
 
 
 def spills(s):
@@ -134,7 +134,7 @@ def test_device_ingest_through_the_binary_with_small_windows_and_caps(tmp_path):
     both = merge_sorted(batch, longs)
     b = to_bamdata(both, ref.lengths, ref.names)
     path = _bam(tmp_path, ref, both, "bounded")
-    env = dict(CAPS, COVERM_INGEST_ROUND_BLOCKS="128", COVERM_CLI_TIMING="1")
+    env = with_knobs(dict(COVERM_CLI_TIMING="1"), ingest_round_blocks=128, **CAPS)
     args = dict(methods=["mean", "trimmed_mean", "covered_fraction", "covered_bases", "variance", "length", "count", "reads_per_base", "rpkm", "tpm", "anir"])
     want = O.run_cli("contig", [path], bams=[b], **args)
     r = binary.run_full("contig", [path], env=env, **args)
@@ -142,7 +142,7 @@ def test_device_ingest_through_the_binary_with_small_windows_and_caps(tmp_path):
     assert "bounded store: spill" in r.stderr
     assert binary.run("contig", [path], **args) == want                       # and without the caps
     # the CPU reader's pushes (no device ingest) and two tid spans meeting in cov_gather, each spilling on its own
-    assert binary.run("contig", [path], env=dict(CAPS, COVERM_NO_GPU_INGEST="1"), **args) == want
+    assert binary.run("contig", [path], env=with_knobs(dict(COVERM_NO_GPU_INGEST="1"), **CAPS), **args) == want
     assert binary.run("contig", [path], env=env, devices="0,0", **args) == want
     args = dict(methods=["relative_abundance", "mean", "variance"], separator="~")
     assert binary.run("genome", [path], env=env, **args) == O.run_cli("genome", [path], bams=[b], **args)
@@ -154,8 +154,7 @@ def test_reset_in_the_middle_of_an_ingest_that_already_spilled(tmp_path, monkeyp
     the session must then take a sample as if nothing had happened.  Drives the raw cov_ingest_* calls of include/covermhip.h (what
     covh_bam_gpu_ingest does) with the file's own BGZF block table."""
     import zlib
-    for k, v in dict(CAPS, COVERM_INGEST_ROUND_BLOCKS="64").items():
-        monkeypatch.setenv(k, v)
+    set_knobs(monkeypatch, ingest_round_blocks=64, **CAPS)
     ref, batch = short_sample(220_000, 120, seed=141)
     path = _bam(tmp_path, ref, batch, "reset")
     raw = open(path, "rb").read()

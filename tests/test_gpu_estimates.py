@@ -13,6 +13,7 @@ from coverm_amd.native import CovError
 from tests.fixtures import load_fixture
 from tests.golden import cases
 from tests.test_gpu_abi_parity import _long_read_batch, to_batch
+from tests.knobs import set_knobs
 
 pytestmark = pytest.mark.gpu
 
@@ -121,7 +122,7 @@ def test_an_assembly_of_many_short_contigs():
 
 
 def test_with_spills_of_the_bounded_store(monkeypatch):
-    monkeypatch.setenv("COVERM_STORE_CAP_RECORDS", "40000")
+    set_knobs(monkeypatch, store_cap_records=40000)
     ref = synth.make_reference(150, 12_000_000, seed=11, min_len=1500, max_len=300_000)
     batch = synth.make_reads(ref, 200_000, seed=12)
     for est in estimator_sets(75)[:2]:

@@ -13,6 +13,7 @@ from coverm_amd import synth
 from coverm_amd.engine import FilterConfig, Session
 from oracle import bamio
 from tests.fixtures import load_fixture, swap_halves
+from tests.knobs import set_knobs, with_knobs
 
 pytestmark = pytest.mark.gpu
 FIELDS = ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq", "cigar_off", "cigar")
@@ -70,7 +71,7 @@ def test_device_ingest_equals_cpu_reader(tmp_path, monkeypatch, with_seq, piece_
     """Product writer output (libdeflate / zlib level 1: dynamic-Huffman blocks), whole pieces and 64 KiB pieces (every BGZF
     block and many headers straddle a staging piece)."""
     if piece_kb:
-        monkeypatch.setenv("COVERM_INGEST_PIECE_KB", str(piece_kb))
+        set_knobs(monkeypatch, ingest_piece_kb=piece_kb)
     ref = synth.make_reference(40, 6_000_000, seed=18, min_len=5000, max_len=800_000)
     b = synth.make_reads(ref, 120_000, seed=19)
     p = str(tmp_path / "s.bam")
@@ -184,11 +185,8 @@ def test_device_ingest_in_many_windows(tmp_path, mode, round_blocks, carry_kb, c
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, COVERM_INGEST_ROUND_BLOCKS=str(round_blocks), COVERM_INGEST_CARRY_KB=str(carry_kb))
-    if cwin_kb:
-        env["COVERM_INGEST_CWIN_KB"] = str(cwin_kb)
-    if piece_kb:
-        env["COVERM_INGEST_PIECE_KB"] = str(piece_kb)
+    env = with_knobs(os.environ, ingest_round_blocks=round_blocks, ingest_carry_kb=carry_kb, ingest_cwin_kb=cwin_kb or None,
+                     ingest_piece_kb=piece_kb or None)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "ingest_windows_worker.py"), mode, str(tmp_path)], capture_output=True, text=True,
                        env=env, cwd=root, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]

@@ -12,6 +12,7 @@ from oracle import oracle as O
 from tests.fixtures import load_fixture
 from tests.golden import cases
 from tests.test_host_golden import _paired_sample
+from tests.knobs import set_knobs
 
 pytestmark = pytest.mark.gpu
 FIELDS = ("tid", "pos", "flag", "mapq", "nm", "nm_kind", "l_seq")
@@ -75,7 +76,7 @@ def test_synthetic_pairs_with_repeated_names(tmp_path, monkeypatch, params, chun
     or more pairs (entries with more than two records: collected, replayed in file order, judged).  chunk = 2048: dozens of table
     chunks cut at reference boundaries."""
     if chunk:
-        monkeypatch.setenv("COVERM_PAIR_CHUNK", str(chunk))
+        set_knobs(monkeypatch, pair_chunk=chunk)
     params = dict(params)
     proper = params.pop("proper", False)
     b = _paired_sample(40_000, seed=3)

@@ -19,6 +19,7 @@ from coverm_amd.host import CoverageTaker, SampleResult
 from oracle import oracle as O
 from tests.fixtures import FIXDIR, load_fixture
 from tests.golden import cases
+from tests.knobs import set_knobs
 
 
 def alignment_file(name) -> AlignmentFile:
@@ -283,9 +284,9 @@ def test_contig_scan_over_thousands_of_contigs_is_the_same_in_parallel(monkeypat
         return SampleResult(af_.stoit_name, out, hist if want_hist else None, prim)
     for kw in (dict(methods=["mean", "trimmed_mean", "covered_fraction", "variance", "rpkm", "tpm", "anir", "count"]),
                dict(methods=["mean", "variance"], no_zeros=True, output_format="sparse")):
-        monkeypatch.setenv("COVERM_FINALISE_THREADS", "4")
+        set_knobs(monkeypatch, finalise_threads=4)
         par = cli.run("contig", [af], sample_provider=provider, **kw)
-        monkeypatch.setenv("COVERM_FINALISE_THREADS", "1")
+        set_knobs(monkeypatch, finalise_threads=1)
         ser = cli.run("contig", [af], sample_provider=provider, **kw)
         assert par == ser == O.run_cli("contig", ["data/many.bam"], bams=[b], **kw)
         assert par.count("\n") > 1000

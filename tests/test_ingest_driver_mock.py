@@ -10,6 +10,7 @@ import sys
 import pytest
 
 from coverm_amd import native
+from tests.knobs import with_knobs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -76,7 +77,7 @@ def test_ingest_driver_feeds_consistent_blocks(tmp_path, mode, piece_kb, io):
     env = dict(os.environ)
     env.pop("COVERM_INGEST_IO", None)
     if piece_kb:
-        env["COVERM_INGEST_PIECE_KB"] = str(piece_kb)
+        env = with_knobs(env, ingest_piece_kb=piece_kb)
     extra, code = IO_MODES[io]
     env.update(extra)
     r = subprocess.run([sys.executable, "-c", WORKER % ROOT, mode, str(tmp_path)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)

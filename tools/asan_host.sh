@@ -21,6 +21,7 @@ struct cov_session { std::vector<uint8_t> comp; std::vector<cov_bgzf_block> bloc
 extern "C" {
 int cov_abi_version(void) { return COVERMHIP_ABI_VERSION; }
 int cov_mock_ingest_present(void) { return 1; }
+int covh_timing_on(void) { static const int on = getenv("COVERM_CLI_TIMING") != nullptr; return on; }      // (lives in covermhip.hip in the real build)
 // cov_host_free reports whether the pointer was one of cov_host_alloc's (callers free other pointers themselves)
 static std::mutex g_hm; static std::set<void *> g_host;
 void *cov_host_alloc(size_t n) { void *p = malloc(n ? n : 1); std::lock_guard<std::mutex> lk(g_hm); g_host.insert(p); return p; }
@@ -44,6 +45,7 @@ cov_status cov_copy_depth(cov_session *, uint32_t, int32_t *) { return COV_ERR_H
 cov_status cov_reset(cov_session *) { return COV_ERR_HIP; }
 cov_status cov_kernel_ms(const cov_session *, cov_kernel_id, double *, uint32_t *) { return COV_ERR_HIP; }
 cov_status cov_algorithmic_bytes(const cov_session *, uint64_t *) { return COV_ERR_HIP; }
+cov_status cov_last_paths(const cov_session *, cov_path_counts *) { return COV_ERR_HIP; }
 cov_status cov_ingest_begin(cov_session *s, uint64_t bytes, uint64_t first, int) {
     s->comp.assign(bytes, 0xAA); s->blocks.clear(); s->first = first; s->fed_to = 0; s->active = true; return COV_OK;
 }

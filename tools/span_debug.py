@@ -6,7 +6,7 @@ batch = synth.make_reads(ref, 200_000, seed=52)
 p = "/tmp/s.bam"
 cbam.write_bam(p, ref.names, ref.lengths, batch, with_seq=2)
 BIN = "coverm_amd/coverm-amd"
-env = dict(os.environ, COVERM_STREAM_WINDOW_KB="512", COVERM_CLI_TIMING="1")
+env = dict(os.environ, COVERM_KNOBS="stream_window_kb=512", COVERM_CLI_TIMING="1")
 base = subprocess.run([BIN, "contig", "-b", p, "-t", "4", "-m", "mean", "trimmed_mean", "variance", "count", "anir"], capture_output=True, text=True, env=env)
 print("base rc", base.returncode, base.stderr[-300:])
 for devs in ("0,0", "0,0,0", "0,0,0", "0,0,0"):

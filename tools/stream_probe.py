@@ -25,7 +25,7 @@ for thr in (16, 32, 64, 128, 256):
     L.covh_bam_close(h)
     print("whole-file threads %d: %.3fs = %.1f M rec/s" % (thr, t1, reads / t1 / 1e6), flush=True)
 for win_kb in (32768, 262144, 1048576):
-    os.environ["COVERM_STREAM_WINDOW_KB"] = str(win_kb)
+    os.environ["COVERM_KNOBS"] = "stream_window_kb=%d" % win_kb
     for thr in (16, 64, 128, 256):
         st = {}
         t = time.time()
