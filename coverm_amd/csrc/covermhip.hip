@@ -188,6 +188,7 @@ struct cov_session {
 
     // device ingest (cov_ingest_*): compressed file and inflated stream in HBM, BGZF block table, record-boundary scratch
     DevBuf<uint8_t> g_scratch, g_carry;
+    DevBuf<u32> g_crc_tab;             // k_crc32_wave's tables (crcw::build_tables), uploaded by the session's first cov_ingest_begin
     DevBuf<uint8_t> g_cwin[3];                             // compressed bytes, one buffer per round in flight (file offsets biased by the round's origin)
     DevBuf<uint8_t> g_win[3];                              // inflated windows (one k_inflate round each): [carry area | blocks]
     DevBuf<covi::BgzfBlock> g_blocks;
@@ -493,6 +494,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
 
 static void ingest_free_buffers(cov_session *s) {
     s->g_scratch.release(); s->g_carry.release(); s->g_blocks.release(); s->g_status.release();
+    s->g_crc_tab.release();
     for (int k = 0; k < 3; k++) { s->g_win[k].release(); s->g_cwin[k].release(); }
     for (int k = 0; k < 4; k++) { s->g_seg[k].release(); s->g_recbase[k].release(); s->g_cigbase[k].release(); }
     s->g_tok.release(); s->g_ntok.release(); s->g_tok2.release(); s->g_ntok2.release();
@@ -1407,6 +1409,11 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     s->ing_check_crc = check_crc ? 1 : 0;
     HIPCHK(s->g_result.reserve(8 + 4 * 8, s->stream));
     HIPCHK(s->g_carry.reserve(inflate_kernel(s).carry, s->stream));
+    if (!s->g_crc_tab.p) {
+        static const std::vector<u32> crc_tables = [] { std::vector<u32> t(covi::crcw::TABLE_WORDS); covi::crcw::build_tables(t.data()); return t; }();
+        HIPCHK(s->g_crc_tab.reserve(covi::crcw::TABLE_WORDS, s->stream));
+        HIPCHK(hipMemcpyAsync(s->g_crc_tab.p, crc_tables.data(), covi::crcw::TABLE_WORDS * sizeof(u32), hipMemcpyHostToDevice, s->stream));
+    }
     HIPCHK(s->g_blocks.reserve(compressed_bytes / 8192 + 1024, s->stream));
     HIPCHK(s->g_status.reserve(compressed_bytes / 8192 + 1024, s->stream));
     if (compressed_bytes / 16384 + 1024 > s->h_blocks_cap) {     // page-locked mirror of the block table: sized once for ordinary ~20 KB blocks (it grows if they are smaller)
@@ -1575,9 +1582,15 @@ static cov_status launch_round_(cov_session *s, uint64_t n64, bool final) {
         // CRC-32 pass, whose verdict is only looked at in cov_ingest_end (the aux stream is in order, so CRC(w) is done before LZ(w + 1)
         // and with it before anything may overwrite window w)
         HIPCHK(hipEventRecord(s->ing_lz_done[bb], s->ing_aux));
-        if (s->ing_check_crc)
-            hipLaunchKernelGGL(covi::k_crc32, dim3((n + 255u) / 256u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n,
-                               (const uint8_t *)out_bias, s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
+        if (s->ing_check_crc) {
+            if (K.version == 3)      // a wave per block, coalesced; resident workgroups stride over the window's blocks
+                hipLaunchKernelGGL(covi::k_crc32_wave, dim3(std::min<u32>((n + 7u) / 8u, (u32)s->n_cus * 4u)), dim3(512), 0, s->ing_aux,
+                                   (const covi::BgzfBlock *)(s->g_blocks.p + b0), n, (const uint8_t *)out_bias, s->g_status.p + b0,
+                                   reinterpret_cast<u32 *>(s->g_result.p + 3), (const u32 *)s->g_crc_tab.p);
+            else                     // the lane-per-block combination keeps the lane-per-block CRC
+                hipLaunchKernelGGL(covi::k_crc32, dim3((n + 255u) / 256u), dim3(256), 0, s->ing_aux, (const covi::BgzfBlock *)(s->g_blocks.p + b0), n,
+                                   (const uint8_t *)out_bias, s->g_status.p + b0, reinterpret_cast<u32 *>(s->g_result.p + 3));
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamWaitEvent(s->ing_parse, s->ing_lz_done[bb], 0));
     }

@@ -12,7 +12,8 @@
 //                   bandwidth is not the limit.
 //   k_lz_resolve    one WAVE per block executes its match tokens (kept in place, in the first bytes of their own match), the
 //                   bytes of all matches that are ready spread over the 64 lanes
-//   k_crc32         every inflated block against the CRC-32 of its BGZF trailer
+//   k_crc32_wave    every inflated block against the CRC-32 of its BGZF trailer: a wave per block, 8-byte columns, csrc/crc_wave_core.h
+//   k_crc32         the same with a lane per block (with the lane-per-block inflate)
 //   k_bam_find      per segment of the inflated stream: first offset from which a chain of 8 plausible records starts
 //   k_bam_hop       per segment: hop the records (block_size chain), count records and CIGAR words, note where it landed
 //   k_bam_verify    every segment's chain must land exactly on the start the next segment found (then the result equals the
@@ -743,6 +744,68 @@ __global__ __launch_bounds__(256) void k_crc32(const BgzfBlock *__restrict__ blo
 // crc(B) with the 64 powers as compile-time constants — was built and measured: 5.6 ms per full round against 2.8 (0.8 against 1.9 for a
 // 12 k-block round).  Either way a wave's load touches 64 different cache lines, and that, not the length of a lane's chain, is what the
 // kernel's time is made of.  profiles/r04_crc_wave.log.)
+// k_crc32_wave (round 6, the default): ONE WAVE per block, the block a matrix of 8-byte words with 64 columns, lane l owning column l — every
+// load of the wave is 512 consecutive bytes — and the columns' registers joined by a scan over the lanes.  The arithmetic (tables for a
+// distance of 512 bytes, the scan's operator, the unaligned head, the tail) is csrc/crc_wave_core.h, which runs lane by lane on the CPU
+// against zlib in tests/test_crc_wave_core.py.  Workgroups of eight waves stay resident and stride over the window's blocks, so the
+// 36 KiB of tables (built on the host, crcw::build_tables) come into LDS once per workgroup.
+#define CRCW_FN __host__ __device__ __forceinline__
+#include "crc_wave_core.h"
+
+__device__ __forceinline__ u32 crc_lane_scan(const u32 *T, u32 s, int lane) {
+#pragma unroll
+    for (u32 m = 0; m < 6u; m++) {
+        u32 left = (u32)__shfl_up((int)s, 1u << m);
+        if (lane < (int)(1u << m)) left = 0u;
+        s = crcw::scan_combine(T, m, left, s);
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(512) void k_crc32_wave(const BgzfBlock *__restrict__ blocks, u32 n_blocks, const uint8_t *__restrict__ out,
+                                                    u32 *__restrict__ status, u32 *__restrict__ n_failed, const u32 *__restrict__ tables) {
+    __shared__ u32 T[crcw::TABLE_WORDS];
+    for (u32 i = threadIdx.x; i < crcw::TABLE_WORDS; i += 512u) T[i] = tables[i];
+    __syncthreads();
+    const int lane = (int)(threadIdx.x & 63u);
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 8u + (threadIdx.x >> 6))), n_waves = gridDim.x * 8u;
+    for (u32 b = wave; b < n_blocks; b += n_waves) {
+        if (status[b] != INF_OK) continue;
+        const BgzfBlock B = blocks[b];
+        const uint8_t *p = out + B.out_off;
+        const u32 n = B.isize;
+        u32 crc;
+        if (n < crcw::SMALL) crc = crcw::small_block(T, p, n);
+        else {
+            const crcw::Shape S = crcw::shape_of(p, n);
+            const u64 *g = reinterpret_cast<const u64 *>(S.base);
+            u32 C = 0;
+            if (S.rows) {
+                u32 s = 0;
+                u64 w = crcw::fix_word(S, (u32)lane, g[lane]);
+                for (u32 j = 1; j < S.rows; j++) {       // the next row's word is on its way while this one is absorbed
+                    const u64 wn = g[64u * j + (u32)lane];
+                    s = crcw::step(T, crcw::T_LO512, crcw::T_HI512, s, w);
+                    w = wn;
+                }
+                s = crcw::step(T, crcw::T_LO8, crcw::T_HI8, s, w);
+                C = (u32)__builtin_amdgcn_readlane((int)crc_lane_scan(T, s, lane), 63);
+            }
+            if (S.tail_words) {      // the partial row's words on the HIGHEST lanes, the register so far entering with the first of them
+                const int lp = lane - (int)(64u - S.tail_words);
+                u32 t = 0;
+                if (lp >= 0) {
+                    const u32 idx = 64u * S.rows + (u32)lp;
+                    t = crcw::step(T, crcw::T_LO8, crcw::T_HI8, lp == 0 ? C : 0u, crcw::fix_word(S, idx, g[idx]));
+                }
+                C = (u32)__builtin_amdgcn_readlane((int)crc_lane_scan(T, t, lane), 63);
+            }
+            crc = crcw::finish(T, S, C, g[64u * S.rows + S.tail_words]);
+        }
+        if (crc != B.crc && lane == 0) { status[b] = INF_ERR_CRC; atomicAdd(n_failed, 1u); }
+    }
+}
+
 // ------------------------------------------------------------------------------------ BAM record parsing on the device
 // The inflated stream is parsed window by window (one window = the blocks of one k_inflate round, in its own buffer): the bytes
 // of a record cut by the window's end (the "tail") are carried in front of the next window's bytes, so a window always starts
