@@ -371,3 +371,58 @@ def test_reference_fixture_files_unmodified_through_the_device_ingest(name):
         np.testing.assert_array_equal(getattr(got, f), np.asarray(g).astype(getattr(got, f).dtype), err_msg=f)
     np.testing.assert_array_equal(got.cigar_off, exp.cigar_off)
     np.testing.assert_array_equal(got.cigar, exp.cigar)
+
+
+def _reblock(raw: bytes, sizes, level=1, wrong_crc_at=None):
+    """The inflated stream of the BGZF file `raw`, cut into blocks of the given inflated sizes (cycled), each deflated on its own; the
+    CRC-32 of block number `wrong_crc_at` gets one bit flipped.  -> (file bytes, number of blocks)"""
+    data, q = b"", 0
+    while q < len(raw):
+        bs = int.from_bytes(raw[q + 16:q + 18], "little") + 1
+        data += zlib.decompress(raw[q + 18:q + bs - 8], -15)
+        q += bs
+    out, off, k = bytearray(), 0, 0
+    while off < len(data):
+        n = min(sizes[k % len(sizes)], len(data) - off)
+        chunk = data[off:off + n]
+        co = zlib.compressobj(level if n < 60_000 else max(level, 1), zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        if len(comp) + 26 > 65536:                      # (random bytes at the largest sizes: store them)
+            co = zlib.compressobj(0, zlib.DEFLATED, -15)
+            comp = co.compress(chunk) + co.flush()
+        crc = zlib.crc32(chunk) ^ (0x0400 if k == wrong_crc_at else 0)
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", crc, n)
+        off += n
+        k += 1
+    out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    return bytes(out), k
+
+
+RAGGED = [1, 2, 7, 8, 9, 15, 16, 17, 23, 24, 25, 63, 64, 65, 503, 504, 505, 511, 512, 513, 519, 520, 1023, 1024, 1025, 1031, 4095, 4096, 4097,
+          32767, 65279, 65280, 65281]
+
+
+def test_crc_of_ragged_blocks(tmp_path):
+    """k_crc32_wave (and, in the lane-per-block combination, k_crc32) over blocks of every length class of its scheme — below the bytewise
+    limit of 16, around a word, around a row of 512 bytes, around two rows, around htslib's 0xff00 — starting at whatever alignment the
+    lengths in front leave (the sizes are odd on purpose): every block's CRC is accepted, the records equal the CPU reader's, and a file
+    with ONE wrong trailer per length class is handed back (bgzf.c:inflate_block behind bam_generator.rs:125-129 fails such a file)."""
+    ref = synth.make_reference(12, 900_000, seed=51, min_len=1500, max_len=200_000)
+    b = synth.make_reads(ref, 40_000, seed=53)
+    good = str(tmp_path / "good.bam")
+    cbam.write_bam(good, ref.names, ref.lengths, b, with_seq=2, threads=2)
+    raw = open(good, "rb").read()
+    body, n_blocks = _reblock(raw, RAGGED)
+    assert n_blocks > 2 * len(RAGGED)
+    p = str(tmp_path / "ragged.bam")
+    open(p, "wb").write(body)
+    w = _check(p, threads=2)
+    assert w.records.n_records == b.n_records
+    # one wrong trailer at a time, in the 26th cycle of the sizes (~2.3 MB into the file: the host inflates the first MiB itself, for the header)
+    with Session(0, FilterConfig(), 75) as s:
+        for j in (0, 3, 6, 8, 12, 14, 16, 19, 20, 23, 27, 29, 30, 31, 32):
+            bad = str(tmp_path / "bad.bam")
+            open(bad, "wb").write(_reblock(raw, RAGGED, wrong_crc_at=25 * len(RAGGED) + j)[0])
+            with pytest.raises(cbam.IngestFallback):
+                cbam.gpu_ingest(s, bad, threads=2)
+            assert cbam.session_records(s).n_records == 0, RAGGED[j]
