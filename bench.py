@@ -300,6 +300,10 @@ def end_to_end(a, threads):
         cmd = [BIN, "contig", "-b", path, "-m"] + ALL_METHODS + E2E_FLAGS + ["-t", str(threads), "-o", out_tsv]
         gpu_s, rep_seconds, gpu_err, gpu_rss = run_binary(cmd, 3)
         gpu_text = open(out_tsv).read()
+        # the same command as ONE process (csrc/cli_main.cc: by default the work runs in a child and the command returns when the table is
+        # written, the kernel taking the runtime's queues, device mappings and page-locked slots apart behind it; here the caller waits for that too)
+        one_s, one_reps, _, _ = run_binary(cmd, 2, env={"COVERM_NO_FAST_EXIT": "1"})
+        one_s = min(one_reps)
         mapped = [l for l in gpu_err.splitlines() if "reads mapped out of" in l]
         # ---- CPU, same basis: same decoder + oracle scan, best of three each
         dec_s, dec_all, recs = cpu_decode(path, threads, 3)
@@ -315,6 +319,8 @@ def end_to_end(a, threads):
         res.update(
             gpu=dict(seconds=gpu_s, seconds_is="median of three runs", reads_per_s=rmp[0] / gpu_s, reads_per_s_is="considered (aligned, filter-passing) reads per second: the metric's unit",
                      records_per_s=reads / gpu_s, rep_seconds=rep_seconds, max_rss_bytes=gpu_rss,
+                     one_process_seconds=one_s, one_process_rep_seconds=one_reps,
+                     one_process_is="best of two runs with COVERM_NO_FAST_EXIT=1: no launcher / child split, the caller also waits for the runtime's teardown",
                      command=" ".join(["coverm-amd"] + cmd[1:]), stderr_mapped=mapped[:1], stderr_timing=timing_lines(gpu_err)),
             cpu=dict(decode_s=dec_s, decode_runs=dec_all, scan_s=scan_s, scan_runs=[round(x, 3) for x in scans], seconds_is="best of three runs each",
                      reads_per_s_serial=rmp[0] / (dec_s + scan_s), reads_per_s_overlapped=rmp[0] / max(dec_s, scan_s),
@@ -324,6 +330,7 @@ def end_to_end(a, threads):
                      note="the reference overlaps htslib's inflate pool with its single scan thread: its rate lies between the two figures, "
                           "at or below the overlapped one"),
             speedup_vs_cpu_overlapped=(reads / gpu_s) / (reads / max(dec_s, scan_s)), speedup_vs_cpu_serial=(reads / gpu_s) / (reads / (dec_s + scan_s)),
+            speedup_vs_cpu_overlapped_one_process=max(dec_s, scan_s) / one_s,
             target=">= 10x the CPU path (BASELINE.json north_star)", tables_equal=same,
             tables_compared="the binary's TSV == the oracle's dense table, text equality over all %d columns x %d contigs" % (len(ALL_METHODS), len(ref.names)),
             considered_reads=rmp[0])
@@ -770,6 +777,7 @@ def main():
             "e2e_reads": e2e.get("reads"),
             "e2e_l1_s": r3((e2e.get("gpu") or {}).get("seconds")), "e2e_l1_x_overlapped": r3(e2e.get("speedup_vs_cpu_overlapped")),
             "e2e_l1_x_serial": r3(e2e.get("speedup_vs_cpu_serial")),
+            "e2e_l1_one_process_s": r3((e2e.get("gpu") or {}).get("one_process_seconds")), "e2e_l1_x_overlapped_one_process": r3(e2e.get("speedup_vs_cpu_overlapped_one_process")),
             "e2e_l6_s": r3(l6.get("gpu_seconds")), "e2e_l6_x_overlapped": r3(l6.get("speedup_vs_cpu_overlapped")), "e2e_l6_x_serial": r3(l6.get("speedup_vs_cpu_serial")),
             "cpu_decode_s": r3((e2e.get("cpu") or {}).get("decode_s")), "cpu_decode_l6_s": r3(l6.get("cpu_decode_s")), "cpu_scan_s": r3((e2e.get("cpu") or {}).get("scan_s")),
             "cpu_threads": e2e.get("threads"), "cpu_inflate_backend": (e2e.get("cpu") or {}).get("inflate_backend"),

@@ -36,6 +36,8 @@
 #include <thread>
 #include <vector>
 
+#include <emmintrin.h>      // SSE2 (x86-64 baseline): non-temporal stores for the staging slots
+
 #include "../../include/coverm_host.h"
 #include "reader_filter.h"
 #include "roctx_ranges.h"
@@ -1266,6 +1268,23 @@ const char *covh_bam_header_target_name(const covh_bam_header *h, uint32_t i) { 
 uint64_t covh_bam_header_target_len(const covh_bam_header *h, uint32_t i) { return h->h.lens[i]; }
 uint64_t covh_bam_header_first_record(const covh_bam_header *h) { return h->h.first_record; }
 
+// Bytes into a page-locked staging slot with non-temporal stores: the destination's lines are not read for ownership and do not stay in
+// the caches (the next reader of them is the DMA engine).  dst 16-byte aligned (a slot is page-aligned, chunks are multiples of 512 KiB);
+// src anywhere (a tid span starts at a block, not at a page).
+static void stream_copy(uint8_t *dst, const uint8_t *src, size_t n) {
+    size_t o = 0;
+    if (((uintptr_t)dst & 15u) == 0) {
+        for (; o + 64 <= n; o += 64) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)(src + o)), b = _mm_loadu_si128((const __m128i *)(src + o + 16));
+            const __m128i c = _mm_loadu_si128((const __m128i *)(src + o + 32)), d = _mm_loadu_si128((const __m128i *)(src + o + 48));
+            _mm_stream_si128((__m128i *)(dst + o), a); _mm_stream_si128((__m128i *)(dst + o + 16), b);
+            _mm_stream_si128((__m128i *)(dst + o + 32), c); _mm_stream_si128((__m128i *)(dst + o + 48), d);
+        }
+    }
+    if (o < n) memcpy(dst + o, src + o, n - o);
+    _mm_sfence();      // before the piece is announced: the upload that reads the slot is enqueued by another thread
+}
+
 // 0 = records are in the session's store; 1 = the file needs the CPU reader (reason in err; nothing appended); -1 = error;
 // -2 = the record keys decrease inside the span (the reference's "appears to be unsorted" text in err).
 // timing (optional, 5 doubles): seconds reading the file, waiting for staging slots, in cov_ingest_end, total, in cov_ingest_begin (allocation).
@@ -1332,14 +1351,22 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     //   per 2.6 GB span, 20.6 GB in ~1.2 s all told = 17 GB/s for the process —, which alone is longer than the whole single-device run
     //   (0.76-0.96 s), while eight staged readers under the same 16-CPU quota copy at the one reader's rate (~49 GB/s in aggregate).  The
     //   staging slots are therefore the default for any number of feeders; COVERM_INGEST_IO=mmap-upfront | mmap remain as options.
+    //   How the staging slots are FILLED (round 6, tools/ubench/copy_probe, profiles/r06_copy_probe.log): the feed was bound by the host's
+    //   memory system — 14 threads pread at 80-88 GB/s alone, but beside them the DMA out of the slots falls from 58 to 37-52 GB/s (pread's
+    //   copy_to_user reads the source, reads the destination lines for ownership and writes them; the DMA reads them once more), and the
+    //   pipeline settles where both run at ~50 GB/s.  Copying from a MAPPING of the file with non-temporal stores (no read for ownership,
+    //   nothing of the destination left in the caches) runs at 99-102 GB/s and leaves the DMA its 58-60 GB/s; zapping every chunk's pages
+    //   behind the copy (74-83 GB/s; a 20 GB mapping's page tables would otherwise cost ~0.4 s when the process ends) still does.  That is
+    //   the default; COVERM_INGEST_IO=pread keeps the preads (and is what a refused mapping falls back to).
     const char *io = getenv("COVERM_INGEST_IO");
     bool use_map = io && (!strcmp(io, "mmap") || !strcmp(io, "mmap-upfront"));
     const bool map_upfront = use_map && !strcmp(io, "mmap-upfront");
+    bool copy_map = !use_map && !(io && !strcmp(io, "pread"));
     uint8_t *map = nullptr;
     const uint64_t PG = 4096, map_len = (file_size + PG - 1) / PG * PG;
-    if (use_map) {
+    if (use_map || copy_map) {
         void *m = mmap(nullptr, (size_t)file_size, PROT_READ, MAP_SHARED, fd, 0);
-        if (m == MAP_FAILED) use_map = false; else map = (uint8_t *)m;
+        if (m == MAP_FAILED) use_map = copy_map = false; else map = (uint8_t *)m;
     }
     constexpr int NS = COV_INGEST_SLOTS;
     uint8_t *buf[NS];
@@ -1383,7 +1410,7 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
         return true;
     };
     if (use_map && !register_piece(f_lo, map_upfront ? size - f_lo : std::min<uint64_t>(piece, size - f_lo))) {     // refused: staging slots instead
-        use_map = false;
+        use_map = false; copy_map = true;      // (the mapping itself is there: its bytes are copied into the slots)
         if (!piece_env) piece = (size_t)32 << 20;
     }
     const double t_begin = now() - t_start;
@@ -1437,6 +1464,17 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     uint64_t ready = 0, fed = 0;        // pieces read so far / pieces handed to cov_ingest_feed so far
     bool reader_failed = false, reader_soft = false, stop = false;      // soft: the file can still go to the CPU reader
     std::string reader_err;
+    // The mapping's pages leave the page table again behind the copy (a 20 GB mapping left to the end of the process costs ~0.4 s there, and
+    // counts as resident meanwhile).  HOW matters: a madvise per 512 KiB chunk interrupts every thread of the process 41 000 times per 20 GB
+    // (a TLB shootdown each) and tripled the time the coordinator spends in the feed calls; the piece in front, in 4 MiB parts handed to the
+    // same pool, is an eighth of the calls (COVERM_KNOBS ingest_zap: 1 = per chunk, 2 = the piece in front (default), 0 = all at the end).
+    long long zap_mode = 2;
+    (void)covknob::get("ingest_zap", zap_mode);
+    const uint64_t ZPART = 4ull << 20;
+    auto zap_range = [&](uint64_t a, uint64_t b) {
+        const uint64_t z0 = (a + PG - 1) / PG * PG, z1 = b / PG * PG;
+        if (z1 > z0) (void)madvise(map + z0, (size_t)(z1 - z0), MADV_DONTNEED);
+    };
     std::thread reader([&]() {
         Pool pool(std::max(1, threads > 6 ? threads - 2 : threads));     // this thread's caller and the coordinator need CPUs too (12 threads read no slower than 16 under a 16-CPU quota)
         for (uint64_t k = 0; k < n_pieces; k++) {
@@ -1472,9 +1510,20 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
             }
             t0 = now();
             uint8_t *dst = buf[slot];
-            pool.run(nch, [&](size_t c) {
+            const size_t nz = (copy_map && zap_mode == 2 && k > 0) ? (size_t)((piece + ZPART - 1) / ZPART) : 0;      // the piece in front, in parts
+            pool.run(nch + nz, [&](size_t c) {
+                if (c >= nch) { const uint64_t a = off - piece + (uint64_t)(c - nch) * ZPART; zap_range(a, std::min<uint64_t>(a + ZPART, off)); return; }
                 const size_t o0 = c * chunk;
                 size_t o = o0; const size_t e = (size_t)std::min<uint64_t>(n, (uint64_t)o + chunk);
+                if (copy_map) {
+                    // from the mapping, with stores that go past the caches; the block headers are hopped in the SOURCE, whose lines the
+                    // copy has just loaded
+                    const uint8_t *src = map + off + o0;
+                    stream_copy(dst + o0, src, e - o0);
+                    prewalk(src, e - o0, off + o0, pre[(size_t)slot * chunks_per_piece + c]);
+                    if (zap_mode == 1) zap_range(off + o0, off + e);
+                    return;
+                }
                 while (o < e) {
                     const ssize_t r = pread(fd, dst + o, e - o, (off_t)(off + o));
                     if (r <= 0) { ok = false; return; }
@@ -1488,6 +1537,12 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
             if (!ok) { reader_failed = true; reader_err = std::string("read error on ") + path; cv.notify_all(); return; }
             ready = k + 1;
             cv.notify_all();
+        }
+        // what of the mapping is still in the page table goes now, beside the device's last window (the pool has nothing else to do)
+        if (copy_map && zap_mode != 1 && n_pieces) {
+            const uint64_t a0 = zap_mode == 2 ? f_lo + (n_pieces - 1) * piece : f_lo;
+            const size_t parts = (size_t)((size - a0 + ZPART - 1) / ZPART);
+            pool.run(parts, [&](size_t c) { const uint64_t a = a0 + (uint64_t)c * ZPART; zap_range(a, std::min<uint64_t>(a + ZPART, size)); });
         }
     });
     struct Join { std::thread &t; std::mutex &mu; std::condition_variable &cv; bool &stop;
@@ -1574,7 +1629,7 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
         cov_host_trim();
     }
     const double t_end = now() - t0;
-    if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; timing[4] = t_begin; timing[5] = t_walk; timing[6] = t_feed; timing[7] = use_map ? (map_upfront ? 2 : 1) : 0; }      /* [7]: where the DMA read the bytes: 0 staging slots, 1 mapped file, 2 mapped and registered up front */
+    if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; timing[4] = t_begin; timing[5] = t_walk; timing[6] = t_feed; timing[7] = use_map ? (map_upfront ? 2 : 1) : copy_map ? 3 : 0; }      /* [7]: where the DMA read the bytes: 0 staging slots filled by pread, 1 mapped file, 2 mapped and registered up front, 3 staging slots filled from the mapping */
     if (rc == COV_ERR_INGEST_FALLBACK) return fail(1, cov_last_error(s));
     if (rc == COV_ERR_UNSORTED) return fail(-2, cov_last_error(s));      // keys decrease inside the span: the caller may send the file through one device whole
     if (rc != COV_OK) return fail(-1, cov_last_error(s));

@@ -248,7 +248,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
             if (timing_on())
                 fprintf(stderr, "[coverm-amd] %s span %u/%u: device ingest: buffers %.3fs, file read %.3fs, staging waits %.3fs, header walk %.3fs, feed calls %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records, bytes from %s\n",
                         S.stoit.c_str(), span_index, span_count, tm[4], tm[0], tm[1], tm[5], tm[6], tm[2], tm[3], (unsigned long long)nrec,
-                        tm[7] == 2 ? "the mapped file (registered up front)" : tm[7] == 1 ? "the mapped file" : "staging slots");
+                        tm[7] == 2 ? "the mapped file (registered up front)" : tm[7] == 1 ? "the mapped file" : tm[7] == 3 ? "staging slots (copied from the mapping)" : "staging slots (pread)");
             S.t_ingest = now() - t0;
             S.stats.resize(S.tlen.size());
             cov_summary summ;
@@ -784,6 +784,24 @@ int run_cli(int argc, char **argv) {
                     fprintf(stderr, "[coverm-amd] %s\n", ln);
                 }
             fclose(ps);
+        }
+        // ... and its eight largest mappings (what the kernel has to take apart when the process ends)
+        if (FILE *sm = fopen("/proc/self/smaps", "r")) {
+            struct M { unsigned long long rss_kb, size_kb; std::string what; };
+            std::vector<M> ms;
+            char ln[512]; std::string cur; unsigned long long size_kb = 0;
+            while (fgets(ln, sizeof ln, sm)) {
+                unsigned long long a, b2, v;
+                if (sscanf(ln, "%llx-%llx ", &a, &b2) == 2 && strchr(ln, '-') && strchr(ln, '-') < ln + 17) {
+                    ln[strcspn(ln, "\n")] = 0;
+                    const char *path = strchr(ln, '/'); const char *br = strchr(ln, '[');
+                    cur = path ? path : br ? br : "(anonymous)"; size_kb = (b2 - a) >> 10;
+                } else if (sscanf(ln, "Rss: %llu kB", &v) == 1) ms.push_back({v, size_kb, cur});
+            }
+            fclose(sm);
+            std::sort(ms.begin(), ms.end(), [](const M &x, const M &y) { return x.rss_kb > y.rss_kb; });
+            for (size_t i = 0; i < ms.size() && i < 8; i++)
+                fprintf(stderr, "[coverm-amd] mapping %zu: %llu MB resident of %llu MB, %s\n", i, ms[i].rss_kb >> 10, ms[i].size_kb >> 10, ms[i].what.c_str());
         }
     }
     if (timing)

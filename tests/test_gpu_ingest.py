@@ -312,7 +312,7 @@ def test_spans_leave_a_file_only_the_reference_would_accept_to_one_device(tmp_pa
 def test_four_feeders_through_staging_slots_and_through_the_mapped_file(tmp_path):
     """Four device ingests at once (four spans of one file on device 0: one GPU here, a functional check): through staging slots — the
     default for any number of feeders since round 6's measurement with eight (profiles/r06_eight_feeders_io.json: eight up-front
-    registrations do not run beside one another) — and with the file mapped and its spans registered with the device once, up front
+    registrations do not run beside one another), filled from a mapping of the file with non-temporal stores or by pread — and with the file mapped and its spans registered with the device once, up front
     (COVERM_INGEST_IO=mmap-upfront).  The table must be the one-device one either way."""
     from oracle import oracle as O
     from tests import binary
@@ -326,11 +326,11 @@ def test_four_feeders_through_staging_slots_and_through_the_mapped_file(tmp_path
     assert r.stdout == want
     assert r.stderr.count("bytes from the mapped file (registered up front)") == 4
     r = binary.run_full("contig", [p], env={"COVERM_CLI_TIMING": "1"}, devices="0,0,0,0", **args)
-    assert r.stdout == want and r.stderr.count("bytes from staging slots") == 4
+    assert r.stdout == want and r.stderr.count("bytes from staging slots (copied from the mapping)") == 4
     r = binary.run_full("contig", [p], env={"COVERM_CLI_TIMING": "1"}, devices="0,0", **args)
-    assert r.stdout == want and r.stderr.count("bytes from staging slots") == 2
+    assert r.stdout == want and r.stderr.count("bytes from staging slots (copied from the mapping)") == 2
     r = binary.run_full("contig", [p], env={"COVERM_CLI_TIMING": "1", "COVERM_INGEST_IO": "pread"}, devices="0,0,0,0", **args)
-    assert r.stdout == want and r.stderr.count("bytes from staging slots") == 4
+    assert r.stdout == want and r.stderr.count("bytes from staging slots (pread)") == 4
 
 
 RAW = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raw")

@@ -60,18 +60,19 @@ print("MOCK_OK", mode, n.value, "io=" + str(int(t[7])))
 
 
 # what timing[7] must say afterwards: 0 staging slots, 1 mapped file registered piece by piece, 2 mapped and registered up front
-IO_MODES = {"default": ({}, 0), "pread": ({"COVERM_INGEST_IO": "pread"}, 0), "mmap": ({"COVERM_INGEST_IO": "mmap"}, 1),
+IO_MODES = {"default": ({}, 3), "pread": ({"COVERM_INGEST_IO": "pread"}, 0), "mmap": ({"COVERM_INGEST_IO": "mmap"}, 1),
             "mmap-upfront": ({"COVERM_INGEST_IO": "mmap-upfront"}, 2),
-            "mmap_refused": ({"COVERM_INGEST_IO": "mmap", "COVERM_MOCK_NO_REGISTER": "1"}, 0),
-            "mmap-upfront_refused": ({"COVERM_INGEST_IO": "mmap-upfront", "COVERM_MOCK_NO_REGISTER": "1"}, 0)}
+            "mmap_refused": ({"COVERM_INGEST_IO": "mmap", "COVERM_MOCK_NO_REGISTER": "1"}, 3),
+            "mmap-upfront_refused": ({"COVERM_INGEST_IO": "mmap-upfront", "COVERM_MOCK_NO_REGISTER": "1"}, 3)}
 
 
 @pytest.mark.parametrize("io", sorted(IO_MODES))
 @pytest.mark.parametrize("mode,piece_kb", [("synth", 0), ("synth", 64), ("synth", 200), ("tiny_blocks", 64), ("tiny_blocks", 0)])
 def test_ingest_driver_feeds_consistent_blocks(tmp_path, mode, piece_kb, io):
-    """io: the bytes come from staging slots filled by pread (the default for one or two feeders), from the registered mapping of the file
-    (registered piece by piece, or the whole span up front: the default for more than two feeders), or the mapping is refused by the runtime
-    and the driver switches to staging slots by itself.  The driver reports which it used (timing[7])."""
+    """io: the bytes come from staging slots filled from a mapping of the file with non-temporal stores (the default since round 6:
+    timing[7] = 3), from staging slots filled by pread (0), from the registered mapping of the file (registered piece by piece, 1, or the
+    whole span up front, 2), or the registration is refused by the runtime and the driver copies the mapping's bytes into staging slots
+    by itself (3).  The driver reports which it used."""
     if not _has_mock():
         pytest.skip("needs the sanitizer build's CPU mock of cov_ingest_* (tools/asan_host.sh); the GPU suite covers the driver otherwise")
     env = dict(os.environ)

@@ -64,11 +64,16 @@ def rows():
                 add("%s %s per launch" % (short, c), sig(v / 1e6, 4) + " M", pm + ": " + short + "." + c)
     add("k_prep HBM traffic per launch (2 x FETCH_SIZE + WRITE_SIZE)", sig(jget("profiles/pmc_traffic.json", ["k_prep"]) / 1e9, 4) + " GB", "profiles/pmc_traffic.json: k_prep")
     add("k_pileup HBM traffic per launch", sig(jget("profiles/pmc_traffic.json", ["k_pileup"]) / 1e9, 4) + " GB", "profiles/pmc_traffic.json: k_pileup")
-    for key, what in (("e2e_l1_s", "end to end, 200 M reads, BGZF level 1: wall"), ("e2e_l1_x_overlapped", "... x the CPU path, decode and scan overlapped"),
+    for key, what in (("e2e_l1_s", "end to end, 200 M reads, BGZF level 1: wall (the command returns when the table is written)"), ("e2e_l1_x_overlapped", "... x the CPU path, decode and scan overlapped"),
+                      ("e2e_l1_one_process_s", "the same as ONE process (`COVERM_NO_FAST_EXIT=1`: the caller also waits for the runtime's teardown)"),
+                      ("e2e_l1_x_overlapped_one_process", "... x the CPU path"),
                       ("e2e_l6_s", "end to end, BGZF level 6: wall"), ("e2e_l6_x_overlapped", "... x the CPU path, overlapped"),
                       ("cpu_decode_s", "CPU decode (16 threads, libdeflate), best of three"), ("cpu_scan_s", "CPU scan (oracle, one thread), best"),
                       ("cfg2_binary_s", "config 2 through the binary, median"), ("cfg3_binary_s", "config 3 through the binary, median")):
-        v = jget(b, [key])
+        try:
+            v = jget(b, [key])
+        except KeyError:
+            continue          # (a bench line from before the field existed)
         add(what, ("%s" % v) + (" s" if key.endswith("_s") else ""), b + ": " + key)
     add("parity of the bench's own check (`parity_equal`, `tables_equal`)", "%s, %s" % (jget(b, ["parity_equal"]), jget(b, ["tables_equal"])), b + ": parity_equal, tables_equal")
     for c in jget(sw, ["configs"]):
