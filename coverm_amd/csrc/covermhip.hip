@@ -228,8 +228,10 @@ struct cov_session {
     bool ing_active = false;
     InflateKernel ing_K;
     hipStream_t ing_copy = nullptr;
-    // second upload queue: the halves of a large piece go to HBM through two DMA engines at once (one queue moved ~42 GB/s of
-    // 32 MiB pieces between table uploads; the link does 57); joined into ing_copy before anything is recorded there
+    // (ONE upload stream.  Its H2D copies are 0.595 ms per 32 MiB piece = 56 GB/s with a ~38 us gap between two of them: the link is busy
+    // 91 % of the time the file streams, profiles/r06_ingest_copy_trace.json.  A second stream — the halves of a piece on two DMA engines in
+    // round 3, whole pieces in turn in round 6 — is SLOWER both ways: 0.82 s of ingest against 0.50 s at 200 M reads,
+    // profiles/r06_copy_streams_ab_200M.json, profiles/r03_copy_queues_50M.log.)
     hipEvent_t ing_ev[COV_INGEST_SLOTS] = {}, ing_fed = nullptr;
     double ing_s_alloc = 0;     // host seconds inside device allocations of the ingest
     double ing_s_part[4] = {0, 0, 0, 0};     // ... inside ingest_drain / launch_round / the upload calls / event waits (COVERM_CLI_TIMING)

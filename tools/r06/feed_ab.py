@@ -28,7 +28,11 @@ cmd = [BIN, "contig", "-b", p, "-m", "mean", "trimmed_mean", "covered_fraction",
 res = {"reads": reads, "bam_bytes": size, "runs": []}
 tables = set()
 MODES = [("mapping + non-temporal copy", {}), ("pread", {"COVERM_INGEST_IO": "pread"})]
-if os.environ.get("FEED_AB_EXIT"):      # the command with its teardown in a detached child (default) against one process (COVERM_NO_FAST_EXIT)
+if os.environ.get("FEED_AB_COPY_STREAMS"):      # one upload stream against two that take the pieces in turn (COVERM_KNOBS ingest_copy_streams)
+    MODES = [("one upload stream", {"COVERM_KNOBS": "ingest_copy_streams=1"}), ("two upload streams", {"COVERM_KNOBS": "ingest_copy_streams=2"})]
+elif os.environ.get("FEED_AB_PIECES"):      # bytes per staging piece = per H2D copy (COVERM_KNOBS ingest_piece_kb; default 32 MiB)
+    MODES = [("pieces of %d MiB" % mb, {"COVERM_KNOBS": "ingest_piece_kb=%d" % (mb << 10)}) for mb in (32, 64, 128, 16)]
+elif os.environ.get("FEED_AB_EXIT"):      # the command with its teardown in a detached child (default) against one process (COVERM_NO_FAST_EXIT)
     MODES = [("teardown in the background (default)", {}), ("one process", {"COVERM_NO_FAST_EXIT": "1"})]
 elif os.environ.get("FEED_AB_ZAPS"):      # how the mapping's pages leave the page table again (COVERM_KNOBS ingest_zap)
     MODES = [("mapping, zap the piece in front (default)", {}), ("mapping, zap per chunk", {"COVERM_KNOBS": "ingest_zap=1"}),
