@@ -7,8 +7,8 @@
 // is the caller's business once the table is written, so by default the work runs in a CHILD forked before the runtime is touched:
 // when covh_cli_main has returned and stdout / stderr are flushed, the child hands its exit code to the launcher through a pipe, lets go of
 // its standard streams and ends by itself; the launcher exits with that code at once.  The command returns when its output is complete;
-// the driver's teardown finishes a moment later in the orphan.  COVERM_NO_FAST_EXIT=1 keeps everything in one process with the ordinary
-// exit path (profilers and sanitizers want that; bench.py reports the end-to-end time both ways).
+// the driver's teardown finishes a moment later in the orphan (which the pid namespace's init reaps).  COVERM_NO_FAST_EXIT=1 keeps
+// everything in one process with the ordinary exit path (profilers and sanitizers want that; bench.py reports the end-to-end time both ways).
 #include <cerrno>
 #include <csignal>
 #include <cstdio>
@@ -28,6 +28,7 @@ int main(int argc, char **argv) {
     const bool fast = getenv("COVERM_NO_FAST_EXIT") == nullptr;
     int fds[2] = {-1, -1};
     pid_t child = -1;
+    const pid_t launcher = getpid();
     if (fast && pipe(fds) == 0) {
         fflush(stdout); fflush(stderr);
         child = fork();
@@ -46,7 +47,7 @@ int main(int argc, char **argv) {
     if (child == 0) {
         close(fds[0]);
         (void)prctl(PR_SET_PDEATHSIG, SIGKILL);      // a launcher that is killed takes the work with it
-        if (getppid() == 1) _exit(1);                // (it already was, between fork and prctl)
+        if (getppid() != launcher) _exit(1);         // (it already was, between fork and prctl)
     }
     covh_cli_set_fast_exit(fast ? 1 : 0);   // the process ends right after the table is written: skip freeing device memory piecemeal
     const int rc = covh_cli_main(argc, argv);
