@@ -889,20 +889,20 @@ def sess_tiles(sess, ref):
 
 
 def ingest_roofline():
-    """The device ingest's two dominant kernels against the HBM roofline, from the newest COMMITTED ingest profile (the files are named in
-    `source`: profiles/r05_ingest_kernel_stats.csv — rocprofv3 --kernel-trace --stats of `coverm-amd contig` over a 20 M-read level-1 BAM = one
-    full round of 81 920 BGZF blocks + one of 12 382 — and profiles/r05_ingest_pmc_summary.json — separate --pmc passes; the ingest kernels
-    did not change in round 6).  Not measured by this run:
-    the bench's timed region is the coverage path; labelled as such.  Algorithmic bytes per full round: compressed bytes read once +
-    inflated bytes written once (k_inflate_wave); token positions + every match byte read and written once (k_lz_stage; k_lz_resolve in profiles
-    that predate it)."""
+    """The device ingest's dominant kernels against the HBM roofline, from the newest COMMITTED ingest profile (the files are named in
+    `source`: profiles/r06_ingest_kernel_stats.csv — rocprofv3 --kernel-trace --stats of `coverm-amd contig` over a 20 M-read level-1 BAM, run
+    with rounds of 81 920 BGZF blocks: one full round + one of 12 382 — and profiles/r06_ingest_pmc_summary.json — separate --pmc passes).
+    The library's default round has been 61 440 blocks since the end of round 6; the figures here are per 81 920, as profiled.  Not
+    measured by this run: the bench's timed region is the coverage path; labelled as such.  Algorithmic bytes per full round: compressed
+    bytes read once + inflated bytes written once (k_inflate_wave); token positions + every match byte read and written once (k_lz_stage;
+    k_lz_resolve in profiles that predate it); the inflated bytes read once (k_crc32_wave)."""
     out = {"source": "no committed ingest profile found",
            "round_blocks": 81920, "peak_GBps": HBM_PEAK_GBPS}
     try:
         import csv
         full_ms = {}
-        stats = next(p for p in ("r05_ingest_kernel_stats.csv", "r04_ingest_kernel_stats.csv") if os.path.exists(os.path.join(ROOT, "profiles", p)))
-        pmc = next(p for p in ("r05_ingest_pmc_summary.json", "r04_ingest_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", p)))
+        stats = next(p for p in ("r06_ingest_kernel_stats.csv", "r05_ingest_kernel_stats.csv", "r04_ingest_kernel_stats.csv") if os.path.exists(os.path.join(ROOT, "profiles", p)))
+        pmc = next(p for p in ("r06_ingest_pmc_summary.json", "r05_ingest_pmc_summary.json", "r04_ingest_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", p)))
         out["source"] = "committed profile (profiles/%s, %s), not this run" % (stats, pmc)
         with open(os.path.join(ROOT, "profiles", stats)) as fh:
             for r in csv.DictReader(fh):
@@ -910,7 +910,8 @@ def ingest_roofline():
         with open(os.path.join(ROOT, "profiles", pmc)) as fh:
             pm = json.load(fh).get("derived_full_round", {})
         blocks = 81920
-        algo = {"covi::k_inflate_wave": blocks * (21100 + 62900), "covi::k_lz_stage": blocks * (5900 * 2 + 2 * 50600), "covi::k_lz_resolve": blocks * (5900 * 2 + 2 * 50600)}
+        algo = {"covi::k_inflate_wave": blocks * (21100 + 62900), "covi::k_lz_stage": blocks * (5900 * 2 + 2 * 50600), "covi::k_lz_resolve": blocks * (5900 * 2 + 2 * 50600),
+                "covi::k_crc32_wave": blocks * 65280}
         for k, b in algo.items():
             ms = full_ms.get(k)
             if not ms:

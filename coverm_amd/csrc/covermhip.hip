@@ -1352,7 +1352,12 @@ static_assert(sizeof(cov_bgzf_block) == sizeof(covi::BgzfBlock) && offsetof(cov_
               offsetof(cov_bgzf_block, out_off) == offsetof(covi::BgzfBlock, out_off), "cov_bgzf_block mirrors the device struct");
 
 constexpr int INF1_LB = 7, INF1_DB = 6;       // k_inflate's primary tables: 7 + 6 bits = 28 KiB per wave, five waves per CU (the fastest measured)
-constexpr u32 WAVE_ROUND_BLOCKS = 81920;
+// Blocks per k_inflate_wave round = per window.  81 920 from round 3 to the middle of round 6 (round 4's sweep: smaller windows lost to the fixed
+// host cost per window); with the feed at the link's rate and round 5-6's faster kernels the sweep was repeated at 200 M reads,
+// alternating: ingest 0.478-0.485 s with 61 440 blocks against 0.487-0.494 s with 81 920, 0.484-0.494 s with 40 960, 0.496-0.505 s with 122 880
+// (profiles/r06_round_blocks_ab_200M.json) — what the device still has to do when the last byte has arrived is about one window's
+// processing, 32 ms instead of 44.  61 440 is also exactly 15 launches' worth of resident waves on 256 CUs (16 per CU).
+constexpr u32 WAVE_ROUND_BLOCKS = 61440;
 // Decided once per ingest (cov_ingest_begin) and kept in the session: the switches are read there, never in a launch path.
 static InflateKernel choose_inflate_kernel(cov_session *s) {
     InflateKernel K;

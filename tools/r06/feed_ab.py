@@ -28,7 +28,9 @@ cmd = [BIN, "contig", "-b", p, "-m", "mean", "trimmed_mean", "covered_fraction",
 res = {"reads": reads, "bam_bytes": size, "runs": []}
 tables = set()
 MODES = [("mapping + non-temporal copy", {}), ("pread", {"COVERM_INGEST_IO": "pread"})]
-if os.environ.get("FEED_AB_COPY_STREAMS"):      # (needs the build of tools/r06/call33.sh: the knob left the library with the measurement)      # one upload stream against two that take the pieces in turn (COVERM_KNOBS ingest_copy_streams)
+if os.environ.get("FEED_AB_ROUNDS"):      # blocks per inflate round = per window (COVERM_KNOBS ingest_round_blocks; default 81920)
+    MODES = [("rounds of %d blocks" % n, {"COVERM_KNOBS": "ingest_round_blocks=%d" % n}) for n in (81920, 61440, 40960, 122880)]
+elif os.environ.get("FEED_AB_COPY_STREAMS"):      # (needs the build of tools/r06/call33.sh: the knob left the library with the measurement)      # one upload stream against two that take the pieces in turn (COVERM_KNOBS ingest_copy_streams)
     MODES = [("one upload stream", {"COVERM_KNOBS": "ingest_copy_streams=1"}), ("two upload streams", {"COVERM_KNOBS": "ingest_copy_streams=2"})]
 elif os.environ.get("FEED_AB_PIECES"):      # bytes per staging piece = per H2D copy (COVERM_KNOBS ingest_piece_kb; default 32 MiB)
     MODES = [("pieces of %d MiB" % mb, {"COVERM_KNOBS": "ingest_piece_kb=%d" % (mb << 10)}) for mb in (32, 64, 128, 16)]
