@@ -18,6 +18,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <future>
 #include <thread>
 #include <vector>
 
@@ -228,6 +229,7 @@ struct cov_session {
     bool ing_active = false;
     InflateKernel ing_K;
     hipStream_t ing_copy = nullptr;
+    std::future<hipError_t> ing_prep;          // COV_WANT_INGEST: the ingest's streams, events and fixed tables, being created since cov_create (ingest_prep_wait)
     // (ONE upload stream.  Its H2D copies are 0.595 ms per 32 MiB piece = 56 GB/s with a ~38 us gap between two of them: the link is busy
     // 91 % of the time the file streams, profiles/r06_ingest_copy_trace.json.  A second stream — the halves of a piece on two DMA engines in
     // round 3, whole pieces in turn in round 6 — is SLOWER both ways: 0.82 s of ingest against 0.50 s at 200 M reads,
@@ -446,6 +448,44 @@ int cov_abi_version(void) { return COVERMHIP_ABI_VERSION; }
 
 const char *cov_last_error(const cov_session *s) { return s ? s->err.c_str() : g_create_error.c_str(); }
 
+// The part of cov_ingest_begin that does not depend on the file: three streams (a hardware queue with its 173 MB save area each), two dozen
+// events, the page-locked result words and block-table mirror, k_crc32_wave's tables — ~50 ms that used to pass between cov_ingest_begin and
+// the first piece's upload (tools/r06/call39.sh: "first upload after 0.053 s").  With COV_WANT_INGEST cov_create starts it on a helper thread
+// as soon as the runtime is up, beside its own stream and whatever the caller does next (targets, estimators, the file's header).
+static hipError_t ingest_prepare_(cov_session *s) {
+    hipError_t e = hipSetDevice(s->cfg.device);
+    if (e != hipSuccess || s->ing_copy) return e;
+#define PREP(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
+    PREP(hipStreamCreateWithFlags(&s->ing_copy, hipStreamNonBlocking));
+    for (int k = 0; k < COV_INGEST_SLOTS; k++) PREP(hipEventCreateWithFlags(&s->ing_ev[k], hipEventDisableTiming));
+    PREP(hipEventCreateWithFlags(&s->ing_fed, hipEventDisableTiming));
+    PREP(hipStreamCreateWithFlags(&s->ing_aux, hipStreamNonBlocking));
+    // (the boundary search on the LZ / CRC stream — the runtime's four hardware queues put the two on one queue anyway — was measured:
+    // ingest 0.650 s against 0.612 s, the extraction of window w then also waits behind the LZ of w + 1, and the exit is no shorter:
+    // profiles/r04_e2e_200M_runs_*.log)
+    PREP(hipStreamCreateWithFlags(&s->ing_parse, hipStreamNonBlocking));
+    s->ing_ext = s->ing_parse;
+    for (int k = 0; k < 2; k++) { PREP(hipEventCreateWithFlags(&s->ing_inf_done[k], hipEventDisableTiming)); PREP(hipEventCreateWithFlags(&s->ing_lz_done[k], hipEventDisableTiming)); }
+    for (int k = 0; k < 4; k++) PREP(hipEventCreateWithFlags(&s->ing_ver_done[k], hipEventDisableTiming));
+    for (int k = 0; k < 3; k++) { PREP(hipEventCreateWithFlags(&s->ing_ext_done[k], hipEventDisableTiming)); PREP(hipEventCreateWithFlags(&s->ing_cdone[k], hipEventDisableTiming)); }
+    PREP(hipHostMalloc((void **)&s->h_winres, 4 * 8 * sizeof(u64), hipHostMallocDefault));
+    {   // page-locked mirror of the block table: room for a 25 GB file of ordinary ~20 KB blocks (cov_ingest_begin replaces it for a larger one)
+        const size_t nc = (size_t)3 << 19;
+        PREP(hipHostMalloc((void **)&s->h_blocks, nc * sizeof(covi::BgzfBlock), hipHostMallocDefault));
+        s->h_blocks_cap = nc;
+    }
+    {
+        static const std::vector<u32> crc_tables = [] { std::vector<u32> t(covi::crcw::TABLE_WORDS); covi::crcw::build_tables(t.data()); return t; }();
+        PREP(s->g_crc_tab.reserve(covi::crcw::TABLE_WORDS, s->ing_copy));
+        PREP(hipMemcpyAsync(s->g_crc_tab.p, crc_tables.data(), covi::crcw::TABLE_WORDS * sizeof(u32), hipMemcpyHostToDevice, s->ing_copy));
+        PREP(hipStreamSynchronize(s->ing_copy));
+    }
+#undef PREP
+    return hipSuccess;
+}
+// Everything that looks at the ingest's streams outside cov_ingest_begin waits for the helper first.
+static hipError_t ingest_prep_wait(cov_session *s) { return s->ing_prep.valid() ? s->ing_prep.get() : hipSuccess; }
+
 cov_status cov_create(const cov_config *cfg, cov_session **out) {
     if (!cfg || !out) { g_create_error = "null argument"; return COV_ERR_INVALID_ARG; }
     *out = nullptr;
@@ -474,6 +514,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) s->n_cus = cus;
         stamp("device attribute");
     }
+    if (cfg->want & COV_WANT_INGEST) s->ing_prep = std::async(std::launch::async, [s] { return ingest_prepare_(s); });
     if (const char *el = getenv("COVERM_EST_LANES")) s->est_lanes = atoi(el) ? 1 : 0;
     if (const char *ft = getenv("COVERM_FAST_TABLES")) s->fast_tables = atoi(ft) == 2 ? 2 : 1;
     if (const char *pk = getenv("COVERM_PREP_KERNEL")) s->prep_kernel = atoi(pk) == 7 ? 7 : 0;
@@ -485,7 +526,7 @@ cov_status cov_create(const cov_config *cfg, cov_session **out) {
     e = hipEventCreateWithFlags(&s->ev_prep_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_side_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete s; return COV_ERR_HIP; }
+    if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); (void)ingest_prep_wait(s); delete s; return COV_ERR_HIP; }
     stamp("streams and events");      // (the kernels' timing events are created by the first cov_finish: a run that ingests a file needs them half a second later)
     e = bind_result_block(s, 1);
     if (e != hipSuccess) { g_create_error = std::string("hipMalloc: ") + hipGetErrorString(e); cov_destroy(s); return COV_ERR_HIP; }
@@ -504,6 +545,7 @@ static void ingest_free_buffers(cov_session *s) {
 
 void cov_destroy(cov_session *s) {
     if (!s) return;
+    (void)ingest_prep_wait(s);
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->d_tlen.release(); s->d_tile_contig.release(); s->d_tile_start.release(); s->d_mask.release();
@@ -940,6 +982,7 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
         HIPCHK(hipGetLastError());
         if (want_id && nT) {   // depends only on k_prep: run beside k_ranges / k_pileup
             if (!s->side) {
+                (void)ingest_prep_wait(s);
                 if (s->ing_aux && !s->ing_active) s->side = s->ing_aux;      // idle since cov_ingest_end
                 else { HIPCHK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking)); s->side_owned = true; }
             }
@@ -1387,22 +1430,8 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     if (!s) return COV_ERR_INVALID_ARG;
     covr::Range rr("ingest: buffers, streams, events (cov_ingest_begin)");
     HIPCHK(hipSetDevice(s->cfg.device));
-    if (!s->ing_copy) {
-        HIPCHK(hipStreamCreateWithFlags(&s->ing_copy, hipStreamNonBlocking));
-        // (two upload queues — the halves of a piece on two DMA engines — were measured slower, profiles/r03_copy_queues_50M.log: removed)
-        for (int k = 0; k < COV_INGEST_SLOTS; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ev[k], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&s->ing_fed, hipEventDisableTiming));
-        HIPCHK(hipStreamCreateWithFlags(&s->ing_aux, hipStreamNonBlocking));
-        // (the boundary search on the LZ / CRC stream — the runtime's four hardware queues put the two on one queue anyway — was measured:
-        // ingest 0.650 s against 0.612 s, the extraction of window w then also waits behind the LZ of w + 1, and the exit is no shorter:
-        // profiles/r04_e2e_200M_runs_*.log)
-        HIPCHK(hipStreamCreateWithFlags(&s->ing_parse, hipStreamNonBlocking));
-        s->ing_ext = s->ing_parse;
-        for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_inf_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_lz_done[k], hipEventDisableTiming)); }
-        for (int k = 0; k < 4; k++) HIPCHK(hipEventCreateWithFlags(&s->ing_ver_done[k], hipEventDisableTiming));
-        for (int k = 0; k < 3; k++) { HIPCHK(hipEventCreateWithFlags(&s->ing_ext_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ing_cdone[k], hipEventDisableTiming)); }
-        HIPCHK(hipHostMalloc((void **)&s->h_winres, 4 * 8 * sizeof(u64), hipHostMallocDefault));
-    }
+    HIPCHK(ingest_prep_wait(s));
+    if (!s->ing_copy) HIPCHK(ingest_prepare_(s));
     if (s->adopted) {  // materialise an adopted device batch into the owned store first
         cov_batch ab = s->adopted_batch;
         s->adopted = false; s->n_records = 0; s->n_cigar = 0;
@@ -1416,10 +1445,11 @@ cov_status cov_ingest_begin(cov_session *s, uint64_t compressed_bytes, uint64_t 
     s->ing_check_crc = check_crc ? 1 : 0;
     HIPCHK(s->g_result.reserve(8 + 4 * 8, s->stream));
     HIPCHK(s->g_carry.reserve(inflate_kernel(s).carry, s->stream));
-    if (!s->g_crc_tab.p) {
-        static const std::vector<u32> crc_tables = [] { std::vector<u32> t(covi::crcw::TABLE_WORDS); covi::crcw::build_tables(t.data()); return t; }();
+    if (!s->g_crc_tab.p) {      // (cov_ingest_release between two files gave the tables back with the buffers)
+        std::vector<u32> t(covi::crcw::TABLE_WORDS);
+        covi::crcw::build_tables(t.data());
         HIPCHK(s->g_crc_tab.reserve(covi::crcw::TABLE_WORDS, s->stream));
-        HIPCHK(hipMemcpyAsync(s->g_crc_tab.p, crc_tables.data(), covi::crcw::TABLE_WORDS * sizeof(u32), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpy(s->g_crc_tab.p, t.data(), covi::crcw::TABLE_WORDS * sizeof(u32), hipMemcpyHostToDevice));
     }
     HIPCHK(s->g_blocks.reserve(compressed_bytes / 8192 + 1024, s->stream));
     HIPCHK(s->g_status.reserve(compressed_bytes / 8192 + 1024, s->stream));

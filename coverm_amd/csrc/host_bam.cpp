@@ -1287,7 +1287,8 @@ static void stream_copy(uint8_t *dst, const uint8_t *src, size_t n) {
 
 // 0 = records are in the session's store; 1 = the file needs the CPU reader (reason in err; nothing appended); -1 = error;
 // -2 = the record keys decrease inside the span (the reference's "appears to be unsorted" text in err).
-// timing (optional, 5 doubles): seconds reading the file, waiting for staging slots, in cov_ingest_end, total, in cov_ingest_begin (allocation).
+// timing (optional, 8 doubles): seconds reading the file, waiting for staging slots, in cov_ingest_end, total, until the first piece's upload call
+// (cov_ingest_begin's streams, events and buffers beside the first reads), in the header walk, in the feed calls, [7] see below.
 int covh_bam_gpu_ingest(const char *path, int threads, cov_session *s, const covh_bam_header *hd, int check_crc, uint64_t *n_records,
                         double *timing, char *err, size_t errcap) {
     return covh_bam_gpu_ingest_span(path, threads, s, hd, check_crc, 0, 1, n_records, timing, err, errcap);
@@ -1417,7 +1418,7 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
     std::vector<cov_bgzf_block> blocks;
     uint64_t next_blk = f_lo, out_off = 0, pending_bsize = 0;     // absolute file offset of the next block header; running inflated size; BSIZE of a block whose header is read but whose end is not here yet
     uint8_t tail[64]; uint64_t tail_end = 0; size_t tail_len = 0;   // last bytes of the previous piece (a header may straddle)
-    double t_read = 0, t_wait = 0, t_walk = 0, t_feed = 0;
+    double t_read = 0, t_wait = 0, t_walk = 0, t_feed = 0, t_first_feed = 0;
     const uint64_t n_pieces = (size - f_lo + piece - 1) / piece;
     // Hopping the block headers is a chain of dependent cache misses (~0.3 us per block, 0.28 s for the 944 k blocks of a 200 M-read
     // file) if one thread does it after the fact.  The pool thread that has just read a 4 MiB chunk hops the blocks that lie
@@ -1609,6 +1610,7 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
         t_walk += now() - t0;
         t0 = now();
         if (begun.valid() && begun.get() != 0) return fail(-1, cov_last_error(s));
+        if (k == 0) t_first_feed = now() - t_start;
         if (cov_ingest_feed(s, slot, dst, off, n, blocks.data(), (uint32_t)blocks.size()) != COV_OK) return fail(-1, cov_last_error(s));
         t_feed += now() - t0;
         { std::lock_guard<std::mutex> lk(mu); fed = k + 1; }
@@ -1629,7 +1631,7 @@ int covh_bam_gpu_ingest_span(const char *path, int threads, cov_session *s, cons
         cov_host_trim();
     }
     const double t_end = now() - t0;
-    if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; timing[4] = t_begin; timing[5] = t_walk; timing[6] = t_feed; timing[7] = use_map ? (map_upfront ? 2 : 1) : copy_map ? 3 : 0; }      /* [7]: where the DMA read the bytes: 0 staging slots filled by pread, 1 mapped file, 2 mapped and registered up front, 3 staging slots filled from the mapping */
+    if (timing) { timing[0] = t_read; timing[1] = t_wait; timing[2] = t_end; timing[3] = now() - t_start; timing[4] = t_first_feed > 0 ? t_first_feed : t_begin; timing[5] = t_walk; timing[6] = t_feed; timing[7] = use_map ? (map_upfront ? 2 : 1) : copy_map ? 3 : 0; }      /* [7]: where the DMA read the bytes: 0 staging slots filled by pread, 1 mapped file, 2 mapped and registered up front, 3 staging slots filled from the mapping */
     if (rc == COV_ERR_INGEST_FALLBACK) return fail(1, cov_last_error(s));
     if (rc == COV_ERR_UNSORTED) return fail(-2, cov_last_error(s));      // keys decrease inside the span: the caller may send the file through one device whole
     if (rc != COV_OK) return fail(-1, cov_last_error(s));

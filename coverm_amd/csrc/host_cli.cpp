@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "../../include/coverm_host.h"
+#include "knobs.h"
 
 namespace {
 
@@ -246,7 +247,7 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         if (rc == 0) {
             S.n_records = nrec; S.device_ingest = true;
             if (timing_on())
-                fprintf(stderr, "[coverm-amd] %s span %u/%u: device ingest: buffers %.3fs, file read %.3fs, staging waits %.3fs, header walk %.3fs, feed calls %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records, bytes from %s\n",
+                fprintf(stderr, "[coverm-amd] %s span %u/%u: device ingest: first upload after %.3fs, file read %.3fs, staging waits %.3fs, header walk %.3fs, feed calls %.3fs, inflate tail + parse %.3fs, total %.3fs, %llu records, bytes from %s\n",
                         S.stoit.c_str(), span_index, span_count, tm[4], tm[0], tm[1], tm[5], tm[6], tm[2], tm[3], (unsigned long long)nrec,
                         tm[7] == 2 ? "the mapped file (registered up front)" : tm[7] == 1 ? "the mapped file" : tm[7] == 3 ? "staging slots (copied from the mapping)" : "staging slots (pread)");
             S.t_ingest = now() - t0;
@@ -666,6 +667,9 @@ int run_cli(int argc, char **argv) {
         for (size_t d = 0; d < nd; d++)
             th.emplace_back([&, d] {
                 cov_config c = cfg; c.device = a.devices[d];
+                long long prep = 1;
+                (void)covknob::get("ingest_prepare", prep);
+                if (!no_gpu_ingest() && prep) c.want |= COV_WANT_INGEST;      // the ingest's streams and events come up beside the rest of the start-up
                 rc[d] = cov_create(&c, &sess[d]);
                 if (rc[d] != COV_OK) { std::lock_guard<std::mutex> lk(em); emsg[d] = cov_last_error(nullptr); }
             });

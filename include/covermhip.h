@@ -58,6 +58,9 @@ typedef enum {
  * the not-supplementary one (genome.rs:220). */
 #define COV_WANT_IDENTITY_PRIMARY_ONLY 4u
 #define COV_WANT_IDENTITY_NONSUPP_ONLY 8u
+/* A device ingest will follow (cov_ingest_begin): its streams, events and fixed tables — ~50 ms of runtime calls — are created by a helper thread
+ * from cov_create on, beside the caller's next steps, instead of inside cov_ingest_begin.  Nothing else changes. */
+#define COV_WANT_INGEST 16u
 
 typedef struct {
     int32_t device; /* HIP device ordinal */

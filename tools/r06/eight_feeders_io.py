@@ -45,7 +45,7 @@ def main():
             wall = time.perf_counter() - t1
             txt = open(os.path.join(a.tmp, "r06_feeders.tsv")).read() if p.returncode == 0 else ""
             tables.setdefault("first", txt)
-            spans = re.findall(r"span (\d+)/\d+: device ingest: buffers ([0-9.]+)s, file read ([0-9.]+)s, staging waits ([0-9.]+)s, header walk [0-9.]+s, feed calls ([0-9.]+)s, inflate tail \+ parse ([0-9.]+)s, total ([0-9.]+)s, \d+ records, bytes from ([a-z ()]+)", p.stderr)
+            spans = re.findall(r"span (\d+)/\d+: device ingest: first upload after ([0-9.]+)s, file read ([0-9.]+)s, staging waits ([0-9.]+)s, header walk [0-9.]+s, feed calls ([0-9.]+)s, inflate tail \+ parse ([0-9.]+)s, total ([0-9.]+)s, \d+ records, bytes from ([a-z ()]+)", p.stderr)
             res["runs"].append({"mode": name, "rep": rep, "wall_s": round(wall, 3), "rc": p.returncode, "table_equals_first_run": txt == tables["first"],
                                 "spans": [{"span": int(s[0]), "buffers_s": float(s[1]), "file_read_s": float(s[2]), "staging_waits_s": float(s[3]), "feed_calls_s": float(s[4]),
                                            "tail_s": float(s[5]), "total_s": float(s[6]), "bytes_from": s[7]} for s in spans]})

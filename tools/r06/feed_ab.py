@@ -28,7 +28,9 @@ cmd = [BIN, "contig", "-b", p, "-m", "mean", "trimmed_mean", "covered_fraction",
 res = {"reads": reads, "bam_bytes": size, "runs": []}
 tables = set()
 MODES = [("mapping + non-temporal copy", {}), ("pread", {"COVERM_INGEST_IO": "pread"})]
-if os.environ.get("FEED_AB_ROUNDS"):      # blocks per inflate round = per window (COVERM_KNOBS ingest_round_blocks; default 81920)
+if os.environ.get("FEED_AB_PREPARE"):      # the ingest's streams and events created from cov_create on (COV_WANT_INGEST) against inside cov_ingest_begin
+    MODES = [("ingest prepared from cov_create on (default)", {}), ("ingest prepared in cov_ingest_begin", {"COVERM_KNOBS": "ingest_prepare=0"})]
+elif os.environ.get("FEED_AB_ROUNDS"):      # blocks per inflate round = per window (COVERM_KNOBS ingest_round_blocks; default 81920)
     MODES = [("rounds of %d blocks" % n, {"COVERM_KNOBS": "ingest_round_blocks=%d" % n}) for n in (81920, 61440, 40960, 122880)]
 elif os.environ.get("FEED_AB_COPY_STREAMS"):      # (needs the build of tools/r06/call33.sh: the knob left the library with the measurement)      # one upload stream against two that take the pieces in turn (COVERM_KNOBS ingest_copy_streams)
     MODES = [("one upload stream", {"COVERM_KNOBS": "ingest_copy_streams=1"}), ("two upload streams", {"COVERM_KNOBS": "ingest_copy_streams=2"})]
@@ -61,6 +63,9 @@ for k in range(len(MODES) * pairs + 1):
     hm = re.search(r"host time in drain ([0-9.]+)s \(waiting for a verification ([0-9.]+)s\), in launches ([0-9.]+)s \(drains inside included\), in upload calls ([0-9.]+)s", r.stderr)
     if hm:
         row.update(drain_s=float(hm.group(1)), launches_s=float(hm.group(3)), upload_calls_s=float(hm.group(4)))
+    um = re.search(r"first upload after ([0-9.]+)s", r.stderr)
+    if um:
+        row["first_upload_after_s"] = float(um.group(1))
     fm = re.search(r"feed calls ([0-9.]+)s", r.stderr)
     if fm:
         row["feed_calls_s"] = float(fm.group(1))
