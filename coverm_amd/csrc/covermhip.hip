@@ -1567,7 +1567,12 @@ static cov_status launch_round_(cov_session *s, uint64_t n64, bool final) {
     DevBuf<covi::tokpos_t> &tokb = bb ? s->g_tok2 : s->g_tok;
     DevBuf<u32> &ntokb = bb ? s->g_ntok2 : s->g_ntok;
     DevBuf<uint8_t> &win = s->g_win[w % 3u];
-    const size_t full = std::max<size_t>(n, K.round_blocks);      // sized for a full round at once: no regrowth between rounds
+    // sized for a full round at once (no regrowth between rounds) — or for the blocks a SMALL file can be expected to have: a 200 MB file does not
+    // need three 4 GB windows and two 2.7 GB token lists, and a process that starts right after another one has given tens of GB back waits
+    // for the driver in its large allocations (0.06 s for these in a 2 M-read run, tools/r06/call43.sh).  The estimate is one block per
+    // 4 KiB of compressed bytes; a file of smaller blocks takes the regrowth path below.
+    const size_t est_blocks = (size_t)((s->ing_span_hi - std::min(s->ing_span_lo, s->ing_span_hi)) / 4096u + 256u);
+    const size_t full = std::max<size_t>(n, std::min<size_t>(K.round_blocks, est_blocks));
     const size_t win_bytes = (size_t)K.carry + full * 65536u + 64u;
     const u32 seg_cap = (u32)((win_bytes + 32767u) / 32768u);
     {
