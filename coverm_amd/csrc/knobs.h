@@ -7,6 +7,8 @@
 //   ingest_piece_kb                         covh_bam_ingest_device: bytes per staging piece
 //   stream_window_kb, filter_window_kb      the streamed CPU reader's and `coverm-amd filter`'s compressed windows
 //   finalise_threads                        the host estimators' thread count
+//   printer_plain                           0: the dense printer always goes through CoverageTakerTypeIterator's merge (tests compare the two)
+//   ingest_zap, ingest_prepare              how the mapped file's pages leave the page table (host_bam.cpp); 0: the ingest's streams are created in cov_ingest_begin
 #pragma once
 #include <cstdlib>
 #include <cstring>

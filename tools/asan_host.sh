@@ -117,4 +117,4 @@ trap 'cp $T/real.so $R/coverm_amd/libcovermhip.so' EXIT
 cp $T/libcovermhip_asan.so $R/coverm_amd/libcovermhip.so
 cd $R
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 \
-    COVERM_MOCK_INGEST=1 python -m pytest tests/test_bam_reader.py tests/test_host_golden.py tests/test_genes.py tests/test_ingest_driver_mock.py tests/test_host_estimated.py tests/test_takers_printers.py tests/test_filter_subcommand.py -q -m "not gpu" -p no:cacheprovider -k "not exports_every_declared_symbol"
+    COVERM_MOCK_INGEST=1 python -m pytest tests/test_bam_reader.py tests/test_host_golden.py tests/test_genes.py tests/test_ingest_driver_mock.py tests/test_host_estimated.py tests/test_takers_printers.py tests/test_printer_paths.py tests/test_filter_subcommand.py -q -m "not gpu" -p no:cacheprovider -k "not exports_every_declared_symbol"
