@@ -242,6 +242,7 @@ struct cov_session {
     bool finished = false;
     // result staging in page-locked memory: [DevGlobal][DevContig x n_targets], one DMA pair per finish
     uint8_t *h_res = nullptr; size_t h_res_cap = 0;
+    std::future<std::pair<uint8_t *, size_t>> h_res_prep;      // an assembly's result staging (hundreds of MB of page-locked memory: ~0.17 s per GiB) being obtained since cov_set_targets
     DevContig *h_ctg = nullptr;
     DevGlobal h_glob{};
     bool last_gen_all = false;         // the last finish ran k_prep_generic over every step (cov_last_paths)
@@ -259,6 +260,22 @@ cov_status spill_store(cov_session *s, bool &progress);      // bounded record s
 namespace {
 
 size_t result_block_bytes(u32 n_targets) { return sizeof(DevGlobal) + (size_t)std::max<u32>(n_targets, 1) * sizeof(DevContig); }
+// Page-locked staging for the results of a sample with very many references: the block is [DevGlobal][DevContig x n][floats x n x n_est] —
+// 350 MB at 2 M contigs and four estimators, 0.06 s of hipHostMalloc that used to sit in the sample's one cov_finish.  cov_set_targets starts
+// it on a helper thread (the ingest or the pushes pass meanwhile); cov_finish takes what the helper got, or allocates as before.
+static size_t result_host_bytes(const cov_session *s, u32 nT) {
+    return result_block_bytes(nT) + (size_t)std::max<u32>(nT, 1) * std::max<u32>(s->est.n, 1u) * sizeof(float);
+}
+static void result_host_take(cov_session *s) {
+    if (!s->h_res_prep.valid()) return;
+    const std::pair<uint8_t *, size_t> r = s->h_res_prep.get();
+    if (!r.first) return;
+    if (r.second > s->h_res_cap) {
+        if (s->h_res) (void)hipHostFree(s->h_res);
+        s->h_res = r.first; s->h_res_cap = r.second;
+    } else (void)hipHostFree(r.first);
+}
+
 // [DevGlobal][DevContig x n_targets] (the block cov_gather sends) and, behind it, room for the estimators' floats (COV_EST_MAX per target):
 // both come to the host in one copy
 hipError_t bind_result_block(cov_session *s, u32 n_targets) {
@@ -577,6 +594,7 @@ void cov_destroy(cov_session *s) {
     s->d_res.release(); s->d_ctg.p = nullptr; s->d_glob.p = nullptr; s->d_desc.release(); s->d_gather.release();
     if (s->h_gather) (void)hipHostFree(s->h_gather);
     s->h_gather = nullptr;
+    result_host_take(s);
     if (s->h_res) (void)hipHostFree(s->h_res);
     s->h_res = nullptr; s->h_res_cap = 0; s->h_ctg = nullptr;
     if (s->h_chist) (void)hipHostFree(s->h_chist);
@@ -637,6 +655,15 @@ cov_status cov_set_targets(cov_session *s, uint32_t n_targets, const uint64_t *t
     HIPCHK(hipStreamSynchronize(s->stream));
     s->have_mask = false;
     s->finished = false;
+    if (n_targets >= 65536u && !s->h_res_prep.valid() && result_host_bytes(s, n_targets) > s->h_res_cap) {
+        const size_t need = result_host_bytes(s, n_targets);
+        const int dev = s->cfg.device;
+        s->h_res_prep = std::async(std::launch::async, [need, dev]() -> std::pair<uint8_t *, size_t> {
+            uint8_t *p = nullptr;
+            if (hipSetDevice(dev) != hipSuccess || hipHostMalloc((void **)&p, need, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return {nullptr, 0}; }
+            return {p, need};
+        });
+    }
     return COV_OK;
 }
 
@@ -1074,12 +1101,14 @@ static cov_status finish_once(cov_session *s, cov_contig_stats *stats, cov_summa
     // per-contig floats — no k_estimate launch, no floats in the copy)
     const size_t block = result_block_bytes(nT), nf = s->have_mask ? 0 : (size_t)nT * s->est.n;
     {
-        const size_t need = block + (size_t)std::max<u32>(nT, 1) * COV_EST_MAX * sizeof(float);
+        result_host_take(s);
+        const size_t need = result_host_bytes(s, nT);
         if (need > s->h_res_cap) {
             if (s->h_res) (void)hipHostFree(s->h_res);
             s->h_res = nullptr; s->h_res_cap = 0;
-            HIPCHK(hipHostMalloc((void **)&s->h_res, need + need / 2, hipHostMallocDefault));
-            s->h_res_cap = need + need / 2;
+            const size_t cap = need < ((size_t)64 << 20) ? need + need / 2 : need;      // (room to grow for small blocks only)
+            HIPCHK(hipHostMalloc((void **)&s->h_res, cap, hipHostMallocDefault));
+            s->h_res_cap = cap;
         }
         s->h_ctg = (DevContig *)(s->h_res + sizeof(DevGlobal));
         s->h_estf = reinterpret_cast<float *>(s->h_res + block);

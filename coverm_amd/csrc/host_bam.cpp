@@ -458,12 +458,21 @@ int parse_bam_header(const uint8_t *u, size_t N, size_t &p, std::vector<std::str
     q += l_text;
     const uint32_t n_ref = rd32(&u[q]); q += 4;
     if ((size_t)n_ref > (N - q) / 9 + 1) return 0;   // every entry takes at least 9 bytes: not all here yet
+    // first walk: is the whole dictionary here?  (The caller asks again after every MiB it has inflated; a header of 2 M references is
+    // 40 MB, and building — and dropping — a million names per question made reading it 0.5 s.)
+    {
+        size_t w = q;
+        for (uint32_t i = 0; i < n_ref; i++) {
+            if (w + 4 > N) return 0;
+            const uint32_t l_name = rd32(&u[w]); w += 4;
+            if (w + (size_t)l_name + 4 > N) return 0;
+            w += (size_t)l_name + 4;
+        }
+    }
     std::vector<std::string> nm; std::vector<uint64_t> ln;
     nm.reserve(n_ref); ln.reserve(n_ref);
     for (uint32_t i = 0; i < n_ref; i++) {
-        if (q + 4 > N) return 0;
         const uint32_t l_name = rd32(&u[q]); q += 4;
-        if (q + (size_t)l_name + 4 > N) return 0;
         nm.emplace_back((const char *)&u[q], l_name ? l_name - 1 : 0); q += l_name;
         ln.push_back(rd32(&u[q])); q += 4;
     }
@@ -1047,6 +1056,19 @@ bool inflate_from(int fd, uint64_t file_size, uint64_t off, std::vector<uint8_t>
         if (!bgzf_block_table(c.data(), n, p, blocks, total, !eof, err)) return false;
         const size_t base = out.size();
         out.resize(base + total);
+        if (blocks.size() >= 32) {      // a long header (an assembly's reference dictionary is tens of MB): the blocks of a chunk on a few threads
+            const size_t T = std::min<size_t>({(size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency()), blocks.size() / 8});
+            std::atomic<size_t> next{0};
+            std::atomic<bool> ok{true};
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < T; t++)
+                th.emplace_back([&] {
+                    for (size_t i; ok.load(std::memory_order_relaxed) && (i = next.fetch_add(1)) < blocks.size();)
+                        if (!inflate_block(c.data(), blocks[i], out.data() + base + blocks[i].out_off)) ok = false;
+                });
+            for (auto &x : th) x.join();
+            if (!ok) { err = "BGZF inflate / CRC failure"; return false; }
+        } else
         for (auto &b : blocks) if (!inflate_block(c.data(), b, out.data() + base + b.out_off)) { err = "BGZF inflate / CRC failure"; return false; }
         if (want(out)) return true;
         if (eof) return true;   // caller decides whether what it got is enough

@@ -227,7 +227,12 @@ void ingest(Run &R, cov_session *s, Sample &S, int threads, uint32_t span_index,
         S.t_open = now() - t0;
         uint64_t nrec = 0; double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         check(s, cov_ingest_want_mates(s, R.fp ? 1 : 0));
+        // (an assembly's statistics are 128 B x millions of contigs: the array is obtained and touched beside the ingest, not behind it)
+        std::future<void> stats_ahead;
+        if (S.tlen.size() >= 65536) stats_ahead = std::async(std::launch::async, [&S] { S.stats.resize(S.tlen.size()); });
+        struct StatsWait { std::future<void> &f; ~StatsWait() { if (f.valid()) f.get(); } } stats_wait{stats_ahead};
         int rc = covh_bam_gpu_ingest_span(S.path.c_str(), threads, s, hd, 1, span_index, span_count, &nrec, tm, err, sizeof err);
+        if (stats_ahead.valid()) stats_ahead.get();
         if (rc == -2 && span_count > 1) throw SpanUnsorted(err);
         if (rc < 0) die(err);
         uint64_t pair_prim = 0; double t_pair = 0;
