@@ -310,3 +310,52 @@ def test_cpu_span_reader_refuses_a_file_that_is_not_sorted_by_reference(tmp_path
     assert seen >= 1
     # the whole-file reader does not judge the order (cov_finish does, in file order with the other per-record errors)
     assert sum(x.n_records for x in list(cbam.stream_batches(p, 2))[1:]) == b.n_records
+
+
+def test_an_assemblys_reference_dictionary(tmp_path):
+    """300 000 references with names of 1 to 40 characters: the header is ~7 MB inflated over ~110 BGZF blocks, so the header reader asks
+    `is the dictionary complete?` several times (once per MiB of compressed bytes) and inflates a chunk's blocks on several threads;
+    names and lengths must be the writer's (HeaderView::target_names / target_len, contig.rs:145), through covh_bam_read_header (the device
+    ingest's header), the streamed reader and the whole-file reader."""
+    import ctypes as C
+    from coverm_amd import native
+    rng = np.random.default_rng(17)
+    n = 300_000
+    alphabet = np.frombuffer(b"ACGTNacgtn_.|0123456789k", dtype=np.uint8)
+    lens_name = rng.integers(1, 41, n)
+    names = ["".join(map(chr, alphabet[rng.integers(0, len(alphabet), int(k))])) + "_%d" % i for i, k in enumerate(lens_name)]
+    ref_lens = rng.integers(200, 50_000, n).astype(np.int64)
+    batch = synth.make_reads(synth.make_reference(50, 500_000, seed=3, min_len=2000, max_len=40_000), 2_000, seed=4)
+    batch.tid[:] = np.sort(rng.integers(0, n, batch.n_records)).astype(np.int32)
+    batch.pos[:] = 0
+    p = str(tmp_path / "assembly.bam")
+    cbam.write_bam(p, names, ref_lens, batch, with_seq=0, threads=4)
+    L = native.lib()
+    L.covh_bam_read_header.restype = C.c_void_p
+    L.covh_bam_read_header.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.covh_bam_header_free.argtypes = [C.c_void_p]
+    L.covh_bam_header_n_targets.argtypes = [C.c_void_p]
+    L.covh_bam_header_n_targets.restype = C.c_uint32
+    L.covh_bam_header_target_name.argtypes = [C.c_void_p, C.c_uint32]
+    L.covh_bam_header_target_name.restype = C.c_char_p
+    L.covh_bam_header_target_len.argtypes = [C.c_void_p, C.c_uint32]
+    L.covh_bam_header_target_len.restype = C.c_uint64
+    err = C.create_string_buffer(512)
+    hd = L.covh_bam_read_header(p.encode(), err, 512)
+    assert hd, err.value
+    try:
+        assert L.covh_bam_header_n_targets(hd) == n
+        for t in list(range(0, n, 9973)) + [n - 1]:
+            assert L.covh_bam_header_target_name(hd, t).decode() == names[t]
+            assert L.covh_bam_header_target_len(hd, t) == int(ref_lens[t])
+    finally:
+        L.covh_bam_header_free(hd)
+    got_names, got_lens, rec = cbam.read_streamed(p, threads=3)
+    assert got_names == names and np.array_equal(np.asarray(got_lens, np.int64), ref_lens) and rec.n_records == batch.n_records
+    whole = cbam.read_alignment_file(p, threads=2, want_names=False)
+    assert whole.ref_names == names and whole.records.n_records == batch.n_records
+    # a dictionary cut short (the file ends inside it) is an error, not a shorter dictionary
+    raw = open(p, "rb").read()
+    cut = str(tmp_path / "cut.bam")
+    open(cut, "wb").write(raw[:len(raw) // 3])
+    assert not L.covh_bam_read_header(cut.encode(), err, 512)
