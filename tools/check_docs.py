@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BEGIN, END = "<!-- numbers:begin -->", "<!-- numbers:end -->"
 DOCS = ["DESIGN.md", "README.md"]
-TAG = "r06e"      # the round's final profile set (tools/r06/final.sh <tag>)
+TAG = "r06g"      # the round's final profile set (tools/r06/final.sh <tag>)
 
 
 def jget(path, keys):
