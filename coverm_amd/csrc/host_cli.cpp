@@ -847,7 +847,9 @@ int run_cli(int argc, char **argv) {
         fprintf(stderr, "[coverm-amd] In sample '%s', found %llu reads mapped out of %llu total (%.2f%%)\n", samples[i].stoit.c_str(),
                 (unsigned long long)rm[i].num_mapped_reads, (unsigned long long)rm[i].num_reads,
                 (double)(rm[i].num_mapped_reads * 100) / (double)rm[i].num_reads);
+    const double t_scanned = now();
     covh_finalise_printing(taker, printer, entry_type, hptr.data(), hptr.size(), rm.data(), rm.size(), norm.data(), norm.size(), rpkm, tpm);
+    const double t_printed = now();
     size_t len = 0;
     const char *txt = covh_taker_text(taker, &len);
     FILE *out = a.output_file.empty() || a.output_file == "-" ? stdout : fopen(a.output_file.c_str(), "w");
@@ -855,8 +857,8 @@ int run_cli(int argc, char **argv) {
     fwrite(txt, 1, len, out);
     if (out != stdout) fclose(out); else fflush(stdout);
     if (timing)
-        fprintf(stderr, "[coverm-amd] main: arguments + device sessions %.3fs, samples %.3fs, scan drivers + table %.3fs (process start-up and exit are outside)\n",
-                t_sessions - t_main0, t_ingested - t_sessions, now() - t_ingested);
+        fprintf(stderr, "[coverm-amd] main: arguments + device sessions %.3fs, samples %.3fs, scan drivers + table %.3fs (scan drivers %.3fs, printer %.3fs, %zu bytes written in %.3fs; process start-up and exit are outside)\n",
+                t_sessions - t_main0, t_ingested - t_sessions, now() - t_ingested, t_scanned - t_ingested, t_printed - t_scanned, len, now() - t_printed);
     return 0;
 }
 
