@@ -1,7 +1,7 @@
 #!/bin/bash
 # Host layer (BAM reader, estimators/drivers/printers — the device-estimate path's taker included —, pair filter, gene driver, the
 # orchestrator with its `filter` subcommand through the coverm-amd binary) under AddressSanitizer + UBSan: a host-only build of the four
-# C++ files with stubs for the device ABI, swapped in for the CPU test run (241 tests, round 5).
+# C++ files with stubs for the device ABI, swapped in for the CPU test run (253 tests, round 6).
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
