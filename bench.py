@@ -304,7 +304,7 @@ def end_to_end(a, threads):
         gpu_text = open(out_tsv).read()
         # the same command as ONE process (csrc/cli_main.cc: by default the work runs in a child and the command returns when the table is
         # written, the kernel taking the runtime's queues, device mappings and page-locked slots apart behind it; here the caller waits for that too)
-        one_s, one_reps, _, _ = run_binary(cmd, 2, env={"COVERM_NO_FAST_EXIT": "1"})
+        one_s, one_reps, _, _ = run_binary(cmd, 3, env={"COVERM_NO_FAST_EXIT": "1"})
         one_s = min(one_reps)
         mapped = [l for l in gpu_err.splitlines() if "reads mapped out of" in l]
         # ---- CPU, same basis: same decoder + oracle scan, best of three each
@@ -322,7 +322,7 @@ def end_to_end(a, threads):
             gpu=dict(seconds=gpu_s, seconds_is="median of five runs", reads_per_s=rmp[0] / gpu_s, reads_per_s_is="considered (aligned, filter-passing) reads per second: the metric's unit",
                      records_per_s=reads / gpu_s, rep_seconds=rep_seconds, max_rss_bytes=gpu_rss,
                      one_process_seconds=one_s, one_process_rep_seconds=one_reps,
-                     one_process_is="best of two runs with COVERM_NO_FAST_EXIT=1: no launcher / child split, the caller also waits for the runtime's teardown",
+                     one_process_is="best of three runs with COVERM_NO_FAST_EXIT=1: no launcher / child split, the caller also waits for the runtime's teardown",
                      command=" ".join(["coverm-amd"] + cmd[1:]), stderr_mapped=mapped[:1], stderr_timing=timing_lines(gpu_err)),
             cpu=dict(decode_s=dec_s, decode_runs=dec_all, scan_s=scan_s, scan_runs=[round(x, 3) for x in scans], seconds_is="best of three runs each",
                      reads_per_s_serial=rmp[0] / (dec_s + scan_s), reads_per_s_overlapped=rmp[0] / max(dec_s, scan_s),
